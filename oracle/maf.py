@@ -1,0 +1,162 @@
+"""ORACLE (test infrastructure, never shipped, never measured as the product).
+
+CPU restatement of the masked autoregressive flow behind ``pocomc.flow.Flow``.
+
+PARITY UNPINNED: the flow arithmetic is not in ``/root/reference``; it lives in
+the third-party package ``zuko`` (``requirements.txt:3``: ``zuko>=1.1.0``, no
+lockfile, not installed, not installable here).  The reference call sites are
+``pocomc/flow.py:55-68`` (constructor), ``:114`` (``transform.call_and_ladj``),
+``:131`` (``transform.inv.call_and_ladj``), ``:147`` (``log_prob``), ``:162``
+(``rsample_and_log_prob``).  The reference's tests hold no numeric expected
+values for it (``tests/test_flow.py`` is property-only), so this file restates
+zuko's *published* algorithm (see ``pocomc_amd/maf_spec.py`` for the exact
+architecture) and is pinned only by those properties:
+round trip <= 1e-5 (``tests/test_flow.py:88``), ``ladj_fwd == -ladj_inv``
+(``:164``, ``:205``), shapes / dtypes / finiteness.
+
+Everything here is float32 like the reference (``pocomc/tools.py:279-292``).
+The inverse is the reference's algorithm: ``D`` fixed-point passes of the full
+masked MLP per transform (zuko ``AutoregressiveTransform._inverse``) plus one
+pass for the log-determinant.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from pocomc_amd.maf_spec import MAFSpec, LOG_SLOPE
+
+F32 = np.float32
+
+
+def soft_log_scale(raw):
+    """zuko ``MonotonicAffineTransform``: ``scale / (1 + |scale / log(slope)|)``."""
+    return (raw / (F32(1.0) + np.abs(raw / F32(LOG_SLOPE)))).astype(F32)
+
+
+class OracleMAF:
+    """float32 numpy MAF with the canonical parameter vector of ``MAFSpec``."""
+
+    def __init__(self, spec: MAFSpec, flat: np.ndarray):
+        self.spec = spec
+        self.flat = np.asarray(flat, dtype=F32)
+        assert self.flat.shape == (spec.n_params,)
+        self._mats = []
+        for t in range(spec.n_transforms):
+            M0, M1, M2, M3 = spec.masks(t)
+            v = lambda n: spec.view(self.flat, t, n)
+            self._mats.append(dict(
+                W0=(v("W0") * M0).astype(F32), b0=v("b0"),
+                W1=(v("W1") * M1).astype(F32), b1=v("b1"),
+                W2=(v("W2") * M2).astype(F32), b2=v("b2"),
+                W3=(v("W3") * M3).astype(F32), b3=v("b3")))
+
+    # hyper-network of one transform: x (N,D) -> shift (N,D), ls (N,D)
+    def _hyper(self, t: int, x: np.ndarray):
+        m = self._mats[t]
+        h = np.maximum(x @ m["W0"].T + m["b0"], F32(0))
+        h = np.maximum(h + (h @ m["W1"].T + m["b1"]), F32(0))
+        h = np.maximum(h + (h @ m["W2"].T + m["b2"]), F32(0))
+        phi = (h @ m["W3"].T + m["b3"]).astype(F32)
+        return phi[:, 0::2], soft_log_scale(phi[:, 1::2])
+
+    def forward(self, x):
+        """data -> latent, ``(z, ladj)``; ``pocomc/flow.py:99-114``."""
+        x = np.asarray(x, dtype=F32)
+        ladj = np.zeros(len(x), dtype=F32)
+        for t in range(self.spec.n_transforms):
+            shift, ls = self._hyper(t, x)
+            x = (x * np.exp(ls) + shift).astype(F32)
+            ladj = (ladj + ls.sum(axis=1, dtype=F32)).astype(F32)
+        return x, ladj
+
+    def inverse(self, z):
+        """latent -> data, ``(x, ladj)``; ``pocomc/flow.py:116-132``.  ``ladj`` is
+        the log-determinant of the inverse map (= ``-ladj_forward(x)``)."""
+        y = np.asarray(z, dtype=F32)
+        D = self.spec.n_dim
+        ladj = np.zeros(len(y), dtype=F32)
+        for t in reversed(range(self.spec.n_transforms)):
+            x = np.zeros_like(y)
+            for _ in range(D):                      # zuko: passes = features
+                shift, ls = self._hyper(t, x)
+                x = ((y - shift) / np.exp(ls)).astype(F32)
+            shift, ls = self._hyper(t, x)           # extra pass for the ladj
+            ladj = (ladj - ls.sum(axis=1, dtype=F32)).astype(F32)
+            y = x
+        return y, ladj
+
+    def log_prob(self, x):
+        """``pocomc/flow.py:134-147``: base ``N(0,I)`` log-density + ladj."""
+        z, ladj = self.forward(x)
+        D = self.spec.n_dim
+        base = (-0.5 * (z.astype(F32) ** 2).sum(axis=1, dtype=F32)
+                - F32(0.5 * D * math.log(2 * math.pi))).astype(F32)
+        return (base + ladj).astype(F32)
+
+    def sample_from(self, z):
+        """``pocomc/flow.py:149-163`` with the base draw ``z`` given (replay)."""
+        x, ladj_inv = self.inverse(z)
+        D = self.spec.n_dim
+        base = (-0.5 * (np.asarray(z, F32) ** 2).sum(axis=1, dtype=F32)
+                - F32(0.5 * D * math.log(2 * math.pi))).astype(F32)
+        # log q(x) = log N(z) + ladj_forward(x) = log N(z) - ladj_inverse(z)
+        return x, (base - ladj_inv).astype(F32)
+
+
+class TorchFlowAdapter:
+    """Duck-typed ``pocomc.flow.Flow`` contract (``pocomc/tools.py:336-349``):
+    ``forward/inverse`` on float32 torch tensors, backed by ``OracleMAF``.
+    Lets the reference's own ``pocomc.mcmc`` kernels run on this flow when
+    golden vectors are generated."""
+
+    def __init__(self, maf: OracleMAF):
+        self.maf = maf
+        self.n_dim = maf.spec.n_dim
+
+    def forward(self, x):
+        import torch
+        z, l = self.maf.forward(x.detach().numpy())
+        return torch.from_numpy(z), torch.from_numpy(l)
+
+    def inverse(self, u):
+        import torch
+        x, l = self.maf.inverse(u.detach().numpy())
+        return torch.from_numpy(x), torch.from_numpy(l)
+
+
+# --------------------------------------------------------------------------
+# torch-autograd twin: the fp32 reference for the training kernels
+# --------------------------------------------------------------------------
+def torch_log_prob(spec: MAFSpec, flat_t, x_t):
+    """Differentiable ``log_prob`` on a flat torch parameter vector."""
+    import torch
+    D = spec.n_dim
+    x = x_t
+    ladj = torch.zeros(x.shape[0], dtype=x.dtype)
+    for t in range(spec.n_transforms):
+        M = [torch.from_numpy(m.astype(np.float32)) for m in spec.masks(t)]
+        def v(name):
+            off, sz = spec.offsets[name]
+            b = t * spec.params_per_transform + off
+            return flat_t[b:b + sz].reshape(spec.shapes()[name])
+        h = torch.relu(x @ (v("W0") * M[0]).T + v("b0"))
+        h = torch.relu(h + h @ (v("W1") * M[1]).T + v("b1"))
+        h = torch.relu(h + h @ (v("W2") * M[2]).T + v("b2"))
+        phi = h @ (v("W3") * M[3]).T + v("b3")
+        shift, raw = phi[:, 0::2], phi[:, 1::2]
+        ls = raw / (1 + torch.abs(raw / LOG_SLOPE))
+        x = x * torch.exp(ls) + shift
+        ladj = ladj + ls.sum(dim=1)
+    base = -0.5 * (x ** 2).sum(dim=1) - 0.5 * D * math.log(2 * math.pi)
+    return base + ladj
+
+
+def torch_loss(spec, flat_t, x_t, w_t=None):
+    """``pocomc/flow.py:308-312``: ``-sum(log_prob)`` or the weighted form
+    ``-(log_prob * w * 1000).sum() / w.sum()``."""
+    lp = torch_log_prob(spec, flat_t, x_t)
+    if w_t is None:
+        return -lp.sum()
+    return (-(lp * w_t * 1000.0)).sum() / w_t.sum()

@@ -1,0 +1,323 @@
+"""Architecture of the masked autoregressive flow (MAF) used on the hot path.
+
+This is host logic only (numpy): mask construction, the canonical parameter
+layout and the index maps that pack canonical parameters into the layouts the
+gfx950 kernels consume.  No arithmetic of the flow itself lives here.
+
+What it restates
+----------------
+``pocomc/flow.py:46-68`` builds ``zuko.flows.MAF(n_dim, transforms=T,
+hidden_features=[H]*3, residual=True)`` with ``H = max(next_pow2(3*n_dim), 32)``
+(``pocomc/flow.py:49-52``).  ``zuko`` is a third-party package that is NOT under
+``/root/reference`` (pinned only as ``zuko>=1.1.0`` in ``requirements.txt:3``),
+so the architecture below is a restatement of zuko's published MAF, not of a
+file in the reference (*parity unpinned*):
+
+* ``T`` masked-autoregressive transforms; variable order alternates identity /
+  reversed per transform; base distribution is a diagonal ``N(0, I)``.
+* each transform: a masked MLP ``D -> H -> H -> H -> 2D`` with ReLU; the two
+  ``H -> H`` layers carry a skip connection (``h' = relu(h + W h + b)``);
+  outputs are ``(shift_j, raw_j)`` per feature ``j`` (row ``2j`` / ``2j+1``).
+* univariate map ``y = x * exp(ls) + shift`` with the soft-clipped log-scale
+  ``ls = raw / (1 + |raw / log(1e-3)|)``; ``ladj = sum_j ls_j``.
+* masks (zuko ``MaskedMLP``): hidden unit ``k`` has degree
+  ``deg(k) = 1 + k mod (D-1)``; it reads inputs of rank ``< deg(k)`` and hidden
+  units of degree ``<= deg(k)``; the outputs of the feature of rank ``r`` read
+  hidden units of degree ``<= r`` (rank 0 reads nothing: bias only).
+
+Canonical parameter layout (one flat fp32 vector, transform after transform):
+``W0[H,D] b0[H] W1[H,H] b1[H] W2[H,H] b2[H] W3[2D,H] b3[2D]`` with torch
+``nn.Linear`` convention ``weight[out, in]``.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+LOG_SLOPE = math.log(1e-3)  # zuko MonotonicAffineTransform slope=1e-3
+
+
+def next_power_of_2(n: int) -> int:
+    """``pocomc/flow.py:49-50``."""
+    return 1 if n == 0 else 2 ** (int(n) - 1).bit_length()
+
+
+def default_hidden(n_dim: int) -> int:
+    """``pocomc/flow.py:52``: ``np.maximum(next_power_of_2(3*n_dim), 32)``."""
+    return max(next_power_of_2(3 * n_dim), 32)
+
+
+def _ceil_to(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class MAFSpec:
+    """Static description of one MAF: shapes, masks, packing maps."""
+
+    n_dim: int
+    n_transforms: int = 3
+    hidden: int | None = None
+
+    # filled by __post_init__
+    orders: list = field(default_factory=list, repr=False)
+
+    def __post_init__(self):
+        D = int(self.n_dim)
+        if D < 2:
+            # zuko raises "The adjacency matrix leads to a null Jacobian." for D=1
+            raise ValueError("MAF needs n_dim >= 2 (the adjacency matrix of a 1-D "
+                             "autoregressive transform leads to a null Jacobian)")
+        self.n_dim = D
+        self.n_transforms = int(self.n_transforms)
+        if self.hidden is None:
+            self.hidden = default_hidden(D)
+        self.hidden = int(self.hidden)
+        H = self.hidden
+        if H < D - 1:
+            raise NotImplementedError("hidden width must be >= n_dim - 1")
+        # rank of every input feature, per transform (zuko MAF: orders[i % 2])
+        ident = np.arange(D)
+        self.orders = [ident.copy() if t % 2 == 0 else ident[::-1].copy()
+                       for t in range(self.n_transforms)]
+        # degree of every hidden unit (same for the three hidden layers)
+        self.degree = 1 + (np.arange(H) % (D - 1))
+        # canonical offsets inside one transform
+        sizes = [("W0", H * D), ("b0", H), ("W1", H * H), ("b1", H),
+                 ("W2", H * H), ("b2", H), ("W3", 2 * D * H), ("b3", 2 * D)]
+        off = 0
+        self.offsets = {}
+        for name, sz in sizes:
+            self.offsets[name] = (off, sz)
+            off += sz
+        self.params_per_transform = off
+        self.n_params = off * self.n_transforms
+        self._build_device_layout()
+
+    # ------------------------------------------------------------------ masks
+    def masks(self, t: int):
+        """Boolean masks ``(M0[H,D], M1[H,H], M2[H,H], M3[2D,H])`` of transform t."""
+        D, H = self.n_dim, self.hidden
+        rank = self.orders[t]                      # rank[j] of feature j
+        deg = self.degree
+        M0 = rank[None, :] < deg[:, None]
+        M1 = deg[None, :] <= deg[:, None]
+        M3 = deg[None, :] <= np.repeat(rank, 2)[:, None]
+        return M0, M1, M1.copy(), M3
+
+    def shapes(self):
+        D, H = self.n_dim, self.hidden
+        return {"W0": (H, D), "b0": (H,), "W1": (H, H), "b1": (H,),
+                "W2": (H, H), "b2": (H,), "W3": (2 * D, H), "b3": (2 * D,)}
+
+    def view(self, flat: np.ndarray, t: int, name: str) -> np.ndarray:
+        """View of one canonical tensor inside the flat parameter vector."""
+        off, sz = self.offsets[name]
+        base = t * self.params_per_transform + off
+        return flat[base:base + sz].reshape(self.shapes()[name])
+
+    def mask_flat(self) -> np.ndarray:
+        """0/1 float mask over the flat parameter vector (1 for biases)."""
+        m = np.ones(self.n_params, dtype=np.float32)
+        for t in range(self.n_transforms):
+            M0, M1, M2, M3 = self.masks(t)
+            for name, M in (("W0", M0), ("W1", M1), ("W2", M2), ("W3", M3)):
+                self.view(m, t, name)[...] = M.astype(np.float32)
+        return m
+
+    def init_params(self, seed: int | None = None) -> np.ndarray:
+        """``nn.Linear`` default init: ``U(-1/sqrt(fan_in), 1/sqrt(fan_in))`` for
+        weights and biases (fan_in = unmasked ``in_features``)."""
+        rng = np.random.default_rng(seed)
+        flat = np.empty(self.n_params, dtype=np.float32)
+        fan = {"W0": self.n_dim, "b0": self.n_dim, "W1": self.hidden, "b1": self.hidden,
+               "W2": self.hidden, "b2": self.hidden, "W3": self.hidden, "b3": self.hidden}
+        for t in range(self.n_transforms):
+            for name in self.offsets:
+                v = self.view(flat, t, name)
+                b = 1.0 / math.sqrt(fan[name])
+                v[...] = rng.uniform(-b, b, size=v.shape).astype(np.float32)
+        return flat
+
+    # ---------------------------------------------------------- device layout
+    def _build_device_layout(self):
+        """Slot layout of the gfx950 kernels.
+
+        Hidden units are sorted by degree; every degree group is padded to a
+        multiple of 4 slots (one *quad* = the K of one ``mfma_f32_16x16x4f32``)
+        and the total to a multiple of 16 (one *tile* = 4 quads = the M of the
+        same MFMA).  Features are addressed by rank, padded to ``Dp`` (multiple
+        of 16).  Output rows are ``2*rank`` (shift) and ``2*rank+1`` (raw),
+        padded to ``Op = 2*Dp``.
+        """
+        D, H = self.n_dim, self.hidden
+        deg = self.degree
+        slots = []          # canonical unit index per slot, -1 = padding
+        sdeg = []           # degree per slot
+        for g in range(1, D):
+            units = np.nonzero(deg == g)[0]
+            pad = _ceil_to(len(units), 4) - len(units)
+            slots += list(units) + [-1] * pad
+            sdeg += [g] * (len(units) + pad)
+        Hp = _ceil_to(len(slots), 16)
+        slots += [-1] * (Hp - len(slots))
+        sdeg += [D] * (Hp - len(sdeg))          # trailing pad: never reached
+        self.Hp = Hp
+        self.nT = Hp // 16                       # hidden tiles
+        self.nQ = Hp // 4                        # hidden quads
+        self.Dp = _ceil_to(D, 16)
+        self.nXT = self.Dp // 16                 # input (rank) tiles
+        self.Op = 2 * self.Dp
+        self.nOT = self.Op // 16                 # output tiles (8 ranks each)
+        self.slot_unit = np.asarray(slots, dtype=np.int64)
+        self.slot_deg = np.asarray(sdeg, dtype=np.int32)
+        qdeg = self.slot_deg.reshape(-1, 4)
+        assert (qdeg == qdeg[:, :1]).all()
+        qdeg = qdeg[:, 0].copy()
+        # a quad is "last" of its degree if the next quad has a different degree
+        qlast = np.ones(self.nQ, dtype=np.int32)
+        qlast[:-1] = (qdeg[1:] != qdeg[:-1]).astype(np.int32)
+        qlast[qdeg >= D] = 0                     # padding quads trigger nothing
+        self.quad_deg = qdeg
+        self.quad_last = qlast
+        # quad meta word: degree | last << 16
+        self.quad_meta = (qdeg.astype(np.int32) | (qlast << 16)).astype(np.int32)
+
+        # ---- sizes of the packed arrays (floats), per transform
+        nT, nXT, nOT = self.nT, self.nXT, self.nOT
+        self.sz_f0 = nT * nXT * 256              # W0 fragments  [tile][xtile][lane][4]
+        self.sz_f12 = nT * nT * 256              # W1/W2 fragments [tile][ktile][lane][4]
+        self.sz_f3 = nOT * nT * 256              # W3 fragments  [otile][ktile][lane][4]
+        self.sz_w0n = self.Dp * Hp               # W0 natural    [rank][slot]
+        self.sz_b = Hp                           # b0,b1,b2      [slot]
+        self.sz_b3 = self.Op                     # b3            [2*rank + {0,1}]
+        parts = [("f0", self.sz_f0), ("f1", self.sz_f12), ("f2", self.sz_f12),
+                 ("f3", self.sz_f3), ("w0n", self.sz_w0n), ("b0", self.sz_b),
+                 ("b1", self.sz_b), ("b2", self.sz_b), ("b3", self.sz_b3)]
+        off = 0
+        self.pk_offsets = {}
+        for name, sz in parts:
+            self.pk_offsets[name] = off
+            off += sz
+        self.pk_per_transform = off
+        self.pk_size = off * self.n_transforms
+
+    def pack_index(self) -> np.ndarray:
+        """int32 gather map: ``packed[i] = flat[idx[i]] if idx[i] >= 0 else 0``.
+
+        Masked-out weights map to -1 (exact zeros in the packed image), so the
+        kernels never need the masks.
+        """
+        D, H, Hp, Dp = self.n_dim, self.hidden, self.Hp, self.Dp
+        nT, nXT, nOT = self.nT, self.nXT, self.nOT
+        idx = np.full(self.pk_size, -1, dtype=np.int64)
+        lane = np.arange(64)
+        lk, li = lane >> 4, lane & 15            # k within quad, row within tile
+        for t in range(self.n_transforms):
+            base_c = t * self.params_per_transform
+            base_p = t * self.pk_per_transform
+            rank = self.orders[t]
+            feat_of_rank = np.argsort(rank)
+            M0, M1, M2, M3 = self.masks(t)
+            su = self.slot_unit
+
+            def cidx(name, row, col, ncol, mask):
+                """canonical flat index of weight[row, col] or -1."""
+                off, _ = self.offsets[name]
+                ok = (row >= 0) & (col >= 0)
+                r = np.where(ok, row, 0)
+                c = np.where(ok, col, 0)
+                ok = ok & mask[r, c]
+                return np.where(ok, base_c + off + r * ncol + c, -1)
+
+            # --- W0 fragments: A[i][k] = W0[out slot 16*T+i][in rank 16*X + 4c + k]
+            f0 = np.full((nT, nXT, 64, 4), -1, dtype=np.int64)
+            for T in range(nT):
+                out_unit = su[16 * T + li]                       # (64,)
+                for X in range(nXT):
+                    for c in range(4):
+                        r_in = 16 * X + 4 * c + lk
+                        feat = np.where(r_in < D, feat_of_rank[np.minimum(r_in, D - 1)], -1)
+                        f0[T, X, :, c] = cidx("W0", out_unit, feat, D, M0)
+            # --- W1/W2 fragments: A[i][k] = W[out slot 16*T+i][in slot 16*K + 4c + k]
+            f12 = {}
+            for name, M in (("W1", M1), ("W2", M2)):
+                f = np.full((nT, nT, 64, 4), -1, dtype=np.int64)
+                for T in range(nT):
+                    out_unit = su[16 * T + li]
+                    for K in range(nT):
+                        for c in range(4):
+                            in_unit = su[16 * K + 4 * c + lk]
+                            f[T, K, :, c] = cidx(name, out_unit, in_unit, H, M)
+                f12[name] = f
+            # --- W3 fragments: A[i][k] = W3[out row of (rank, s)][in slot]
+            f3 = np.full((nOT, nT, 64, 4), -1, dtype=np.int64)
+            for O in range(nOT):
+                orow = 16 * O + li                               # packed out row
+                r_out = orow >> 1
+                s = orow & 1
+                crow = np.where(r_out < D, 2 * feat_of_rank[np.minimum(r_out, D - 1)] + s, -1)
+                for K in range(nT):
+                    for c in range(4):
+                        in_unit = su[16 * K + 4 * c + lk]
+                        f3[O, K, :, c] = cidx("W3", crow, in_unit, H, M3)
+            # --- W0 natural [rank][slot]
+            w0n = np.full((Dp, Hp), -1, dtype=np.int64)
+            for r in range(D):
+                feat = np.full(Hp, feat_of_rank[r])
+                w0n[r] = cidx("W0", su, feat, D, M0)
+
+            def bidx(name):
+                off, _ = self.offsets[name]
+                return np.where(su >= 0, base_c + off + np.maximum(su, 0), -1)
+
+            b3 = np.full(self.Op, -1, dtype=np.int64)
+            off3, _ = self.offsets["b3"]
+            for r in range(D):
+                b3[2 * r] = base_c + off3 + 2 * feat_of_rank[r]
+                b3[2 * r + 1] = base_c + off3 + 2 * feat_of_rank[r] + 1
+
+            po = self.pk_offsets
+            def put(name, arr):
+                a = arr.reshape(-1)
+                idx[base_p + po[name]: base_p + po[name] + a.size] = a
+            put("f0", f0); put("f1", f12["W1"]); put("f2", f12["W2"]); put("f3", f3)
+            put("w0n", w0n); put("b0", bidx("b0")); put("b1", bidx("b1")); put("b2", bidx("b2"))
+            put("b3", b3)
+        return idx.astype(np.int32)
+
+    def device_meta(self) -> np.ndarray:
+        """int32 metadata consumed by the kernels.
+
+        ``[0:8]``  header: D, H, T, Hp, Dp, nT, pk_per_transform, reserved
+        ``[8:8+T*D]``      feature index of every rank, per transform
+        ``[8+T*D: +nQ]``   quad meta words (degree | last<<16), shared by all transforms
+        """
+        D, T = self.n_dim, self.n_transforms
+        hdr = np.array([D, self.hidden, T, self.Hp, self.Dp, self.nT,
+                        self.pk_per_transform, 0], dtype=np.int32)
+        f_o_r = np.concatenate([np.argsort(o) for o in self.orders]).astype(np.int32)
+        return np.concatenate([hdr, f_o_r, self.quad_meta]).astype(np.int32)
+
+    # ------------------------------------------------------------ accounting
+    def flops_forward_dense(self) -> int:
+        """``F_fwd = T*2*(3*D*H + 2*H*H)`` per particle."""
+        D, H = self.n_dim, self.hidden
+        return self.n_transforms * 2 * (3 * D * H + 2 * H * H)
+
+    def flops_inverse_naive(self) -> int:
+        """``F_inv = (D+1) * F_fwd`` per particle."""
+        return (self.n_dim + 1) * self.flops_forward_dense()
+
+    def macs_masked(self) -> int:
+        """Unmasked multiply-accumulates per particle (the work that is left
+        once the masks are exploited)."""
+        n = 0
+        for t in range(self.n_transforms):
+            n += sum(int(M.sum()) for M in self.masks(t))
+        return n
+
+
+SPEC_BY_NAME = {"maf3": 3, "maf6": 6, "maf12": 12}
