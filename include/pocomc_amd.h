@@ -1,0 +1,195 @@
+/* pocomc_amd -- C ABI of the MI355X (gfx950) engine for pocoMC's flow-preconditioned
+ * particle MCMC step.
+ *
+ * The reference (minaskar/pocomc v1.2.6) has no FFI: its seam is two duck-typed
+ * Python contracts:
+ *   - the MCMC-kernel contract  kernel(state_dict, function_dict, option_dict)
+ *     called from Sampler._mutate (pocomc/sampler.py:568-617), and
+ *   - the Flow contract  forward / inverse / log_prob / sample / fit
+ *     (pocomc/flow.py:99-384, pocomc/tools.py:336-349).
+ * Every entry point below replaces one piece of reference arithmetic on that
+ * path and cites it.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - all data pointers are DEVICE pointers to contiguous row-major arrays owned
+ *     by the caller; the library allocates nothing and keeps no state between
+ *     calls (except the last error string, per thread);
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work;
+ *   - return 0 on success, non-zero on error; pmc_last_error() returns the text;
+ *   - "f32"/"f64" in a parameter comment is the element type.  The reference
+ *     keeps MCMC state in float64 numpy and the flow in float32 torch
+ *     (pocomc/tools.py:279-292); so does this library.
+ */
+#ifndef POCOMC_AMD_H
+#define POCOMC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMC_ABI_VERSION 1
+
+const char* pmc_last_error(void);
+int pmc_abi_version(void);
+
+/* ------------------------------------------------------------------ flow */
+
+/* Device image of one MAF (pocomc/flow.py:55-68 -> zuko.flows.MAF).  Built by
+ * the host side (pocomc_amd/maf_spec.py) and filled by pmc_maf_pack(). */
+typedef struct pmc_maf {
+    const float* packed;      /* packed weights, T * pk_per_transform floats */
+    const int32_t* meta;      /* [8 hdr][T*D feat_of_rank][T*D rank_of_feat][nQ quad meta] */
+    int32_t D, H, T;          /* features, hidden width, transforms */
+    int32_t Hp, Dp;           /* padded hidden slots / ranks (multiples of 16) */
+    int32_t nT, nXT, nOT;     /* hidden, input and output tiles */
+    int64_t pk_per_transform;
+    int32_t tri_ok;           /* every degree group fits one 16-slot tile */
+    int32_t reserved;
+} pmc_maf_t;
+
+#define PMC_INVERSE_AUTO 0
+#define PMC_INVERSE_TRIANGULAR 1   /* one sweep over the degree groups */
+#define PMC_INVERSE_NAIVE 2        /* the reference's D fixed-point passes (zuko) */
+
+/* packed[i] = idx[i] >= 0 ? flat[idx[i]] : 0   (canonical fp32 params -> kernel layout) */
+int pmc_maf_pack(const float* flat, const int32_t* pack_idx, float* packed, int64_t n_packed, void* stream);
+
+/* Flow.forward, pocomc/flow.py:99-114: data -> latent.  x,z f32 [n][D]; ladj f32 [n] or NULL;
+ * log_prob f32 [n] or NULL (Flow.log_prob, flow.py:134-147). */
+int pmc_maf_forward(const pmc_maf_t* m, const float* x, float* z, float* ladj, float* log_prob,
+                    int64_t n, void* stream);
+
+/* Flow.inverse, pocomc/flow.py:116-132: latent -> data with the log-determinant of the
+ * inverse map.  z,x f32 [n][D]; ladj f32 [n] or NULL. */
+int pmc_maf_inverse(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
+                    int algo, void* stream);
+
+/* ---------------------------------------------------------------- scaler */
+
+/* pocomc/scaler.py Reparameterize with the Sampler's settings (diagonal affine,
+ * scale=True; sampler.py:309-313). */
+typedef struct pmc_scaler {
+    const double* low;        /* [D] */
+    const double* high;       /* [D] */
+    const double* mu;         /* [D] */
+    const double* sigma;      /* [D] */
+    const int32_t* kind;      /* [D] 0 none, 1 low only, 2 high only, 3 both (scaler.py:463-489) */
+    const int32_t* bc;        /* [D] bit 0 periodic, bit 1 reflective; NULL = no boundary conditions */
+    const double* log_width;  /* [D] log(high-low) where kind == 3 (scaler.py:421, :424), else 0 */
+    int32_t D;
+    int32_t logit;            /* 0 probit, 1 logit */
+    int32_t scale;            /* apply the affine part (scaler.py:219) */
+    int32_t reserved;
+    double sum_log_sigma;     /* sum(log(sigma)), scaler.py:306 */
+} pmc_scaler_t;
+
+/* Reparameterize.inverse (scaler.py:204-226) + the boundary-condition round trip of
+ * mcmc.py:94-97 + the finite mask of mcmc.py:100-102.
+ * u_in: f32 [n][D] (flow output) or NULL;  u_in64: f64 [n][D] or NULL (exactly one non-NULL)
+ * u_out f64 [n][D] (u', re-derived from x' when boundary conditions apply), x f64 [n][D],
+ * logdetj f64 [n], finite int32 [n] (1 = logdetj and every x finite). */
+int pmc_scaler_inverse(const pmc_scaler_t* s, const float* u_in, const double* u_in64, double* u_out,
+                       double* x, double* logdetj, int32_t* finite, int64_t n, void* stream);
+
+/* Reparameterize.forward (scaler.py:180-202), no input check.  x f64 [n][D] -> u f64 [n][D]. */
+int pmc_scaler_forward(const pmc_scaler_t* s, const double* x, double* u, int64_t n, void* stream);
+
+/* ------------------------------------------------------------ MCMC step */
+
+#define PMC_KIND_TPCN 0   /* t-preconditioned Crank-Nicolson proposal (mcmc.py:77-85, :394-402) */
+#define PMC_KIND_RWM 1    /* random-walk proposal (mcmc.py:251-253, :561-563) */
+
+/* Random variates of one step: replay arrays (parity tests; recorded from the
+ * reference's legacy numpy stream) or, when they are NULL, a counter-based
+ * Philox4x32-10 keyed by (seed, step, particle). */
+typedef struct pmc_rng {
+    const double* gamma;      /* [n] standard-gamma draws G_k (mcmc.py:80) or NULL */
+    const double* normal;     /* [n][D] N(0,1) draws (mcmc.py:85) or NULL */
+    const double* uniform;    /* [n] U(0,1) draws (mcmc.py:137) or NULL */
+    uint64_t seed;
+    uint64_t step;
+    uint64_t offset;          /* global index of this shard's first particle */
+} pmc_rng_t;
+
+/* Proposal, mcmc.py:77-85 (tpCN) / :251-253 (RWM).
+ * cur32: f32 [n][D] (theta of the preconditioned kernels lives in float32, it is the
+ * numpy view of a torch float32 tensor, tools.py:336-340) or NULL; cur64: f64 [n][D]
+ * (u of pcn/rwm) or NULL.  mu f64 [D], inv_cov f64 [D][D], chol f64 [D][D] (lower).
+ * Outputs: prop64 f64 [n][D], prop32 f32 [n][D] (what the flow consumes, tools.py:344),
+ * quad f64 [n] = diff^T inv_cov diff (current), quad_prop f64 [n] (proposed); the last
+ * two may be NULL for RWM.  cn_a = (1 - sigma**2)**0.5, evaluated by the caller exactly as
+ * mcmc.py:85 does (ignored for RWM). */
+int pmc_propose(int kind, const float* cur32, const double* cur64, const double* mu,
+                const double* inv_cov, const double* chol, double nu, double sigma, double cn_a,
+                const pmc_rng_t* rng, double* prop64, float* prop32, double* quad,
+                double* quad_prop, int64_t n, int32_t D, void* stream);
+
+/* Arrays of one particle population (current or proposed). */
+typedef struct pmc_state {
+    float* theta32;           /* f32 [n][D] current theta (preconditioned kernels) or NULL */
+    double* u;                /* f64 [n][D] */
+    double* x;                /* f64 [n][D] */
+    double* logdetj;          /* f64 [n] */
+    double* logl;             /* f64 [n] */
+    double* logp;             /* f64 [n] */
+    float* logdetj_flow;      /* f32 [n] or NULL */
+} pmc_state_t;
+
+typedef struct pmc_proposal {
+    const double* theta64;    /* f64 [n][D] proposed theta or NULL (pcn/rwm) */
+    const double* u;          /* f64 [n][D] */
+    const double* x;          /* f64 [n][D] */
+    const double* logdetj;    /* f64 [n] */
+    const double* logl;       /* f64 [n]  (-inf where not evaluated, mcmc.py:118) */
+    const double* logp;       /* f64 [n]  (-inf where not finite, mcmc.py:107) */
+    const float* logdetj_flow;/* f32 [n] or NULL */
+    const double* quad;       /* f64 [n] current quadratic form (tpCN) or NULL */
+    const double* quad_prop;  /* f64 [n] proposed quadratic form (tpCN) or NULL */
+} pmc_proposal_t;
+
+/* Metropolis ratio + accept + reductions: mcmc.py:124-156 (and the three variants).
+ * sums f64 [D+4] <- { sum(alpha), sum(logl+logp) after accept, sum(logl+logp+logdetj) after accept,
+ *                     number accepted, sum_k theta[k][0..D) after accept (cur theta32 or u) }
+ * kind: PMC_KIND_TPCN adds the Student-t terms -A+B (mcmc.py:124-129); preconditioned != 0 adds the
+ * flow log-determinants and moves theta (preconditioned_pcn / preconditioned_rwm), otherwise u is the
+ * moved variable (pcn / rwm).
+ * alpha_out f64 [n] and accept_out int32 [n] may be NULL.  workspace: pmc_accept_workspace_bytes(). */
+int64_t pmc_accept_workspace_bytes(int64_t n, int32_t D);
+int pmc_accept(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposal_t* prop, double beta, double nu,
+               const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums,
+               void* workspace, int64_t n, int32_t D, void* stream);
+
+/* --------------------------------------------------------- particle math */
+
+/* Particles.compute_logw_and_logz, particles.py:215-231, un-normalised part:
+ * logw[t*N+k] = logl[t][k]*beta_final - (logsumexp_i(logl[t][k]*beta[i]-logz[i]) - log T). */
+int pmc_logw(const double* logl, const double* beta, const double* logz, double beta_final,
+             double* logw, int32_t T, int64_t N, void* stream);
+
+/* stats f64 [4] <- { max(logw), sum exp(logw-max), sum exp(2(logw-max)), sum 1-(1-w)^k }  with
+ * w = exp(logw-max)/sum: everything effective_sample_size / unique_sample_size /
+ * increment_logz need (tools.py:56-133).  k <= 0 skips the last entry.
+ * workspace: pmc_reduce_workspace_bytes(P). */
+int64_t pmc_reduce_workspace_bytes(int64_t P);
+int pmc_logw_stats(const double* logw, int64_t P, int64_t k, double* stats, void* workspace, void* stream);
+
+/* Sampler._resample gather, sampler.py:707-713: dst[i] = src[idx[i]] for the five arrays. */
+int pmc_gather(const int64_t* idx, int64_t n_out, int32_t D, const double* u, const double* x,
+               const double* logdetj, const double* logl, const double* logp, double* u_out,
+               double* x_out, double* logdetj_out, double* logl_out, double* logp_out, void* stream);
+
+/* Resampling indices from normalised weights w f64 [P]:
+ * multinomial (np.random.choice(p=w), sampler.py:703: cdf.searchsorted(uniform, 'right'))
+ * with uniforms f64 [n_out]; systematic (tools.py:136-186) with one offset in [0,1).
+ * cdf: f64 [P] scratch. */
+int pmc_resample_multinomial(const double* w, int64_t P, const double* uniforms, int64_t n_out,
+                             double* cdf, int64_t* idx, void* stream);
+int pmc_resample_systematic(const double* w, int64_t P, double offset, int64_t n_out, double* cdf,
+                            int64_t* idx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POCOMC_AMD_H */

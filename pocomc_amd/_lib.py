@@ -1,0 +1,125 @@
+"""ctypes binding of ``libpocomc_amd.so`` (the C ABI in ``include/pocomc_amd.h``).
+
+There is no CPU fallback: if the shared library is missing or no MI355X is
+visible, every entry point raises.  PyTorch is used for device memory and
+streams only; all arithmetic happens in the HIP kernels behind this ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpocomc_amd.so")
+
+c_p = C.c_void_p
+
+
+class pmc_maf_t(C.Structure):
+    _fields_ = [("packed", c_p), ("meta", c_p),
+                ("D", C.c_int32), ("H", C.c_int32), ("T", C.c_int32),
+                ("Hp", C.c_int32), ("Dp", C.c_int32),
+                ("nT", C.c_int32), ("nXT", C.c_int32), ("nOT", C.c_int32),
+                ("pk_per_transform", C.c_int64),
+                ("tri_ok", C.c_int32), ("reserved", C.c_int32)]
+
+
+class pmc_scaler_t(C.Structure):
+    _fields_ = [("low", c_p), ("high", c_p), ("mu", c_p), ("sigma", c_p),
+                ("kind", c_p), ("bc", c_p), ("log_width", c_p),
+                ("D", C.c_int32), ("logit", C.c_int32), ("scale", C.c_int32),
+                ("reserved", C.c_int32), ("sum_log_sigma", C.c_double)]
+
+
+class pmc_rng_t(C.Structure):
+    _fields_ = [("gamma", c_p), ("normal", c_p), ("uniform", c_p),
+                ("seed", C.c_uint64), ("step", C.c_uint64), ("offset", C.c_uint64)]
+
+
+class pmc_state_t(C.Structure):
+    _fields_ = [("theta32", c_p), ("u", c_p), ("x", c_p), ("logdetj", c_p),
+                ("logl", c_p), ("logp", c_p), ("logdetj_flow", c_p)]
+
+
+class pmc_proposal_t(C.Structure):
+    _fields_ = [("theta64", c_p), ("u", c_p), ("x", c_p), ("logdetj", c_p),
+                ("logl", c_p), ("logp", c_p), ("logdetj_flow", c_p),
+                ("quad", c_p), ("quad_prop", c_p)]
+
+
+# name -> (restype, argtypes); every symbol include/pocomc_amd.h declares
+i32, i64, f64 = C.c_int32, C.c_int64, C.c_double
+P = C.POINTER
+SIGNATURES = {
+    "pmc_last_error": (C.c_char_p, []),
+    "pmc_abi_version": (C.c_int, []),
+    "pmc_maf_pack": (C.c_int, [c_p, c_p, c_p, i64, c_p]),
+    "pmc_maf_forward": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, c_p, i64, c_p]),
+    "pmc_maf_inverse": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, i64, C.c_int, c_p]),
+    "pmc_scaler_inverse": (C.c_int, [P(pmc_scaler_t), c_p, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
+    "pmc_scaler_forward": (C.c_int, [P(pmc_scaler_t), c_p, c_p, i64, c_p]),
+    "pmc_propose": (C.c_int, [C.c_int, c_p, c_p, c_p, c_p, c_p, f64, f64, f64, P(pmc_rng_t),
+                              c_p, c_p, c_p, c_p, i64, i32, c_p]),
+    "pmc_accept_workspace_bytes": (i64, [i64, i32]),
+    "pmc_accept": (C.c_int, [C.c_int, C.c_int, P(pmc_state_t), P(pmc_proposal_t), f64, f64,
+                             P(pmc_rng_t), c_p, c_p, c_p, c_p, i64, i32, c_p]),
+    "pmc_logw": (C.c_int, [c_p, c_p, c_p, f64, c_p, i32, i64, c_p]),
+    "pmc_reduce_workspace_bytes": (i64, [i64]),
+    "pmc_logw_stats": (C.c_int, [c_p, i64, i64, c_p, c_p, c_p]),
+    "pmc_gather": (C.c_int, [c_p, i64, i32] + [c_p] * 10 + [c_p]),
+    "pmc_resample_multinomial": (C.c_int, [c_p, i64, c_p, i64, c_p, c_p, c_p]),
+    "pmc_resample_systematic": (C.c_int, [c_p, i64, f64, i64, c_p, c_p, c_p]),
+}
+
+_lib = None
+
+
+class PocomcAmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (no GPU needed for this) and bind every symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PocomcAmdError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  pocomc_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pmc_abi_version() != 1:
+        raise PocomcAmdError("libpocomc_amd.so: ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise PocomcAmdError("pocomc_amd needs an AMD MI355X (gfx950) visible to PyTorch-ROCm; "
+                             "there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().pmc_last_error()
+        raise PocomcAmdError(f"{what}: {msg.decode() if msg else 'error'} (rc={rc})")
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_handle():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

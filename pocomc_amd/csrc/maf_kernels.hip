@@ -1,0 +1,484 @@
+// MAF (masked autoregressive flow) kernels for gfx950 (MI355X, CDNA4).
+//
+// Replaces, on the device, what pocomc/flow.py:99-163 gets from zuko:
+//   forward  (data -> latent, ladj)          flow.py:99-114
+//   inverse  (latent -> data, ladj)          flow.py:116-132   <- every MCMC step (mcmc.py:88)
+//   log_prob                                 flow.py:134-147
+//
+// Execution model: one wavefront (64 lanes) owns 16 particles.  All matrix work
+// is exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), computed transposed:
+//     D[out row i][particle j] += sum_k  W[out i][in k] * act[in k][particle j]
+// so the A operand is a weight fragment (pre-packed on the host side in lane
+// order, one coalesced 1 KiB float4 load feeds 4 MFMAs) and the B operand is a
+// slice of the activations, which live in wave-private LDS in a layout where
+// the B operands of 4 consecutive K-chunks are one ds_read_b128:
+//     idx(row r, particle p) = (r>>4)*256 + (r&3)*64 + p*4 + ((r>>2)&3)
+// Lane l = (q = l>>4, p = l&15) of an accumulator holds rows 4q..4q+3 of the
+// 16-row tile for particle p.
+//
+// The inverse is NOT the reference's D fixed-point passes: hidden units are
+// sorted by autoregressive degree on the host (maf_spec.py), so the masked
+// weights are block lower-triangular and the inverse is a single sweep over the
+// degree groups (a blocked triangular solve): per hidden tile one left-looking
+// "burst" against everything already final, then per degree group a short
+// dependent chain  h0 -> h1 -> h2 -> (shift, raw) -> x_rank -> rank-1 update.
+// Work = one masked forward pass instead of D+1 dense ones.  The D-pass
+// algorithm is kept (mode NAIVE) as the on-device cross-check and for layouts
+// whose degree groups exceed one tile.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pmc_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// zuko MonotonicAffineTransform: log(slope) with slope = 1e-3
+#define PMC_LOG_SLOPE (-6.907755278982137f)
+
+__device__ __forceinline__ int lidx(int r, int p) {
+    return ((r >> 4) << 8) + ((r & 3) << 6) + (p << 2) + ((r >> 2) & 3);
+}
+
+__device__ __forceinline__ float sel4(const float4& v, int j) {
+    return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
+}
+
+__device__ __forceinline__ int sel4i(const int4& v, int j) {
+    return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
+}
+
+__device__ __forceinline__ float soft_ls(float raw) {
+    return raw / (1.0f + fabsf(raw / PMC_LOG_SLOPE));
+}
+
+__device__ __forceinline__ f32x4 bias4(const float* __restrict__ b, int off) {
+    const float4 v = *reinterpret_cast<const float4*>(b + off);
+    f32x4 r; r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; return r;
+}
+
+// acc += W[tile rows][K tile] * act[K tile]  : one float4 weight load + one
+// ds_read_b128 feed four MFMAs.
+__device__ __forceinline__ f32x4 tile_mac(f32x4 acc, const float4* __restrict__ frag,
+                                          const float* act, int ktile, int lane) {
+    const float4 a = frag[ktile * 64 + lane];
+    const float4 b = *reinterpret_cast<const float4*>(act + (ktile << 8) + (lane << 2));
+    acc = MFMA(a.x, b.x, acc);
+    acc = MFMA(a.y, b.y, acc);
+    acc = MFMA(a.z, b.z, acc);
+    acc = MFMA(a.w, b.w, acc);
+    return acc;
+}
+
+// store the 4 rows this lane holds of tile T into an activation array
+__device__ __forceinline__ void store_rows(float* act, int T, int q, int p, const f32x4& v) {
+    float* base = act + (T << 8) + (p << 2) + q;
+    base[0] = v[0]; base[64] = v[1]; base[128] = v[2]; base[192] = v[3];
+}
+
+struct MafView {
+    const float4* f0; const float4* f1; const float4* f2; const float4* f3;
+    const float* w0n; const float* b0; const float* b1; const float* b2; const float* b3;
+};
+
+__device__ __forceinline__ MafView maf_view(const pmc_maf_t& m, int t) {
+    const float* base = m.packed + (size_t)t * m.pk_per_transform;
+    MafView v;
+    const size_t sz_f0 = (size_t)m.nT * m.nXT * 256, sz_f12 = (size_t)m.nT * m.nT * 256;
+    const size_t sz_f3 = (size_t)m.nOT * m.nT * 256, sz_w0n = (size_t)m.Dp * m.Hp;
+    const float* p = base;
+    v.f0 = reinterpret_cast<const float4*>(p); p += sz_f0;
+    v.f1 = reinterpret_cast<const float4*>(p); p += sz_f12;
+    v.f2 = reinterpret_cast<const float4*>(p); p += sz_f12;
+    v.f3 = reinterpret_cast<const float4*>(p); p += sz_f3;
+    v.w0n = p; p += sz_w0n;
+    v.b0 = p; p += m.Hp;
+    v.b1 = p; p += m.Hp;
+    v.b2 = p; p += m.Hp;
+    v.b3 = p;
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// Dense pass of the hyper-network of one transform for 16 particles:
+// in: xin (LDS, by rank).  out: natural (shift, raw) accumulators are consumed
+// by the callback-free epilogue below.  H0/H1/H2 are scratch.
+// mode 0: forward  y = x*exp(ls)+shift      (xin = x, writes y to xout)
+// mode 1: inverse pass x' = (y-shift)/exp(ls) (xin = current x, yin = y)
+// ---------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ float maf_dense_pass(const pmc_maf_t& m, const MafView& w,
+                                                const float* xin, const float* yin, float* xout,
+                                                float* H0, float* H1, float* H2,
+                                                int lane, bool want_ladj) {
+    const int q = lane >> 4, p = lane & 15;
+    const int nT = m.nT, nXT = m.nXT, nOT = m.nOT, D = m.D;
+    // layer 0
+    for (int T = 0; T < nT; ++T) {
+        f32x4 a = bias4(w.b0, 16 * T + 4 * q);
+        for (int X = 0; X < nXT; ++X) a = tile_mac(a, w.f0 + (size_t)T * nXT * 64, xin, X, lane);
+        for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.0f);
+        store_rows(H0, T, q, p, a);
+    }
+    __syncthreads();
+    // layers 1, 2: h' = relu(h + W h + b).  Units are sorted by degree, so tile T
+    // only reads tiles <= T unless a degree group is wider than a tile.
+    for (int layer = 1; layer <= 2; ++layer) {
+        const float* Hin = layer == 1 ? H0 : H1;
+        float* Hout = layer == 1 ? H1 : H2;
+        const float4* f = layer == 1 ? w.f1 : w.f2;
+        const float* b = layer == 1 ? w.b1 : w.b2;
+        for (int T = 0; T < nT; ++T) {
+            f32x4 a = bias4(b, 16 * T + 4 * q);
+            const int kend = m.tri_ok ? T + 1 : nT;
+            for (int K = 0; K < kend; ++K) a = tile_mac(a, f + (size_t)T * nT * 64, Hin, K, lane);
+            const float* hb = Hin + (T << 8) + (p << 2) + q;
+            a[0] = fmaxf(a[0] + hb[0], 0.0f);
+            a[1] = fmaxf(a[1] + hb[64], 0.0f);
+            a[2] = fmaxf(a[2] + hb[128], 0.0f);
+            a[3] = fmaxf(a[3] + hb[192], 0.0f);
+            store_rows(Hout, T, q, p, a);
+        }
+        __syncthreads();
+    }
+    float ladj = 0.0f;
+    for (int O = 0; O < nOT; ++O) {
+        if (8 * O >= D) break;
+        f32x4 o = bias4(w.b3, 16 * O + 4 * q);
+        for (int K = 0; K < nT; ++K) o = tile_mac(o, w.f3 + (size_t)O * nT * 64, H2, K, lane);
+        for (int s = 0; s < 2; ++s) {
+            const int rank = 8 * O + 2 * q + s;
+            if (rank < D) {
+                const float shift = s ? o[2] : o[0];
+                const float ls = soft_ls(s ? o[3] : o[1]);
+                if (MODE == 0) {
+                    const float x = xin[lidx(rank, p)];
+                    xout[lidx(rank, p)] = x * expf(ls) + shift;
+                } else {
+                    const float y = yin[lidx(rank, p)];
+                    xout[lidx(rank, p)] = (y - shift) / expf(ls);
+                }
+                if (want_ladj) ladj += ls;
+            }
+        }
+    }
+    __syncthreads();
+    return ladj;
+}
+
+// sum a per-lane partial over the 4 quads that share a particle
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// load 16 particle rows (row-major [n][D] fp32) into an LDS rank-indexed array
+__device__ __forceinline__ void load_rows(float* dst, const float* __restrict__ src, int64_t row0,
+                                          int64_t n, int D, int Dp, const int* __restrict__ feat_of_rank,
+                                          int lane) {
+    for (int e = lane; e < Dp * 16; e += 64) {
+        const int r = e >> 4, p = e & 15;      // rank-major so that LDS writes spread
+        float v = 0.0f;
+        if (r < D && row0 + p < n) v = src[(row0 + p) * D + feat_of_rank[r]];
+        dst[lidx(r, p)] = v;
+    }
+}
+
+// re-rank an LDS array for the next transform, or write it out
+__device__ __forceinline__ void rerank_or_store(const float* cur, float* nxt, float* __restrict__ out,
+                                                int64_t row0, int64_t n, int D, int Dp,
+                                                const int* __restrict__ for_cur,
+                                                const int* __restrict__ rank_next, int lane) {
+    for (int e = lane; e < Dp * 16; e += 64) {
+        const int r = e >> 4, p = e & 15;
+        if (r < D) {
+            const float v = cur[lidx(r, p)];
+            const int feat = for_cur[r];
+            if (rank_next) nxt[lidx(rank_next[feat], p)] = v;
+            else if (row0 + p < n) out[(row0 + p) * D + feat] = v;
+        }
+    }
+    if (rank_next) {
+        for (int e = lane; e < (Dp - D) * 16; e += 64) {
+            const int r = D + (e >> 4), p = e & 15;
+            nxt[lidx(r, p)] = 0.0f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// forward (MODE 0) and naive D-pass inverse (MODE 1)
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(64) void maf_dense_kernel(pmc_maf_t m, const float* __restrict__ in,
+                                                       float* __restrict__ out, float* __restrict__ ladj_out,
+                                                       float* __restrict__ logprob_out, int64_t n) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int p = lane & 15;
+    const int64_t row0 = (int64_t)blockIdx.x * 16;
+    const int D = m.D, Dp = m.Dp, Hp = m.Hp, T = m.T;
+    float* A = smem;                 // current values by rank
+    float* B = A + Dp * 16;          // next values
+    float* C = B + Dp * 16;          // (inverse) iterate
+    float* H0 = C + Dp * 16;
+    float* H1 = H0 + Hp * 16;
+    float* H2 = H1 + Hp * 16;
+    const int* feat_of_rank = m.meta + 8;
+    const int* rank_of_feat = m.meta + 8 + T * D;
+
+    float ladj = 0.0f;
+    if (MODE == 0) {
+        load_rows(A, in, row0, n, D, Dp, feat_of_rank, lane);
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const MafView w = maf_view(m, t);
+            ladj += maf_dense_pass<0>(m, w, A, nullptr, B, H0, H1, H2, lane, true);
+            const bool last = (t == T - 1);
+            rerank_or_store(B, A, out, row0, n, D, Dp, feat_of_rank + t * D,
+                            last ? nullptr : rank_of_feat + (t + 1) * D, lane);
+            __syncthreads();
+            if (last && logprob_out) {
+                // base N(0,I) log-density of z (flow.py:147 -> zuko DiagNormal)
+                float ss = 0.0f;
+                for (int r = (lane >> 4); r < D; r += 4) { const float z = B[lidx(r, p)]; ss += z * z; }
+                ss = quad_sum(ss);
+                const float l = quad_sum(ladj);
+                if (lane < 16 && row0 + p < n)
+                    logprob_out[row0 + p] = (-0.5f * ss - 0.9189385332046727f * (float)D) + l;
+            }
+        }
+        ladj = quad_sum(ladj);
+        if (ladj_out && lane < 16 && row0 + p < n) ladj_out[row0 + p] = ladj;
+    } else {
+        load_rows(A, in, row0, n, D, Dp, feat_of_rank + (T - 1) * D, lane);
+        __syncthreads();
+        for (int t = T - 1; t >= 0; --t) {
+            const MafView w = maf_view(m, t);
+            for (int e = lane; e < Dp * 16; e += 64) C[e] = 0.0f;
+            __syncthreads();
+            float* cur = C; float* nxt = B;
+            for (int pass = 0; pass < D; ++pass) {      // zuko: passes = features
+                maf_dense_pass<1>(m, w, cur, A, nxt, H0, H1, H2, lane, false);
+                float* tmp = cur; cur = nxt; nxt = tmp;
+                for (int e = lane; e < (Dp - D) * 16; e += 64) cur[lidx(D + (e >> 4), e & 15)] = 0.0f;
+                __syncthreads();
+            }
+            // one more pass for the log-determinant (zuko inv.call_and_ladj)
+            ladj -= maf_dense_pass<1>(m, w, cur, A, nxt, H0, H1, H2, lane, true);
+            const bool last = (t == 0);
+            rerank_or_store(cur, A, out, row0, n, D, Dp, feat_of_rank + t * D,
+                            last ? nullptr : rank_of_feat + (t - 1) * D, lane);
+            __syncthreads();
+        }
+        ladj = quad_sum(ladj);
+        if (ladj_out && lane < 16 && row0 + p < n) ladj_out[row0 + p] = ladj;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// triangular-sweep inverse
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void maf_inverse_tri_kernel(pmc_maf_t m, const float* __restrict__ in,
+                                                             float* __restrict__ out,
+                                                             float* __restrict__ ladj_out, int64_t n) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int q = lane >> 4, p = lane & 15;
+    const int64_t row0 = (int64_t)blockIdx.x * 16;
+    const int D = m.D, Dp = m.Dp, Hp = m.Hp, T = m.T, nT = m.nT, nXT = m.nXT;
+    float* Y = smem;                 // input of the transform being inverted, by rank
+    float* X = Y + Dp * 16;          // its output, filled rank after rank
+    float* H0 = X + Dp * 16;
+    float* H1 = H0 + Hp * 16;
+    float* H2 = H1 + Hp * 16;
+    const int* feat_of_rank = m.meta + 8;
+    const int* rank_of_feat = m.meta + 8 + T * D;
+    const int* quad_meta = m.meta + 8 + 2 * T * D;
+
+    load_rows(Y, in, row0, n, D, Dp, feat_of_rank + (T - 1) * D, lane);
+    float ladj = 0.0f;               // per-lane partial: owner lanes add their ranks
+
+    for (int t = T - 1; t >= 0; --t) {
+        const MafView w = maf_view(m, t);
+        // zero X and the activations: bursts read whole tiles, unknown == 0
+        {
+            float4* z4 = reinterpret_cast<float4*>(X);
+            const int n4 = (Dp * 16 + 3 * Hp * 16) >> 2;
+            for (int e = lane; e < n4; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+
+        int o_cur = 0;
+        f32x4 oacc = bias4(w.b3, 4 * q);
+        float xg;
+        // ---- rank 0 reads nothing: bias only
+        {
+            const float yv = Y[lidx(0, p)];
+            const float ls = soft_ls(oacc[1]);
+            xg = (yv - oacc[0]) / expf(ls);
+            if (q == 0) { X[lidx(0, p)] = xg; ladj -= ls; }
+        }
+        __syncthreads();
+
+        for (int Tt = 0; Tt < nT; ++Tt) {
+            int4 dg = *reinterpret_cast<const int4*>(quad_meta + 4 * Tt);
+            dg.x &= 0xffff; dg.y &= 0xffff; dg.z &= 0xffff; dg.w &= 0xffff;
+            if (dg.x >= D && dg.y >= D && dg.z >= D && dg.w >= D) break;       // padding tiles
+
+            // ---- bursts against everything that is already final
+            f32x4 a0 = bias4(w.b0, 16 * Tt + 4 * q);
+            for (int Xt = 0; Xt < nXT; ++Xt) a0 = tile_mac(a0, w.f0 + (size_t)Tt * nXT * 64, X, Xt, lane);
+            f32x4 a1 = bias4(w.b1, 16 * Tt + 4 * q);
+            f32x4 a2 = bias4(w.b2, 16 * Tt + 4 * q);
+            for (int K = 0; K < Tt; ++K) {
+                a1 = tile_mac(a1, w.f1 + (size_t)Tt * nT * 64, H0, K, lane);
+                a2 = tile_mac(a2, w.f2 + (size_t)Tt * nT * 64, H1, K, lane);
+            }
+            const float4 d1 = w.f1[((size_t)Tt * nT + Tt) * 64 + lane];
+            const float4 d2 = w.f2[((size_t)Tt * nT + Tt) * 64 + lane];
+
+            // ---- the degree groups of this tile, one after the other
+            int j0 = 0;
+            while (j0 < 4) {
+                const int g = sel4i(dg, j0);
+                int j1 = j0;
+                while (j1 + 1 < 4 && sel4i(dg, j1 + 1) == g) ++j1;
+                if (g >= D) { j0 = j1 + 1; continue; }
+                const bool mine = (q >= j0) && (q <= j1);
+                const int hb = (Tt << 8) + (lane << 2);          // B-operand base of this tile
+
+                f32x4 h0, h1, h2;
+                for (int r = 0; r < 4; ++r) h0[r] = fmaxf(a0[r], 0.0f);
+                if (mine) store_rows(H0, Tt, q, p, h0);
+                __syncthreads();
+                for (int j = j0; j <= j1; ++j) a1 = MFMA(sel4(d1, j), H0[hb + j], a1);
+                for (int r = 0; r < 4; ++r) h1[r] = fmaxf(a1[r] + h0[r], 0.0f);
+                if (mine) store_rows(H1, Tt, q, p, h1);
+                __syncthreads();
+                for (int j = j0; j <= j1; ++j) a2 = MFMA(sel4(d2, j), H1[hb + j], a2);
+                for (int r = 0; r < 4; ++r) h2[r] = fmaxf(a2[r] + h1[r], 0.0f);
+                if (mine) store_rows(H2, Tt, q, p, h2);
+                __syncthreads();
+
+                // ---- (shift, raw) of rank g
+                if ((g & 7) == 0) {
+                    o_cur = g >> 3;                               // new output tile: left-looking burst
+                    oacc = bias4(w.b3, 16 * o_cur + 4 * q);
+                    for (int K = 0; K <= Tt; ++K) oacc = tile_mac(oacc, w.f3 + (size_t)o_cur * nT * 64, H2, K, lane);
+                } else {
+                    const float4 d3 = w.f3[((size_t)o_cur * nT + Tt) * 64 + lane];
+                    for (int j = j0; j <= j1; ++j) oacc = MFMA(sel4(d3, j), H2[hb + j], oacc);
+                }
+                {
+                    const int s = g & 1, qo = (g & 7) >> 1;
+                    const float shift = s ? oacc[2] : oacc[0];
+                    const float ls = soft_ls(s ? oacc[3] : oacc[1]);
+                    const float yv = Y[lidx(g, p)];
+                    const float xv = (yv - shift) / expf(ls);
+                    if (q == qo) { X[lidx(g, p)] = xv; ladj -= ls; }
+                }
+                __syncthreads();
+                xg = X[lidx(g, p)];
+                // ---- rank-1 update of this tile's layer-0 pre-activations
+                {
+                    const float4 wv = *reinterpret_cast<const float4*>(w.w0n + (size_t)g * Hp + 16 * Tt + 4 * q);
+                    a0[0] += wv.x * xg; a0[1] += wv.y * xg; a0[2] += wv.z * xg; a0[3] += wv.w * xg;
+                }
+                j0 = j1 + 1;
+            }
+        }
+        __syncthreads();
+        const bool last = (t == 0);
+        rerank_or_store(X, Y, out, row0, n, D, Dp, feat_of_rank + t * D,
+                        last ? nullptr : rank_of_feat + (t - 1) * D, lane);
+        __syncthreads();
+    }
+    ladj = quad_sum(ladj);
+    if (ladj_out && lane < 16 && row0 + p < n) ladj_out[row0 + p] = ladj;
+}
+
+// ---------------------------------------------------------------------------
+// packing: packed[i] = idx[i] >= 0 ? flat[idx[i]] : 0
+// ---------------------------------------------------------------------------
+__global__ void maf_pack_kernel(const float* __restrict__ flat, const int32_t* __restrict__ idx,
+                                float* __restrict__ packed, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t j = idx[i];
+        packed[i] = j >= 0 ? flat[j] : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static size_t maf_lds_bytes(const pmc_maf_t& m, int n_rank_arrays) {
+    return (size_t)(n_rank_arrays * m.Dp * 16 + 3 * m.Hp * 16) * sizeof(float);
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+    if (bytes > 160 * 1024) return pmc_fail("MAF too wide for one wave's LDS budget (160 KiB)");
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    return 0;
+}
+
+extern "C" int pmc_maf_pack(const float* flat, const int32_t* pack_idx, float* packed, int64_t n_packed,
+                            void* stream) {
+    if (!flat || !pack_idx || !packed || n_packed <= 0) return pmc_fail("pmc_maf_pack: bad argument");
+    const int block = 256;
+    int64_t grid = (n_packed + block - 1) / block;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(maf_pack_kernel, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream,
+                       flat, pack_idx, packed, n_packed);
+    return pmc_check_launch("maf_pack_kernel");
+}
+
+static int check_maf(const pmc_maf_t* m) {
+    if (!m || !m->packed || !m->meta) return pmc_fail("pmc_maf: null descriptor field");
+    if (m->D < 2 || m->T < 1 || (m->Hp & 15) || (m->Dp & 15) || m->nT * 16 != m->Hp ||
+        m->nXT * 16 != m->Dp || m->nOT * 16 != 2 * m->Dp)
+        return pmc_fail("pmc_maf: inconsistent descriptor");
+    return 0;
+}
+
+extern "C" int pmc_maf_forward(const pmc_maf_t* m, const float* x, float* z, float* ladj, float* log_prob,
+                               int64_t n, void* stream) {
+    if (int e = check_maf(m)) return e;
+    if (n == 0) return 0;
+    if (!x || !z || n < 0) return pmc_fail("pmc_maf_forward: bad argument");
+    const size_t lds = maf_lds_bytes(*m, 3);
+    if (int e = set_lds(maf_dense_kernel<0>, lds)) return e;
+    hipLaunchKernelGGL(maf_dense_kernel<0>, dim3((unsigned)((n + 15) / 16)), dim3(64), lds, (hipStream_t)stream,
+                       *m, x, z, ladj, log_prob, n);
+    return pmc_check_launch("maf_dense_kernel<forward>");
+}
+
+extern "C" int pmc_maf_inverse(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
+                               int algo, void* stream) {
+    if (int e = check_maf(m)) return e;
+    if (n == 0) return 0;
+    if (!z || !x || n < 0) return pmc_fail("pmc_maf_inverse: bad argument");
+    if (algo == PMC_INVERSE_AUTO) algo = m->tri_ok ? PMC_INVERSE_TRIANGULAR : PMC_INVERSE_NAIVE;
+    if (algo == PMC_INVERSE_TRIANGULAR) {
+        if (!m->tri_ok) return pmc_fail("pmc_maf_inverse: triangular sweep needs degree groups <= one tile");
+        const size_t lds = maf_lds_bytes(*m, 2);
+        if (int e = set_lds(maf_inverse_tri_kernel, lds)) return e;
+        hipLaunchKernelGGL(maf_inverse_tri_kernel, dim3((unsigned)((n + 15) / 16)), dim3(64), lds,
+                           (hipStream_t)stream, *m, z, x, ladj, n);
+        return pmc_check_launch("maf_inverse_tri_kernel");
+    } else if (algo == PMC_INVERSE_NAIVE) {
+        const size_t lds = maf_lds_bytes(*m, 3);
+        if (int e = set_lds(maf_dense_kernel<1>, lds)) return e;
+        hipLaunchKernelGGL(maf_dense_kernel<1>, dim3((unsigned)((n + 15) / 16)), dim3(64), lds,
+                           (hipStream_t)stream, *m, z, x, ladj, (float*)nullptr, n);
+        return pmc_check_launch("maf_dense_kernel<naive inverse>");
+    }
+    return pmc_fail("pmc_maf_inverse: unknown algo");
+}

@@ -1,0 +1,664 @@
+// Per-particle kernels of the MCMC step (pocomc/mcmc.py) and the scaler inside it
+// (pocomc/scaler.py).  float64 like the reference's numpy arithmetic; the
+// expressions that decide accept/reject keep the reference's operation order and
+// are compiled without FMA contraction so that a replayed step makes the same
+// decisions as the reference.
+//
+// These are HBM/L2-streaming sweeps with wave-level reductions -- no MFMA here.
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "philox.h"
+#include "pmc_internal.h"
+
+// The reference evaluates these expressions with numpy: one rounding per operation.
+#pragma clang fp contract(off)
+
+#define PROP_ROWS 64          // particles per block in propose_kernel (one wave)
+#define ACC_ROWS 256          // particles per block in accept_kernel
+#define SCL_ROWS 64           // particles per block in the scaler kernels
+
+// ===========================================================================
+// proposal: mcmc.py:77-85 (tpCN), :251-253 / :561-563 (RWM)
+// ===========================================================================
+__global__ __launch_bounds__(PROP_ROWS) void propose_kernel(
+    int kind, const float* __restrict__ cur32, const double* __restrict__ cur64,
+    const double* __restrict__ mu, const double* __restrict__ inv_cov, const double* __restrict__ chol,
+    double nu, double sigma, double cn_a, pmc_rng_t rng, double* __restrict__ prop64,
+    float* __restrict__ prop32, double* __restrict__ quad, double* __restrict__ quad_prop,
+    int64_t n, int D) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int LD = PROP_ROWS + 1;
+    double* dif = sm;                 // [D][LD]  theta - mu (tpCN) or theta (RWM)
+    double* zz = sm + (size_t)D * LD; // [D][LD]  z, overwritten by the proposal
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * PROP_ROWS;
+    const int rows = (int)min((int64_t)PROP_ROWS, n - row0);
+
+    // coalesced load of the block's [rows][D] slab
+    for (int e = tid; e < rows * D; e += PROP_ROWS) {
+        const int r = e / D, j = e - r * D;
+        const double v = cur32 ? (double)cur32[(row0 + r) * D + j] : cur64[(row0 + r) * D + j];
+        dif[j * LD + r] = (kind == PMC_KIND_TPCN) ? v - mu[j] : v;
+        if (rng.normal) zz[j * LD + r] = rng.normal[(row0 + r) * D + j];
+    }
+    __syncthreads();
+    if (tid >= rows) return;
+    const int64_t gidx = rng.offset + row0 + tid;
+    if (!rng.normal) {
+        Philox ph(rng.seed, rng.step, gidx, 1);
+        for (int j = 0; j < D; j += 2) {
+            double a, b;
+            ph.normal2(a, b);
+            zz[j * LD + tid] = a;
+            if (j + 1 < D) zz[(j + 1) * LD + tid] = b;
+        }
+    }
+
+    double scale_z;                   // multiplies L z
+    double q_cur = 0.0;
+    if (kind == PMC_KIND_TPCN) {
+        // diff^T inv_cov diff  (mcmc.py:80)
+        for (int i = 0; i < D; ++i) {
+            double w = 0.0;
+            const double* Si = inv_cov + (size_t)i * D;
+            for (int j = 0; j < D; ++j) w += Si[j] * dif[j * LD + tid];
+            q_cur += dif[i * LD + tid] * w;
+        }
+        double g;
+        if (rng.gamma) g = rng.gamma[row0 + tid];
+        else { Philox ph(rng.seed, rng.step, gidx, 0); g = ph.std_gamma(0.5 * ((double)D + nu)); }
+        const double s = 1.0 / ((2.0 / (nu + q_cur)) * g);         // 1/np.random.gamma(shape, scale)
+        scale_z = sigma * sqrt(s);
+    } else {
+        scale_z = sigma;
+    }
+
+    // proposal, last coordinate first so that z can be overwritten in place
+    for (int i = D - 1; i >= 0; --i) {
+        double lz = 0.0;
+        const double* Li = chol + (size_t)i * D;
+        for (int j = 0; j <= i; ++j) lz += Li[j] * zz[j * LD + tid];
+        double v;
+        if (kind == PMC_KIND_TPCN) v = (mu[i] + cn_a * dif[i * LD + tid]) + scale_z * lz;
+        else v = dif[i * LD + tid] + scale_z * lz;
+        zz[i * LD + tid] = v;
+    }
+    if (kind == PMC_KIND_TPCN) {
+        double q_new = 0.0;
+        for (int i = 0; i < D; ++i) {
+            double w = 0.0;
+            const double* Si = inv_cov + (size_t)i * D;
+            for (int j = 0; j < D; ++j) w += Si[j] * (zz[j * LD + tid] - mu[j]);
+            q_new += (zz[i * LD + tid] - mu[i]) * w;
+        }
+        if (quad) quad[row0 + tid] = q_cur;
+        if (quad_prop) quad_prop[row0 + tid] = q_new;
+    }
+    // each lane writes its own row: D*8 B per lane, whole cache lines per lane
+    for (int j = 0; j < D; ++j) {
+        const double v = zz[j * LD + tid];
+        if (prop64) prop64[(row0 + tid) * D + j] = v;
+        if (prop32) prop32[(row0 + tid) * D + j] = (float)v;
+    }
+}
+
+// ===========================================================================
+// scaler: Reparameterize.inverse / forward (scaler.py:180-226, :293-425)
+// ===========================================================================
+#define LOG_SQRT_2PI 0.91893853320467267   // np.log(np.sqrt(2.0*np.pi))
+#define SQRT2 1.4142135623730951           // np.sqrt(2.0)
+
+struct ScalerDev {
+    pmc_scaler_t s;
+};
+
+// numpy's pairwise summation (umath loops, PW_BLOCKSIZE = 128), so that the row sum of
+// the Jacobian terms (scaler.py:270) is accumulated in numpy's order
+__device__ __forceinline__ double np_pairwise_leaf(const double* a, int n) {   // n <= 128
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += a[i + 0]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+// numpy splits n > 128 in halves (first half rounded down to a multiple of 8), recursively;
+// three explicit levels cover n <= 1024 without a device-side call stack
+template <int LEVEL>
+__device__ __forceinline__ double np_pairwise_sum_l(const double* a, int n) {
+    if (n <= 128) return np_pairwise_leaf(a, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    if constexpr (LEVEL > 0) return np_pairwise_sum_l<LEVEL - 1>(a, n2) + np_pairwise_sum_l<LEVEL - 1>(a + n2, n - n2);
+    else return np_pairwise_leaf(a, n2) + np_pairwise_leaf(a + n2, n - n2);
+}
+
+__device__ __forceinline__ double np_pairwise_sum(const double* a, int n) { return np_pairwise_sum_l<2>(a, n); }
+
+// bounded <- unbounded for one element; t is the (affine-transformed) input.  scaler.py:329-425
+__device__ __forceinline__ void bound_inverse(const pmc_scaler_t& s, int j, double t, double& x, double& J) {
+    {
+        const int kind = s.kind[j];
+        if (kind == 0) { x = t; J = 0.0; }
+        else if (kind == 1) { x = exp(t) + s.low[j]; J = t; }
+        else if (kind == 2) { x = s.high[j] - exp(t); J = t; }
+        else {
+            const double w = s.high[j] - s.low[j];
+            if (s.logit) {
+                // p = exp(-logaddexp(0, -t))
+                const double mt = -t;
+                double lae;
+                if (mt == 0.0) lae = 0.6931471805599453;
+                else if (0.0 - mt > 0.0) lae = 0.0 + log1p(exp(-(0.0 - mt)));
+                else lae = mt + log1p(exp(0.0 - mt));
+                const double p = exp(-lae);
+                x = p * w + s.low[j];
+                J = (s.log_width[j] + log(p)) + log(1.0 - p);
+            } else {
+                const double p = (erf(t / SQRT2) + 1.0) / 2.0;
+                x = p * w + s.low[j];
+                J = (s.log_width[j] + (-(t * t) / 2.0)) - LOG_SQRT_2PI;
+            }
+        }
+    }
+}
+
+// unbounded <- bounded (scaler.py:228-247, :315-400), then the affine part (:273-289)
+__device__ __forceinline__ double bound_forward(const pmc_scaler_t& s, int j, double x) {
+    double u;
+    {
+        const int kind = s.kind[j];
+        if (kind == 0) u = x;
+        else if (kind == 1) u = log(x - s.low[j]);
+        else if (kind == 2) u = log(s.high[j] - x);
+        else {
+            const double p = (x - s.low[j]) / (s.high[j] - s.low[j]);
+            if (s.logit) u = log(p / (1.0 - p));
+            else u = SQRT2 * erfinv(2.0 * p - 1.0);
+        }
+        if (s.scale) u = (u - s.mu[j]) / s.sigma[j];
+    }
+    return u;
+}
+
+// periodic wrap / reflective fold (scaler.py:109-157).  The reference loops "while
+// outside"; a non-finite x would never leave that loop, the device bounds it.
+__device__ __forceinline__ double apply_bc(const pmc_scaler_t& s, int j, double x) {
+    const int bc = s.bc[j];
+    if (bc == 0) return x;
+    const double lo = s.low[j], hi = s.high[j];
+    {
+        if (bc & 1) {
+            for (int it = 0; it < 4096 && x > hi; ++it) x = lo + x - hi;
+            for (int it = 0; it < 4096 && x < lo; ++it) x = hi + x - lo;
+        }
+        if (bc & 2) {
+            for (int it = 0; it < 4096 && x > hi; ++it) x = hi - x + hi;
+            for (int it = 0; it < 4096 && x < lo; ++it) x = lo + lo - x;
+        }
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(256) void scaler_inverse_kernel(
+    pmc_scaler_t s, const float* __restrict__ u_in, const double* __restrict__ u_in64,
+    double* __restrict__ u_out, double* __restrict__ x_out, double* __restrict__ ldj_out,
+    int32_t* __restrict__ finite_out, int64_t n) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int D = s.D;
+    double* Jt = sm;                              // [SCL_ROWS][D]
+    int* rowfin = reinterpret_cast<int*>(sm + (size_t)SCL_ROWS * D);
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * SCL_ROWS;
+    const int rows = (int)min((int64_t)SCL_ROWS, n - row0);
+    if (tid < SCL_ROWS) rowfin[tid] = 1;
+    __syncthreads();
+    for (int e = tid; e < rows * D; e += 256) {
+        const int r = e / D, j = e - r * D;
+        const int64_t g = (row0 + r) * D + j;
+        double u = u_in ? (double)u_in[g] : u_in64[g];
+        double t, x, J;
+        t = s.scale ? s.mu[j] + s.sigma[j] * u : u;
+        bound_inverse(s, j, t, x, J);
+        if (s.bc) {
+            // mcmc.py:94-97: wrap x, re-derive u from it, invert again
+            x = apply_bc(s, j, x);
+            u = bound_forward(s, j, x);
+            t = s.scale ? s.mu[j] + s.sigma[j] * u : u;
+            bound_inverse(s, j, t, x, J);
+        }
+        u_out[g] = u;
+        x_out[g] = x;
+        Jt[r * D + j] = J;
+        if (!isfinite(x)) rowfin[r] = 0;
+    }
+    __syncthreads();
+    if (tid < rows) {
+        double l = np_pairwise_sum(Jt + (size_t)tid * D, D);
+        if (s.scale) l = s.sum_log_sigma + l;
+        ldj_out[row0 + tid] = l;
+        finite_out[row0 + tid] = (rowfin[tid] && isfinite(l)) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void scaler_forward_kernel(pmc_scaler_t s, const double* __restrict__ x,
+                                                             double* __restrict__ u, int64_t n) {
+    const int D = s.D;
+    const int64_t total = n * D;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int j = (int)(e % D);
+        u[e] = bound_forward(s, j, x[e]);
+    }
+}
+
+// ===========================================================================
+// Metropolis ratio, accept, reductions: mcmc.py:124-156 and variants
+// ===========================================================================
+__device__ __forceinline__ double block_sum_256(double v, double* red, int tid) {
+    // deterministic tree: wave shuffle, then 4 wave totals in fixed order
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(ACC_ROWS) void accept_kernel(
+    int preconditioned, int tpcn, pmc_state_t cur, pmc_proposal_t prop, double beta, double nu,
+    pmc_rng_t rng, double* __restrict__ alpha_out, int32_t* __restrict__ accept_out,
+    double* __restrict__ partials, int64_t n, int D) {
+    __shared__ int flag[ACC_ROWS];
+    __shared__ double red[4];
+    __shared__ double colsum[8][33];
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * ACC_ROWS;
+    const int rows = (int)min((int64_t)ACC_ROWS, n - row0);
+    const int64_t k = row0 + tid;
+
+    double alpha = 0.0, lp_post = 0.0, ldj_post = 0.0;
+    int acc = 0;
+    if (tid < rows) {
+        const double logl = cur.logl[k], logp = cur.logp[k], ldj = cur.logdetj[k];
+        const double logl_p = prop.logl[k], logp_p = prop.logp[k], ldj_p = prop.logdetj[k];
+        double e;
+        {
+            // mcmc.py:130-133, left to right
+            e = logl_p * beta - logl * beta + logp_p - logp + ldj_p - ldj;
+            if (preconditioned) e = e + (double)prop.logdetj_flow[k] - (double)cur.logdetj_flow[k];
+            if (tpcn) {
+                const double c = -((double)D + nu) / 2.0;
+                const double A = c * log(1.0 + prop.quad_prop[k] / nu);     // mcmc.py:128
+                const double B = c * log(1.0 + prop.quad[k] / nu);          // mcmc.py:129
+                e = e - A + B;
+            }
+        }
+        const double v = exp(e);
+        alpha = (v != v) ? 0.0 : (v < 1.0 ? v : 1.0);      // np.minimum(1, .); NaN -> 0 (mcmc.py:134)
+        double ur;
+        if (rng.uniform) ur = rng.uniform[k];
+        else { Philox ph(rng.seed, rng.step, rng.offset + k, 2); double d; ph.uniform2(ur, d); }
+        acc = ur < alpha;
+        if (acc) {
+            cur.logdetj[k] = ldj_p; cur.logl[k] = logl_p; cur.logp[k] = logp_p;
+            if (preconditioned) cur.logdetj_flow[k] = prop.logdetj_flow[k];
+        }
+        lp_post = acc ? (logl_p + logp_p) : (logl + logp);
+        ldj_post = lp_post + (acc ? ldj_p : ldj);             // logl + logp + logdetj (mcmc.py:243, :327)
+        if (alpha_out) alpha_out[k] = alpha;
+        if (accept_out) accept_out[k] = acc;
+    }
+    flag[tid] = acc;
+    const double s_alpha = block_sum_256(alpha, red, tid);
+    const double s_lp = block_sum_256(lp_post, red, tid);
+    const double s_ldj = block_sum_256(ldj_post, red, tid);
+    const double s_acc = block_sum_256((double)acc, red, tid);
+    double* P = partials + (size_t)blockIdx.x * (D + 4);
+    if (tid == 0) { P[0] = s_alpha; P[1] = s_lp; P[2] = s_ldj; P[3] = s_acc; }
+
+    // accepted rows overwrite theta / u / x; the column sums of the moved variable
+    // (theta for the preconditioned kernels, u otherwise) are taken on the fly
+    const int tx = tid & 31, ty = tid >> 5;
+    for (int j0 = 0; j0 < D; j0 += 32) {
+        const int j = j0 + tx;
+        double csum = 0.0;
+        if (j < D) {
+            for (int r = ty; r < rows; r += 8) {
+                const int64_t g = (row0 + r) * D + j;
+                const int a = flag[r];
+                if (a) { cur.u[g] = prop.u[g]; cur.x[g] = prop.x[g]; }
+                if (preconditioned) {
+                    float th = cur.theta32[g];
+                    if (a) { th = (float)prop.theta64[g]; cur.theta32[g] = th; }   // theta is a float32 array (tools.py:339)
+                    csum += (double)th;
+                } else {
+                    csum += a ? prop.u[g] : cur.u[g];
+                }
+            }
+        }
+        colsum[ty][tx] = csum;
+        __syncthreads();
+        if (ty == 0 && j < D) {
+            double t = 0.0;
+            for (int y = 0; y < 8; ++y) t += colsum[y][tx];
+            P[4 + j] = t;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials,
+                                                              double* __restrict__ sums, int nblocks, int width) {
+    for (int c = threadIdx.x; c < width; c += 256) {
+        double t = 0.0;
+        for (int b = 0; b < nblocks; ++b) t += partials[(size_t)b * width + c];
+        sums[c] = t;
+    }
+}
+
+// ===========================================================================
+// particle math: particles.py:215-231, tools.py:56-133, sampler.py:680-715
+// ===========================================================================
+__device__ __forceinline__ double np_logaddexp(double x, double y) {
+    // numpy npy_logaddexp
+    if (x == y) return x + 0.6931471805599453;
+    const double tmp = x - y;
+    if (tmp > 0) return x + log1p(exp(-tmp));
+    else if (tmp <= 0) return y + log1p(exp(tmp));
+    return tmp;   // NaN
+}
+
+__global__ __launch_bounds__(256) void logw_kernel(const double* __restrict__ logl, const double* __restrict__ beta,
+                                                   const double* __restrict__ logz, double beta_final,
+                                                   double* __restrict__ logw, int T, int64_t N) {
+    const int64_t total = (int64_t)T * N;
+    const double logT = log((double)T);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const double l = logl[e];
+        double B;
+        {
+            B = l * beta[0] - logz[0];
+            for (int i = 1; i < T; ++i) B = np_logaddexp(B, l * beta[i] - logz[i]);   // np.logaddexp.reduce(b, axis=0)
+            logw[e] = l * beta_final - (B - logT);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void max_partial_kernel(const double* __restrict__ v, int64_t P, double* __restrict__ part) {
+    __shared__ double red[4];
+    double m = -INFINITY;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < P; e += (int64_t)gridDim.x * 256) m = fmax(m, v[e]);
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void max_final_kernel(double* part, int nb) {
+    if (threadIdx.x == 0) {
+        double m = -INFINITY;
+        for (int b = 0; b < nb; ++b) m = fmax(m, part[b]);
+        part[nb] = m;
+    }
+}
+
+__global__ __launch_bounds__(256) void wsum_partial_kernel(const double* __restrict__ logw, int64_t P, const double* __restrict__ mx,
+                                                           const double* __restrict__ tot, int64_t kk, int mode,
+                                                           double* __restrict__ part) {
+    // mode 0: sum w, sum w^2 with w = exp(logw - max);  mode 1: sum 1-(1-w/tot)^k
+    __shared__ double red[4];
+    const double m = *mx;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < P; e += (int64_t)gridDim.x * 256) {
+        const double w = exp(logw[e] - m);
+        if (mode == 0) { s1 += w; s2 += w * w; }
+        else { s1 += 1.0 - pow(1.0 - w / *tot, (double)kk); }
+    }
+    const double a = block_sum_256(s1, red, threadIdx.x);
+    const double b = block_sum_256(s2, red, threadIdx.x);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = b; }
+}
+
+__global__ void wsum_final_kernel(const double* __restrict__ part, int nb, double* __restrict__ out, int o1, int o2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i < nb; ++i) { a += part[2 * i]; b += part[2 * i + 1]; }
+        out[o1] = a;
+        if (o2 >= 0) out[o2] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const int64_t* __restrict__ idx, int64_t n_out, int D,
+                                                     const double* __restrict__ u, const double* __restrict__ x,
+                                                     const double* __restrict__ a, const double* __restrict__ b,
+                                                     const double* __restrict__ c, double* __restrict__ uo,
+                                                     double* __restrict__ xo, double* __restrict__ ao,
+                                                     double* __restrict__ bo, double* __restrict__ co) {
+    const int64_t total = n_out * D;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / D;
+        const int j = (int)(e - r * D);
+        const int64_t s = idx[r];
+        if (u) uo[e] = u[s * D + j];
+        if (x) xo[e] = x[s * D + j];
+        if (j == 0) {
+            if (a) ao[r] = a[s];
+            if (b) bo[r] = b[s];
+            if (c) co[r] = c[s];
+        }
+    }
+}
+
+// cumulative sum in the reference's order (np.cumsum / the running sum of
+// tools.py:176-183 are sequential), so that resampled INDICES are bit-exact.
+__global__ void serial_cumsum_kernel(const double* __restrict__ w, int64_t P, double* __restrict__ cdf, int normalise) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double c = 0.0;
+        for (int64_t i = 0; i < P; ++i) { c += w[i]; cdf[i] = c; }
+    }
+    (void)normalise;
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(double* __restrict__ v, int64_t P) {
+    const double last = v[P - 1];
+    __syncthreads();
+    // every block reads v[P-1] before anyone rewrites it: the last element is handled by
+    // the thread that owns it, after its own read
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < P - 1; e += (int64_t)gridDim.x * 256) v[e] = v[e] / last;
+}
+
+__global__ void scale_last_kernel(double* __restrict__ v, int64_t P) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) v[P - 1] = v[P - 1] / v[P - 1];
+}
+
+__global__ __launch_bounds__(256) void searchsorted_kernel(const double* __restrict__ cdf, int64_t P,
+                                                           const double* __restrict__ uniforms, double offset,
+                                                           int64_t n_out, int systematic, int64_t* __restrict__ idx) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * 256) {
+        double v;
+        if (systematic) v = (offset + (double)i) / (double)n_out;          // tools.py:175
+        else v = uniforms[i];
+        int64_t lo = 0, hi = P;
+        if (systematic) {
+            // first j with cdf[j] >= v   ("while positions[i] > cumulative_sum: j += 1")
+            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (cdf[mid] < v) lo = mid + 1; else hi = mid; }
+        } else {
+            // searchsorted(side='right'): first j with cdf[j] > v
+            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (cdf[mid] <= v) lo = mid + 1; else hi = mid; }
+        }
+        idx[i] = lo < P ? lo : P - 1;
+    }
+}
+
+// ===========================================================================
+// host side
+// ===========================================================================
+static inline unsigned grid_for(int64_t n, int per_block, int cap = 2048) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+extern "C" int pmc_propose(int kind, const float* cur32, const double* cur64, const double* mu,
+                           const double* inv_cov, const double* chol, double nu, double sigma, double cn_a,
+                           const pmc_rng_t* rng, double* prop64, float* prop32, double* quad,
+                           double* quad_prop, int64_t n, int32_t D, void* stream) {
+    if (n == 0) return 0;
+    if ((!cur32) == (!cur64)) return pmc_fail("pmc_propose: exactly one of cur32 / cur64 must be given");
+    if (!chol || !rng || n < 0 || D < 1) return pmc_fail("pmc_propose: bad argument");
+    if (kind == PMC_KIND_TPCN && (!mu || !inv_cov)) return pmc_fail("pmc_propose: tpCN needs mu and inv_cov");
+    if (kind != PMC_KIND_TPCN && kind != PMC_KIND_RWM) return pmc_fail("pmc_propose: unknown kind");
+    if (!prop64 && !prop32) return pmc_fail("pmc_propose: no output");
+    const size_t lds = (size_t)2 * D * (PROP_ROWS + 1) * sizeof(double);
+    if (lds > 160 * 1024) return pmc_fail("pmc_propose: n_dim too large for the LDS-staged proposal");
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(propose_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(propose_kernel)");
+    }
+    hipLaunchKernelGGL(propose_kernel, dim3((unsigned)((n + PROP_ROWS - 1) / PROP_ROWS)), dim3(PROP_ROWS), lds,
+                       (hipStream_t)stream, kind, cur32, cur64, mu, inv_cov, chol, nu, sigma, cn_a, *rng,
+                       prop64, prop32, quad, quad_prop, n, (int)D);
+    return pmc_check_launch("propose_kernel");
+}
+
+static int check_scaler(const pmc_scaler_t* s) {
+    if (!s || !s->low || !s->high || !s->kind || s->D < 1) return pmc_fail("pmc_scaler: bad descriptor");
+    if (s->scale && (!s->mu || !s->sigma)) return pmc_fail("pmc_scaler: scale=1 needs mu and sigma");
+    if (!s->log_width) return pmc_fail("pmc_scaler: log_width missing");
+    return 0;
+}
+
+extern "C" int pmc_scaler_inverse(const pmc_scaler_t* s, const float* u_in, const double* u_in64, double* u_out,
+                                  double* x, double* logdetj, int32_t* finite, int64_t n, void* stream) {
+    if (int e = check_scaler(s)) return e;
+    if (n == 0) return 0;
+    if ((!u_in) == (!u_in64)) return pmc_fail("pmc_scaler_inverse: exactly one of u_in / u_in64 must be given");
+    if (!u_out || !x || !logdetj || !finite || n < 0) return pmc_fail("pmc_scaler_inverse: bad argument");
+    const size_t lds = (size_t)SCL_ROWS * s->D * sizeof(double) + SCL_ROWS * sizeof(int);
+    if (lds > 160 * 1024 || s->D > 1024) return pmc_fail("pmc_scaler_inverse: n_dim too large");
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scaler_inverse_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(scaler_inverse_kernel)");
+    }
+    hipLaunchKernelGGL(scaler_inverse_kernel, dim3((unsigned)((n + SCL_ROWS - 1) / SCL_ROWS)), dim3(256), lds,
+                       (hipStream_t)stream, *s, u_in, u_in64, u_out, x, logdetj, finite, n);
+    return pmc_check_launch("scaler_inverse_kernel");
+}
+
+extern "C" int pmc_scaler_forward(const pmc_scaler_t* s, const double* x, double* u, int64_t n, void* stream) {
+    if (int e = check_scaler(s)) return e;
+    if (n == 0) return 0;
+    if (!x || !u || n < 0) return pmc_fail("pmc_scaler_forward: bad argument");
+    hipLaunchKernelGGL(scaler_forward_kernel, dim3(grid_for(n * s->D, 256)), dim3(256), 0, (hipStream_t)stream,
+                       *s, x, u, n);
+    return pmc_check_launch("scaler_forward_kernel");
+}
+
+extern "C" int64_t pmc_accept_workspace_bytes(int64_t n, int32_t D) {
+    const int64_t nb = (n + ACC_ROWS - 1) / ACC_ROWS;
+    return (nb > 0 ? nb : 1) * (int64_t)(D + 4) * (int64_t)sizeof(double);
+}
+
+extern "C" int pmc_accept(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposal_t* prop, double beta,
+                          double nu, const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums,
+                          void* workspace, int64_t n, int32_t D, void* stream) {
+    if (!cur || !prop || !rng || !sums || !workspace || n < 0 || D < 1) return pmc_fail("pmc_accept: bad argument");
+    if (!cur->u || !cur->x || !cur->logdetj || !cur->logl || !cur->logp || !prop->u || !prop->x ||
+        !prop->logdetj || !prop->logl || !prop->logp)
+        return pmc_fail("pmc_accept: null state array");
+    if (preconditioned && (!cur->theta32 || !cur->logdetj_flow || !prop->theta64 || !prop->logdetj_flow))
+        return pmc_fail("pmc_accept: preconditioned kernels need theta and logdetj_flow");
+    const int tpcn = (kind == PMC_KIND_TPCN);
+    if (tpcn && (!prop->quad || !prop->quad_prop)) return pmc_fail("pmc_accept: tpCN needs the quadratic forms");
+    if (D > 32 * 8 * 4096) return pmc_fail("pmc_accept: n_dim too large");
+    const int nb = (int)((n + ACC_ROWS - 1) / ACC_ROWS);
+    if (nb > 0)
+        hipLaunchKernelGGL(accept_kernel, dim3(nb), dim3(ACC_ROWS), 0, (hipStream_t)stream, preconditioned, tpcn,
+                           *cur, *prop, beta, nu, *rng, alpha_out, accept_out, (double*)workspace, n, (int)D);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)workspace, sums, nb, (int)D + 4);
+    return pmc_check_launch("accept_kernel");
+}
+
+extern "C" int pmc_logw(const double* logl, const double* beta, const double* logz, double beta_final,
+                        double* logw, int32_t T, int64_t N, void* stream) {
+    if (!logl || !beta || !logz || !logw || T < 1 || N < 0) return pmc_fail("pmc_logw: bad argument");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(logw_kernel, dim3(grid_for((int64_t)T * N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       logl, beta, logz, beta_final, logw, (int)T, N);
+    return pmc_check_launch("logw_kernel");
+}
+
+#define RED_BLOCKS 256
+extern "C" int64_t pmc_reduce_workspace_bytes(int64_t P) {
+    (void)P;
+    return (int64_t)(2 * RED_BLOCKS + 8) * (int64_t)sizeof(double);
+}
+
+extern "C" int pmc_logw_stats(const double* logw, int64_t P, int64_t k, double* stats, void* workspace,
+                              void* stream) {
+    if (!logw || !stats || !workspace || P < 1) return pmc_fail("pmc_logw_stats: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    double* ws = (double*)workspace;
+    const int nb = (int)grid_for(P, 256, RED_BLOCKS);
+    hipLaunchKernelGGL(max_partial_kernel, dim3(nb), dim3(256), 0, st, logw, P, ws);
+    hipLaunchKernelGGL(max_final_kernel, dim3(1), dim3(256), 0, st, ws, nb);
+    hipMemcpyAsync(stats, ws + nb, sizeof(double), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(wsum_partial_kernel, dim3(nb), dim3(256), 0, st, logw, P, (const double*)stats,
+                       (const double*)nullptr, (int64_t)0, 0, ws);
+    hipLaunchKernelGGL(wsum_final_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nb, stats, 1, 2);
+    if (k > 0) {
+        hipLaunchKernelGGL(wsum_partial_kernel, dim3(nb), dim3(256), 0, st, logw, P, (const double*)stats,
+                           (const double*)(stats + 1), k, 1, ws);
+        hipLaunchKernelGGL(wsum_final_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nb, stats, 3, -1);
+    }
+    return pmc_check_launch("pmc_logw_stats");
+}
+
+extern "C" int pmc_gather(const int64_t* idx, int64_t n_out, int32_t D, const double* u, const double* x,
+                          const double* logdetj, const double* logl, const double* logp, double* u_out,
+                          double* x_out, double* logdetj_out, double* logl_out, double* logp_out, void* stream) {
+    if (!idx || n_out < 0 || D < 1) return pmc_fail("pmc_gather: bad argument");
+    if (n_out == 0) return 0;
+    hipLaunchKernelGGL(gather_kernel, dim3(grid_for(n_out * D, 256)), dim3(256), 0, (hipStream_t)stream, idx,
+                       n_out, (int)D, u, x, logdetj, logl, logp, u_out, x_out, logdetj_out, logl_out, logp_out);
+    return pmc_check_launch("gather_kernel");
+}
+
+extern "C" int pmc_resample_multinomial(const double* w, int64_t P, const double* uniforms, int64_t n_out,
+                                        double* cdf, int64_t* idx, void* stream) {
+    if (!w || !uniforms || !cdf || !idx || P < 1 || n_out < 0) return pmc_fail("pmc_resample_multinomial: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(serial_cumsum_kernel, dim3(1), dim3(64), 0, st, w, P, cdf, 1);
+    // cdf /= cdf[-1]  (numpy's legacy choice): all but the last element first, then the last
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(P, 256, 256)), dim3(256), 0, st, cdf, P);
+    hipLaunchKernelGGL(scale_last_kernel, dim3(1), dim3(64), 0, st, cdf, P);
+    if (n_out > 0)
+        hipLaunchKernelGGL(searchsorted_kernel, dim3(grid_for(n_out, 256)), dim3(256), 0, st, (const double*)cdf, P,
+                           uniforms, 0.0, n_out, 0, idx);
+    return pmc_check_launch("pmc_resample_multinomial");
+}
+
+extern "C" int pmc_resample_systematic(const double* w, int64_t P, double offset, int64_t n_out, double* cdf,
+                                       int64_t* idx, void* stream) {
+    if (!w || !cdf || !idx || P < 1 || n_out < 0) return pmc_fail("pmc_resample_systematic: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(serial_cumsum_kernel, dim3(1), dim3(64), 0, st, w, P, cdf, 0);
+    if (n_out > 0)
+        hipLaunchKernelGGL(searchsorted_kernel, dim3(grid_for(n_out, 256)), dim3(256), 0, st, (const double*)cdf, P,
+                           (const double*)nullptr, offset, n_out, 1, idx);
+    return pmc_check_launch("pmc_resample_systematic");
+}

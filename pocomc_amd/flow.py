@@ -1,0 +1,156 @@
+"""``Flow`` -- host-side mirror of ``pocomc.flow.Flow`` (``pocomc/flow.py:12-384``)
+whose arithmetic runs in the gfx950 kernels behind ``include/pocomc_amd.h``.
+
+Same constructor and methods as the reference class: ``Flow(n_dim, flow='maf3')``,
+``forward / inverse / log_prob / sample / fit``.  Tensors may live on the CPU or
+on the GPU; results come back on the input's device with dtype float32, float64
+input is cast with the reference's warning (``pocomc/tools.py:295-316``).
+
+The predefined MAFs of the reference are supported (``maf3 | maf6 | maf12``,
+``pocomc/flow.py:54-68``); a ``MAFSpec`` gives a custom depth/width (the
+reference takes a ``zuko.flows.Flow`` object there, ``flow.py:87-88``).  The
+spline flows ``nsf*`` are the next row of the scope table.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib
+from .maf_spec import MAFSpec, SPEC_BY_NAME
+
+
+def torch_double_to_float(x: torch.Tensor, warn: bool = True) -> torch.Tensor:
+    """``pocomc/tools.py:295-316``."""
+    if x.dtype == torch.float64 and warn:
+        warnings.warn("Float64 data is currently unsupported, casting to Float32. "
+                      "Output will also have type Float32.")
+        return x.float()
+    elif x.dtype == torch.float32:
+        return x
+    raise ValueError(f"Unsupported datatype for input data: {x.dtype}")
+
+
+class Flow:
+    """Masked autoregressive flow resident on one MI355X."""
+
+    def __init__(self, n_dim, flow="maf3", device=None, seed=None):
+        self.n_dim = int(n_dim)
+        if isinstance(flow, MAFSpec):
+            spec = flow
+            if spec.n_dim != self.n_dim:
+                raise ValueError("MAFSpec.n_dim does not match n_dim")
+        elif flow in SPEC_BY_NAME:
+            spec = MAFSpec(self.n_dim, SPEC_BY_NAME[flow])
+        elif flow in ("nsf3", "nsf6", "nsf12"):
+            raise NotImplementedError(
+                f"{flow}: the rational-quadratic spline flows are not built yet "
+                "(SURVEY.md section 8(f) row 2); use maf3 | maf6 | maf12")
+        else:
+            raise ValueError("Invalid flow type. Choose from: maf3, maf6, maf12, nsf3, nsf6, nsf12, "
+                             "or provide a MAFSpec object.")
+        self.spec = spec
+        self.lib = _lib.load()
+        self.device = torch.device(device) if device is not None else _lib.require_gpu()
+        if self.device.type != "cuda":
+            raise _lib.PocomcAmdError("Flow lives on the GPU; there is no CPU fallback")
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())   # follows torch.manual_seed like zuko's init
+        self.params = torch.from_numpy(spec.init_params(seed)).to(self.device)
+        self._pack_idx = torch.from_numpy(spec.pack_index()).to(self.device)
+        self._meta = torch.from_numpy(spec.device_meta()).to(self.device)
+        self._packed = torch.zeros(spec.pk_size, dtype=torch.float32, device=self.device)
+        self._desc = _lib.pmc_maf_t(
+            packed=self._packed.data_ptr(), meta=self._meta.data_ptr(),
+            D=spec.n_dim, H=spec.hidden, T=spec.n_transforms, Hp=spec.Hp, Dp=spec.Dp,
+            nT=spec.nT, nXT=spec.nXT, nOT=spec.nOT, pk_per_transform=spec.pk_per_transform,
+            tri_ok=int(spec.tri_ok), reserved=0)
+        self.inverse_algo = 0          # PMC_INVERSE_AUTO
+        self.repack()
+
+    # ------------------------------------------------------------ parameters
+    def repack(self):
+        """Refresh the kernel-layout image after ``params`` changed."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pmc_maf_pack(_lib.ptr(self.params), _lib.ptr(self._pack_idx),
+                                             _lib.ptr(self._packed), self._packed.numel(),
+                                             _lib.stream_handle()), "pmc_maf_pack")
+
+    def set_params(self, flat):
+        flat = torch.as_tensor(flat, dtype=torch.float32).reshape(-1)
+        if flat.numel() != self.spec.n_params:
+            raise ValueError("parameter vector has the wrong length")
+        self.params.copy_(flat.to(self.device))
+        self.repack()
+
+    def state_dict(self):
+        return {"params": self.params.detach().cpu().clone(), "n_dim": self.spec.n_dim,
+                "n_transforms": self.spec.n_transforms, "hidden": self.spec.hidden}
+
+    def load_state_dict(self, sd):
+        self.set_params(sd["params"])
+
+    # -------------------------------------------------------------- plumbing
+    def _in(self, x):
+        x = torch_double_to_float(x)
+        if x.dim() != 2 or x.shape[1] != self.n_dim:
+            raise ValueError(f"expected a (n, {self.n_dim}) tensor, got {tuple(x.shape)}")
+        return x.to(self.device).contiguous(), x.device
+
+    # -------------------------------------------------------------- contract
+    @torch.no_grad()
+    def forward(self, x):
+        """``pocomc/flow.py:99-114``: data -> latent, returns ``(u, ladj)``."""
+        xd, src = self._in(x)
+        n = xd.shape[0]
+        z = torch.empty_like(xd)
+        ladj = torch.empty(n, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pmc_maf_forward(C.byref(self._desc), _lib.ptr(xd), _lib.ptr(z), _lib.ptr(ladj),
+                                                None, n, _lib.stream_handle()), "pmc_maf_forward")
+        return z.to(src), ladj.to(src)
+
+    __call__ = forward
+
+    @torch.no_grad()
+    def inverse(self, u):
+        """``pocomc/flow.py:116-132``: latent -> data, returns ``(x, ladj)``."""
+        ud, src = self._in(u)
+        n = ud.shape[0]
+        x = torch.empty_like(ud)
+        ladj = torch.empty(n, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pmc_maf_inverse(C.byref(self._desc), _lib.ptr(ud), _lib.ptr(x), _lib.ptr(ladj),
+                                                n, self.inverse_algo, _lib.stream_handle()), "pmc_maf_inverse")
+        return x.to(src), ladj.to(src)
+
+    @torch.no_grad()
+    def log_prob(self, x):
+        """``pocomc/flow.py:134-147``."""
+        xd, src = self._in(x)
+        n = xd.shape[0]
+        z = torch.empty_like(xd)
+        lp = torch.empty(n, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pmc_maf_forward(C.byref(self._desc), _lib.ptr(xd), _lib.ptr(z), None,
+                                                _lib.ptr(lp), n, _lib.stream_handle()), "pmc_maf_forward")
+        return lp.to(src)
+
+    @torch.no_grad()
+    def sample(self, size: int = 1, z=None):
+        """``pocomc/flow.py:149-163``: ``(samples, log_prob)``.  ``z`` replays the
+        base draw (tests)."""
+        if z is None:
+            z = torch.randn(int(size), self.n_dim, dtype=torch.float32, device=self.device)
+        zd, src = self._in(z)
+        x, ladj_inv = self.inverse(zd)
+        base = -0.5 * (zd * zd).sum(dim=1) - 0.5 * self.n_dim * float(np.log(2 * np.pi))
+        return x.to(src), (base - ladj_inv).to(src)
+
+    def fit(self, x, weights=None, **kwargs):
+        """``pocomc/flow.py:165-384``."""
+        from .train import fit_flow
+        return fit_flow(self, x, weights=weights, **kwargs)

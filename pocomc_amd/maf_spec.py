@@ -155,12 +155,26 @@ class MAFSpec:
         D, H = self.n_dim, self.hidden
         deg = self.degree
         slots = []          # canonical unit index per slot, -1 = padding
-        sdeg = []           # degree per slot
+        sdeg = []           # degree per slot (D = padding, never reached)
+        tri_ok = True
         for g in range(1, D):
             units = np.nonzero(deg == g)[0]
-            pad = _ceil_to(len(units), 4) - len(units)
+            nq = _ceil_to(len(units), 4) // 4
+            if nq <= 4:
+                # a degree group never straddles a tile boundary: its units all
+                # read each other's previous-layer values, so the sweep of the
+                # triangular inverse finishes a group inside one tile
+                in_tile = (len(slots) // 4) % 4
+                if in_tile + nq > 4:
+                    fill = (4 - in_tile) * 4
+                    slots += [-1] * fill
+                    sdeg += [D] * fill
+            else:
+                tri_ok = False
+            pad = nq * 4 - len(units)
             slots += list(units) + [-1] * pad
             sdeg += [g] * (len(units) + pad)
+        self.tri_ok = tri_ok
         Hp = _ceil_to(len(slots), 16)
         slots += [-1] * (Hp - len(slots))
         sdeg += [D] * (Hp - len(sdeg))          # trailing pad: never reached
@@ -292,14 +306,16 @@ class MAFSpec:
         """int32 metadata consumed by the kernels.
 
         ``[0:8]``  header: D, H, T, Hp, Dp, nT, pk_per_transform, reserved
-        ``[8:8+T*D]``      feature index of every rank, per transform
-        ``[8+T*D: +nQ]``   quad meta words (degree | last<<16), shared by all transforms
+        ``[8:8+T*D]``        feature index of every rank, per transform
+        ``[8+T*D:8+2*T*D]``  rank of every feature, per transform
+        ``[8+2*T*D: +nQ]``   quad meta words (degree | last<<16), shared by all transforms
         """
         D, T = self.n_dim, self.n_transforms
         hdr = np.array([D, self.hidden, T, self.Hp, self.Dp, self.nT,
                         self.pk_per_transform, 0], dtype=np.int32)
         f_o_r = np.concatenate([np.argsort(o) for o in self.orders]).astype(np.int32)
-        return np.concatenate([hdr, f_o_r, self.quad_meta]).astype(np.int32)
+        r_o_f = np.concatenate(self.orders).astype(np.int32)
+        return np.concatenate([hdr, f_o_r, r_o_f, self.quad_meta]).astype(np.int32)
 
     # ------------------------------------------------------------ accounting
     def flops_forward_dense(self) -> int:

@@ -1,0 +1,377 @@
+"""MCMC kernels -- host-side mirror of ``pocomc/mcmc.py`` behind the same contract
+
+    results = kernel(state_dict, function_dict, option_dict)
+
+(``pocomc/sampler.py:568-631``).  The particle state lives in HBM for the whole
+call; per step the device runs  propose -> flow inverse -> scaler inverse  and
+accept -> reductions  (``include/pocomc_amd.h``), the host only evaluates the
+user's prior / likelihood black boxes on the compacted finite rows
+(``mcmc.py:100-121``) and the scalar adaptation / stopping logic
+(``mcmc.py:152-180``).
+
+``StepEngine`` is the reusable object (bench.py drives it directly); the four
+functions ``preconditioned_pcn | preconditioned_rwm | pcn | rwm`` wrap it with
+the reference's signature.
+
+Multi-GPU: the walkers are row-sharded, one process per GPU.  The only
+exchange per step is the all-reduce of ``D+4`` float64 sums (RCCL over xGMI via
+``torch.distributed``) that makes sigma, mu and the stop decision identical on
+every rank.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+KINDS = ("preconditioned_pcn", "preconditioned_rwm", "pcn", "rwm")
+PMC_KIND_TPCN, PMC_KIND_RWM = 0, 1
+
+
+# --------------------------------------------------------------------------
+# host-side scalar logic, shared with the CPU tests of the sharded path
+# --------------------------------------------------------------------------
+class Adaptation:
+    """sigma / mu adaptation and the plateau stop of one kernel call
+    (``mcmc.py:152-180`` and the variants ``:314-336``, ``:476-502``, ``:627-650``).
+
+    Fed with GLOBAL sums (already all-reduced), so every rank takes the same
+    decisions."""
+
+    def __init__(self, kind, n_dim, n_total, n_steps, n_max, sigma0, mu0, logp2_0):
+        self.kind = kind
+        self.tpcn = kind in ("preconditioned_pcn", "pcn")
+        self.D = n_dim
+        self.N = n_total
+        self.n_steps = n_steps
+        self.n_max = n_max
+        self.sigma = np.minimum(sigma0, 0.99) if self.tpcn else sigma0        # mcmc.py:54
+        self.mu = None if mu0 is None else np.array(mu0, dtype=np.float64)
+        self.logp2_val = logp2_0
+        self.cnt = 0
+        self.i = 0
+        self.mean_alpha = 0.0
+
+    def update(self, sums):
+        """``sums`` = [sum alpha, sum(logl+logp), sum(logl+logp+logdetj), n_accept, sum theta_j...].
+        Returns True when the loop must stop."""
+        self.i += 1
+        i, D, N = self.i, self.D, self.N
+        mean_alpha = sums[0] / N
+        self.mean_alpha = mean_alpha
+        cap = np.minimum(2.38 / D ** 0.5, 0.99)
+        if self.tpcn:
+            self.sigma = np.abs(np.minimum(self.sigma + 1 / (i + 1) ** 0.75 * (mean_alpha - 0.234), cap))
+        elif self.kind == "preconditioned_rwm":
+            self.sigma = self.sigma + 1 / (i + 1) * (mean_alpha - 0.234)
+        else:
+            self.sigma = np.abs(self.sigma + 1 / (i + 1) * (mean_alpha - 0.234))
+        if self.kind == "preconditioned_pcn":
+            # np.mean of the float32 theta array is a float32 (mcmc.py:156)
+            mean_theta = (np.asarray(sums[4:4 + D]) / N).astype(np.float32)
+            self.mu = self.mu + 1.0 / (i + 1.0) * (mean_theta - self.mu)
+        new = (sums[1] if self.tpcn else sums[2]) / N
+        if new > self.logp2_val:
+            self.cnt = 0
+            self.logp2_val = new
+        else:
+            self.cnt += 1
+            ratio = (2.38 / D ** 0.5) / self.sigma
+            if self.kind == "preconditioned_rwm":
+                ratio = np.minimum(1.0, ratio)
+            if self.cnt >= self.n_steps * ratio ** 2.0:
+                return True
+        return i >= self.n_max
+
+
+def allreduce_sums(sums_dev, group=None):
+    """Sum the per-shard reductions over all ranks (no-op without a process group)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(sums_dev, op=dist.ReduceOp.SUM, group=group)
+    return sums_dev
+
+
+# --------------------------------------------------------------------------
+class StepEngine:
+    """Device-resident state + buffers of one MCMC kernel call."""
+
+    def __init__(self, kind, n, n_dim, flow, scaler, device=None, group=None, shard_offset=0, seed=0):
+        assert kind in KINDS
+        self.kind = kind
+        self.pre = kind.startswith("preconditioned")
+        self.tpcn = kind in ("preconditioned_pcn", "pcn")
+        self.n, self.D = int(n), int(n_dim)
+        self.lib = _lib.load()
+        self.device = torch.device(device) if device is not None else _lib.require_gpu()
+        self.flow = flow
+        self.scaler = scaler
+        self.group = group
+        self.seed = int(seed) & (2 ** 64 - 1)
+        self.offset = int(shard_offset)
+        n, D, dev = self.n, self.D, self.device
+        f64 = lambda *s: torch.empty(*s, dtype=torch.float64, device=dev)
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        # current state
+        self.theta32 = f32(n, D) if self.pre else None
+        self.u, self.x = f64(n, D), f64(n, D)
+        self.logdetj, self.logl, self.logp = f64(n), f64(n), f64(n)
+        self.ldjf = f32(n) if self.pre else None
+        # proposal
+        self.p_theta64 = f64(n, D)
+        self.p_theta32 = f32(n, D) if self.pre else None
+        self.p_u32 = f32(n, D) if self.pre else None
+        self.p_ldjf = f32(n) if self.pre else None
+        self.p_u, self.p_x = f64(n, D), f64(n, D)
+        self.p_logdetj, self.p_logl, self.p_logp = f64(n), f64(n), f64(n)
+        self.p_fin = torch.empty(n, dtype=torch.int32, device=dev)
+        self.quad, self.p_quad = (f64(n), f64(n)) if self.tpcn else (None, None)
+        self.alpha = f64(n)
+        self.accept = torch.empty(n, dtype=torch.int32, device=dev)
+        self.sums = f64(D + 4)
+        self.ws = torch.empty(max(int(self.lib.pmc_accept_workspace_bytes(n, D)), 8), dtype=torch.uint8, device=dev)
+        # geometry
+        self.mu_d, self.inv_cov_d, self.chol_d = f64(D), f64(D, D), f64(D, D)
+        # replay variates
+        self.r_gamma, self.r_normal, self.r_uniform = f64(n), f64(n, D), f64(n)
+        # pinned host mirrors
+        pin = lambda *s, dt=torch.float64: torch.empty(*s, dtype=dt).pin_memory()
+        self.h_x, self.h_fin = pin(n, D), pin(n, dt=torch.int32)
+        self.h_logl, self.h_logp = pin(n), pin(n)
+        self.h_sums = pin(D + 4)
+        self.h_accept = pin(n, dt=torch.int32)
+        self.scaler_desc = scaler.device_descriptor()
+        self._state = _lib.pmc_state_t(
+            theta32=self.theta32.data_ptr() if self.pre else None, u=self.u.data_ptr(), x=self.x.data_ptr(),
+            logdetj=self.logdetj.data_ptr(), logl=self.logl.data_ptr(), logp=self.logp.data_ptr(),
+            logdetj_flow=self.ldjf.data_ptr() if self.pre else None)
+        self._prop = _lib.pmc_proposal_t(
+            theta64=self.p_theta64.data_ptr() if self.pre else None, u=self.p_u.data_ptr(), x=self.p_x.data_ptr(),
+            logdetj=self.p_logdetj.data_ptr(), logl=self.p_logl.data_ptr(), logp=self.p_logp.data_ptr(),
+            logdetj_flow=self.p_ldjf.data_ptr() if self.pre else None,
+            quad=self.quad.data_ptr() if self.tpcn else None, quad_prop=self.p_quad.data_ptr() if self.tpcn else None)
+        self.step_idx = 0
+
+    # ---------------------------------------------------------------- setup
+    def load_state(self, u, x, logdetj, logl, logp):
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+        self.u.copy_(up(u)); self.x.copy_(up(x))
+        self.logdetj.copy_(up(logdetj)); self.logl.copy_(up(logl)); self.logp.copy_(up(logp))
+        if self.pre:
+            # theta, logdetj_flow = flow.forward(u)  through tools.py:336-340 (float32, sign flipped)
+            u32 = self.u.to(torch.float32)
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.pmc_maf_forward(C.byref(self.flow._desc), _lib.ptr(u32), _lib.ptr(self.theta32),
+                                                    _lib.ptr(self.ldjf), None, self.n, _lib.stream_handle()),
+                           "pmc_maf_forward")
+            self.ldjf.neg_()
+
+    def set_geometry(self, mu=None, cov=None):
+        """tpCN: ``t_mean, t_cov`` (``mcmc.py:63-68``); RWM: ``normal_cov`` (``:237-238``)."""
+        cov = np.asarray(cov, dtype=np.float64)
+        chol = np.linalg.cholesky(cov)
+        self.chol_d.copy_(torch.from_numpy(np.ascontiguousarray(chol)))
+        if self.tpcn:
+            self.inv_cov_d.copy_(torch.from_numpy(np.ascontiguousarray(np.linalg.inv(cov))))
+            self.set_mu(mu)
+
+    def set_mu(self, mu):
+        self.mu_d.copy_(torch.from_numpy(np.ascontiguousarray(mu, dtype=np.float64)))
+
+    # ----------------------------------------------------------------- step
+    def _rng(self, replay):
+        if replay is not None:
+            if self.tpcn:
+                self.r_gamma.copy_(torch.from_numpy(np.ascontiguousarray(replay["gamma"], dtype=np.float64)))
+            self.r_normal.copy_(torch.from_numpy(np.ascontiguousarray(replay["z"], dtype=np.float64)))
+            self.r_uniform.copy_(torch.from_numpy(np.ascontiguousarray(replay["u"], dtype=np.float64)))
+            return _lib.pmc_rng_t(gamma=self.r_gamma.data_ptr() if self.tpcn else None,
+                                  normal=self.r_normal.data_ptr(), uniform=self.r_uniform.data_ptr(),
+                                  seed=0, step=self.step_idx, offset=self.offset)
+        return _lib.pmc_rng_t(gamma=None, normal=None, uniform=None, seed=self.seed, step=self.step_idx,
+                              offset=self.offset)
+
+    def propose(self, sigma, nu=0.0, replay=None):
+        """propose -> flow inverse -> scaler inverse, then start the D2H of x'."""
+        lib, n, D = self.lib, self.n, self.D
+        self._rng_cur = self._rng(replay)
+        st = _lib.stream_handle()
+        kind = PMC_KIND_TPCN if self.tpcn else PMC_KIND_RWM
+        cn_a = float((1.0 - sigma ** 2.0) ** 0.5) if self.tpcn else 0.0            # mcmc.py:85
+        with torch.cuda.device(self.device):
+            _lib.check(lib.pmc_propose(
+                kind, _lib.ptr(self.theta32) if self.pre else None, None if self.pre else _lib.ptr(self.u),
+                _lib.ptr(self.mu_d), _lib.ptr(self.inv_cov_d), _lib.ptr(self.chol_d), float(nu), float(sigma), cn_a,
+                C.byref(self._rng_cur), _lib.ptr(self.p_theta64), _lib.ptr(self.p_theta32) if self.pre else None,
+                _lib.ptr(self.quad) if self.tpcn else None, _lib.ptr(self.p_quad) if self.tpcn else None,
+                n, D, st), "pmc_propose")
+            if self.pre:
+                _lib.check(lib.pmc_maf_inverse(C.byref(self.flow._desc), _lib.ptr(self.p_theta32), _lib.ptr(self.p_u32),
+                                               _lib.ptr(self.p_ldjf), n, self.flow.inverse_algo, st), "pmc_maf_inverse")
+                _lib.check(lib.pmc_scaler_inverse(C.byref(self.scaler_desc), _lib.ptr(self.p_u32), None,
+                                                  _lib.ptr(self.p_u), _lib.ptr(self.p_x), _lib.ptr(self.p_logdetj),
+                                                  _lib.ptr(self.p_fin), n, st), "pmc_scaler_inverse")
+            else:
+                _lib.check(lib.pmc_scaler_inverse(C.byref(self.scaler_desc), None, _lib.ptr(self.p_theta64),
+                                                  _lib.ptr(self.p_u), _lib.ptr(self.p_x), _lib.ptr(self.p_logdetj),
+                                                  _lib.ptr(self.p_fin), n, st), "pmc_scaler_inverse")
+        self.h_x.copy_(self.p_x, non_blocking=True)
+        self.h_fin.copy_(self.p_fin, non_blocking=True)
+
+    def evaluate(self, log_prior, log_like, have_blobs=False, blobs=None):
+        """Host black boxes on the compacted rows, ``mcmc.py:100-121``.  Returns
+        ``(n_calls, blobs_prime)``."""
+        torch.cuda.current_stream().synchronize()
+        n = self.n
+        x_prime = self.h_x.numpy()
+        finite = self.h_fin.numpy().astype(bool)
+        logp_prime = self.h_logp.numpy()
+        logl_prime = self.h_logl.numpy()
+        logp_prime[finite] = log_prior(x_prime[finite])
+        logp_prime[~finite] = -np.inf
+        finite = finite & np.isfinite(logp_prime)
+        blobs_prime = None
+        if have_blobs:
+            blobs_prime = np.empty(n, dtype=np.dtype((blobs[0].dtype, blobs[0].shape)))
+            logl_prime[finite], blobs_prime[finite] = log_like(x_prime[finite])
+        else:
+            logl_prime[finite], _ = log_like(x_prime[finite])
+        logl_prime[~finite] = -np.inf
+        self.p_logl.copy_(self.h_logl, non_blocking=True)
+        self.p_logp.copy_(self.h_logp, non_blocking=True)
+        return int(np.sum(finite)), blobs_prime
+
+    def accept_reduce(self, beta, nu=0.0, want_mask=False):
+        """Metropolis accept + global sums; returns the (all-reduced) host copy."""
+        kind = PMC_KIND_TPCN if self.tpcn else PMC_KIND_RWM
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pmc_accept(kind, int(self.pre), C.byref(self._state), C.byref(self._prop), float(beta),
+                                           float(nu), C.byref(self._rng_cur), _lib.ptr(self.alpha), _lib.ptr(self.accept),
+                                           _lib.ptr(self.sums), _lib.ptr(self.ws), self.n, self.D,
+                                           _lib.stream_handle()), "pmc_accept")
+        allreduce_sums(self.sums, self.group)
+        self.h_sums.copy_(self.sums, non_blocking=True)
+        if want_mask:
+            self.h_accept.copy_(self.accept, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        self.step_idx += 1
+        return self.h_sums.numpy()
+
+    def download(self):
+        g = lambda t: t.cpu().numpy()
+        return dict(u=g(self.u), x=g(self.x), logdetj=g(self.logdetj), logl=g(self.logl), logp=g(self.logp))
+
+
+# --------------------------------------------------------------------------
+def _global_count(n, group):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        return n * dist.get_world_size(group)        # equal shards by construction
+    return n
+
+
+def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
+    pre = kind.startswith("preconditioned")
+    tpcn = kind in ("preconditioned_pcn", "pcn")
+    u = np.copy(state_dict.get("u"))
+    x = np.copy(state_dict.get("x"))
+    logdetj = np.copy(state_dict.get("logdetj"))
+    logl = np.copy(state_dict.get("logl"))
+    logp = np.copy(state_dict.get("logp"))
+    beta = state_dict.get("beta")
+    blobs = state_dict.get("blobs")
+    have_blobs = blobs is not None
+
+    log_like = function_dict.get("loglike")
+    log_prior = function_dict.get("logprior")
+    scaler = function_dict.get("scaler")
+    flow = function_dict.get("flow") if pre else None
+    geometry = function_dict.get("theta_geometry" if pre else "u_geometry")
+
+    n_max = option_dict.get("n_max")
+    n_steps = option_dict.get("n_steps")
+    progress_bar = option_dict.get("progress_bar")
+    group = option_dict.get("group")
+    seed = option_dict.get("seed")
+    if seed is None:
+        # Philox key; taken from numpy's global stream so that np.random.seed() makes a run
+        # reproducible like the reference (not touched when the variates are replayed)
+        seed = 0 if replay is not None else (int(np.random.randint(0, 2 ** 31 - 1)) * 2 ** 31
+                                             + int(np.random.randint(0, 2 ** 31 - 1)))
+    n_walkers, n_dim = x.shape
+
+    eng = StepEngine(kind, n_walkers, n_dim, flow, scaler, group=group,
+                     shard_offset=option_dict.get("shard_offset", 0), seed=seed)
+    eng.load_state(u, x, logdetj, logl, logp)
+    nu = 0.0
+    if tpcn:
+        nu = float(geometry.t_nu)
+        eng.set_geometry(mu=geometry.t_mean, cov=geometry.t_cov)
+    else:
+        eng.set_geometry(cov=geometry.normal_cov)
+
+    n_total = _global_count(n_walkers, group)
+    # stop metric before the first step (mcmc.py:70 / :243), global over the shards
+    init = torch.tensor([0.0, float(np.sum(logl + logp)), float(np.sum(logl + logp + logdetj))] + [0.0] * (n_dim + 1),
+                        dtype=torch.float64, device=eng.device)
+    allreduce_sums(init, group)
+    init = init.cpu().numpy()
+    ad = Adaptation(kind, n_dim, n_total, n_steps, n_max, option_dict.get("proposal_scale"),
+                    geometry.t_mean if tpcn else None, (init[1] if tpcn else init[2]) / n_total)
+
+    n_calls = 0
+    while True:
+        rp = None
+        if replay is not None:
+            replay.begin_step()
+            rp = dict(gamma=replay.std_gamma((n_dim + nu) / 2, n_walkers) if tpcn else None,
+                      z=replay.normal(n_walkers, n_dim), u=replay.uniform(n_walkers))
+        eng.propose(ad.sigma, nu, rp)
+        calls, blobs_prime = eng.evaluate(log_prior, log_like, have_blobs, blobs)
+        n_calls += calls
+        sums = eng.accept_reduce(beta, nu, want_mask=have_blobs or trace is not None)
+        if have_blobs:
+            mask = eng.h_accept.numpy().astype(bool)
+            blobs[mask] = blobs_prime[mask]
+        stop = ad.update(sums)
+        if kind == "preconditioned_pcn":
+            eng.set_mu(ad.mu)
+        if trace is not None:
+            trace.append(dict(alpha=eng.alpha.cpu().numpy(), accept=eng.h_accept.numpy().astype(bool).copy(),
+                              theta_prime=eng.p_theta64.cpu().numpy(), u_prime=eng.p_u.cpu().numpy(),
+                              x_prime=eng.p_x.cpu().numpy(), logdetj_prime=eng.p_logdetj.cpu().numpy(),
+                              logdetj_flow_prime=eng.p_ldjf.cpu().numpy() if pre else None,
+                              finite=eng.p_fin.cpu().numpy().astype(bool), sigma=float(ad.sigma),
+                              mu=None if ad.mu is None else ad.mu.copy(), **eng.download()))
+        if progress_bar is not None:
+            progress_bar.update_stats(dict(calls=progress_bar.info["calls"] + calls, acc=ad.mean_alpha, steps=ad.i,
+                                           logP=sums[1] / n_total, eff=ad.sigma / (2.38 / np.sqrt(n_dim))))
+        if stop:
+            break
+
+    out = eng.download()
+    return dict(u=out["u"], x=out["x"], logdetj=out["logdetj"], logl=out["logl"], logp=out["logp"], blobs=blobs,
+                efficiency=ad.sigma, accept=ad.mean_alpha, steps=ad.i, calls=n_calls, proposal_scale=ad.sigma)
+
+
+def preconditioned_pcn(state_dict, function_dict, option_dict, replay=None, trace=None):
+    """``pocomc/mcmc.py:8-183``."""
+    return _run("preconditioned_pcn", state_dict, function_dict, option_dict, replay, trace)
+
+
+def preconditioned_rwm(state_dict, function_dict, option_dict, replay=None, trace=None):
+    """``pocomc/mcmc.py:186-341``."""
+    return _run("preconditioned_rwm", state_dict, function_dict, option_dict, replay, trace)
+
+
+def pcn(state_dict, function_dict, option_dict, replay=None, trace=None):
+    """``pocomc/mcmc.py:344-506``."""
+    return _run("pcn", state_dict, function_dict, option_dict, replay, trace)
+
+
+def rwm(state_dict, function_dict, option_dict, replay=None, trace=None):
+    """``pocomc/mcmc.py:508-654``."""
+    return _run("rwm", state_dict, function_dict, option_dict, replay, trace)

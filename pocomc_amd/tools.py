@@ -1,0 +1,133 @@
+"""Particle math around the MCMC step -- host-side mirror of ``pocomc/tools.py`` and
+``pocomc/particles.py:215-231`` whose reductions run on the GPU
+(``pmc_logw``, ``pmc_logw_stats``, ``pmc_resample_*``, ``pmc_gather``)."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+SQRTEPS = math.sqrt(float(np.finfo(np.float64).eps))
+
+
+def _dev():
+    return _lib.require_gpu()
+
+
+def _up(a, dtype=np.float64):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(_dev())
+
+
+def logw_stats(logw_d, k=0):
+    """``[max, sum exp(logw-max), sum exp(2(logw-max)), sum 1-(1-w)^k]`` of a device vector."""
+    lib = _lib.load()
+    P = logw_d.numel()
+    stats = torch.zeros(4, dtype=torch.float64, device=logw_d.device)
+    ws = torch.empty(int(lib.pmc_reduce_workspace_bytes(P)), dtype=torch.uint8, device=logw_d.device)
+    with torch.cuda.device(logw_d.device):
+        _lib.check(lib.pmc_logw_stats(_lib.ptr(logw_d), P, int(k), _lib.ptr(stats), _lib.ptr(ws),
+                                      _lib.stream_handle()), "pmc_logw_stats")
+    return stats.cpu().numpy()
+
+
+def compute_logw_and_logz(logl, beta, logz, beta_final=1.0, normalize=True):
+    """``pocomc/particles.py:215-231`` on plain arrays (``logl`` is ``(T, N)``)."""
+    lib = _lib.load()
+    logl = np.asarray(logl, dtype=np.float64)
+    T, N = logl.shape
+    ld, bd, zd = _up(logl), _up(beta), _up(logz)
+    lw = torch.empty(T * N, dtype=torch.float64, device=ld.device)
+    with torch.cuda.device(ld.device):
+        _lib.check(lib.pmc_logw(_lib.ptr(ld), _lib.ptr(bd), _lib.ptr(zd), float(beta_final), _lib.ptr(lw), T, N,
+                                _lib.stream_handle()), "pmc_logw")
+    st = logw_stats(lw)
+    lse = st[0] + np.log(st[1])
+    logz_new = lse - np.log(T * N)
+    logw = lw.cpu().numpy()
+    if normalize:
+        logw -= lse
+    return logw, logz_new
+
+
+def effective_sample_size(weights):
+    """``pocomc/tools.py:56-71`` (normalises ``weights`` in place like the reference)."""
+    weights /= np.sum(weights)
+    with np.errstate(divide="ignore"):
+        st = logw_stats(_up(np.log(weights)))
+    return (st[1] * st[1]) / st[2]
+
+
+def unique_sample_size(weights, k=None):
+    """``pocomc/tools.py:74-93``."""
+    if k is None:
+        k = len(weights)
+    weights /= np.sum(weights)
+    with np.errstate(divide="ignore"):
+        st = logw_stats(_up(np.log(weights)), k=int(k))
+    return st[3]
+
+
+def compute_ess(logw):
+    """``pocomc/tools.py:96-114``."""
+    st = logw_stats(_up(logw))
+    return (st[1] * st[1]) / st[2] / len(logw)
+
+
+def increment_logz(logw):
+    """``pocomc/tools.py:117-133``."""
+    st = logw_stats(_up(logw))
+    return st[0] + np.log(st[1])
+
+
+def systematic_resample(size, weights, random_state=None, offset=None):
+    """``pocomc/tools.py:136-186``; indices are bit-exact with the reference."""
+    lib = _lib.load()
+    if random_state is not None:
+        np.random.seed(random_state)
+    if abs(np.sum(weights) - 1.) > SQRTEPS:
+        weights = np.array(weights) / np.sum(weights)
+    if offset is None:
+        offset = np.random.random()
+    wd = _up(weights)
+    cdf = torch.empty_like(wd)
+    idx = torch.empty(int(size), dtype=torch.int64, device=wd.device)
+    with torch.cuda.device(wd.device):
+        _lib.check(lib.pmc_resample_systematic(_lib.ptr(wd), wd.numel(), float(offset), int(size), _lib.ptr(cdf),
+                                               _lib.ptr(idx), _lib.stream_handle()), "pmc_resample_systematic")
+    return idx.cpu().numpy()
+
+
+def multinomial_resample(size, weights, uniforms=None):
+    """``np.random.choice(len(w), size, p=w)`` of ``pocomc/sampler.py:703``."""
+    lib = _lib.load()
+    if uniforms is None:
+        uniforms = np.random.random_sample(int(size))
+    wd, ud = _up(weights), _up(uniforms)
+    cdf = torch.empty_like(wd)
+    idx = torch.empty(int(size), dtype=torch.int64, device=wd.device)
+    with torch.cuda.device(wd.device):
+        _lib.check(lib.pmc_resample_multinomial(_lib.ptr(wd), wd.numel(), _lib.ptr(ud), int(size), _lib.ptr(cdf),
+                                                _lib.ptr(idx), _lib.stream_handle()), "pmc_resample_multinomial")
+    return idx.cpu().numpy()
+
+
+def gather(idx, u, x, logdetj, logl, logp):
+    """``pocomc/sampler.py:707-713``: the five row gathers of ``_resample``."""
+    lib = _lib.load()
+    idx_d = _up(idx, np.int64)
+    n_out = idx_d.numel()
+    ud, xd, a, b, c = _up(u), _up(x), _up(logdetj), _up(logl), _up(logp)
+    D = ud.shape[1]
+    uo = torch.empty(n_out, D, dtype=torch.float64, device=ud.device)
+    xo = torch.empty_like(uo)
+    ao, bo, co = (torch.empty(n_out, dtype=torch.float64, device=ud.device) for _ in range(3))
+    with torch.cuda.device(ud.device):
+        _lib.check(lib.pmc_gather(_lib.ptr(idx_d), n_out, D, _lib.ptr(ud), _lib.ptr(xd), _lib.ptr(a), _lib.ptr(b),
+                                  _lib.ptr(c), _lib.ptr(uo), _lib.ptr(xo), _lib.ptr(ao), _lib.ptr(bo), _lib.ptr(co),
+                                  _lib.stream_handle()), "pmc_gather")
+    g = lambda t: t.cpu().numpy()
+    return g(uo), g(xo), g(ao), g(bo), g(co)

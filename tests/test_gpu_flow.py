@@ -1,0 +1,138 @@
+"""Parity of the HIP flow kernels (through the C ABI) against the oracle, plus the
+reference's own property tests (``tests/test_flow.py``) on the product ``Flow``.
+
+Tolerance: the north star asks for 1e-5 relative in fp32; the oracle computes the same
+fp32 arithmetic in a different summation order, so values are compared with
+``rtol=1e-5`` and an ``atol`` of 1e-5 times the array's scale."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle.maf import OracleMAF
+from pocomc_amd.maf_spec import MAFSpec
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(2, 3), (3, 3), (4, 3), (5, 3), (7, 6), (10, 3), (17, 2), (32, 3), (50, 6)]
+
+
+def close(a, b, tol=1e-5):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = max(1.0, float(np.abs(b).max()) if b.size else 1.0)
+    np.testing.assert_allclose(a, b, rtol=tol, atol=tol * scale)
+
+
+def make(D, T, seed=3):
+    from pocomc_amd import Flow
+    spec = MAFSpec(D, T)
+    flat = cases.flow_params(spec, seed)
+    f = Flow(D, spec)
+    f.set_params(flat)
+    return f, OracleMAF(spec, flat)
+
+
+@pytest.mark.parametrize("D,T", SHAPES)
+@pytest.mark.parametrize("n", [1, 16, 100, 1000])
+def test_forward_logprob_matches_oracle(D, T, n):
+    f, o = make(D, T)
+    x = (np.random.default_rng(n).normal(size=(n, D)) * 1.5).astype(np.float32)
+    z, ladj = f.forward(torch.from_numpy(x))
+    zo, lo = o.forward(x)
+    close(z.numpy(), zo)
+    close(ladj.numpy(), lo)
+    close(f.log_prob(torch.from_numpy(x)).numpy(), o.log_prob(x))
+
+
+@pytest.mark.parametrize("D,T", SHAPES)
+@pytest.mark.parametrize("n", [1, 33, 500])
+def test_inverse_matches_oracle(D, T, n):
+    f, o = make(D, T)
+    z = (np.random.default_rng(7 + n).normal(size=(n, D)) * 1.2).astype(np.float32)
+    xo, lo = o.inverse(z)                       # the reference's D-pass algorithm
+    for algo in ([1, 2] if f.spec.tri_ok else [2]):
+        f.inverse_algo = algo
+        x, l = f.inverse(torch.from_numpy(z))
+        close(x.numpy(), xo)
+        close(l.numpy(), lo)
+    f.inverse_algo = 0
+    x, l = f.inverse(torch.from_numpy(z))
+    close(x.numpy(), xo)
+
+
+def test_triangular_equals_naive_on_device():
+    f, _ = make(32, 3)
+    z = torch.randn(4096, 32, generator=torch.Generator().manual_seed(0))
+    f.inverse_algo = 1
+    x1, l1 = f.inverse(z)
+    f.inverse_algo = 2
+    x2, l2 = f.inverse(z)
+    close(x1.numpy(), x2.numpy(), 2e-6)
+    close(l1.numpy(), l2.numpy(), 2e-6)
+
+
+def test_empty_input():
+    f, _ = make(4, 3)
+    z, l = f.forward(torch.empty(0, 4))
+    assert z.shape == (0, 4) and l.shape == (0,)
+    x, l = f.inverse(torch.empty(0, 4))
+    assert x.shape == (0, 4)
+
+
+def test_sample_matches_oracle():
+    f, o = make(10, 3)
+    z = np.random.default_rng(5).normal(size=(257, 10)).astype(np.float32)
+    x, lq = f.sample(257, z=torch.from_numpy(z))
+    xo, lqo = o.sample_from(z)
+    close(x.numpy(), xo)
+    close(lq.numpy(), lqo)
+
+
+# ----------------------------------------------- the reference's tests/test_flow.py
+def _data():
+    torch.manual_seed(0)
+    return torch.randn(size=(100, 4)) * 1.5           # tests/test_flow.py:8-13
+
+
+def test_reference_flow_properties():
+    from pocomc_amd import Flow
+    torch.manual_seed(0)
+    data = _data()
+    flow = Flow(n_dim=4, flow="maf3")
+    z, ladj = flow.forward(data)                       # :16-29
+    assert not torch.any(torch.isnan(z)) and not torch.any(torch.isinf(z))
+    assert z.shape == data.shape and z.dtype == data.dtype
+    x, ladj_inv = flow.inverse(z)                      # :75-88
+    assert x.shape == data.shape and x.dtype == data.dtype
+    assert torch.allclose(data, x, atol=1e-5)
+    torch.testing.assert_close(ladj, -ladj_inv, rtol=1e-5, atol=1e-5)   # :164, :205
+    lp = flow.log_prob(data)                           # :46-58
+    assert lp.shape == (100,) and lp.dtype == data.dtype and torch.isfinite(lp).all()
+    xs, lq = flow.sample(100)                          # :61-72
+    assert xs.shape == data.shape and xs.dtype == data.dtype and torch.isfinite(xs).all()
+
+
+def test_reference_float64_warns_and_casts():
+    from pocomc_amd import Flow
+    flow = Flow(n_dim=4, flow="maf3")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        lp = flow.log_prob(_data().double())           # tests/test_flow.py:106-119
+        assert any("Float64" in str(i.message) for i in w)
+    assert lp.dtype == torch.float32
+    with pytest.raises(ValueError):
+        flow.forward(_data().to(torch.float16))        # tools.py:316
+    z, _ = flow.forward(_data()[:1])                   # single row, :122-134
+    assert z.shape == (1, 4)
+
+
+def test_flow_names():
+    from pocomc_amd import Flow
+    assert Flow(6, "maf6").spec.n_transforms == 6
+    assert Flow(6, "maf12").spec.n_transforms == 12
+    with pytest.raises(ValueError):
+        Flow(6, "bogus")
+    with pytest.raises(NotImplementedError):
+        Flow(6, "nsf6")

@@ -1,0 +1,202 @@
+"""Parity of the device MCMC step against the oracle (which is pinned to the
+reference by ``tests/test_oracle_golden.py``), in replay mode: the random
+variates the reference drew from numpy's legacy stream are inputs.
+
+Two levels:
+* teacher-forced, step by step: the oracle's pre-step state goes in, the proposal
+  (theta', u', x', log-dets), alpha and the accept decisions come out and are compared.
+  Decisions may only differ where ``|u_rand - alpha|`` is below the fp32 flow's noise.
+* whole kernel call against the golden vectors generated from the reference itself.
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import mcmc as omcmc
+from oracle.maf import OracleMAF, TorchFlowAdapter
+from oracle.scaler import Reparameterize as OracleScaler
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def close(a, b, tol=TOL, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    fin = np.isfinite(b)
+    assert (np.isfinite(a) == fin).all(), what
+    assert ((a == b) | fin).all(), what                     # same +-inf
+    scale = max(1.0, float(np.abs(b[fin]).max()) if fin.any() else 1.0)
+    np.testing.assert_allclose(a[fin], b[fin], rtol=tol, atol=tol * scale, err_msg=what)
+
+
+def product_case(name):
+    """The case with the product's scaler and flow."""
+    from pocomc_amd import Flow, Reparameterize
+    state, funcs, opts, aux = cases.build_case(name, Reparameterize)
+    flow = Flow(aux["spec"].n_dim, aux["spec"])
+    flow.set_params(aux["flat"])
+    funcs["flow"] = flow
+    return state, funcs, opts, aux
+
+
+def oracle_case(name):
+    state, funcs, opts, aux = cases.build_case(name, OracleScaler)
+    funcs["flow"] = TorchFlowAdapter(OracleMAF(aux["spec"], aux["flat"]))
+    return state, funcs, opts, aux
+
+
+@pytest.mark.parametrize("name", list(cases.MCMC_CASES))
+def test_inputs_built_with_device_scaler_match_golden(name, golden_dir):
+    """scaler.fit / forward / inverse on the device reproduce the inputs the reference saw."""
+    g = np.load(f"{golden_dir}/mcmc_reference.npz")
+    state, funcs, _, _ = product_case(name)
+    np.testing.assert_allclose(funcs["scaler"].mu, g[f"mcmc/{name}/in/scaler_mu"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(funcs["scaler"].sigma, g[f"mcmc/{name}/in/scaler_sigma"], rtol=1e-12, atol=1e-12)
+    for k in ("u", "logdetj"):
+        np.testing.assert_allclose(state[k], g[f"mcmc/{name}/in/{k}"], rtol=1e-11, atol=1e-11, err_msg=k)
+
+
+@pytest.mark.parametrize("name", list(cases.MCMC_CASES))
+def test_step_teacher_forced(name):
+    from pocomc_amd.mcmc import StepEngine
+    c = cases.MCMC_CASES[name]
+    kind = c["kind"]
+    pre = kind.startswith("preconditioned")
+    tpcn = kind in ("preconditioned_pcn", "pcn")
+    # oracle run with trace and recorded variates
+    state, funcs, opts, aux = oracle_case(name)
+    rng = omcmc.LegacyStream()
+    trace = []
+    np.random.seed(c["seed"])
+    getattr(omcmc, kind)(state, funcs, opts, rng=rng, trace=trace)
+    assert len(trace) >= 1
+
+    pstate, pfuncs, popts, paux = product_case(name)
+    N, D = c["N"], c["D"]
+    geo = pfuncs["theta_geometry"]
+    eng = StepEngine(kind, N, D, pfuncs["flow"] if pre else None, pfuncs["scaler"])
+    eng.load_state(state["u"], state["x"], state["logdetj"], state["logl"], state["logp"])
+    nu = float(geo.t_nu) if tpcn else 0.0
+    if tpcn:
+        eng.set_geometry(mu=geo.t_mean, cov=geo.t_cov)
+    else:
+        eng.set_geometry(cov=geo.normal_cov)
+
+    sigma = np.minimum(opts["proposal_scale"], 0.99) if tpcn else opts["proposal_scale"]
+    mu = np.array(geo.t_mean, dtype=float)
+    prev = None
+    n_flips = 0
+    for i, tr in enumerate(trace):
+        if prev is not None:
+            # teacher forcing: start every step from the oracle's state
+            eng.u.copy_(torch.from_numpy(prev["u"])); eng.x.copy_(torch.from_numpy(prev["x"]))
+            eng.logdetj.copy_(torch.from_numpy(prev["logdetj"]))
+            eng.logl.copy_(torch.from_numpy(prev["logl"])); eng.logp.copy_(torch.from_numpy(prev["logp"]))
+            if pre:
+                eng.theta32.copy_(torch.from_numpy(prev["theta"].astype(np.float32)))
+                eng.ldjf.copy_(torch.from_numpy(prev["logdetj_flow"].astype(np.float32)))
+            sigma = prev["sigma"]
+            if kind == "preconditioned_pcn":
+                mu = prev["mu"]
+        elif pre:
+            # the theta the device derived from u must be the oracle's
+            th0, l0 = omcmc.flow_numpy_wrapper(funcs["flow"]).forward(state["u"])
+            close(eng.theta32.cpu().numpy(), th0, what="theta0")
+            close(eng.ldjf.cpu().numpy(), l0, what="logdetj_flow0")
+            eng.theta32.copy_(torch.from_numpy(th0)); eng.ldjf.copy_(torch.from_numpy(l0))
+        if tpcn:
+            eng.set_mu(mu)
+        rec = rng.record[i]
+        eng.propose(sigma, nu, dict(gamma=rec.get("gamma"), z=rec["z"], u=rec["u"]))
+        close(eng.p_theta64.cpu().numpy(), tr["theta_prime"], 1e-12 if not pre else 1e-6, "theta_prime")
+        close(eng.p_u.cpu().numpy(), tr["u_prime"], TOL, "u_prime")
+        close(eng.p_x.cpu().numpy(), tr["x_prime"], TOL, "x_prime")
+        close(eng.p_logdetj.cpu().numpy(), tr["logdetj_prime"], TOL, "logdetj_prime")
+        if pre:
+            close(eng.p_ldjf.cpu().numpy(), tr["logdetj_flow_prime"], TOL, "logdetj_flow_prime")
+        calls, _ = eng.evaluate(pfuncs["logprior"], pfuncs["loglike"])
+        fin = np.isfinite(tr["logl_prime"])
+        assert abs(calls - int(tr["finite"].sum())) <= 1
+        sums = eng.accept_reduce(c["beta"], nu, want_mask=True)
+        alpha = eng.alpha.cpu().numpy()
+        acc = eng.h_accept.numpy().astype(bool)
+        # alpha: relative agreement where it is not saturated
+        np.testing.assert_allclose(alpha, tr["alpha"], rtol=2e-3, atol=2e-5)
+        ambiguous = np.abs(rec["u"] - tr["alpha"]) < 1e-3 * np.maximum(tr["alpha"], 1e-3)
+        flips = acc != tr["accept"]
+        assert not (flips & ~ambiguous).any(), f"step {i}: unexplained accept flips"
+        n_flips += int(flips.sum())
+        ok = ~flips
+        post = eng.download()
+        for k in ("u", "x", "logdetj", "logl", "logp"):
+            close(post[k][ok], tr[k][ok], TOL, f"post {k}")
+        if not flips.any():
+            np.testing.assert_allclose(sums[0] / N, tr["alpha"].mean(), rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(sums[1] / N, (tr["logl"] + tr["logp"]).mean(), rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(sums[3], tr["accept"].sum())
+            moved = tr["theta"] if pre else tr["u"]
+            np.testing.assert_allclose(sums[4:4 + D] / N, moved.mean(axis=0, dtype=np.float64), rtol=1e-4, atol=1e-5)
+        prev = tr
+    assert n_flips <= 2
+
+
+@pytest.mark.parametrize("name", list(cases.MCMC_CASES))
+def test_kernel_call_matches_reference_golden(name, golden_dir):
+    """Whole call through the reference's contract vs the vectors the reference produced."""
+    from pocomc_amd import mcmc as pmcmc
+    g = np.load(f"{golden_dir}/mcmc_reference.npz")
+    c = cases.MCMC_CASES[name]
+    for n_max in sorted({1, c["n_max"]}):
+        state, funcs, opts, aux = product_case(name)
+        opts["n_max"] = n_max
+        np.random.seed(c["seed"])
+        res = getattr(pmcmc, c["kind"])(state, funcs, opts, replay=omcmc.LegacyStream())
+        tag = f"mcmc/{name}/nmax{n_max}"
+        same_path = res["steps"] == int(g[f"{tag}/steps"])
+        assert abs(res["steps"] - int(g[f"{tag}/steps"])) <= 1
+        if not same_path:
+            continue
+        assert abs(res["calls"] - int(g[f"{tag}/calls"])) <= 2
+        # a flipped marginal decision perturbs sigma for everybody afterwards: demand that
+        # (almost) every particle followed the reference's trajectory
+        for k in ("x", "logl"):
+            a, b = res[k], g[f"{tag}/{k}"]
+            fin = np.isfinite(b)
+            rel = np.abs(a - b)[fin] / np.maximum(1.0, np.abs(b[fin]))
+            assert (rel < 1e-3).mean() > 0.97, f"{tag}/{k}: {(rel < 1e-3).mean()}"
+        np.testing.assert_allclose(res["accept"], g[f"{tag}/accept"], atol=0.02)
+        np.testing.assert_allclose(res["proposal_scale"], g[f"{tag}/proposal_scale"], rtol=5e-3)
+
+
+def test_philox_mode_statistics():
+    """Throughput mode: counter-based RNG.  Moments of the proposal noise and the gamma
+    scale, acceptance in a sane range, determinism for a fixed seed."""
+    from pocomc_amd.mcmc import StepEngine
+    name = "tpcn_n512_d32_uniform"
+    state, funcs, opts, aux = product_case(name)
+    c = cases.MCMC_CASES[name]
+    N, D = c["N"], c["D"]
+    geo = funcs["theta_geometry"]
+    outs = []
+    for rep in range(2):
+        eng = StepEngine("preconditioned_pcn", N, D, funcs["flow"], funcs["scaler"], seed=1234)
+        eng.load_state(state["u"], state["x"], state["logdetj"], state["logl"], state["logp"])
+        eng.set_geometry(mu=geo.t_mean, cov=geo.t_cov)
+        eng.propose(0.3, 5.0)
+        outs.append(eng.p_theta64.cpu().numpy().copy())
+        theta = eng.theta32.cpu().numpy().astype(np.float64)
+    np.testing.assert_array_equal(outs[0], outs[1])
+    # theta' - mu - sqrt(1-s^2)(theta-mu) = s*sqrt(s_k) L z  ->  whiten and check moments
+    L = np.linalg.cholesky(geo.t_cov)
+    r = outs[0] - geo.t_mean - (1 - 0.3 ** 2) ** 0.5 * (theta - geo.t_mean)
+    w = np.linalg.solve(L, r.T).T / 0.3                   # sqrt(s_k) z_k
+    zn = w / np.sqrt((w ** 2).mean(axis=1, keepdims=True))
+    assert abs(zn.mean()) < 0.02 and abs((zn ** 2).mean() - 1) < 1e-6
+    assert abs(np.mean(zn[:, 0] * zn[:, 1])) < 0.15
+    s = (w ** 2).mean(axis=1)                              # ~ s_k = 1/Gamma((D+nu)/2, 2/(nu+delta))
+    assert np.all(s > 0) and np.isfinite(s).all()
+    calls, _ = eng.evaluate(funcs["logprior"], funcs["loglike"])
+    sums = eng.accept_reduce(c["beta"], 5.0)
+    assert 0.0 <= sums[0] / N <= 1.0

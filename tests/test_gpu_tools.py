@@ -1,0 +1,103 @@
+"""Device particle math against the golden vectors generated from the reference
+(``pocomc/tools.py``, ``pocomc/particles.py:215-231``, ``pocomc/scaler.py``)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return {k: np.load(os.path.join(golden_dir, f"{k}_reference.npz")) for k in ("scaler", "tools")}
+
+
+def test_compute_ess_single_particle():
+    """tests/test_tools.py:10-14, the reference's only KAT."""
+    from pocomc_amd import tools
+    for v in (1.0, 251.0, -421.0, -421.125251, 0.0):
+        assert tools.compute_ess(np.array([v])) == 1.0
+
+
+@pytest.mark.parametrize("n", [1, 17, 1000, 5000])
+def test_weight_statistics(gold, n):
+    from pocomc_amd import tools
+    g = gold["tools"]
+    lw = g[f"tools/n{n}/logw"]
+    w = np.exp(lw - lw.max())
+    np.testing.assert_allclose(tools.effective_sample_size(w.copy()), g[f"tools/n{n}/ess"], rtol=1e-12)
+    np.testing.assert_allclose(tools.unique_sample_size(w.copy()), g[f"tools/n{n}/uss"], rtol=1e-11)
+    np.testing.assert_allclose(tools.unique_sample_size(w.copy(), k=64), g[f"tools/n{n}/uss_k64"], rtol=1e-11)
+    np.testing.assert_allclose(tools.compute_ess(lw), g[f"tools/n{n}/compute_ess"], rtol=1e-12)
+    np.testing.assert_allclose(tools.increment_logz(lw), g[f"tools/n{n}/increment_logz"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("n", [17, 1000, 5000])
+def test_resample_indices_bit_exact(gold, n):
+    from pocomc_amd import tools
+    g = gold["tools"]
+    lw = g[f"tools/n{n}/logw"]
+    w = np.exp(lw - lw.max())
+    wn = w / w.sum()
+    for s in (0, 1):
+        got = tools.systematic_resample(min(n, 256), wn.copy(), offset=float(g[f"tools/n{n}/syst_{s}_offset"]))
+        np.testing.assert_array_equal(got, g[f"tools/n{n}/syst_{s}"])
+        got = tools.multinomial_resample(min(n, 256), wn, uniforms=g[f"tools/n{n}/mult_{s}_uniforms"])
+        np.testing.assert_array_equal(got, g[f"tools/n{n}/mult_{s}"])
+
+
+def test_logw_logz(gold):
+    from pocomc_amd import tools
+    g = gold["tools"]
+    for bf in (0.3, 1.0):
+        lw, lz = tools.compute_logw_and_logz(g["particles/logl"], g["particles/beta"], g["particles/logz"], bf)
+        np.testing.assert_allclose(lw, g[f"particles/logw_b{bf}"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(lz, g[f"particles/logz_b{bf}"], rtol=1e-12, atol=1e-12)
+        lw2, _ = tools.compute_logw_and_logz(g["particles/logl"], g["particles/beta"], g["particles/logz"], bf,
+                                             normalize=False)
+        np.testing.assert_allclose(lw2, g[f"particles/logw_raw_b{bf}"], rtol=1e-13, atol=1e-13)
+
+
+def test_gather():
+    from pocomc_amd import tools
+    rng = np.random.default_rng(0)
+    u, x = rng.normal(size=(300, 7)), rng.normal(size=(300, 7))
+    a, b, c = rng.normal(size=300), rng.normal(size=300), rng.normal(size=300)
+    idx = rng.integers(0, 300, size=128)
+    uo, xo, ao, bo, co = tools.gather(idx, u, x, a, b, c)
+    np.testing.assert_array_equal(uo, u[idx]); np.testing.assert_array_equal(xo, x[idx])
+    np.testing.assert_array_equal(ao, a[idx]); np.testing.assert_array_equal(bo, b[idx])
+    np.testing.assert_array_equal(co, c[idx])
+
+
+@pytest.mark.parametrize("transform", ["probit", "logit"])
+@pytest.mark.parametrize("bname", ["none", "left", "right", "both"])
+def test_scaler_matches_reference(gold, transform, bname):
+    """The four bound types of tests/test_scaler.py:9-54 on the device scaler."""
+    from pocomc_amd import Reparameterize
+    g = gold["scaler"]
+    tag = f"scaler/{transform}/{bname}"
+    sc = Reparameterize(10, g[f"{tag}/bounds"], transform=transform)
+    x = g[f"{tag}/x"]
+    sc.fit(x)
+    np.testing.assert_allclose(sc.mu, g[f"{tag}/mu"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(sc.sigma, g[f"{tag}/sigma"], rtol=1e-12, atol=1e-13)
+    u = sc.forward(x)
+    np.testing.assert_allclose(u, g[f"{tag}/u"], rtol=1e-11, atol=1e-11)
+    xr, ldj = sc.inverse(g[f"{tag}/u"])
+    np.testing.assert_allclose(xr, g[f"{tag}/x_rt"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ldj, g[f"{tag}/ldj"], rtol=1e-12, atol=1e-11)
+    assert np.allclose(x, xr)                               # tests/test_scaler.py:73,92,111,130
+    xf, ldjf = sc.inverse(g[f"{tag}/u_far"])
+    np.testing.assert_allclose(xf, g[f"{tag}/x_far"], rtol=1e-12, atol=1e-12)
+    # far tails: log(1 - p) with p -> 1 amplifies the last-bit difference between libm's and the
+    # device's exp (scaler.py:419 is ill-conditioned there), hence the looser bound
+    np.testing.assert_allclose(ldjf, g[f"{tag}/ldj_far"], rtol=1e-9, atol=1e-9)
+
+
+def test_scaler_out_of_bounds_raises():
+    from pocomc_amd import Reparameterize
+    sc = Reparameterize(3, np.tile(np.array([[0.0, 1.0]]), (3, 1)))
+    with pytest.raises(ValueError):
+        sc.fit(np.full((5, 3), 2.0))
