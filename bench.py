@@ -1,0 +1,229 @@
+"""Headline benchmark: flow-preconditioned MCMC steps/s (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (``config.workload``): the tpCN kernel of ``pocomc/mcmc.py:8-183`` on the
+32-D Rosenbrock likelihood (``README.md:53-55``), prior U(-10,10)^32, 10 000 walkers per
+GPU, maf3 flow (H=128), beta=0.5 -- SURVEY.md section 8(d) cfg 2/4.  A *step* is one
+iteration of the kernel's ``while`` loop: propose -> flow inverse -> scaler inverse ->
+[host: prior + likelihood black boxes on the compacted rows] -> Metropolis accept ->
+global reductions -> adaptation; the data-dependent stop is disabled for timing.
+The particle state is resident in HBM when the timed region starts.
+
+``value`` = (walkers over all ranks x steps / wall time) / 1e4, i.e. steps/s of a
+1e4-walker population; at N=1 that is plain steps/s.  Weak scaling (walkers per GPU fixed).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def rosenbrock(x):
+    return -np.sum(10.0 * (x[:, ::2] ** 2.0 - x[:, 1::2]) ** 2.0 + (x[:, ::2] - 1.0) ** 2.0, axis=1)
+
+
+class UniformBox:
+    """Host prior black box: product of U(low, high)."""
+
+    def __init__(self, low, high, D):
+        self.low, self.high, self.D = float(low), float(high), D
+        self.bounds = np.tile(np.array([[self.low, self.high]]), (D, 1))
+        self.const = -D * np.log(self.high - self.low)
+
+    def logpdf(self, x):
+        inside = np.all((x >= self.low) & (x <= self.high), axis=1)
+        return np.where(inside, self.const, -np.inf)
+
+
+def cpu_baseline(D, n, beta, flat, spec, x0, u0_unused, geo, sigma0, seed, max_seconds=30.0):
+    """The oracle (CPU restatement of the reference's algorithm: per-step numpy float64 +
+    the float32 D-pass MAF inverse) timed on the host cores, on a bounded sample."""
+    from threadpoolctl import threadpool_info
+    from oracle import mcmc as omcmc
+    from oracle.maf import OracleMAF, TorchFlowAdapter
+    from oracle.scaler import Reparameterize as OracleScaler
+    prior = UniformBox(-10.0, 10.0, D)
+    sc = OracleScaler(D, bounds=prior.bounds)
+    sc.fit(x0)
+    # bounded sample: shrink the population until one step is affordable, then scale linearly
+    n_s = n
+    maf = OracleMAF(spec, flat)
+    flow = TorchFlowAdapter(maf)
+    t_probe = time.perf_counter()
+    maf.inverse(np.zeros((256, D), np.float32))
+    per_row = (time.perf_counter() - t_probe) / 256
+    while n_s > 500 and per_row * n_s * 3 > max_seconds:
+        n_s //= 2
+    x = x0[:n_s]
+    u = sc.forward(x)
+    state = dict(u=u, x=x, logdetj=sc.inverse(u)[1], logl=rosenbrock(x), logp=prior.logpdf(x), beta=beta, blobs=None)
+    funcs = dict(loglike=lambda xx: (rosenbrock(xx), None), logprior=prior.logpdf, scaler=sc, flow=flow,
+                 theta_geometry=geo)
+    steps = 2
+    opts = dict(n_max=steps, n_steps=10 ** 9, progress_bar=None, proposal_scale=sigma0)
+    np.random.seed(seed)
+    t0 = time.perf_counter()
+    res = omcmc.preconditioned_pcn(state, funcs, opts)
+    dt = time.perf_counter() - t0
+    threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+    # steps/s of a 1e4-walker population, scaled linearly from the sample
+    value = res["steps"] / dt * (n_s / 1e4)
+    return {"value": value, "unit": "steps/s (1e4 walkers, 32-D)", "cores": int(threads), "kind": "port",
+            "sample": f"{res['steps']} steps of {n_s} walkers (oracle: numpy f64 step + f32 D-pass MAF inverse, "
+                      f"BLAS threads={threads}, host cpu_count={os.cpu_count()}), scaled linearly to 1e4 walkers"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--particles", type=int, default=10000, help="walkers per GPU")
+    ap.add_argument("--dim", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inverse", choices=["auto", "triangular", "naive"], default="auto")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pocomc_amd import Flow, Reparameterize
+    from pocomc_amd.geometry import Geometry
+    from pocomc_amd.mcmc import StepEngine, Adaptation
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    D, n, beta = args.dim, args.particles, 0.5
+    prior = UniformBox(-10.0, 10.0, D)
+    rng = np.random.default_rng(1000 + rank)
+    # ---- synthetic setup (untimed): x ~ prior, scaler fitted on prior draws, flow, geometry
+    fit_rng = np.random.default_rng(7)                      # identical on every rank
+    x_fit = fit_rng.uniform(-10.0, 10.0, size=(2 * n, D))
+    scaler = Reparameterize(D, bounds=prior.bounds)
+    scaler.fit(x_fit)
+    x = rng.uniform(-10.0, 10.0, size=(n, D))
+    u = scaler.forward(x)
+    logdetj = scaler.inverse(u)[1]
+    logl, logp = rosenbrock(x), prior.logpdf(x)
+    flow = Flow(D, "maf3", seed=0)                          # replicated weights
+    flow.inverse_algo = {"auto": 0, "triangular": 1, "naive": 2}[args.inverse]
+    flow_trained = False
+    try:
+        flow.fit(torch.from_numpy(scaler.forward(x_fit[:n])).float(), epochs=50, batch_size=512,
+                 validation_split=0.5, patience=D, annealing=False, verbose=0)
+        flow_trained = True
+    except NotImplementedError:
+        pass
+    # geometry of theta = flow.forward(u): fitted on rank 0's shard, broadcast (replicated input of the step)
+    theta0 = flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64)
+    geo = Geometry()
+    geo.fit(theta0)
+    if world > 1:
+        g = torch.tensor(np.concatenate([geo.t_mean, geo.t_cov.ravel(), [geo.t_nu]]), device="cuda")
+        dist.broadcast(g, 0)
+        g = g.cpu().numpy()
+        geo.t_mean, geo.t_cov, geo.t_nu = g[:D], g[D:D + D * D].reshape(D, D), float(g[-1])
+    nu = float(geo.t_nu)
+    sigma0 = 2.38 / D ** 0.5
+
+    eng = StepEngine("preconditioned_pcn", n, D, flow, scaler, group=None, shard_offset=rank * n, seed=20240928)
+    eng.load_state(u, x, logdetj, logl, logp)
+    eng.set_geometry(mu=geo.t_mean, cov=geo.t_cov)
+    ad = Adaptation("preconditioned_pcn", D, n * world, n_steps=10 ** 9, n_max=10 ** 9, sigma0=sigma0,
+                    mu0=geo.t_mean, logp2_0=-np.inf)
+    loglike = lambda xx: (rosenbrock(xx), None)
+    t_host = [0.0]
+
+    def step():
+        eng.propose(ad.sigma, nu)
+        th = time.perf_counter()
+        eng.evaluate(prior.logpdf, loglike)
+        t_host[0] += time.perf_counter() - th
+        sums = eng.accept_reduce(beta, nu)
+        ad.update(sums)
+        eng.set_mu(ad.mu)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.events = []
+    t_host[0] = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- per-kernel device times from the HIP events recorded inside the timed region
+    ev = eng.events
+    seg = lambda a, b: float(np.mean([e[a].elapsed_time(e[b]) for e in ev])) * 1e3     # us
+    us = {"propose": seg(0, 1), "maf_inverse": seg(1, 2), "scaler_inverse": seg(2, 3), "d2h_x": seg(3, 4),
+          "accept_reduce": seg(5, 6)}
+    spec = flow.spec
+    algo_flops = n * spec.flops_inverse_naive()                   # (D+1)*F_fwd per walker
+    actual_flops = n * 2 * spec.macs_masked()                     # what the triangular sweep needs
+    t_inv = us["maf_inverse"] * 1e-6
+    achieved = algo_flops / t_inv / 1e12
+    roofline = {"bound": "mfma", "kernel": "maf_inverse_tri_kernel" if (spec.tri_ok and args.inverse != "naive")
+                else "maf_dense_kernel<1>", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "avg_launch_us": us["maf_inverse"],
+                "note": "achieved = SURVEY 8(d) naive-equivalent flops ((D+1)*F_fwd per walker) / launch time; the "
+                        "triangular sweep executes only the masked MACs once, so frac > 1 is an algorithmic gain",
+                "actual_tflops": actual_flops / t_inv / 1e12,
+                "actual_frac": actual_flops / t_inv / 1e12 / PEAK_F32_MFMA_TFLOPS}
+    ms_per_step = dt / args.steps * 1e3
+    value = (n * world * args.steps / dt) / 1e4
+    out = {"metric": "preconditioned MCMC steps/sec (1e4 particles, 32-D)", "value": value,
+           "unit": "steps/s per 1e4 walkers", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 flow (MFMA) + f64 step", "data": "synthetic",
+           "config": {"workload": f"{D}-D Rosenbrock, U(-10,10)^{D} prior, {n} walkers/GPU x {world} GPU, maf3 "
+                                  f"(H={spec.hidden}), beta={beta}, tpCN kernel, host numpy likelihood in the loop",
+                      "walkers_per_gpu": n, "global_walkers": n * world, "n_dim": D, "flow": "maf3",
+                      "flow_trained_50_epochs": flow_trained, "parallelism": f"walker-sharded x{world}",
+                      "inverse_algo": args.inverse, "accept_rate": float(ad.mean_alpha)},
+           "roofline": roofline,
+           "breakdown_us_per_step": dict(us, host_prior_likelihood=t_host[0] / args.steps * 1e6,
+                                         device_kernels=us["propose"] + us["maf_inverse"] + us["scaler_inverse"]
+                                         + us["accept_reduce"], wall=ms_per_step * 1e3)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(D, n, beta, flow.params.cpu().numpy(), spec, x, u, geo, sigma0, seed=0)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

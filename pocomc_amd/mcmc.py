@@ -154,6 +154,12 @@ class StepEngine:
             logdetj_flow=self.p_ldjf.data_ptr() if self.pre else None,
             quad=self.quad.data_ptr() if self.tpcn else None, quad_prop=self.p_quad.data_ptr() if self.tpcn else None)
         self.step_idx = 0
+        self.events = None       # bench.py: list of per-step HIP event tuples when not None
+
+    def _ev(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        return e
 
     # ---------------------------------------------------------------- setup
     def load_state(self, u, x, logdetj, logl, logp):
@@ -201,16 +207,21 @@ class StepEngine:
         st = _lib.stream_handle()
         kind = PMC_KIND_TPCN if self.tpcn else PMC_KIND_RWM
         cn_a = float((1.0 - sigma ** 2.0) ** 0.5) if self.tpcn else 0.0            # mcmc.py:85
+        timed = self.events is not None
         with torch.cuda.device(self.device):
+            e0 = self._ev() if timed else None
             _lib.check(lib.pmc_propose(
                 kind, _lib.ptr(self.theta32) if self.pre else None, None if self.pre else _lib.ptr(self.u),
                 _lib.ptr(self.mu_d), _lib.ptr(self.inv_cov_d), _lib.ptr(self.chol_d), float(nu), float(sigma), cn_a,
                 C.byref(self._rng_cur), _lib.ptr(self.p_theta64), _lib.ptr(self.p_theta32) if self.pre else None,
                 _lib.ptr(self.quad) if self.tpcn else None, _lib.ptr(self.p_quad) if self.tpcn else None,
                 n, D, st), "pmc_propose")
+            e1 = self._ev() if timed else None
+            e2 = e1
             if self.pre:
                 _lib.check(lib.pmc_maf_inverse(C.byref(self.flow._desc), _lib.ptr(self.p_theta32), _lib.ptr(self.p_u32),
                                                _lib.ptr(self.p_ldjf), n, self.flow.inverse_algo, st), "pmc_maf_inverse")
+                e2 = self._ev() if timed else None
                 _lib.check(lib.pmc_scaler_inverse(C.byref(self.scaler_desc), _lib.ptr(self.p_u32), None,
                                                   _lib.ptr(self.p_u), _lib.ptr(self.p_x), _lib.ptr(self.p_logdetj),
                                                   _lib.ptr(self.p_fin), n, st), "pmc_scaler_inverse")
@@ -218,8 +229,11 @@ class StepEngine:
                 _lib.check(lib.pmc_scaler_inverse(C.byref(self.scaler_desc), None, _lib.ptr(self.p_theta64),
                                                   _lib.ptr(self.p_u), _lib.ptr(self.p_x), _lib.ptr(self.p_logdetj),
                                                   _lib.ptr(self.p_fin), n, st), "pmc_scaler_inverse")
+            e3 = self._ev() if timed else None
         self.h_x.copy_(self.p_x, non_blocking=True)
         self.h_fin.copy_(self.p_fin, non_blocking=True)
+        if timed:
+            self._cur_ev = [e0, e1, e2, e3, self._ev()]
 
     def evaluate(self, log_prior, log_like, have_blobs=False, blobs=None):
         """Host black boxes on the compacted rows, ``mcmc.py:100-121``.  Returns
@@ -247,11 +261,15 @@ class StepEngine:
     def accept_reduce(self, beta, nu=0.0, want_mask=False):
         """Metropolis accept + global sums; returns the (all-reduced) host copy."""
         kind = PMC_KIND_TPCN if self.tpcn else PMC_KIND_RWM
+        timed = self.events is not None
         with torch.cuda.device(self.device):
+            e5 = self._ev() if timed else None
             _lib.check(self.lib.pmc_accept(kind, int(self.pre), C.byref(self._state), C.byref(self._prop), float(beta),
                                            float(nu), C.byref(self._rng_cur), _lib.ptr(self.alpha), _lib.ptr(self.accept),
                                            _lib.ptr(self.sums), _lib.ptr(self.ws), self.n, self.D,
                                            _lib.stream_handle()), "pmc_accept")
+            if timed:
+                self.events.append(self._cur_ev + [e5, self._ev()])
         allreduce_sums(self.sums, self.group)
         self.h_sums.copy_(self.sums, non_blocking=True)
         if want_mask:
