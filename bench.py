@@ -32,7 +32,16 @@ PEAK_HBM_GBS = 8000.0
 
 
 def rosenbrock(x):
-    return -np.sum(10.0 * (x[:, ::2] ** 2.0 - x[:, 1::2]) ** 2.0 + (x[:, ::2] - 1.0) ** 2.0, axis=1)
+    """README.md:53-55 formula, written with two temporaries instead of eight (same values)."""
+    a, b = x[:, ::2], x[:, 1::2]
+    t = a * a
+    t -= b
+    t *= t
+    t *= 10.0
+    u = a - 1.0
+    u *= u
+    t += u
+    return -t.sum(axis=1)
 
 
 class UniformBox:
@@ -44,8 +53,9 @@ class UniformBox:
         self.const = -D * np.log(self.high - self.low)
 
     def logpdf(self, x):
-        inside = np.all((x >= self.low) & (x <= self.high), axis=1)
-        return np.where(inside, self.const, -np.inf)
+        inside = x >= self.low
+        inside &= x <= self.high
+        return np.where(inside.all(axis=1), self.const, -np.inf)
 
 
 def cpu_baseline(D, n, beta, flat, spec, x0, u0_unused, geo, sigma0, seed, max_seconds=30.0):
@@ -94,7 +104,10 @@ def main():
     ap.add_argument("--particles", type=int, default=10000, help="walkers per GPU")
     ap.add_argument("--dim", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inverse", choices=["auto", "triangular", "naive"], default="auto")
+    ap.add_argument("--host-threads", type=int, default=1, help="host threads evaluating the prior/likelihood")
+    ap.add_argument("--x-order", choices=["C", "F"], default="F",
+                    help="memory order of the (n, D) array handed to the host prior/likelihood")
+    ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "triangular_v1"], default="auto")
     args = ap.parse_args()
 
     import torch
@@ -125,7 +138,7 @@ def main():
     logdetj = scaler.inverse(u)[1]
     logl, logp = rosenbrock(x), prior.logpdf(x)
     flow = Flow(D, "maf3", seed=0)                          # replicated weights
-    flow.inverse_algo = {"auto": 0, "triangular": 1, "naive": 2}[args.inverse]
+    flow.inverse_algo = {"auto": 0, "triangular": 1, "naive": 2, "triangular_v1": 3}[args.inverse]
     flow_trained = False
     try:
         flow.fit(torch.from_numpy(scaler.forward(x_fit[:n])).float(), epochs=50, batch_size=512,
@@ -145,7 +158,18 @@ def main():
     nu = float(geo.t_nu)
     sigma0 = 2.38 / D ** 0.5
 
-    eng = StepEngine("preconditioned_pcn", n, D, flow, scaler, group=None, shard_offset=rank * n, seed=20240928)
+    # numpy temporaries of the host black boxes: keep them on the heap instead of one mmap +
+    # page-fault storm per call (glibc M_MMAP_THRESHOLD / M_TRIM_THRESHOLD)
+    try:
+        import ctypes
+        libc = ctypes.CDLL("libc.so.6")
+        libc.mallopt(-3, 1 << 30)
+        libc.mallopt(-1, 1 << 30)
+    except OSError:
+        pass
+    eng = StepEngine("preconditioned_pcn", n, D, flow, scaler, group=None, shard_offset=rank * n, seed=20240928,
+                     x_order=args.x_order)
+    eng.host_threads = args.host_threads
     eng.load_state(u, x, logdetj, logl, logp)
     eng.set_geometry(mu=geo.t_mean, cov=geo.t_cov)
     ad = Adaptation("preconditioned_pcn", D, n * world, n_steps=10 ** 9, n_max=10 ** 9, sigma0=sigma0,
@@ -153,14 +177,22 @@ def main():
     loglike = lambda xx: (rosenbrock(xx), None)
     t_host = [0.0]
 
+    t_seg = {"propose_call": 0.0, "evaluate_call": 0.0, "accept_call": 0.0, "adapt": 0.0}
+
     def step():
+        ta = time.perf_counter()
         eng.propose(ad.sigma, nu)
         th = time.perf_counter()
         eng.evaluate(prior.logpdf, loglike)
-        t_host[0] += time.perf_counter() - th
+        tb = time.perf_counter()
+        t_host[0] += tb - th
         sums = eng.accept_reduce(beta, nu)
+        tc = time.perf_counter()
         ad.update(sums)
         eng.set_mu(ad.mu)
+        td = time.perf_counter()
+        t_seg["propose_call"] += th - ta; t_seg["evaluate_call"] += tb - th
+        t_seg["accept_call"] += tc - tb; t_seg["adapt"] += td - tc
 
     def barrier():
         if world > 1:
@@ -170,7 +202,9 @@ def main():
     for _ in range(args.warmup):
         step()
     eng.events = []
+    eng.host_timers = {"wait_device": 0.0, "prior": 0.0, "likelihood": 0.0}
     t_host[0] = 0.0
+    t_seg = {"propose_call": 0.0, "evaluate_call": 0.0, "accept_call": 0.0, "adapt": 0.0}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -192,8 +226,8 @@ def main():
     actual_flops = n * 2 * spec.macs_masked()                     # what the triangular sweep needs
     t_inv = us["maf_inverse"] * 1e-6
     achieved = algo_flops / t_inv / 1e12
-    roofline = {"bound": "mfma", "kernel": "maf_inverse_tri_kernel" if (spec.tri_ok and args.inverse != "naive")
-                else "maf_dense_kernel<1>", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+    roofline = {"bound": "mfma", "kernel": ("maf_dense_kernel<1>" if (args.inverse == "naive" or not spec.tri_ok) else
+                           ("maf_inverse_tri_kernel" if args.inverse == "triangular_v1" else "maf_inverse_tri2_kernel")), "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                 "avg_launch_us": us["maf_inverse"],
                 "note": "achieved = SURVEY 8(d) naive-equivalent flops ((D+1)*F_fwd per walker) / launch time; the "
@@ -210,11 +244,13 @@ def main():
                                   f"(H={spec.hidden}), beta={beta}, tpCN kernel, host numpy likelihood in the loop",
                       "walkers_per_gpu": n, "global_walkers": n * world, "n_dim": D, "flow": "maf3",
                       "flow_trained_50_epochs": flow_trained, "parallelism": f"walker-sharded x{world}",
-                      "inverse_algo": args.inverse, "accept_rate": float(ad.mean_alpha)},
+                      "inverse_algo": args.inverse, "host_threads": args.host_threads, "host_x_order": args.x_order, "accept_rate": float(ad.mean_alpha)},
            "roofline": roofline,
            "breakdown_us_per_step": dict(us, host_prior_likelihood=t_host[0] / args.steps * 1e6,
                                          device_kernels=us["propose"] + us["maf_inverse"] + us["scaler_inverse"]
-                                         + us["accept_reduce"], wall=ms_per_step * 1e3)}
+                                         + us["accept_reduce"], wall=ms_per_step * 1e3),
+           "host_us_per_step": {**{k: v / args.steps * 1e6 for k, v in eng.host_timers.items()},
+                                **{k: v / args.steps * 1e6 for k, v in t_seg.items()}}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(D, n, beta, flow.params.cpu().numpy(), spec, x, u, geo, sigma0, seed=0)
     elif rank == 0:

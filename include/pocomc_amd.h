@@ -52,6 +52,7 @@ typedef struct pmc_maf {
 #define PMC_INVERSE_AUTO 0
 #define PMC_INVERSE_TRIANGULAR 1   /* one sweep over the degree groups */
 #define PMC_INVERSE_NAIVE 2        /* the reference's D fixed-point passes (zuko) */
+#define PMC_INVERSE_TRIANGULAR_V1 3 /* first (un-prefetched, barrier-synchronised) sweep; kept for A/B */
 
 /* packed[i] = idx[i] >= 0 ? flat[idx[i]] : 0   (canonical fp32 params -> kernel layout) */
 int pmc_maf_pack(const float* flat, const int32_t* pack_idx, float* packed, int64_t n_packed, void* stream);
@@ -89,9 +90,11 @@ typedef struct pmc_scaler {
  * mcmc.py:94-97 + the finite mask of mcmc.py:100-102.
  * u_in: f32 [n][D] (flow output) or NULL;  u_in64: f64 [n][D] or NULL (exactly one non-NULL)
  * u_out f64 [n][D] (u', re-derived from x' when boundary conditions apply), x f64 [n][D],
- * logdetj f64 [n], finite int32 [n] (1 = logdetj and every x finite). */
+ * logdetj f64 [n], finite int32 [n] (1 = logdetj and every x finite).
+ * x_colmajor: optional second copy of x as f64 [D][n] (what the host likelihood reads as an (n, D)
+ * Fortran-ordered array: numpy's inner loops then run over n instead of over D), or NULL. */
 int pmc_scaler_inverse(const pmc_scaler_t* s, const float* u_in, const double* u_in64, double* u_out,
-                       double* x, double* logdetj, int32_t* finite, int64_t n, void* stream);
+                       double* x, double* x_colmajor, double* logdetj, int32_t* finite, int64_t n, void* stream);
 
 /* Reparameterize.forward (scaler.py:180-202), no input check.  x f64 [n][D] -> u f64 [n][D]. */
 int pmc_scaler_forward(const pmc_scaler_t* s, const double* x, double* u, int64_t n, void* stream);

@@ -56,7 +56,7 @@ SIGNATURES = {
     "pmc_maf_pack": (C.c_int, [c_p, c_p, c_p, i64, c_p]),
     "pmc_maf_forward": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, c_p, i64, c_p]),
     "pmc_maf_inverse": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, i64, C.c_int, c_p]),
-    "pmc_scaler_inverse": (C.c_int, [P(pmc_scaler_t), c_p, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
+    "pmc_scaler_inverse": (C.c_int, [P(pmc_scaler_t), c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
     "pmc_scaler_forward": (C.c_int, [P(pmc_scaler_t), c_p, c_p, i64, c_p]),
     "pmc_propose": (C.c_int, [C.c_int, c_p, c_p, c_p, c_p, c_p, f64, f64, f64, P(pmc_rng_t),
                               c_p, c_p, c_p, c_p, i64, i32, c_p]),

@@ -1,0 +1,126 @@
+// Shared device helpers of the MAF kernels (layouts, MFMA tile step, LDS staging).
+#ifndef PMC_MAF_COMMON_H
+#define PMC_MAF_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pmc_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// zuko MonotonicAffineTransform: log(slope) with slope = 1e-3
+#define PMC_LOG_SLOPE (-6.907755278982137f)
+
+__device__ __forceinline__ int lidx(int r, int p) {
+    return ((r >> 4) << 8) + ((r & 3) << 6) + (p << 2) + ((r >> 2) & 3);
+}
+
+__device__ __forceinline__ float sel4(const float4& v, int j) {
+    return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
+}
+
+__device__ __forceinline__ int sel4i(const int4& v, int j) {
+    return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
+}
+
+__device__ __forceinline__ float soft_ls(float raw) {
+    return raw / (1.0f + fabsf(raw / PMC_LOG_SLOPE));
+}
+
+__device__ __forceinline__ f32x4 bias4(const float* __restrict__ b, int off) {
+    const float4 v = *reinterpret_cast<const float4*>(b + off);
+    f32x4 r; r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; return r;
+}
+
+// acc += W[tile rows][K tile] * act[K tile]  : one float4 weight load + one
+// ds_read_b128 feed four MFMAs.
+__device__ __forceinline__ f32x4 tile_mac(f32x4 acc, const float4* __restrict__ frag,
+                                          const float* act, int ktile, int lane) {
+    const float4 a = frag[ktile * 64 + lane];
+    const float4 b = *reinterpret_cast<const float4*>(act + (ktile << 8) + (lane << 2));
+    acc = MFMA(a.x, b.x, acc);
+    acc = MFMA(a.y, b.y, acc);
+    acc = MFMA(a.z, b.z, acc);
+    acc = MFMA(a.w, b.w, acc);
+    return acc;
+}
+
+// store the 4 rows this lane holds of tile T into an activation array
+__device__ __forceinline__ void store_rows(float* act, int T, int q, int p, const f32x4& v) {
+    float* base = act + (T << 8) + (p << 2) + q;
+    base[0] = v[0]; base[64] = v[1]; base[128] = v[2]; base[192] = v[3];
+}
+
+struct MafView {
+    const float4* f0; const float4* f1; const float4* f2; const float4* f3;
+    const float* w0n; const float* b0; const float* b1; const float* b2; const float* b3;
+};
+
+__device__ __forceinline__ MafView maf_view(const pmc_maf_t& m, int t) {
+    const float* base = m.packed + (size_t)t * m.pk_per_transform;
+    MafView v;
+    const size_t sz_f0 = (size_t)m.nT * m.nXT * 256, sz_f12 = (size_t)m.nT * m.nT * 256;
+    const size_t sz_f3 = (size_t)m.nOT * m.nT * 256, sz_w0n = (size_t)m.Dp * m.Hp;
+    const float* p = base;
+    v.f0 = reinterpret_cast<const float4*>(p); p += sz_f0;
+    v.f1 = reinterpret_cast<const float4*>(p); p += sz_f12;
+    v.f2 = reinterpret_cast<const float4*>(p); p += sz_f12;
+    v.f3 = reinterpret_cast<const float4*>(p); p += sz_f3;
+    v.w0n = p; p += sz_w0n;
+    v.b0 = p; p += m.Hp;
+    v.b1 = p; p += m.Hp;
+    v.b2 = p; p += m.Hp;
+    v.b3 = p;
+    return v;
+}
+
+// sum a per-lane partial over the 4 quads that share a particle
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// load 16 particle rows (row-major [n][D] fp32) into an LDS rank-indexed array
+__device__ __forceinline__ void load_rows(float* dst, const float* __restrict__ src, int64_t row0,
+                                          int64_t n, int D, int Dp, const int* __restrict__ feat_of_rank,
+                                          int lane) {
+    for (int e = lane; e < Dp * 16; e += 64) {
+        const int r = e >> 4, p = e & 15;      // rank-major so that LDS writes spread
+        float v = 0.0f;
+        if (r < D && row0 + p < n) v = src[(row0 + p) * D + feat_of_rank[r]];
+        dst[lidx(r, p)] = v;
+    }
+}
+
+// re-rank an LDS array for the next transform, or write it out
+__device__ __forceinline__ void rerank_or_store(const float* cur, float* nxt, float* __restrict__ out,
+                                                int64_t row0, int64_t n, int D, int Dp,
+                                                const int* __restrict__ for_cur,
+                                                const int* __restrict__ rank_next, int lane) {
+    for (int e = lane; e < Dp * 16; e += 64) {
+        const int r = e >> 4, p = e & 15;
+        if (r < D) {
+            const float v = cur[lidx(r, p)];
+            const int feat = for_cur[r];
+            if (rank_next) nxt[lidx(rank_next[feat], p)] = v;
+            else if (row0 + p < n) out[(row0 + p) * D + feat] = v;
+        }
+    }
+    if (rank_next) {
+        for (int e = lane; e < (Dp - D) * 16; e += 64) {
+            const int r = D + (e >> 4), p = e & 15;
+            nxt[lidx(r, p)] = 0.0f;
+        }
+    }
+}
+
+
+// Compiler-only fence between dependent LDS accesses of ONE wavefront: a wave's DS
+// instructions execute in issue order, so a ds_read after a ds_write needs no s_barrier
+// and no s_waitcnt -- only that the compiler keeps the program order.
+#define WAVE_LDS_FENCE() asm volatile("" ::: "memory")
+
+#endif

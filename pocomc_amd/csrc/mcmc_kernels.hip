@@ -16,7 +16,7 @@
 #pragma clang fp contract(off)
 
 #define PROP_ROWS 64          // particles per block in propose_kernel (one wave)
-#define ACC_ROWS 256          // particles per block in accept_kernel
+#define ACC_ROWS 64           // particles per block in accept_kernel
 #define SCL_ROWS 64           // particles per block in the scaler kernels
 
 // ===========================================================================
@@ -213,12 +213,13 @@ __device__ __forceinline__ double apply_bc(const pmc_scaler_t& s, int j, double 
 
 __global__ __launch_bounds__(256) void scaler_inverse_kernel(
     pmc_scaler_t s, const float* __restrict__ u_in, const double* __restrict__ u_in64,
-    double* __restrict__ u_out, double* __restrict__ x_out, double* __restrict__ ldj_out,
-    int32_t* __restrict__ finite_out, int64_t n) {
+    double* __restrict__ u_out, double* __restrict__ x_out, double* __restrict__ x_colmajor,
+    double* __restrict__ ldj_out, int32_t* __restrict__ finite_out, int64_t n) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int D = s.D;
     double* Jt = sm;                              // [SCL_ROWS][D]
-    int* rowfin = reinterpret_cast<int*>(sm + (size_t)SCL_ROWS * D);
+    double* Xt = sm + (size_t)SCL_ROWS * D;       // [D][SCL_ROWS+1]  (only when x_colmajor)
+    int* rowfin = reinterpret_cast<int*>(sm + (size_t)SCL_ROWS * D + (x_colmajor ? (size_t)D * (SCL_ROWS + 1) : 0));
     const int tid = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * SCL_ROWS;
     const int rows = (int)min((int64_t)SCL_ROWS, n - row0);
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(256) void scaler_inverse_kernel(
         }
         u_out[g] = u;
         x_out[g] = x;
+        if (x_colmajor) Xt[j * (SCL_ROWS + 1) + r] = x;
         Jt[r * D + j] = J;
         if (!isfinite(x)) rowfin[r] = 0;
     }
@@ -249,6 +251,13 @@ __global__ __launch_bounds__(256) void scaler_inverse_kernel(
         if (s.scale) l = s.sum_log_sigma + l;
         ldj_out[row0 + tid] = l;
         finite_out[row0 + tid] = (rowfin[tid] && isfinite(l)) ? 1 : 0;
+    }
+    if (x_colmajor) {
+        // host copy of x' in column-major order ((n, D) Fortran array on the host): coalesced along rows
+        for (int e = tid; e < rows * D; e += 256) {
+            const int j = e / rows, r = e - j * rows;
+            x_colmajor[(size_t)j * n + row0 + r] = Xt[j * (SCL_ROWS + 1) + r];
+        }
     }
 }
 
@@ -274,75 +283,89 @@ __device__ __forceinline__ double block_sum_256(double v, double* red, int tid) 
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(ACC_ROWS) void accept_kernel(
+// Block = 256 threads = ACC_ROWS (64) walkers.  Wave 0 evaluates the Metropolis ratio of the block's
+// walkers; then all four waves copy the accepted rows (independent, unrolled loads) and take the
+// column sums on the fly.  The last block to arrive (agent-scope release -> ticket -> acquire) folds
+// the per-block partials in a fixed order, so the result is deterministic and needs no second launch.
+__global__ __launch_bounds__(256) void accept_kernel(
     int preconditioned, int tpcn, pmc_state_t cur, pmc_proposal_t prop, double beta, double nu,
     pmc_rng_t rng, double* __restrict__ alpha_out, int32_t* __restrict__ accept_out,
-    double* __restrict__ partials, int64_t n, int D) {
+    double* __restrict__ partials, unsigned* __restrict__ ticket, double* __restrict__ sums,
+    int64_t n, int D) {
     __shared__ int flag[ACC_ROWS];
-    __shared__ double red[4];
     __shared__ double colsum[8][33];
+    __shared__ int is_last;
     const int tid = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * ACC_ROWS;
     const int rows = (int)min((int64_t)ACC_ROWS, n - row0);
-    const int64_t k = row0 + tid;
+    const int W = D + 4;
+    double* P = partials + (size_t)blockIdx.x * W;
 
-    double alpha = 0.0, lp_post = 0.0, ldj_post = 0.0;
-    int acc = 0;
-    if (tid < rows) {
-        const double logl = cur.logl[k], logp = cur.logp[k], ldj = cur.logdetj[k];
-        const double logl_p = prop.logl[k], logp_p = prop.logp[k], ldj_p = prop.logdetj[k];
-        double e;
-        {
-            // mcmc.py:130-133, left to right
-            e = logl_p * beta - logl * beta + logp_p - logp + ldj_p - ldj;
-            if (preconditioned) e = e + (double)prop.logdetj_flow[k] - (double)cur.logdetj_flow[k];
-            if (tpcn) {
-                const double c = -((double)D + nu) / 2.0;
-                const double A = c * log(1.0 + prop.quad_prop[k] / nu);     // mcmc.py:128
-                const double B = c * log(1.0 + prop.quad[k] / nu);          // mcmc.py:129
-                e = e - A + B;
+    if (tid < 64) {
+        const int64_t k = row0 + tid;
+        double alpha = 0.0, lp_post = 0.0, ldj_post = 0.0;
+        int acc = 0;
+        if (tid < rows) {
+            const double logl = cur.logl[k], logp = cur.logp[k], ldj = cur.logdetj[k];
+            const double logl_p = prop.logl[k], logp_p = prop.logp[k], ldj_p = prop.logdetj[k];
+            double e;
+            {
+                // mcmc.py:130-133, left to right
+                e = logl_p * beta - logl * beta + logp_p - logp + ldj_p - ldj;
+                if (preconditioned) e = e + (double)prop.logdetj_flow[k] - (double)cur.logdetj_flow[k];
+                if (tpcn) {
+                    const double c = -((double)D + nu) / 2.0;
+                    const double A = c * log(1.0 + prop.quad_prop[k] / nu);     // mcmc.py:128
+                    const double B = c * log(1.0 + prop.quad[k] / nu);          // mcmc.py:129
+                    e = e - A + B;
+                }
             }
+            const double v = exp(e);
+            alpha = (v != v) ? 0.0 : (v < 1.0 ? v : 1.0);      // np.minimum(1, .); NaN -> 0 (mcmc.py:134)
+            double ur;
+            if (rng.uniform) ur = rng.uniform[k];
+            else { Philox ph(rng.seed, rng.step, rng.offset + k, 2); double d; ph.uniform2(ur, d); }
+            acc = ur < alpha;
+            if (acc) {
+                cur.logdetj[k] = ldj_p; cur.logl[k] = logl_p; cur.logp[k] = logp_p;
+                if (preconditioned) cur.logdetj_flow[k] = prop.logdetj_flow[k];
+            }
+            lp_post = acc ? (logl_p + logp_p) : (logl + logp);
+            ldj_post = lp_post + (acc ? ldj_p : ldj);             // logl + logp + logdetj (mcmc.py:243, :327)
+            if (alpha_out) alpha_out[k] = alpha;
+            if (accept_out) accept_out[k] = acc;
         }
-        const double v = exp(e);
-        alpha = (v != v) ? 0.0 : (v < 1.0 ? v : 1.0);      // np.minimum(1, .); NaN -> 0 (mcmc.py:134)
-        double ur;
-        if (rng.uniform) ur = rng.uniform[k];
-        else { Philox ph(rng.seed, rng.step, rng.offset + k, 2); double d; ph.uniform2(ur, d); }
-        acc = ur < alpha;
-        if (acc) {
-            cur.logdetj[k] = ldj_p; cur.logl[k] = logl_p; cur.logp[k] = logp_p;
-            if (preconditioned) cur.logdetj_flow[k] = prop.logdetj_flow[k];
+        flag[tid] = acc;
+        double s0 = alpha, s1 = lp_post, s2 = ldj_post, s3 = (double)acc;
+        for (int o = 32; o > 0; o >>= 1) {
+            s0 += __shfl_down(s0, o); s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); s3 += __shfl_down(s3, o);
         }
-        lp_post = acc ? (logl_p + logp_p) : (logl + logp);
-        ldj_post = lp_post + (acc ? ldj_p : ldj);             // logl + logp + logdetj (mcmc.py:243, :327)
-        if (alpha_out) alpha_out[k] = alpha;
-        if (accept_out) accept_out[k] = acc;
+        if (tid == 0) { P[0] = s0; P[1] = s1; P[2] = s2; P[3] = s3; }
     }
-    flag[tid] = acc;
-    const double s_alpha = block_sum_256(alpha, red, tid);
-    const double s_lp = block_sum_256(lp_post, red, tid);
-    const double s_ldj = block_sum_256(ldj_post, red, tid);
-    const double s_acc = block_sum_256((double)acc, red, tid);
-    double* P = partials + (size_t)blockIdx.x * (D + 4);
-    if (tid == 0) { P[0] = s_alpha; P[1] = s_lp; P[2] = s_ldj; P[3] = s_acc; }
+    __syncthreads();
 
-    // accepted rows overwrite theta / u / x; the column sums of the moved variable
-    // (theta for the preconditioned kernels, u otherwise) are taken on the fly
+    // accepted rows overwrite theta / u / x; column sums of the moved variable on the fly
     const int tx = tid & 31, ty = tid >> 5;
     for (int j0 = 0; j0 < D; j0 += 32) {
         const int j = j0 + tx;
         double csum = 0.0;
         if (j < D) {
-            for (int r = ty; r < rows; r += 8) {
-                const int64_t g = (row0 + r) * D + j;
-                const int a = flag[r];
-                if (a) { cur.u[g] = prop.u[g]; cur.x[g] = prop.x[g]; }
-                if (preconditioned) {
-                    float th = cur.theta32[g];
-                    if (a) { th = (float)prop.theta64[g]; cur.theta32[g] = th; }   // theta is a float32 array (tools.py:339)
-                    csum += (double)th;
-                } else {
-                    csum += a ? prop.u[g] : cur.u[g];
+#pragma unroll
+            for (int i = 0; i < ACC_ROWS / 8; ++i) {
+                const int r = ty + 8 * i;
+                if (r < rows) {
+                    const int64_t g = (row0 + r) * D + j;
+                    const int a = flag[r];
+                    const double pu = prop.u[g], px = prop.x[g];
+                    if (a) { cur.u[g] = pu; cur.x[g] = px; }
+                    if (preconditioned) {
+                        const float th_new = (float)prop.theta64[g];            // theta is a float32 array (tools.py:339)
+                        const float th_old = cur.theta32[g];
+                        if (a) cur.theta32[g] = th_new;
+                        csum += (double)(a ? th_new : th_old);
+                    } else {
+                        csum += a ? pu : cur.u[g];
+                    }
                 }
             }
         }
@@ -355,15 +378,39 @@ __global__ __launch_bounds__(ACC_ROWS) void accept_kernel(
         }
         __syncthreads();
     }
-}
 
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials,
-                                                              double* __restrict__ sums, int nblocks, int width) {
-    for (int c = threadIdx.x; c < width; c += 256) {
-        double t = 0.0;
-        for (int b = 0; b < nblocks; ++b) t += partials[(size_t)b * width + c];
-        sums[c] = t;
+    // ---- publish this block's partials, draw a ticket; the last arriver reduces (guide G16)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (t == gridDim.x - 1);
+        if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
+    __syncthreads();
+    if (!is_last) return;
+    const int nb = gridDim.x;
+    __shared__ double fold[256];
+    for (int c0 = 0; c0 < W; c0 += 256) {
+        // S threads per column, each folding every S-th block; then the S partial sums in order
+        const int Wc = min(256, W - c0);
+        const int S = max(1, 256 / Wc);
+        const int c = tid % Wc, sidx = tid / Wc;
+        double t = 0.0;
+        if (sidx < S)
+            for (int b2 = sidx; b2 < nb; b2 += S) t += partials[(size_t)b2 * W + c0 + c];
+        fold[tid] = (sidx < S) ? t : 0.0;
+        __syncthreads();
+        if (tid < Wc) {
+            double tot = 0.0;
+            for (int s2 = 0; s2 < S; ++s2) tot += fold[s2 * Wc + tid];
+            sums[c0 + tid] = tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *ticket = 0u;       // ready for the next launch (the caller zeroes it once at allocation)
 }
 
 // ===========================================================================
@@ -520,6 +567,11 @@ extern "C" int pmc_propose(int kind, const float* cur32, const double* cur64, co
     if (kind == PMC_KIND_TPCN && (!mu || !inv_cov)) return pmc_fail("pmc_propose: tpCN needs mu and inv_cov");
     if (kind != PMC_KIND_TPCN && kind != PMC_KIND_RWM) return pmc_fail("pmc_propose: unknown kind");
     if (!prop64 && !prop32) return pmc_fail("pmc_propose: no output");
+    {   // f64 matrix-core kernel (D <= 128); the LDS-staged VALU kernel below covers larger D
+        const int rc = pmc_launch_propose_mfma(kind, cur32, cur64, mu, inv_cov, chol, nu, sigma, cn_a, rng, prop64,
+                                               prop32, quad, quad_prop, n, D, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     const size_t lds = (size_t)2 * D * (PROP_ROWS + 1) * sizeof(double);
     if (lds > 160 * 1024) return pmc_fail("pmc_propose: n_dim too large for the LDS-staged proposal");
     if (lds > 48 * 1024) {
@@ -541,12 +593,14 @@ static int check_scaler(const pmc_scaler_t* s) {
 }
 
 extern "C" int pmc_scaler_inverse(const pmc_scaler_t* s, const float* u_in, const double* u_in64, double* u_out,
-                                  double* x, double* logdetj, int32_t* finite, int64_t n, void* stream) {
+                                  double* x, double* x_colmajor, double* logdetj, int32_t* finite, int64_t n,
+                                  void* stream) {
     if (int e = check_scaler(s)) return e;
     if (n == 0) return 0;
     if ((!u_in) == (!u_in64)) return pmc_fail("pmc_scaler_inverse: exactly one of u_in / u_in64 must be given");
     if (!u_out || !x || !logdetj || !finite || n < 0) return pmc_fail("pmc_scaler_inverse: bad argument");
-    const size_t lds = (size_t)SCL_ROWS * s->D * sizeof(double) + SCL_ROWS * sizeof(int);
+    const size_t lds = (size_t)SCL_ROWS * s->D * sizeof(double) + SCL_ROWS * sizeof(int) +
+                       (x_colmajor ? (size_t)s->D * (SCL_ROWS + 1) * sizeof(double) : 0);
     if (lds > 160 * 1024 || s->D > 1024) return pmc_fail("pmc_scaler_inverse: n_dim too large");
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scaler_inverse_kernel),
@@ -554,7 +608,7 @@ extern "C" int pmc_scaler_inverse(const pmc_scaler_t* s, const float* u_in, cons
         if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(scaler_inverse_kernel)");
     }
     hipLaunchKernelGGL(scaler_inverse_kernel, dim3((unsigned)((n + SCL_ROWS - 1) / SCL_ROWS)), dim3(256), lds,
-                       (hipStream_t)stream, *s, u_in, u_in64, u_out, x, logdetj, finite, n);
+                       (hipStream_t)stream, *s, u_in, u_in64, u_out, x, x_colmajor, logdetj, finite, n);
     return pmc_check_launch("scaler_inverse_kernel");
 }
 
@@ -569,7 +623,7 @@ extern "C" int pmc_scaler_forward(const pmc_scaler_t* s, const double* x, double
 
 extern "C" int64_t pmc_accept_workspace_bytes(int64_t n, int32_t D) {
     const int64_t nb = (n + ACC_ROWS - 1) / ACC_ROWS;
-    return (nb > 0 ? nb : 1) * (int64_t)(D + 4) * (int64_t)sizeof(double);
+    return 64 + (nb > 0 ? nb : 1) * (int64_t)(D + 4) * (int64_t)sizeof(double);   // [ticket | partials]
 }
 
 extern "C" int pmc_accept(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposal_t* prop, double beta,
@@ -583,13 +637,18 @@ extern "C" int pmc_accept(int kind, int preconditioned, pmc_state_t* cur, const 
         return pmc_fail("pmc_accept: preconditioned kernels need theta and logdetj_flow");
     const int tpcn = (kind == PMC_KIND_TPCN);
     if (tpcn && (!prop->quad || !prop->quad_prop)) return pmc_fail("pmc_accept: tpCN needs the quadratic forms");
-    if (D > 32 * 8 * 4096) return pmc_fail("pmc_accept: n_dim too large");
+    hipStream_t st = (hipStream_t)stream;
     const int nb = (int)((n + ACC_ROWS - 1) / ACC_ROWS);
-    if (nb > 0)
-        hipLaunchKernelGGL(accept_kernel, dim3(nb), dim3(ACC_ROWS), 0, (hipStream_t)stream, preconditioned, tpcn,
-                           *cur, *prop, beta, nu, *rng, alpha_out, accept_out, (double*)workspace, n, (int)D);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
-                       (const double*)workspace, sums, nb, (int)D + 4);
+    unsigned* ticket = (unsigned*)workspace;
+    double* partials = (double*)((char*)workspace + 64);
+    if (nb == 0) {
+        if (hipMemsetAsync(sums, 0, (size_t)(D + 4) * sizeof(double), st) != hipSuccess) return pmc_fail("pmc_accept: memset");
+        return 0;
+    }
+    // the ticket word is re-armed by every call (a memset node ahead of the launch): no state between calls
+    if (hipMemsetAsync(ticket, 0, sizeof(unsigned), st) != hipSuccess) return pmc_fail("pmc_accept: memset");
+    hipLaunchKernelGGL(accept_kernel, dim3(nb), dim3(256), 0, st, preconditioned, tpcn, *cur, *prop, beta, nu, *rng,
+                       alpha_out, accept_out, partials, ticket, sums, n, (int)D);
     return pmc_check_launch("accept_kernel");
 }
 

@@ -8,5 +8,12 @@
 int pmc_fail(const char* msg);
 int pmc_fail_hip(hipError_t e, const char* what);
 int pmc_check_launch(const char* what);
+int pmc_launch_inverse_tri2(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, size_t lds,
+                            hipStream_t stream);
+
+int pmc_launch_propose_mfma(int kind, const float* cur32, const double* cur64, const double* mu,
+                            const double* inv_cov, const double* chol, double nu, double sigma, double cn_a,
+                            const pmc_rng_t* rng, double* prop64, float* prop32, double* quad, double* quad_prop,
+                            int64_t n, int32_t D, hipStream_t stream);
 
 #endif

@@ -21,6 +21,7 @@ every rank.
 from __future__ import annotations
 
 import ctypes as C
+import time
 
 import numpy as np
 import torch
@@ -99,7 +100,10 @@ def allreduce_sums(sums_dev, group=None):
 class StepEngine:
     """Device-resident state + buffers of one MCMC kernel call."""
 
-    def __init__(self, kind, n, n_dim, flow, scaler, device=None, group=None, shard_offset=0, seed=0):
+    def __init__(self, kind, n, n_dim, flow, scaler, device=None, group=None, shard_offset=0, seed=0,
+                 x_order="C"):
+        """``x_order='F'`` hands the host callbacks x' as an (n, D) Fortran-ordered array (same
+        values; numpy's inner loops then run over the n walkers instead of over D)."""
         assert kind in KINDS
         self.kind = kind
         self.pre = kind.startswith("preconditioned")
@@ -139,10 +143,18 @@ class StepEngine:
         self.r_gamma, self.r_normal, self.r_uniform = f64(n), f64(n, D), f64(n)
         # pinned host mirrors
         pin = lambda *s, dt=torch.float64: torch.empty(*s, dtype=dt).pin_memory()
-        self.h_x, self.h_fin = pin(n, D), pin(n, dt=torch.int32)
+        assert x_order in ("C", "F")
+        self.x_order = x_order
+        self.p_xT = f64(D, n) if x_order == "F" else None
+        self.h_x, self.h_fin = (pin(D, n) if x_order == "F" else pin(n, D)), pin(n, dt=torch.int32)
         self.h_logl, self.h_logp = pin(n), pin(n)
         self.h_sums = pin(D + 4)
         self.h_accept = pin(n, dt=torch.int32)
+        self.h_mu = pin(D)
+        self._np_x = self.h_x.numpy().T if x_order == "F" else self.h_x.numpy()
+        self._np_fin = self.h_fin.numpy()
+        self._np_logl, self._np_logp = self.h_logl.numpy(), self.h_logp.numpy()
+        self._np_mu, self._np_sums = self.h_mu.numpy(), self.h_sums.numpy()
         self.scaler_desc = scaler.device_descriptor()
         self._state = _lib.pmc_state_t(
             theta32=self.theta32.data_ptr() if self.pre else None, u=self.u.data_ptr(), x=self.x.data_ptr(),
@@ -154,7 +166,10 @@ class StepEngine:
             logdetj_flow=self.p_ldjf.data_ptr() if self.pre else None,
             quad=self.quad.data_ptr() if self.tpcn else None, quad_prop=self.p_quad.data_ptr() if self.tpcn else None)
         self.step_idx = 0
+        self.host_threads = 1    # >1: evaluate the black boxes on row chunks in a thread pool
+        self._pool = None
         self.events = None       # bench.py: list of per-step HIP event tuples when not None
+        self.host_timers = None  # bench.py: dict of accumulated host seconds when not None
 
     def _ev(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -185,7 +200,10 @@ class StepEngine:
             self.set_mu(mu)
 
     def set_mu(self, mu):
-        self.mu_d.copy_(torch.from_numpy(np.ascontiguousarray(mu, dtype=np.float64)))
+        # pinned staging + async copy; the previous upload was consumed by a kernel that has
+        # completed (accept_reduce synchronises) before the host buffer is rewritten
+        self._np_mu[:] = mu
+        self.mu_d.copy_(self.h_mu, non_blocking=True)
 
     # ----------------------------------------------------------------- step
     def _rng(self, replay):
@@ -223,14 +241,16 @@ class StepEngine:
                                                _lib.ptr(self.p_ldjf), n, self.flow.inverse_algo, st), "pmc_maf_inverse")
                 e2 = self._ev() if timed else None
                 _lib.check(lib.pmc_scaler_inverse(C.byref(self.scaler_desc), _lib.ptr(self.p_u32), None,
-                                                  _lib.ptr(self.p_u), _lib.ptr(self.p_x), _lib.ptr(self.p_logdetj),
+                                                  _lib.ptr(self.p_u), _lib.ptr(self.p_x), _lib.ptr(self.p_xT),
+                                                  _lib.ptr(self.p_logdetj),
                                                   _lib.ptr(self.p_fin), n, st), "pmc_scaler_inverse")
             else:
                 _lib.check(lib.pmc_scaler_inverse(C.byref(self.scaler_desc), None, _lib.ptr(self.p_theta64),
-                                                  _lib.ptr(self.p_u), _lib.ptr(self.p_x), _lib.ptr(self.p_logdetj),
+                                                  _lib.ptr(self.p_u), _lib.ptr(self.p_x), _lib.ptr(self.p_xT),
+                                                  _lib.ptr(self.p_logdetj),
                                                   _lib.ptr(self.p_fin), n, st), "pmc_scaler_inverse")
             e3 = self._ev() if timed else None
-        self.h_x.copy_(self.p_x, non_blocking=True)
+        self.h_x.copy_(self.p_xT if self.x_order == "F" else self.p_x, non_blocking=True)
         self.h_fin.copy_(self.p_fin, non_blocking=True)
         if timed:
             self._cur_ev = [e0, e1, e2, e3, self._ev()]
@@ -238,16 +258,70 @@ class StepEngine:
     def evaluate(self, log_prior, log_like, have_blobs=False, blobs=None):
         """Host black boxes on the compacted rows, ``mcmc.py:100-121``.  Returns
         ``(n_calls, blobs_prime)``."""
+        tm = self.host_timers
+        t0 = time.perf_counter() if tm is not None else 0.0
         torch.cuda.current_stream().synchronize()
+        if tm is not None:
+            t1 = time.perf_counter(); tm["wait_device"] += t1 - t0
+            _lp, _ll = log_prior, log_like
+
+            def log_prior(a, _f=_lp):
+                ta = time.perf_counter(); r = _f(a); tm["prior"] += time.perf_counter() - ta
+                return r
+
+            def log_like(a, _f=_ll):
+                ta = time.perf_counter(); r = _f(a); tm["likelihood"] += time.perf_counter() - ta
+                return r
         n = self.n
-        x_prime = self.h_x.numpy()
-        finite = self.h_fin.numpy().astype(bool)
-        logp_prime = self.h_logp.numpy()
-        logl_prime = self.h_logl.numpy()
-        logp_prime[finite] = log_prior(x_prime[finite])
-        logp_prime[~finite] = -np.inf
-        finite = finite & np.isfinite(logp_prime)
+        x_prime = self._np_x
+        logp_prime = self._np_logp
+        logl_prime = self._np_logl
+        fin_i = self._np_fin
         blobs_prime = None
+        if fin_i.all() and self.host_threads > 1 and not have_blobs:
+            # rows are independent for a vectorised likelihood (the reference itself calls it on
+            # arbitrary compacted subsets, mcmc.py:106,117): evaluate row chunks concurrently
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=self.host_threads)
+            k = self.host_threads
+            bounds = [(i * n // k, (i + 1) * n // k) for i in range(k)]
+
+            def work(b):
+                lo, hi = b
+                xs = x_prime[lo:hi]
+                lp = log_prior(xs)
+                logp_prime[lo:hi] = lp
+                ok = np.isfinite(lp)
+                if ok.all():
+                    logl_prime[lo:hi] = log_like(xs)[0]
+                    return hi - lo
+                ll = np.full(hi - lo, -np.inf)
+                ll[ok] = log_like(xs[ok])[0]
+                logl_prime[lo:hi] = ll
+                return int(ok.sum())
+            calls = sum(self._pool.map(work, bounds))
+            self.p_logl.copy_(self.h_logl, non_blocking=True)
+            self.p_logp.copy_(self.h_logp, non_blocking=True)
+            return calls, None
+        if fin_i.all():
+            # every proposal is finite (the usual case): x'[mask] of mcmc.py:106 is x' itself
+            logp_prime[:] = log_prior(x_prime)
+            finite = np.isfinite(logp_prime)
+            if finite.all():
+                if have_blobs:
+                    blobs_prime = np.empty(n, dtype=np.dtype((blobs[0].dtype, blobs[0].shape)))
+                    logl_prime[:], blobs_prime[:] = log_like(x_prime)
+                else:
+                    logl_prime[:], _ = log_like(x_prime)
+                self.p_logl.copy_(self.h_logl, non_blocking=True)
+                self.p_logp.copy_(self.h_logp, non_blocking=True)
+                return n, blobs_prime
+        else:
+            finite = fin_i.astype(bool)
+            logp_prime[finite] = log_prior(x_prime[finite])
+            logp_prime[~finite] = -np.inf
+            finite = finite & np.isfinite(logp_prime)
         if have_blobs:
             blobs_prime = np.empty(n, dtype=np.dtype((blobs[0].dtype, blobs[0].shape)))
             logl_prime[finite], blobs_prime[finite] = log_like(x_prime[finite])
@@ -276,7 +350,7 @@ class StepEngine:
             self.h_accept.copy_(self.accept, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         self.step_idx += 1
-        return self.h_sums.numpy()
+        return self._np_sums
 
     def download(self):
         g = lambda t: t.cpu().numpy()

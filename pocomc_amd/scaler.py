@@ -144,6 +144,6 @@ class Reparameterize:
         fin = torch.empty(n, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pmc_scaler_inverse(C.byref(desc), None, _lib.ptr(ud), _lib.ptr(uo), _lib.ptr(xo),
-                                                   _lib.ptr(ldj), _lib.ptr(fin), n, _lib.stream_handle()),
+                                                   None, _lib.ptr(ldj), _lib.ptr(fin), n, _lib.stream_handle()),
                        "pmc_scaler_inverse")
         return xo.cpu().numpy(), ldj.cpu().numpy()
