@@ -67,6 +67,33 @@ int pmc_maf_forward(const pmc_maf_t* m, const float* x, float* z, float* ladj, f
 int pmc_maf_inverse(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
                     int algo, void* stream);
 
+/* Training-side device image (host side: MAFSpec.train_index()). */
+typedef struct pmc_maf_train {
+    const float* packedT;     /* transposed weight fragments, filled by pmc_maf_pack with the packT map */
+    const int32_t* gmap;      /* canonical index of every weight-gradient tile element, -1 = masked */
+    int64_t pkT_per_transform;
+    int64_t gmap_per_transform;
+} pmc_maf_train_t;
+
+/* One minibatch of Flow.fit, pocomc/flow.py:297-323: loss and parameter gradient.
+ *   loss += sum_n c_n * (-log_prob(x_n));  c_n = 1 (w == NULL, flow.py:309) or
+ *   c_n = w_n * wmul / *wsum (flow.py:311-312 with wmul = 1000, *wsum = sum of the batch weights).
+ * x f32 [n][D]; w f32 [n] or NULL; wsum f32 [1] (device); grad f32 [n_params] in the canonical
+ * layout and loss f32 [1] are ACCUMULATED (caller zeroes them). */
+int pmc_maf_loss_grad(const pmc_maf_t* m, const pmc_maf_train_t* tr, const float* x, const float* w,
+                      const float* wsum, float wmul, float* grad, float* loss, int64_t n, void* stream);
+
+/* out += sum_n -(logp_n * c_n)  (validation loss, flow.py:336-341);  out += sum_n v_n. */
+int pmc_neg_weighted_sum(const float* logp, const float* w, const float* wsum, float wmul, float* out,
+                         int64_t n, void* stream);
+int pmc_sum_f32(const float* v, float* out, int64_t n, void* stream);
+
+/* torch.nn.utils.clip_grad_norm_(max_norm) (flow.py:318; max_norm <= 0 disables) followed by one
+ * torch.optim.AdamW step (flow.py:268, :319).  step counts from 1.  sqnorm_scratch f32 [1]. */
+int pmc_adamw_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   double lr, double beta1, double beta2, double eps, double weight_decay,
+                   double max_norm, int64_t step, float* sqnorm_scratch, void* stream);
+
 /* ---------------------------------------------------------------- scaler */
 
 /* pocomc/scaler.py Reparameterize with the Sampler's settings (diagonal affine,
@@ -177,6 +204,14 @@ int pmc_logw(const double* logl, const double* beta, const double* logz, double 
  * workspace: pmc_reduce_workspace_bytes(P). */
 int64_t pmc_reduce_workspace_bytes(int64_t P);
 int pmc_logw_stats(const double* logw, int64_t P, int64_t k, double* stats, void* workspace, void* stream);
+
+/* trim_weights, tools.py:10-53: the weight threshold the reference's downward percentile scan stops at.
+ * w f64 [P] (normalised; not modified); result f64 [2] <- { threshold, index of the accepted percentile bin };
+ * the caller keeps the samples with w >= threshold (tools.py:38-39).  One radix sort + two scans
+ * instead of up to `bins` np.percentile passes.  workspace: pmc_trim_workspace_bytes(P). */
+int64_t pmc_trim_workspace_bytes(int64_t P);
+int pmc_trim_threshold(const double* w, int64_t P, double ess, int32_t bins, double* result,
+                       void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Sampler._resample gather, sampler.py:707-713: dst[i] = src[idx[i]] for the five arrays. */
 int pmc_gather(const int64_t* idx, int64_t n_out, int32_t D, const double* u, const double* x,

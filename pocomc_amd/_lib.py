@@ -24,6 +24,11 @@ class pmc_maf_t(C.Structure):
                 ("tri_ok", C.c_int32), ("reserved", C.c_int32)]
 
 
+class pmc_maf_train_t(C.Structure):
+    _fields_ = [("packedT", c_p), ("gmap", c_p), ("pkT_per_transform", C.c_int64),
+                ("gmap_per_transform", C.c_int64)]
+
+
 class pmc_scaler_t(C.Structure):
     _fields_ = [("low", c_p), ("high", c_p), ("mu", c_p), ("sigma", c_p),
                 ("kind", c_p), ("bc", c_p), ("log_width", c_p),
@@ -56,6 +61,10 @@ SIGNATURES = {
     "pmc_maf_pack": (C.c_int, [c_p, c_p, c_p, i64, c_p]),
     "pmc_maf_forward": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, c_p, i64, c_p]),
     "pmc_maf_inverse": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, i64, C.c_int, c_p]),
+    "pmc_maf_loss_grad": (C.c_int, [P(pmc_maf_t), P(pmc_maf_train_t), c_p, c_p, c_p, C.c_float, c_p, c_p, i64, c_p]),
+    "pmc_neg_weighted_sum": (C.c_int, [c_p, c_p, c_p, C.c_float, c_p, i64, c_p]),
+    "pmc_sum_f32": (C.c_int, [c_p, c_p, i64, c_p]),
+    "pmc_adamw_step": (C.c_int, [c_p, c_p, c_p, c_p, i64, f64, f64, f64, f64, f64, f64, i64, c_p, c_p]),
     "pmc_scaler_inverse": (C.c_int, [P(pmc_scaler_t), c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
     "pmc_scaler_forward": (C.c_int, [P(pmc_scaler_t), c_p, c_p, i64, c_p]),
     "pmc_propose": (C.c_int, [C.c_int, c_p, c_p, c_p, c_p, c_p, f64, f64, f64, P(pmc_rng_t),
@@ -66,6 +75,8 @@ SIGNATURES = {
     "pmc_logw": (C.c_int, [c_p, c_p, c_p, f64, c_p, i32, i64, c_p]),
     "pmc_reduce_workspace_bytes": (i64, [i64]),
     "pmc_logw_stats": (C.c_int, [c_p, i64, i64, c_p, c_p, c_p]),
+    "pmc_trim_workspace_bytes": (i64, [i64]),
+    "pmc_trim_threshold": (C.c_int, [c_p, i64, f64, i32, c_p, c_p, i64, c_p]),
     "pmc_gather": (C.c_int, [c_p, i64, i32] + [c_p] * 10 + [c_p]),
     "pmc_resample_multinomial": (C.c_int, [c_p, i64, c_p, i64, c_p, c_p, c_p]),
     "pmc_resample_systematic": (C.c_int, [c_p, i64, f64, i64, c_p, c_p, c_p]),

@@ -41,35 +41,8 @@ __device__ __forceinline__ float maf_dense_pass(const pmc_maf_t& m, const MafVie
                                                 float* H0, float* H1, float* H2,
                                                 int lane, bool want_ladj) {
     const int q = lane >> 4, p = lane & 15;
-    const int nT = m.nT, nXT = m.nXT, nOT = m.nOT, D = m.D;
-    // layer 0
-    for (int T = 0; T < nT; ++T) {
-        f32x4 a = bias4(w.b0, 16 * T + 4 * q);
-        for (int X = 0; X < nXT; ++X) a = tile_mac(a, w.f0 + (size_t)T * nXT * 64, xin, X, lane);
-        for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.0f);
-        store_rows(H0, T, q, p, a);
-    }
-    __syncthreads();
-    // layers 1, 2: h' = relu(h + W h + b).  Units are sorted by degree, so tile T
-    // only reads tiles <= T unless a degree group is wider than a tile.
-    for (int layer = 1; layer <= 2; ++layer) {
-        const float* Hin = layer == 1 ? H0 : H1;
-        float* Hout = layer == 1 ? H1 : H2;
-        const float4* f = layer == 1 ? w.f1 : w.f2;
-        const float* b = layer == 1 ? w.b1 : w.b2;
-        for (int T = 0; T < nT; ++T) {
-            f32x4 a = bias4(b, 16 * T + 4 * q);
-            const int kend = m.tri_ok ? T + 1 : nT;
-            for (int K = 0; K < kend; ++K) a = tile_mac(a, f + (size_t)T * nT * 64, Hin, K, lane);
-            const float* hb = Hin + (T << 8) + (p << 2) + q;
-            a[0] = fmaxf(a[0] + hb[0], 0.0f);
-            a[1] = fmaxf(a[1] + hb[64], 0.0f);
-            a[2] = fmaxf(a[2] + hb[128], 0.0f);
-            a[3] = fmaxf(a[3] + hb[192], 0.0f);
-            store_rows(Hout, T, q, p, a);
-        }
-        __syncthreads();
-    }
+    const int nT = m.nT, nOT = m.nOT, D = m.D;
+    maf_hidden_pass(m, w, xin, H0, H1, H2, lane);
     float ladj = 0.0f;
     for (int O = 0; O < nOT; ++O) {
         if (8 * O >= D) break;

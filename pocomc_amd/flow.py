@@ -71,6 +71,19 @@ class Flow:
         self.inverse_algo = 0          # PMC_INVERSE_AUTO
         self.repack()
 
+    # ---------------------------------------------------------- checkpoints
+    def __getstate__(self):
+        """Plain tensors instead of device handles (the reference pickles the whole zuko module,
+        sampler.py:1023-1049)."""
+        return {"n_dim": self.n_dim, "spec": (self.spec.n_dim, self.spec.n_transforms, self.spec.hidden),
+                "params": self.params.detach().cpu().numpy(), "inverse_algo": self.inverse_algo}
+
+    def __setstate__(self, st):
+        spec = MAFSpec(*st["spec"])
+        self.__init__(st["n_dim"], spec)
+        self.set_params(st["params"])
+        self.inverse_algo = st.get("inverse_algo", 0)
+
     # ------------------------------------------------------------ parameters
     def repack(self):
         """Refresh the kernel-layout image after ``params`` changed."""
@@ -144,7 +157,8 @@ class Flow:
         """``pocomc/flow.py:149-163``: ``(samples, log_prob)``.  ``z`` replays the
         base draw (tests)."""
         if z is None:
-            z = torch.randn(int(size), self.n_dim, dtype=torch.float32, device=self.device)
+            # base draw from torch's global CPU generator, like zuko's rsample under torch.manual_seed
+            z = torch.randn(int(size), self.n_dim, dtype=torch.float32)
         zd, src = self._in(z)
         x, ladj_inv = self.inverse(zd)
         base = -0.5 * (zd * zd).sum(dim=1) - 0.5 * self.n_dim * float(np.log(2 * np.pi))

@@ -317,6 +317,122 @@ class MAFSpec:
         r_o_f = np.concatenate(self.orders).astype(np.int32)
         return np.concatenate([hdr, f_o_r, r_o_f, self.quad_meta]).astype(np.int32)
 
+    # ------------------------------------------------------------- training
+    def train_layout(self):
+        """Sizes of the training-side device arrays, per transform.
+
+        ``packedT`` (float): transposed weight fragments for the data-gradient products
+        ``dh = W^T da``:  f0T [nXT][nT], f1T/f2T [nT][nT], f3T [nT][nOT], each ``[..][..][lane][4]``
+        with ``A[i][k] = W[out 16*To + 4c + k][in 16*Ti + i]``.
+        ``gmap`` (int32): canonical index of every element of a weight-gradient tile in MFMA C
+        layout (lane (q, j) reg r <-> W[out 16*To + 4q + r][in 16*Ti + j]), -1 = masked / padding:
+        g0 [nT][nXT], g1/g2 [nT][nT], g3 [nOT][nT], then the bias maps b0,b1,b2 [Hp], b3 [Op].
+        """
+        nT, nXT, nOT = self.nT, self.nXT, self.nOT
+        szT = {"f0T": nXT * nT * 256, "f1T": nT * nT * 256, "f2T": nT * nT * 256, "f3T": nT * nOT * 256}
+        szG = {"g0": nT * nXT * 256, "g1": nT * nT * 256, "g2": nT * nT * 256, "g3": nOT * nT * 256,
+               "gb0": self.Hp, "gb1": self.Hp, "gb2": self.Hp, "gb3": self.Op}
+        offT, o = {}, 0
+        for k, v in szT.items():
+            offT[k] = o
+            o += v
+        pkT = o
+        offG, o = {}, 0
+        for k, v in szG.items():
+            offG[k] = o
+            o += v
+        return dict(szT=szT, offT=offT, pkT_per_transform=pkT, szG=szG, offG=offG, gmap_per_transform=o)
+
+    def train_index(self):
+        """``(packT_idx, gmap)``: gather map for ``packedT`` (like ``pack_index``) and the
+        gradient scatter map, both int32, all transforms concatenated."""
+        D, H, Hp = self.n_dim, self.hidden, self.Hp
+        nT, nXT, nOT = self.nT, self.nXT, self.nOT
+        L = self.train_layout()
+        pT = np.full(L["pkT_per_transform"] * self.n_transforms, -1, dtype=np.int64)
+        gm = np.full(L["gmap_per_transform"] * self.n_transforms, -1, dtype=np.int64)
+        lane = np.arange(64)
+        li, lk = lane & 15, lane >> 4
+        su = self.slot_unit
+        for t in range(self.n_transforms):
+            base_c = t * self.params_per_transform
+            rank = self.orders[t]
+            feat_of_rank = np.argsort(rank)
+            M0, M1, M2, M3 = self.masks(t)
+
+            def cidx(name, row, col, ncol, mask):
+                off, _ = self.offsets[name]
+                ok = (row >= 0) & (col >= 0)
+                r = np.where(ok, row, 0)
+                c = np.where(ok, col, 0)
+                ok = ok & mask[r, c]
+                return np.where(ok, base_c + off + r * ncol + c, -1)
+
+            def feat(r_in):
+                return np.where(r_in < D, feat_of_rank[np.minimum(r_in, D - 1)], -1)
+
+            def orow(o):
+                r_out, s = o >> 1, o & 1
+                return np.where(r_out < D, 2 * feat_of_rank[np.minimum(r_out, D - 1)] + s, -1)
+
+            # ---- transposed fragments: A[i = lane&15][k = lane>>4], component c
+            f0T = np.full((nXT, nT, 64, 4), -1, dtype=np.int64)
+            f1T = np.full((nT, nT, 64, 4), -1, dtype=np.int64)
+            f2T = np.full((nT, nT, 64, 4), -1, dtype=np.int64)
+            f3T = np.full((nT, nOT, 64, 4), -1, dtype=np.int64)
+            for To in range(nT):
+                for c in range(4):
+                    out_u = su[16 * To + 4 * c + lk]
+                    for Xi in range(nXT):
+                        f0T[Xi, To, :, c] = cidx("W0", out_u, feat(16 * Xi + li), D, M0)
+                    for Ti in range(nT):
+                        in_u = su[16 * Ti + li]
+                        f1T[Ti, To, :, c] = cidx("W1", out_u, in_u, H, M1)
+                        f2T[Ti, To, :, c] = cidx("W2", out_u, in_u, H, M2)
+            for O in range(nOT):
+                for c in range(4):
+                    crow = orow(16 * O + 4 * c + lk)
+                    for Ki in range(nT):
+                        f3T[Ki, O, :, c] = cidx("W3", crow, su[16 * Ki + li], H, M3)
+            # ---- gradient scatter: lane (q = lane>>4, j = lane&15), reg r
+            g0 = np.full((nT, nXT, 64, 4), -1, dtype=np.int64)
+            g1 = np.full((nT, nT, 64, 4), -1, dtype=np.int64)
+            g2 = np.full((nT, nT, 64, 4), -1, dtype=np.int64)
+            g3 = np.full((nOT, nT, 64, 4), -1, dtype=np.int64)
+            for To in range(nT):
+                for r in range(4):
+                    out_u = su[16 * To + 4 * lk + r]
+                    for Xi in range(nXT):
+                        g0[To, Xi, :, r] = cidx("W0", out_u, feat(16 * Xi + li), D, M0)
+                    for Ti in range(nT):
+                        in_u = su[16 * Ti + li]
+                        g1[To, Ti, :, r] = cidx("W1", out_u, in_u, H, M1)
+                        g2[To, Ti, :, r] = cidx("W2", out_u, in_u, H, M2)
+            for O in range(nOT):
+                for r in range(4):
+                    crow = orow(16 * O + 4 * lk + r)
+                    for Ki in range(nT):
+                        g3[O, Ki, :, r] = cidx("W3", crow, su[16 * Ki + li], H, M3)
+
+            def bidx(name):
+                off, _ = self.offsets[name]
+                return np.where(su >= 0, base_c + off + np.maximum(su, 0), -1)
+
+            gb3 = np.full(self.Op, -1, dtype=np.int64)
+            off3, _ = self.offsets["b3"]
+            for r in range(D):
+                gb3[2 * r] = base_c + off3 + 2 * feat_of_rank[r]
+                gb3[2 * r + 1] = base_c + off3 + 2 * feat_of_rank[r] + 1
+            bT, bG = t * L["pkT_per_transform"], t * L["gmap_per_transform"]
+            for name, arr in (("f0T", f0T), ("f1T", f1T), ("f2T", f2T), ("f3T", f3T)):
+                a = arr.reshape(-1)
+                pT[bT + L["offT"][name]: bT + L["offT"][name] + a.size] = a
+            for name, arr in (("g0", g0), ("g1", g1), ("g2", g2), ("g3", g3), ("gb0", bidx("b0")),
+                              ("gb1", bidx("b1")), ("gb2", bidx("b2")), ("gb3", gb3)):
+                a = arr.reshape(-1)
+                gm[bG + L["offG"][name]: bG + L["offG"][name] + a.size] = a
+        return pT.astype(np.int32), gm.astype(np.int32)
+
     # ------------------------------------------------------------ accounting
     def flops_forward_dense(self) -> int:
         """``F_fwd = T*2*(3*D*H + 2*H*H)`` per particle."""

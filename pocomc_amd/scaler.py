@@ -63,6 +63,17 @@ class Reparameterize:
         self._dev = None
         self._desc = None
 
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        for k in ("lib", "device", "_dev", "_desc"):
+            st.pop(k, None)
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self.lib = _lib.load()
+        self.device, self._dev, self._desc = None, None, None
+
     # ---------------------------------------------------------- descriptor
     def _descriptor(self, scale=None):
         """(Re)build the device image; ``scale`` overrides ``self.scale``."""

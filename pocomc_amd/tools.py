@@ -53,6 +53,27 @@ def compute_logw_and_logz(logl, beta, logz, beta_final=1.0, normalize=True):
     return logw, logz_new
 
 
+def trim_weights(samples, weights, ess=0.99, bins=1000):
+    """``pocomc/tools.py:10-53`` (normalises ``weights`` in place like the reference).  The
+    threshold search runs on the GPU (``pmc_trim_threshold``); the final mask / renormalisation
+    are the reference's own two lines."""
+    lib = _lib.load()
+    weights /= np.sum(weights)
+    wd = _up(weights)
+    P = wd.numel()
+    nbytes = int(lib.pmc_trim_workspace_bytes(P))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=wd.device)
+    res = torch.zeros(2, dtype=torch.float64, device=wd.device)
+    with torch.cuda.device(wd.device):
+        _lib.check(lib.pmc_trim_threshold(_lib.ptr(wd), P, float(ess), int(bins), _lib.ptr(res), _lib.ptr(ws), nbytes,
+                                          _lib.stream_handle()), "pmc_trim_threshold")
+    threshold = float(res[0].item())
+    mask = weights >= threshold
+    weights_trimmed = weights[mask]
+    weights_trimmed /= np.sum(weights_trimmed)
+    return samples[mask], weights_trimmed
+
+
 def effective_sample_size(weights):
     """``pocomc/tools.py:56-71`` (normalises ``weights`` in place like the reference)."""
     weights /= np.sum(weights)

@@ -1,6 +1,222 @@
-"""Flow training loop -- host-side mirror of ``pocomc/flow.py:165-384`` (placeholder:
-the fwd+bwd+AdamW kernels are the next milestone)."""
+"""Flow training -- host-side mirror of ``Flow.fit`` (``pocomc/flow.py:165-384``).
+
+The loop structure, the split quirk (``validation_split`` is the TRAIN fraction,
+``flow.py:248-249``), the weighted loss (``:311-312``), global-norm clipping (``:318``),
+AdamW (``:268``), the per-dataset loss normalisation (``:323``, ``:348``),
+ReduceLROnPlateau (``:275-283``, ``:352-355``), the best-state snapshot (``:364-367``) and the
+early stop at ``int(1.5 * patience)`` stale epochs (``:369-374``) follow the reference.
+The arithmetic -- forward, backward, clip, optimizer -- runs in the gfx950 kernels
+(``pmc_maf_loss_grad``, ``pmc_adamw_step``, ``pmc_maf_forward``, ``pmc_neg_weighted_sum``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
 
 
-def fit_flow(flow, x, weights=None, **kwargs):
-    raise NotImplementedError("Flow.fit: the gfx950 training kernels are not built yet")
+class TrainState:
+    """Training-side device buffers of one Flow (built on first ``fit``)."""
+
+    def __init__(self, flow):
+        spec, dev = flow.spec, flow.device
+        L = spec.train_layout()
+        pT_idx, gmap = spec.train_index()
+        self.packT_idx = torch.from_numpy(pT_idx).to(dev)
+        self.gmap = torch.from_numpy(gmap).to(dev)
+        self.packedT = torch.zeros(pT_idx.size, dtype=torch.float32, device=dev)
+        self.desc = _lib.pmc_maf_train_t(packedT=self.packedT.data_ptr(), gmap=self.gmap.data_ptr(),
+                                         pkT_per_transform=L["pkT_per_transform"],
+                                         gmap_per_transform=L["gmap_per_transform"])
+        n = spec.n_params
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.scal = torch.zeros(4, dtype=torch.float32, device=dev)      # [loss, wsum, sqnorm, spare]
+
+    def repack(self, flow):
+        with torch.cuda.device(flow.device):
+            _lib.check(flow.lib.pmc_maf_pack(_lib.ptr(flow.params), _lib.ptr(self.packT_idx), _lib.ptr(self.packedT),
+                                             self.packedT.numel(), _lib.stream_handle()), "pmc_maf_pack(T)")
+
+
+def _train_state(flow):
+    if getattr(flow, "_train", None) is None:
+        flow._train = TrainState(flow)
+    return flow._train
+
+
+def loss_and_grad(flow, xb, wb=None):
+    """Loss of one batch (device scalar tensor) and its gradient (in ``flow._train.grad``)."""
+    ts = _train_state(flow)
+    lib = flow.lib
+    st = _lib.stream_handle()
+    ts.grad.zero_()
+    ts.scal.zero_()
+    with torch.cuda.device(flow.device):
+        if wb is not None:
+            _lib.check(lib.pmc_sum_f32(_lib.ptr(wb), C.c_void_p(ts.scal.data_ptr() + 4), wb.numel(), st), "pmc_sum_f32")
+        _lib.check(lib.pmc_maf_loss_grad(C.byref(flow._desc), C.byref(ts.desc), _lib.ptr(xb),
+                                         _lib.ptr(wb) if wb is not None else None,
+                                         C.c_void_p(ts.scal.data_ptr() + 4) if wb is not None else None,
+                                         1000.0, _lib.ptr(ts.grad), _lib.ptr(ts.scal), xb.shape[0], st),
+                   "pmc_maf_loss_grad")
+    return ts.scal[0]
+
+
+def batch_loss(flow, xb, wb=None):
+    """Loss of one batch without gradient (validation, ``flow.py:327-346``)."""
+    ts = _train_state(flow)
+    lib = flow.lib
+    st = _lib.stream_handle()
+    n = xb.shape[0]
+    z = torch.empty_like(xb)
+    lp = torch.empty(n, dtype=torch.float32, device=flow.device)
+    ts.scal.zero_()
+    with torch.cuda.device(flow.device):
+        _lib.check(lib.pmc_maf_forward(C.byref(flow._desc), _lib.ptr(xb), _lib.ptr(z), None, _lib.ptr(lp), n, st),
+                   "pmc_maf_forward")
+        if wb is not None:
+            _lib.check(lib.pmc_sum_f32(_lib.ptr(wb), C.c_void_p(ts.scal.data_ptr() + 4), n, st), "pmc_sum_f32")
+        _lib.check(lib.pmc_neg_weighted_sum(_lib.ptr(lp), _lib.ptr(wb) if wb is not None else None,
+                                            C.c_void_p(ts.scal.data_ptr() + 4) if wb is not None else None,
+                                            1000.0, _lib.ptr(ts.scal), n, st), "pmc_neg_weighted_sum")
+    return ts.scal[0]
+
+
+class AdamW:
+    """``torch.optim.AdamW`` on the flat parameter vector (``flow.py:268``)."""
+
+    def __init__(self, flow, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):
+        self.flow, self.lr, self.wd, self.betas, self.eps = flow, float(lr), float(weight_decay), betas, eps
+        self.m = torch.zeros_like(flow.params)
+        self.v = torch.zeros_like(flow.params)
+        self.t = 0
+
+    def step(self, max_norm):
+        f = self.flow
+        ts = _train_state(f)
+        self.t += 1
+        with torch.cuda.device(f.device):
+            _lib.check(f.lib.pmc_adamw_step(_lib.ptr(f.params), _lib.ptr(ts.grad), _lib.ptr(self.m), _lib.ptr(self.v),
+                                            f.params.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                                            float(max_norm) if max_norm is not None else 0.0, self.t,
+                                            C.c_void_p(ts.scal.data_ptr() + 8), _lib.stream_handle()),
+                       "pmc_adamw_step")
+        f.repack()
+        ts.repack(f)
+
+
+class ReduceLROnPlateau:
+    """``torch.optim.lr_scheduler.ReduceLROnPlateau(mode='min', factor=0.2, threshold=1e-4,
+    threshold_mode='abs', min_lr=1e-6)`` as configured at ``flow.py:275-283``."""
+
+    def __init__(self, opt, patience, factor=0.2, threshold=1e-4, min_lr=1e-6):
+        self.opt, self.patience, self.factor, self.threshold, self.min_lr = opt, patience, factor, threshold, min_lr
+        self.best, self.bad = float("inf"), 0
+
+    def step(self, metric):
+        if metric < self.best - self.threshold:
+            self.best, self.bad = metric, 0
+        else:
+            self.bad += 1
+        if self.bad > self.patience:
+            new = max(self.opt.lr * self.factor, self.min_lr)
+            if self.opt.lr - new > 1e-8:
+                self.opt.lr = new
+            self.bad = 0
+
+
+def _batches(n, batch_size, shuffle):
+    """``DataLoader(TensorDataset(...), batch_size, shuffle)``: a fresh permutation per epoch,
+    last partial batch kept."""
+    idx = torch.randperm(n) if shuffle else torch.arange(n)
+    return [idx[i:i + batch_size] for i in range(0, n, batch_size)]
+
+
+def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_size=1000, patience=20,
+             learning_rate=1e-3, weight_decay=0, laplace_scale=None, gaussian_scale=None, annealing=True,
+             noise=None, shuffle=True, clip_grad_norm=1.0, verbose=0):
+    from .flow import torch_double_to_float
+    if laplace_scale is not None or gaussian_scale is not None:
+        raise NotImplementedError("weight regularisation (flow.py:387-421) is not built; the Sampler leaves it off")
+    if noise is not None:
+        raise NotImplementedError("noise augmentation (flow.py:240-245) is not built; the Sampler leaves it off")
+    x = torch_double_to_float(torch.as_tensor(x))
+    dev = flow.device
+    n_samples, n_dim = x.shape
+    if n_dim != flow.n_dim:
+        raise ValueError("x has the wrong number of columns")
+    w = None if weights is None else torch.as_tensor(weights).to(torch.float32)
+
+    if shuffle:                                                     # flow.py:234-238
+        rand_indx = torch.randperm(n_samples)
+        x = x[rand_indx.to(x.device)]
+        if w is not None:
+            w = w[rand_indx.to(w.device)]
+    x = x.to(dev).contiguous()
+    w = None if w is None else w.to(dev).contiguous()
+
+    if validation_split > 0.0:                                      # flow.py:247-259
+        cut = int(validation_split * n_samples)
+        x_train, x_valid = x[:cut], x[cut:]
+        w_train, w_valid = (None, None) if w is None else (w[:cut], w[cut:])
+        validation = True
+    else:
+        x_train, w_train, x_valid, w_valid = x, w, None, None
+        validation = False
+
+    opt = AdamW(flow, learning_rate, weight_decay)
+    sched = ReduceLROnPlateau(opt, patience) if annealing else None
+    _train_state(flow).repack(flow)
+
+    history = dict(loss=[], val_loss=[])
+    monitor = "val_loss" if validation else "loss"
+    best_epoch, best_loss = 0, np.inf
+    best_model = flow.params.clone()
+    start = time.time()
+
+    n_train = x_train.shape[0]
+    for epoch in range(epochs):
+        acc = torch.zeros((), dtype=torch.float32, device=dev)
+        for idx in _batches(n_train, batch_size, shuffle):
+            idx = idx.to(dev)
+            xb = x_train[idx].contiguous()
+            wb = None if w_train is None else w_train[idx].contiguous()
+            loss = loss_and_grad(flow, xb, wb)
+            acc += loss                                              # device-side: one sync per epoch
+            opt.step(clip_grad_norm)
+        vacc = torch.zeros((), dtype=torch.float32, device=dev)
+        if validation:
+            for idx in _batches(x_valid.shape[0], batch_size, shuffle):
+                idx = idx.to(dev)
+                vacc += batch_loss(flow, x_valid[idx].contiguous(),
+                                   None if w_valid is None else w_valid[idx].contiguous())
+        both = torch.stack([acc, vacc]).cpu().numpy()
+        train_loss = float(both[0]) / max(n_train, 1)                # flow.py:323
+        history["loss"].append(train_loss)
+        if validation:
+            val_loss = float(both[1]) / max(x_valid.shape[0], 1)     # flow.py:348
+            history["val_loss"].append(val_loss)
+        if sched is not None:
+            sched.step(val_loss if validation else train_loss)
+        if verbose > 1:
+            print("Epoch %3d/%3d, train loss: %5.2f" % (epoch + 1, epochs, train_loss)
+                  + (", val loss: %5.2f" % val_loss if validation else ""))
+        if history[monitor][-1] < best_loss:                          # flow.py:364-367
+            best_loss, best_epoch = history[monitor][-1], epoch
+            best_model.copy_(flow.params)
+        if epoch - best_epoch >= int(1.5 * patience):                 # flow.py:369-374
+            flow.params.copy_(best_model)
+            flow.repack()
+            if verbose > 0:
+                print("Finished early after %3d epochs" % best_epoch)
+                print("Best loss achieved %5.2f" % best_loss)
+            break
+    if verbose > 0:
+        total = time.time() - start
+        print("\nTime total:     %5.2f sec" % total)
+        print("Time per epoch: %5.2f sec" % (total / epochs))
+    return history

@@ -1,0 +1,80 @@
+"""The SMC orchestrator on the device kernels: the reference's own smoke tests
+(``tests/test_sampler.py:19-44``, ``tests/test_state.py:16-63``) and statistical checks on an
+analytic target (the flow is parity-unpinned, so end-to-end agreement is statistical:
+SURVEY.md section 8(c))."""
+import numpy as np
+import pytest
+from scipy.stats import norm, uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def log_likelihood_single(x):
+    return -0.5 * np.sum(x ** 2)
+
+
+def log_likelihood_vectorized(x):
+    return -0.5 * np.sum(x ** 2, axis=1)
+
+
+def test_run_scalar_likelihood():
+    """tests/test_sampler.py:19-30."""
+    import pocomc_amd as pc
+    prior = pc.Prior([norm(0, 1), norm(0, 1)])
+    s = pc.Sampler(prior=prior, likelihood=log_likelihood_single, train_config={"epochs": 1}, random_state=0)
+    s.run(progress=False)
+    assert np.isfinite(s.evidence()[0])
+
+
+def test_run_vectorized_likelihood():
+    """tests/test_sampler.py:32-44."""
+    import pocomc_amd as pc
+    prior = pc.Prior([norm(0, 1), norm(0, 1)])
+    s = pc.Sampler(prior=prior, likelihood=log_likelihood_vectorized, vectorize=True, train_config={"epochs": 1},
+                   random_state=0)
+    s.run(progress=False)
+    x, w, logl, logp = s.posterior()
+    assert x.shape[1] == 2 and len(w) == len(x) and np.isfinite(logl).all()
+
+
+def test_save_load_resume(tmp_path):
+    """tests/test_state.py:16-63."""
+    import pocomc_amd as pc
+    prior = pc.Prior([norm(0, 1), norm(0, 1)])
+    s = pc.Sampler(prior=prior, likelihood=log_likelihood_vectorized, vectorize=True, train_config={"epochs": 1},
+                   random_state=0, output_dir=tmp_path, output_label="t")
+    s.run(progress=False, save_every=1, n_total=512, n_evidence=0)
+    files = sorted(tmp_path.glob("t_*.state"))
+    assert (tmp_path / "t_final.state").exists() and len(files) >= 2
+    s2 = pc.Sampler(prior=prior, likelihood=log_likelihood_vectorized, vectorize=True, train_config={"epochs": 1},
+                    random_state=0)
+    s2.load_state(tmp_path / "t_final.state")
+    assert s2.t == s.t and np.allclose(s2.flow.params.cpu().numpy(), s.flow.params.cpu().numpy())
+    first = [f for f in files if "final" not in f.name][0]
+    s3 = pc.Sampler(prior=prior, likelihood=log_likelihood_vectorized, vectorize=True, train_config={"epochs": 1},
+                    random_state=0)
+    s3.run(progress=False, resume_state_path=first, n_total=512, n_evidence=0)
+    assert np.isfinite(s3.evidence()[0])
+
+
+@pytest.mark.parametrize("sample,precondition", [("tpcn", True), ("rwm", True), ("tpcn", False)])
+def test_gaussian_posterior_and_evidence(sample, precondition):
+    """6-D Gaussian likelihood N(mu, 0.5^2) inside U(-5,5)^6: logZ = -6 log 10 analytically
+    (likelihood normalised), posterior mean mu, std 0.5."""
+    import pocomc_amd as pc
+    D, mu, sd = 6, 0.7, 0.5
+    prior = pc.Prior([uniform(-5, 10)] * D)
+
+    def loglike(x):
+        return np.sum(-0.5 * ((x - mu) / sd) ** 2 - np.log(sd) - 0.5 * np.log(2 * np.pi), axis=1)
+    s = pc.Sampler(prior=prior, likelihood=loglike, vectorize=True, flow="maf3", sample=sample,
+                   precondition=precondition, random_state=1, n_effective=512, n_active=256,
+                   train_config={"epochs": 200})
+    s.run(progress=False, n_total=2048, n_evidence=2048 if precondition else 0)
+    x, w, logl, logp = s.posterior()
+    m = np.average(x, axis=0, weights=w)
+    sdev = np.sqrt(np.average((x - m) ** 2, axis=0, weights=w))
+    assert np.abs(m - mu).max() < 0.08, m
+    assert np.abs(sdev - sd).max() < 0.08, sdev
+    logz = s.evidence()[0]
+    assert abs(logz - (-D * np.log(10.0))) < 0.25, logz

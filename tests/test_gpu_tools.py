@@ -34,6 +34,28 @@ def test_weight_statistics(gold, n):
 
 
 @pytest.mark.parametrize("n", [17, 1000, 5000])
+def test_trim_weights_matches_reference(gold, n):
+    from pocomc_amd import tools
+    g = gold["tools"]
+    lw = g[f"tools/n{n}/logw"]
+    w = np.exp(lw - lw.max())
+    idx, wt = tools.trim_weights(np.arange(n), w.copy())
+    np.testing.assert_array_equal(idx, g[f"tools/n{n}/trim_idx"])            # indices: bit-exact
+    np.testing.assert_allclose(wt, g[f"tools/n{n}/trim_w"], rtol=1e-14)
+
+
+def test_trim_weights_large_pool():
+    from pocomc_amd import tools
+    from oracle import tools as otools
+    rng = np.random.default_rng(3)
+    w = np.exp(rng.normal(size=200_000) * 2.5)
+    i1, w1 = tools.trim_weights(np.arange(w.size), w.copy())
+    i2, w2 = otools.trim_weights(np.arange(w.size), w.copy())
+    np.testing.assert_array_equal(i1, i2)
+    np.testing.assert_allclose(w1, w2, rtol=1e-13)
+
+
+@pytest.mark.parametrize("n", [17, 1000, 5000])
 def test_resample_indices_bit_exact(gold, n):
     from pocomc_amd import tools
     g = gold["tools"]

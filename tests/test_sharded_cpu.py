@@ -1,0 +1,95 @@
+"""The N>1 path on CPU: world_size-2 ``gloo`` processes.  Each rank owns half of the walkers;
+per step it reduces its own shard, all-reduces the D+4 sums (``pocomc_amd.mcmc.allreduce_sums``)
+and runs the product's scalar logic (``pocomc_amd.mcmc.Adaptation``).  Both ranks must take
+identical sigma / mu / stop decisions, equal to the unsharded oracle run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+from oracle import mcmc as omcmc
+from oracle.maf import OracleMAF, TorchFlowAdapter
+from oracle.scaler import Reparameterize
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_trace(name):
+    c = cases.MCMC_CASES[name]
+    state, funcs, opts, aux = cases.build_case(name, Reparameterize)
+    funcs["flow"] = TorchFlowAdapter(OracleMAF(aux["spec"], aux["flat"]))
+    trace = []
+    np.random.seed(c["seed"])
+    res = getattr(omcmc, c["kind"])(state, funcs, opts, trace=trace)
+    return c, state, funcs, opts, trace, res
+
+
+def _worker(rank, world, port, name, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pocomc_amd.mcmc import Adaptation, allreduce_sums
+    c, state, funcs, opts, trace, res = _oracle_trace(name)
+    N, D = c["N"], c["D"]
+    lo, hi = rank * N // world, (rank + 1) * N // world
+    kind = c["kind"]
+    pre = kind.startswith("preconditioned")
+    tpcn = kind in ("preconditioned_pcn", "pcn")
+    geo = funcs["theta_geometry"]
+    init = torch.tensor([0.0, float(np.sum((state["logl"] + state["logp"])[lo:hi])),
+                         float(np.sum((state["logl"] + state["logp"] + state["logdetj"])[lo:hi]))] + [0.0] * (D + 1),
+                        dtype=torch.float64)
+    allreduce_sums(init)
+    ad = Adaptation(kind, D, N, opts["n_steps"], opts["n_max"], opts["proposal_scale"],
+                    geo.t_mean if tpcn else None, float(init[1] if tpcn else init[2]) / N)
+    sig, mus, stops = [], [], []
+    for tr in trace:
+        moved = tr["theta"] if pre else tr["u"]
+        lp = tr["logl"] + tr["logp"]
+        sums = torch.tensor(np.concatenate([[tr["alpha"][lo:hi].sum(), lp[lo:hi].sum(),
+                                             (lp + tr["logdetj"])[lo:hi].sum(), tr["accept"][lo:hi].sum()],
+                                            moved[lo:hi].astype(np.float64).sum(axis=0)]), dtype=torch.float64)
+        allreduce_sums(sums)                       # the step's only exchange
+        stops.append(bool(ad.update(sums.numpy())))
+        sig.append(float(ad.sigma))
+        mus.append(None if ad.mu is None else ad.mu.copy())
+    out[rank] = dict(sigma=sig, mu=mus, stops=stops, steps=ad.i)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["tpcn_n256_d10_normal", "prwm_n128_d8_uniform", "pcn_n128_d8_uniform",
+                                  "rwm_n128_d8_normal"])
+def test_two_rank_adaptation_equals_unsharded(name):
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, name, out), nprocs=2, join=True)
+    a, b = out[0], out[1]
+    assert a["sigma"] == b["sigma"] and a["stops"] == b["stops"] and a["steps"] == b["steps"]
+    c, state, funcs, opts, trace, res = _oracle_trace(name)
+    assert a["steps"] == res["steps"] == len(trace)
+    assert a["stops"][-1] and not any(a["stops"][:-1])
+    np.testing.assert_allclose(a["sigma"], [t["sigma"] for t in trace], rtol=1e-12)
+    if c["kind"] == "preconditioned_pcn":
+        for m0, m1, t in zip(a["mu"], b["mu"], trace):
+            np.testing.assert_array_equal(m0, m1)
+            # np.mean of the float32 theta array (mcmc.py:156) vs float64 sums rounded to float32
+            np.testing.assert_allclose(m0, t["mu"], rtol=1e-6, atol=1e-7)
+
+
+def test_philox_offsets_make_shards_independent_of_world_size():
+    """Host-side contract of the sharded RNG: the walker's global index keys the stream."""
+    from pocomc_amd import _lib
+    r = _lib.pmc_rng_t(gamma=None, normal=None, uniform=None, seed=7, step=3, offset=5000)
+    assert r.offset == 5000 and r.seed == 7 and r.step == 3
