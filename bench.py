@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--host-threads", type=int, default=1, help="host threads evaluating the prior/likelihood")
     ap.add_argument("--x-order", choices=["C", "F"], default="F",
                     help="memory order of the (n, D) array handed to the host prior/likelihood")
-    ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "triangular_v1"], default="auto")
+    ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "triangular_v1", "triangular_v2"], default="auto")
     args = ap.parse_args()
 
     import torch
@@ -138,7 +138,7 @@ def main():
     logdetj = scaler.inverse(u)[1]
     logl, logp = rosenbrock(x), prior.logpdf(x)
     flow = Flow(D, "maf3", seed=0)                          # replicated weights
-    flow.inverse_algo = {"auto": 0, "triangular": 1, "naive": 2, "triangular_v1": 3}[args.inverse]
+    flow.inverse_algo = {"auto": 0, "triangular": 1, "naive": 2, "triangular_v1": 3, "triangular_v2": 4}[args.inverse]
     flow_trained = False
     try:
         flow.fit(torch.from_numpy(scaler.forward(x_fit[:n])).float(), epochs=50, batch_size=512,
@@ -201,16 +201,36 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    eng.events = []
-    eng.host_timers = {"wait_device": 0.0, "prior": 0.0, "likelihood": 0.0}
-    t_host[0] = 0.0
-    t_seg = {"propose_call": 0.0, "evaluate_call": 0.0, "accept_call": 0.0, "adapt": 0.0}
+    # ---- timed region: K steps through the composite entry points; the only instrumentation is one
+    #      HIP event pair per step around the flow-inverse launch (recorded inside pmc_step_pre, on the
+    #      stream the kernel is launched on)
+    lib = eng.lib
+    ev_pairs = [(lib.pmc_event_create(), lib.pmc_event_create()) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        eng._step.ev_inv0, eng._step.ev_inv1 = ev_pairs[k]
         step()
     barrier()
     dt = time.perf_counter() - t0
+    eng._step.ev_inv0, eng._step.ev_inv1 = None, None
+    seg_timed = {k: v / args.steps * 1e6 for k, v in t_seg.items()}
+    inv_us_live = float(np.mean([lib.pmc_event_elapsed_ms(a, b) for a, b in ev_pairs])) * 1e3
+    for a, b in ev_pairs:
+        lib.pmc_event_destroy(a); lib.pmc_event_destroy(b)
+    # ---- instrumented pass (same steps, fine-grained entry points + HIP events + host timers):
+    #      per-kernel durations for the roofline object and the host/device breakdown
+    eng.events = []
+    eng.host_timers = {"wait_device": 0.0, "prior": 0.0, "likelihood": 0.0}
+    t_host[0] = 0.0
+    for k in t_seg:
+        t_seg[k] = 0.0
+    n_inst = max(20, min(args.steps, 100))
+    ti0 = time.perf_counter()
+    for _ in range(n_inst):
+        step()
+    torch.cuda.synchronize()
+    dt_inst = time.perf_counter() - ti0
     if world > 1:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -224,12 +244,24 @@ def main():
     spec = flow.spec
     algo_flops = n * spec.flops_inverse_naive()                   # (D+1)*F_fwd per walker
     actual_flops = n * 2 * spec.macs_masked()                     # what the triangular sweep needs
-    t_inv = us["maf_inverse"] * 1e-6
+    us["maf_inverse_timed_region"] = inv_us_live            # HIP events inside the timed region
+    t_inv = inv_us_live * 1e-6
+    # HBM bytes per launch of the dominant kernel: PMC passes cannot run inside this process, the value
+    # is the committed rocprofv3 measurement of this very command (profiles/r01_c_rocprof_summary.txt)
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if n == 10000 and D == 32 and args.inverse == "auto":
+            traffic = {"hbm_bytes_per_launch": pm["hbm_bytes_per_launch"], "unit": "B", "source": pm["source"],
+                       "correction": pm["correction"]}
+    except (OSError, KeyError, ValueError):
+        pass
     achieved = algo_flops / t_inv / 1e12
     roofline = {"bound": "mfma", "kernel": ("maf_dense_kernel<1>" if (args.inverse == "naive" or not spec.tri_ok) else
-                           ("maf_inverse_tri_kernel" if args.inverse == "triangular_v1" else "maf_inverse_tri2_kernel")), "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                "avg_launch_us": us["maf_inverse"],
+                           {"triangular_v1": "maf_inverse_tri_kernel", "triangular_v2": "maf_inverse_tri2_kernel"}.get(
+                               args.inverse, "maf_inverse_tri3_kernel" if spec.nOT <= 8 else "maf_inverse_tri2_kernel")), "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                "avg_launch_us": inv_us_live,
                 "note": "achieved = SURVEY 8(d) naive-equivalent flops ((D+1)*F_fwd per walker) / launch time; the "
                         "triangular sweep executes only the masked MACs once, so frac > 1 is an algorithmic gain",
                 "actual_tflops": actual_flops / t_inv / 1e12,
@@ -246,11 +278,13 @@ def main():
                       "flow_trained_50_epochs": flow_trained, "parallelism": f"walker-sharded x{world}",
                       "inverse_algo": args.inverse, "host_threads": args.host_threads, "host_x_order": args.x_order, "accept_rate": float(ad.mean_alpha)},
            "roofline": roofline,
-           "breakdown_us_per_step": dict(us, host_prior_likelihood=t_host[0] / args.steps * 1e6,
+           "breakdown_us_per_step": dict(us, host_prior_likelihood=t_host[0] / n_inst * 1e6,
                                          device_kernels=us["propose"] + us["maf_inverse"] + us["scaler_inverse"]
-                                         + us["accept_reduce"], wall=ms_per_step * 1e3),
-           "host_us_per_step": {**{k: v / args.steps * 1e6 for k, v in eng.host_timers.items()},
-                                **{k: v / args.steps * 1e6 for k, v in t_seg.items()}}}
+                                         + us["accept_reduce"], wall=ms_per_step * 1e3,
+                                         instrumented_pass_wall=dt_inst / n_inst * 1e6),
+           "timed_region_host_us_per_step": seg_timed,
+           "host_us_per_step": {**{k: v / n_inst * 1e6 for k, v in eng.host_timers.items()},
+                                **{k: v / n_inst * 1e6 for k, v in t_seg.items()}}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(D, n, beta, flow.params.cpu().numpy(), spec, x, u, geo, sigma0, seed=0)
     elif rank == 0:

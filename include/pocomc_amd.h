@@ -53,6 +53,7 @@ typedef struct pmc_maf {
 #define PMC_INVERSE_TRIANGULAR 1   /* one sweep over the degree groups */
 #define PMC_INVERSE_NAIVE 2        /* the reference's D fixed-point passes (zuko) */
 #define PMC_INVERSE_TRIANGULAR_V1 3 /* first (un-prefetched, barrier-synchronised) sweep; kept for A/B */
+#define PMC_INVERSE_TRIANGULAR_V2 4 /* prefetching sweep whose chain hops through LDS; used when D > 64 */
 
 /* packed[i] = idx[i] >= 0 ? flat[idx[i]] : 0   (canonical fp32 params -> kernel layout) */
 int pmc_maf_pack(const float* flat, const int32_t* pack_idx, float* packed, int64_t n_packed, void* stream);
@@ -190,6 +191,59 @@ int64_t pmc_accept_workspace_bytes(int64_t n, int32_t D);
 int pmc_accept(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposal_t* prop, double beta, double nu,
                const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums,
                void* workspace, int64_t n, int32_t D, void* stream);
+
+/* All buffers of one step in one place, for the composite entry points below. */
+typedef struct pmc_step {
+    int32_t kind;             /* PMC_KIND_TPCN | PMC_KIND_RWM */
+    int32_t preconditioned;
+    int64_t n;
+    int32_t D;
+    int32_t inverse_algo;
+    const pmc_maf_t* maf;     /* NULL unless preconditioned */
+    const pmc_scaler_t* scaler;
+    pmc_state_t cur;          /* current population (device) */
+    const double* mu;         /* device [D];  */
+    const double* inv_cov;    /* device [D][D] */
+    const double* chol;       /* device [D][D] */
+    double* p_theta64;        /* proposal buffers (device): see pmc_propose / pmc_scaler_inverse / pmc_accept */
+    float* p_theta32;
+    float* p_u32;
+    float* p_ldjf;
+    double* p_u;
+    double* p_x;
+    double* p_xT;             /* optional column-major copy of x' (NULL: the host gets the row-major x') */
+    double* p_logdetj;
+    int32_t* p_fin;
+    double* quad;
+    double* p_quad;
+    double* p_logl;
+    double* p_logp;
+    double* alpha;
+    int32_t* accept;
+    double* sums;             /* device [D+4] */
+    void* ws;                 /* pmc_accept_workspace_bytes() */
+    const double* h_mu;       /* pinned host [D] or NULL: uploaded to mu at the start of pmc_step_pre */
+    double* h_x;              /* pinned host [n*D] */
+    int32_t* h_fin;           /* pinned host [n] */
+    const double* h_logl;     /* pinned host [n] */
+    const double* h_logp;     /* pinned host [n] */
+    double* h_sums;           /* pinned host [D+4] */
+    int32_t* h_accept;        /* pinned host [n] or NULL */
+    void* ev_inv0;            /* optional hipEvent_t recorded right before / after the flow-inverse launch */
+    void* ev_inv1;
+} pmc_step_t;
+
+/* mcmc.py:77-102 in one call: [H2D mu] -> propose -> flow inverse -> scaler inverse -> D2H x', finite. */
+int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu, double sigma, double cn_a, void* stream);
+/* mcmc.py:124-156 in one call: H2D logl', logp' -> accept + reductions -> [D2H sums, accept mask]. */
+int pmc_step_post(const pmc_step_t* s, const pmc_rng_t* rng, double beta, double nu, int want_mask,
+                  int copy_sums, void* stream);
+int pmc_stream_synchronize(void* stream);
+/* hipEvent helpers for the host language (live kernel timing inside bench.py). */
+void* pmc_event_create(void);
+int pmc_event_record(void* ev, void* stream);
+float pmc_event_elapsed_ms(void* a, void* b);
+void pmc_event_destroy(void* ev);
 
 /* --------------------------------------------------------- particle math */
 

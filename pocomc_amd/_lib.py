@@ -52,6 +52,17 @@ class pmc_proposal_t(C.Structure):
                 ("quad", c_p), ("quad_prop", c_p)]
 
 
+class pmc_step_t(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("preconditioned", C.c_int32), ("n", C.c_int64), ("D", C.c_int32),
+                ("inverse_algo", C.c_int32), ("maf", c_p), ("scaler", c_p), ("cur", pmc_state_t),
+                ("mu", c_p), ("inv_cov", c_p), ("chol", c_p),
+                ("p_theta64", c_p), ("p_theta32", c_p), ("p_u32", c_p), ("p_ldjf", c_p), ("p_u", c_p), ("p_x", c_p),
+                ("p_xT", c_p), ("p_logdetj", c_p), ("p_fin", c_p), ("quad", c_p), ("p_quad", c_p), ("p_logl", c_p),
+                ("p_logp", c_p), ("alpha", c_p), ("accept", c_p), ("sums", c_p), ("ws", c_p),
+                ("h_mu", c_p), ("h_x", c_p), ("h_fin", c_p), ("h_logl", c_p), ("h_logp", c_p), ("h_sums", c_p),
+                ("h_accept", c_p), ("ev_inv0", c_p), ("ev_inv1", c_p)]
+
+
 # name -> (restype, argtypes); every symbol include/pocomc_amd.h declares
 i32, i64, f64 = C.c_int32, C.c_int64, C.c_double
 P = C.POINTER
@@ -72,6 +83,13 @@ SIGNATURES = {
     "pmc_accept_workspace_bytes": (i64, [i64, i32]),
     "pmc_accept": (C.c_int, [C.c_int, C.c_int, P(pmc_state_t), P(pmc_proposal_t), f64, f64,
                              P(pmc_rng_t), c_p, c_p, c_p, c_p, i64, i32, c_p]),
+    "pmc_step_pre": (C.c_int, [P(pmc_step_t), P(pmc_rng_t), f64, f64, f64, c_p]),
+    "pmc_step_post": (C.c_int, [P(pmc_step_t), P(pmc_rng_t), f64, f64, C.c_int, C.c_int, c_p]),
+    "pmc_stream_synchronize": (C.c_int, [c_p]),
+    "pmc_event_create": (c_p, []),
+    "pmc_event_record": (C.c_int, [c_p, c_p]),
+    "pmc_event_elapsed_ms": (C.c_float, [c_p, c_p]),
+    "pmc_event_destroy": (None, [c_p]),
     "pmc_logw": (C.c_int, [c_p, c_p, c_p, f64, c_p, i32, i64, c_p]),
     "pmc_reduce_workspace_bytes": (i64, [i64]),
     "pmc_logw_stats": (C.c_int, [c_p, i64, i64, c_p, c_p, c_p]),

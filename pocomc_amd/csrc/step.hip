@@ -1,0 +1,95 @@
+// Composite entry points of one MCMC step (pocomc/mcmc.py:74-149): everything the device does
+// before and after the host's prior / likelihood call, enqueued by ONE C call each, so that the
+// host-side driver spends its time in the user's black boxes instead of in dispatch overhead.
+//
+//   pmc_step_pre :  [H2D mu] -> propose -> flow inverse -> scaler inverse -> D2H x', finite
+//   pmc_step_post:  H2D logl', logp' -> accept + reductions -> D2H sums
+//
+// Pure sequencing of the single-purpose entry points (same kernels, same stream order); host
+// buffers must be pinned for the copies to be asynchronous.
+
+#include <hip/hip_runtime.h>
+#include "pmc_internal.h"
+
+extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu, double sigma, double cn_a,
+                            void* stream) {
+    if (!s || !rng) return pmc_fail("pmc_step_pre: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = s->n;
+    const int32_t D = s->D;
+    const bool tpcn = (s->kind == PMC_KIND_TPCN);
+    if (tpcn && s->h_mu) {
+        if (hipMemcpyAsync((void*)s->mu, s->h_mu, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+            return pmc_fail("pmc_step_pre: H2D mu");
+    }
+    int rc = pmc_propose(s->kind, s->preconditioned ? s->cur.theta32 : nullptr, s->preconditioned ? nullptr : s->cur.u,
+                         s->mu, s->inv_cov, s->chol, nu, sigma, cn_a, rng, s->p_theta64,
+                         s->preconditioned ? s->p_theta32 : nullptr, tpcn ? s->quad : nullptr,
+                         tpcn ? s->p_quad : nullptr, n, D, stream);
+    if (rc) return rc;
+    if (s->preconditioned) {
+        if (s->ev_inv0) (void)hipEventRecord((hipEvent_t)s->ev_inv0, st);
+        rc = pmc_maf_inverse(s->maf, s->p_theta32, s->p_u32, s->p_ldjf, n, s->inverse_algo, stream);
+        if (s->ev_inv1) (void)hipEventRecord((hipEvent_t)s->ev_inv1, st);
+        if (rc) return rc;
+        rc = pmc_scaler_inverse(s->scaler, s->p_u32, nullptr, s->p_u, s->p_x, s->p_xT, s->p_logdetj, s->p_fin, n, stream);
+    } else {
+        rc = pmc_scaler_inverse(s->scaler, nullptr, s->p_theta64, s->p_u, s->p_x, s->p_xT, s->p_logdetj, s->p_fin, n, stream);
+    }
+    if (rc) return rc;
+    const double* xsrc = s->p_xT ? s->p_xT : s->p_x;
+    if (hipMemcpyAsync(s->h_x, xsrc, (size_t)n * D * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(s->h_fin, s->p_fin, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess)
+        return pmc_fail("pmc_step_pre: D2H");
+    return 0;
+}
+
+extern "C" int pmc_step_post(const pmc_step_t* s, const pmc_rng_t* rng, double beta, double nu, int want_mask,
+                             int copy_sums, void* stream) {
+    if (!s || !rng) return pmc_fail("pmc_step_post: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = s->n;
+    if (hipMemcpyAsync(s->p_logl, s->h_logl, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(s->p_logp, s->h_logp, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+        return pmc_fail("pmc_step_post: H2D");
+    pmc_state_t cur = s->cur;
+    pmc_proposal_t prop;
+    prop.theta64 = s->preconditioned ? s->p_theta64 : nullptr;
+    prop.u = s->p_u; prop.x = s->p_x; prop.logdetj = s->p_logdetj; prop.logl = s->p_logl; prop.logp = s->p_logp;
+    prop.logdetj_flow = s->preconditioned ? s->p_ldjf : nullptr;
+    prop.quad = s->quad; prop.quad_prop = s->p_quad;
+    int rc = pmc_accept(s->kind, s->preconditioned, &cur, &prop, beta, nu, rng, s->alpha, s->accept, s->sums, s->ws, n,
+                        s->D, stream);
+    if (rc) return rc;
+    if (copy_sums &&
+        hipMemcpyAsync(s->h_sums, s->sums, (size_t)(s->D + 4) * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess)
+        return pmc_fail("pmc_step_post: D2H sums");
+    if (want_mask && s->h_accept &&
+        hipMemcpyAsync(s->h_accept, s->accept, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess)
+        return pmc_fail("pmc_step_post: D2H accept");
+    return 0;
+}
+
+extern "C" int pmc_stream_synchronize(void* stream) {
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return pmc_fail_hip(e, "hipStreamSynchronize");
+    return 0;
+}
+
+// HIP events for live kernel timing from the host language (bench.py records the flow-inverse
+// launch of every timed step through pmc_step_t.ev_inv0 / ev_inv1).
+extern "C" void* pmc_event_create(void) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) { pmc_fail("hipEventCreate failed"); return nullptr; }
+    return (void*)e;
+}
+extern "C" int pmc_event_record(void* ev, void* stream) {
+    hipError_t e = hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : pmc_fail_hip(e, "hipEventRecord");
+}
+extern "C" float pmc_event_elapsed_ms(void* a, void* b) {
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) return -1.0f;
+    return ms;
+}
+extern "C" void pmc_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }

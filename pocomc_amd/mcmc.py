@@ -165,6 +165,27 @@ class StepEngine:
             logdetj=self.p_logdetj.data_ptr(), logl=self.p_logl.data_ptr(), logp=self.p_logp.data_ptr(),
             logdetj_flow=self.p_ldjf.data_ptr() if self.pre else None,
             quad=self.quad.data_ptr() if self.tpcn else None, quad_prop=self.p_quad.data_ptr() if self.tpcn else None)
+        self._step = _lib.pmc_step_t(
+            kind=PMC_KIND_TPCN if self.tpcn else PMC_KIND_RWM, preconditioned=int(self.pre), n=n, D=D,
+            inverse_algo=flow.inverse_algo if self.pre else 0,
+            maf=C.cast(C.pointer(flow._desc), C.c_void_p) if self.pre else None,
+            scaler=C.cast(C.pointer(self.scaler_desc), C.c_void_p), cur=self._state,
+            mu=self.mu_d.data_ptr(), inv_cov=self.inv_cov_d.data_ptr(), chol=self.chol_d.data_ptr(),
+            p_theta64=self.p_theta64.data_ptr(), p_theta32=self.p_theta32.data_ptr() if self.pre else None,
+            p_u32=self.p_u32.data_ptr() if self.pre else None, p_ldjf=self.p_ldjf.data_ptr() if self.pre else None,
+            p_u=self.p_u.data_ptr(), p_x=self.p_x.data_ptr(),
+            p_xT=self.p_xT.data_ptr() if self.p_xT is not None else None, p_logdetj=self.p_logdetj.data_ptr(),
+            p_fin=self.p_fin.data_ptr(), quad=self.quad.data_ptr() if self.tpcn else None,
+            p_quad=self.p_quad.data_ptr() if self.tpcn else None, p_logl=self.p_logl.data_ptr(),
+            p_logp=self.p_logp.data_ptr(), alpha=self.alpha.data_ptr(), accept=self.accept.data_ptr(),
+            sums=self.sums.data_ptr(), ws=self.ws.data_ptr(),
+            h_mu=self.h_mu.data_ptr() if self.tpcn else None, h_x=self.h_x.data_ptr(), h_fin=self.h_fin.data_ptr(),
+            h_logl=self.h_logl.data_ptr(), h_logp=self.h_logp.data_ptr(), h_sums=self.h_sums.data_ptr(),
+            h_accept=self.h_accept.data_ptr())
+        self._rng_fast = _lib.pmc_rng_t(gamma=None, normal=None, uniform=None, seed=self.seed, step=0,
+                                        offset=self.offset)
+        self.composite = True    # one C call before / after the host black boxes (pmc_step_pre / _post)
+        self._post_uploads = False
         self.step_idx = 0
         self.host_threads = 1    # >1: evaluate the black boxes on row chunks in a thread pool
         self._pool = None
@@ -203,7 +224,8 @@ class StepEngine:
         # pinned staging + async copy; the previous upload was consumed by a kernel that has
         # completed (accept_reduce synchronises) before the host buffer is rewritten
         self._np_mu[:] = mu
-        self.mu_d.copy_(self.h_mu, non_blocking=True)
+        if not (self.composite and self.events is None):
+            self.mu_d.copy_(self.h_mu, non_blocking=True)      # the composite pre-step uploads h_mu itself
 
     # ----------------------------------------------------------------- step
     def _rng(self, replay):
@@ -221,6 +243,21 @@ class StepEngine:
     def propose(self, sigma, nu=0.0, replay=None):
         """propose -> flow inverse -> scaler inverse, then start the D2H of x'."""
         lib, n, D = self.lib, self.n, self.D
+        if self.composite and self.events is None:
+            if replay is not None:
+                self._rng_cur = self._rng(replay)
+            else:
+                self._rng_fast.step = self.step_idx
+                self._rng_cur = self._rng_fast
+            if self.pre:
+                self._step.inverse_algo = self.flow.inverse_algo
+            cn_a = float((1.0 - sigma ** 2.0) ** 0.5) if self.tpcn else 0.0        # mcmc.py:85
+            self._stream = _lib.stream_handle()
+            _lib.check(lib.pmc_step_pre(C.byref(self._step), C.byref(self._rng_cur), float(nu), float(sigma), cn_a,
+                                        self._stream), "pmc_step_pre")
+            self._post_uploads = True
+            return
+        self._post_uploads = False
         self._rng_cur = self._rng(replay)
         st = _lib.stream_handle()
         kind = PMC_KIND_TPCN if self.tpcn else PMC_KIND_RWM
@@ -260,7 +297,10 @@ class StepEngine:
         ``(n_calls, blobs_prime)``."""
         tm = self.host_timers
         t0 = time.perf_counter() if tm is not None else 0.0
-        torch.cuda.current_stream().synchronize()
+        if self._post_uploads:
+            _lib.check(self.lib.pmc_stream_synchronize(self._stream), "pmc_stream_synchronize")
+        else:
+            torch.cuda.current_stream().synchronize()
         if tm is not None:
             t1 = time.perf_counter(); tm["wait_device"] += t1 - t0
             _lp, _ll = log_prior, log_like
@@ -301,8 +341,7 @@ class StepEngine:
                 logl_prime[lo:hi] = ll
                 return int(ok.sum())
             calls = sum(self._pool.map(work, bounds))
-            self.p_logl.copy_(self.h_logl, non_blocking=True)
-            self.p_logp.copy_(self.h_logp, non_blocking=True)
+            self._upload_logs()
             return calls, None
         if fin_i.all():
             # every proposal is finite (the usual case): x'[mask] of mcmc.py:106 is x' itself
@@ -314,8 +353,7 @@ class StepEngine:
                     logl_prime[:], blobs_prime[:] = log_like(x_prime)
                 else:
                     logl_prime[:], _ = log_like(x_prime)
-                self.p_logl.copy_(self.h_logl, non_blocking=True)
-                self.p_logp.copy_(self.h_logp, non_blocking=True)
+                self._upload_logs()
                 return n, blobs_prime
         else:
             finite = fin_i.astype(bool)
@@ -328,12 +366,29 @@ class StepEngine:
         else:
             logl_prime[finite], _ = log_like(x_prime[finite])
         logl_prime[~finite] = -np.inf
-        self.p_logl.copy_(self.h_logl, non_blocking=True)
-        self.p_logp.copy_(self.h_logp, non_blocking=True)
+        self._upload_logs()
         return int(np.sum(finite)), blobs_prime
+
+    def _upload_logs(self):
+        if not self._post_uploads:                    # the composite post step does the H2D itself
+            self.p_logl.copy_(self.h_logl, non_blocking=True)
+            self.p_logp.copy_(self.h_logp, non_blocking=True)
 
     def accept_reduce(self, beta, nu=0.0, want_mask=False):
         """Metropolis accept + global sums; returns the (all-reduced) host copy."""
+        if self._post_uploads:
+            import torch.distributed as dist
+            sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+            _lib.check(self.lib.pmc_step_post(C.byref(self._step), C.byref(self._rng_cur), float(beta), float(nu),
+                                              int(want_mask), int(not sharded), self._stream), "pmc_step_post")
+            if sharded:
+                allreduce_sums(self.sums, self.group)
+                self.h_sums.copy_(self.sums, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+            else:
+                _lib.check(self.lib.pmc_stream_synchronize(self._stream), "pmc_stream_synchronize")
+            self.step_idx += 1
+            return self._np_sums
         kind = PMC_KIND_TPCN if self.tpcn else PMC_KIND_RWM
         timed = self.events is not None
         with torch.cuda.device(self.device):
