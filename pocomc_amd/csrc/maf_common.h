@@ -47,6 +47,34 @@ __device__ __forceinline__ f32x4 tile_mac(f32x4 acc, const float4* __restrict__ 
     return acc;
 }
 
+
+// acc += sum_{K in [K0, K1)} frag[K] . act[K]  with the weight fragments of four K tiles in flight:
+// a lone wave per SIMD has nothing else to hide the ~500-cycle L2 latency of a fragment load.
+__device__ __forceinline__ f32x4 mac_range(f32x4 acc, const float4* __restrict__ frag, const float* act,
+                                           int K0, int K1, int lane) {
+    const float4* f = frag + lane;
+    float4 a0, a1, a2, a3;
+    if (K0 + 0 < K1) a0 = f[(K0 + 0) * 64];
+    if (K0 + 1 < K1) a1 = f[(K0 + 1) * 64];
+    if (K0 + 2 < K1) a2 = f[(K0 + 2) * 64];
+    if (K0 + 3 < K1) a3 = f[(K0 + 3) * 64];
+#define PMC_MAC_STEP(A, KK)                                                                      \
+    if ((KK) < K1) {                                                                             \
+        const float4 b_ = *reinterpret_cast<const float4*>(act + ((KK) << 8) + (lane << 2));     \
+        acc = MFMA(A.x, b_.x, acc); acc = MFMA(A.y, b_.y, acc);                                  \
+        acc = MFMA(A.z, b_.z, acc); acc = MFMA(A.w, b_.w, acc);                                  \
+        if ((KK) + 4 < K1) A = f[((KK) + 4) * 64];                                               \
+    }
+    for (int K = K0; K < K1; K += 4) {
+        PMC_MAC_STEP(a0, K)
+        PMC_MAC_STEP(a1, K + 1)
+        PMC_MAC_STEP(a2, K + 2)
+        PMC_MAC_STEP(a3, K + 3)
+    }
+#undef PMC_MAC_STEP
+    return acc;
+}
+
 // store the 4 rows this lane holds of tile T into an activation array
 __device__ __forceinline__ void store_rows(float* act, int T, int q, int p, const f32x4& v) {
     float* base = act + (T << 8) + (p << 2) + q;
@@ -126,7 +154,7 @@ __device__ __forceinline__ void maf_hidden_pass(const pmc_maf_t& m, const MafVie
     // layer 0
     for (int T = 0; T < nT; ++T) {
         f32x4 a = bias4(w.b0, 16 * T + 4 * q);
-        for (int X = 0; X < nXT; ++X) a = tile_mac(a, w.f0 + (size_t)T * nXT * 64, xin, X, lane);
+        a = mac_range(a, w.f0 + (size_t)T * nXT * 64, xin, 0, nXT, lane);
         for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.0f);
         store_rows(H0, T, q, p, a);
     }
@@ -141,7 +169,7 @@ __device__ __forceinline__ void maf_hidden_pass(const pmc_maf_t& m, const MafVie
         for (int T = 0; T < nT; ++T) {
             f32x4 a = bias4(b, 16 * T + 4 * q);
             const int kend = m.tri_ok ? T + 1 : nT;
-            for (int K = 0; K < kend; ++K) a = tile_mac(a, f + (size_t)T * nT * 64, Hin, K, lane);
+            a = mac_range(a, f + (size_t)T * nT * 64, Hin, 0, kend, lane);
             const float* hb = Hin + (T << 8) + (p << 2) + q;
             a[0] = fmaxf(a[0] + hb[0], 0.0f);
             a[1] = fmaxf(a[1] + hb[64], 0.0f);

@@ -47,7 +47,7 @@ __device__ __forceinline__ float maf_dense_pass(const pmc_maf_t& m, const MafVie
     for (int O = 0; O < nOT; ++O) {
         if (8 * O >= D) break;
         f32x4 o = bias4(w.b3, 16 * O + 4 * q);
-        for (int K = 0; K < nT; ++K) o = tile_mac(o, w.f3 + (size_t)O * nT * 64, H2, K, lane);
+        o = mac_range(o, w.f3 + (size_t)O * nT * 64, H2, 0, nT, lane);
         for (int s = 0; s < 2; ++s) {
             const int rank = 8 * O + 2 * q + s;
             if (rank < D) {

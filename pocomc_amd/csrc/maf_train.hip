@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64) void maf_lossgrad_kernel(pmc_maf_t m, pmc_maf_t
         for (int O = 0; O < nOT; ++O) {
             if (8 * O >= D) break;
             f32x4 o = bias4(wv.b3, 16 * O + 4 * q);
-            for (int K = 0; K < nT; ++K) o = tile_mac(o, wv.f3 + (size_t)O * nT * 64, H2, K, lane);
+            o = mac_range(o, wv.f3 + (size_t)O * nT * 64, H2, 0, nT, lane);
             for (int s = 0; s < 2; ++s) {
                 const int rank = 8 * O + 2 * q + s;
                 if (rank < D) {
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64) void maf_lossgrad_kernel(pmc_maf_t m, pmc_maf_t
         maf_hidden_pass(m, wv, X, H0, H1, H2, lane);
         for (int O = 0; O < nOT; ++O) {
             f32x4 o = bias4(wv.b3, 16 * O + 4 * q);
-            if (8 * O < D) for (int K = 0; K < nT; ++K) o = tile_mac(o, wv.f3 + (size_t)O * nT * 64, H2, K, lane);
+            if (8 * O < D) o = mac_range(o, wv.f3 + (size_t)O * nT * 64, H2, 0, nT, lane);
             store_rows(PHI, O, q, p, o);
         }
         __syncthreads();
@@ -197,10 +197,7 @@ __global__ __launch_bounds__(64) void maf_lossgrad_kernel(pmc_maf_t m, pmc_maf_t
         }
         for (int K = 0; K < nT; ++K) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            for (int O = 0; O < nOT; ++O) {
-                if (8 * O >= D) break;
-                a = tile_mac(a, tv.f3T + (size_t)K * nOT * 64, GPHI, O, lane);
-            }
+            a = mac_range(a, tv.f3T + (size_t)K * nOT * 64, GPHI, 0, min(nOT, (D + 7) / 8), lane);
             const float* hb = H2 + (K << 8) + (p << 2) + q;
             a[0] = hb[0] > 0.f ? a[0] : 0.f; a[1] = hb[64] > 0.f ? a[1] : 0.f;
             a[2] = hb[128] > 0.f ? a[2] : 0.f; a[3] = hb[192] > 0.f ? a[3] : 0.f;
@@ -217,7 +214,7 @@ __global__ __launch_bounds__(64) void maf_lossgrad_kernel(pmc_maf_t m, pmc_maf_t
         for (int Ti = 0; Ti < nT; ++Ti) {
             const float* db_ = DA + (Ti << 8) + (p << 2) + q;
             f32x4 a = {db_[0], db_[64], db_[128], db_[192]};
-            for (int To = (m.tri_ok ? Ti : 0); To < nT; ++To) a = tile_mac(a, tv.f2T + (size_t)Ti * nT * 64, DA, To, lane);
+            a = mac_range(a, tv.f2T + (size_t)Ti * nT * 64, DA, (m.tri_ok ? Ti : 0), nT, lane);
             const float* hb = H1 + (Ti << 8) + (p << 2) + q;
             a[0] = hb[0] > 0.f ? a[0] : 0.f; a[1] = hb[64] > 0.f ? a[1] : 0.f;
             a[2] = hb[128] > 0.f ? a[2] : 0.f; a[3] = hb[192] > 0.f ? a[3] : 0.f;
@@ -235,7 +232,7 @@ __global__ __launch_bounds__(64) void maf_lossgrad_kernel(pmc_maf_t m, pmc_maf_t
         for (int Ti = 0; Ti < nT; ++Ti) {
             const float* db_ = DB + (Ti << 8) + (p << 2) + q;
             f32x4 a = {db_[0], db_[64], db_[128], db_[192]};
-            for (int To = (m.tri_ok ? Ti : 0); To < nT; ++To) a = tile_mac(a, tv.f1T + (size_t)Ti * nT * 64, DB, To, lane);
+            a = mac_range(a, tv.f1T + (size_t)Ti * nT * 64, DB, (m.tri_ok ? Ti : 0), nT, lane);
             const float* hb = H0 + (Ti << 8) + (p << 2) + q;
             a[0] = hb[0] > 0.f ? a[0] : 0.f; a[1] = hb[64] > 0.f ? a[1] : 0.f;
             a[2] = hb[128] > 0.f ? a[2] : 0.f; a[3] = hb[192] > 0.f ? a[3] : 0.f;
@@ -251,7 +248,7 @@ __global__ __launch_bounds__(64) void maf_lossgrad_kernel(pmc_maf_t m, pmc_maf_t
             for (int Xi = 0; Xi < nXT; ++Xi) {
                 const float* gb_ = GX + (Xi << 8) + (p << 2) + q;
                 f32x4 a = {gb_[0], gb_[64], gb_[128], gb_[192]};
-                for (int To = 0; To < nT; ++To) a = tile_mac(a, tv.f0T + (size_t)Xi * nT * 64, DA, To, lane);
+                a = mac_range(a, tv.f0T + (size_t)Xi * nT * 64, DA, 0, nT, lane);
                 store_rows(PHI, Xi, q, p, a);                      // PHI is free now: staging by rank of t
             }
             __syncthreads();
