@@ -45,7 +45,7 @@ def rosenbrock(x):
 
 
 class UniformBox:
-    """Host prior black box: product of U(low, high)."""
+    """Host prior (used by the CPU baseline): product of U(low, high)."""
 
     def __init__(self, low, high, D):
         self.low, self.high, self.D = float(low), float(high), D
@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--dim", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-threads", type=int, default=1, help="host threads evaluating the prior/likelihood")
+    ap.add_argument("--host-prior", action="store_true",
+                    help="evaluate Prior.logpdf on the host (default: on the device, it is a product of scipy.stats "
+                         "uniform factors, not a black box)")
     ap.add_argument("--x-order", choices=["C", "F"], default="F",
                     help="memory order of the (n, D) array handed to the host prior/likelihood")
     ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "triangular_v1", "triangular_v2"], default="auto")
@@ -170,6 +173,10 @@ def main():
     eng = StepEngine("preconditioned_pcn", n, D, flow, scaler, group=None, shard_offset=rank * n, seed=20240928,
                      x_order=args.x_order)
     eng.host_threads = args.host_threads
+    from scipy.stats import uniform as sp_uniform
+    from pocomc_amd import Prior
+    pc_prior = Prior([sp_uniform(-10.0, 20.0)] * D)                   # pocoMC's own prior object
+    device_prior = (not args.host_prior) and eng.set_device_prior(pc_prior)
     eng.load_state(u, x, logdetj, logl, logp)
     eng.set_geometry(mu=geo.t_mean, cov=geo.t_cov)
     ad = Adaptation("preconditioned_pcn", D, n * world, n_steps=10 ** 9, n_max=10 ** 9, sigma0=sigma0,
@@ -183,7 +190,7 @@ def main():
         ta = time.perf_counter()
         eng.propose(ad.sigma, nu)
         th = time.perf_counter()
-        eng.evaluate(prior.logpdf, loglike)
+        eng.evaluate(pc_prior.logpdf, loglike)
         tb = time.perf_counter()
         t_host[0] += tb - th
         sums = eng.accept_reduce(beta, nu)
@@ -276,7 +283,7 @@ def main():
                                   f"(H={spec.hidden}), beta={beta}, tpCN kernel, host numpy likelihood in the loop",
                       "walkers_per_gpu": n, "global_walkers": n * world, "n_dim": D, "flow": "maf3",
                       "flow_trained_50_epochs": flow_trained, "parallelism": f"walker-sharded x{world}",
-                      "inverse_algo": args.inverse, "host_threads": args.host_threads, "host_x_order": args.x_order, "accept_rate": float(ad.mean_alpha)},
+                      "inverse_algo": args.inverse, "host_threads": args.host_threads, "host_x_order": args.x_order, "prior_on_device": bool(device_prior), "accept_rate": float(ad.mean_alpha)},
            "roofline": roofline,
            "breakdown_us_per_step": dict(us, host_prior_likelihood=t_host[0] / n_inst * 1e6,
                                          device_kernels=us["propose"] + us["maf_inverse"] + us["scaler_inverse"]

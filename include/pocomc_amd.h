@@ -127,6 +127,25 @@ int pmc_scaler_inverse(const pmc_scaler_t* s, const float* u_in, const double* u
 /* Reparameterize.forward (scaler.py:180-202), no input check.  x f64 [n][D] -> u f64 [n][D]. */
 int pmc_scaler_forward(const pmc_scaler_t* s, const double* x, double* u, int64_t n, void* stream);
 
+/* ----------------------------------------------------------------- prior */
+
+/* pocomc/prior.py: a product of frozen scipy.stats distributions.  Unlike the likelihood it is not a
+ * user black box: the families below are evaluated on the device, everything else stays on the host. */
+#define PMC_PRIOR_UNIFORM 1   /* scipy.stats.uniform(loc, scale) */
+#define PMC_PRIOR_NORM 2      /* scipy.stats.norm(loc, scale) */
+typedef struct pmc_prior {
+    const int32_t* family;    /* [D] */
+    const double* loc;        /* [D] */
+    const double* scale;      /* [D] */
+    int32_t D;
+    int32_t reserved;
+} pmc_prior_t;
+
+/* Prior.logpdf, prior.py:70-100, with the gating of mcmc.py:105-107: logp[k] = -inf where finite[k] == 0
+ * (finite may be NULL).  x f64 [n][D], logp f64 [n]. */
+int pmc_prior_logpdf(const pmc_prior_t* pr, const double* x, const int32_t* finite, double* logp, int64_t n,
+                     void* stream);
+
 /* ------------------------------------------------------------ MCMC step */
 
 #define PMC_KIND_TPCN 0   /* t-preconditioned Crank-Nicolson proposal (mcmc.py:77-85, :394-402) */
@@ -231,6 +250,8 @@ typedef struct pmc_step {
     int32_t* h_accept;        /* pinned host [n] or NULL */
     void* ev_inv0;            /* optional hipEvent_t recorded right before / after the flow-inverse launch */
     void* ev_inv1;
+    const pmc_prior_t* prior; /* non-NULL: logp' is evaluated on the device in pmc_step_pre and copied to h_logp_out */
+    double* h_logp_out;       /* pinned host [n] (may alias h_logp) */
 } pmc_step_t;
 
 /* mcmc.py:77-102 in one call: [H2D mu] -> propose -> flow inverse -> scaler inverse -> D2H x', finite. */

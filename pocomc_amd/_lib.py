@@ -36,6 +36,10 @@ class pmc_scaler_t(C.Structure):
                 ("reserved", C.c_int32), ("sum_log_sigma", C.c_double)]
 
 
+class pmc_prior_t(C.Structure):
+    _fields_ = [("family", c_p), ("loc", c_p), ("scale", c_p), ("D", C.c_int32), ("reserved", C.c_int32)]
+
+
 class pmc_rng_t(C.Structure):
     _fields_ = [("gamma", c_p), ("normal", c_p), ("uniform", c_p),
                 ("seed", C.c_uint64), ("step", C.c_uint64), ("offset", C.c_uint64)]
@@ -60,7 +64,8 @@ class pmc_step_t(C.Structure):
                 ("p_xT", c_p), ("p_logdetj", c_p), ("p_fin", c_p), ("quad", c_p), ("p_quad", c_p), ("p_logl", c_p),
                 ("p_logp", c_p), ("alpha", c_p), ("accept", c_p), ("sums", c_p), ("ws", c_p),
                 ("h_mu", c_p), ("h_x", c_p), ("h_fin", c_p), ("h_logl", c_p), ("h_logp", c_p), ("h_sums", c_p),
-                ("h_accept", c_p), ("ev_inv0", c_p), ("ev_inv1", c_p)]
+                ("h_accept", c_p), ("ev_inv0", c_p), ("ev_inv1", c_p),
+                ("prior", c_p), ("h_logp_out", c_p)]
 
 
 # name -> (restype, argtypes); every symbol include/pocomc_amd.h declares
@@ -78,6 +83,7 @@ SIGNATURES = {
     "pmc_adamw_step": (C.c_int, [c_p, c_p, c_p, c_p, i64, f64, f64, f64, f64, f64, f64, i64, c_p, c_p]),
     "pmc_scaler_inverse": (C.c_int, [P(pmc_scaler_t), c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
     "pmc_scaler_forward": (C.c_int, [P(pmc_scaler_t), c_p, c_p, i64, c_p]),
+    "pmc_prior_logpdf": (C.c_int, [P(pmc_prior_t), c_p, c_p, c_p, i64, c_p]),
     "pmc_propose": (C.c_int, [C.c_int, c_p, c_p, c_p, c_p, c_p, f64, f64, f64, P(pmc_rng_t),
                               c_p, c_p, c_p, c_p, i64, i32, c_p]),
     "pmc_accept_workspace_bytes": (i64, [i64, i32]),

@@ -272,6 +272,48 @@ __global__ __launch_bounds__(256) void scaler_forward_kernel(pmc_scaler_t s, con
 }
 
 // ===========================================================================
+// Prior.logpdf (pocomc/prior.py:70-100) for the scipy.stats families the device knows:
+// logp = sum_j dist_j.logpdf(x[:, j]), accumulated dimension after dimension like the reference
+// ===========================================================================
+__global__ __launch_bounds__(256) void prior_logpdf_kernel(pmc_prior_t pr, const double* __restrict__ x,
+                                                           const int32_t* __restrict__ finite,
+                                                           double* __restrict__ logp, int64_t n) {
+    const int D = pr.D;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        double lp = -INFINITY;
+        if (!finite || finite[k]) {                                  // mcmc.py:105-107
+            lp = 0.0;
+            const double* xr = x + k * D;
+            for (int j = 0; j < D; ++j) {
+                const double xv = xr[j], loc = pr.loc[j], sc = pr.scale[j];
+                double t;
+                if (pr.family[j] == PMC_PRIOR_UNIFORM) {
+                    // scipy uniform(loc, scale).logpdf: -log(scale) on [loc, loc+scale], -inf outside
+                    t = (xv >= loc && xv <= loc + sc) ? -log(sc) : -INFINITY;
+                } else {
+                    // scipy norm(loc, scale).logpdf: _norm_logpdf((x-loc)/scale) - log(scale)
+                    const double z = (xv - loc) / sc;
+                    t = (-(z * z) / 2.0 - LOG_SQRT_2PI) - log(sc);
+                }
+                lp += t;
+            }
+        }
+        logp[k] = lp;
+    }
+}
+
+extern "C" int pmc_prior_logpdf(const pmc_prior_t* pr, const double* x, const int32_t* finite, double* logp,
+                                int64_t n, void* stream) {
+    if (!pr || !pr->family || !pr->loc || !pr->scale || pr->D < 1 || !x || !logp || n < 0)
+        return pmc_fail("pmc_prior_logpdf: bad argument");
+    if (n == 0) return 0;
+    int64_t grid = (n + 255) / 256; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(prior_logpdf_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *pr, x, finite,
+                       logp, n);
+    return pmc_check_launch("prior_logpdf_kernel");
+}
+
+// ===========================================================================
 // Metropolis ratio, accept, reductions: mcmc.py:124-156 and variants
 // ===========================================================================
 __device__ __forceinline__ double block_sum_256(double v, double* red, int tid) {

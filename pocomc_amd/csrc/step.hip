@@ -37,6 +37,12 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
         rc = pmc_scaler_inverse(s->scaler, nullptr, s->p_theta64, s->p_u, s->p_x, s->p_xT, s->p_logdetj, s->p_fin, n, stream);
     }
     if (rc) return rc;
+    if (s->prior) {
+        rc = pmc_prior_logpdf(s->prior, s->p_x, s->p_fin, s->p_logp, n, stream);
+        if (rc) return rc;
+        if (hipMemcpyAsync(s->h_logp_out, s->p_logp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess)
+            return pmc_fail("pmc_step_pre: D2H logp");
+    }
     const double* xsrc = s->p_xT ? s->p_xT : s->p_x;
     if (hipMemcpyAsync(s->h_x, xsrc, (size_t)n * D * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(s->h_fin, s->p_fin, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess)
@@ -49,7 +55,9 @@ extern "C" int pmc_step_post(const pmc_step_t* s, const pmc_rng_t* rng, double b
     if (!s || !rng) return pmc_fail("pmc_step_post: null argument");
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = s->n;
-    if (hipMemcpyAsync(s->p_logl, s->h_logl, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+    if (hipMemcpyAsync(s->p_logl, s->h_logl, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+        return pmc_fail("pmc_step_post: H2D");
+    if (!s->prior &&     // with a device prior logp' never left the device
         hipMemcpyAsync(s->p_logp, s->h_logp, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
         return pmc_fail("pmc_step_post: H2D");
     pmc_state_t cur = s->cur;

@@ -184,6 +184,7 @@ class StepEngine:
             h_accept=self.h_accept.data_ptr())
         self._rng_fast = _lib.pmc_rng_t(gamma=None, normal=None, uniform=None, seed=self.seed, step=0,
                                         offset=self.offset)
+        self.prior_desc = None   # pmc_prior_t when Prior.logpdf runs on the device (set_device_prior)
         self.composite = True    # one C call before / after the host black boxes (pmc_step_pre / _post)
         self._post_uploads = False
         self.step_idx = 0
@@ -219,6 +220,19 @@ class StepEngine:
         if self.tpcn:
             self.inv_cov_d.copy_(torch.from_numpy(np.ascontiguousarray(np.linalg.inv(cov))))
             self.set_mu(mu)
+
+    def set_device_prior(self, prior):
+        """Evaluate ``prior.logpdf`` (a product of uniform / normal ``scipy.stats`` factors) on the
+        device right after the scaler instead of on the host.  Returns False if the prior has a factor
+        the device does not know (then it stays a host callback)."""
+        desc = prior.device_descriptor(self.device) if hasattr(prior, "device_descriptor") else None
+        if desc is None:
+            return False
+        self._prior_obj = prior                      # keeps the descriptor's tensors alive
+        self.prior_desc = desc
+        self._step.prior = C.cast(C.pointer(desc), C.c_void_p)
+        self._step.h_logp_out = self.h_logp.data_ptr()
+        return True
 
     def set_mu(self, mu):
         # pinned staging + async copy; the previous upload was consumed by a kernel that has
@@ -287,6 +301,11 @@ class StepEngine:
                                                   _lib.ptr(self.p_logdetj),
                                                   _lib.ptr(self.p_fin), n, st), "pmc_scaler_inverse")
             e3 = self._ev() if timed else None
+            if self.prior_desc is not None:
+                _lib.check(lib.pmc_prior_logpdf(C.byref(self.prior_desc), _lib.ptr(self.p_x), _lib.ptr(self.p_fin),
+                                                _lib.ptr(self.p_logp), n, st), "pmc_prior_logpdf")
+        if self.prior_desc is not None:
+            self.h_logp.copy_(self.p_logp, non_blocking=True)
         self.h_x.copy_(self.p_xT if self.x_order == "F" else self.p_x, non_blocking=True)
         self.h_fin.copy_(self.p_fin, non_blocking=True)
         if timed:
@@ -312,6 +331,8 @@ class StepEngine:
             def log_like(a, _f=_ll):
                 ta = time.perf_counter(); r = _f(a); tm["likelihood"] += time.perf_counter() - ta
                 return r
+        if self.prior_desc is not None:
+            log_prior = None                          # logp' came back from the device with x'
         n = self.n
         x_prime = self._np_x
         logp_prime = self._np_logp
@@ -330,8 +351,9 @@ class StepEngine:
             def work(b):
                 lo, hi = b
                 xs = x_prime[lo:hi]
-                lp = log_prior(xs)
-                logp_prime[lo:hi] = lp
+                if log_prior is not None:
+                    logp_prime[lo:hi] = log_prior(xs)
+                lp = logp_prime[lo:hi]
                 ok = np.isfinite(lp)
                 if ok.all():
                     logl_prime[lo:hi] = log_like(xs)[0]
@@ -345,7 +367,8 @@ class StepEngine:
             return calls, None
         if fin_i.all():
             # every proposal is finite (the usual case): x'[mask] of mcmc.py:106 is x' itself
-            logp_prime[:] = log_prior(x_prime)
+            if log_prior is not None:
+                logp_prime[:] = log_prior(x_prime)
             finite = np.isfinite(logp_prime)
             if finite.all():
                 if have_blobs:
@@ -357,8 +380,9 @@ class StepEngine:
                 return n, blobs_prime
         else:
             finite = fin_i.astype(bool)
-            logp_prime[finite] = log_prior(x_prime[finite])
-            logp_prime[~finite] = -np.inf
+            if log_prior is not None:
+                logp_prime[finite] = log_prior(x_prime[finite])
+                logp_prime[~finite] = -np.inf
             finite = finite & np.isfinite(logp_prime)
         if have_blobs:
             blobs_prime = np.empty(n, dtype=np.dtype((blobs[0].dtype, blobs[0].shape)))
@@ -372,7 +396,8 @@ class StepEngine:
     def _upload_logs(self):
         if not self._post_uploads:                    # the composite post step does the H2D itself
             self.p_logl.copy_(self.h_logl, non_blocking=True)
-            self.p_logp.copy_(self.h_logp, non_blocking=True)
+            if self.prior_desc is None:
+                self.p_logp.copy_(self.h_logp, non_blocking=True)
 
     def accept_reduce(self, beta, nu=0.0, want_mask=False):
         """Metropolis accept + global sums; returns the (all-reduced) host copy."""
@@ -452,6 +477,9 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
 
     eng = StepEngine(kind, n_walkers, n_dim, flow, scaler, group=group,
                      shard_offset=option_dict.get("shard_offset", 0), seed=seed)
+    owner = getattr(log_prior, "__self__", None)
+    if owner is not None and option_dict.get("device_prior", True) and hasattr(owner, "device_descriptor"):
+        eng.set_device_prior(owner)                 # Prior.logpdf of uniform / normal factors on the device
     eng.load_state(u, x, logdetj, logl, logp)
     nu = 0.0
     if tpcn:

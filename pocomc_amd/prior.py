@@ -20,6 +20,28 @@ class Prior:
         except Exception:
             self._fast = None
 
+    # ---------------------------------------------------------------- device
+    def device_descriptor(self, device=None):
+        """``pmc_prior_t`` for the MCMC engine, or ``None`` when a factor is not a family the device
+        evaluates (then ``logpdf`` is called on the host like any black box)."""
+        if self._fast is None:
+            return None
+        if getattr(self, "_ddesc", None) is None:
+            import torch
+            from . import _lib
+            dev = device if device is not None else _lib.require_gpu()
+            is_u, loc, scale = self._fast
+            fam = np.where(is_u, 1, 2).astype(np.int32)
+            self._dtensors = [torch.from_numpy(a).to(dev) for a in (fam, loc.copy(), scale.copy())]
+            self._ddesc = _lib.pmc_prior_t(family=self._dtensors[0].data_ptr(), loc=self._dtensors[1].data_ptr(),
+                                           scale=self._dtensors[2].data_ptr(), D=len(fam), reserved=0)
+        return self._ddesc
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st.pop("_ddesc", None); st.pop("_dtensors", None)
+        return st
+
     def logpdf(self, x):
         """``pocomc/prior.py:70-100``."""
         if self._fast is not None:

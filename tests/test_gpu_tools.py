@@ -123,3 +123,66 @@ def test_scaler_out_of_bounds_raises():
     sc = Reparameterize(3, np.tile(np.array([[0.0, 1.0]]), (3, 1)))
     with pytest.raises(ValueError):
         sc.fit(np.full((5, 3), 2.0))
+
+
+def test_device_prior_matches_scipy():
+    """Prior.logpdf (pocomc/prior.py:70-100) of uniform / normal factors on the device."""
+    import ctypes as C
+    import torch
+    from scipy.stats import norm, uniform
+    import pocomc_amd as pc
+    from pocomc_amd import _lib
+    dists = [uniform(-2.0, 5.0), norm(0.5, 1.7), uniform(0.0, 1.0), norm(-3.0, 0.2), norm(0.0, 1.0)]
+    prior = pc.Prior(dists)
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(1000, 5)) * 1.5
+    x[:, 2] = rng.uniform(-0.2, 1.2, size=1000)
+    ref = np.zeros(len(x))
+    for i, d in enumerate(dists):                              # the reference's loop
+        ref += d.logpdf(x[:, i])
+    np.testing.assert_allclose(prior.logpdf(x), ref, rtol=1e-13)      # host fast path
+    desc = prior.device_descriptor()
+    xd = torch.from_numpy(x).cuda()
+    fin = torch.ones(len(x), dtype=torch.int32, device="cuda")
+    fin[:10] = 0
+    out = torch.empty(len(x), dtype=torch.float64, device="cuda")
+    _lib.check(_lib.load().pmc_prior_logpdf(C.byref(desc), _lib.ptr(xd), _lib.ptr(fin), _lib.ptr(out), len(x),
+                                           _lib.stream_handle()))
+    got = out.cpu().numpy()
+    assert np.isneginf(got[:10]).all()
+    assert (np.isneginf(got[10:]) == np.isneginf(ref[10:])).all()
+    ok = np.isfinite(ref) & (np.arange(len(x)) >= 10)
+    np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-13, atol=1e-13)
+    from scipy.stats import gamma
+    assert pc.Prior([gamma(2.0)]).device_descriptor() is None    # unknown family: stays on the host
+
+
+def test_kernel_call_with_device_prior_equals_host_prior():
+    """Same kernel call with the prior evaluated on the device and on the host (Philox mode, same seed)."""
+    from scipy.stats import uniform
+    import pocomc_amd as pc
+    from pocomc_amd import mcmc as pmcmc
+    from pocomc_amd.geometry import Geometry
+    import torch
+    D, N = 6, 512
+    prior = pc.Prior([uniform(-5, 10)] * D)
+    rng = np.random.default_rng(1)
+    scaler = pc.Reparameterize(D, bounds=prior.bounds)
+    scaler.fit(prior.rvs(2000))
+    x = rng.uniform(-4, 4, size=(N, D))
+    u = scaler.forward(x)
+    like = lambda xx: (-0.5 * np.sum(xx ** 2, axis=1), None)
+    flow = pc.Flow(D, "maf3", seed=0)
+    geo = Geometry()
+    geo.fit(flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64))
+    res = []
+    for dev in (True, False):
+        state = dict(u=u.copy(), x=x.copy(), logdetj=scaler.inverse(u)[1], logl=like(x)[0], logp=prior.logpdf(x),
+                     beta=0.5, blobs=None)
+        funcs = dict(loglike=like, logprior=prior.logpdf, scaler=scaler, flow=flow, theta_geometry=geo)
+        opts = dict(n_max=5, n_steps=10 ** 6, progress_bar=None, proposal_scale=2.38 / D ** 0.5, seed=99,
+                    device_prior=dev)
+        res.append(pmcmc.preconditioned_pcn(state, funcs, opts))
+    for k in ("u", "x", "logl", "logp", "logdetj"):
+        np.testing.assert_allclose(res[0][k], res[1][k], rtol=1e-12, atol=1e-12)
+    assert res[0]["steps"] == res[1]["steps"] == 5 and res[0]["calls"] == res[1]["calls"]
