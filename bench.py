@@ -122,10 +122,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # PMC_BENCH_BACKEND=gloo PMC_BENCH_SHARE_GPU=1: functional check of the N>1 code path on a 1-GPU box
+    backend = os.environ.get("PMC_BENCH_BACKEND", "nccl")
+    if os.environ.get("PMC_BENCH_SHARE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     D, n, beta = args.dim, args.particles, 0.5
@@ -143,12 +150,16 @@ def main():
     flow = Flow(D, "maf3", seed=0)                          # replicated weights
     flow.inverse_algo = {"auto": 0, "triangular": 1, "naive": 2, "triangular_v1": 3, "triangular_v2": 4}[args.inverse]
     flow_trained = False
+    torch.manual_seed(0)                                    # same shuffles / batches on every rank
     try:
         flow.fit(torch.from_numpy(scaler.forward(x_fit[:n])).float(), epochs=50, batch_size=512,
                  validation_split=0.5, patience=D, annealing=False, verbose=0)
         flow_trained = True
     except NotImplementedError:
         pass
+    if world > 1:                                           # replicated weights: bit-identical on every rank
+        dist.broadcast(flow.params, 0)
+        flow.repack()
     # geometry of theta = flow.forward(u): fitted on rank 0's shard, broadcast (replicated input of the step)
     theta0 = flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64)
     geo = Geometry()
