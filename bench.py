@@ -110,7 +110,7 @@ def main():
                          "uniform factors, not a black box)")
     ap.add_argument("--x-order", choices=["C", "F"], default="F",
                     help="memory order of the (n, D) array handed to the host prior/likelihood")
-    ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "triangular_v1", "triangular_v2"], default="auto")
+    ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "triangular_v1", "triangular_v2", "triangular_v3"], default="auto")
     args = ap.parse_args()
 
     import torch
@@ -148,7 +148,7 @@ def main():
     logdetj = scaler.inverse(u)[1]
     logl, logp = rosenbrock(x), prior.logpdf(x)
     flow = Flow(D, "maf3", seed=0)                          # replicated weights
-    flow.inverse_algo = {"auto": 0, "triangular": 1, "naive": 2, "triangular_v1": 3, "triangular_v2": 4}[args.inverse]
+    flow.inverse_algo = {"auto": 0, "triangular": 1, "naive": 2, "triangular_v1": 3, "triangular_v2": 4, "triangular_v3": 5}[args.inverse]
     flow_trained = False
     torch.manual_seed(0)                                    # same shuffles / batches on every rank
     try:
@@ -276,8 +276,9 @@ def main():
         pass
     achieved = algo_flops / t_inv / 1e12
     roofline = {"bound": "mfma", "kernel": ("maf_dense_kernel<1>" if (args.inverse == "naive" or not spec.tri_ok) else
-                           {"triangular_v1": "maf_inverse_tri_kernel", "triangular_v2": "maf_inverse_tri2_kernel"}.get(
-                               args.inverse, "maf_inverse_tri3_kernel" if spec.nOT <= 8 else "maf_inverse_tri2_kernel")), "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           {"triangular_v1": "maf_inverse_tri_kernel", "triangular_v2": "maf_inverse_tri2_kernel",
+                            "triangular_v3": "maf_inverse_tri3_kernel"}.get(
+                               args.inverse, "maf_inverse_tri4_kernel" if spec.nOT <= 8 else "maf_inverse_tri2_kernel")), "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                 "avg_launch_us": inv_us_live,
                 "note": "achieved = SURVEY 8(d) naive-equivalent flops ((D+1)*F_fwd per walker) / launch time; the "

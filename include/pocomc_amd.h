@@ -53,6 +53,7 @@ typedef struct pmc_maf {
 #define PMC_INVERSE_TRIANGULAR 1   /* one sweep over the degree groups */
 #define PMC_INVERSE_NAIVE 2        /* the reference's D fixed-point passes (zuko) */
 #define PMC_INVERSE_TRIANGULAR_V1 3 /* first (un-prefetched, barrier-synchronised) sweep; kept for A/B */
+#define PMC_INVERSE_TRIANGULAR_V3 5 /* register-resident chain, pointer-addressed weights; kept for A/B */
 #define PMC_INVERSE_TRIANGULAR_V2 4 /* prefetching sweep whose chain hops through LDS; used when D > 64 */
 
 /* packed[i] = idx[i] >= 0 ? flat[idx[i]] : 0   (canonical fp32 params -> kernel layout) */

@@ -1,0 +1,341 @@
+// Triangular-sweep MAF inverse, register-resident chain (maf_chain.h) + buffer-addressed weights.
+//
+// PMC on maf_inverse_tri3_kernel (profiles/r01_c_rocprof_summary.txt): 15.7 k VALU instructions against
+// 2061 MFMAs per wave and the MFMA pipe busy only 26 % of the wave's lifetime -- most VALU work was
+// 64-bit address arithmetic for ~50 weight loads per tile and the copies of a double-buffered
+// fragment set.  This version
+//   * reads every weight through ONE bounds-checked buffer resource per transform
+//     (raw_buffer_load_b128: wave-constant VGPR offset + SGPR byte offset + immediate), so a load
+//     costs one SALU add instead of 5-6 VALU instructions and needs no per-array base pointers;
+//   * fetches the chain's own fragments at the top of the tile, where the natural-layout bursts
+//     (tens of MFMAs) hide their latency -- no second register set, no copies;
+//   * keeps the prefetch of the NEXT tile's burst fragments issued right after the bursts.
+
+#include "maf_chain_rot.h"
+
+#define PX4 2
+#define PK4 8
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+
+// Straight-line burst of hidden tile TT against tiles 0..TT-1 (TT is a compile-time constant):
+// every LDS read is issued up front and two independent accumulators per layer keep the MFMAs
+// back to back (a dependent v_mfma_f32_16x16x4_f32 waits 40 cycles, an independent one issues after 32).
+template <int TT>
+__device__ __forceinline__ void burst_tile(f32x4& a1, f32x4& a2, const float4 (&pf1)[PK4], const float4 (&pf2)[PK4],
+                                           const float* H0, const float* H1, int lane) {
+    if constexpr (TT > 0) {
+        float4 b1[TT], b2[TT];
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            b1[i] = *reinterpret_cast<const float4*>(H0 + (i << 8) + (lane << 2));
+            b2[i] = *reinterpret_cast<const float4*>(H1 + (i << 8) + (lane << 2));
+        }
+        f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, c2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            a1 = MFMA(pf1[i].x, b1[i].x, a1); a2 = MFMA(pf2[i].x, b2[i].x, a2);
+            c1 = MFMA(pf1[i].y, b1[i].y, c1); c2 = MFMA(pf2[i].y, b2[i].y, c2);
+            a1 = MFMA(pf1[i].z, b1[i].z, a1); a2 = MFMA(pf2[i].z, b2[i].z, a2);
+            c1 = MFMA(pf1[i].w, b1[i].w, c1); c2 = MFMA(pf2[i].w, b2[i].w, c2);
+        }
+        for (int r = 0; r < 4; ++r) { a1[r] += c1[r]; a2[r] += c2[r]; }
+    }
+}
+
+template <int TT>
+__device__ __forceinline__ void prefetch_tile(float4 (&pf1)[PK4], float4 (&pf2)[PK4], __amdgpu_buffer_rsrc_t rs,
+                                              int vo_lane, int so1, int so2) {
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        pf1[i] = bload4(rs, vo_lane, so1 + i * 1024);
+        pf2[i] = bload4(rs, vo_lane, so2 + i * 1024);
+    }
+}
+
+// ABL: timing-only ablations (see maf_chain_rot.h); 4 = no bursts, 8 = no chain, 16 = no next-tile prefetch,
+// 32 = no tile-top fragment loads
+template <int MAXO, int ABL>
+__global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const float* __restrict__ in,
+                                                              float* __restrict__ out,
+                                                              float* __restrict__ ladj_out, int64_t n) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int q = lane >> 4, p = lane & 15;
+    const int64_t row0 = (int64_t)blockIdx.x * 16;
+    const int D = m.D, Dp = m.Dp, Hp = m.Hp, T = m.T, nT = m.nT, nXT = m.nXT, nOT = m.nOT;
+    float* Y = smem;
+    float* X = Y + Dp * 16;
+    float* H0 = X + Dp * 16;
+    float* H1 = H0 + Hp * 16;
+    float* H2 = H1 + Hp * 16;
+    float* S = H2 + Hp * 16;                   // staging: [3 layers][16 p][16 rows] then [MAXO][16 p][16 rows]
+    float* SO = S + 3 * 256;
+    const int* feat_of_rank = m.meta + 8;
+    const int* rank_of_feat = m.meta + 8 + T * D;
+    const int* quad_meta = m.meta + 8 + 2 * T * D;
+
+    // byte offsets of the packed arrays inside one transform's block (maf_spec.py: pk_offsets)
+    const int oF0 = 0;
+    const int oF1 = oF0 + nT * nXT * 1024;
+    const int oF2 = oF1 + nT * nT * 1024;
+    const int oF3 = oF2 + nT * nT * 1024;
+    const int oW0 = oF3 + nOT * nT * 1024;
+    const int oB0 = oW0 + Dp * Hp * 4;
+    const int oB1 = oB0 + Hp * 4;
+    const int oB2 = oB1 + Hp * 4;
+    const int oB3 = oB2 + Hp * 4;
+    const int blk_bytes = (int)(m.pk_per_transform * 4);
+
+    // wave-constant lane offsets (bytes)
+    const int vo_lane = lane << 4;                              // natural fragment record: lane * 16 B
+    // rotated R-layout gather inside a record (+ 64*jt): tile row i = lane&15 carries quad row ((i>>2) + (i&3)) & 3
+    const int vo_R = ((q << 4) + ((((lane & 15) >> 2) + (lane & 3)) & 3)) << 4;
+    const int vo_q = q << 4;                                    // 4 consecutive floats of quad q
+
+    load_rows(Y, in, row0, n, D, Dp, feat_of_rank + (T - 1) * D, lane);
+    {   // padding slots of the activations are read by the bursts (times zero weights): zero once
+        float4* z4 = reinterpret_cast<float4*>(H0);
+        const int n4 = (3 * Hp * 16) >> 2;
+        for (int e = lane; e < n4; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float ladj = 0.0f;
+
+    for (int t = T - 1; t >= 0; --t) {
+        const float* blk = m.packed + (size_t)t * m.pk_per_transform;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)blk, 0, blk_bytes, 0x00020000);
+        {
+            float4* z4 = reinterpret_cast<float4*>(X);
+            for (int e = lane; e < (Dp * 16) >> 2; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+
+        ChainRot<MAXO> s;
+#pragma unroll
+        for (int O = 0; O < MAXO; ++O) {
+            const float4 bb = (O < nOT) ? bload4(rs, vo_q, oB3 + 64 * O) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s.oN[O][0] = bb.x; s.oN[O][1] = bb.y; s.oN[O][2] = bb.z; s.oN[O][3] = bb.w;
+        }
+        // ---- rank 0 reads nothing: bias only
+        {
+            const float* b3 = blk + (oB3 >> 2);
+            const float shift = b3[0], ls = fast_ls(b3[1]);
+            const float xv = (Y[lidx(0, p)] - shift) * fast_exp_neg(ls);
+            ladj -= ls;
+            if (q == 0) X[lidx(0, p)] = xv;
+        }
+        WAVE_LDS_FENCE();
+
+        // burst fragments of the NEXT tile (filled while the current tile's chain runs)
+        float4 pf0[PX4], pf1[PK4], pf2[PK4], pb0, pb1, pb2;
+#define PREFETCH4(TT)                                                                                          \
+        if (!(ABL & 16)) {                                                                                                      \
+            const int TT_ = (TT);                                                                              \
+            _Pragma("unroll") for (int i_ = 0; i_ < PX4; ++i_)                                                 \
+                if (i_ < nXT) pf0[i_] = bload4(rs, vo_lane, oF0 + (TT_ * nXT + i_) * 1024);                     \
+            {                                                                                                  \
+                const int so1_ = oF1 + TT_ * nT * 1024, so2_ = oF2 + TT_ * nT * 1024;                          \
+                switch (TT_ < PK4 ? TT_ : PK4) {                                                               \
+                    case 1: prefetch_tile<1>(pf1, pf2, rs, vo_lane, so1_, so2_); break;                        \
+                    case 2: prefetch_tile<2>(pf1, pf2, rs, vo_lane, so1_, so2_); break;                        \
+                    case 3: prefetch_tile<3>(pf1, pf2, rs, vo_lane, so1_, so2_); break;                        \
+                    case 4: prefetch_tile<4>(pf1, pf2, rs, vo_lane, so1_, so2_); break;                        \
+                    case 5: prefetch_tile<5>(pf1, pf2, rs, vo_lane, so1_, so2_); break;                        \
+                    case 6: prefetch_tile<6>(pf1, pf2, rs, vo_lane, so1_, so2_); break;                        \
+                    case 7: prefetch_tile<7>(pf1, pf2, rs, vo_lane, so1_, so2_); break;                        \
+                    case 8: prefetch_tile<8>(pf1, pf2, rs, vo_lane, so1_, so2_); break;                        \
+                    default: break;                                                                            \
+                }                                                                                              \
+            }                                                                                                  \
+            pb0 = bload4(rs, vo_q, oB0 + 64 * TT_);                                                            \
+            pb1 = bload4(rs, vo_q, oB1 + 64 * TT_);                                                            \
+            pb2 = bload4(rs, vo_q, oB2 + 64 * TT_);                                                            \
+        }
+        PREFETCH4(0);
+        int4 dg_next = *reinterpret_cast<const int4*>(quad_meta);
+
+        for (int Tt = 0; Tt < nT; ++Tt) {
+            int4 dg = dg_next;
+            dg.x &= 0xffff; dg.y &= 0xffff; dg.z &= 0xffff; dg.w &= 0xffff;
+            if (dg.x >= D && dg.y >= D && dg.z >= D && dg.w >= D) break;       // padding tiles
+            const int pat = 1 | ((dg.y != dg.x) << 1) | ((dg.z != dg.y) << 2) | ((dg.w != dg.z) << 3);
+
+            // ---- the chain's own fragments: issued first, they land while the bursts run
+            {
+                const bool ny = dg.y != dg.x, nz = dg.z != dg.y, nw = dg.w != dg.z;
+                s.g[0] = dg.x;
+                s.g[1] = ny ? dg.y : (nz ? dg.z : (nw ? dg.w : D));
+                s.g[2] = ny ? (nz ? dg.z : (nw ? dg.w : D)) : ((nz && nw) ? dg.w : D);
+                s.g[3] = (ny && nz && nw) ? dg.w : D;
+            }
+            const int soD1 = oF1 + (Tt * nT + Tt) * 1024, soD2 = oF2 + (Tt * nT + Tt) * 1024;
+            if (!(ABL & 32)) {
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                s.wd1[jt] = bload4(rs, vo_R + 64 * jt, soD1);
+                s.wd2[jt] = bload4(rs, vo_R + 64 * jt, soD2);
+            }
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                // rows (lane&3): 0,1 -> (shift, raw) of group 2*sl; 2,3 -> group 2*sl+1
+                const int g_even = s.g[2 * sl], g_odd = s.g[2 * sl + 1];
+                const int gsel = (lane & 2) ? g_odd : g_even;
+                const bool ok = gsel < D;
+                const int gg = ok ? gsel : 0;
+                const int vo = ((((gg >> 3) * nT) << 6) + (q << 4) + 2 * (gg & 7) + (lane & 1)) << 4;
+                const float4 v = bload4(rs, vo, oF3 + Tt * 1024);
+                s.wo[sl] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int O = 0; O < MAXO; ++O)
+                s.f3n[O] = (O < nOT) ? bload4(rs, vo_lane, oF3 + (O * nT + Tt) * 1024) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int gg = s.g[i] < D ? s.g[i] : 0;
+#pragma unroll
+                for (int jt = i + 1; jt < 4; ++jt)
+                    s.w0r[i][jt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        rs, q << 2, oW0 + (gg * Hp + 16 * Tt + 4 * jt) * 4, 0));
+            }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s.yv[i] = Y[lidx(s.g[i] < D ? s.g[i] : 0, p)];
+
+            // ---- natural-layout bursts against everything that is already final
+            f32x4 a0, a1, a2;
+            a0[0] = pb0.x; a0[1] = pb0.y; a0[2] = pb0.z; a0[3] = pb0.w;
+            a1[0] = pb1.x; a1[1] = pb1.y; a1[2] = pb1.z; a1[3] = pb1.w;
+            a2[0] = pb2.x; a2[1] = pb2.y; a2[2] = pb2.z; a2[3] = pb2.w;
+#pragma unroll
+            for (int i = 0; i < PX4; ++i) {
+                if (i < nXT) {
+                    const float4 b = *reinterpret_cast<const float4*>(X + (i << 8) + (lane << 2));
+                    a0 = MFMA(pf0[i].x, b.x, a0); a0 = MFMA(pf0[i].y, b.y, a0);
+                    a0 = MFMA(pf0[i].z, b.z, a0); a0 = MFMA(pf0[i].w, b.w, a0);
+                }
+            }
+            for (int Xt = PX4; Xt < nXT; ++Xt) {
+                const float4 a = bload4(rs, vo_lane, oF0 + (Tt * nXT + Xt) * 1024);
+                const float4 b = *reinterpret_cast<const float4*>(X + (Xt << 8) + (lane << 2));
+                a0 = MFMA(a.x, b.x, a0); a0 = MFMA(a.y, b.y, a0); a0 = MFMA(a.z, b.z, a0); a0 = MFMA(a.w, b.w, a0);
+            }
+            if (!(ABL & 4))
+            switch (Tt < PK4 ? Tt : PK4) {
+                case 1: burst_tile<1>(a1, a2, pf1, pf2, H0, H1, lane); break;
+                case 2: burst_tile<2>(a1, a2, pf1, pf2, H0, H1, lane); break;
+                case 3: burst_tile<3>(a1, a2, pf1, pf2, H0, H1, lane); break;
+                case 4: burst_tile<4>(a1, a2, pf1, pf2, H0, H1, lane); break;
+                case 5: burst_tile<5>(a1, a2, pf1, pf2, H0, H1, lane); break;
+                case 6: burst_tile<6>(a1, a2, pf1, pf2, H0, H1, lane); break;
+                case 7: burst_tile<7>(a1, a2, pf1, pf2, H0, H1, lane); break;
+                case 8: burst_tile<8>(a1, a2, pf1, pf2, H0, H1, lane); break;
+                default: break;
+            }
+            for (int K = PK4; K < Tt; ++K) {
+                const float4 w1 = bload4(rs, vo_lane, oF1 + (Tt * nT + K) * 1024);
+                const float4 w2 = bload4(rs, vo_lane, oF2 + (Tt * nT + K) * 1024);
+                const float4 b1 = *reinterpret_cast<const float4*>(H0 + (K << 8) + (lane << 2));
+                const float4 b2 = *reinterpret_cast<const float4*>(H1 + (K << 8) + (lane << 2));
+                a1 = MFMA(w1.x, b1.x, a1); a2 = MFMA(w2.x, b2.x, a2);
+                a1 = MFMA(w1.y, b1.y, a1); a2 = MFMA(w2.y, b2.y, a2);
+                a1 = MFMA(w1.z, b1.z, a1); a2 = MFMA(w2.z, b2.z, a2);
+                a1 = MFMA(w1.w, b1.w, a1); a2 = MFMA(w2.w, b2.w, a2);
+            }
+            // ---- stage natural -> R layout ([p][row] so that a quad is one float4)
+            {
+                float* sp = S + (p << 4) + (q << 2);
+                *reinterpret_cast<float4*>(sp) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+                *reinterpret_cast<float4*>(sp + 256) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+                *reinterpret_cast<float4*>(sp + 512) = make_float4(a2[0], a2[1], a2[2], a2[3]);
+                float* so = SO + (p << 4) + (q << 2);
+#pragma unroll
+                for (int O = 0; O < MAXO; ++O)
+                    *reinterpret_cast<float4*>(so + O * 256) = make_float4(s.oN[O][0], s.oN[O][1], s.oN[O][2], s.oN[O][3]);
+            }
+            WAVE_LDS_FENCE();
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                // only row q of every quad is ever used by this lane (rotated layout)
+                s.a0[jt] = S[(p << 4) + (jt << 2) + q];
+                s.p1[jt] = S[256 + (p << 4) + (jt << 2) + q];
+                s.p2[jt] = S[512 + (p << 4) + (jt << 2) + q];
+                s.a1[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                s.a2[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            s.outR[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            s.outR[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gg = s.g[i] < D ? s.g[i] : 0;
+                s.po[i] = *reinterpret_cast<const float2*>(SO + (gg >> 3) * 256 + (p << 4) + 2 * (gg & 7));
+            }
+
+            // first group, then the next tile's burst fragments (loads return in order: issued any earlier
+            // they would sit between the chain and its own fragments), then the remaining groups
+            if (!(ABL & 8))
+            switch (pat) {
+#define CASE(P) case P: chain_group_rot<P, 0, 1, MAXO, ABL>(s, H0, H1, H2, X, Tt, D, nOT, q, p, ladj); break;
+                CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
+#undef CASE
+            }
+            if (Tt + 1 < nT) {
+                PREFETCH4(Tt + 1);
+                dg_next = *reinterpret_cast<const int4*>(quad_meta + 4 * (Tt + 1));
+            }
+            if (!(ABL & 8))
+            switch (pat) {
+#define CASE(P) case P: chain_group_rot<P, 1, 4, MAXO, ABL>(s, H0, H1, H2, X, Tt, D, nOT, q, p, ladj); break;
+                CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
+#undef CASE
+                default: break;
+            }
+            WAVE_LDS_FENCE();
+        }
+#undef PREFETCH4
+        __syncthreads();
+        const bool last = (t == 0);
+        rerank_or_store(X, Y, out, row0, n, D, Dp, feat_of_rank + t * D,
+                        last ? nullptr : rank_of_feat + (t - 1) * D, lane);
+        __syncthreads();
+    }
+    if (ladj_out && lane < 16 && row0 + p < n) ladj_out[row0 + p] = ladj;
+}
+
+int pmc_launch_inverse_tri4(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream) {
+    if (m->nOT > 8) return -1;                                     // caller falls back
+    if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;         // 32-bit buffer offsets
+    const int maxo = m->nOT <= 4 ? 4 : 8;
+    const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
+    if (lds > 160 * 1024) return -1;
+#define LAUNCH(MO)                                                                                               \
+    {                                                                                                            \
+        if (lds > 48 * 1024) {                                                                                   \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri4_kernel<MO, 0>),        \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+            if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_inverse_tri4_kernel)");         \
+        }                                                                                                        \
+        hipLaunchKernelGGL((maf_inverse_tri4_kernel<MO, 0>), dim3((unsigned)((n + 15) / 16)), dim3(64), lds,      \
+                           stream, *m, z, x, ladj, n);                                                           \
+    }
+    if (maxo == 4) LAUNCH(4) else LAUNCH(8)
+#undef LAUNCH
+    return pmc_check_launch("maf_inverse_tri4_kernel");
+}
+
+// timing-only ablations of the D <= 32 instance (scripts/ablate_inverse.py); NOT part of the ABI
+extern "C" int pmc_debug_inverse4_ablate(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, int abl,
+                                         void* stream) {
+    const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + 4 * 256) * sizeof(float);
+    const dim3 g((unsigned)((n + 15) / 16)), b(64);
+    hipStream_t st = (hipStream_t)stream;
+#define AB(V) case V: hipLaunchKernelGGL((maf_inverse_tri4_kernel<4, V>), g, b, lds, st, *m, z, x, ladj, n); break;
+    switch (abl) { AB(0) AB(1) AB(2) AB(3) AB(4) AB(8) AB(16) AB(32) AB(64) AB(12) AB(60) AB(127) default: return pmc_fail("unknown ablation"); }
+#undef AB
+    return pmc_check_launch("maf_inverse_tri4_kernel<ablate>");
+}

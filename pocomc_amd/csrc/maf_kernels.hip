@@ -331,10 +331,15 @@ extern "C" int pmc_maf_inverse(const pmc_maf_t* m, const float* z, float* x, flo
         const size_t lds = maf_lds_bytes(*m, 2);
         if (lds > 160 * 1024) return pmc_fail("MAF too wide for one wave's LDS budget (160 KiB)");
         {   // register-resident chain (output tiles <= 8, i.e. D <= 64); otherwise the LDS-hop sweep
-            const int rc = pmc_launch_inverse_tri3(m, z, x, ladj, n, (hipStream_t)stream);
+            const int rc = pmc_launch_inverse_tri4(m, z, x, ladj, n, (hipStream_t)stream);
             if (rc >= 0) return rc;
         }
         return pmc_launch_inverse_tri2(m, z, x, ladj, n, lds, (hipStream_t)stream);
+    } else if (algo == PMC_INVERSE_TRIANGULAR_V3) {
+        if (!m->tri_ok) return pmc_fail("pmc_maf_inverse: triangular sweep needs degree groups <= one tile");
+        const int rc = pmc_launch_inverse_tri3(m, z, x, ladj, n, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+        return pmc_fail("pmc_maf_inverse: the register-resident sweep needs D <= 64");
     } else if (algo == PMC_INVERSE_TRIANGULAR_V2) {
         if (!m->tri_ok) return pmc_fail("pmc_maf_inverse: triangular sweep needs degree groups <= one tile");
         const size_t lds = maf_lds_bytes(*m, 2);

@@ -11,6 +11,7 @@ int pmc_check_launch(const char* what);
 int pmc_launch_inverse_tri2(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, size_t lds,
                             hipStream_t stream);
 
+int pmc_launch_inverse_tri4(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream);
 int pmc_launch_inverse_tri3(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream);
 int pmc_launch_propose_mfma(int kind, const float* cur32, const double* cur64, const double* mu,
                             const double* inv_cov, const double* chol, double nu, double sigma, double cn_a,
