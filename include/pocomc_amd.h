@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PMC_ABI_VERSION 1
+#define PMC_ABI_VERSION 2
 
 const char* pmc_last_error(void);
 int pmc_abi_version(void);
@@ -69,21 +69,54 @@ int pmc_maf_forward(const pmc_maf_t* m, const float* x, float* z, float* ladj, f
 int pmc_maf_inverse(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
                     int algo, void* stream);
 
-/* Training-side device image (host side: MAFSpec.train_index()). */
+/* Training-side device image (host side: MAFSpec.train_index()).  The loss/gradient kernel
+ * gives every workgroup a private gradient slab in tile order and a scratch copy of each
+ * transform's input; a second kernel sums the slabs into the canonical gradient (no atomics,
+ * fixed summation order). */
 typedef struct pmc_maf_train {
     const float* packedT;     /* transposed weight fragments, filled by pmc_maf_pack with the packT map */
-    const int32_t* gmap;      /* canonical index of every weight-gradient tile element, -1 = masked */
+    const int32_t* gmap;      /* canonical index of every slab element, -1 = masked / padding */
     int64_t pkT_per_transform;
     int64_t gmap_per_transform;
+    float* slabs;             /* [n_slabs][slab_stride] */
+    int64_t slab_stride;      /* floats, >= T * gmap_per_transform, multiple of 4 */
+    int32_t n_slabs;          /* workgroups per launch (row sets beyond that are looped over) */
+    int32_t n_sq_partial;     /* capacity of sq_partial, >= ceil(T * gmap_per_transform / 1024) */
+    float* xt_scratch;        /* [n_slabs][T + 1][Dp * 16] */
+    float* loss_partial;      /* [n_slabs] */
+    float* sq_partial;        /* [n_sq_partial] per-block sums of squared gradient entries */
 } pmc_maf_train_t;
 
 /* One minibatch of Flow.fit, pocomc/flow.py:297-323: loss and parameter gradient.
  *   loss += sum_n c_n * (-log_prob(x_n));  c_n = 1 (w == NULL, flow.py:309) or
- *   c_n = w_n * wmul / *wsum (flow.py:311-312 with wmul = 1000, *wsum = sum of the batch weights).
- * x f32 [n][D]; w f32 [n] or NULL; wsum f32 [1] (device); grad f32 [n_params] in the canonical
- * layout and loss f32 [1] are ACCUMULATED (caller zeroes them). */
+ *   c_n = w_n * wmul / sum(w of the batch) (flow.py:311-312 with wmul = 1000).
+ * The batch is rows idx[0..n) of x / w (idx i64 device, or NULL for rows 0..n).  x f32 [.][D];
+ * grad f32 [n_params] in the canonical layout is OVERWRITTEN at every unmasked entry (masked
+ * entries are never touched: allocate it zeroed); loss f32 [1] is ACCUMULATED.
+ * tr->sq_partial receives the per-block sums of squares that pmc_maf_train_epoch clips with. */
 int pmc_maf_loss_grad(const pmc_maf_t* m, const pmc_maf_train_t* tr, const float* x, const float* w,
-                      const float* wsum, float wmul, float* grad, float* loss, int64_t n, void* stream);
+                      const int64_t* idx, float wmul, float* grad, float* loss, int64_t n, void* stream);
+
+/* Optimizer state of pmc_maf_train_epoch: torch.optim.AdamW (flow.py:268) on the canonical
+ * parameter vector + the two kernel images that are refreshed after every step. */
+typedef struct pmc_adamw {
+    float* params; float* grad; float* exp_avg; float* exp_avg_sq;
+    int64_t n_params;
+    const int32_t* pack_idx; float* packed; int64_t n_packed;       /* pmc_maf_t.packed */
+    const int32_t* packT_idx; float* packedT; int64_t n_packedT;    /* pmc_maf_train_t.packedT */
+    double lr, beta1, beta2, eps, weight_decay;
+    double max_norm;          /* clip_grad_norm_ (flow.py:318); <= 0 disables */
+    int64_t step;             /* optimizer steps taken so far; advanced by the call */
+} pmc_adamw_t;
+
+/* One epoch of the training loop, pocomc/flow.py:297-323: for every batch of `batch_size` rows
+ * (rows perm[b0 .. b0+nb) of x and w, or consecutive rows when perm == NULL; the last batch may
+ * be short): loss/gradient, global-norm clip, AdamW step, refresh of both kernel images.
+ * loss f32 [1] accumulates the sum of the batch losses (flow.py:321).  Everything is enqueued on
+ * `stream`; nothing synchronises. */
+int pmc_maf_train_epoch(const pmc_maf_t* m, const pmc_maf_train_t* tr, pmc_adamw_t* opt, const float* x,
+                        const float* w, const int64_t* perm, int64_t n, int64_t batch_size, float* loss,
+                        void* stream);
 
 /* out += sum_n -(logp_n * c_n)  (validation loss, flow.py:336-341);  out += sum_n v_n. */
 int pmc_neg_weighted_sum(const float* logp, const float* w, const float* wsum, float wmul, float* out,
@@ -91,10 +124,12 @@ int pmc_neg_weighted_sum(const float* logp, const float* w, const float* wsum, f
 int pmc_sum_f32(const float* v, float* out, int64_t n, void* stream);
 
 /* torch.nn.utils.clip_grad_norm_(max_norm) (flow.py:318; max_norm <= 0 disables) followed by one
- * torch.optim.AdamW step (flow.py:268, :319).  step counts from 1.  sqnorm_scratch f32 [1]. */
+ * torch.optim.AdamW step (flow.py:268, :319).  step counts from 1.
+ * sq_scratch f32 [PMC_ADAMW_SCRATCH]. */
+#define PMC_ADAMW_SCRATCH 256
 int pmc_adamw_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    double lr, double beta1, double beta2, double eps, double weight_decay,
-                   double max_norm, int64_t step, float* sqnorm_scratch, void* stream);
+                   double max_norm, int64_t step, float* sq_scratch, void* stream);
 
 /* ---------------------------------------------------------------- scaler */
 

@@ -26,7 +26,17 @@ class pmc_maf_t(C.Structure):
 
 class pmc_maf_train_t(C.Structure):
     _fields_ = [("packedT", c_p), ("gmap", c_p), ("pkT_per_transform", C.c_int64),
-                ("gmap_per_transform", C.c_int64)]
+                ("gmap_per_transform", C.c_int64),
+                ("slabs", c_p), ("slab_stride", C.c_int64), ("n_slabs", C.c_int32), ("n_sq_partial", C.c_int32),
+                ("xt_scratch", c_p), ("loss_partial", c_p), ("sq_partial", c_p)]
+
+
+class pmc_adamw_t(C.Structure):
+    _fields_ = [("params", c_p), ("grad", c_p), ("exp_avg", c_p), ("exp_avg_sq", c_p), ("n_params", C.c_int64),
+                ("pack_idx", c_p), ("packed", c_p), ("n_packed", C.c_int64),
+                ("packT_idx", c_p), ("packedT", c_p), ("n_packedT", C.c_int64),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("weight_decay", C.c_double), ("max_norm", C.c_double), ("step", C.c_int64)]
 
 
 class pmc_scaler_t(C.Structure):
@@ -78,6 +88,8 @@ SIGNATURES = {
     "pmc_maf_forward": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, c_p, i64, c_p]),
     "pmc_maf_inverse": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, i64, C.c_int, c_p]),
     "pmc_maf_loss_grad": (C.c_int, [P(pmc_maf_t), P(pmc_maf_train_t), c_p, c_p, c_p, C.c_float, c_p, c_p, i64, c_p]),
+    "pmc_maf_train_epoch": (C.c_int, [P(pmc_maf_t), P(pmc_maf_train_t), P(pmc_adamw_t), c_p, c_p, c_p, i64, i64, c_p,
+                                      c_p]),
     "pmc_neg_weighted_sum": (C.c_int, [c_p, c_p, c_p, C.c_float, c_p, i64, c_p]),
     "pmc_sum_f32": (C.c_int, [c_p, c_p, i64, c_p]),
     "pmc_adamw_step": (C.c_int, [c_p, c_p, c_p, c_p, i64, f64, f64, f64, f64, f64, f64, i64, c_p, c_p]),
@@ -127,7 +139,7 @@ def load():
         fn = getattr(lib, name)            # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.pmc_abi_version() != 1:
+    if lib.pmc_abi_version() != 2:
         raise PocomcAmdError("libpocomc_amd.so: ABI version mismatch")
     _lib = lib
     return lib

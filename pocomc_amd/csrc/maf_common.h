@@ -48,31 +48,56 @@ __device__ __forceinline__ f32x4 tile_mac(f32x4 acc, const float4* __restrict__ 
 }
 
 
-// acc += sum_{K in [K0, K1)} frag[K] . act[K]  with the weight fragments of four K tiles in flight:
-// a lone wave per SIMD has nothing else to hide the ~500-cycle L2 latency of a fragment load.
+// acc += sum_{K in [K0, K1)} frag[K] . act[K]  with the weight fragments of PF K tiles in flight
+// (a lone wave per SIMD has nothing else to hide the latency of a fragment load) and the LDS operand
+// of the next K tile read while the four MFMAs of the current one run.  The main loop is branch
+// free (loads past the end are clamped to the last tile and never used) so that the compiler keeps
+// the software pipeline; two accumulators keep the matrix pipe from waiting on its own result.
+template <int PF = 4>
 __device__ __forceinline__ f32x4 mac_range(f32x4 acc, const float4* __restrict__ frag, const float* act,
                                            int K0, int K1, int lane) {
-    const float4* f = frag + lane;
-    float4 a0, a1, a2, a3;
-    if (K0 + 0 < K1) a0 = f[(K0 + 0) * 64];
-    if (K0 + 1 < K1) a1 = f[(K0 + 1) * 64];
-    if (K0 + 2 < K1) a2 = f[(K0 + 2) * 64];
-    if (K0 + 3 < K1) a3 = f[(K0 + 3) * 64];
-#define PMC_MAC_STEP(A, KK)                                                                      \
-    if ((KK) < K1) {                                                                             \
-        const float4 b_ = *reinterpret_cast<const float4*>(act + ((KK) << 8) + (lane << 2));     \
-        acc = MFMA(A.x, b_.x, acc); acc = MFMA(A.y, b_.y, acc);                                  \
-        acc = MFMA(A.z, b_.z, acc); acc = MFMA(A.w, b_.w, acc);                                  \
-        if ((KK) + 4 < K1) A = f[((KK) + 4) * 64];                                               \
+    const int n = K1 - K0;
+    if (n <= 0) return acc;
+    const float4* f = frag + (size_t)K0 * 64 + lane;
+    const float* bp = act + (K0 << 8) + (lane << 2);
+    float4 a[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) a[j] = f[min(j, n - 1) * 64];
+    float4 b = *reinterpret_cast<const float4*>(bp);
+    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + PF <= n; k += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const float4 bn = *reinterpret_cast<const float4*>(bp + (min(k + j + 1, n - 1) << 8));
+            const float4 aj = a[j];
+            a[j] = f[min(k + j + PF, n - 1) * 64];
+            if (j & 1) {
+                acc1 = MFMA(aj.x, b.x, acc1); acc1 = MFMA(aj.y, b.y, acc1);
+                acc1 = MFMA(aj.z, b.z, acc1); acc1 = MFMA(aj.w, b.w, acc1);
+            } else {
+                acc = MFMA(aj.x, b.x, acc); acc = MFMA(aj.y, b.y, acc);
+                acc = MFMA(aj.z, b.z, acc); acc = MFMA(aj.w, b.w, acc);
+            }
+            b = bn;
+        }
     }
-    for (int K = K0; K < K1; K += 4) {
-        PMC_MAC_STEP(a0, K)
-        PMC_MAC_STEP(a1, K + 1)
-        PMC_MAC_STEP(a2, K + 2)
-        PMC_MAC_STEP(a3, K + 3)
+#pragma unroll
+    for (int j = 0; j < PF - 1; ++j) {
+        if (k + j < n) {
+            const float4 bn = *reinterpret_cast<const float4*>(bp + (min(k + j + 1, n - 1) << 8));
+            const float4 aj = a[j];
+            if (j & 1) {
+                acc1 = MFMA(aj.x, b.x, acc1); acc1 = MFMA(aj.y, b.y, acc1);
+                acc1 = MFMA(aj.z, b.z, acc1); acc1 = MFMA(aj.w, b.w, acc1);
+            } else {
+                acc = MFMA(aj.x, b.x, acc); acc = MFMA(aj.y, b.y, acc);
+                acc = MFMA(aj.z, b.z, acc); acc = MFMA(aj.w, b.w, acc);
+            }
+            b = bn;
+        }
     }
-#undef PMC_MAC_STEP
-    return acc;
+    return acc + acc1;
 }
 
 // store the 4 rows this lane holds of tile T into an activation array

@@ -1,25 +1,52 @@
 // Flow training kernels (pocomc/flow.py:165-384): loss + parameter gradient of one minibatch,
-// global-norm clip + AdamW.
+// global-norm clip + AdamW, and the per-epoch driver.
 //
 //   loss = sum_n c_n * (-log_prob(x_n)),   c_n = 1                         (flow.py:309)
 //                                          c_n = w_n * 1000 / sum(w_batch) (flow.py:311-312)
 //
-// One wavefront owns 16 rows (same layouts as the inference kernels).  Forward keeps only the
-// INPUT of every transform; the backward sweep recomputes one transform's activations at a time
-// (LDS holds a single transform), then
+// A minibatch is at most 512 rows (sampler.py:289), so the step is latency bound, not throughput
+// bound.  One WORKGROUP of four wavefronts owns 16 rows: the tiles of every layer are dealt to the
+// four waves (cost-balanced over the triangular layers), the activations sit in workgroup LDS in
+// the MFMA operand layout of the inference kernels, and a barrier separates dependent layers.
+// Forward stores only the INPUT of every transform (global scratch, L2 resident); the backward
+// sweep recomputes one transform's activations at a time, then
 //     d(shift, raw) -> dW3, db3 -> dh2 = W3^T . -> relu' -> dW2, db2 -> dh1 = da2 + W2^T da2 -> ...
 // Data-gradient products  dh = W^T da  are MFMA bursts over pre-transposed weight fragments
 // (packedT); weight-gradient tiles  dW[out][in] = sum_rows da[out][row] h[in][row]  contract over
-// the wave's 16 rows with four v_mfma_f32_16x16x4_f32 and are scattered into the canonical fp32
-// gradient vector with hardware fp32 atomics through a host-built index map (masked weights and
-// padding map to -1 and are never touched).
+// the 16 rows with four v_mfma_f32_16x16x4_f32.
+//
+// No atomics: every workgroup owns a gradient SLAB in tile order (one coalesced float4 store per
+// lane per tile; a workgroup that processes several row sets read-modify-writes its own slab), and
+// reduce_slabs_kernel sums the slabs into the canonical gradient through the host-built map
+// (masked weights and padding map to -1 and are never touched).  Sums run in a fixed order, so a
+// training run is bitwise reproducible.
+//
+// LDS buffers alias along the backward sweep (4 hidden-width buffers instead of 7):
+//     E: x_t -> da2 -> da0      A: h0      B: h1 -> x_t (reload for dW0)      C: h2 -> da1
+//     P: (shift, raw) -> their gradients -> dx      G: dL/dy -> direct dL/dx term -> dL/dy of t-1
+// which keeps the 8-transform, H=512, D=128 flow (BASELINE config 5) inside 160 KB.
 
+#include <string>
 #include "maf_common.h"
+
+#ifndef TRAIN_PF
+#define TRAIN_PF 4                  // weight fragments in flight per wave
+#endif
+#ifndef TRAIN_WAVES
+#define TRAIN_WAVES 8
+#endif
+#define TRAIN_THREADS (64 * TRAIN_WAVES)
+
+// Workgroup barrier that orders LDS traffic only: global stores (gradient slabs) and prefetched
+// weight loads stay in flight across it (a __syncthreads() would drain vmcnt to zero).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 struct TrainView {
     const float4* f0T; const float4* f1T; const float4* f2T; const float4* f3T;
-    const int4* g0; const int4* g1; const int4* g2; const int4* g3;
-    const int* gb0; const int* gb1; const int* gb2; const int* gb3;
+    // slab offsets (floats) of this transform's gradient tiles / bias rows
+    int64_t g0, g1, g2, g3, gb0, gb1, gb2, gb3;
 };
 
 __device__ __forceinline__ TrainView train_view(const pmc_maf_t& m, const pmc_maf_train_t& tr, int t) {
@@ -30,11 +57,11 @@ __device__ __forceinline__ TrainView train_view(const pmc_maf_t& m, const pmc_ma
     v.f1T = reinterpret_cast<const float4*>(p); p += nT * nT * 256;
     v.f2T = reinterpret_cast<const float4*>(p); p += nT * nT * 256;
     v.f3T = reinterpret_cast<const float4*>(p);
-    const int* g = tr.gmap + (size_t)t * tr.gmap_per_transform;
-    v.g0 = reinterpret_cast<const int4*>(g); g += nT * nXT * 256;
-    v.g1 = reinterpret_cast<const int4*>(g); g += nT * nT * 256;
-    v.g2 = reinterpret_cast<const int4*>(g); g += nT * nT * 256;
-    v.g3 = reinterpret_cast<const int4*>(g); g += nOT * nT * 256;
+    int64_t g = (int64_t)t * tr.gmap_per_transform;
+    v.g0 = g; g += nT * nXT * 256;
+    v.g1 = g; g += nT * nT * 256;
+    v.g2 = g; g += nT * nT * 256;
+    v.g3 = g; g += nOT * nT * 256;
     v.gb0 = g; g += m.Hp;
     v.gb1 = g; g += m.Hp;
     v.gb2 = g; g += m.Hp;
@@ -42,11 +69,17 @@ __device__ __forceinline__ TrainView train_view(const pmc_maf_t& m, const pmc_ma
     return v;
 }
 
-__device__ __forceinline__ void scatter4(float* __restrict__ grad, const int4 idx, const f32x4& v) {
-    if (idx.x >= 0) unsafeAtomicAdd(grad + idx.x, v[0]);
-    if (idx.y >= 0) unsafeAtomicAdd(grad + idx.y, v[1]);
-    if (idx.z >= 0) unsafeAtomicAdd(grad + idx.z, v[2]);
-    if (idx.w >= 0) unsafeAtomicAdd(grad + idx.w, v[3]);
+// Deal tiles whose cost falls with `r` to the waves in a snake, so the sums balance.
+__device__ __forceinline__ int snake_owner(int r) {
+    const int pos = r % TRAIN_WAVES;
+    return ((r / TRAIN_WAVES) & 1) ? TRAIN_WAVES - 1 - pos : pos;
+}
+
+__device__ __forceinline__ void slab_put4(float* __restrict__ dst, const f32x4& v, bool first) {
+    float4* d = reinterpret_cast<float4*>(dst);
+    float4 o = make_float4(v[0], v[1], v[2], v[3]);
+    if (!first) { const float4 c = *d; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+    *d = o;
 }
 
 // dW tile: D[i][j] = sum_p a_rows[16*Ta + i][p] * b_rows[16*Tb + j][p]
@@ -63,202 +96,356 @@ __device__ __forceinline__ f32x4 outer_tile(const float* A, int Ta, const float*
     return acc;
 }
 
-// bias gradient of the 4 rows a lane holds: sum over the 16 walkers, one atomic per row
-__device__ __forceinline__ void bias_scatter(float* __restrict__ grad, const int* __restrict__ gb, int row0,
-                                             f32x4 v, int lane) {
+// bias gradient of the 4 rows a lane holds: sum over the 16 rows of the set, written by lane p == 0
+__device__ __forceinline__ void bias_put(float* __restrict__ dst, f32x4 v, int lane, bool first) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float s = v[r];
         s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-        if ((lane & 15) == 0) { const int idx = gb[row0 + r]; if (idx >= 0) unsafeAtomicAdd(grad + idx, s); }
+        if ((lane & 15) == 0) dst[r] = first ? s : dst[r] + s;
     }
 }
 
-__global__ __launch_bounds__(64) void maf_lossgrad_kernel(pmc_maf_t m, pmc_maf_train_t tr,
-                                                          const float* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ wsum, float wmul,
-                                                          float* __restrict__ grad, float* __restrict__ loss,
-                                                          int64_t n) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x;
+__device__ __forceinline__ f32x4 rows_of(const float* H, int T, int q, int p) {
+    const float* hb = H + (T << 8) + (p << 2) + q;
+    f32x4 a = {hb[0], hb[64], hb[128], hb[192]};
+    return a;
+}
+
+__device__ __forceinline__ f32x4 relu_gate(f32x4 a, const float* H, int T, int q, int p) {
+    const f32x4 h = rows_of(H, T, q, p);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = h[r] > 0.f ? a[r] : 0.f;
+    return a;
+}
+
+#define TICKT() (PROF ? (long long)__builtin_readcyclecounter() : 0LL)
+#define LAPT(I) if (PROF) { const long long t2_ = TICKT(); pacc[I] += t2_ - tk; tk = t2_; }
+// phase barrier: time up to the barrier goes to phase I, the wait itself to slot 10
+#define PHASE_END(I) { LAPT(I) lds_barrier(); LAPT(10) }
+
+// hidden layers of one transform for the workgroup's 16 rows: X -> H0, H1, H2 (tiles dealt to the waves)
+template <bool PROF>
+__device__ __forceinline__ void hidden_pass_wg(const pmc_maf_t& m, const MafView& w, const float* X, float* H0,
+                                               float* H1, float* H2, int wv, int lane, long long* pacc,
+                                               long long& tk) {
     const int q = lane >> 4, p = lane & 15;
-    const int64_t row0 = (int64_t)blockIdx.x * 16;
+    const int nT = m.nT, nXT = m.nXT;
+    for (int T = wv; T < nT; T += TRAIN_WAVES) {
+        f32x4 a = bias4(w.b0, 16 * T + 4 * q);
+        a = mac_range<TRAIN_PF>(a, w.f0 + (size_t)T * nXT * 64, X, 0, nXT, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.0f);
+        store_rows(H0, T, q, p, a);
+    }
+    LAPT(11)
+    lds_barrier();
+    LAPT(12)
+    for (int layer = 1; layer <= 2; ++layer) {
+        const float* Hin = layer == 1 ? H0 : H1;
+        float* Hout = layer == 1 ? H1 : H2;
+        const float4* f = layer == 1 ? w.f1 : w.f2;
+        const float* b = layer == 1 ? w.b1 : w.b2;
+        for (int T = 0; T < nT; ++T) {
+            if (snake_owner(nT - 1 - T) != wv) continue;
+            f32x4 a = bias4(b, 16 * T + 4 * q);
+            a = mac_range<TRAIN_PF>(a, f + (size_t)T * nT * 64, Hin, 0, m.tri_ok ? T + 1 : nT, lane);
+            const f32x4 h = rows_of(Hin, T, q, p);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r] + h[r], 0.0f);
+            store_rows(Hout, T, q, p, a);
+        }
+        LAPT(13)
+        lds_barrier();
+        LAPT(14)
+    }
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m, pmc_maf_train_t tr,
+                                                                     const float* __restrict__ x,
+                                                                     const float* __restrict__ w,
+                                                                     const int64_t* __restrict__ idx, float wmul,
+                                                                     int64_t n, long long* __restrict__ prof) {
+    long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tk = TICKT();
+    const long long t_begin = tk;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: tile ownership branches stay scalar
+    const int q = lane >> 4, p = lane & 15;
     const int D = m.D, Dp = m.Dp, Hp = m.Hp, Op = 2 * m.Dp, T = m.T, nT = m.nT, nXT = m.nXT, nOT = m.nOT;
-    float* XT = smem;                         // [T+1][Dp*16] inputs of every transform (+ z)
-    float* H0 = XT + (size_t)(T + 1) * Dp * 16;
-    float* H1 = H0 + Hp * 16;
-    float* H2 = H1 + Hp * 16;
-    float* DA = H2 + Hp * 16;
-    float* DB = DA + Hp * 16;
-    float* PHI = DB + Hp * 16;                // [Op*16] (shift, raw) by packed output row
-    float* GPHI = PHI + Op * 16;
-    float* G = GPHI + Op * 16;                // [Dp*16] gradient wrt the transform's output, by rank
-    float* GX = G + Dp * 16;
-    float* CC = GX + Dp * 16;                 // [16] per-row loss coefficient
+    const int nOeff = min(nOT, (D + 7) / 8);
+    float* A = smem;
+    float* B = A + Hp * 16;
+    float* Cb = B + Hp * 16;
+    float* E = Cb + Hp * 16;
+    float* P = E + Hp * 16;                   // [Op*16]
+    float* Gb = P + Op * 16;                  // [Dp*16]
+    float* CC = Gb + Dp * 16;                 // [16] per-row loss coefficient
+    float* RED = CC + 16;                     // [16 * TRAIN_WAVES]
     const int* feat_of_rank = m.meta + 8;
     const int* rank_of_feat = m.meta + 8 + T * D;
+    float* slab = tr.slabs + (size_t)blockIdx.x * tr.slab_stride;
+    float* xt = tr.xt_scratch + (size_t)blockIdx.x * (T + 1) * Dp * 16;
 
-    // per-row coefficient c_n
-    if (lane < 16) {
-        float c = 0.0f;
-        if (row0 + lane < n) c = w ? w[row0 + lane] * (wmul / *wsum) : 1.0f;
-        CC[lane] = c;
+    // sum of the batch weights, the same fixed-order sum in every workgroup (flow.py:311)
+    float wscale = 1.0f;
+    if (w) {
+        float s = 0.0f;
+        for (int64_t i = tid; i < n; i += TRAIN_THREADS) s += w[idx ? idx[i] : i];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) RED[wv] = s;
+        __syncthreads();
+        float tot = 0.0f;
+        for (int k = 0; k < TRAIN_WAVES; ++k) tot += RED[k];
+        wscale = wmul / tot;
+        __syncthreads();
     }
-    load_rows(XT, x, row0, n, D, Dp, feat_of_rank, lane);
-    __syncthreads();
 
-    // ------------------------------------------------------------- forward
-    float ladj = 0.0f;
-    for (int t = 0; t < T; ++t) {
-        const MafView wv = maf_view(m, t);
-        float* xin = XT + (size_t)t * Dp * 16;
-        float* xout = XT + (size_t)(t + 1) * Dp * 16;
-        maf_hidden_pass(m, wv, xin, H0, H1, H2, lane);
-        for (int O = 0; O < nOT; ++O) {
-            if (8 * O >= D) break;
-            f32x4 o = bias4(wv.b3, 16 * O + 4 * q);
-            o = mac_range(o, wv.f3 + (size_t)O * nT * 64, H2, 0, nT, lane);
-            for (int s = 0; s < 2; ++s) {
-                const int rank = 8 * O + 2 * q + s;
-                if (rank < D) {
-                    const float shift = s ? o[2] : o[0];
-                    const float ls = soft_ls(s ? o[3] : o[1]);
-                    const float y = xin[lidx(rank, p)] * expf(ls) + shift;
-                    // the next transform reads its input by its own rank order
-                    const int r2 = (t + 1 < T) ? rank_of_feat[(t + 1) * D + feat_of_rank[t * D + rank]] : rank;
-                    xout[lidx(r2, p)] = y;
-                    ladj += ls;
+    float loss_acc = 0.0f;
+    bool first = true;
+    const int64_t nsets = (n + 15) / 16;
+    for (int64_t set = blockIdx.x; set < nsets; set += gridDim.x, first = false) {
+        const int64_t row0 = set * 16;
+        if (tid < 16) {
+            float c = 0.0f;
+            if (row0 + tid < n) {
+                const int64_t r = idx ? idx[row0 + tid] : row0 + tid;
+                c = w ? w[r] * wscale : 1.0f;
+            }
+            CC[tid] = c;
+        }
+        float* Xc = E;
+        float* Xn = Gb;
+        for (int e = tid; e < Dp * 16; e += TRAIN_THREADS) {
+            const int r = e >> 4, pp = e & 15;
+            float v = 0.0f;
+            if (r < D && row0 + pp < n) {
+                const int64_t row = idx ? idx[row0 + pp] : row0 + pp;
+                v = x[row * D + feat_of_rank[r]];
+            }
+            Xc[lidx(r, pp)] = v;
+            xt[lidx(r, pp)] = v;
+        }
+        PHASE_END(1)
+
+        // --------------------------------------------------------- forward
+        float ladj = 0.0f;
+        for (int t = 0; t < T; ++t) {
+            const MafView wvw = maf_view(m, t);
+            float* xtn = xt + (size_t)(t + 1) * Dp * 16;
+            hidden_pass_wg<PROF>(m, wvw, Xc, A, B, Cb, wv, lane, pacc, tk);
+            LAPT(2)
+            for (int O = wv; O < nOeff; O += TRAIN_WAVES) {
+                f32x4 o = bias4(wvw.b3, 16 * O + 4 * q);
+                o = mac_range<TRAIN_PF>(o, wvw.f3 + (size_t)O * nT * 64, Cb, 0, nT, lane);
+                for (int s = 0; s < 2; ++s) {
+                    const int rank = 8 * O + 2 * q + s;
+                    if (rank < D) {
+                        const float shift = s ? o[2] : o[0];
+                        const float ls = soft_ls(s ? o[3] : o[1]);
+                        const float y = Xc[lidx(rank, p)] * expf(ls) + shift;
+                        // the next transform reads its input by its own rank order
+                        const int r2 = (t + 1 < T) ? rank_of_feat[(t + 1) * D + feat_of_rank[t * D + rank]] : rank;
+                        Xn[lidx(r2, p)] = y;
+                        xtn[lidx(r2, p)] = y;
+                        ladj += ls;
+                    }
                 }
             }
-        }
-        for (int e = lane; e < (Dp - D) * 16; e += 64) xout[lidx(D + (e >> 4), e & 15)] = 0.0f;
-        __syncthreads();
-    }
-    // ---------------------------------------------------------------- loss
-    {
-        const float* Z = XT + (size_t)T * Dp * 16;     // rank order of the last transform
-        float ss = 0.0f;
-        for (int r = q; r < D; r += 4) { const float z = Z[lidx(r, p)]; ss += z * z; }
-        ss = quad_sum(ss);
-        const float l = quad_sum(ladj);
-        const float c = CC[p];
-        if (lane < 16 && row0 + p < n) {
-            const float logp = (-0.5f * ss - 0.9189385332046727f * (float)D) + l;
-            unsafeAtomicAdd(loss, -c * logp);
-        }
-        // dL/dz = c * z
-        for (int e = lane; e < Dp * 16; e += 64) {
-            const int r = e >> 4, pp = e & 15;
-            G[lidx(r, pp)] = (r < D) ? CC[pp] * Z[lidx(r, pp)] : 0.0f;
-        }
-    }
-    __syncthreads();
-
-    // ------------------------------------------------------------ backward
-    for (int t = T - 1; t >= 0; --t) {
-        const MafView wv = maf_view(m, t);
-        const TrainView tv = train_view(m, tr, t);
-        const float* X = XT + (size_t)t * Dp * 16;
-        // recompute this transform's activations and (shift, raw)
-        maf_hidden_pass(m, wv, X, H0, H1, H2, lane);
-        for (int O = 0; O < nOT; ++O) {
-            f32x4 o = bias4(wv.b3, 16 * O + 4 * q);
-            if (8 * O < D) o = mac_range(o, wv.f3 + (size_t)O * nT * 64, H2, 0, nT, lane);
-            store_rows(PHI, O, q, p, o);
-        }
-        __syncthreads();
-        // element-wise part: y = x e^{ls} + shift,  L += -c * sum ls
-        for (int e = lane; e < Dp * 16; e += 64) {
-            const int r = e >> 4, pp = e & 15;
-            float gs = 0.0f, gr = 0.0f, gx = 0.0f;
-            if (r < D) {
-                const float xv = X[lidx(r, pp)];
-                const float raw = PHI[lidx(2 * r + 1, pp)];
-                const float den = 1.0f + fabsf(raw / PMC_LOG_SLOPE);
-                const float el = expf(raw / den);
-                const float gy = G[lidx(r, pp)];
-                gs = gy;
-                gr = (gy * xv * el - CC[pp]) / (den * den);
-                gx = gy * el;
+            for (int e = tid; e < (Dp - D) * 16; e += TRAIN_THREADS) {
+                Xn[lidx(D + (e >> 4), e & 15)] = 0.0f;
+                xtn[lidx(D + (e >> 4), e & 15)] = 0.0f;
             }
-            GPHI[lidx(2 * r, pp)] = gs;
-            GPHI[lidx(2 * r + 1, pp)] = gr;
-            GX[lidx(r, pp)] = gx;
+            PHASE_END(3)
+            float* sw = Xc; Xc = Xn; Xn = sw;
         }
-        __syncthreads();
-        // ---- layer 3: dW3, db3, dh2 -> da2
-        for (int O = 0; O < nOT; ++O) {
-            if (8 * O >= D) break;
-            const float* gp = GPHI + (O << 8) + (p << 2) + q;
-            f32x4 gv = {gp[0], gp[64], gp[128], gp[192]};
-            bias_scatter(grad, tv.gb3, 16 * O + 4 * q, gv, lane);
-            for (int K = 0; K < nT; ++K)
-                scatter4(grad, tv.g3[((size_t)O * nT + K) * 64 + lane], outer_tile(GPHI, O, H2, K, lane));
-        }
-        for (int K = 0; K < nT; ++K) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            a = mac_range(a, tv.f3T + (size_t)K * nOT * 64, GPHI, 0, min(nOT, (D + 7) / 8), lane);
-            const float* hb = H2 + (K << 8) + (p << 2) + q;
-            a[0] = hb[0] > 0.f ? a[0] : 0.f; a[1] = hb[64] > 0.f ? a[1] : 0.f;
-            a[2] = hb[128] > 0.f ? a[2] : 0.f; a[3] = hb[192] > 0.f ? a[3] : 0.f;
-            store_rows(DA, K, q, p, a);
-            bias_scatter(grad, tv.gb2, 16 * K + 4 * q, a, lane);
-        }
-        __syncthreads();
-        // ---- layer 2: dW2 (da2 x h1), dh1 = da2 + W2^T da2 -> da1
-        for (int To = 0; To < nT; ++To) {
-            const int kend = m.tri_ok ? To + 1 : nT;
-            for (int Ti = 0; Ti < kend; ++Ti)
-                scatter4(grad, tv.g2[((size_t)To * nT + Ti) * 64 + lane], outer_tile(DA, To, H1, Ti, lane));
-        }
-        for (int Ti = 0; Ti < nT; ++Ti) {
-            const float* db_ = DA + (Ti << 8) + (p << 2) + q;
-            f32x4 a = {db_[0], db_[64], db_[128], db_[192]};
-            a = mac_range(a, tv.f2T + (size_t)Ti * nT * 64, DA, (m.tri_ok ? Ti : 0), nT, lane);
-            const float* hb = H1 + (Ti << 8) + (p << 2) + q;
-            a[0] = hb[0] > 0.f ? a[0] : 0.f; a[1] = hb[64] > 0.f ? a[1] : 0.f;
-            a[2] = hb[128] > 0.f ? a[2] : 0.f; a[3] = hb[192] > 0.f ? a[3] : 0.f;
-            store_rows(DB, Ti, q, p, a);
-            bias_scatter(grad, tv.gb1, 16 * Ti + 4 * q, a, lane);
-        }
-        __syncthreads();
-        // ---- layer 1: dW1 (da1 x h0), dh0 = da1 + W1^T da1 -> da0 (reuses DA)
-        for (int To = 0; To < nT; ++To) {
-            const int kend = m.tri_ok ? To + 1 : nT;
-            for (int Ti = 0; Ti < kend; ++Ti)
-                scatter4(grad, tv.g1[((size_t)To * nT + Ti) * 64 + lane], outer_tile(DB, To, H0, Ti, lane));
-        }
-        __syncthreads();
-        for (int Ti = 0; Ti < nT; ++Ti) {
-            const float* db_ = DB + (Ti << 8) + (p << 2) + q;
-            f32x4 a = {db_[0], db_[64], db_[128], db_[192]};
-            a = mac_range(a, tv.f1T + (size_t)Ti * nT * 64, DB, (m.tri_ok ? Ti : 0), nT, lane);
-            const float* hb = H0 + (Ti << 8) + (p << 2) + q;
-            a[0] = hb[0] > 0.f ? a[0] : 0.f; a[1] = hb[64] > 0.f ? a[1] : 0.f;
-            a[2] = hb[128] > 0.f ? a[2] : 0.f; a[3] = hb[192] > 0.f ? a[3] : 0.f;
-            store_rows(DA, Ti, q, p, a);
-            bias_scatter(grad, tv.gb0, 16 * Ti + 4 * q, a, lane);
-        }
-        __syncthreads();
-        // ---- layer 0: dW0 (da0 x x), dx = gx + W0^T da0
-        for (int To = 0; To < nT; ++To)
-            for (int Xi = 0; Xi < nXT; ++Xi)
-                scatter4(grad, tv.g0[((size_t)To * nXT + Xi) * 64 + lane], outer_tile(DA, To, X, Xi, lane));
-        if (t > 0) {
-            for (int Xi = 0; Xi < nXT; ++Xi) {
-                const float* gb_ = GX + (Xi << 8) + (p << 2) + q;
-                f32x4 a = {gb_[0], gb_[64], gb_[128], gb_[192]};
-                a = mac_range(a, tv.f0T + (size_t)Xi * nT * 64, DA, 0, nT, lane);
-                store_rows(PHI, Xi, q, p, a);                      // PHI is free now: staging by rank of t
+        // ------------------------------------------------------------ loss
+        {
+            const float l = quad_sum(ladj);
+            if (lane < 16) RED[wv * 16 + lane] = l;
+            __syncthreads();                             // full barrier: the xt scratch written above is read below
+            const float* Z = Xc;                         // rank order of the last transform
+            if (wv == 0) {
+                float ss = 0.0f;
+                for (int r = q; r < D; r += 4) { const float z = Z[lidx(r, p)]; ss += z * z; }
+                ss = quad_sum(ss);
+                float lt = 0.0f;
+                for (int k = 0; k < TRAIN_WAVES; ++k) lt += RED[16 * k + p];
+                float term = 0.0f;
+                if (row0 + p < n) term = -CC[p] * ((-0.5f * ss - 0.9189385332046727f * (float)D) + lt);
+                term += __shfl_xor(term, 1); term += __shfl_xor(term, 2);
+                term += __shfl_xor(term, 4); term += __shfl_xor(term, 8);
+                loss_acc += term;
             }
-            __syncthreads();
-            // re-rank for transform t-1 (its output order)
-            for (int e = lane; e < Dp * 16; e += 64) {
+            __syncthreads();                             // Z may be Gb itself: finish reading it first
+            // dL/dz = c * z
+            for (int e = tid; e < Dp * 16; e += TRAIN_THREADS) {
                 const int r = e >> 4, pp = e & 15;
-                if (r < D) G[lidx(rank_of_feat[(t - 1) * D + feat_of_rank[t * D + r]], pp)] = PHI[lidx(r, pp)];
+                Gb[lidx(r, pp)] = (r < D) ? CC[pp] * Z[lidx(r, pp)] : 0.0f;
             }
         }
-        __syncthreads();
+        PHASE_END(1)
+
+        // -------------------------------------------------------- backward
+        for (int t = T - 1; t >= 0; --t) {
+            const MafView wvw = maf_view(m, t);
+            const TrainView tv = train_view(m, tr, t);
+            const float4* xsrc = reinterpret_cast<const float4*>(xt + (size_t)t * Dp * 16);
+            for (int e = tid; e < Dp * 4; e += TRAIN_THREADS) reinterpret_cast<float4*>(E)[e] = xsrc[e];
+            lds_barrier();
+            // recompute this transform's activations and (shift, raw)
+            hidden_pass_wg<PROF>(m, wvw, E, A, B, Cb, wv, lane, pacc, tk);
+            for (int O = wv; O < nOeff; O += TRAIN_WAVES) {
+                f32x4 o = bias4(wvw.b3, 16 * O + 4 * q);
+                o = mac_range<TRAIN_PF>(o, wvw.f3 + (size_t)O * nT * 64, Cb, 0, nT, lane);
+                store_rows(P, O, q, p, o);
+            }
+            PHASE_END(4)
+            // element-wise part: y = x e^{ls} + shift,  L += -c * sum ls   (in place: P -> dP, G -> direct dx)
+            for (int e = tid; e < Dp * 16; e += TRAIN_THREADS) {
+                const int r = e >> 4, pp = e & 15;
+                float gs = 0.0f, gr = 0.0f, gx = 0.0f;
+                if (r < D) {
+                    const float xv = E[lidx(r, pp)];
+                    const float raw = P[lidx(2 * r + 1, pp)];
+                    const float den = 1.0f + fabsf(raw / PMC_LOG_SLOPE);
+                    const float el = expf(raw / den);
+                    const float gy = Gb[lidx(r, pp)];
+                    gs = gy;
+                    gr = (gy * xv * el - CC[pp]) / (den * den);
+                    gx = gy * el;
+                }
+                P[lidx(2 * r, pp)] = gs;
+                P[lidx(2 * r + 1, pp)] = gr;
+                Gb[lidx(r, pp)] = gx;
+            }
+            PHASE_END(5)
+            // ---- layer 3: da2 = relu'(h2) . W3^T dP -> E ; dW3, db3, db2
+            for (int K = wv; K < nT; K += TRAIN_WAVES) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                a = mac_range<TRAIN_PF>(a, tv.f3T + (size_t)K * nOT * 64, P, 0, nOeff, lane);
+                a = relu_gate(a, Cb, K, q, p);
+                store_rows(E, K, q, p, a);
+                bias_put(slab + tv.gb2 + 16 * K + 4 * q, a, lane, first);
+            }
+            for (int O = wv; O < nOeff; O += TRAIN_WAVES)
+                bias_put(slab + tv.gb3 + 16 * O + 4 * q, rows_of(P, O, q, p), lane, first);
+            for (int i = wv; i < nOeff * nT; i += TRAIN_WAVES) {
+                const int O = i / nT, K = i - O * nT;
+                slab_put4(slab + tv.g3 + ((size_t)i * 64 + lane) * 4, outer_tile(P, O, Cb, K, lane), first);
+            }
+            PHASE_END(6)
+            // ---- layer 2: da1 = relu'(h1) . (da2 + W2^T da2) -> C ; dW2 (da2 x h1), db1
+            for (int Ti = 0; Ti < nT; ++Ti) {
+                if (snake_owner(Ti) != wv) continue;
+                f32x4 a = rows_of(E, Ti, q, p);
+                a = mac_range<TRAIN_PF>(a, tv.f2T + (size_t)Ti * nT * 64, E, (m.tri_ok ? Ti : 0), nT, lane);
+                a = relu_gate(a, B, Ti, q, p);
+                store_rows(Cb, Ti, q, p, a);
+                bias_put(slab + tv.gb1 + 16 * Ti + 4 * q, a, lane, first);
+            }
+            {
+                int i = 0;
+                for (int To = 0; To < nT; ++To) {
+                    const int kend = m.tri_ok ? To + 1 : nT;
+                    for (int Ti = 0; Ti < kend; ++Ti, ++i)
+                        if (i % TRAIN_WAVES == wv)
+                            slab_put4(slab + tv.g2 + (((size_t)To * nT + Ti) * 64 + lane) * 4,
+                                      outer_tile(E, To, B, Ti, lane), first);
+                }
+            }
+            PHASE_END(7)
+            // ---- layer 1: da0 = relu'(h0) . (da1 + W1^T da1) -> E ; dW1 (da1 x h0), db0 ; x_t -> B
+            for (int Ti = 0; Ti < nT; ++Ti) {
+                if (snake_owner(Ti) != wv) continue;
+                f32x4 a = rows_of(Cb, Ti, q, p);
+                a = mac_range<TRAIN_PF>(a, tv.f1T + (size_t)Ti * nT * 64, Cb, (m.tri_ok ? Ti : 0), nT, lane);
+                a = relu_gate(a, A, Ti, q, p);
+                store_rows(E, Ti, q, p, a);
+                bias_put(slab + tv.gb0 + 16 * Ti + 4 * q, a, lane, first);
+            }
+            for (int e = tid; e < Dp * 4; e += TRAIN_THREADS) reinterpret_cast<float4*>(B)[e] = xsrc[e];
+            {
+                int i = 0;
+                for (int To = 0; To < nT; ++To) {
+                    const int kend = m.tri_ok ? To + 1 : nT;
+                    for (int Ti = 0; Ti < kend; ++Ti, ++i)
+                        if (i % TRAIN_WAVES == wv)
+                            slab_put4(slab + tv.g1 + (((size_t)To * nT + Ti) * 64 + lane) * 4,
+                                      outer_tile(Cb, To, A, Ti, lane), first);
+                }
+            }
+            PHASE_END(8)
+            // ---- layer 0: dW0 (da0 x x), dx = direct + W0^T da0 -> P
+            if (t > 0) {
+                for (int Xi = wv; Xi < nXT; Xi += TRAIN_WAVES) {
+                    f32x4 a = rows_of(Gb, Xi, q, p);
+                    a = mac_range<TRAIN_PF>(a, tv.f0T + (size_t)Xi * nT * 64, E, 0, nT, lane);
+                    store_rows(P, Xi, q, p, a);
+                }
+            }
+            for (int i = TRAIN_WAVES - 1 - wv; i < nT * nXT; i += TRAIN_WAVES)
+                slab_put4(slab + tv.g0 + ((size_t)i * 64 + lane) * 4, outer_tile(E, i / nXT, B, i % nXT, lane), first);
+            PHASE_END(9)
+            if (t > 0) {
+                // re-rank for transform t-1 (its output order)
+                for (int e = tid; e < Dp * 16; e += TRAIN_THREADS) {
+                    const int r = e >> 4, pp = e & 15;
+                    if (r < D) Gb[lidx(rank_of_feat[(t - 1) * D + feat_of_rank[t * D + r]], pp)] = P[lidx(r, pp)];
+                }
+                PHASE_END(9)
+            }
+        }
+    }
+    if (tid == 0) tr.loss_partial[blockIdx.x] = loss_acc;
+    if (PROF && lane == 0) {
+        pacc[0] = TICKT() - t_begin;
+        long long* o = prof + ((size_t)blockIdx.x * TRAIN_WAVES + wv) * 16;
+        for (int i = 0; i < 16; ++i) o[i] = pacc[i];
+    }
+}
+
+// grad[gmap[i]] = sum over slabs of slab[i]; per-block sum of squares; loss += sum of the per-workgroup losses
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(pmc_maf_train_t tr, int n_slabs, int64_t g_total,
+                                                           float* __restrict__ grad, float* __restrict__ loss) {
+    __shared__ float red[4];
+    const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float sq = 0.0f;
+    if (i4 * 4 < g_total) {
+        const int4 g = reinterpret_cast<const int4*>(tr.gmap)[i4];
+        if ((g.x & g.y & g.z & g.w) >= 0) {               // any element mapped
+            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+            const float4* src = reinterpret_cast<const float4*>(tr.slabs) + i4;
+            const size_t stride4 = (size_t)tr.slab_stride / 4;
+            int b = 0;
+            for (; b + 1 < n_slabs; b += 2) {
+                const float4 u = src[(size_t)b * stride4], v = src[(size_t)(b + 1) * stride4];
+                s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+            }
+            if (b < n_slabs) {
+                const float4 u = src[(size_t)b * stride4];
+                s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+            }
+            s0.x += s1.x; s0.y += s1.y; s0.z += s1.z; s0.w += s1.w;
+            if (g.x >= 0) { grad[g.x] = s0.x; sq += s0.x * s0.x; }
+            if (g.y >= 0) { grad[g.y] = s0.y; sq += s0.y * s0.y; }
+            if (g.z >= 0) { grad[g.z] = s0.z; sq += s0.z * s0.z; }
+            if (g.w >= 0) { grad[g.w] = s0.w; sq += s0.w * s0.w; }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tr.sq_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (blockIdx.x == 0 && loss) {
+            float s = 0.0f;
+            for (int b = 0; b < n_slabs; ++b) s += tr.loss_partial[b];
+            *loss += s;
+        }
     }
 }
 
@@ -292,24 +479,31 @@ __global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ v, f
 // ---------------------------------------------------------------------------
 // clip_grad_norm_ (flow.py:318) + AdamW (flow.py:268, :319)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, float* __restrict__ out, int64_t n) {
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, float* __restrict__ part,
+                                                             int64_t n) {
     __shared__ float red[4];
     float s = 0.0f;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) s += g[e] * g[e];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ mo, float* __restrict__ vo, int64_t n,
                                                     float lr, float b1, float b2, float eps, float wd, float max_norm,
-                                                    float bc1, float bc2, const float* __restrict__ sqnorm) {
+                                                    float bc1, float bc2, const float* __restrict__ sq_part, int n_part) {
     // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
+    __shared__ float red[4];
     float coef = 1.0f;
     if (max_norm > 0.0f) {
-        coef = max_norm / (sqrtf(*sqnorm) + 1e-6f);
+        float s = 0.0f;                                   // every block adds the partials in the same order
+        for (int i = threadIdx.x; i < n_part; i += 256) s += sq_part[i];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        coef = max_norm / (sqrtf((red[0] + red[1]) + (red[2] + red[3])) + 1e-6f);
         coef = coef > 1.0f ? 1.0f : coef;
     }
     const float step = lr / bc1, rs2 = 1.0f / sqrtf(bc2);
@@ -323,27 +517,75 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// both kernel images from the canonical vector in one launch
+__global__ __launch_bounds__(256) void pack2_kernel(const float* __restrict__ flat, const int* __restrict__ idx_a,
+                                                    float* __restrict__ dst_a, int64_t n_a,
+                                                    const int* __restrict__ idx_b, float* __restrict__ dst_b,
+                                                    int64_t n_b) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n_a + n_b; e += (int64_t)gridDim.x * 256) {
+        if (e < n_a) { const int i = idx_a[e]; dst_a[e] = i >= 0 ? flat[i] : 0.0f; }
+        else { const int64_t f = e - n_a; const int i = idx_b[f]; dst_b[f] = i >= 0 ? flat[i] : 0.0f; }
+    }
+}
+
 // ---------------------------------------------------------------------------
 static size_t train_lds_bytes(const pmc_maf_t& m) {
-    return (size_t)((m.T + 1) * m.Dp * 16 + 5 * m.Hp * 16 + 2 * 2 * m.Dp * 16 + 2 * m.Dp * 16 + 16) * sizeof(float);
+    return (size_t)(4 * m.Hp * 16 + 2 * m.Dp * 16 + m.Dp * 16 + 16 + 16 * TRAIN_WAVES) * sizeof(float);
+}
+
+static int train_check(const pmc_maf_t* m, const pmc_maf_train_t* tr, const char* who) {
+    if (!m || !tr || !tr->packedT || !tr->gmap || !tr->slabs || !tr->xt_scratch || !tr->loss_partial ||
+        !tr->sq_partial || tr->n_slabs < 1 || tr->slab_stride < (int64_t)m->T * tr->gmap_per_transform ||
+        (tr->slab_stride & 3))
+        return pmc_fail((std::string(who) + ": incomplete training image").c_str());
+    return 0;
+}
+
+static int launch_lossgrad(const pmc_maf_t* m, const pmc_maf_train_t* tr, const float* x, const float* w,
+                           const int64_t* idx, float wmul, float* grad, float* loss, int64_t n, hipStream_t st,
+                           long long* prof = nullptr) {
+    const size_t lds = train_lds_bytes(*m);
+    if (lds > 160 * 1024) return pmc_fail("pmc_maf_loss_grad: flow too wide for the 160 KB LDS of one workgroup");
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_lossgrad_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_lossgrad_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_lossgrad_kernel)");
+        lds_set = lds;
+    }
+    const int64_t nsets = (n + 15) / 16;
+    const int n_wg = (int)(nsets < tr->n_slabs ? nsets : tr->n_slabs);
+    if (prof)
+        hipLaunchKernelGGL(maf_lossgrad_kernel<true>, dim3((unsigned)n_wg), dim3(TRAIN_THREADS), lds, st, *m, *tr, x, w,
+                           idx, wmul, n, prof);
+    else
+        hipLaunchKernelGGL(maf_lossgrad_kernel<false>, dim3((unsigned)n_wg), dim3(TRAIN_THREADS), lds, st, *m, *tr, x,
+                           w, idx, wmul, n, (long long*)nullptr);
+    const int64_t g_total = (int64_t)m->T * tr->gmap_per_transform;
+    const int64_t blocks = (g_total / 4 + 255) / 256;
+    if (blocks > tr->n_sq_partial) return pmc_fail("pmc_maf_loss_grad: sq_partial too small");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, *tr, n_wg, g_total, grad, loss);
+    return pmc_check_launch("maf_lossgrad_kernel");
 }
 
 extern "C" int pmc_maf_loss_grad(const pmc_maf_t* m, const pmc_maf_train_t* tr, const float* x, const float* w,
-                                 const float* wsum, float wmul, float* grad, float* loss, int64_t n, void* stream) {
-    if (!m || !tr || !tr->packedT || !tr->gmap || !x || !grad || !loss || n < 0) return pmc_fail("pmc_maf_loss_grad: bad argument");
-    if (w && !wsum) return pmc_fail("pmc_maf_loss_grad: weights need their sum");
+                                 const int64_t* idx, float wmul, float* grad, float* loss, int64_t n, void* stream) {
+    if (train_check(m, tr, "pmc_maf_loss_grad")) return 1;
+    if (!x || !grad || !loss || n < 0) return pmc_fail("pmc_maf_loss_grad: bad argument");
     if (n == 0) return 0;
-    const size_t lds = train_lds_bytes(*m);
-    if (lds > 160 * 1024) return pmc_fail("pmc_maf_loss_grad: flow too wide for the one-wave-per-16-rows training kernel");
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_lossgrad_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_lossgrad_kernel)");
-    }
-    hipLaunchKernelGGL(maf_lossgrad_kernel, dim3((unsigned)((n + 15) / 16)), dim3(64), lds, (hipStream_t)stream, *m,
-                       *tr, x, w, wsum, wmul, grad, loss, n);
-    return pmc_check_launch("maf_lossgrad_kernel");
+    return launch_lossgrad(m, tr, x, w, idx, wmul, grad, loss, n, (hipStream_t)stream);
 }
+
+// in-kernel cycle profile (scripts/profile_train.py; not part of the ABI): prof i64 [n_wg][TRAIN_WAVES][16]
+extern "C" int pmc_debug_lossgrad_profile(const pmc_maf_t* m, const pmc_maf_train_t* tr, const float* x, float* grad,
+                                          float* loss, int64_t n, long long* prof, void* stream) {
+    if (train_check(m, tr, "pmc_debug_lossgrad_profile")) return 1;
+    return launch_lossgrad(m, tr, x, nullptr, nullptr, 1000.0f, grad, loss, n, (hipStream_t)stream, prof);
+}
+extern "C" int pmc_debug_train_waves(void) { return TRAIN_WAVES; }
 
 extern "C" int pmc_neg_weighted_sum(const float* logp, const float* w, const float* wsum, float wmul, float* out,
                                     int64_t n, void* stream) {
@@ -363,19 +605,102 @@ extern "C" int pmc_sum_f32(const float* v, float* out, int64_t n, void* stream) 
     return pmc_check_launch("sum_kernel");
 }
 
+static void launch_adamw(float* params, const float* grad, float* m1, float* m2, int64_t n, double lr, double beta1,
+                         double beta2, double eps, double wd, double max_norm, int64_t step, const float* sq_part,
+                         int n_part, hipStream_t st) {
+    int64_t grid = (n + 255) / 256; if (grid > 512) grid = 512;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, st, params, grad, m1, m2, n, (float)lr,
+                       (float)beta1, (float)beta2, (float)eps, (float)wd, (float)max_norm, (float)bc1, (float)bc2,
+                       sq_part, n_part);
+}
+
 extern "C" int pmc_adamw_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                               double lr, double beta1, double beta2, double eps, double weight_decay,
-                              double max_norm, int64_t step, float* sqnorm_scratch, void* stream) {
-    if (!params || !grad || !exp_avg || !exp_avg_sq || !sqnorm_scratch || n <= 0 || step < 1)
+                              double max_norm, int64_t step, float* sq_scratch, void* stream) {
+    if (!params || !grad || !exp_avg || !exp_avg_sq || !sq_scratch || n <= 0 || step < 1)
         return pmc_fail("pmc_adamw_step: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sqnorm_scratch, 0, sizeof(float), st) != hipSuccess) return pmc_fail("pmc_adamw_step: memset");
-    int64_t grid = (n + 255) / 256; if (grid > 512) grid = 512;
+    const int n_part = PMC_ADAMW_SCRATCH;
     if (max_norm > 0.0)
-        hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)grid), dim3(256), 0, st, grad, sqnorm_scratch, n);
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, st, params, grad, exp_avg, exp_avg_sq, n,
-                       (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)max_norm,
-                       (float)bc1, (float)bc2, (const float*)sqnorm_scratch);
+        hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(n_part), dim3(256), 0, st, grad, sq_scratch, n);
+    launch_adamw(params, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, max_norm, step,
+                 sq_scratch, n_part, st);
     return pmc_check_launch("adamw_kernel");
+}
+
+extern "C" int pmc_maf_train_epoch(const pmc_maf_t* m, const pmc_maf_train_t* tr, pmc_adamw_t* opt, const float* x,
+                                   const float* w, const int64_t* perm, int64_t n, int64_t batch_size, float* loss,
+                                   void* stream) {
+    if (train_check(m, tr, "pmc_maf_train_epoch")) return 1;
+    if (!opt || !opt->params || !opt->grad || !opt->exp_avg || !opt->exp_avg_sq || !opt->pack_idx || !opt->packed ||
+        !opt->packT_idx || !opt->packedT || opt->n_params <= 0 || !x || !loss || n < 0 || batch_size < 1)
+        return pmc_fail("pmc_maf_train_epoch: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t g_total = (int64_t)m->T * tr->gmap_per_transform;
+    const int n_part = (int)((g_total / 4 + 255) / 256);
+    for (int64_t b0 = 0; b0 < n; b0 += batch_size) {
+        const int64_t nb = (n - b0 < batch_size) ? n - b0 : batch_size;
+        // a batch is rows perm[b0 .. b0+nb) of x, or rows b0 .. b0+nb when perm == NULL
+        const float* xb = perm ? x : x + b0 * m->D;
+        const float* wb = (w && !perm) ? w + b0 : w;
+        if (launch_lossgrad(m, tr, xb, wb, perm ? perm + b0 : nullptr, 1000.0f, opt->grad, loss, nb, st)) return 1;
+        opt->step += 1;
+        launch_adamw(opt->params, opt->grad, opt->exp_avg, opt->exp_avg_sq, opt->n_params, opt->lr, opt->beta1,
+                     opt->beta2, opt->eps, opt->weight_decay, opt->max_norm, opt->step, tr->sq_partial, n_part, st);
+        const int64_t tot = opt->n_packed + opt->n_packedT;
+        int64_t grid = (tot + 255) / 256; if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(pack2_kernel, dim3((unsigned)grid), dim3(256), 0, st, opt->params, opt->pack_idx,
+                           opt->packed, opt->n_packed, opt->packT_idx, opt->packedT, opt->n_packedT);
+    }
+    return pmc_check_launch("pmc_maf_train_epoch");
+}
+
+// ---------------------------------------------------------------------------
+// latency probe (scripts/profile_train.py --probe; not part of the ABI)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void latency_probe_kernel(const float4* __restrict__ wts, long long* out) {
+    __shared__ __attribute__((aligned(16))) float lds[16 * 256];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 16 * 256; i += blockDim.x) lds[i] = 0.001f * i;
+    __syncthreads();
+    long long t[10];
+    const float4* f = wts + (size_t)blockIdx.x * 64 * 64 + lane;
+    t[0] = __builtin_readcyclecounter();
+    float4 a = f[0];
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(a.x) : "memory");
+    t[1] = __builtin_readcyclecounter();                       // cold load
+    float4 b = f[0];
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(b.x) : "memory");
+    t[2] = __builtin_readcyclecounter();                       // same line again
+    float4 c0 = f[64], c1 = f[128], c2 = f[192], c3 = f[256];
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(c0.x), "v"(c1.x), "v"(c2.x), "v"(c3.x) : "memory");
+    t[3] = __builtin_readcyclecounter();                       // 4 new lines in flight
+    f32x4 acc = {a.x, b.y, c0.z, c1.w};
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc = MFMA(c2.x, c3.y, acc);
+    asm volatile("s_nop 0" :: "v"(acc[0]));
+    t[4] = __builtin_readcyclecounter();                       // 36 dependent MFMAs
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const float4 bb = *reinterpret_cast<const float4*>(lds + (k << 8) + (lane << 2));
+        acc = MFMA(c0.x, bb.x, acc); acc = MFMA(c0.y, bb.y, acc); acc = MFMA(c0.z, bb.z, acc); acc = MFMA(c0.w, bb.w, acc);
+    }
+    asm volatile("s_nop 0" :: "v"(acc[0]));
+    t[5] = __builtin_readcyclecounter();                       // 9 x (ds_read_b128 + 4 MFMA)
+    __syncthreads();
+    t[6] = __builtin_readcyclecounter();                       // one barrier
+    lds_barrier();
+    t[7] = __builtin_readcyclecounter();                       // one LDS-only barrier
+    if (lane == 0) {
+        long long* o = out + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8;
+        for (int i = 0; i < 7; ++i) o[i] = t[i + 1] - t[i];
+        o[7] = (long long)acc[1];
+    }
+}
+
+extern "C" int pmc_debug_latency_probe(const float* wts, long long* out, int blocks, void* stream) {
+    hipLaunchKernelGGL(latency_probe_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(wts), out);
+    return pmc_check_launch("latency_probe_kernel");
 }

@@ -19,6 +19,9 @@ import torch
 from . import _lib
 
 
+MAX_SLABS = 64      # workgroups per loss/gradient launch (16 rows each; larger batches are looped over)
+
+
 class TrainState:
     """Training-side device buffers of one Flow (built on first ``fit``)."""
 
@@ -29,12 +32,34 @@ class TrainState:
         self.packT_idx = torch.from_numpy(pT_idx).to(dev)
         self.gmap = torch.from_numpy(gmap).to(dev)
         self.packedT = torch.zeros(pT_idx.size, dtype=torch.float32, device=dev)
+        self.g_total = spec.n_transforms * L["gmap_per_transform"]
+        self.n_sq = (self.g_total // 4 + 255) // 256
+        self.sq_partial = torch.zeros(max(self.n_sq, 256), dtype=torch.float32, device=dev)   # >= PMC_ADAMW_SCRATCH
         self.desc = _lib.pmc_maf_train_t(packedT=self.packedT.data_ptr(), gmap=self.gmap.data_ptr(),
                                          pkT_per_transform=L["pkT_per_transform"],
-                                         gmap_per_transform=L["gmap_per_transform"])
+                                         gmap_per_transform=L["gmap_per_transform"],
+                                         slab_stride=self.g_total, n_sq_partial=self.sq_partial.numel(),
+                                         sq_partial=self.sq_partial.data_ptr())
+        self.n_slabs = 0
+        self.xt_floats = (spec.n_transforms + 1) * spec.Dp * 16
         n = spec.n_params
-        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.scal = torch.zeros(4, dtype=torch.float32, device=dev)      # [loss, wsum, sqnorm, spare]
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)      # masked entries stay 0 for ever
+        self.scal = torch.zeros(4, dtype=torch.float32, device=dev)      # [loss, spare...]
+
+    def ensure_slabs(self, n_rows):
+        """One gradient slab + one scratch block per concurrently running workgroup."""
+        need = max(1, min(MAX_SLABS, (int(n_rows) + 15) // 16))
+        if need <= self.n_slabs:
+            return
+        dev = self.grad.device
+        self.slabs = torch.empty(need * self.g_total, dtype=torch.float32, device=dev)
+        self.xt_scratch = torch.empty(need * self.xt_floats, dtype=torch.float32, device=dev)
+        self.loss_partial = torch.zeros(need, dtype=torch.float32, device=dev)
+        self.n_slabs = need
+        self.desc.slabs = self.slabs.data_ptr()
+        self.desc.xt_scratch = self.xt_scratch.data_ptr()
+        self.desc.loss_partial = self.loss_partial.data_ptr()
+        self.desc.n_slabs = need
 
     def repack(self, flow):
         with torch.cuda.device(flow.device):
@@ -48,20 +73,18 @@ def _train_state(flow):
     return flow._train
 
 
-def loss_and_grad(flow, xb, wb=None):
-    """Loss of one batch (device scalar tensor) and its gradient (in ``flow._train.grad``)."""
+def loss_and_grad(flow, xb, wb=None, idx=None):
+    """Loss of one batch (device scalar tensor) and its gradient (in ``flow._train.grad``).
+    ``idx`` (int64, device) selects the batch rows out of ``xb`` / ``wb``."""
     ts = _train_state(flow)
-    lib = flow.lib
-    st = _lib.stream_handle()
-    ts.grad.zero_()
+    n = xb.shape[0] if idx is None else idx.numel()
+    ts.ensure_slabs(n)
     ts.scal.zero_()
     with torch.cuda.device(flow.device):
-        if wb is not None:
-            _lib.check(lib.pmc_sum_f32(_lib.ptr(wb), C.c_void_p(ts.scal.data_ptr() + 4), wb.numel(), st), "pmc_sum_f32")
-        _lib.check(lib.pmc_maf_loss_grad(C.byref(flow._desc), C.byref(ts.desc), _lib.ptr(xb),
-                                         _lib.ptr(wb) if wb is not None else None,
-                                         C.c_void_p(ts.scal.data_ptr() + 4) if wb is not None else None,
-                                         1000.0, _lib.ptr(ts.grad), _lib.ptr(ts.scal), xb.shape[0], st),
+        _lib.check(flow.lib.pmc_maf_loss_grad(C.byref(flow._desc), C.byref(ts.desc), _lib.ptr(xb),
+                                              _lib.ptr(wb) if wb is not None else None,
+                                              _lib.ptr(idx) if idx is not None else None,
+                                              1000.0, _lib.ptr(ts.grad), _lib.ptr(ts.scal), n, _lib.stream_handle()),
                    "pmc_maf_loss_grad")
     return ts.scal[0]
 
@@ -96,6 +119,7 @@ class AdamW:
         self.t = 0
 
     def step(self, max_norm):
+        """One clipped step on the gradient in ``flow._train.grad``, then refresh both kernel images."""
         f = self.flow
         ts = _train_state(f)
         self.t += 1
@@ -103,10 +127,32 @@ class AdamW:
             _lib.check(f.lib.pmc_adamw_step(_lib.ptr(f.params), _lib.ptr(ts.grad), _lib.ptr(self.m), _lib.ptr(self.v),
                                             f.params.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                                             float(max_norm) if max_norm is not None else 0.0, self.t,
-                                            C.c_void_p(ts.scal.data_ptr() + 8), _lib.stream_handle()),
+                                            _lib.ptr(ts.sq_partial), _lib.stream_handle()),
                        "pmc_adamw_step")
         f.repack()
         ts.repack(f)
+
+    def epoch(self, x, w, perm, batch_size, max_norm, loss_acc):
+        """``flow.py:297-323`` for one epoch in a single library call: every batch's loss/gradient,
+        clip, AdamW step and image refresh is enqueued back to back; ``loss_acc`` (f32 [1], device)
+        accumulates the batch losses."""
+        f = self.flow
+        ts = _train_state(f)
+        ts.ensure_slabs(batch_size)
+        c = _lib.pmc_adamw_t(params=f.params.data_ptr(), grad=ts.grad.data_ptr(), exp_avg=self.m.data_ptr(),
+                             exp_avg_sq=self.v.data_ptr(), n_params=f.params.numel(),
+                             pack_idx=f._pack_idx.data_ptr(), packed=f._packed.data_ptr(), n_packed=f._packed.numel(),
+                             packT_idx=ts.packT_idx.data_ptr(), packedT=ts.packedT.data_ptr(),
+                             n_packedT=ts.packedT.numel(), lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
+                             eps=self.eps, weight_decay=self.wd,
+                             max_norm=float(max_norm) if max_norm is not None else 0.0, step=self.t)
+        with torch.cuda.device(f.device):
+            _lib.check(f.lib.pmc_maf_train_epoch(C.byref(f._desc), C.byref(ts.desc), C.byref(c), _lib.ptr(x),
+                                                 _lib.ptr(w) if w is not None else None,
+                                                 _lib.ptr(perm) if perm is not None else None,
+                                                 x.shape[0], int(batch_size), _lib.ptr(loss_acc),
+                                                 _lib.stream_handle()), "pmc_maf_train_epoch")
+        self.t = int(c.step)
 
 
 class ReduceLROnPlateau:
@@ -179,22 +225,19 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
     start = time.time()
 
     n_train = x_train.shape[0]
+    acc2 = torch.zeros(2, dtype=torch.float32, device=dev)         # [train loss, val loss] of the epoch
     for epoch in range(epochs):
-        acc = torch.zeros((), dtype=torch.float32, device=dev)
-        for idx in _batches(n_train, batch_size, shuffle):
-            idx = idx.to(dev)
-            xb = x_train[idx].contiguous()
-            wb = None if w_train is None else w_train[idx].contiguous()
-            loss = loss_and_grad(flow, xb, wb)
-            acc += loss                                              # device-side: one sync per epoch
-            opt.step(clip_grad_norm)
-        vacc = torch.zeros((), dtype=torch.float32, device=dev)
+        acc2.zero_()
+        acc = acc2[0:1]
+        perm = torch.randperm(n_train).to(dev) if shuffle else None  # DataLoader(shuffle=...), flow.py:251-265
+        opt.epoch(x_train, w_train, perm, batch_size, clip_grad_norm, acc)
+        vacc = acc2[1:2]
         if validation:
             for idx in _batches(x_valid.shape[0], batch_size, shuffle):
                 idx = idx.to(dev)
                 vacc += batch_loss(flow, x_valid[idx].contiguous(),
                                    None if w_valid is None else w_valid[idx].contiguous())
-        both = torch.stack([acc, vacc]).cpu().numpy()
+        both = acc2.cpu().numpy()                                      # the one sync of the epoch
         train_loss = float(both[0]) / max(n_train, 1)                # flow.py:323
         history["loss"].append(train_loss)
         if validation:
