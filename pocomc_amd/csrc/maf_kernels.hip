@@ -313,6 +313,14 @@ extern "C" int pmc_maf_forward(const pmc_maf_t* m, const float* x, float* z, flo
     if (int e = check_maf(m)) return e;
     if (n == 0) return 0;
     if (!x || !z || n < 0) return pmc_fail("pmc_maf_forward: bad argument");
+    return pmc_launch_forward_wg(m, x, z, ladj, log_prob, n, (hipStream_t)stream);
+}
+
+// the lone-wave forward (one wavefront per 16 rows), kept as a cross-check of the workgroup kernel
+extern "C" int pmc_debug_forward_lone_wave(const pmc_maf_t* m, const float* x, float* z, float* ladj, float* log_prob,
+                                           int64_t n, void* stream) {
+    if (int e = check_maf(m)) return e;
+    if (n == 0) return 0;
     const size_t lds = maf_lds_bytes(*m, 3);
     if (int e = set_lds(maf_dense_kernel<0>, lds)) return e;
     hipLaunchKernelGGL(maf_dense_kernel<0>, dim3((unsigned)((n + 15) / 16)), dim3(64), lds, (hipStream_t)stream,

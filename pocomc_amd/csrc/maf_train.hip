@@ -28,6 +28,7 @@
 
 #include <string>
 #include "maf_common.h"
+#include "maf_wg.h"
 
 #ifndef TRAIN_PF
 #define TRAIN_PF 4                  // weight fragments in flight per wave
@@ -36,12 +37,6 @@
 #define TRAIN_WAVES 8
 #endif
 #define TRAIN_THREADS (64 * TRAIN_WAVES)
-
-// Workgroup barrier that orders LDS traffic only: global stores (gradient slabs) and prefetched
-// weight loads stay in flight across it (a __syncthreads() would drain vmcnt to zero).
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 struct TrainView {
     const float4* f0T; const float4* f1T; const float4* f2T; const float4* f3T;
@@ -67,12 +62,6 @@ __device__ __forceinline__ TrainView train_view(const pmc_maf_t& m, const pmc_ma
     v.gb2 = g; g += m.Hp;
     v.gb3 = g;
     return v;
-}
-
-// Deal tiles whose cost falls with `r` to the waves in a snake, so the sums balance.
-__device__ __forceinline__ int snake_owner(int r) {
-    const int pos = r % TRAIN_WAVES;
-    return ((r / TRAIN_WAVES) & 1) ? TRAIN_WAVES - 1 - pos : pos;
 }
 
 __device__ __forceinline__ void slab_put4(float* __restrict__ dst, const f32x4& v, bool first) {
@@ -103,61 +92,6 @@ __device__ __forceinline__ void bias_put(float* __restrict__ dst, f32x4 v, int l
         float s = v[r];
         s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
         if ((lane & 15) == 0) dst[r] = first ? s : dst[r] + s;
-    }
-}
-
-__device__ __forceinline__ f32x4 rows_of(const float* H, int T, int q, int p) {
-    const float* hb = H + (T << 8) + (p << 2) + q;
-    f32x4 a = {hb[0], hb[64], hb[128], hb[192]};
-    return a;
-}
-
-__device__ __forceinline__ f32x4 relu_gate(f32x4 a, const float* H, int T, int q, int p) {
-    const f32x4 h = rows_of(H, T, q, p);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) a[r] = h[r] > 0.f ? a[r] : 0.f;
-    return a;
-}
-
-#define TICKT() (PROF ? (long long)__builtin_readcyclecounter() : 0LL)
-#define LAPT(I) if (PROF) { const long long t2_ = TICKT(); pacc[I] += t2_ - tk; tk = t2_; }
-// phase barrier: time up to the barrier goes to phase I, the wait itself to slot 10
-#define PHASE_END(I) { LAPT(I) lds_barrier(); LAPT(10) }
-
-// hidden layers of one transform for the workgroup's 16 rows: X -> H0, H1, H2 (tiles dealt to the waves)
-template <bool PROF>
-__device__ __forceinline__ void hidden_pass_wg(const pmc_maf_t& m, const MafView& w, const float* X, float* H0,
-                                               float* H1, float* H2, int wv, int lane, long long* pacc,
-                                               long long& tk) {
-    const int q = lane >> 4, p = lane & 15;
-    const int nT = m.nT, nXT = m.nXT;
-    for (int T = wv; T < nT; T += TRAIN_WAVES) {
-        f32x4 a = bias4(w.b0, 16 * T + 4 * q);
-        a = mac_range<TRAIN_PF>(a, w.f0 + (size_t)T * nXT * 64, X, 0, nXT, lane);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.0f);
-        store_rows(H0, T, q, p, a);
-    }
-    LAPT(11)
-    lds_barrier();
-    LAPT(12)
-    for (int layer = 1; layer <= 2; ++layer) {
-        const float* Hin = layer == 1 ? H0 : H1;
-        float* Hout = layer == 1 ? H1 : H2;
-        const float4* f = layer == 1 ? w.f1 : w.f2;
-        const float* b = layer == 1 ? w.b1 : w.b2;
-        for (int T = 0; T < nT; ++T) {
-            if (snake_owner(nT - 1 - T) != wv) continue;
-            f32x4 a = bias4(b, 16 * T + 4 * q);
-            a = mac_range<TRAIN_PF>(a, f + (size_t)T * nT * 64, Hin, 0, m.tri_ok ? T + 1 : nT, lane);
-            const f32x4 h = rows_of(Hin, T, q, p);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r] + h[r], 0.0f);
-            store_rows(Hout, T, q, p, a);
-        }
-        LAPT(13)
-        lds_barrier();
-        LAPT(14)
     }
 }
 
@@ -235,7 +169,7 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
         for (int t = 0; t < T; ++t) {
             const MafView wvw = maf_view(m, t);
             float* xtn = xt + (size_t)(t + 1) * Dp * 16;
-            hidden_pass_wg<PROF>(m, wvw, Xc, A, B, Cb, wv, lane, pacc, tk);
+            hidden_pass_wg<TRAIN_WAVES, TRAIN_PF, PROF>(m, wvw, Xc, A, B, Cb, wv, lane, pacc, tk);
             LAPT(2)
             for (int O = wv; O < nOeff; O += TRAIN_WAVES) {
                 f32x4 o = bias4(wvw.b3, 16 * O + 4 * q);
@@ -296,7 +230,7 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
             for (int e = tid; e < Dp * 4; e += TRAIN_THREADS) reinterpret_cast<float4*>(E)[e] = xsrc[e];
             lds_barrier();
             // recompute this transform's activations and (shift, raw)
-            hidden_pass_wg<PROF>(m, wvw, E, A, B, Cb, wv, lane, pacc, tk);
+            hidden_pass_wg<TRAIN_WAVES, TRAIN_PF, PROF>(m, wvw, E, A, B, Cb, wv, lane, pacc, tk);
             for (int O = wv; O < nOeff; O += TRAIN_WAVES) {
                 f32x4 o = bias4(wvw.b3, 16 * O + 4 * q);
                 o = mac_range<TRAIN_PF>(o, wvw.f3 + (size_t)O * nT * 64, Cb, 0, nT, lane);
@@ -339,7 +273,7 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
             PHASE_END(6)
             // ---- layer 2: da1 = relu'(h1) . (da2 + W2^T da2) -> C ; dW2 (da2 x h1), db1
             for (int Ti = 0; Ti < nT; ++Ti) {
-                if (snake_owner(Ti) != wv) continue;
+                if (snake_owner<TRAIN_WAVES>(Ti) != wv) continue;
                 f32x4 a = rows_of(E, Ti, q, p);
                 a = mac_range<TRAIN_PF>(a, tv.f2T + (size_t)Ti * nT * 64, E, (m.tri_ok ? Ti : 0), nT, lane);
                 a = relu_gate(a, B, Ti, q, p);
@@ -359,7 +293,7 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
             PHASE_END(7)
             // ---- layer 1: da0 = relu'(h0) . (da1 + W1^T da1) -> E ; dW1 (da1 x h0), db0 ; x_t -> B
             for (int Ti = 0; Ti < nT; ++Ti) {
-                if (snake_owner(Ti) != wv) continue;
+                if (snake_owner<TRAIN_WAVES>(Ti) != wv) continue;
                 f32x4 a = rows_of(Cb, Ti, q, p);
                 a = mac_range<TRAIN_PF>(a, tv.f1T + (size_t)Ti * nT * 64, Cb, (m.tri_ok ? Ti : 0), nT, lane);
                 a = relu_gate(a, A, Ti, q, p);
