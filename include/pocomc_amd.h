@@ -46,7 +46,7 @@ typedef struct pmc_maf {
     int32_t nT, nXT, nOT;     /* hidden, input and output tiles */
     int64_t pk_per_transform;
     int32_t tri_ok;           /* every degree group fits one 16-slot tile */
-    int32_t reserved;
+    int32_t n_out;            /* hyper-network outputs per feature: 2 = affine (MAF), 23 = 8-bin spline (NSF) */
 } pmc_maf_t;
 
 #define PMC_INVERSE_AUTO 0

@@ -35,8 +35,91 @@ def soft_log_scale(raw):
     return (raw / (F32(1.0) + np.abs(raw / F32(LOG_SLOPE)))).astype(F32)
 
 
+# --------------------------------------------------------------------------
+# NSF univariate: zuko ``MonotonicRQSTransform(widths, heights, derivatives, bound=5, slope=1e-3)``
+# (pocomc/flow.py:69-86 builds ``zuko.flows.NSF(bins=8)``).  PARITY UNPINNED like the rest of the
+# flow: restated from zuko's published definition --
+#   widths, heights: ``v / (1 + |2 v / log(slope)|)`` -> softmax -> knots ``bound * (2 cumsum - 1)``
+#   derivatives:     ``v / (1 + |v / log(slope)|)`` -> exp, end knots have derivative 1
+#   bin ``k = searchsorted(knots, x) - 1``; outside ``[0, K)`` the map is the identity
+#   (Durkan et al. 2019 rational-quadratic spline inside).
+# --------------------------------------------------------------------------
+RQS_BOUND = 5.0
+
+
+def _rqs_knots(phi, K, xp):
+    """phi (..., 3K-1) -> knots x (..., K+1), y (..., K+1), derivatives (..., K+1)."""
+    ls = LOG_SLOPE
+    w, h, d = phi[..., :K], phi[..., K:2 * K], phi[..., 2 * K:]
+    w = w / (1 + abs(2 * w / ls))
+    h = h / (1 + abs(2 * h / ls))
+    d = d / (1 + abs(d / ls))
+    if xp is np:
+        def softmax(v):
+            e = np.exp(v - v.max(axis=-1, keepdims=True))
+            return (e / e.sum(axis=-1, keepdims=True, dtype=F32)).astype(F32)
+        zero = np.zeros(phi.shape[:-1] + (1,), dtype=F32)
+        xk = (F32(RQS_BOUND) * (2 * np.cumsum(np.concatenate([zero, softmax(w)], -1), axis=-1, dtype=F32) - 1)).astype(F32)
+        yk = (F32(RQS_BOUND) * (2 * np.cumsum(np.concatenate([zero, softmax(h)], -1), axis=-1, dtype=F32) - 1)).astype(F32)
+        dk = np.exp(np.concatenate([zero, d, zero], -1)).astype(F32)
+        return xk, yk, dk
+    import torch
+    zero = torch.zeros(phi.shape[:-1] + (1,), dtype=phi.dtype)
+    xk = RQS_BOUND * (2 * torch.cumsum(torch.cat([zero, torch.softmax(w, -1)], -1), -1) - 1)
+    yk = RQS_BOUND * (2 * torch.cumsum(torch.cat([zero, torch.softmax(h, -1)], -1), -1) - 1)
+    dk = torch.exp(torch.cat([zero, d, zero], -1))
+    return xk, yk, dk
+
+
+def _take(a, k, xp):
+    if xp is np:
+        return np.take_along_axis(a, k[..., None], axis=-1)[..., 0]
+    return a.gather(-1, k[..., None])[..., 0]
+
+
+def rqs_forward(x, phi, K=8, xp=np):
+    """``y, ladj`` of the spline at ``x`` (..., ) with parameters ``phi`` (..., 3K-1)."""
+    xk, yk, dk = _rqs_knots(phi, K, xp)
+    k = (xk < x[..., None]).sum(-1) - 1                  # searchsorted(knots, x) - 1
+    mask = (k >= 0) & (k < K)
+    kc = k.clip(0, K - 1) if xp is np else k.clamp(0, K - 1)
+    x0, x1 = _take(xk, kc, xp), _take(xk, kc + 1, xp)
+    y0, y1 = _take(yk, kc, xp), _take(yk, kc + 1, xp)
+    d0, d1 = _take(dk, kc, xp), _take(dk, kc + 1, xp)
+    s = (y1 - y0) / (x1 - x0)
+    z = (x - x0) / (x1 - x0)
+    z = xp.where(mask, z, xp.zeros_like(z))
+    den = s + (d0 + d1 - 2 * s) * z * (1 - z)
+    y = y0 + (y1 - y0) * (s * z * z + d0 * z * (1 - z)) / den
+    jac = s * s * (2 * s * z * (1 - z) + d0 * (1 - z) ** 2 + d1 * z * z) / (den * den)
+    ladj = xp.log(jac)
+    return xp.where(mask, y, x), xp.where(mask, ladj, xp.zeros_like(ladj))
+
+
+def rqs_inverse(y, phi, K=8, xp=np):
+    """``x, ladj_forward(x)`` with ``rqs_forward(x) = y``."""
+    xk, yk, dk = _rqs_knots(phi, K, xp)
+    k = (yk < y[..., None]).sum(-1) - 1
+    mask = (k >= 0) & (k < K)
+    kc = k.clip(0, K - 1) if xp is np else k.clamp(0, K - 1)
+    x0, x1 = _take(xk, kc, xp), _take(xk, kc + 1, xp)
+    y0, y1 = _take(yk, kc, xp), _take(yk, kc + 1, xp)
+    d0, d1 = _take(dk, kc, xp), _take(dk, kc + 1, xp)
+    s = (y1 - y0) / (x1 - x0)
+    y_ = xp.where(mask, y - y0, xp.zeros_like(y))
+    a = (y1 - y0) * (s - d0) + y_ * (d0 + d1 - 2 * s)
+    b = (y1 - y0) * d0 - y_ * (d0 + d1 - 2 * s)
+    c = -s * y_
+    z = 2 * c / (-b - xp.sqrt(b * b - 4 * a * c))
+    x = x0 + z * (x1 - x0)
+    den = s + (d0 + d1 - 2 * s) * z * (1 - z)
+    jac = s * s * (2 * s * z * (1 - z) + d0 * (1 - z) ** 2 + d1 * z * z) / (den * den)
+    ladj = xp.log(jac)
+    return xp.where(mask, x, y), xp.where(mask, ladj, xp.zeros_like(ladj))
+
+
 class OracleMAF:
-    """float32 numpy MAF with the canonical parameter vector of ``MAFSpec``."""
+    """float32 numpy MAF / NSF with the canonical parameter vector of ``MAFSpec``."""
 
     def __init__(self, spec: MAFSpec, flat: np.ndarray):
         self.spec = spec
@@ -52,23 +135,45 @@ class OracleMAF:
                 W2=(v("W2") * M2).astype(F32), b2=v("b2"),
                 W3=(v("W3") * M3).astype(F32), b3=v("b3")))
 
-    # hyper-network of one transform: x (N,D) -> shift (N,D), ls (N,D)
-    def _hyper(self, t: int, x: np.ndarray):
+    # hyper-network of one transform: x (N,D) -> phi (N, D, n_out)
+    def _phi(self, t: int, x: np.ndarray):
         m = self._mats[t]
         h = np.maximum(x @ m["W0"].T + m["b0"], F32(0))
         h = np.maximum(h + (h @ m["W1"].T + m["b1"]), F32(0))
         h = np.maximum(h + (h @ m["W2"].T + m["b2"]), F32(0))
         phi = (h @ m["W3"].T + m["b3"]).astype(F32)
-        return phi[:, 0::2], soft_log_scale(phi[:, 1::2])
+        return phi.reshape(len(x), self.spec.n_dim, self.spec.n_out)
+
+    def _hyper(self, t: int, x: np.ndarray):
+        """affine flows: ``(shift, soft-clipped log-scale)`` of transform t."""
+        phi = self._phi(t, x)
+        return phi[..., 0], soft_log_scale(phi[..., 1])
+
+    def _fwd(self, t, x):
+        """univariate maps of transform t at x: ``(y, per-feature ladj)``."""
+        phi = self._phi(t, x)
+        if self.spec.univariate == "affine":
+            ls = soft_log_scale(phi[..., 1])
+            return (x * np.exp(ls) + phi[..., 0]).astype(F32), ls
+        y, l = rqs_forward(x, phi, self.spec.bins)
+        return y.astype(F32), l.astype(F32)
+
+    def _inv(self, t, xcur, y):
+        """one fixed-point pass: parameters from ``xcur``, inverse univariate applied to ``y``."""
+        phi = self._phi(t, xcur)
+        if self.spec.univariate == "affine":
+            ls = soft_log_scale(phi[..., 1])
+            return ((y - phi[..., 0]) / np.exp(ls)).astype(F32), ls
+        x, l = rqs_inverse(y, phi, self.spec.bins)
+        return x.astype(F32), l.astype(F32)
 
     def forward(self, x):
         """data -> latent, ``(z, ladj)``; ``pocomc/flow.py:99-114``."""
         x = np.asarray(x, dtype=F32)
         ladj = np.zeros(len(x), dtype=F32)
         for t in range(self.spec.n_transforms):
-            shift, ls = self._hyper(t, x)
-            x = (x * np.exp(ls) + shift).astype(F32)
-            ladj = (ladj + ls.sum(axis=1, dtype=F32)).astype(F32)
+            x, l = self._fwd(t, x)
+            ladj = (ladj + l.sum(axis=1, dtype=F32)).astype(F32)
         return x, ladj
 
     def inverse(self, z):
@@ -80,10 +185,9 @@ class OracleMAF:
         for t in reversed(range(self.spec.n_transforms)):
             x = np.zeros_like(y)
             for _ in range(D):                      # zuko: passes = features
-                shift, ls = self._hyper(t, x)
-                x = ((y - shift) / np.exp(ls)).astype(F32)
-            shift, ls = self._hyper(t, x)           # extra pass for the ladj
-            ladj = (ladj - ls.sum(axis=1, dtype=F32)).astype(F32)
+                x, _l = self._inv(t, x, y)
+            _x, l = self._inv(t, x, y)              # extra pass for the ladj
+            ladj = (ladj - l.sum(axis=1, dtype=F32)).astype(F32)
             y = x
         return y, ladj
 
@@ -144,10 +248,13 @@ def torch_log_prob(spec: MAFSpec, flat_t, x_t):
         h = torch.relu(x @ (v("W0") * M[0]).T + v("b0"))
         h = torch.relu(h + h @ (v("W1") * M[1]).T + v("b1"))
         h = torch.relu(h + h @ (v("W2") * M[2]).T + v("b2"))
-        phi = h @ (v("W3") * M[3]).T + v("b3")
-        shift, raw = phi[:, 0::2], phi[:, 1::2]
-        ls = raw / (1 + torch.abs(raw / LOG_SLOPE))
-        x = x * torch.exp(ls) + shift
+        phi = (h @ (v("W3") * M[3]).T + v("b3")).reshape(x.shape[0], D, spec.n_out)
+        if spec.univariate == "affine":
+            shift, raw = phi[..., 0], phi[..., 1]
+            ls = raw / (1 + torch.abs(raw / LOG_SLOPE))
+            x = x * torch.exp(ls) + shift
+        else:
+            x, ls = rqs_forward(x, phi, spec.bins, xp=torch)
         ladj = ladj + ls.sum(dim=1)
     base = -0.5 * (x ** 2).sum(dim=1) - 0.5 * D * math.log(2 * math.pi)
     return base + ladj

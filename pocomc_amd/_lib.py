@@ -21,7 +21,7 @@ class pmc_maf_t(C.Structure):
                 ("Hp", C.c_int32), ("Dp", C.c_int32),
                 ("nT", C.c_int32), ("nXT", C.c_int32), ("nOT", C.c_int32),
                 ("pk_per_transform", C.c_int64),
-                ("tri_ok", C.c_int32), ("reserved", C.c_int32)]
+                ("tri_ok", C.c_int32), ("n_out", C.c_int32)]
 
 
 class pmc_maf_train_t(C.Structure):

@@ -303,7 +303,7 @@ extern "C" int pmc_maf_pack(const float* flat, const int32_t* pack_idx, float* p
 static int check_maf(const pmc_maf_t* m) {
     if (!m || !m->packed || !m->meta) return pmc_fail("pmc_maf: null descriptor field");
     if (m->D < 2 || m->T < 1 || (m->Hp & 15) || (m->Dp & 15) || m->nT * 16 != m->Hp ||
-        m->nXT * 16 != m->Dp || m->nOT * 16 != 2 * m->Dp)
+        m->nXT * 16 != m->Dp || (m->n_out != 2 && m->n_out != 23) || m->nOT * 16 != m->n_out * m->Dp)
         return pmc_fail("pmc_maf: inconsistent descriptor");
     return 0;
 }
@@ -333,6 +333,12 @@ extern "C" int pmc_maf_inverse(const pmc_maf_t* m, const float* z, float* x, flo
     if (int e = check_maf(m)) return e;
     if (n == 0) return 0;
     if (!z || !x || n < 0) return pmc_fail("pmc_maf_inverse: bad argument");
+    if (m->n_out != 2) {
+        // spline flows: the D-pass algorithm of the reference (zuko), workgroup-of-waves kernel
+        if (algo != PMC_INVERSE_AUTO && algo != PMC_INVERSE_NAIVE)
+            return pmc_fail("pmc_maf_inverse: the triangular sweeps are built for the affine (MAF) flows");
+        return pmc_launch_inverse_dpass_wg(m, z, x, ladj, n, (hipStream_t)stream);
+    }
     if (algo == PMC_INVERSE_AUTO) algo = m->tri_ok ? PMC_INVERSE_TRIANGULAR : PMC_INVERSE_NAIVE;
     if (algo == PMC_INVERSE_TRIANGULAR) {
         if (!m->tri_ok) return pmc_fail("pmc_maf_inverse: triangular sweep needs degree groups <= one tile");

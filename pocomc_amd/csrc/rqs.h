@@ -1,0 +1,179 @@
+// Univariate map of the neural spline flows (pocomc/flow.py:69-86 -> zuko.flows.NSF(bins=8)):
+// zuko's MonotonicRQSTransform(widths, heights, derivatives, bound=5, slope=1e-3), one thread per
+// (feature, row).  The 23 hyper-network outputs of a feature are
+//     phi[0:8]  widths,  phi[8:16] heights   -> v / (1 + |2 v / log(slope)|) -> softmax
+//                                            -> knots bound * (2 cumsum - 1)
+//     phi[16:23] interior derivatives         -> exp(v / (1 + |v / log(slope)|)); end knots: 1
+// bin k = searchsorted(knots, x) - 1; outside [0, 8) the map is the identity.  Inside, the
+// rational-quadratic spline of Durkan et al. (2019).  Everything is unrolled over the 8 bins with
+// compile-time indices so the knot tables stay in registers.
+#ifndef PMC_RQS_H
+#define PMC_RQS_H
+
+#include "maf_common.h"
+
+#define RQS_K 8
+#define RQS_NOUT 23
+#define RQS_BOUND 5.0f
+
+struct RqsBin {                 // the selected bin and what the backward pass needs of the tables
+    float x0, x1, y0, y1, d0, d1;
+    int k;                      // bin index, valid only if inside
+    bool inside;
+};
+
+struct RqsTables {
+    float pw[RQS_K], ph[RQS_K];     // softmax probabilities (bin widths / heights over 2*bound)
+    float xk[RQS_K + 1], yk[RQS_K + 1];
+};
+
+__device__ __forceinline__ float rqs_clip2(float v) { return v / (1.0f + fabsf(2.0f * v / PMC_LOG_SLOPE)); }
+__device__ __forceinline__ float rqs_clip1(float v) { return v / (1.0f + fabsf(v / PMC_LOG_SLOPE)); }
+
+__device__ __forceinline__ void rqs_softmax_knots(const float* v, float* p, float* knots) {
+    float c[RQS_K];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < RQS_K; ++j) { c[j] = rqs_clip2(v[j]); mx = fmaxf(mx, c[j]); }
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < RQS_K; ++j) { c[j] = expf(c[j] - mx); sum += c[j]; }
+    float cum = 0.0f;
+    knots[0] = -RQS_BOUND;
+#pragma unroll
+    for (int j = 0; j < RQS_K; ++j) {
+        p[j] = c[j] / sum;
+        cum += p[j];
+        knots[j + 1] = RQS_BOUND * (2.0f * cum - 1.0f);
+    }
+}
+
+__device__ __forceinline__ void rqs_tables(const float* phi, RqsTables& t) {
+    rqs_softmax_knots(phi, t.pw, t.xk);
+    rqs_softmax_knots(phi + RQS_K, t.ph, t.yk);
+}
+
+// bin of `v` in `knots` (the x knots for the forward map, the y knots for the inverse)
+__device__ __forceinline__ void rqs_select(const RqsTables& t, const float* phi, const float* knots, float v,
+                                           RqsBin& b) {
+    b.inside = (v > knots[0]) && (v <= knots[RQS_K]);
+    b.k = 0;
+    b.x0 = t.xk[0]; b.x1 = t.xk[1]; b.y0 = t.yk[0]; b.y1 = t.yk[1];
+    float r0 = 0.0f, r1 = rqs_clip1(phi[2 * RQS_K]);          // raw (clipped) log-derivatives at the bin's knots
+#pragma unroll
+    for (int j = 1; j < RQS_K; ++j) {
+        if (knots[j] < v) {
+            b.k = j;
+            b.x0 = t.xk[j]; b.x1 = t.xk[j + 1]; b.y0 = t.yk[j]; b.y1 = t.yk[j + 1];
+            r0 = rqs_clip1(phi[2 * RQS_K + j - 1]);
+            r1 = (j + 1 < RQS_K) ? rqs_clip1(phi[2 * RQS_K + j]) : 0.0f;
+        }
+    }
+    b.d0 = expf(r0);
+    b.d1 = expf(r1);
+}
+
+// y = f(x), ladj = log f'(x)
+__device__ __forceinline__ void rqs_forward(const float* phi, float x, float& y, float& ladj) {
+    RqsTables t;
+    rqs_tables(phi, t);
+    RqsBin b;
+    rqs_select(t, phi, t.xk, x, b);
+    const float dx = b.x1 - b.x0, dy = b.y1 - b.y0;
+    const float s = dy / dx;
+    const float z = b.inside ? (x - b.x0) / dx : 0.0f;
+    const float u = z * (1.0f - z);
+    const float den = s + (b.d0 + b.d1 - 2.0f * s) * u;
+    const float yy = b.y0 + dy * (s * z * z + b.d0 * u) / den;
+    const float jac = s * s * (2.0f * s * u + b.d0 * (1.0f - z) * (1.0f - z) + b.d1 * z * z) / (den * den);
+    y = b.inside ? yy : x;
+    ladj = b.inside ? logf(jac) : 0.0f;
+}
+
+// x = f^-1(y), ladj = log f'(x)  (the forward log-derivative at the solution)
+__device__ __forceinline__ void rqs_inverse(const float* phi, float y, float& x, float& ladj) {
+    RqsTables t;
+    rqs_tables(phi, t);
+    RqsBin b;
+    rqs_select(t, phi, t.yk, y, b);
+    const float dx = b.x1 - b.x0, dy = b.y1 - b.y0;
+    const float s = dy / dx;
+    const float yr = b.inside ? y - b.y0 : 0.0f;
+    const float e = b.d0 + b.d1 - 2.0f * s;
+    const float qa = dy * (s - b.d0) + yr * e;
+    const float qb = dy * b.d0 - yr * e;
+    const float qc = -s * yr;
+    const float z = 2.0f * qc / (-qb - sqrtf(qb * qb - 4.0f * qa * qc));
+    const float u = z * (1.0f - z);
+    const float den = s + e * u;
+    const float jac = s * s * (2.0f * s * u + b.d0 * (1.0f - z) * (1.0f - z) + b.d1 * z * z) / (den * den);
+    x = b.inside ? b.x0 + z * dx : y;
+    ladj = b.inside ? logf(jac) : 0.0f;
+}
+
+// Reverse mode of F = gy * y + gl * ladj:  dphi[23] and gx = dF/dx.
+__device__ __forceinline__ void rqs_backward(const float* phi, float x, float gy, float gl, float* dphi, float& gx) {
+    RqsTables t;
+    rqs_tables(phi, t);
+    RqsBin b;
+    rqs_select(t, phi, t.xk, x, b);
+#pragma unroll
+    for (int j = 0; j < RQS_NOUT; ++j) dphi[j] = 0.0f;
+    gx = gy;
+    if (!b.inside) return;
+    const float dx = b.x1 - b.x0, dy = b.y1 - b.y0;
+    const float s = dy / dx;
+    const float z = (x - b.x0) / dx;
+    const float u = z * (1.0f - z);
+    const float e = b.d0 + b.d1 - 2.0f * s;
+    const float num = s * z * z + b.d0 * u;
+    const float den = s + e * u;
+    const float jn = 2.0f * s * u + b.d0 * (1.0f - z) * (1.0f - z) + b.d1 * z * z;
+    // adjoints of the spline formula
+    const float g_num = gy * dy / den;
+    const float g_den = -gy * dy * num / (den * den) - 2.0f * gl / den;
+    const float g_jn = gl / jn;
+    float g_dy = gy * num / den;
+    const float g_s = g_num * z * z + g_den * (1.0f - 2.0f * u) + 2.0f * gl / s + g_jn * 2.0f * u;
+    const float g_d0 = (g_num + g_den) * u + g_jn * (1.0f - z) * (1.0f - z);
+    const float g_d1 = g_den * u + g_jn * z * z;
+    const float g_u = g_num * b.d0 + g_den * e + g_jn * 2.0f * s;
+    const float g_z = g_num * 2.0f * s * z + g_u * (1.0f - 2.0f * z) + g_jn * (-2.0f * b.d0 * (1.0f - z) + 2.0f * b.d1 * z);
+    // s = dy / dx,  z = (x - x0) / dx
+    g_dy += g_s / dx;
+    const float g_dx = -g_s * s / dx - g_z * z / dx;
+    gx = g_z / dx;
+    const float g_x0 = -g_z / dx - g_dx, g_x1 = g_dx;
+    const float g_y0 = gy - g_dy, g_y1 = g_dy;
+    // knots -> softmax probabilities: knot_j = B (2 sum_{i<j} p_i - 1)
+    //   dF/dp_i = 2B (g_k0 [i < k] + g_k1 [i < k+1])
+    float gpw[RQS_K], gph[RQS_K];
+    float dotw = 0.0f, doth = 0.0f;
+#pragma unroll
+    for (int i = 0; i < RQS_K; ++i) {
+        const float lo = (i < b.k) ? 1.0f : 0.0f, hi = (i <= b.k) ? 1.0f : 0.0f;
+        gpw[i] = 2.0f * RQS_BOUND * (g_x0 * lo + g_x1 * hi);
+        gph[i] = 2.0f * RQS_BOUND * (g_y0 * lo + g_y1 * hi);
+        dotw += t.pw[i] * gpw[i];
+        doth += t.ph[i] * gph[i];
+    }
+#pragma unroll
+    for (int i = 0; i < RQS_K; ++i) {
+        // softmax backward, then the soft clip v / (1 + |2v/ls|) whose derivative is 1 / (1 + |2v/ls|)^2
+        const float cw = 1.0f + fabsf(2.0f * phi[i] / PMC_LOG_SLOPE);
+        const float ch = 1.0f + fabsf(2.0f * phi[RQS_K + i] / PMC_LOG_SLOPE);
+        dphi[i] = t.pw[i] * (gpw[i] - dotw) / (cw * cw);
+        dphi[RQS_K + i] = t.ph[i] * (gph[i] - doth) / (ch * ch);
+    }
+    // derivatives: d = exp(clip1(v)); knot k uses phi[16 + k - 1] (k >= 1), knot k+1 uses phi[16 + k] (k + 1 <= 7)
+#pragma unroll
+    for (int j = 0; j < RQS_K - 1; ++j) {
+        const float c = 1.0f + fabsf(phi[2 * RQS_K + j] / PMC_LOG_SLOPE);
+        float g = 0.0f;
+        if (j == b.k - 1) g = g_d0 * b.d0;
+        if (j == b.k) g = g_d1 * b.d1;
+        dphi[2 * RQS_K + j] = g / (c * c);
+    }
+}
+
+#endif

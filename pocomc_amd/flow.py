@@ -7,9 +7,11 @@ on the GPU; results come back on the input's device with dtype float32, float64
 input is cast with the reference's warning (``pocomc/tools.py:295-316``).
 
 The predefined MAFs of the reference are supported (``maf3 | maf6 | maf12``,
-``pocomc/flow.py:54-68``); a ``MAFSpec`` gives a custom depth/width (the
-reference takes a ``zuko.flows.Flow`` object there, ``flow.py:87-88``).  The
-spline flows ``nsf*`` are the next row of the scope table.
+``pocomc/flow.py:54-68``) and the neural spline flows (``nsf3 | nsf6 | nsf12``,
+``flow.py:69-86``: the same masked hyper-network with an 8-bin monotonic
+rational-quadratic spline per feature); a ``MAFSpec`` gives a custom
+depth/width (the reference takes a ``zuko.flows.Flow`` object there,
+``flow.py:87-88``).
 """
 from __future__ import annotations
 
@@ -20,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .maf_spec import MAFSpec, SPEC_BY_NAME
+from .maf_spec import MAFSpec, SPEC_BY_NAME, NSF_BY_NAME, spec_by_name
 
 
 def torch_double_to_float(x: torch.Tensor, warn: bool = True) -> torch.Tensor:
@@ -43,12 +45,8 @@ class Flow:
             spec = flow
             if spec.n_dim != self.n_dim:
                 raise ValueError("MAFSpec.n_dim does not match n_dim")
-        elif flow in SPEC_BY_NAME:
-            spec = MAFSpec(self.n_dim, SPEC_BY_NAME[flow])
-        elif flow in ("nsf3", "nsf6", "nsf12"):
-            raise NotImplementedError(
-                f"{flow}: the rational-quadratic spline flows are not built yet "
-                "(SURVEY.md section 8(f) row 2); use maf3 | maf6 | maf12")
+        elif flow in SPEC_BY_NAME or flow in NSF_BY_NAME:
+            spec = spec_by_name(self.n_dim, flow)
         else:
             raise ValueError("Invalid flow type. Choose from: maf3, maf6, maf12, nsf3, nsf6, nsf12, "
                              "or provide a MAFSpec object.")
@@ -67,7 +65,7 @@ class Flow:
             packed=self._packed.data_ptr(), meta=self._meta.data_ptr(),
             D=spec.n_dim, H=spec.hidden, T=spec.n_transforms, Hp=spec.Hp, Dp=spec.Dp,
             nT=spec.nT, nXT=spec.nXT, nOT=spec.nOT, pk_per_transform=spec.pk_per_transform,
-            tri_ok=int(spec.tri_ok), reserved=0)
+            tri_ok=int(spec.tri_ok), n_out=spec.n_out)
         self.inverse_algo = 0          # PMC_INVERSE_AUTO
         self.repack()
 
@@ -75,7 +73,8 @@ class Flow:
     def __getstate__(self):
         """Plain tensors instead of device handles (the reference pickles the whole zuko module,
         sampler.py:1023-1049)."""
-        return {"n_dim": self.n_dim, "spec": (self.spec.n_dim, self.spec.n_transforms, self.spec.hidden),
+        return {"n_dim": self.n_dim,
+                "spec": (self.spec.n_dim, self.spec.n_transforms, self.spec.hidden, self.spec.univariate, self.spec.bins),
                 "params": self.params.detach().cpu().numpy(), "inverse_algo": self.inverse_algo}
 
     def __setstate__(self, st):

@@ -60,6 +60,8 @@ class MAFSpec:
     n_dim: int
     n_transforms: int = 3
     hidden: int | None = None
+    univariate: str = "affine"      # "affine" (MAF) | "rqs" (NSF: monotonic rational-quadratic spline)
+    bins: int = 8                   # spline bins (pocomc/flow.py:71), ignored for "affine"
 
     # filled by __post_init__
     orders: list = field(default_factory=list, repr=False)
@@ -78,6 +80,13 @@ class MAFSpec:
         H = self.hidden
         if H < D - 1:
             raise NotImplementedError("hidden width must be >= n_dim - 1")
+        if self.univariate not in ("affine", "rqs"):
+            raise ValueError("univariate must be 'affine' or 'rqs'")
+        if self.univariate == "rqs" and self.bins != 8:
+            raise NotImplementedError("the spline kernels are built for 8 bins (pocomc/flow.py:71,77,83)")
+        # hyper-network outputs per feature: (shift, raw log-scale) or (K widths, K heights, K-1 derivatives)
+        self.n_out = 2 if self.univariate == "affine" else 3 * int(self.bins) - 1
+        NO = self.n_out
         # rank of every input feature, per transform (zuko MAF: orders[i % 2])
         ident = np.arange(D)
         self.orders = [ident.copy() if t % 2 == 0 else ident[::-1].copy()
@@ -86,7 +95,7 @@ class MAFSpec:
         self.degree = 1 + (np.arange(H) % (D - 1))
         # canonical offsets inside one transform
         sizes = [("W0", H * D), ("b0", H), ("W1", H * H), ("b1", H),
-                 ("W2", H * H), ("b2", H), ("W3", 2 * D * H), ("b3", 2 * D)]
+                 ("W2", H * H), ("b2", H), ("W3", NO * D * H), ("b3", NO * D)]
         off = 0
         self.offsets = {}
         for name, sz in sizes:
@@ -104,13 +113,13 @@ class MAFSpec:
         deg = self.degree
         M0 = rank[None, :] < deg[:, None]
         M1 = deg[None, :] <= deg[:, None]
-        M3 = deg[None, :] <= np.repeat(rank, 2)[:, None]
+        M3 = deg[None, :] <= np.repeat(rank, self.n_out)[:, None]
         return M0, M1, M1.copy(), M3
 
     def shapes(self):
         D, H = self.n_dim, self.hidden
         return {"W0": (H, D), "b0": (H,), "W1": (H, H), "b1": (H,),
-                "W2": (H, H), "b2": (H,), "W3": (2 * D, H), "b3": (2 * D,)}
+                "W2": (H, H), "b2": (H,), "W3": (self.n_out * D, H), "b3": (self.n_out * D,)}
 
     def view(self, flat: np.ndarray, t: int, name: str) -> np.ndarray:
         """View of one canonical tensor inside the flat parameter vector."""
@@ -183,8 +192,8 @@ class MAFSpec:
         self.nQ = Hp // 4                        # hidden quads
         self.Dp = _ceil_to(D, 16)
         self.nXT = self.Dp // 16                 # input (rank) tiles
-        self.Op = 2 * self.Dp
-        self.nOT = self.Op // 16                 # output tiles (8 ranks each)
+        self.Op = _ceil_to(self.n_out * self.Dp, 16)   # output rows n_out*rank + j
+        self.nOT = self.Op // 16                 # output tiles (8 ranks each for the affine map)
         self.slot_unit = np.asarray(slots, dtype=np.int64)
         self.slot_deg = np.asarray(sdeg, dtype=np.int32)
         qdeg = self.slot_deg.reshape(-1, 4)
@@ -270,9 +279,9 @@ class MAFSpec:
             f3 = np.full((nOT, nT, 64, 4), -1, dtype=np.int64)
             for O in range(nOT):
                 orow = 16 * O + li                               # packed out row
-                r_out = orow >> 1
-                s = orow & 1
-                crow = np.where(r_out < D, 2 * feat_of_rank[np.minimum(r_out, D - 1)] + s, -1)
+                r_out = orow // self.n_out
+                s = orow % self.n_out
+                crow = np.where(r_out < D, self.n_out * feat_of_rank[np.minimum(r_out, D - 1)] + s, -1)
                 for K in range(nT):
                     for c in range(4):
                         in_unit = su[16 * K + 4 * c + lk]
@@ -290,8 +299,8 @@ class MAFSpec:
             b3 = np.full(self.Op, -1, dtype=np.int64)
             off3, _ = self.offsets["b3"]
             for r in range(D):
-                b3[2 * r] = base_c + off3 + 2 * feat_of_rank[r]
-                b3[2 * r + 1] = base_c + off3 + 2 * feat_of_rank[r] + 1
+                for j in range(self.n_out):
+                    b3[self.n_out * r + j] = base_c + off3 + self.n_out * feat_of_rank[r] + j
 
             po = self.pk_offsets
             def put(name, arr):
@@ -372,8 +381,8 @@ class MAFSpec:
                 return np.where(r_in < D, feat_of_rank[np.minimum(r_in, D - 1)], -1)
 
             def orow(o):
-                r_out, s = o >> 1, o & 1
-                return np.where(r_out < D, 2 * feat_of_rank[np.minimum(r_out, D - 1)] + s, -1)
+                r_out, s = o // self.n_out, o % self.n_out
+                return np.where(r_out < D, self.n_out * feat_of_rank[np.minimum(r_out, D - 1)] + s, -1)
 
             # ---- transposed fragments: A[i = lane&15][k = lane>>4], component c
             f0T = np.full((nXT, nT, 64, 4), -1, dtype=np.int64)
@@ -421,8 +430,8 @@ class MAFSpec:
             gb3 = np.full(self.Op, -1, dtype=np.int64)
             off3, _ = self.offsets["b3"]
             for r in range(D):
-                gb3[2 * r] = base_c + off3 + 2 * feat_of_rank[r]
-                gb3[2 * r + 1] = base_c + off3 + 2 * feat_of_rank[r] + 1
+                for j in range(self.n_out):
+                    gb3[self.n_out * r + j] = base_c + off3 + self.n_out * feat_of_rank[r] + j
             bT, bG = t * L["pkT_per_transform"], t * L["gmap_per_transform"]
             for name, arr in (("f0T", f0T), ("f1T", f1T), ("f2T", f2T), ("f3T", f3T)):
                 a = arr.reshape(-1)
@@ -453,3 +462,13 @@ class MAFSpec:
 
 
 SPEC_BY_NAME = {"maf3": 3, "maf6": 6, "maf12": 12}
+NSF_BY_NAME = {"nsf3": 3, "nsf6": 6, "nsf12": 12}          # pocomc/flow.py:69-86
+
+
+def spec_by_name(n_dim: int, name: str) -> "MAFSpec":
+    """The six predefined flows of ``pocomc/flow.py:54-86``."""
+    if name in SPEC_BY_NAME:
+        return MAFSpec(n_dim, SPEC_BY_NAME[name])
+    if name in NSF_BY_NAME:
+        return MAFSpec(n_dim, NSF_BY_NAME[name], univariate="rqs", bins=8)
+    raise KeyError(name)
