@@ -29,6 +29,7 @@
 #include <string>
 #include "maf_common.h"
 #include "maf_wg.h"
+#include "rqs.h"
 
 #ifndef TRAIN_PF
 #define TRAIN_PF 4                  // weight fragments in flight per wave
@@ -95,7 +96,21 @@ __device__ __forceinline__ void bias_put(float* __restrict__ dst, f32x4 v, int l
     }
 }
 
-template <bool PROF>
+// out-layer panel of ranks [16c, 16c+16) of a spline flow: output tiles 23c .. 23c+22 -> P (local tile index)
+__device__ __forceinline__ void rqs_panel_train(const pmc_maf_t& m, const MafView& w, const float* H2, float* P, int c,
+                                                int wv, int lane) {
+    const int q = lane >> 4, p = lane & 15;
+    for (int i = wv; i < RQS_NOUT; i += TRAIN_WAVES) {
+        const int O = RQS_NOUT * c + i;
+        if (16 * O >= RQS_NOUT * m.D) continue;              // padding rows: never read
+        f32x4 o = bias4(w.b3, 16 * O + 4 * q);
+        o = mac_range<TRAIN_PF>(o, w.f3 + (size_t)O * m.nT * 64, H2, 0, m.nT, lane);
+        store_rows(P, i, q, p, o);
+    }
+}
+
+// UNI 0: affine univariate (MAF), 2 outputs per feature.  UNI 1: 8-bin spline (NSF), 23 outputs.
+template <bool PROF, int UNI>
 __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m, pmc_maf_train_t tr,
                                                                      const float* __restrict__ x,
                                                                      const float* __restrict__ w,
@@ -108,16 +123,18 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: tile ownership branches stay scalar
     const int q = lane >> 4, p = lane & 15;
-    const int D = m.D, Dp = m.Dp, Hp = m.Hp, Op = 2 * m.Dp, T = m.T, nT = m.nT, nXT = m.nXT, nOT = m.nOT;
-    const int nOeff = min(nOT, (D + 7) / 8);
+    const int D = m.D, Dp = m.Dp, Hp = m.Hp, T = m.T, nT = m.nT, nXT = m.nXT, nOT = m.nOT;
+    const int Psz = UNI ? RQS_NOUT * 256 : 2 * Dp * 16;       // spline flows: one 16-rank panel at a time
+    const int nOeff = UNI ? (RQS_NOUT * D + 15) / 16 : min(nOT, (D + 7) / 8);   // output tiles with real rows
     float* A = smem;
     float* B = A + Hp * 16;
     float* Cb = B + Hp * 16;
     float* E = Cb + Hp * 16;
-    float* P = E + Hp * 16;                   // [Op*16]
-    float* Gb = P + Op * 16;                  // [Dp*16]
+    float* P = E + Hp * 16;                   // [Psz]
+    float* Gb = P + Psz;                      // [Dp*16]
     float* CC = Gb + Dp * 16;                 // [16] per-row loss coefficient
     float* RED = CC + 16;                     // [16 * TRAIN_WAVES]
+    float* XB = RED + 16 * TRAIN_WAVES;       // UNI 1: [Dp*16] the transform's input during its backward sweep
     const int* feat_of_rank = m.meta + 8;
     const int* rank_of_feat = m.meta + 8 + T * D;
     float* slab = tr.slabs + (size_t)blockIdx.x * tr.slab_stride;
@@ -171,21 +188,43 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
             float* xtn = xt + (size_t)(t + 1) * Dp * 16;
             hidden_pass_wg<TRAIN_WAVES, TRAIN_PF, PROF>(m, wvw, Xc, A, B, Cb, wv, lane, pacc, tk);
             LAPT(2)
-            for (int O = wv; O < nOeff; O += TRAIN_WAVES) {
-                f32x4 o = bias4(wvw.b3, 16 * O + 4 * q);
-                o = mac_range<TRAIN_PF>(o, wvw.f3 + (size_t)O * nT * 64, Cb, 0, nT, lane);
-                for (int s = 0; s < 2; ++s) {
-                    const int rank = 8 * O + 2 * q + s;
-                    if (rank < D) {
-                        const float shift = s ? o[2] : o[0];
-                        const float ls = soft_ls(s ? o[3] : o[1]);
-                        const float y = Xc[lidx(rank, p)] * expf(ls) + shift;
-                        // the next transform reads its input by its own rank order
-                        const int r2 = (t + 1 < T) ? rank_of_feat[(t + 1) * D + feat_of_rank[t * D + rank]] : rank;
-                        Xn[lidx(r2, p)] = y;
-                        xtn[lidx(r2, p)] = y;
-                        ladj += ls;
+            if (UNI == 0) {
+                for (int O = wv; O < nOeff; O += TRAIN_WAVES) {
+                    f32x4 o = bias4(wvw.b3, 16 * O + 4 * q);
+                    o = mac_range<TRAIN_PF>(o, wvw.f3 + (size_t)O * nT * 64, Cb, 0, nT, lane);
+                    for (int s = 0; s < 2; ++s) {
+                        const int rank = 8 * O + 2 * q + s;
+                        if (rank < D) {
+                            const float shift = s ? o[2] : o[0];
+                            const float ls = soft_ls(s ? o[3] : o[1]);
+                            const float y = Xc[lidx(rank, p)] * expf(ls) + shift;
+                            // the next transform reads its input by its own rank order
+                            const int r2 = (t + 1 < T) ? rank_of_feat[(t + 1) * D + feat_of_rank[t * D + rank]] : rank;
+                            Xn[lidx(r2, p)] = y;
+                            xtn[lidx(r2, p)] = y;
+                            ladj += ls;
+                        }
                     }
+                }
+            } else {
+                for (int c = 0; c < nXT; ++c) {
+                    rqs_panel_train(m, wvw, Cb, P, c, wv, lane);
+                    lds_barrier();
+                    for (int e = tid; e < 256; e += TRAIN_THREADS) {
+                        const int rr = e >> 4, pp = e & 15, rank = 16 * c + rr;
+                        if (rank < D) {
+                            float phi[RQS_NOUT];
+#pragma unroll
+                            for (int j = 0; j < RQS_NOUT; ++j) phi[j] = P[lidx(RQS_NOUT * rr + j, pp)];
+                            float y, l;
+                            rqs_forward(phi, Xc[lidx(rank, pp)], y, l);
+                            const int r2 = (t + 1 < T) ? rank_of_feat[(t + 1) * D + feat_of_rank[t * D + rank]] : rank;
+                            Xn[lidx(r2, pp)] = y;
+                            xtn[lidx(r2, pp)] = y;
+                            ladj += l;
+                        }
+                    }
+                    lds_barrier();
                 }
             }
             for (int e = tid; e < (Dp - D) * 16; e += TRAIN_THREADS) {
@@ -227,50 +266,102 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
             const MafView wvw = maf_view(m, t);
             const TrainView tv = train_view(m, tr, t);
             const float4* xsrc = reinterpret_cast<const float4*>(xt + (size_t)t * Dp * 16);
-            for (int e = tid; e < Dp * 4; e += TRAIN_THREADS) reinterpret_cast<float4*>(E)[e] = xsrc[e];
-            lds_barrier();
-            // recompute this transform's activations and (shift, raw)
-            hidden_pass_wg<TRAIN_WAVES, TRAIN_PF, PROF>(m, wvw, E, A, B, Cb, wv, lane, pacc, tk);
-            for (int O = wv; O < nOeff; O += TRAIN_WAVES) {
-                f32x4 o = bias4(wvw.b3, 16 * O + 4 * q);
-                o = mac_range<TRAIN_PF>(o, wvw.f3 + (size_t)O * nT * 64, Cb, 0, nT, lane);
-                store_rows(P, O, q, p, o);
-            }
-            PHASE_END(4)
-            // element-wise part: y = x e^{ls} + shift,  L += -c * sum ls   (in place: P -> dP, G -> direct dx)
-            for (int e = tid; e < Dp * 16; e += TRAIN_THREADS) {
-                const int r = e >> 4, pp = e & 15;
-                float gs = 0.0f, gr = 0.0f, gx = 0.0f;
-                if (r < D) {
-                    const float xv = E[lidx(r, pp)];
-                    const float raw = P[lidx(2 * r + 1, pp)];
-                    const float den = 1.0f + fabsf(raw / PMC_LOG_SLOPE);
-                    const float el = expf(raw / den);
-                    const float gy = Gb[lidx(r, pp)];
-                    gs = gy;
-                    gr = (gy * xv * el - CC[pp]) / (den * den);
-                    gx = gy * el;
+            if (UNI == 0) {
+                for (int e = tid; e < Dp * 4; e += TRAIN_THREADS) reinterpret_cast<float4*>(E)[e] = xsrc[e];
+                lds_barrier();
+                // recompute this transform's activations and (shift, raw)
+                hidden_pass_wg<TRAIN_WAVES, TRAIN_PF, PROF>(m, wvw, E, A, B, Cb, wv, lane, pacc, tk);
+                for (int O = wv; O < nOeff; O += TRAIN_WAVES) {
+                    f32x4 o = bias4(wvw.b3, 16 * O + 4 * q);
+                    o = mac_range<TRAIN_PF>(o, wvw.f3 + (size_t)O * nT * 64, Cb, 0, nT, lane);
+                    store_rows(P, O, q, p, o);
                 }
-                P[lidx(2 * r, pp)] = gs;
-                P[lidx(2 * r + 1, pp)] = gr;
-                Gb[lidx(r, pp)] = gx;
+                PHASE_END(4)
+                // element-wise part: y = x e^{ls} + shift,  L += -c * sum ls   (in place: P -> dP, G -> direct dx)
+                for (int e = tid; e < Dp * 16; e += TRAIN_THREADS) {
+                    const int r = e >> 4, pp = e & 15;
+                    float gs = 0.0f, gr = 0.0f, gx = 0.0f;
+                    if (r < D) {
+                        const float xv = E[lidx(r, pp)];
+                        const float raw = P[lidx(2 * r + 1, pp)];
+                        const float den = 1.0f + fabsf(raw / PMC_LOG_SLOPE);
+                        const float el = expf(raw / den);
+                        const float gy = Gb[lidx(r, pp)];
+                        gs = gy;
+                        gr = (gy * xv * el - CC[pp]) / (den * den);
+                        gx = gy * el;
+                    }
+                    P[lidx(2 * r, pp)] = gs;
+                    P[lidx(2 * r + 1, pp)] = gr;
+                    Gb[lidx(r, pp)] = gx;
+                }
+                PHASE_END(5)
+                // ---- layer 3: da2 = relu'(h2) . W3^T dP -> E ; dW3, db3, db2
+                for (int K = wv; K < nT; K += TRAIN_WAVES) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                    a = mac_range<TRAIN_PF>(a, tv.f3T + (size_t)K * nOT * 64, P, 0, nOeff, lane);
+                    a = relu_gate(a, Cb, K, q, p);
+                    store_rows(E, K, q, p, a);
+                    bias_put(slab + tv.gb2 + 16 * K + 4 * q, a, lane, first);
+                }
+                for (int O = wv; O < nOeff; O += TRAIN_WAVES)
+                    bias_put(slab + tv.gb3 + 16 * O + 4 * q, rows_of(P, O, q, p), lane, first);
+                for (int i = wv; i < nOeff * nT; i += TRAIN_WAVES) {
+                    const int O = i / nT, K = i - O * nT;
+                    slab_put4(slab + tv.g3 + ((size_t)i * 64 + lane) * 4, outer_tile(P, O, Cb, K, lane), first);
+                }
+                PHASE_END(6)
+            } else {
+                // x_t -> XB (kept for the whole spline sweep), E <- 0 (accumulates W3^T dP over the panels)
+                for (int e = tid; e < Dp * 4; e += TRAIN_THREADS) reinterpret_cast<float4*>(XB)[e] = xsrc[e];
+                for (int e = tid; e < Hp * 4; e += TRAIN_THREADS)
+                    reinterpret_cast<float4*>(E)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+                lds_barrier();
+                hidden_pass_wg<TRAIN_WAVES, TRAIN_PF, PROF>(m, wvw, XB, A, B, Cb, wv, lane, pacc, tk);
+                LAPT(4)
+                for (int c = 0; c < nXT; ++c) {
+                    const int O0 = RQS_NOUT * c;                         // first output tile of the panel
+                    const int nO = min(RQS_NOUT, nOeff - O0);            // its tiles with real rows
+                    rqs_panel_train(m, wvw, Cb, P, c, wv, lane);
+                    PHASE_END(4)
+                    // spline backward in place: P -> dP, G -> direct dL/dx term
+                    for (int e = tid; e < 256; e += TRAIN_THREADS) {
+                        const int rr = e >> 4, pp = e & 15, rank = 16 * c + rr;
+                        if (rank < D) {
+                            float phi[RQS_NOUT], dphi[RQS_NOUT];
+#pragma unroll
+                            for (int j = 0; j < RQS_NOUT; ++j) phi[j] = P[lidx(RQS_NOUT * rr + j, pp)];
+                            float gx;
+                            rqs_backward(phi, XB[lidx(rank, pp)], Gb[lidx(rank, pp)], -CC[pp], dphi, gx);
+#pragma unroll
+                            for (int j = 0; j < RQS_NOUT; ++j) P[lidx(RQS_NOUT * rr + j, pp)] = dphi[j];
+                            Gb[lidx(rank, pp)] = gx;
+                        }
+                    }
+                    PHASE_END(5)
+                    // W3^T dP of this panel into E (every wave owns whole tiles of E), db3, dW3
+                    for (int K = wv; K < nT; K += TRAIN_WAVES) {
+                        f32x4 a = rows_of(E, K, q, p);
+                        a = mac_range<TRAIN_PF>(a, tv.f3T + ((size_t)K * nOT + O0) * 64, P, 0, nO, lane);
+                        store_rows(E, K, q, p, a);
+                    }
+                    for (int i = wv; i < nO; i += TRAIN_WAVES)
+                        bias_put(slab + tv.gb3 + 16 * (O0 + i) + 4 * q, rows_of(P, i, q, p), lane, first);
+                    for (int i = wv; i < nO * nT; i += TRAIN_WAVES) {
+                        const int Ol = i / nT, K = i - Ol * nT;
+                        slab_put4(slab + tv.g3 + (((size_t)(O0 + Ol) * nT + K) * 64 + lane) * 4,
+                                  outer_tile(P, Ol, Cb, K, lane), first);
+                    }
+                    PHASE_END(6)
+                }
+                // da2 = relu'(h2) . (W3^T dP), db2
+                for (int K = wv; K < nT; K += TRAIN_WAVES) {
+                    f32x4 a = relu_gate(rows_of(E, K, q, p), Cb, K, q, p);
+                    store_rows(E, K, q, p, a);
+                    bias_put(slab + tv.gb2 + 16 * K + 4 * q, a, lane, first);
+                }
+                PHASE_END(6)
             }
-            PHASE_END(5)
-            // ---- layer 3: da2 = relu'(h2) . W3^T dP -> E ; dW3, db3, db2
-            for (int K = wv; K < nT; K += TRAIN_WAVES) {
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                a = mac_range<TRAIN_PF>(a, tv.f3T + (size_t)K * nOT * 64, P, 0, nOeff, lane);
-                a = relu_gate(a, Cb, K, q, p);
-                store_rows(E, K, q, p, a);
-                bias_put(slab + tv.gb2 + 16 * K + 4 * q, a, lane, first);
-            }
-            for (int O = wv; O < nOeff; O += TRAIN_WAVES)
-                bias_put(slab + tv.gb3 + 16 * O + 4 * q, rows_of(P, O, q, p), lane, first);
-            for (int i = wv; i < nOeff * nT; i += TRAIN_WAVES) {
-                const int O = i / nT, K = i - O * nT;
-                slab_put4(slab + tv.g3 + ((size_t)i * 64 + lane) * 4, outer_tile(P, O, Cb, K, lane), first);
-            }
-            PHASE_END(6)
             // ---- layer 2: da1 = relu'(h1) . (da2 + W2^T da2) -> C ; dW2 (da2 x h1), db1
             for (int Ti = 0; Ti < nT; ++Ti) {
                 if (snake_owner<TRAIN_WAVES>(Ti) != wv) continue;
@@ -464,6 +555,8 @@ __global__ __launch_bounds__(256) void pack2_kernel(const float* __restrict__ fl
 
 // ---------------------------------------------------------------------------
 static size_t train_lds_bytes(const pmc_maf_t& m) {
+    if (m.n_out == RQS_NOUT)
+        return (size_t)(4 * m.Hp * 16 + RQS_NOUT * 256 + 2 * m.Dp * 16 + 16 + 16 * TRAIN_WAVES) * sizeof(float);
     return (size_t)(4 * m.Hp * 16 + 2 * m.Dp * 16 + m.Dp * 16 + 16 + 16 * TRAIN_WAVES) * sizeof(float);
 }
 
@@ -482,21 +575,30 @@ static int launch_lossgrad(const pmc_maf_t* m, const pmc_maf_train_t* tr, const 
     if (lds > 160 * 1024) return pmc_fail("pmc_maf_loss_grad: flow too wide for the 160 KB LDS of one workgroup");
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_lossgrad_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_lossgrad_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipSuccess;
+        const void* ks[4] = {reinterpret_cast<const void*>(maf_lossgrad_kernel<false, 0>),
+                             reinterpret_cast<const void*>(maf_lossgrad_kernel<true, 0>),
+                             reinterpret_cast<const void*>(maf_lossgrad_kernel<false, 1>),
+                             reinterpret_cast<const void*>(maf_lossgrad_kernel<true, 1>)};
+        for (int i = 0; i < 4 && e == hipSuccess; ++i)
+            e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_lossgrad_kernel)");
         lds_set = lds;
     }
     const int64_t nsets = (n + 15) / 16;
     const int n_wg = (int)(nsets < tr->n_slabs ? nsets : tr->n_slabs);
-    if (prof)
-        hipLaunchKernelGGL(maf_lossgrad_kernel<true>, dim3((unsigned)n_wg), dim3(TRAIN_THREADS), lds, st, *m, *tr, x, w,
-                           idx, wmul, n, prof);
+    const bool rqs = (m->n_out == RQS_NOUT);
+    if (prof && rqs)
+        hipLaunchKernelGGL((maf_lossgrad_kernel<true, 1>), dim3((unsigned)n_wg), dim3(TRAIN_THREADS), lds, st, *m, *tr, x,
+                           w, idx, wmul, n, prof);
+    else if (prof)
+        hipLaunchKernelGGL((maf_lossgrad_kernel<true, 0>), dim3((unsigned)n_wg), dim3(TRAIN_THREADS), lds, st, *m, *tr, x,
+                           w, idx, wmul, n, prof);
+    else if (rqs)
+        hipLaunchKernelGGL((maf_lossgrad_kernel<false, 1>), dim3((unsigned)n_wg), dim3(TRAIN_THREADS), lds, st, *m, *tr, x,
+                           w, idx, wmul, n, (long long*)nullptr);
     else
-        hipLaunchKernelGGL(maf_lossgrad_kernel<false>, dim3((unsigned)n_wg), dim3(TRAIN_THREADS), lds, st, *m, *tr, x,
+        hipLaunchKernelGGL((maf_lossgrad_kernel<false, 0>), dim3((unsigned)n_wg), dim3(TRAIN_THREADS), lds, st, *m, *tr, x,
                            w, idx, wmul, n, (long long*)nullptr);
     const int64_t g_total = (int64_t)m->T * tr->gmap_per_transform;
     const int64_t blocks = (g_total / 4 + 255) / 256;
