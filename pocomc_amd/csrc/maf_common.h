@@ -109,6 +109,7 @@ __device__ __forceinline__ void store_rows(float* act, int T, int q, int p, cons
 struct MafView {
     const float4* f0; const float4* f1; const float4* f2; const float4* f3;
     const float* w0n; const float* b0; const float* b1; const float* b2; const float* b3;
+    const float4* f3i; const float* b3i;      // spline flows only: per-rank padded output rows (inverse sweep)
 };
 
 __device__ __forceinline__ MafView maf_view(const pmc_maf_t& m, int t) {
@@ -125,7 +126,9 @@ __device__ __forceinline__ MafView maf_view(const pmc_maf_t& m, int t) {
     v.b0 = p; p += m.Hp;
     v.b1 = p; p += m.Hp;
     v.b2 = p; p += m.Hp;
-    v.b3 = p;
+    v.b3 = p; p += (size_t)m.nOT * 16;
+    v.f3i = reinterpret_cast<const float4*>(p); p += (size_t)m.D * 2 * m.nT * 256;
+    v.b3i = p;
     return v;
 }
 

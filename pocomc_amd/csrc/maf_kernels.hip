@@ -334,10 +334,15 @@ extern "C" int pmc_maf_inverse(const pmc_maf_t* m, const float* z, float* x, flo
     if (n == 0) return 0;
     if (!z || !x || n < 0) return pmc_fail("pmc_maf_inverse: bad argument");
     if (m->n_out != 2) {
-        // spline flows: the D-pass algorithm of the reference (zuko), workgroup-of-waves kernel
-        if (algo != PMC_INVERSE_AUTO && algo != PMC_INVERSE_NAIVE)
-            return pmc_fail("pmc_maf_inverse: the triangular sweeps are built for the affine (MAF) flows");
-        return pmc_launch_inverse_dpass_wg(m, z, x, ladj, n, (hipStream_t)stream);
+        // spline flows: triangular sweep, or the D-pass algorithm of the reference (zuko) as cross-check
+        // and for layouts whose degree groups exceed a tile
+        if (algo == PMC_INVERSE_AUTO) algo = m->tri_ok ? PMC_INVERSE_TRIANGULAR : PMC_INVERSE_NAIVE;
+        if (algo == PMC_INVERSE_TRIANGULAR) {
+            if (!m->tri_ok) return pmc_fail("pmc_maf_inverse: triangular sweep needs degree groups <= one tile");
+            return pmc_launch_inverse_tri_nsf(m, z, x, ladj, n, (hipStream_t)stream);
+        }
+        if (algo == PMC_INVERSE_NAIVE) return pmc_launch_inverse_dpass_wg(m, z, x, ladj, n, (hipStream_t)stream);
+        return pmc_fail("pmc_maf_inverse: spline flows know PMC_INVERSE_TRIANGULAR and PMC_INVERSE_NAIVE");
     }
     if (algo == PMC_INVERSE_AUTO) algo = m->tri_ok ? PMC_INVERSE_TRIANGULAR : PMC_INVERSE_NAIVE;
     if (algo == PMC_INVERSE_TRIANGULAR) {

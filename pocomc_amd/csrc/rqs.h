@@ -27,8 +27,15 @@ struct RqsTables {
     float xk[RQS_K + 1], yk[RQS_K + 1];
 };
 
-__device__ __forceinline__ float rqs_clip2(float v) { return v / (1.0f + fabsf(2.0f * v / PMC_LOG_SLOPE)); }
-__device__ __forceinline__ float rqs_clip1(float v) { return v / (1.0f + fabsf(v / PMC_LOG_SLOPE)); }
+// Hardware transcendentals (v_rcp_f32 / v_exp_f32 / v_log_f32, ~1 ulp): a lone wave per SIMD pays four
+// cycles per VALU instruction, and the IEEE-exact division / expf sequences of ~60 divisions and 18
+// exponentials per spline were the bulk of the inverse sweep's time.
+#define RQS_INV_LS (1.0f / PMC_LOG_SLOPE)
+__device__ __forceinline__ float rqs_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+__device__ __forceinline__ float rqs_exp(float v) { return __builtin_amdgcn_exp2f(v * 1.4426950408889634f); }
+__device__ __forceinline__ float rqs_log(float v) { return __builtin_amdgcn_logf(v) * 0.6931471805599453f; }
+__device__ __forceinline__ float rqs_clip2(float v) { return v * rqs_rcp(1.0f + fabsf(v * (2.0f * RQS_INV_LS))); }
+__device__ __forceinline__ float rqs_clip1(float v) { return v * rqs_rcp(1.0f + fabsf(v * RQS_INV_LS)); }
 
 __device__ __forceinline__ void rqs_softmax_knots(const float* v, float* p, float* knots) {
     float c[RQS_K];
@@ -37,12 +44,13 @@ __device__ __forceinline__ void rqs_softmax_knots(const float* v, float* p, floa
     for (int j = 0; j < RQS_K; ++j) { c[j] = rqs_clip2(v[j]); mx = fmaxf(mx, c[j]); }
     float sum = 0.0f;
 #pragma unroll
-    for (int j = 0; j < RQS_K; ++j) { c[j] = expf(c[j] - mx); sum += c[j]; }
+    for (int j = 0; j < RQS_K; ++j) { c[j] = rqs_exp(c[j] - mx); sum += c[j]; }
+    const float rsum = rqs_rcp(sum);
     float cum = 0.0f;
     knots[0] = -RQS_BOUND;
 #pragma unroll
     for (int j = 0; j < RQS_K; ++j) {
-        p[j] = c[j] / sum;
+        p[j] = c[j] * rsum;
         cum += p[j];
         knots[j + 1] = RQS_BOUND * (2.0f * cum - 1.0f);
     }
@@ -69,8 +77,8 @@ __device__ __forceinline__ void rqs_select(const RqsTables& t, const float* phi,
             r1 = (j + 1 < RQS_K) ? rqs_clip1(phi[2 * RQS_K + j]) : 0.0f;
         }
     }
-    b.d0 = expf(r0);
-    b.d1 = expf(r1);
+    b.d0 = rqs_exp(r0);
+    b.d1 = rqs_exp(r1);
 }
 
 // y = f(x), ladj = log f'(x)
@@ -80,14 +88,15 @@ __device__ __forceinline__ void rqs_forward(const float* phi, float x, float& y,
     RqsBin b;
     rqs_select(t, phi, t.xk, x, b);
     const float dx = b.x1 - b.x0, dy = b.y1 - b.y0;
-    const float s = dy / dx;
-    const float z = b.inside ? (x - b.x0) / dx : 0.0f;
+    const float rdx = rqs_rcp(dx);
+    const float s = dy * rdx;
+    const float z = b.inside ? (x - b.x0) * rdx : 0.0f;
     const float u = z * (1.0f - z);
-    const float den = s + (b.d0 + b.d1 - 2.0f * s) * u;
-    const float yy = b.y0 + dy * (s * z * z + b.d0 * u) / den;
-    const float jac = s * s * (2.0f * s * u + b.d0 * (1.0f - z) * (1.0f - z) + b.d1 * z * z) / (den * den);
+    const float rden = rqs_rcp(s + (b.d0 + b.d1 - 2.0f * s) * u);
+    const float yy = b.y0 + dy * (s * z * z + b.d0 * u) * rden;
+    const float jac = s * s * (2.0f * s * u + b.d0 * (1.0f - z) * (1.0f - z) + b.d1 * z * z) * (rden * rden);
     y = b.inside ? yy : x;
-    ladj = b.inside ? logf(jac) : 0.0f;
+    ladj = b.inside ? rqs_log(jac) : 0.0f;
 }
 
 // x = f^-1(y), ladj = log f'(x)  (the forward log-derivative at the solution)
@@ -97,18 +106,18 @@ __device__ __forceinline__ void rqs_inverse(const float* phi, float y, float& x,
     RqsBin b;
     rqs_select(t, phi, t.yk, y, b);
     const float dx = b.x1 - b.x0, dy = b.y1 - b.y0;
-    const float s = dy / dx;
+    const float s = dy * rqs_rcp(dx);
     const float yr = b.inside ? y - b.y0 : 0.0f;
     const float e = b.d0 + b.d1 - 2.0f * s;
     const float qa = dy * (s - b.d0) + yr * e;
     const float qb = dy * b.d0 - yr * e;
     const float qc = -s * yr;
-    const float z = 2.0f * qc / (-qb - sqrtf(qb * qb - 4.0f * qa * qc));
+    const float z = 2.0f * qc * rqs_rcp(-qb - __builtin_amdgcn_sqrtf(qb * qb - 4.0f * qa * qc));
     const float u = z * (1.0f - z);
-    const float den = s + e * u;
-    const float jac = s * s * (2.0f * s * u + b.d0 * (1.0f - z) * (1.0f - z) + b.d1 * z * z) / (den * den);
+    const float rden = rqs_rcp(s + e * u);
+    const float jac = s * s * (2.0f * s * u + b.d0 * (1.0f - z) * (1.0f - z) + b.d1 * z * z) * (rden * rden);
     x = b.inside ? b.x0 + z * dx : y;
-    ladj = b.inside ? logf(jac) : 0.0f;
+    ladj = b.inside ? rqs_log(jac) : 0.0f;
 }
 
 // Reverse mode of F = gy * y + gl * ladj:  dphi[23] and gx = dF/dx.
@@ -122,28 +131,29 @@ __device__ __forceinline__ void rqs_backward(const float* phi, float x, float gy
     gx = gy;
     if (!b.inside) return;
     const float dx = b.x1 - b.x0, dy = b.y1 - b.y0;
-    const float s = dy / dx;
-    const float z = (x - b.x0) / dx;
+    const float rdx = rqs_rcp(dx);
+    const float s = dy * rdx;
+    const float z = (x - b.x0) * rdx;
     const float u = z * (1.0f - z);
     const float e = b.d0 + b.d1 - 2.0f * s;
     const float num = s * z * z + b.d0 * u;
-    const float den = s + e * u;
+    const float rden = rqs_rcp(s + e * u);
     const float jn = 2.0f * s * u + b.d0 * (1.0f - z) * (1.0f - z) + b.d1 * z * z;
     // adjoints of the spline formula
-    const float g_num = gy * dy / den;
-    const float g_den = -gy * dy * num / (den * den) - 2.0f * gl / den;
-    const float g_jn = gl / jn;
-    float g_dy = gy * num / den;
-    const float g_s = g_num * z * z + g_den * (1.0f - 2.0f * u) + 2.0f * gl / s + g_jn * 2.0f * u;
+    const float g_num = gy * dy * rden;
+    const float g_den = -gy * dy * num * (rden * rden) - 2.0f * gl * rden;
+    const float g_jn = gl * rqs_rcp(jn);
+    float g_dy = gy * num * rden;
+    const float g_s = g_num * z * z + g_den * (1.0f - 2.0f * u) + 2.0f * gl * rqs_rcp(s) + g_jn * 2.0f * u;
     const float g_d0 = (g_num + g_den) * u + g_jn * (1.0f - z) * (1.0f - z);
     const float g_d1 = g_den * u + g_jn * z * z;
     const float g_u = g_num * b.d0 + g_den * e + g_jn * 2.0f * s;
     const float g_z = g_num * 2.0f * s * z + g_u * (1.0f - 2.0f * z) + g_jn * (-2.0f * b.d0 * (1.0f - z) + 2.0f * b.d1 * z);
     // s = dy / dx,  z = (x - x0) / dx
-    g_dy += g_s / dx;
-    const float g_dx = -g_s * s / dx - g_z * z / dx;
-    gx = g_z / dx;
-    const float g_x0 = -g_z / dx - g_dx, g_x1 = g_dx;
+    g_dy += g_s * rdx;
+    const float g_dx = -(g_s * s + g_z * z) * rdx;
+    gx = g_z * rdx;
+    const float g_x0 = -g_z * rdx - g_dx, g_x1 = g_dx;
     const float g_y0 = gy - g_dy, g_y1 = g_dy;
     // knots -> softmax probabilities: knot_j = B (2 sum_{i<j} p_i - 1)
     //   dF/dp_i = 2B (g_k0 [i < k] + g_k1 [i < k+1])
@@ -160,19 +170,19 @@ __device__ __forceinline__ void rqs_backward(const float* phi, float x, float gy
 #pragma unroll
     for (int i = 0; i < RQS_K; ++i) {
         // softmax backward, then the soft clip v / (1 + |2v/ls|) whose derivative is 1 / (1 + |2v/ls|)^2
-        const float cw = 1.0f + fabsf(2.0f * phi[i] / PMC_LOG_SLOPE);
-        const float ch = 1.0f + fabsf(2.0f * phi[RQS_K + i] / PMC_LOG_SLOPE);
-        dphi[i] = t.pw[i] * (gpw[i] - dotw) / (cw * cw);
-        dphi[RQS_K + i] = t.ph[i] * (gph[i] - doth) / (ch * ch);
+        const float cw = rqs_rcp(1.0f + fabsf(phi[i] * (2.0f * RQS_INV_LS)));
+        const float ch = rqs_rcp(1.0f + fabsf(phi[RQS_K + i] * (2.0f * RQS_INV_LS)));
+        dphi[i] = t.pw[i] * (gpw[i] - dotw) * (cw * cw);
+        dphi[RQS_K + i] = t.ph[i] * (gph[i] - doth) * (ch * ch);
     }
     // derivatives: d = exp(clip1(v)); knot k uses phi[16 + k - 1] (k >= 1), knot k+1 uses phi[16 + k] (k + 1 <= 7)
 #pragma unroll
     for (int j = 0; j < RQS_K - 1; ++j) {
-        const float c = 1.0f + fabsf(phi[2 * RQS_K + j] / PMC_LOG_SLOPE);
+        const float c = rqs_rcp(1.0f + fabsf(phi[2 * RQS_K + j] * RQS_INV_LS));
         float g = 0.0f;
         if (j == b.k - 1) g = g_d0 * b.d0;
         if (j == b.k) g = g_d1 * b.d1;
-        dphi[2 * RQS_K + j] = g / (c * c);
+        dphi[2 * RQS_K + j] = g * (c * c);
     }
 }
 

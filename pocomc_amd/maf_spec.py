@@ -219,6 +219,11 @@ class MAFSpec:
         parts = [("f0", self.sz_f0), ("f1", self.sz_f12), ("f2", self.sz_f12),
                  ("f3", self.sz_f3), ("w0n", self.sz_w0n), ("b0", self.sz_b),
                  ("b1", self.sz_b), ("b2", self.sz_b), ("b3", self.sz_b3)]
+        if self.univariate == "rqs":
+            # inverse sweep: the 23 output rows of every rank padded to two 16-row tiles of their own
+            self.sz_f3i = D * 2 * nT * 256       # [rank][half][ktile][lane][4]
+            self.sz_b3i = D * 32                 # [rank][32]
+            parts += [("f3i", self.sz_f3i), ("b3i", self.sz_b3i)]
         off = 0
         self.pk_offsets = {}
         for name, sz in parts:
@@ -309,6 +314,21 @@ class MAFSpec:
             put("f0", f0); put("f1", f12["W1"]); put("f2", f12["W2"]); put("f3", f3)
             put("w0n", w0n); put("b0", bidx("b0")); put("b1", bidx("b1")); put("b2", bidx("b2"))
             put("b3", b3)
+            if self.univariate == "rqs":
+                NO = self.n_out
+                f3i = np.full((D, 2, nT, 64, 4), -1, dtype=np.int64)
+                b3i = np.full((D, 32), -1, dtype=np.int64)
+                for r in range(D):
+                    feat = feat_of_rank[r]
+                    for half in range(2):
+                        j = 16 * half + li                           # output j of this rank held by row li
+                        crow = np.where(j < NO, NO * feat + np.minimum(j, NO - 1), -1)
+                        for K in range(nT):
+                            for c in range(4):
+                                in_unit = su[16 * K + 4 * c + lk]
+                                f3i[r, half, K, :, c] = cidx("W3", crow, in_unit, H, M3)
+                    b3i[r, :NO] = base_c + off3 + NO * feat + np.arange(NO)
+                put("f3i", f3i); put("b3i", b3i)
         return idx.astype(np.int32)
 
     def device_meta(self) -> np.ndarray:

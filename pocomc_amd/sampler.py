@@ -62,12 +62,11 @@ class _Progress:
 class Sampler:
     def __init__(self, prior, likelihood, n_dim=None, n_effective=512, n_active=256, likelihood_args=None,
                  likelihood_kwargs=None, vectorize=False, blobs_dtype=None, periodic=None, reflective=None,
-                 transform="probit", pool=None, pytorch_threads=1, flow="maf6", train_config=None,
+                 transform="probit", pool=None, pytorch_threads=1, flow="nsf6", train_config=None,
                  train_frequency=None, precondition=True, dynamic=True, metric="ess", n_prior=None,
                  sample="tpcn", n_steps=None, n_max_steps=None, resample="mult", output_dir=None,
                  output_label=None, random_state=None, n_ess=None):
-        # sampler.py:186-373.  The reference's default flow is the spline flow 'nsf6'
-        # (sampler.py:169); until the NSF kernels exist the default here is its MAF sibling.
+        # sampler.py:186-373; default flow 'nsf6' like the reference (sampler.py:169)
         if n_ess is not None:
             import warnings
             n_effective = n_ess

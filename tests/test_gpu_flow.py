@@ -170,6 +170,12 @@ def test_nsf_inverse_matches_oracle(D, T, n):
     f, o = make_nsf(D, T)
     z = (np.random.default_rng(7 + n).normal(size=(n, D)) * 1.5).astype(np.float32)
     xo, lo = o.inverse(z)                       # the reference's D-pass algorithm
+    for algo in ([1, 2] if f.spec.tri_ok else [2]):     # triangular sweep, D-pass on the device
+        f.inverse_algo = algo
+        x, l = f.inverse(torch.from_numpy(z))
+        close(x.numpy(), xo, 5e-5)
+        close(l.numpy(), lo, 5e-5)
+    f.inverse_algo = 0
     x, l = f.inverse(torch.from_numpy(z))
     close(x.numpy(), xo, 5e-5)
     close(l.numpy(), lo, 5e-5)
