@@ -110,6 +110,7 @@ def main():
                          "uniform factors, not a black box)")
     ap.add_argument("--x-order", choices=["C", "F"], default="F",
                     help="memory order of the (n, D) array handed to the host prior/likelihood")
+    ap.add_argument("--flow", default="maf3", help="maf3 | maf6 | maf12 | nsf3 | nsf6 | nsf12 (BASELINE configs use maf3)")
     ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "triangular_v1", "triangular_v2", "triangular_v3"], default="auto")
     args = ap.parse_args()
 
@@ -147,16 +148,21 @@ def main():
     u = scaler.forward(x)
     logdetj = scaler.inverse(u)[1]
     logl, logp = rosenbrock(x), prior.logpdf(x)
-    flow = Flow(D, "maf3", seed=0)                          # replicated weights
+    flow = Flow(D, args.flow, seed=0)                       # replicated weights
     flow.inverse_algo = {"auto": 0, "triangular": 1, "naive": 2, "triangular_v1": 3, "triangular_v2": 4, "triangular_v3": 5}[args.inverse]
-    flow_trained = False
     torch.manual_seed(0)                                    # same shuffles / batches on every rank
-    try:
-        flow.fit(torch.from_numpy(scaler.forward(x_fit[:n])).float(), epochs=50, batch_size=512,
-                 validation_split=0.5, patience=D, annealing=False, verbose=0)
-        flow_trained = True
-    except NotImplementedError:
-        pass
+    u_fit = torch.from_numpy(scaler.forward(x_fit[:n])).float().cuda()
+    torch.cuda.synchronize()
+    tf0 = time.perf_counter()
+    hist = flow.fit(u_fit, epochs=50, batch_size=512, validation_split=0.5, patience=D, annealing=False, verbose=0)
+    torch.cuda.synchronize()
+    fit_s = time.perf_counter() - tf0
+    flow_trained = True
+    n_ep = len(hist["loss"])
+    # Sampler-style fit (sampler.py:655-669): half the rows train, half validate, every epoch
+    flow_fit = {"epochs": n_ep, "rows": n, "batch_size": 512, "validation_split": 0.5,
+                "ms_per_epoch": fit_s / n_ep * 1e3, "rows_per_s": n * n_ep / fit_s,
+                "note": "untimed setup of the step benchmark, reported as the flow-training sub-metric"}
     if world > 1:                                           # replicated weights: bit-identical on every rank
         dist.broadcast(flow.params, 0)
         flow.repack()
@@ -269,13 +275,14 @@ def main():
     traffic = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if n == 10000 and D == 32 and args.inverse == "auto":
+        if n == 10000 and D == 32 and args.inverse == "auto" and args.flow == "maf3":
             traffic = {"hbm_bytes_per_launch": pm["hbm_bytes_per_launch"], "unit": "B", "source": pm["source"],
                        "correction": pm["correction"]}
     except (OSError, KeyError, ValueError):
         pass
     achieved = algo_flops / t_inv / 1e12
     roofline = {"bound": "mfma", "kernel": ("maf_dense_kernel<1>" if (args.inverse == "naive" or not spec.tri_ok) else
+                           "maf_inverse_tri_nsf_kernel" if spec.univariate == "rqs" else
                            {"triangular_v1": "maf_inverse_tri_kernel", "triangular_v2": "maf_inverse_tri2_kernel",
                             "triangular_v3": "maf_inverse_tri3_kernel"}.get(
                                args.inverse, "maf_inverse_tri4_kernel" if spec.nOT <= 8 else "maf_inverse_tri2_kernel")), "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -291,12 +298,15 @@ def main():
            "unit": "steps/s per 1e4 walkers", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32 flow (MFMA) + f64 step", "data": "synthetic",
-           "config": {"workload": f"{D}-D Rosenbrock, U(-10,10)^{D} prior, {n} walkers/GPU x {world} GPU, maf3 "
+           "config": {"workload": f"{D}-D Rosenbrock, U(-10,10)^{D} prior, {n} walkers/GPU x {world} GPU, {args.flow} "
                                   f"(H={spec.hidden}), beta={beta}, tpCN kernel, host numpy likelihood in the loop",
-                      "walkers_per_gpu": n, "global_walkers": n * world, "n_dim": D, "flow": "maf3",
+                      "walkers_per_gpu": n, "global_walkers": n * world, "n_dim": D, "flow": args.flow,
                       "flow_trained_50_epochs": flow_trained, "parallelism": f"walker-sharded x{world}",
                       "inverse_algo": args.inverse, "host_threads": args.host_threads, "host_x_order": args.x_order, "prior_on_device": bool(device_prior), "accept_rate": float(ad.mean_alpha)},
            "roofline": roofline,
+           "flow_fit": flow_fit,
+           "device_only_steps_per_s": 1e6 / (us["propose"] + us["maf_inverse"] + us["scaler_inverse"]
+                                             + us["accept_reduce"]),
            "breakdown_us_per_step": dict(us, host_prior_likelihood=t_host[0] / n_inst * 1e6,
                                          device_kernels=us["propose"] + us["maf_inverse"] + us["scaler_inverse"]
                                          + us["accept_reduce"], wall=ms_per_step * 1e3,

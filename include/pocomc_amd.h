@@ -85,6 +85,8 @@ typedef struct pmc_maf_train {
     float* xt_scratch;        /* [n_slabs][T + 1][Dp * 16] */
     float* loss_partial;      /* [n_slabs] */
     float* sq_partial;        /* [n_sq_partial] per-block sums of squared gradient entries */
+    const float* wsum;        /* NULL: c_n uses the sum of THIS call's weights; else f32 [1] (device) with the sum of
+                               * the whole batch's weights, e.g. all-reduced over the ranks of a sharded batch */
 } pmc_maf_train_t;
 
 /* One minibatch of Flow.fit, pocomc/flow.py:297-323: loss and parameter gradient.

@@ -142,7 +142,9 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
 
     // sum of the batch weights, the same fixed-order sum in every workgroup (flow.py:311)
     float wscale = 1.0f;
-    if (w) {
+    if (w && tr.wsum) {
+        wscale = wmul / *tr.wsum;
+    } else if (w) {
         float s = 0.0f;
         for (int64_t i = tid; i < n; i += TRAIN_THREADS) s += w[idx ? idx[i] : i];
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);

@@ -464,9 +464,10 @@ class MAFSpec:
 
     # ------------------------------------------------------------ accounting
     def flops_forward_dense(self) -> int:
-        """``F_fwd = T*2*(3*D*H + 2*H*H)`` per particle."""
+        """SURVEY.md section 8(d): ``F_fwd = T*2*(3*D*H + 2*H*H)`` per particle for the affine flows;
+        in general the output layer has ``n_out*D`` rows: ``T*2*((1 + n_out)*D*H + 2*H*H)``."""
         D, H = self.n_dim, self.hidden
-        return self.n_transforms * 2 * (3 * D * H + 2 * H * H)
+        return self.n_transforms * 2 * ((1 + self.n_out) * D * H + 2 * H * H)
 
     def flops_inverse_naive(self) -> int:
         """``F_inv = (D+1) * F_fwd`` per particle."""

@@ -43,7 +43,11 @@ class TrainState:
         self.n_slabs = 0
         self.xt_floats = (spec.n_transforms + 1) * spec.Dp * 16
         n = spec.n_params
-        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)      # masked entries stay 0 for ever
+        # masked entries stay 0 for ever; one extra element carries the batch loss through the
+        # gradient all-reduce of sharded training
+        self.grad_ext = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self.grad = self.grad_ext[:n]
+        self.wsum = torch.zeros(1, dtype=torch.float32, device=dev)
         self.scal = torch.zeros(4, dtype=torch.float32, device=dev)      # [loss, spare...]
 
     def ensure_slabs(self, n_rows):
@@ -89,8 +93,9 @@ def loss_and_grad(flow, xb, wb=None, idx=None):
     return ts.scal[0]
 
 
-def batch_loss(flow, xb, wb=None):
-    """Loss of one batch without gradient (validation, ``flow.py:327-346``)."""
+def batch_loss(flow, xb, wb=None, group=None, sharded=False):
+    """Loss of one batch without gradient (validation, ``flow.py:327-346``).  ``sharded``: ``xb`` is
+    this rank's part of the batch, the weight normalisation uses the all-reduced weight sum."""
     ts = _train_state(flow)
     lib = flow.lib
     st = _lib.stream_handle()
@@ -103,6 +108,9 @@ def batch_loss(flow, xb, wb=None):
                    "pmc_maf_forward")
         if wb is not None:
             _lib.check(lib.pmc_sum_f32(_lib.ptr(wb), C.c_void_p(ts.scal.data_ptr() + 4), n, st), "pmc_sum_f32")
+            if sharded:
+                import torch.distributed as dist
+                dist.all_reduce(ts.scal[1:2], group=group)
         _lib.check(lib.pmc_neg_weighted_sum(_lib.ptr(lp), _lib.ptr(wb) if wb is not None else None,
                                             C.c_void_p(ts.scal.data_ptr() + 4) if wb is not None else None,
                                             1000.0, _lib.ptr(ts.scal), n, st), "pmc_neg_weighted_sum")
@@ -175,6 +183,50 @@ class ReduceLROnPlateau:
             self.bad = 0
 
 
+def _dist_world(group):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group)
+    return 1
+
+
+def sharded_epoch(flow, opt, x, w, perm, batch_size, max_norm, loss_acc, group):
+    """One epoch of data-parallel training: every rank holds a shard of the
+    training rows; a global batch of ``batch_size`` rows is ``batch_size / world`` local rows per rank.
+    Per batch: [all-reduce of the weight sum] -> local loss/gradient -> ONE all-reduce of
+    (gradient, loss) -> the same clip + AdamW step on every rank (the clip needs the norm of the
+    reduced gradient, flow.py:318)."""
+    import torch.distributed as dist
+    ts = _train_state(flow)
+    world = dist.get_world_size(group)
+    lb = max(1, int(batch_size) // world)
+    n = x.shape[0]
+    ts.ensure_slabs(lb)
+    st = _lib.stream_handle()
+    for b0 in range(0, n, lb):
+        nb = min(lb, n - b0)
+        idx = perm[b0:b0 + nb] if perm is not None else None
+        xb = x if idx is not None else x[b0:b0 + nb]
+        wb = None if w is None else (w if idx is not None else w[b0:b0 + nb])
+        with torch.cuda.device(flow.device):
+            if w is not None:
+                ts.wsum.zero_()
+                wsel = w[idx] if idx is not None else wb
+                _lib.check(flow.lib.pmc_sum_f32(_lib.ptr(wsel), _lib.ptr(ts.wsum), nb, st), "pmc_sum_f32")
+                dist.all_reduce(ts.wsum, group=group)
+                ts.desc.wsum = ts.wsum.data_ptr()
+            ts.grad_ext[-1:].zero_()
+            _lib.check(flow.lib.pmc_maf_loss_grad(C.byref(flow._desc), C.byref(ts.desc), _lib.ptr(xb),
+                                                  _lib.ptr(wb) if wb is not None else None,
+                                                  _lib.ptr(idx) if idx is not None else None, 1000.0,
+                                                  _lib.ptr(ts.grad), C.c_void_p(ts.grad_ext.data_ptr() + 4 * ts.grad.numel()),
+                                                  nb, st), "pmc_maf_loss_grad")
+            ts.desc.wsum = None
+        dist.all_reduce(ts.grad_ext, group=group)
+        loss_acc += ts.grad_ext[-1:]
+        opt.step(max_norm)
+
+
 def _batches(n, batch_size, shuffle):
     """``DataLoader(TensorDataset(...), batch_size, shuffle)``: a fresh permutation per epoch,
     last partial batch kept."""
@@ -184,7 +236,11 @@ def _batches(n, batch_size, shuffle):
 
 def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_size=1000, patience=20,
              learning_rate=1e-3, weight_decay=0, laplace_scale=None, gaussian_scale=None, annealing=True,
-             noise=None, shuffle=True, clip_grad_norm=1.0, verbose=0):
+             noise=None, shuffle=True, clip_grad_norm=1.0, verbose=0, group=None, sharded=None):
+    """``sharded`` (default: a ``torch.distributed`` group with more than one rank exists): ``x`` /
+    ``weights`` are THIS rank's shard of the training rows (equal shard sizes), ``batch_size`` is the
+    global batch; gradients and losses are all-reduced (RCCL on the GPUs) so that every rank takes
+    the same optimizer steps and the same early-stopping decisions."""
     from .flow import torch_double_to_float
     if laplace_scale is not None or gaussian_scale is not None:
         raise NotImplementedError("weight regularisation (flow.py:387-421) is not built; the Sampler leaves it off")
@@ -214,6 +270,11 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
         x_train, w_train, x_valid, w_valid = x, w, None, None
         validation = False
 
+    world = _dist_world(group)
+    if sharded is None:
+        sharded = world > 1
+    if sharded:
+        import torch.distributed as dist
     opt = AdamW(flow, learning_rate, weight_decay)
     sched = ReduceLROnPlateau(opt, patience) if annealing else None
     _train_state(flow).repack(flow)
@@ -230,18 +291,28 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
         acc2.zero_()
         acc = acc2[0:1]
         perm = torch.randperm(n_train).to(dev) if shuffle else None  # DataLoader(shuffle=...), flow.py:251-265
-        opt.epoch(x_train, w_train, perm, batch_size, clip_grad_norm, acc)
+        if sharded:
+            sharded_epoch(flow, opt, x_train, w_train, perm, batch_size, clip_grad_norm, acc, group)
+        else:
+            opt.epoch(x_train, w_train, perm, batch_size, clip_grad_norm, acc)
         vacc = acc2[1:2]
         if validation:
-            for idx in _batches(x_valid.shape[0], batch_size, shuffle):
+            vb = max(1, batch_size // world) if sharded else batch_size
+            for idx in _batches(x_valid.shape[0], vb, shuffle):
                 idx = idx.to(dev)
                 vacc += batch_loss(flow, x_valid[idx].contiguous(),
-                                   None if w_valid is None else w_valid[idx].contiguous())
+                                   None if w_valid is None else w_valid[idx].contiguous(), group, sharded)
+        n_tr, n_va = n_train, (x_valid.shape[0] if validation else 0)
+        if sharded:
+            # the validation loss is a sum over the ranks' shards (the training loss already is: it rode
+            # along with the gradients); the row counts are global
+            dist.all_reduce(acc2[1:2], group=group)
+            n_tr, n_va = n_tr * world, n_va * world
         both = acc2.cpu().numpy()                                      # the one sync of the epoch
-        train_loss = float(both[0]) / max(n_train, 1)                # flow.py:323
+        train_loss = float(both[0]) / max(n_tr, 1)                   # flow.py:323
         history["loss"].append(train_loss)
         if validation:
-            val_loss = float(both[1]) / max(x_valid.shape[0], 1)     # flow.py:348
+            val_loss = float(both[1]) / max(n_va, 1)                 # flow.py:348
             history["val_loss"].append(val_loss)
         if sched is not None:
             sched.step(val_loss if validation else train_loss)
