@@ -34,6 +34,37 @@ def logw_stats(logw_d, k=0):
     return stats.cpu().numpy()
 
 
+def combine_logw_stats(per_shard):
+    """Merge the ``[max, sum exp(logw-max), sum exp(2(logw-max))]`` triples of several shards into the
+    triple of their union (rescaling every shard to the global maximum)."""
+    per_shard = np.asarray(per_shard, dtype=np.float64).reshape(-1, per_shard[0].shape[-1] if hasattr(per_shard[0], "shape") else len(per_shard[0]))
+    m = per_shard[:, 0]
+    M = m.max()
+    sc = np.exp(m - M)
+    return np.array([M, np.sum(per_shard[:, 1] * sc), np.sum(per_shard[:, 2] * sc * sc)])
+
+
+def allgather_logw_stats(local_stats, group=None):
+    """Global ESS / logZ statistics of a walker-sharded pool (the reduction
+    behind the temperature ladder, sampler.py:739-777): all-gather three doubles per rank, merge.
+    Without a process group the local triple is returned."""
+    import torch.distributed as dist
+    local = np.asarray(local_stats, dtype=np.float64)[:3]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local.copy()
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    mine = torch.tensor(local, dtype=torch.float64, device=dev)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, mine, group=group)
+    return combine_logw_stats([p.cpu().numpy() for p in parts])
+
+
+def ess_from_stats(st):
+    """``effective_sample_size`` of normalised weights (tools.py:56-71): ``1 / sum w~^2``."""
+    return float(st[1] * st[1] / st[2])
+
+
 def compute_logw_and_logz(logl, beta, logz, beta_final=1.0, normalize=True):
     """``pocomc/particles.py:215-231`` on plain arrays (``logl`` is ``(T, N)``)."""
     lib = _lib.load()
