@@ -110,6 +110,9 @@ def main():
                          "uniform factors, not a black box)")
     ap.add_argument("--x-order", choices=["C", "F"], default="F",
                     help="memory order of the (n, D) array handed to the host prior/likelihood")
+    ap.add_argument("--no-pin", action="store_true",
+                    help="do not pin the driver thread to the core it starts on (the host likelihood is single-threaded "
+                         "numpy; migrations between cores cost ~8 %% and most of the run-to-run noise)")
     ap.add_argument("--flow", default="maf3", help="maf3 | maf6 | maf12 | nsf3 | nsf6 | nsf12 (BASELINE configs use maf3)")
     ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "triangular_v1", "triangular_v2", "triangular_v3"], default="auto")
     args = ap.parse_args()
@@ -223,6 +226,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # pin the driver thread for the step loops only (threads created during the setup above, e.g. the BLAS
+    # pool the CPU baseline uses later, keep the full affinity mask)
+    affinity0 = os.sched_getaffinity(0)
+    pinned_core = None
+    if not args.no_pin:
+        try:
+            import ctypes
+            pinned_core = ctypes.CDLL("libc.so.6").sched_getcpu()
+            # prefer a core of the NUMA node the GPU hangs off (its PCI device's local_cpulist)
+            try:
+                pr = torch.cuda.get_device_properties(local)
+                bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+                cl = open(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read().strip()
+                first = cl.split(",")[0]
+                lo = int(first.split("-")[0]); hi = int(first.split("-")[-1])
+                cand = [c for c in range(lo, hi + 1) if c in affinity0]
+                if cand:
+                    pinned_core = cand[(4 + 2 * local) % len(cand)]
+            except (OSError, ValueError, AttributeError):
+                pass
+            if pinned_core in affinity0:
+                os.sched_setaffinity(0, {pinned_core})
+            else:
+                pinned_core = None
+        except (OSError, AttributeError):
+            pinned_core = None
     for _ in range(args.warmup):
         step()
     # ---- timed region: K steps through the composite entry points; the only instrumentation is one
@@ -255,6 +284,8 @@ def main():
         step()
     torch.cuda.synchronize()
     dt_inst = time.perf_counter() - ti0
+    if pinned_core is not None:
+        os.sched_setaffinity(0, affinity0)
     if world > 1:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -314,6 +345,7 @@ def main():
            "timed_region_host_us_per_step": seg_timed,
            "host_us_per_step": {**{k: v / n_inst * 1e6 for k, v in eng.host_timers.items()},
                                 **{k: v / n_inst * 1e6 for k, v in t_seg.items()}}}
+    out["config"]["driver_pinned_to_core"] = pinned_core
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(D, n, beta, flow.params.cpu().numpy(), spec, x, u, geo, sigma0, seed=0)
     elif rank == 0:

@@ -184,6 +184,14 @@ typedef struct pmc_prior {
 int pmc_prior_logpdf(const pmc_prior_t* pr, const double* x, const int32_t* finite, double* logp, int64_t n,
                      void* stream);
 
+/* pmc_scaler_inverse and pmc_prior_logpdf in ONE launch (the step's pre-phase is a chain of small
+ * latency-bound kernels; each launch costs ~15-20 us end to end): additionally
+ * logp f64 [n] <- Prior.logpdf(x') on the finite rows, -inf elsewhere (mcmc.py:105-107).
+ * prior == NULL and logp == NULL: exactly pmc_scaler_inverse. */
+int pmc_scaler_inverse_prior(const pmc_scaler_t* s, const pmc_prior_t* prior, const float* u_in,
+                             const double* u_in64, double* u_out, double* x, double* x_colmajor,
+                             double* logdetj, int32_t* finite, double* logp, int64_t n, void* stream);
+
 /* ------------------------------------------------------------ MCMC step */
 
 #define PMC_KIND_TPCN 0   /* t-preconditioned Crank-Nicolson proposal (mcmc.py:77-85, :394-402) */

@@ -96,6 +96,8 @@ SIGNATURES = {
     "pmc_scaler_inverse": (C.c_int, [P(pmc_scaler_t), c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
     "pmc_scaler_forward": (C.c_int, [P(pmc_scaler_t), c_p, c_p, i64, c_p]),
     "pmc_prior_logpdf": (C.c_int, [P(pmc_prior_t), c_p, c_p, c_p, i64, c_p]),
+    "pmc_scaler_inverse_prior": (C.c_int, [P(pmc_scaler_t), P(pmc_prior_t), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                           i64, c_p]),
     "pmc_propose": (C.c_int, [C.c_int, c_p, c_p, c_p, c_p, c_p, f64, f64, f64, P(pmc_rng_t),
                               c_p, c_p, c_p, c_p, i64, i32, c_p]),
     "pmc_accept_workspace_bytes": (i64, [i64, i32]),

@@ -211,15 +211,29 @@ __device__ __forceinline__ double apply_bc(const pmc_scaler_t& s, int j, double 
     return x;
 }
 
+// one factor of Prior.logpdf (pocomc/prior.py:70-100), shared by prior_logpdf_kernel and the fused scaler kernel
+__device__ __forceinline__ double prior_term(const pmc_prior_t& pr, int j, double xv) {
+    const double loc = pr.loc[j], sc = pr.scale[j];
+    if (pr.family[j] == PMC_PRIOR_UNIFORM) {
+        // scipy uniform(loc, scale).logpdf: -log(scale) on [loc, loc+scale], -inf outside
+        return (xv >= loc && xv <= loc + sc) ? -log(sc) : -INFINITY;
+    }
+    // scipy norm(loc, scale).logpdf: _norm_logpdf((x-loc)/scale) - log(scale)
+    const double z = (xv - loc) / sc;
+    return (-(z * z) / 2.0 - LOG_SQRT_2PI) - log(sc);
+}
+
 __global__ __launch_bounds__(256) void scaler_inverse_kernel(
     pmc_scaler_t s, const float* __restrict__ u_in, const double* __restrict__ u_in64,
     double* __restrict__ u_out, double* __restrict__ x_out, double* __restrict__ x_colmajor,
-    double* __restrict__ ldj_out, int32_t* __restrict__ finite_out, int64_t n) {
+    double* __restrict__ ldj_out, int32_t* __restrict__ finite_out, int64_t n, pmc_prior_t pr,
+    double* __restrict__ logp_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int D = s.D;
+    const bool keep_x = x_colmajor || logp_out;   // x' stays in LDS for the column-major copy / the fused prior
     double* Jt = sm;                              // [SCL_ROWS][D]
-    double* Xt = sm + (size_t)SCL_ROWS * D;       // [D][SCL_ROWS+1]  (only when x_colmajor)
-    int* rowfin = reinterpret_cast<int*>(sm + (size_t)SCL_ROWS * D + (x_colmajor ? (size_t)D * (SCL_ROWS + 1) : 0));
+    double* Xt = sm + (size_t)SCL_ROWS * D;       // [D][SCL_ROWS+1]  (only when keep_x)
+    int* rowfin = reinterpret_cast<int*>(sm + (size_t)SCL_ROWS * D + (keep_x ? (size_t)D * (SCL_ROWS + 1) : 0));
     const int tid = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * SCL_ROWS;
     const int rows = (int)min((int64_t)SCL_ROWS, n - row0);
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(256) void scaler_inverse_kernel(
         }
         u_out[g] = u;
         x_out[g] = x;
-        if (x_colmajor) Xt[j * (SCL_ROWS + 1) + r] = x;
+        if (keep_x) Xt[j * (SCL_ROWS + 1) + r] = x;
         Jt[r * D + j] = J;
         if (!isfinite(x)) rowfin[r] = 0;
     }
@@ -250,7 +264,17 @@ __global__ __launch_bounds__(256) void scaler_inverse_kernel(
         double l = np_pairwise_sum(Jt + (size_t)tid * D, D);
         if (s.scale) l = s.sum_log_sigma + l;
         ldj_out[row0 + tid] = l;
-        finite_out[row0 + tid] = (rowfin[tid] && isfinite(l)) ? 1 : 0;
+        const int fin = (rowfin[tid] && isfinite(l)) ? 1 : 0;
+        finite_out[row0 + tid] = fin;
+        if (logp_out) {
+            // Prior.logpdf of the finite rows (mcmc.py:105-107), dimension after dimension like prior_logpdf_kernel
+            double lp = -INFINITY;
+            if (fin) {
+                lp = 0.0;
+                for (int j = 0; j < D; ++j) lp += prior_term(pr, j, Xt[j * (SCL_ROWS + 1) + tid]);
+            }
+            logp_out[row0 + tid] = lp;
+        }
     }
     if (x_colmajor) {
         // host copy of x' in column-major order ((n, D) Fortran array on the host): coalesced along rows
@@ -284,19 +308,7 @@ __global__ __launch_bounds__(256) void prior_logpdf_kernel(pmc_prior_t pr, const
         if (!finite || finite[k]) {                                  // mcmc.py:105-107
             lp = 0.0;
             const double* xr = x + k * D;
-            for (int j = 0; j < D; ++j) {
-                const double xv = xr[j], loc = pr.loc[j], sc = pr.scale[j];
-                double t;
-                if (pr.family[j] == PMC_PRIOR_UNIFORM) {
-                    // scipy uniform(loc, scale).logpdf: -log(scale) on [loc, loc+scale], -inf outside
-                    t = (xv >= loc && xv <= loc + sc) ? -log(sc) : -INFINITY;
-                } else {
-                    // scipy norm(loc, scale).logpdf: _norm_logpdf((x-loc)/scale) - log(scale)
-                    const double z = (xv - loc) / sc;
-                    t = (-(z * z) / 2.0 - LOG_SQRT_2PI) - log(sc);
-                }
-                lp += t;
-            }
+            for (int j = 0; j < D; ++j) lp += prior_term(pr, j, xr[j]);
         }
         logp[k] = lp;
     }
@@ -637,12 +649,23 @@ static int check_scaler(const pmc_scaler_t* s) {
 extern "C" int pmc_scaler_inverse(const pmc_scaler_t* s, const float* u_in, const double* u_in64, double* u_out,
                                   double* x, double* x_colmajor, double* logdetj, int32_t* finite, int64_t n,
                                   void* stream) {
+    return pmc_scaler_inverse_prior(s, nullptr, u_in, u_in64, u_out, x, x_colmajor, logdetj, finite, nullptr, n, stream);
+}
+
+extern "C" int pmc_scaler_inverse_prior(const pmc_scaler_t* s, const pmc_prior_t* prior, const float* u_in,
+                                        const double* u_in64, double* u_out, double* x, double* x_colmajor,
+                                        double* logdetj, int32_t* finite, double* logp, int64_t n, void* stream) {
     if (int e = check_scaler(s)) return e;
     if (n == 0) return 0;
     if ((!u_in) == (!u_in64)) return pmc_fail("pmc_scaler_inverse: exactly one of u_in / u_in64 must be given");
     if (!u_out || !x || !logdetj || !finite || n < 0) return pmc_fail("pmc_scaler_inverse: bad argument");
+    if ((prior != nullptr) != (logp != nullptr)) return pmc_fail("pmc_scaler_inverse_prior: prior and logp go together");
+    if (prior && (!prior->family || !prior->loc || !prior->scale || prior->D != s->D))
+        return pmc_fail("pmc_scaler_inverse_prior: bad prior descriptor");
+    pmc_prior_t pr_val = {};
+    if (prior) pr_val = *prior;
     const size_t lds = (size_t)SCL_ROWS * s->D * sizeof(double) + SCL_ROWS * sizeof(int) +
-                       (x_colmajor ? (size_t)s->D * (SCL_ROWS + 1) * sizeof(double) : 0);
+                       ((x_colmajor || logp) ? (size_t)s->D * (SCL_ROWS + 1) * sizeof(double) : 0);
     if (lds > 160 * 1024 || s->D > 1024) return pmc_fail("pmc_scaler_inverse: n_dim too large");
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scaler_inverse_kernel),
@@ -650,7 +673,7 @@ extern "C" int pmc_scaler_inverse(const pmc_scaler_t* s, const float* u_in, cons
         if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(scaler_inverse_kernel)");
     }
     hipLaunchKernelGGL(scaler_inverse_kernel, dim3((unsigned)((n + SCL_ROWS - 1) / SCL_ROWS)), dim3(256), lds,
-                       (hipStream_t)stream, *s, u_in, u_in64, u_out, x, x_colmajor, logdetj, finite, n);
+                       (hipStream_t)stream, *s, u_in, u_in64, u_out, x, x_colmajor, logdetj, finite, n, pr_val, logp);
     return pmc_check_launch("scaler_inverse_kernel");
 }
 

@@ -2,7 +2,7 @@
 // before and after the host's prior / likelihood call, enqueued by ONE C call each, so that the
 // host-side driver spends its time in the user's black boxes instead of in dispatch overhead.
 //
-//   pmc_step_pre :  [H2D mu] -> propose -> flow inverse -> scaler inverse -> D2H x', finite
+//   pmc_step_pre :  [H2D mu] -> propose -> flow inverse -> scaler inverse [+ prior] -> D2H x', finite
 //   pmc_step_post:  H2D logl', logp' -> accept + reductions -> D2H sums
 //
 // Pure sequencing of the single-purpose entry points (same kernels, same stream order); host
@@ -27,19 +27,22 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
                          s->preconditioned ? s->p_theta32 : nullptr, tpcn ? s->quad : nullptr,
                          tpcn ? s->p_quad : nullptr, n, D, stream);
     if (rc) return rc;
+    // scaler inverse and (when it runs on the device) Prior.logpdf share one launch
+    const pmc_prior_t* pr = s->prior;
+    double* lp = pr ? s->p_logp : nullptr;
     if (s->preconditioned) {
         if (s->ev_inv0) (void)hipEventRecord((hipEvent_t)s->ev_inv0, st);
         rc = pmc_maf_inverse(s->maf, s->p_theta32, s->p_u32, s->p_ldjf, n, s->inverse_algo, stream);
         if (s->ev_inv1) (void)hipEventRecord((hipEvent_t)s->ev_inv1, st);
         if (rc) return rc;
-        rc = pmc_scaler_inverse(s->scaler, s->p_u32, nullptr, s->p_u, s->p_x, s->p_xT, s->p_logdetj, s->p_fin, n, stream);
+        rc = pmc_scaler_inverse_prior(s->scaler, pr, s->p_u32, nullptr, s->p_u, s->p_x, s->p_xT, s->p_logdetj, s->p_fin,
+                                      lp, n, stream);
     } else {
-        rc = pmc_scaler_inverse(s->scaler, nullptr, s->p_theta64, s->p_u, s->p_x, s->p_xT, s->p_logdetj, s->p_fin, n, stream);
+        rc = pmc_scaler_inverse_prior(s->scaler, pr, nullptr, s->p_theta64, s->p_u, s->p_x, s->p_xT, s->p_logdetj,
+                                      s->p_fin, lp, n, stream);
     }
     if (rc) return rc;
-    if (s->prior) {
-        rc = pmc_prior_logpdf(s->prior, s->p_x, s->p_fin, s->p_logp, n, stream);
-        if (rc) return rc;
+    if (pr) {
         if (hipMemcpyAsync(s->h_logp_out, s->p_logp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess)
             return pmc_fail("pmc_step_pre: D2H logp");
     }

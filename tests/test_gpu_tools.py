@@ -186,3 +186,43 @@ def test_kernel_call_with_device_prior_equals_host_prior():
     for k in ("u", "x", "logl", "logp", "logdetj"):
         np.testing.assert_allclose(res[0][k], res[1][k], rtol=1e-12, atol=1e-12)
     assert res[0]["steps"] == res[1]["steps"] == 5 and res[0]["calls"] == res[1]["calls"]
+
+
+@pytest.mark.parametrize("colmajor", [False, True])
+def test_fused_scaler_prior_equals_the_two_launches(colmajor):
+    """pmc_scaler_inverse_prior: same u', x', logdetj, finite mask as pmc_scaler_inverse and, bit for bit, the
+    logp of pmc_prior_logpdf on those x' (rows with a non-finite x' get -inf, mcmc.py:105-107)."""
+    import ctypes as C
+    import torch
+    from scipy.stats import norm, uniform
+    import pocomc_amd as pc
+    from pocomc_amd import _lib
+    lib = _lib.load()
+    D, n = 5, 777
+    dists = [uniform(-2.0, 5.0), norm(0.5, 1.7), uniform(0.0, 1.0), norm(-3.0, 0.2), uniform(-10.0, 20.0)]
+    prior = pc.Prior(dists)
+    scaler = pc.Reparameterize(D, bounds=prior.bounds)
+    scaler.fit(prior.rvs(3000))
+    rng = np.random.default_rng(2)
+    u32 = torch.from_numpy((rng.normal(size=(n, D)) * 2.0).astype(np.float32)).cuda()
+    u32[5, 1] = float("nan")                               # a non-finite proposal
+    sd, pd = scaler.device_descriptor(), prior.device_descriptor()
+    mk = lambda *s, dt=torch.float64: torch.empty(*s, dtype=dt, device="cuda")
+    outs = []
+    for fused in (False, True):
+        uo, x, ldj, fin, lp = mk(n, D), mk(n, D), mk(n), mk(n, dt=torch.int32), mk(n)
+        xT = mk(D, n) if colmajor else None
+        if fused:
+            _lib.check(lib.pmc_scaler_inverse_prior(C.byref(sd), C.byref(pd), _lib.ptr(u32), None, _lib.ptr(uo),
+                                                    _lib.ptr(x), _lib.ptr(xT) if colmajor else None, _lib.ptr(ldj),
+                                                    _lib.ptr(fin), _lib.ptr(lp), n, _lib.stream_handle()))
+        else:
+            _lib.check(lib.pmc_scaler_inverse(C.byref(sd), _lib.ptr(u32), None, _lib.ptr(uo), _lib.ptr(x),
+                                              _lib.ptr(xT) if colmajor else None, _lib.ptr(ldj), _lib.ptr(fin), n,
+                                              _lib.stream_handle()))
+            _lib.check(lib.pmc_prior_logpdf(C.byref(pd), _lib.ptr(x), _lib.ptr(fin), _lib.ptr(lp), n,
+                                            _lib.stream_handle()))
+        outs.append([t.cpu().numpy() for t in (uo, x, ldj, fin, lp)] + ([xT.cpu().numpy()] if colmajor else []))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert outs[1][3][5] == 0 and np.isneginf(outs[1][4][5])
