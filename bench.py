@@ -110,6 +110,9 @@ def main():
                          "uniform factors, not a black box)")
     ap.add_argument("--x-order", choices=["C", "F"], default="F",
                     help="memory order of the (n, D) array handed to the host prior/likelihood")
+    ap.add_argument("--event-every", type=int, default=10,
+                    help="record the HIP event pair around the flow-inverse launch on every k-th timed step (an event "
+                         "pair per step costs ~5 %% of the step rate: it splits the pre-phase's back-to-back launches)")
     ap.add_argument("--no-pin", action="store_true",
                     help="do not pin the driver thread to the core it starts on (the host likelihood is single-threaded "
                          "numpy; migrations between cores cost ~8 %% and most of the run-to-run noise)")
@@ -262,15 +265,28 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        eng._step.ev_inv0, eng._step.ev_inv1 = ev_pairs[k]
+        if k % args.event_every == 0:
+            eng._step.ev_inv0, eng._step.ev_inv1 = ev_pairs[k]
+        else:
+            eng._step.ev_inv0, eng._step.ev_inv1 = None, None
         step()
     barrier()
     dt = time.perf_counter() - t0
     eng._step.ev_inv0, eng._step.ev_inv1 = None, None
     seg_timed = {k: v / args.steps * 1e6 for k, v in t_seg.items()}
-    inv_us_live = float(np.mean([lib.pmc_event_elapsed_ms(a, b) for a, b in ev_pairs])) * 1e3
+    inv_us_live = float(np.mean([lib.pmc_event_elapsed_ms(a, b) for a, b in ev_pairs[::args.event_every]])) * 1e3
     for a, b in ev_pairs:
         lib.pmc_event_destroy(a); lib.pmc_event_destroy(b)
+    # ---- composite path again with host timers only (no HIP events): where the host thread's time goes
+    eng.host_timers = {"wait_device": 0.0, "prior": 0.0, "likelihood": 0.0}
+    for k in t_seg:
+        t_seg[k] = 0.0
+    n_ht = max(20, min(args.steps, 100))
+    for _ in range(n_ht):
+        step()
+    torch.cuda.synchronize()
+    composite_host = {**{k: v / n_ht * 1e6 for k, v in eng.host_timers.items()},
+                      **{k: v / n_ht * 1e6 for k, v in t_seg.items()}}
     # ---- instrumented pass (same steps, fine-grained entry points + HIP events + host timers):
     #      per-kernel durations for the roofline object and the host/device breakdown
     eng.events = []
@@ -318,7 +334,7 @@ def main():
                             "triangular_v3": "maf_inverse_tri3_kernel"}.get(
                                args.inverse, "maf_inverse_tri4_kernel" if spec.nOT <= 8 else "maf_inverse_tri2_kernel")), "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                "avg_launch_us": inv_us_live,
+                "avg_launch_us": inv_us_live, "launches_timed": len(ev_pairs[::args.event_every]),
                 "note": "achieved = SURVEY 8(d) naive-equivalent flops ((D+1)*F_fwd per walker) / launch time; the "
                         "triangular sweep executes only the masked MACs once, so frac > 1 is an algorithmic gain",
                 "actual_tflops": actual_flops / t_inv / 1e12,
@@ -343,6 +359,7 @@ def main():
                                          + us["accept_reduce"], wall=ms_per_step * 1e3,
                                          instrumented_pass_wall=dt_inst / n_inst * 1e6),
            "timed_region_host_us_per_step": seg_timed,
+           "composite_path_host_us_per_step": composite_host,
            "host_us_per_step": {**{k: v / n_inst * 1e6 for k, v in eng.host_timers.items()},
                                 **{k: v / n_inst * 1e6 for k, v in t_seg.items()}}}
     out["config"]["driver_pinned_to_core"] = pinned_core
