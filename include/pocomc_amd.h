@@ -187,10 +187,14 @@ int pmc_prior_logpdf(const pmc_prior_t* pr, const double* x, const int32_t* fini
 /* pmc_scaler_inverse and pmc_prior_logpdf in ONE launch (the step's pre-phase is a chain of small
  * latency-bound kernels; each launch costs ~15-20 us end to end): additionally
  * logp f64 [n] <- Prior.logpdf(x') on the finite rows, -inf elsewhere (mcmc.py:105-107).
- * prior == NULL and logp == NULL: exactly pmc_scaler_inverse. */
+ * prior == NULL and logp == NULL: exactly pmc_scaler_inverse.
+ * finite_copy / logp_copy: optional second destinations.  Together with x_colmajor they may point into
+ * PINNED HOST memory (device-accessible, e.g. hipHostMalloc): the kernel then writes what the host
+ * callbacks read straight over PCIe while it computes, and no device-to-host copy follows it. */
 int pmc_scaler_inverse_prior(const pmc_scaler_t* s, const pmc_prior_t* prior, const float* u_in,
                              const double* u_in64, double* u_out, double* x, double* x_colmajor,
-                             double* logdetj, int32_t* finite, double* logp, int64_t n, void* stream);
+                             double* logdetj, int32_t* finite, double* logp, int32_t* finite_copy,
+                             double* logp_copy, int64_t n, void* stream);
 
 /* ------------------------------------------------------------ MCMC step */
 
@@ -257,6 +261,14 @@ int pmc_accept(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposa
                const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums,
                void* workspace, int64_t n, int32_t D, void* stream);
 
+/* pmc_accept without the memset that re-arms the workspace (the kernel leaves the ticket word at zero itself;
+ * the caller zeroes the workspace ONCE after allocating it and never aborts a launch), and with an optional
+ * second destination of the sums -- pinned host memory, so that no device-to-host copy follows the kernel.
+ * prop->logl / prop->logp may likewise point into pinned host memory (read straight over PCIe). */
+int pmc_accept_armed(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposal_t* prop, double beta,
+                     double nu, const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums,
+                     double* sums_copy, void* workspace, int64_t n, int32_t D, void* stream);
+
 /* All buffers of one step in one place, for the composite entry points below. */
 typedef struct pmc_step {
     int32_t kind;             /* PMC_KIND_TPCN | PMC_KIND_RWM */
@@ -298,6 +310,9 @@ typedef struct pmc_step {
     void* ev_inv1;
     const pmc_prior_t* prior; /* non-NULL: logp' is evaluated on the device in pmc_step_pre and copied to h_logp_out */
     double* h_logp_out;       /* pinned host [n] (may alias h_logp) */
+    int32_t host_direct;      /* 1: h_x (column-major, p_xT == NULL), h_fin, h_logp_out and h_mu are device-accessible
+                               * pinned memory that the kernels read / write themselves -- no copies in pmc_step_pre */
+    int32_t reserved;
 } pmc_step_t;
 
 /* mcmc.py:77-102 in one call: [H2D mu] -> propose -> flow inverse -> scaler inverse -> D2H x', finite. */

@@ -75,7 +75,7 @@ class pmc_step_t(C.Structure):
                 ("p_logp", c_p), ("alpha", c_p), ("accept", c_p), ("sums", c_p), ("ws", c_p),
                 ("h_mu", c_p), ("h_x", c_p), ("h_fin", c_p), ("h_logl", c_p), ("h_logp", c_p), ("h_sums", c_p),
                 ("h_accept", c_p), ("ev_inv0", c_p), ("ev_inv1", c_p),
-                ("prior", c_p), ("h_logp_out", c_p)]
+                ("prior", c_p), ("h_logp_out", c_p), ("host_direct", C.c_int32), ("reserved", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/pocomc_amd.h declares
@@ -97,12 +97,14 @@ SIGNATURES = {
     "pmc_scaler_forward": (C.c_int, [P(pmc_scaler_t), c_p, c_p, i64, c_p]),
     "pmc_prior_logpdf": (C.c_int, [P(pmc_prior_t), c_p, c_p, c_p, i64, c_p]),
     "pmc_scaler_inverse_prior": (C.c_int, [P(pmc_scaler_t), P(pmc_prior_t), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
-                                           i64, c_p]),
+                                           c_p, c_p, i64, c_p]),
     "pmc_propose": (C.c_int, [C.c_int, c_p, c_p, c_p, c_p, c_p, f64, f64, f64, P(pmc_rng_t),
                               c_p, c_p, c_p, c_p, i64, i32, c_p]),
     "pmc_accept_workspace_bytes": (i64, [i64, i32]),
     "pmc_accept": (C.c_int, [C.c_int, C.c_int, P(pmc_state_t), P(pmc_proposal_t), f64, f64,
                              P(pmc_rng_t), c_p, c_p, c_p, c_p, i64, i32, c_p]),
+    "pmc_accept_armed": (C.c_int, [C.c_int, C.c_int, P(pmc_state_t), P(pmc_proposal_t), f64, f64,
+                                   P(pmc_rng_t), c_p, c_p, c_p, c_p, c_p, i64, i32, c_p]),
     "pmc_step_pre": (C.c_int, [P(pmc_step_t), P(pmc_rng_t), f64, f64, f64, c_p]),
     "pmc_step_post": (C.c_int, [P(pmc_step_t), P(pmc_rng_t), f64, f64, C.c_int, C.c_int, c_p]),
     "pmc_stream_synchronize": (C.c_int, [c_p]),

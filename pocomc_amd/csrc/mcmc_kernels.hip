@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void scaler_inverse_kernel(
     pmc_scaler_t s, const float* __restrict__ u_in, const double* __restrict__ u_in64,
     double* __restrict__ u_out, double* __restrict__ x_out, double* __restrict__ x_colmajor,
     double* __restrict__ ldj_out, int32_t* __restrict__ finite_out, int64_t n, pmc_prior_t pr,
-    double* __restrict__ logp_out) {
+    double* __restrict__ logp_out, int32_t* __restrict__ finite_copy, double* __restrict__ logp_copy) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int D = s.D;
     const bool keep_x = x_colmajor || logp_out;   // x' stays in LDS for the column-major copy / the fused prior
@@ -266,6 +266,7 @@ __global__ __launch_bounds__(256) void scaler_inverse_kernel(
         ldj_out[row0 + tid] = l;
         const int fin = (rowfin[tid] && isfinite(l)) ? 1 : 0;
         finite_out[row0 + tid] = fin;
+        if (finite_copy) finite_copy[row0 + tid] = fin;
         if (logp_out) {
             // Prior.logpdf of the finite rows (mcmc.py:105-107), dimension after dimension like prior_logpdf_kernel
             double lp = -INFINITY;
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(256) void scaler_inverse_kernel(
                 for (int j = 0; j < D; ++j) lp += prior_term(pr, j, Xt[j * (SCL_ROWS + 1) + tid]);
             }
             logp_out[row0 + tid] = lp;
+            if (logp_copy) logp_copy[row0 + tid] = lp;
         }
     }
     if (x_colmajor) {
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(256) void accept_kernel(
     int preconditioned, int tpcn, pmc_state_t cur, pmc_proposal_t prop, double beta, double nu,
     pmc_rng_t rng, double* __restrict__ alpha_out, int32_t* __restrict__ accept_out,
     double* __restrict__ partials, unsigned* __restrict__ ticket, double* __restrict__ sums,
-    int64_t n, int D) {
+    double* __restrict__ sums_copy, int64_t n, int D) {
     __shared__ int flag[ACC_ROWS];
     __shared__ double colsum[8][33];
     __shared__ int is_last;
@@ -461,6 +463,7 @@ __global__ __launch_bounds__(256) void accept_kernel(
             double tot = 0.0;
             for (int s2 = 0; s2 < S; ++s2) tot += fold[s2 * Wc + tid];
             sums[c0 + tid] = tot;
+            if (sums_copy) sums_copy[c0 + tid] = tot;
         }
         __syncthreads();
     }
@@ -649,17 +652,20 @@ static int check_scaler(const pmc_scaler_t* s) {
 extern "C" int pmc_scaler_inverse(const pmc_scaler_t* s, const float* u_in, const double* u_in64, double* u_out,
                                   double* x, double* x_colmajor, double* logdetj, int32_t* finite, int64_t n,
                                   void* stream) {
-    return pmc_scaler_inverse_prior(s, nullptr, u_in, u_in64, u_out, x, x_colmajor, logdetj, finite, nullptr, n, stream);
+    return pmc_scaler_inverse_prior(s, nullptr, u_in, u_in64, u_out, x, x_colmajor, logdetj, finite, nullptr, nullptr,
+                                    nullptr, n, stream);
 }
 
 extern "C" int pmc_scaler_inverse_prior(const pmc_scaler_t* s, const pmc_prior_t* prior, const float* u_in,
                                         const double* u_in64, double* u_out, double* x, double* x_colmajor,
-                                        double* logdetj, int32_t* finite, double* logp, int64_t n, void* stream) {
+                                        double* logdetj, int32_t* finite, double* logp, int32_t* finite_copy,
+                                        double* logp_copy, int64_t n, void* stream) {
     if (int e = check_scaler(s)) return e;
     if (n == 0) return 0;
     if ((!u_in) == (!u_in64)) return pmc_fail("pmc_scaler_inverse: exactly one of u_in / u_in64 must be given");
     if (!u_out || !x || !logdetj || !finite || n < 0) return pmc_fail("pmc_scaler_inverse: bad argument");
     if ((prior != nullptr) != (logp != nullptr)) return pmc_fail("pmc_scaler_inverse_prior: prior and logp go together");
+    if (logp_copy && !logp) return pmc_fail("pmc_scaler_inverse_prior: logp_copy without logp");
     if (prior && (!prior->family || !prior->loc || !prior->scale || prior->D != s->D))
         return pmc_fail("pmc_scaler_inverse_prior: bad prior descriptor");
     pmc_prior_t pr_val = {};
@@ -673,7 +679,8 @@ extern "C" int pmc_scaler_inverse_prior(const pmc_scaler_t* s, const pmc_prior_t
         if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(scaler_inverse_kernel)");
     }
     hipLaunchKernelGGL(scaler_inverse_kernel, dim3((unsigned)((n + SCL_ROWS - 1) / SCL_ROWS)), dim3(256), lds,
-                       (hipStream_t)stream, *s, u_in, u_in64, u_out, x, x_colmajor, logdetj, finite, n, pr_val, logp);
+                       (hipStream_t)stream, *s, u_in, u_in64, u_out, x, x_colmajor, logdetj, finite, n, pr_val, logp, finite_copy,
+                       logp_copy);
     return pmc_check_launch("scaler_inverse_kernel");
 }
 
@@ -691,9 +698,9 @@ extern "C" int64_t pmc_accept_workspace_bytes(int64_t n, int32_t D) {
     return 64 + (nb > 0 ? nb : 1) * (int64_t)(D + 4) * (int64_t)sizeof(double);   // [ticket | partials]
 }
 
-extern "C" int pmc_accept(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposal_t* prop, double beta,
-                          double nu, const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums,
-                          void* workspace, int64_t n, int32_t D, void* stream) {
+static int accept_impl(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposal_t* prop, double beta,
+                       double nu, const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums,
+                       double* sums_copy, bool armed, void* workspace, int64_t n, int32_t D, void* stream) {
     if (!cur || !prop || !rng || !sums || !workspace || n < 0 || D < 1) return pmc_fail("pmc_accept: bad argument");
     if (!cur->u || !cur->x || !cur->logdetj || !cur->logl || !cur->logp || !prop->u || !prop->x ||
         !prop->logdetj || !prop->logl || !prop->logp)
@@ -710,11 +717,26 @@ extern "C" int pmc_accept(int kind, int preconditioned, pmc_state_t* cur, const 
         if (hipMemsetAsync(sums, 0, (size_t)(D + 4) * sizeof(double), st) != hipSuccess) return pmc_fail("pmc_accept: memset");
         return 0;
     }
-    // the ticket word is re-armed by every call (a memset node ahead of the launch): no state between calls
-    if (hipMemsetAsync(ticket, 0, sizeof(unsigned), st) != hipSuccess) return pmc_fail("pmc_accept: memset");
+    // the ticket word is re-armed by every call (a memset node ahead of the launch): no state between calls.
+    // pmc_accept_armed skips it: the kernel leaves the word at zero itself.
+    if (!armed && hipMemsetAsync(ticket, 0, sizeof(unsigned), st) != hipSuccess) return pmc_fail("pmc_accept: memset");
     hipLaunchKernelGGL(accept_kernel, dim3(nb), dim3(256), 0, st, preconditioned, tpcn, *cur, *prop, beta, nu, *rng,
-                       alpha_out, accept_out, partials, ticket, sums, n, (int)D);
+                       alpha_out, accept_out, partials, ticket, sums, sums_copy, n, (int)D);
     return pmc_check_launch("accept_kernel");
+}
+
+extern "C" int pmc_accept(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposal_t* prop, double beta,
+                          double nu, const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums,
+                          void* workspace, int64_t n, int32_t D, void* stream) {
+    return accept_impl(kind, preconditioned, cur, prop, beta, nu, rng, alpha_out, accept_out, sums, nullptr, false,
+                       workspace, n, D, stream);
+}
+
+extern "C" int pmc_accept_armed(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposal_t* prop, double beta,
+                                double nu, const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums,
+                                double* sums_copy, void* workspace, int64_t n, int32_t D, void* stream) {
+    return accept_impl(kind, preconditioned, cur, prop, beta, nu, rng, alpha_out, accept_out, sums, sums_copy, true,
+                       workspace, n, D, stream);
 }
 
 extern "C" int pmc_logw(const double* logl, const double* beta, const double* logz, double beta_final,

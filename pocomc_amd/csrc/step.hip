@@ -18,30 +18,38 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
     const int64_t n = s->n;
     const int32_t D = s->D;
     const bool tpcn = (s->kind == PMC_KIND_TPCN);
+    // host_direct: the kernels read mu from / write x', finite, logp' to pinned host memory themselves
+    const bool direct = s->host_direct && !s->p_xT;
+    const double* mu = s->mu;
     if (tpcn && s->h_mu) {
-        if (hipMemcpyAsync((void*)s->mu, s->h_mu, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+        if (direct) mu = s->h_mu;
+        else if (hipMemcpyAsync((void*)s->mu, s->h_mu, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
             return pmc_fail("pmc_step_pre: H2D mu");
     }
     int rc = pmc_propose(s->kind, s->preconditioned ? s->cur.theta32 : nullptr, s->preconditioned ? nullptr : s->cur.u,
-                         s->mu, s->inv_cov, s->chol, nu, sigma, cn_a, rng, s->p_theta64,
+                         mu, s->inv_cov, s->chol, nu, sigma, cn_a, rng, s->p_theta64,
                          s->preconditioned ? s->p_theta32 : nullptr, tpcn ? s->quad : nullptr,
                          tpcn ? s->p_quad : nullptr, n, D, stream);
     if (rc) return rc;
     // scaler inverse and (when it runs on the device) Prior.logpdf share one launch
     const pmc_prior_t* pr = s->prior;
     double* lp = pr ? s->p_logp : nullptr;
+    double* xT = direct ? s->h_x : s->p_xT;
+    int32_t* fin2 = direct ? s->h_fin : nullptr;
+    double* lp2 = (direct && pr) ? s->h_logp_out : nullptr;
     if (s->preconditioned) {
         if (s->ev_inv0) (void)hipEventRecord((hipEvent_t)s->ev_inv0, st);
         rc = pmc_maf_inverse(s->maf, s->p_theta32, s->p_u32, s->p_ldjf, n, s->inverse_algo, stream);
         if (s->ev_inv1) (void)hipEventRecord((hipEvent_t)s->ev_inv1, st);
         if (rc) return rc;
-        rc = pmc_scaler_inverse_prior(s->scaler, pr, s->p_u32, nullptr, s->p_u, s->p_x, s->p_xT, s->p_logdetj, s->p_fin,
-                                      lp, n, stream);
+        rc = pmc_scaler_inverse_prior(s->scaler, pr, s->p_u32, nullptr, s->p_u, s->p_x, xT, s->p_logdetj, s->p_fin, lp,
+                                      fin2, lp2, n, stream);
     } else {
-        rc = pmc_scaler_inverse_prior(s->scaler, pr, nullptr, s->p_theta64, s->p_u, s->p_x, s->p_xT, s->p_logdetj,
-                                      s->p_fin, lp, n, stream);
+        rc = pmc_scaler_inverse_prior(s->scaler, pr, nullptr, s->p_theta64, s->p_u, s->p_x, xT, s->p_logdetj, s->p_fin,
+                                      lp, fin2, lp2, n, stream);
     }
     if (rc) return rc;
+    if (direct) return 0;
     if (pr) {
         if (hipMemcpyAsync(s->h_logp_out, s->p_logp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess)
             return pmc_fail("pmc_step_pre: D2H logp");
@@ -58,21 +66,32 @@ extern "C" int pmc_step_post(const pmc_step_t* s, const pmc_rng_t* rng, double b
     if (!s || !rng) return pmc_fail("pmc_step_post: null argument");
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = s->n;
-    if (hipMemcpyAsync(s->p_logl, s->h_logl, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
-        return pmc_fail("pmc_step_post: H2D");
-    if (!s->prior &&     // with a device prior logp' never left the device
-        hipMemcpyAsync(s->p_logp, s->h_logp, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
-        return pmc_fail("pmc_step_post: H2D");
+    const bool direct = s->host_direct && !s->p_xT;
+    if (!direct) {
+        if (hipMemcpyAsync(s->p_logl, s->h_logl, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+            return pmc_fail("pmc_step_post: H2D");
+        if (!s->prior &&     // with a device prior logp' never left the device
+            hipMemcpyAsync(s->p_logp, s->h_logp, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+            return pmc_fail("pmc_step_post: H2D");
+    }
     pmc_state_t cur = s->cur;
     pmc_proposal_t prop;
     prop.theta64 = s->preconditioned ? s->p_theta64 : nullptr;
-    prop.u = s->p_u; prop.x = s->p_x; prop.logdetj = s->p_logdetj; prop.logl = s->p_logl; prop.logp = s->p_logp;
+    prop.u = s->p_u; prop.x = s->p_x; prop.logdetj = s->p_logdetj;
+    // host_direct: the accept kernel reads logl' (and a host-evaluated logp') from the pinned host buffers
+    prop.logl = direct ? s->h_logl : s->p_logl;
+    prop.logp = (direct && !s->prior) ? s->h_logp : s->p_logp;
     prop.logdetj_flow = s->preconditioned ? s->p_ldjf : nullptr;
     prop.quad = s->quad; prop.quad_prop = s->p_quad;
-    int rc = pmc_accept(s->kind, s->preconditioned, &cur, &prop, beta, nu, rng, s->alpha, s->accept, s->sums, s->ws, n,
+    int rc;
+    if (direct)
+        rc = pmc_accept_armed(s->kind, s->preconditioned, &cur, &prop, beta, nu, rng, s->alpha, s->accept, s->sums,
+                              copy_sums ? s->h_sums : nullptr, s->ws, n, s->D, stream);
+    else
+        rc = pmc_accept(s->kind, s->preconditioned, &cur, &prop, beta, nu, rng, s->alpha, s->accept, s->sums, s->ws, n,
                         s->D, stream);
     if (rc) return rc;
-    if (copy_sums &&
+    if (copy_sums && !direct &&
         hipMemcpyAsync(s->h_sums, s->sums, (size_t)(s->D + 4) * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess)
         return pmc_fail("pmc_step_post: D2H sums");
     if (want_mask && s->h_accept &&

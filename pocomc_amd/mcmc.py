@@ -136,7 +136,7 @@ class StepEngine:
         self.alpha = f64(n)
         self.accept = torch.empty(n, dtype=torch.int32, device=dev)
         self.sums = f64(D + 4)
-        self.ws = torch.empty(max(int(self.lib.pmc_accept_workspace_bytes(n, D)), 8), dtype=torch.uint8, device=dev)
+        self.ws = torch.zeros(max(int(self.lib.pmc_accept_workspace_bytes(n, D)), 8), dtype=torch.uint8, device=dev)   # zeroed once: pmc_accept_armed
         # geometry
         self.mu_d, self.inv_cov_d, self.chol_d = f64(D), f64(D, D), f64(D, D)
         # replay variates
@@ -186,6 +186,9 @@ class StepEngine:
                                         offset=self.offset)
         self.prior_desc = None   # pmc_prior_t when Prior.logpdf runs on the device (set_device_prior)
         self.composite = True    # one C call before / after the host black boxes (pmc_step_pre / _post)
+        # x_order 'F' on the composite path: the scaler kernel writes x', the finite mask and logp' straight
+        # into the pinned host buffers (and the proposal reads mu from one) -- no copy operations in the pre-step
+        self.host_direct = (x_order == "F")
         self._post_uploads = False
         self.step_idx = 0
         self.host_threads = 1    # >1: evaluate the black boxes on row chunks in a thread pool
@@ -265,6 +268,9 @@ class StepEngine:
                 self._rng_cur = self._rng_fast
             if self.pre:
                 self._step.inverse_algo = self.flow.inverse_algo
+            direct = bool(self.host_direct and self.x_order == "F")
+            self._step.host_direct = int(direct)
+            self._step.p_xT = None if (direct or self.p_xT is None) else self.p_xT.data_ptr()
             cn_a = float((1.0 - sigma ** 2.0) ** 0.5) if self.tpcn else 0.0        # mcmc.py:85
             self._stream = _lib.stream_handle()
             _lib.check(lib.pmc_step_pre(C.byref(self._step), C.byref(self._rng_cur), float(nu), float(sigma), cn_a,
@@ -476,7 +482,10 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
     n_walkers, n_dim = x.shape
 
     eng = StepEngine(kind, n_walkers, n_dim, flow, scaler, group=group,
-                     shard_offset=option_dict.get("shard_offset", 0), seed=seed)
+                     shard_offset=option_dict.get("shard_offset", 0), seed=seed,
+                     x_order=option_dict.get("x_order", "C"))
+    if "host_direct" in option_dict:
+        eng.host_direct = bool(option_dict["host_direct"])
     owner = getattr(log_prior, "__self__", None)
     if owner is not None and option_dict.get("device_prior", True) and hasattr(owner, "device_descriptor"):
         eng.set_device_prior(owner)                 # Prior.logpdf of uniform / normal factors on the device

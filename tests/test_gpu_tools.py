@@ -215,7 +215,7 @@ def test_fused_scaler_prior_equals_the_two_launches(colmajor):
         if fused:
             _lib.check(lib.pmc_scaler_inverse_prior(C.byref(sd), C.byref(pd), _lib.ptr(u32), None, _lib.ptr(uo),
                                                     _lib.ptr(x), _lib.ptr(xT) if colmajor else None, _lib.ptr(ldj),
-                                                    _lib.ptr(fin), _lib.ptr(lp), n, _lib.stream_handle()))
+                                                    _lib.ptr(fin), _lib.ptr(lp), None, None, n, _lib.stream_handle()))
         else:
             _lib.check(lib.pmc_scaler_inverse(C.byref(sd), _lib.ptr(u32), None, _lib.ptr(uo), _lib.ptr(x),
                                               _lib.ptr(xT) if colmajor else None, _lib.ptr(ldj), _lib.ptr(fin), n,
@@ -226,3 +226,35 @@ def test_fused_scaler_prior_equals_the_two_launches(colmajor):
     for a, b in zip(*outs):
         assert np.array_equal(a, b, equal_nan=True)
     assert outs[1][3][5] == 0 and np.isneginf(outs[1][4][5])
+
+
+def test_step_outputs_written_straight_to_pinned_host_memory():
+    """host_direct (x_order='F', composite path): x', the finite mask and logp' land in the pinned host buffers
+    without a copy operation; the kernel call gives the same results as the copy path, bit for bit."""
+    from scipy.stats import uniform
+    import pocomc_amd as pc
+    from pocomc_amd import mcmc as pmcmc
+    from pocomc_amd.geometry import Geometry
+    import torch
+    D, N = 6, 700
+    prior = pc.Prior([uniform(-5, 10)] * D)
+    rng = np.random.default_rng(3)
+    scaler = pc.Reparameterize(D, bounds=prior.bounds)
+    scaler.fit(prior.rvs(2000))
+    x = rng.uniform(-4, 4, size=(N, D))
+    u = scaler.forward(x)
+    like = lambda xx: (-0.5 * np.sum(xx ** 2, axis=1), None)
+    flow = pc.Flow(D, "maf3", seed=0)
+    geo = Geometry()
+    geo.fit(flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64))
+    res = []
+    for direct in (True, False):
+        state = dict(u=u.copy(), x=x.copy(), logdetj=scaler.inverse(u)[1], logl=like(x)[0], logp=prior.logpdf(x),
+                     beta=0.5, blobs=None)
+        funcs = dict(loglike=like, logprior=prior.logpdf, scaler=scaler, flow=flow, theta_geometry=geo)
+        opts = dict(n_max=6, n_steps=10 ** 6, progress_bar=None, proposal_scale=2.38 / D ** 0.5, seed=7,
+                    device_prior=True, x_order="F", host_direct=direct)
+        res.append(pmcmc.preconditioned_pcn(state, funcs, opts))
+    for k in ("u", "x", "logl", "logp", "logdetj"):
+        assert np.array_equal(res[0][k], res[1][k])
+    assert res[0]["steps"] == res[1]["steps"] == 6 and res[0]["accept"] == res[1]["accept"]
