@@ -310,10 +310,36 @@ typedef struct pmc_step {
     void* ev_inv1;
     const pmc_prior_t* prior; /* non-NULL: logp' is evaluated on the device in pmc_step_pre and copied to h_logp_out */
     double* h_logp_out;       /* pinned host [n] (may alias h_logp) */
+    /* Philox variates drawn ahead of time (throughput mode, rng->normal == NULL): the draws of step k+1 do not
+     * depend on step k, so pmc_step_pre(k) enqueues pmc_rng_fill(k+1) behind its own kernels and the GPU
+     * generates them while the host evaluates the likelihood; the kernels of step k+1 then read them like
+     * replayed variates.  Two buffer sets, used alternately; rng_ready (host int64, -1 at start) holds the step
+     * whose variates sit in set [step & 1].  All NULL: the kernels draw inline. */
+    double* rng_normal[2];    /* device f64 [n][D] each */
+    double* rng_gamma[2];     /* device f64 [n] each (tpCN) */
+    double* rng_uniform[2];   /* device f64 [n] each */
+    int64_t* rng_ready;       /* host */
+    void* ev_pre_done;        /* optional hipEvent_t recorded when x', finite and logp' are complete (the variates of the
+                               * next step are generated behind it: wait for this event, not for the stream) */
+    int32_t no_fuse;          /* 1: always launch the proposal and the flow inverse separately */
     int32_t host_direct;      /* 1: h_x (column-major, p_xT == NULL), h_fin, h_logp_out and h_mu are device-accessible
                                * pinned memory that the kernels read / write themselves -- no copies in pmc_step_pre */
-    int32_t reserved;
 } pmc_step_t;
+
+/* The Philox variates of one step into arrays, exactly the values the kernels draw inline for the same
+ * (seed, step, offset): normal f64 [n][D] (stream 1, pair j/2), gamma f64 [n] = standard gamma of shape
+ * `gamma_shape` (stream 0; NULL or gamma_shape <= 0: skipped), uniform f64 [n] (stream 2; NULL: skipped). */
+int pmc_rng_fill(const pmc_rng_t* rng, double gamma_shape, double* normal, double* gamma, double* uniform,
+                 int64_t n, int32_t D, void* stream);
+int pmc_event_synchronize(void* ev);
+
+/* Proposal (pmc_propose, preconditioned kernels: cur32 = theta) and flow inverse (pmc_maf_inverse) of the
+ * proposed theta' in ONE launch: every wave proposes for its 16 walkers and sweeps them through the inverse
+ * flow without a global round trip.  prop64 f64 [n][D] = theta', quad / quad_prop f64 [n] (tpCN),
+ * u_out f32 [n][D], ladj f32 [n] or NULL.  Affine flows with D <= 64 only (error otherwise). */
+int pmc_propose_inverse(int kind, const float* cur32, const double* mu, const double* inv_cov, const double* chol,
+                        double nu, double sigma, double cn_a, const pmc_rng_t* rng, double* prop64, double* quad,
+                        double* quad_prop, const pmc_maf_t* maf, float* u_out, float* ladj, int64_t n, void* stream);
 
 /* mcmc.py:77-102 in one call: [H2D mu] -> propose -> flow inverse -> scaler inverse -> D2H x', finite. */
 int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu, double sigma, double cn_a, void* stream);

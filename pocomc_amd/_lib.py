@@ -75,7 +75,9 @@ class pmc_step_t(C.Structure):
                 ("p_logp", c_p), ("alpha", c_p), ("accept", c_p), ("sums", c_p), ("ws", c_p),
                 ("h_mu", c_p), ("h_x", c_p), ("h_fin", c_p), ("h_logl", c_p), ("h_logp", c_p), ("h_sums", c_p),
                 ("h_accept", c_p), ("ev_inv0", c_p), ("ev_inv1", c_p),
-                ("prior", c_p), ("h_logp_out", c_p), ("host_direct", C.c_int32), ("reserved", C.c_int32)]
+                ("prior", c_p), ("h_logp_out", c_p),
+                ("rng_normal", c_p * 2), ("rng_gamma", c_p * 2), ("rng_uniform", c_p * 2), ("rng_ready", c_p),
+                ("ev_pre_done", c_p), ("no_fuse", C.c_int32), ("host_direct", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/pocomc_amd.h declares
@@ -105,12 +107,16 @@ SIGNATURES = {
                              P(pmc_rng_t), c_p, c_p, c_p, c_p, i64, i32, c_p]),
     "pmc_accept_armed": (C.c_int, [C.c_int, C.c_int, P(pmc_state_t), P(pmc_proposal_t), f64, f64,
                                    P(pmc_rng_t), c_p, c_p, c_p, c_p, c_p, i64, i32, c_p]),
+    "pmc_propose_inverse": (C.c_int, [C.c_int, c_p, c_p, c_p, c_p, f64, f64, f64, P(pmc_rng_t), c_p, c_p, c_p,
+                                      P(pmc_maf_t), c_p, c_p, i64, c_p]),
     "pmc_step_pre": (C.c_int, [P(pmc_step_t), P(pmc_rng_t), f64, f64, f64, c_p]),
     "pmc_step_post": (C.c_int, [P(pmc_step_t), P(pmc_rng_t), f64, f64, C.c_int, C.c_int, c_p]),
     "pmc_stream_synchronize": (C.c_int, [c_p]),
     "pmc_event_create": (c_p, []),
     "pmc_event_record": (C.c_int, [c_p, c_p]),
     "pmc_event_elapsed_ms": (C.c_float, [c_p, c_p]),
+    "pmc_event_synchronize": (C.c_int, [c_p]),
+    "pmc_rng_fill": (C.c_int, [P(pmc_rng_t), f64, c_p, c_p, c_p, i64, i32, c_p]),
     "pmc_event_destroy": (None, [c_p]),
     "pmc_logw": (C.c_int, [c_p, c_p, c_p, f64, c_p, i32, i64, c_p]),
     "pmc_reduce_workspace_bytes": (i64, [i64]),

@@ -12,6 +12,7 @@
 //   * keeps the prefetch of the NEXT tile's burst fragments issued right after the bursts.
 
 #include "maf_chain_rot.h"
+#include "propose_body.h"
 
 #define PX4 2
 #define PK4 8
@@ -59,12 +60,25 @@ __device__ __forceinline__ void prefetch_tile(float4 (&pf1)[PK4], float4 (&pf2)[
     }
 }
 
+// Proposal arguments of the fused variant (pmc_propose_inverse): the wave first proposes theta' for its 16
+// walkers (propose_body.h) straight into the sweep's LDS input -- one launch and one global round trip less
+// per MCMC step.
+struct ProposeArgs {
+    int kind;
+    const float* cur32;
+    const double* mu; const double* inv_cov; const double* chol;
+    double nu, sigma, cn_a;
+    pmc_rng_t rng;
+    double* prop64; double* quad; double* quad_prop;
+};
+
 // ABL: timing-only ablations (see maf_chain_rot.h); 4 = no bursts, 8 = no chain, 16 = no next-tile prefetch,
-// 32 = no tile-top fragment loads
-template <int MAXO, int ABL>
+// 32 = no tile-top fragment loads.  FM: 0 = plain inverse of `in`; 4 / 8 / 16 = fused proposal with D <= 4 FM.
+template <int MAXO, int ABL, int FM = 0>
 __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const float* __restrict__ in,
                                                               float* __restrict__ out,
-                                                              float* __restrict__ ladj_out, int64_t n) {
+                                                              float* __restrict__ ladj_out, int64_t n,
+                                                              ProposeArgs pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
     const int q = lane >> 4, p = lane & 15;
@@ -99,7 +113,13 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
     const int vo_R = ((q << 4) + ((((lane & 15) >> 2) + (lane & 3)) & 3)) << 4;
     const int vo_q = q << 4;                                    // 4 consecutive floats of quad q
 
-    load_rows(Y, in, row0, n, D, Dp, feat_of_rank + (T - 1) * D, lane);
+    if constexpr (FM > 0) {
+        for (int e = lane; e < (Dp - D) * 16; e += 64) Y[lidx(D + (e >> 4), e & 15)] = 0.0f;
+        propose_body<FM>(pa.kind, pa.cur32, nullptr, pa.mu, pa.inv_cov, pa.chol, pa.nu, pa.sigma, pa.cn_a, pa.rng,
+                         pa.prop64, nullptr, pa.quad, pa.quad_prop, n, D, Y, rank_of_feat + (T - 1) * D);
+    } else {
+        load_rows(Y, in, row0, n, D, Dp, feat_of_rank + (T - 1) * D, lane);
+    }
     {   // padding slots of the activations are read by the bursts (times zero weights): zero once
         float4* z4 = reinterpret_cast<float4*>(H0);
         const int n4 = (3 * Hp * 16) >> 2;
@@ -321,7 +341,7 @@ int pmc_launch_inverse_tri4(const pmc_maf_t* m, const float* z, float* x, float*
             if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_inverse_tri4_kernel)");         \
         }                                                                                                        \
         hipLaunchKernelGGL((maf_inverse_tri4_kernel<MO, 0>), dim3((unsigned)((n + 15) / 16)), dim3(64), lds,      \
-                           stream, *m, z, x, ladj, n);                                                           \
+                           stream, *m, z, x, ladj, n, ProposeArgs{});                                            \
     }
     if (maxo == 4) LAUNCH(4) else LAUNCH(8)
 #undef LAUNCH
@@ -334,8 +354,37 @@ extern "C" int pmc_debug_inverse4_ablate(const pmc_maf_t* m, const float* z, flo
     const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + 4 * 256) * sizeof(float);
     const dim3 g((unsigned)((n + 15) / 16)), b(64);
     hipStream_t st = (hipStream_t)stream;
-#define AB(V) case V: hipLaunchKernelGGL((maf_inverse_tri4_kernel<4, V>), g, b, lds, st, *m, z, x, ladj, n); break;
+#define AB(V) case V: hipLaunchKernelGGL((maf_inverse_tri4_kernel<4, V>), g, b, lds, st, *m, z, x, ladj, n, ProposeArgs{}); break;
     switch (abl) { AB(0) AB(1) AB(2) AB(3) AB(4) AB(8) AB(16) AB(32) AB(64) AB(12) AB(60) AB(127) default: return pmc_fail("unknown ablation"); }
 #undef AB
     return pmc_check_launch("maf_inverse_tri4_kernel<ablate>");
+}
+
+// Proposal (mcmc.py:77-85) + flow inverse (mcmc.py:88) in one launch; -1 when this flow / size is not covered by
+// the fused instances (the caller then launches pmc_propose and pmc_maf_inverse).
+int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* mu, const double* inv_cov,
+                                    const double* chol, double nu, double sigma, double cn_a, const pmc_rng_t* rng,
+                                    double* prop64, double* quad, double* quad_prop, const pmc_maf_t* m, float* x,
+                                    float* ladj, int64_t n, hipStream_t stream) {
+    if (m->n_out != 2 || !m->tri_ok || m->nOT > 8 || m->D > 64) return -1;
+    if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
+    const int maxo = m->nOT <= 4 ? 4 : 8;
+    const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
+    if (lds > 160 * 1024) return -1;
+    ProposeArgs pa{kind, cur32, mu, inv_cov, chol, nu, sigma, cn_a, *rng, prop64, quad, quad_prop};
+#define LAUNCHF(MO, FMV)                                                                                          \
+    {                                                                                                             \
+        if (lds > 48 * 1024) {                                                                                    \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri4_kernel<MO, 0, FMV>),    \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+            if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_inverse_tri4_kernel)");          \
+        }                                                                                                         \
+        hipLaunchKernelGGL((maf_inverse_tri4_kernel<MO, 0, FMV>), dim3((unsigned)((n + 15) / 16)), dim3(64), lds,  \
+                           stream, *m, (const float*)nullptr, x, ladj, n, pa);                                    \
+    }
+    if (m->D <= 16) { if (maxo == 4) LAUNCHF(4, 4) else LAUNCHF(8, 4) }
+    else if (m->D <= 32) { if (maxo == 4) LAUNCHF(4, 8) else LAUNCHF(8, 8) }
+    else { if (maxo == 4) LAUNCHF(4, 16) else LAUNCHF(8, 16) }
+#undef LAUNCHF
+    return pmc_check_launch("maf_inverse_tri4_kernel<fused proposal>");
 }

@@ -642,6 +642,49 @@ extern "C" int pmc_propose(int kind, const float* cur32, const double* cur64, co
     return pmc_check_launch("propose_kernel");
 }
 
+// ===========================================================================
+// Philox variates of one step ahead of time (same values as the inline draws of propose_body.h / accept_kernel)
+// ===========================================================================
+__global__ __launch_bounds__(256) void rng_fill_kernel(pmc_rng_t rng, double gamma_shape, double* __restrict__ normal,
+                                                       double* __restrict__ gamma, double* __restrict__ uniform,
+                                                       int64_t n, int D) {
+    const int pairs = (D + 1) >> 1;
+    const int slots = pairs + 2;                         // per walker: D/2 normal pairs, the gamma, the uniform
+    const int64_t total = n * slots;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t k = e / slots;
+        const int sl = (int)(e - k * slots);
+        const uint64_t gidx = rng.offset + (uint64_t)k;
+        if (sl < pairs) {
+            if (normal) {
+                Philox ph(rng.seed, rng.step, gidx, 1);
+                ph.ctr[0] = (uint32_t)sl;
+                double a, b;
+                ph.normal2(a, b);
+                normal[k * D + 2 * sl] = a;
+                if (2 * sl + 1 < D) normal[k * D + 2 * sl + 1] = b;
+            }
+        } else if (sl == pairs) {
+            if (gamma && gamma_shape > 0.0) { Philox ph(rng.seed, rng.step, gidx, 0); gamma[k] = ph.std_gamma(gamma_shape); }
+        } else if (uniform) {
+            Philox ph(rng.seed, rng.step, gidx, 2);
+            double ur, d;
+            ph.uniform2(ur, d);
+            uniform[k] = ur;
+        }
+    }
+}
+
+extern "C" int pmc_rng_fill(const pmc_rng_t* rng, double gamma_shape, double* normal, double* gamma, double* uniform,
+                            int64_t n, int32_t D, void* stream) {
+    if (!rng || n < 0 || D < 1) return pmc_fail("pmc_rng_fill: bad argument");
+    if (n == 0) return 0;
+    const int64_t total = n * (((D + 1) >> 1) + 2);
+    hipLaunchKernelGGL(rng_fill_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, *rng, gamma_shape,
+                       normal, gamma, uniform, n, (int)D);
+    return pmc_check_launch("rng_fill_kernel");
+}
+
 static int check_scaler(const pmc_scaler_t* s) {
     if (!s || !s->low || !s->high || !s->kind || s->D < 1) return pmc_fail("pmc_scaler: bad descriptor");
     if (s->scale && (!s->mu || !s->sigma)) return pmc_fail("pmc_scaler: scale=1 needs mu and sigma");

@@ -1,58 +1,6 @@
-// Proposal kernel on the f64 matrix cores (pocomc/mcmc.py:77-85, :251-253).
-//
-// One wavefront owns 16 walkers.  The three D x D products per walker of the tpCN proposal
-//     delta  = diff^T  S diff        (S = inv_cov, mcmc.py:80)
-//     L z                            (L = chol_cov, mcmc.py:85)
-//     delta' = diff'^T S diff'       (mcmc.py:127-128)
-// are batched over the 16 walkers as  S . diff^T,  L . z^T,  S . diff'^T  with
-// v_mfma_f64_16x16x4_f64 (A = matrix tile [16 i x 4 j], B = walker slice [4 j x 16 walkers]).
-// Lane (q = lane>>4, p = lane&15) keeps coordinates {q + 4m} of walker p in registers: that set
-// is at once the B operand of every K step, the rows the lane receives in the f64 C layout
-// (row = q + 4*reg), and the coordinates of theta' it produces -- so the proposal, its quadratic
-// form and the stores never leave the lane; only the two dot products need a 4-quad shuffle sum.
-//
-// float64 like the reference; the expressions of mcmc.py:80/:85 keep their operation order
-// (no FMA contraction), the D-term sums inside the products are accumulated by the MFMA.
-
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include "philox.h"
-#include "pmc_internal.h"
-
-#pragma clang fp contract(off)
-
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-#define DMFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
-
-__device__ __forceinline__ double quad_sum_d(double v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
-}
-
-// acc[it][r] = sum_j MAT[16*it + q + 4r][j] * vec[j]   for the lane's walker
-// LOWER: MAT is lower-triangular, K steps above the diagonal tile are skipped.
-template <int M, bool LOWER>
-__device__ __forceinline__ void matvec16(const double* __restrict__ mat, int D, const double (&vec)[M],
-                                         double (&res)[M], int q, int p_lane) {
-    const int i_l = p_lane;              // A operand: row within tile = lane & 15
-#pragma unroll
-    for (int it = 0; it < M / 4; ++it) {
-        if (16 * it < D) {
-            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-            const int i = 16 * it + i_l;
-#pragma unroll
-            for (int k = 0; k < M; ++k) {
-                if (4 * k < D && (!LOWER || 4 * k <= 16 * it + 15)) {
-                    const int j = 4 * k + q;
-                    const double a = (i < D && j < D) ? mat[(size_t)i * D + j] : 0.0;
-                    acc = DMFMA(a, vec[k], acc);
-                }
-            }
-            res[4 * it + 0] = acc[0]; res[4 * it + 1] = acc[1]; res[4 * it + 2] = acc[2]; res[4 * it + 3] = acc[3];
-        }
-    }
-}
+// Proposal kernel on the f64 matrix cores (pocomc/mcmc.py:77-85, :251-253): propose_body.h, one wavefront per
+// 16 walkers.
+#include "propose_body.h"
 
 template <int M>
 __global__ __launch_bounds__(64) void propose_mfma_kernel(
@@ -61,83 +9,8 @@ __global__ __launch_bounds__(64) void propose_mfma_kernel(
     double nu, double sigma, double cn_a, pmc_rng_t rng, double* __restrict__ prop64,
     float* __restrict__ prop32, double* __restrict__ quad, double* __restrict__ quad_prop,
     int64_t n, int D) {
-    const int lane = threadIdx.x;
-    const int q = lane >> 4, p = lane & 15;
-    const int64_t k_w = (int64_t)blockIdx.x * 16 + p;          // this lane's walker
-    const bool live = k_w < n;
-    const int64_t gidx = rng.offset + k_w;
-    const bool tpcn = (kind == PMC_KIND_TPCN);
-
-    // coordinates j = q + 4m of the walker: current position (minus mu for tpCN), noise
-    double dif[M], zz[M], muv[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        const int j = q + 4 * m;
-        double v = 0.0, z = 0.0, mj = 0.0;
-        if (j < D) {
-            mj = tpcn ? mu[j] : 0.0;
-            if (live) {
-                v = cur32 ? (double)cur32[k_w * D + j] : cur64[k_w * D + j];
-                if (rng.normal) z = rng.normal[k_w * D + j];
-                else {
-                    Philox ph(rng.seed, rng.step, gidx, 1);
-                    ph.ctr[0] = (uint32_t)(j >> 1);              // pair index: same stream as a sequential walk
-                    double a, b;
-                    ph.normal2(a, b);
-                    z = (j & 1) ? b : a;
-                }
-            }
-        }
-        muv[m] = mj;
-        dif[m] = tpcn ? v - mj : v;
-        zz[m] = z;
-    }
-
-    double scale_z = sigma, q_cur = 0.0;
-    double tmp[M];
-    if (tpcn) {
-        matvec16<M, false>(inv_cov, D, dif, tmp, q, p);         // rows q+4m of S.diff
-        double part = 0.0;
-#pragma unroll
-        for (int m = 0; m < M; ++m) part += dif[m] * tmp[m];
-        q_cur = quad_sum_d(part);
-        double g;
-        if (rng.gamma) g = live ? rng.gamma[k_w] : 1.0;
-        else { Philox ph(rng.seed, rng.step, gidx, 0); g = ph.std_gamma(0.5 * ((double)D + nu)); }
-        const double s = 1.0 / ((2.0 / (nu + q_cur)) * g);       // 1/np.random.gamma(shape, scale), mcmc.py:80
-        scale_z = sigma * sqrt(s);
-    }
-    matvec16<M, true>(chol, D, zz, tmp, q, p);                  // rows q+4m of L.z
-    double prop[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        if (tpcn) prop[m] = (muv[m] + cn_a * dif[m]) + scale_z * tmp[m];     // mcmc.py:85
-        else prop[m] = dif[m] + scale_z * tmp[m];                             // mcmc.py:253
-    }
-    if (tpcn) {
-        double dp[M];
-#pragma unroll
-        for (int m = 0; m < M; ++m) dp[m] = (q + 4 * m < D) ? prop[m] - muv[m] : 0.0;
-        matvec16<M, false>(inv_cov, D, dp, tmp, q, p);
-        double part = 0.0;
-#pragma unroll
-        for (int m = 0; m < M; ++m) part += dp[m] * tmp[m];
-        const double q_new = quad_sum_d(part);
-        if (live && q == 0) {
-            if (quad) quad[k_w] = q_cur;
-            if (quad_prop) quad_prop[k_w] = q_new;
-        }
-    }
-    if (live) {
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const int j = q + 4 * m;
-            if (j < D) {
-                if (prop64) prop64[k_w * D + j] = prop[m];
-                if (prop32) prop32[k_w * D + j] = (float)prop[m];
-            }
-        }
-    }
+    propose_body<M>(kind, cur32, cur64, mu, inv_cov, chol, nu, sigma, cn_a, rng, prop64, prop32, quad, quad_prop, n, D,
+                    nullptr, nullptr);
 }
 
 template <int M>

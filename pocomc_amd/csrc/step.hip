@@ -2,7 +2,7 @@
 // before and after the host's prior / likelihood call, enqueued by ONE C call each, so that the
 // host-side driver spends its time in the user's black boxes instead of in dispatch overhead.
 //
-//   pmc_step_pre :  [H2D mu] -> propose -> flow inverse -> scaler inverse [+ prior] -> D2H x', finite
+//   pmc_step_pre :  [H2D mu] -> propose -> flow inverse (one launch for the affine flows) -> scaler inverse [+ prior] -> D2H x', finite
 //   pmc_step_post:  H2D logl', logp' -> accept + reductions -> D2H sums
 //
 // Pure sequencing of the single-purpose entry points (same kernels, same stream order); host
@@ -18,6 +18,36 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
     const int64_t n = s->n;
     const int32_t D = s->D;
     const bool tpcn = (s->kind == PMC_KIND_TPCN);
+    // throughput mode: this step's Philox variates were drawn ahead of time (see pmc_step_t.rng_normal)
+    pmc_rng_t rr = *rng;
+    const bool prefill = s->rng_ready && s->rng_normal[0] && s->rng_normal[1] && s->rng_uniform[0] &&
+                         s->rng_uniform[1] && (!tpcn || (s->rng_gamma[0] && s->rng_gamma[1])) && !rng->normal &&
+                         !rng->gamma && !rng->uniform;
+    const int rb = (int)(rng->step & 1);
+    const double gshape = tpcn ? 0.5 * ((double)D + nu) : 0.0;             // mcmc.py:80
+    if (prefill) {
+        if (*s->rng_ready != (int64_t)rng->step) {                       // first step of a run
+            int rcf = pmc_rng_fill(rng, gshape, s->rng_normal[rb], s->rng_gamma[rb], s->rng_uniform[rb], n, D, stream);
+            if (rcf) return rcf;
+        }
+        rr.normal = s->rng_normal[rb];
+        rr.gamma = tpcn ? s->rng_gamma[rb] : nullptr;
+        rng = &rr;
+    }
+    // what follows the last kernel whose results the host waits for
+    auto finish = [&]() -> int {
+        if (s->ev_pre_done) (void)hipEventRecord((hipEvent_t)s->ev_pre_done, st);
+        if (prefill) {
+            pmc_rng_t nx = *rng;
+            nx.normal = nullptr; nx.gamma = nullptr; nx.uniform = nullptr;
+            nx.step = rng->step + 1;
+            int rcf = pmc_rng_fill(&nx, gshape, s->rng_normal[rb ^ 1], s->rng_gamma[rb ^ 1], s->rng_uniform[rb ^ 1], n, D,
+                                   stream);
+            if (rcf) return rcf;
+            *s->rng_ready = (int64_t)nx.step;
+        }
+        return 0;
+    };
     // host_direct: the kernels read mu from / write x', finite, logp' to pinned host memory themselves
     const bool direct = s->host_direct && !s->p_xT;
     const double* mu = s->mu;
@@ -26,11 +56,26 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
         else if (hipMemcpyAsync((void*)s->mu, s->h_mu, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
             return pmc_fail("pmc_step_pre: H2D mu");
     }
-    int rc = pmc_propose(s->kind, s->preconditioned ? s->cur.theta32 : nullptr, s->preconditioned ? nullptr : s->cur.u,
+    int rc;
+    bool fused = false;
+    if (s->preconditioned && !s->no_fuse &&
+        (s->inverse_algo == PMC_INVERSE_AUTO || s->inverse_algo == PMC_INVERSE_TRIANGULAR)) {
+        // proposal + flow inverse in one launch (affine flows, D <= 64)
+        if (s->ev_inv0) (void)hipEventRecord((hipEvent_t)s->ev_inv0, st);
+        rc = pmc_launch_propose_inverse_tri4(s->kind, s->cur.theta32, mu, s->inv_cov, s->chol, nu, sigma, cn_a, rng,
+                                             s->p_theta64, tpcn ? s->quad : nullptr, tpcn ? s->p_quad : nullptr, s->maf,
+                                             s->p_u32, s->p_ldjf, n, st);
+        if (rc > 0) return rc;
+        fused = (rc == 0);
+        if (fused && s->ev_inv1) (void)hipEventRecord((hipEvent_t)s->ev_inv1, st);
+    }
+    if (!fused) {
+        rc = pmc_propose(s->kind, s->preconditioned ? s->cur.theta32 : nullptr, s->preconditioned ? nullptr : s->cur.u,
                          mu, s->inv_cov, s->chol, nu, sigma, cn_a, rng, s->p_theta64,
                          s->preconditioned ? s->p_theta32 : nullptr, tpcn ? s->quad : nullptr,
                          tpcn ? s->p_quad : nullptr, n, D, stream);
-    if (rc) return rc;
+        if (rc) return rc;
+    }
     // scaler inverse and (when it runs on the device) Prior.logpdf share one launch
     const pmc_prior_t* pr = s->prior;
     double* lp = pr ? s->p_logp : nullptr;
@@ -38,10 +83,12 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
     int32_t* fin2 = direct ? s->h_fin : nullptr;
     double* lp2 = (direct && pr) ? s->h_logp_out : nullptr;
     if (s->preconditioned) {
-        if (s->ev_inv0) (void)hipEventRecord((hipEvent_t)s->ev_inv0, st);
-        rc = pmc_maf_inverse(s->maf, s->p_theta32, s->p_u32, s->p_ldjf, n, s->inverse_algo, stream);
-        if (s->ev_inv1) (void)hipEventRecord((hipEvent_t)s->ev_inv1, st);
-        if (rc) return rc;
+        if (!fused) {
+            if (s->ev_inv0) (void)hipEventRecord((hipEvent_t)s->ev_inv0, st);
+            rc = pmc_maf_inverse(s->maf, s->p_theta32, s->p_u32, s->p_ldjf, n, s->inverse_algo, stream);
+            if (s->ev_inv1) (void)hipEventRecord((hipEvent_t)s->ev_inv1, st);
+            if (rc) return rc;
+        }
         rc = pmc_scaler_inverse_prior(s->scaler, pr, s->p_u32, nullptr, s->p_u, s->p_x, xT, s->p_logdetj, s->p_fin, lp,
                                       fin2, lp2, n, stream);
     } else {
@@ -49,7 +96,7 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
                                       lp, fin2, lp2, n, stream);
     }
     if (rc) return rc;
-    if (direct) return 0;
+    if (direct) return finish();
     if (pr) {
         if (hipMemcpyAsync(s->h_logp_out, s->p_logp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess)
             return pmc_fail("pmc_step_pre: D2H logp");
@@ -58,7 +105,21 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
     if (hipMemcpyAsync(s->h_x, xsrc, (size_t)n * D * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(s->h_fin, s->p_fin, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess)
         return pmc_fail("pmc_step_pre: D2H");
-    return 0;
+    return finish();
+}
+
+extern "C" int pmc_propose_inverse(int kind, const float* cur32, const double* mu, const double* inv_cov,
+                                   const double* chol, double nu, double sigma, double cn_a, const pmc_rng_t* rng,
+                                   double* prop64, double* quad, double* quad_prop, const pmc_maf_t* maf, float* u_out,
+                                   float* ladj, int64_t n, void* stream) {
+    if (!cur32 || !chol || !rng || !prop64 || !maf || !u_out || n < 0) return pmc_fail("pmc_propose_inverse: bad argument");
+    if (kind == PMC_KIND_TPCN && (!mu || !inv_cov || !quad || !quad_prop))
+        return pmc_fail("pmc_propose_inverse: tpCN needs mu, inv_cov and the quadratic-form outputs");
+    if (n == 0) return 0;
+    const int rc = pmc_launch_propose_inverse_tri4(kind, cur32, mu, inv_cov, chol, nu, sigma, cn_a, rng, prop64, quad,
+                                                   quad_prop, maf, u_out, ladj, n, (hipStream_t)stream);
+    if (rc < 0) return pmc_fail("pmc_propose_inverse: only the affine flows with D <= 64 have a fused instance");
+    return rc;
 }
 
 extern "C" int pmc_step_post(const pmc_step_t* s, const pmc_rng_t* rng, double beta, double nu, int want_mask,
@@ -66,6 +127,12 @@ extern "C" int pmc_step_post(const pmc_step_t* s, const pmc_rng_t* rng, double b
     if (!s || !rng) return pmc_fail("pmc_step_post: null argument");
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = s->n;
+    pmc_rng_t rr = *rng;
+    if (s->rng_ready && s->rng_uniform[0] && s->rng_uniform[1] && !rng->uniform && !rng->normal && !rng->gamma &&
+        *s->rng_ready == (int64_t)rng->step + 1) {
+        rr.uniform = s->rng_uniform[rng->step & 1];                      // drawn ahead of time by pmc_step_pre
+        rng = &rr;
+    }
     const bool direct = s->host_direct && !s->p_xT;
     if (!direct) {
         if (hipMemcpyAsync(s->p_logl, s->h_logl, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
@@ -116,6 +183,10 @@ extern "C" void* pmc_event_create(void) {
 extern "C" int pmc_event_record(void* ev, void* stream) {
     hipError_t e = hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
     return e == hipSuccess ? 0 : pmc_fail_hip(e, "hipEventRecord");
+}
+extern "C" int pmc_event_synchronize(void* ev) {
+    hipError_t e = hipEventSynchronize((hipEvent_t)ev);
+    return e == hipSuccess ? 0 : pmc_fail_hip(e, "hipEventSynchronize");
 }
 extern "C" float pmc_event_elapsed_ms(void* a, void* b) {
     float ms = -1.0f;

@@ -184,6 +184,19 @@ class StepEngine:
             h_accept=self.h_accept.data_ptr())
         self._rng_fast = _lib.pmc_rng_t(gamma=None, normal=None, uniform=None, seed=self.seed, step=0,
                                         offset=self.offset)
+        # throughput mode: the Philox variates of step k+1 are generated behind step k's kernels, while the host
+        # evaluates the likelihood (pmc_step_t.rng_normal ...); two buffer sets, used alternately
+        self.rng_prefill = True
+        self._pf_normal = [f64(n, D), f64(n, D)]
+        self._pf_gamma = [f64(n), f64(n)]
+        self._pf_uniform = [f64(n), f64(n)]
+        self._rng_ready = C.c_int64(-1)
+        self._ev_pre = self.lib.pmc_event_create()
+        for b in range(2):
+            self._step.rng_normal[b] = self._pf_normal[b].data_ptr()
+            self._step.rng_gamma[b] = self._pf_gamma[b].data_ptr()
+            self._step.rng_uniform[b] = self._pf_uniform[b].data_ptr()
+        self._step.ev_pre_done = self._ev_pre
         self.prior_desc = None   # pmc_prior_t when Prior.logpdf runs on the device (set_device_prior)
         self.composite = True    # one C call before / after the host black boxes (pmc_step_pre / _post)
         # x_order 'F' on the composite path: the scaler kernel writes x', the finite mask and logp' straight
@@ -195,6 +208,15 @@ class StepEngine:
         self._pool = None
         self.events = None       # bench.py: list of per-step HIP event tuples when not None
         self.host_timers = None  # bench.py: dict of accumulated host seconds when not None
+
+    def __del__(self):
+        ev = getattr(self, "_ev_pre", None)
+        if ev:
+            try:
+                self.lib.pmc_event_destroy(ev)
+            except Exception:
+                pass
+            self._ev_pre = None
 
     def _ev(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -268,6 +290,7 @@ class StepEngine:
                 self._rng_cur = self._rng_fast
             if self.pre:
                 self._step.inverse_algo = self.flow.inverse_algo
+            self._step.rng_ready = C.cast(C.pointer(self._rng_ready), C.c_void_p) if self.rng_prefill else None
             direct = bool(self.host_direct and self.x_order == "F")
             self._step.host_direct = int(direct)
             self._step.p_xT = None if (direct or self.p_xT is None) else self.p_xT.data_ptr()
@@ -323,7 +346,8 @@ class StepEngine:
         tm = self.host_timers
         t0 = time.perf_counter() if tm is not None else 0.0
         if self._post_uploads:
-            _lib.check(self.lib.pmc_stream_synchronize(self._stream), "pmc_stream_synchronize")
+            # x', finite, logp' are complete at this event; the next step's variates are generated behind it
+            _lib.check(self.lib.pmc_event_synchronize(self._ev_pre), "pmc_event_synchronize")
         else:
             torch.cuda.current_stream().synchronize()
         if tm is not None:
@@ -486,6 +510,8 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
                      x_order=option_dict.get("x_order", "C"))
     if "host_direct" in option_dict:
         eng.host_direct = bool(option_dict["host_direct"])
+    if "rng_prefill" in option_dict:
+        eng.rng_prefill = bool(option_dict["rng_prefill"])
     owner = getattr(log_prior, "__self__", None)
     if owner is not None and option_dict.get("device_prior", True) and hasattr(owner, "device_descriptor"):
         eng.set_device_prior(owner)                 # Prior.logpdf of uniform / normal factors on the device

@@ -200,3 +200,72 @@ def test_philox_mode_statistics():
     calls, _ = eng.evaluate(funcs["logprior"], funcs["loglike"])
     sums = eng.accept_reduce(c["beta"], 5.0)
     assert 0.0 <= sums[0] / N <= 1.0
+
+
+@pytest.mark.parametrize("D,N,kind", [(4, 100, 0), (10, 333, 0), (32, 1000, 0), (50, 77, 0), (6, 64, 1)])
+def test_fused_proposal_and_inverse_equal_the_two_launches(D, N, kind):
+    """pmc_propose_inverse (the proposal as prologue of the flow-inverse kernel) gives bit for bit the
+    theta', quadratic forms, u' and log-determinant of pmc_propose followed by pmc_maf_inverse."""
+    import ctypes as C
+    import torch
+    import pocomc_amd as pc
+    from pocomc_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(D)
+    flow = pc.Flow(D, "maf3", seed=1)
+    A = rng.normal(size=(D, D))
+    cov = A @ A.T / D + np.eye(D)
+    up = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).cuda()
+    mu, icov, chol = up(rng.normal(size=D)), up(np.linalg.inv(cov)), up(np.linalg.cholesky(cov))
+    cur32 = up(rng.normal(size=(N, D)), torch.float32)
+    r = _lib.pmc_rng_t(gamma=None, normal=None, uniform=None, seed=1234, step=7, offset=5)
+    mk = lambda *s, dt=torch.float64: torch.zeros(*s, dtype=dt, device="cuda")
+    st = _lib.stream_handle()
+    # two launches
+    t64, t32, qa, qb = mk(N, D), mk(N, D, dt=torch.float32), mk(N), mk(N)
+    _lib.check(lib.pmc_propose(kind, _lib.ptr(cur32), None, _lib.ptr(mu), _lib.ptr(icov), _lib.ptr(chol), 5.0, 0.4,
+                               float((1 - 0.4 ** 2) ** 0.5), C.byref(r), _lib.ptr(t64), _lib.ptr(t32), _lib.ptr(qa),
+                               _lib.ptr(qb), N, D, st))
+    u_a, l_a = mk(N, D, dt=torch.float32), mk(N, dt=torch.float32)
+    _lib.check(lib.pmc_maf_inverse(C.byref(flow._desc), _lib.ptr(t32), _lib.ptr(u_a), _lib.ptr(l_a), N, 0, st))
+    # one launch
+    t64f, qaf, qbf = mk(N, D), mk(N), mk(N)
+    u_b, l_b = mk(N, D, dt=torch.float32), mk(N, dt=torch.float32)
+    _lib.check(lib.pmc_propose_inverse(kind, _lib.ptr(cur32), _lib.ptr(mu), _lib.ptr(icov), _lib.ptr(chol), 5.0, 0.4,
+                                       float((1 - 0.4 ** 2) ** 0.5), C.byref(r), _lib.ptr(t64f), _lib.ptr(qaf),
+                                       _lib.ptr(qbf), C.byref(flow._desc), _lib.ptr(u_b), _lib.ptr(l_b), N, st))
+    for a, b in ((t64, t64f), (u_a, u_b), (l_a, l_b)) + (((qa, qaf), (qb, qbf)) if kind == 0 else ()):
+        assert torch.equal(a, b)
+
+
+def test_variates_drawn_ahead_equal_inline_draws():
+    """pmc_rng_fill writes exactly the Philox variates the kernels draw inline, so a kernel call with the
+    variates of step k+1 generated behind step k (rng_prefill) is bit-identical to one that draws inline."""
+    from scipy.stats import uniform
+    import pocomc_amd as pc
+    from pocomc_amd import mcmc as pmcmc
+    from pocomc_amd.geometry import Geometry
+    import torch
+    D, N = 7, 600
+    prior = pc.Prior([uniform(-5, 10)] * D)
+    rng = np.random.default_rng(5)
+    scaler = pc.Reparameterize(D, bounds=prior.bounds)
+    scaler.fit(prior.rvs(2000))
+    x = rng.uniform(-4, 4, size=(N, D))
+    u = scaler.forward(x)
+    like = lambda xx: (-0.5 * np.sum(xx ** 2, axis=1), None)
+    flow = pc.Flow(D, "maf3", seed=0)
+    geo = Geometry()
+    geo.fit(flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64))
+    for kind in ("preconditioned_pcn", "preconditioned_rwm"):
+        res = []
+        for pf in (True, False):
+            state = dict(u=u.copy(), x=x.copy(), logdetj=scaler.inverse(u)[1], logl=like(x)[0], logp=prior.logpdf(x),
+                         beta=0.5, blobs=None)
+            funcs = dict(loglike=like, logprior=prior.logpdf, scaler=scaler, flow=flow, theta_geometry=geo)
+            opts = dict(n_max=7, n_steps=10 ** 6, progress_bar=None, proposal_scale=2.38 / D ** 0.5, seed=11,
+                        rng_prefill=pf)
+            res.append(getattr(pmcmc, kind)(state, funcs, opts))
+        for k in ("u", "x", "logl", "logp", "logdetj"):
+            assert np.array_equal(res[0][k], res[1][k]), (kind, k)
+        assert res[0]["accept"] == res[1]["accept"]
