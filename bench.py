@@ -317,26 +317,30 @@ def main():
     actual_flops = n * 2 * spec.macs_masked()                     # what the triangular sweep needs
     us["maf_inverse_timed_region"] = inv_us_live            # HIP events inside the timed region
     t_inv = inv_us_live * 1e-6
+    fused = eng.pre and spec.univariate == "affine" and spec.tri_ok and spec.nOT <= 8 and args.inverse in ("auto", "triangular")
+    roof_kernel = ("maf_dense_kernel<1>" if (args.inverse == "naive" or not spec.tri_ok) else
+                   "maf_inverse_tri_nsf_kernel" if spec.univariate == "rqs" else
+                   {"triangular_v1": "maf_inverse_tri_kernel", "triangular_v2": "maf_inverse_tri2_kernel",
+                    "triangular_v3": "maf_inverse_tri3_kernel"}.get(
+                       args.inverse, "maf_inverse_tri4_kernel" if spec.nOT <= 8 else "maf_inverse_tri2_kernel"))
     # HBM bytes per launch of the dominant kernel: PMC passes cannot run inside this process, the value
     # is the committed rocprofv3 measurement of this very command (profiles/r01_c_rocprof_summary.txt)
     traffic = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if n == 10000 and D == 32 and args.inverse == "auto" and args.flow == "maf3":
+        if n == 10000 and D == 32 and args.inverse == "auto" and args.flow == "maf3" and pm.get("kernel", "").startswith(roof_kernel):
             traffic = {"hbm_bytes_per_launch": pm["hbm_bytes_per_launch"], "unit": "B", "source": pm["source"],
                        "correction": pm["correction"]}
     except (OSError, KeyError, ValueError):
         pass
     achieved = algo_flops / t_inv / 1e12
-    roofline = {"bound": "mfma", "kernel": ("maf_dense_kernel<1>" if (args.inverse == "naive" or not spec.tri_ok) else
-                           "maf_inverse_tri_nsf_kernel" if spec.univariate == "rqs" else
-                           {"triangular_v1": "maf_inverse_tri_kernel", "triangular_v2": "maf_inverse_tri2_kernel",
-                            "triangular_v3": "maf_inverse_tri3_kernel"}.get(
-                               args.inverse, "maf_inverse_tri4_kernel" if spec.nOT <= 8 else "maf_inverse_tri2_kernel")), "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+    roofline = {"bound": "mfma", "kernel": roof_kernel, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                 "avg_launch_us": inv_us_live, "launches_timed": len(ev_pairs[::args.event_every]),
                 "note": "achieved = SURVEY 8(d) naive-equivalent flops ((D+1)*F_fwd per walker) / launch time; the "
-                        "triangular sweep executes only the masked MACs once, so frac > 1 is an algorithmic gain",
+                        "triangular sweep executes only the masked MACs once, so frac > 1 is an algorithmic gain"
+                        + ("; the launch also proposes theta' for its walkers (fused proposal prologue, ~15 us)" if fused else ""),
+                "fused_proposal": bool(fused),
                 "actual_tflops": actual_flops / t_inv / 1e12,
                 "actual_frac": actual_flops / t_inv / 1e12 / PEAK_F32_MFMA_TFLOPS}
     ms_per_step = dt / args.steps * 1e3
