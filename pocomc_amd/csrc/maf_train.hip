@@ -34,6 +34,9 @@
 #ifndef TRAIN_PF
 #define TRAIN_PF 4                  // weight fragments in flight per wave
 #endif
+#ifndef TRAIN_WARM_L2
+#define TRAIN_WARM_L2 1
+#endif
 #ifndef TRAIN_WAVES
 #define TRAIN_WAVES 8
 #endif
@@ -154,6 +157,19 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
         for (int k = 0; k < TRAIN_WAVES; ++k) tot += RED[k];
         wscale = wmul / tot;
         __syncthreads();
+    }
+
+    // Both weight images were rewritten by the previous batch's optimizer step, so this XCD's L2 holds none of
+    // them and every layer would start with a miss to MALL / HBM (~1.5-2 k cycles, ~45 dependent phases).
+    // Workgroups are dealt round-robin to the 8 XCDs: the workgroups of one XCD each touch a share of the two
+    // images once, up front (one dword per 128-byte line, consumed at the very end so nothing waits on them).
+    float warm = 0.0f;
+    if (TRAIN_WARM_L2) {
+        const int per_xcd = max(1, (int)((gridDim.x + 7) >> 3));
+        const int share = min((int)(blockIdx.x >> 3), per_xcd - 1);
+        const int64_t lines_a = ((int64_t)T * m.pk_per_transform * 4) >> 7, lines_b = ((int64_t)T * tr.pkT_per_transform * 4) >> 7;
+        for (int64_t l = (int64_t)share * TRAIN_THREADS + tid; l < lines_a + lines_b; l += (int64_t)per_xcd * TRAIN_THREADS)
+            warm += (l < lines_a) ? m.packed[l << 5] : tr.packedT[(l - lines_a) << 5];
     }
 
     float loss_acc = 0.0f;
@@ -308,8 +324,8 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                 }
                 for (int O = wv; O < nOeff; O += TRAIN_WAVES)
                     bias_put(slab + tv.gb3 + 16 * O + 4 * q, rows_of(P, O, q, p), lane, first);
-                for (int i = wv; i < nOeff * nT; i += TRAIN_WAVES) {
-                    const int O = i / nT, K = i - O * nT;
+                for (int i = wv, O = 0, K = wv; i < nOeff * nT; i += TRAIN_WAVES, K += TRAIN_WAVES) {
+                    while (K >= nT) { K -= nT; ++O; }              // (O, K) of tile i without a division
                     slab_put4(slab + tv.g3 + ((size_t)i * 64 + lane) * 4, outer_tile(P, O, Cb, K, lane), first);
                 }
                 PHASE_END(6)
@@ -349,8 +365,8 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                     }
                     for (int i = wv; i < nO; i += TRAIN_WAVES)
                         bias_put(slab + tv.gb3 + 16 * (O0 + i) + 4 * q, rows_of(P, i, q, p), lane, first);
-                    for (int i = wv; i < nO * nT; i += TRAIN_WAVES) {
-                        const int Ol = i / nT, K = i - Ol * nT;
+                    for (int i = wv, Ol = 0, K = wv; i < nO * nT; i += TRAIN_WAVES, K += TRAIN_WAVES) {
+                        while (K >= nT) { K -= nT; ++Ol; }
                         slab_put4(slab + tv.g3 + (((size_t)(O0 + Ol) * nT + K) * 64 + lane) * 4,
                                   outer_tile(P, Ol, Cb, K, lane), first);
                     }
@@ -365,28 +381,31 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                 PHASE_END(6)
             }
             // ---- layer 2: da1 = relu'(h1) . (da2 + W2^T da2) -> C ; dW2 (da2 x h1), db1
-            for (int Ti = 0; Ti < nT; ++Ti) {
-                if (snake_owner<TRAIN_WAVES>(Ti) != wv) continue;
+            for (int it = 0;; ++it) {                              // the tiles this wave owns, most expensive first
+                const int Ti = snake_item<TRAIN_WAVES>(wv, it);
+                if (Ti >= nT) break;
                 f32x4 a = rows_of(E, Ti, q, p);
                 a = mac_range<TRAIN_PF>(a, tv.f2T + (size_t)Ti * nT * 64, E, (m.tri_ok ? Ti : 0), nT, lane);
                 a = relu_gate(a, B, Ti, q, p);
                 store_rows(Cb, Ti, q, p, a);
                 bias_put(slab + tv.gb1 + 16 * Ti + 4 * q, a, lane, first);
             }
-            {
-                int i = 0;
-                for (int To = 0; To < nT; ++To) {
-                    const int kend = m.tri_ok ? To + 1 : nT;
-                    for (int Ti = 0; Ti < kend; ++Ti, ++i)
-                        if (i % TRAIN_WAVES == wv)
-                            slab_put4(slab + tv.g2 + (((size_t)To * nT + Ti) * 64 + lane) * 4,
-                                      outer_tile(E, To, B, Ti, lane), first);
+            {   // weight-gradient tiles (To, Ti <= To): every TRAIN_WAVES-th one in row-major order is this wave's
+                int To = 0, Ti = wv;
+                for (;;) {
+                    if (m.tri_ok) { while (Ti > To) { Ti -= To + 1; ++To; } }
+                    else { while (Ti >= nT) { Ti -= nT; ++To; } }
+                    if (To >= nT) break;
+                    slab_put4(slab + tv.g2 + (((size_t)To * nT + Ti) * 64 + lane) * 4, outer_tile(E, To, B, Ti, lane),
+                              first);
+                    Ti += TRAIN_WAVES;
                 }
             }
             PHASE_END(7)
             // ---- layer 1: da0 = relu'(h0) . (da1 + W1^T da1) -> E ; dW1 (da1 x h0), db0 ; x_t -> B
-            for (int Ti = 0; Ti < nT; ++Ti) {
-                if (snake_owner<TRAIN_WAVES>(Ti) != wv) continue;
+            for (int it = 0;; ++it) {
+                const int Ti = snake_item<TRAIN_WAVES>(wv, it);
+                if (Ti >= nT) break;
                 f32x4 a = rows_of(Cb, Ti, q, p);
                 a = mac_range<TRAIN_PF>(a, tv.f1T + (size_t)Ti * nT * 64, Cb, (m.tri_ok ? Ti : 0), nT, lane);
                 a = relu_gate(a, A, Ti, q, p);
@@ -394,14 +413,15 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                 bias_put(slab + tv.gb0 + 16 * Ti + 4 * q, a, lane, first);
             }
             for (int e = tid; e < Dp * 4; e += TRAIN_THREADS) reinterpret_cast<float4*>(B)[e] = xsrc[e];
-            {
-                int i = 0;
-                for (int To = 0; To < nT; ++To) {
-                    const int kend = m.tri_ok ? To + 1 : nT;
-                    for (int Ti = 0; Ti < kend; ++Ti, ++i)
-                        if (i % TRAIN_WAVES == wv)
-                            slab_put4(slab + tv.g1 + (((size_t)To * nT + Ti) * 64 + lane) * 4,
-                                      outer_tile(Cb, To, A, Ti, lane), first);
+            {   // weight-gradient tiles (To, Ti <= To): every TRAIN_WAVES-th one in row-major order is this wave's
+                int To = 0, Ti = wv;
+                for (;;) {
+                    if (m.tri_ok) { while (Ti > To) { Ti -= To + 1; ++To; } }
+                    else { while (Ti >= nT) { Ti -= nT; ++To; } }
+                    if (To >= nT) break;
+                    slab_put4(slab + tv.g1 + (((size_t)To * nT + Ti) * 64 + lane) * 4, outer_tile(Cb, To, A, Ti, lane),
+                              first);
+                    Ti += TRAIN_WAVES;
                 }
             }
             PHASE_END(8)
@@ -413,8 +433,11 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                     store_rows(P, Xi, q, p, a);
                 }
             }
-            for (int i = TRAIN_WAVES - 1 - wv; i < nT * nXT; i += TRAIN_WAVES)
-                slab_put4(slab + tv.g0 + ((size_t)i * 64 + lane) * 4, outer_tile(E, i / nXT, B, i % nXT, lane), first);
+            for (int i = TRAIN_WAVES - 1 - wv, To = 0, Xi = TRAIN_WAVES - 1 - wv; i < nT * nXT;
+                 i += TRAIN_WAVES, Xi += TRAIN_WAVES) {
+                while (Xi >= nXT) { Xi -= nXT; ++To; }
+                slab_put4(slab + tv.g0 + ((size_t)i * 64 + lane) * 4, outer_tile(E, To, B, Xi, lane), first);
+            }
             PHASE_END(9)
             if (t > 0) {
                 // re-rank for transform t-1 (its output order)
@@ -426,6 +449,7 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
             }
         }
     }
+    if (TRAIN_WARM_L2) asm volatile("" :: "v"(warm));
     if (tid == 0) tr.loss_partial[blockIdx.x] = loss_acc;
     if (PROF && lane == 0) {
         pacc[0] = TICKT() - t_begin;
