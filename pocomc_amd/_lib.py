@@ -28,7 +28,8 @@ class pmc_maf_train_t(C.Structure):
     _fields_ = [("packedT", c_p), ("gmap", c_p), ("pkT_per_transform", C.c_int64),
                 ("gmap_per_transform", C.c_int64),
                 ("slabs", c_p), ("slab_stride", C.c_int64), ("n_slabs", C.c_int32), ("n_sq_partial", C.c_int32),
-                ("xt_scratch", c_p), ("loss_partial", c_p), ("sq_partial", c_p), ("wsum", c_p)]
+                ("xt_scratch", c_p), ("loss_partial", c_p), ("sq_partial", c_p),
+                ("sched", c_p), ("sched_waves", C.c_int32), ("reserved", C.c_int32), ("wsum", c_p)]
 
 
 class pmc_adamw_t(C.Structure):
@@ -116,6 +117,7 @@ SIGNATURES = {
     "pmc_event_record": (C.c_int, [c_p, c_p]),
     "pmc_event_elapsed_ms": (C.c_float, [c_p, c_p]),
     "pmc_event_synchronize": (C.c_int, [c_p]),
+    "pmc_debug_train_waves": (C.c_int, []),
     "pmc_rng_fill": (C.c_int, [P(pmc_rng_t), f64, c_p, c_p, c_p, i64, i32, c_p]),
     "pmc_event_destroy": (None, [c_p]),
     "pmc_logw": (C.c_int, [c_p, c_p, c_p, f64, c_p, i32, i64, c_p]),

@@ -35,10 +35,10 @@
 #define TRAIN_PF 4                  // weight fragments in flight per wave
 #endif
 #ifndef TRAIN_WARM_L2
-#define TRAIN_WARM_L2 1
+#define TRAIN_WARM_L2 0      // measured neutral on MI355X (the phases are not L2-miss bound)
 #endif
 #ifndef TRAIN_WAVES
-#define TRAIN_WAVES 8
+#define TRAIN_WAVES 16
 #endif
 #define TRAIN_THREADS (64 * TRAIN_WAVES)
 
@@ -171,6 +171,12 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
         for (int64_t l = (int64_t)share * TRAIN_THREADS + tid; l < lines_a + lines_b; l += (int64_t)per_xcd * TRAIN_THREADS)
             warm += (l < lines_a) ? m.packed[l << 5] : tr.packedT[(l - lines_a) << 5];
     }
+
+    // contiguous ranges of weight-gradient tiles per phase (layer 3 | layers 2,1 | layer 0), balanced on the host
+    // against the data-gradient tiles the dealing rules give each wave (MAFSpec.train_schedule)
+    const int dw3_start = tr.sched[(0 * TRAIN_WAVES + wv) * 2], dw3_count = tr.sched[(0 * TRAIN_WAVES + wv) * 2 + 1];
+    const int dwt_start = tr.sched[(1 * TRAIN_WAVES + wv) * 2], dwt_count = tr.sched[(1 * TRAIN_WAVES + wv) * 2 + 1];
+    const int dw0_start = tr.sched[(2 * TRAIN_WAVES + wv) * 2], dw0_count = tr.sched[(2 * TRAIN_WAVES + wv) * 2 + 1];
 
     float loss_acc = 0.0f;
     bool first = true;
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                 }
                 for (int O = wv; O < nOeff; O += TRAIN_WAVES)
                     bias_put(slab + tv.gb3 + 16 * O + 4 * q, rows_of(P, O, q, p), lane, first);
-                for (int i = wv, O = 0, K = wv; i < nOeff * nT; i += TRAIN_WAVES, K += TRAIN_WAVES) {
+                for (int i = dw3_start, O = 0, K = dw3_start; i < dw3_start + dw3_count; ++i, ++K) {
                     while (K >= nT) { K -= nT; ++O; }              // (O, K) of tile i without a division
                     slab_put4(slab + tv.g3 + ((size_t)i * 64 + lane) * 4, outer_tile(P, O, Cb, K, lane), first);
                 }
@@ -390,15 +396,13 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                 store_rows(Cb, Ti, q, p, a);
                 bias_put(slab + tv.gb1 + 16 * Ti + 4 * q, a, lane, first);
             }
-            {   // weight-gradient tiles (To, Ti <= To): every TRAIN_WAVES-th one in row-major order is this wave's
-                int To = 0, Ti = wv;
-                for (;;) {
+            {   // weight-gradient tiles (To, Ti <= To) in row-major order: this wave's contiguous range
+                int To = 0, Ti = dwt_start;
+                for (int i = 0; i < dwt_count; ++i, ++Ti) {
                     if (m.tri_ok) { while (Ti > To) { Ti -= To + 1; ++To; } }
                     else { while (Ti >= nT) { Ti -= nT; ++To; } }
-                    if (To >= nT) break;
                     slab_put4(slab + tv.g2 + (((size_t)To * nT + Ti) * 64 + lane) * 4, outer_tile(E, To, B, Ti, lane),
                               first);
-                    Ti += TRAIN_WAVES;
                 }
             }
             PHASE_END(7)
@@ -413,15 +417,13 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                 bias_put(slab + tv.gb0 + 16 * Ti + 4 * q, a, lane, first);
             }
             for (int e = tid; e < Dp * 4; e += TRAIN_THREADS) reinterpret_cast<float4*>(B)[e] = xsrc[e];
-            {   // weight-gradient tiles (To, Ti <= To): every TRAIN_WAVES-th one in row-major order is this wave's
-                int To = 0, Ti = wv;
-                for (;;) {
+            {   // weight-gradient tiles (To, Ti <= To) in row-major order: this wave's contiguous range
+                int To = 0, Ti = dwt_start;
+                for (int i = 0; i < dwt_count; ++i, ++Ti) {
                     if (m.tri_ok) { while (Ti > To) { Ti -= To + 1; ++To; } }
                     else { while (Ti >= nT) { Ti -= nT; ++To; } }
-                    if (To >= nT) break;
                     slab_put4(slab + tv.g1 + (((size_t)To * nT + Ti) * 64 + lane) * 4, outer_tile(Cb, To, A, Ti, lane),
                               first);
-                    Ti += TRAIN_WAVES;
                 }
             }
             PHASE_END(8)
@@ -433,10 +435,12 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                     store_rows(P, Xi, q, p, a);
                 }
             }
-            for (int i = TRAIN_WAVES - 1 - wv, To = 0, Xi = TRAIN_WAVES - 1 - wv; i < nT * nXT;
-                 i += TRAIN_WAVES, Xi += TRAIN_WAVES) {
-                while (Xi >= nXT) { Xi -= nXT; ++To; }
-                slab_put4(slab + tv.g0 + ((size_t)i * 64 + lane) * 4, outer_tile(E, To, B, Xi, lane), first);
+            {
+                // without the dx tiles (t == 0) the ranges are still a valid partition, just less balanced
+                for (int i = dw0_start, To = 0, Xi = dw0_start; i < dw0_start + dw0_count; ++i, ++Xi) {
+                    while (Xi >= nXT) { Xi -= nXT; ++To; }
+                    slab_put4(slab + tv.g0 + ((size_t)i * 64 + lane) * 4, outer_tile(E, To, B, Xi, lane), first);
+                }
             }
             PHASE_END(9)
             if (t > 0) {
@@ -588,7 +592,7 @@ static size_t train_lds_bytes(const pmc_maf_t& m) {
 
 static int train_check(const pmc_maf_t* m, const pmc_maf_train_t* tr, const char* who) {
     if (!m || !tr || !tr->packedT || !tr->gmap || !tr->slabs || !tr->xt_scratch || !tr->loss_partial ||
-        !tr->sq_partial || tr->n_slabs < 1 || tr->slab_stride < (int64_t)m->T * tr->gmap_per_transform ||
+        !tr->sq_partial || !tr->sched || tr->sched_waves != TRAIN_WAVES || tr->n_slabs < 1 || tr->slab_stride < (int64_t)m->T * tr->gmap_per_transform ||
         (tr->slab_stride & 3))
         return pmc_fail((std::string(who) + ": incomplete training image").c_str());
     return 0;

@@ -372,6 +372,46 @@ class MAFSpec:
             o += v
         return dict(szT=szT, offT=offT, pkT_per_transform=pkT, szG=szG, offG=offG, gmap_per_transform=o)
 
+    def train_schedule(self, n_waves: int = 8, light_cost: float = 2.0) -> np.ndarray:
+        """``int32 [3][n_waves][2]``: (first, count) of the weight-gradient tiles each wave of a training
+        workgroup takes in the phases {layer 3, layers 2 / 1, layer 0}.
+
+        Every phase also has data-gradient tiles that are dealt by fixed rules (``K = wave, wave + n_waves, ...``
+        for layer 3 and layer 0, the cost snake ``wave, 2n-1-wave, 2n+wave, ...`` for the triangular layers);
+        a data-gradient tile costs its number of K tiles + 1, a weight-gradient tile ``light_cost`` (its
+        operands are 8 scalar LDS reads and it ends in a global store).  The weight-gradient tiles are handed
+        out as contiguous ranges so that the waves finish a phase at about the same time."""
+        nT, nXT, nOT = self.nT, self.nXT, self.nOT
+        n_oeff = min(nOT, -(-self.n_out * self.n_dim // 16))
+
+        def snake(w):
+            i = 0
+            while True:
+                r = (i + 1) * n_waves - 1 - w if i & 1 else i * n_waves + w
+                if r >= nT:
+                    return
+                yield r
+                i += 1
+
+        heavy3 = [sum(n_oeff + 1 for _ in range(w, nT, n_waves)) for w in range(n_waves)]
+        heavyt = [sum(((nT - Ti) if self.tri_ok else nT) + 1 for Ti in snake(w)) for w in range(n_waves)]
+        heavy0 = [sum(nT + 1 for _ in range(w, nXT, n_waves)) for w in range(n_waves)]
+        n3 = n_oeff * nT
+        nt = nT * (nT + 1) // 2 if self.tri_ok else nT * nT
+        n0 = nT * nXT
+        out = np.zeros((3, n_waves, 2), dtype=np.int32)
+        for ph, (heavy, n_light) in enumerate(((heavy3, n3), (heavyt, nt), (heavy0, n0))):
+            target = (sum(heavy) + light_cost * n_light) / n_waves
+            want = np.maximum(0.0, (target - np.asarray(heavy, dtype=np.float64)) / light_cost)
+            if want.sum() <= 0:
+                want[:] = 1.0
+            cum = np.round(np.cumsum(want) * (n_light / want.sum())).astype(np.int64)
+            cnt = np.diff(np.concatenate([[0], cum]))
+            out[ph, :, 0] = np.concatenate([[0], cum[:-1]])
+            out[ph, :, 1] = cnt
+            assert cnt.sum() == n_light and (cnt >= 0).all()
+        return out
+
     def train_index(self):
         """``(packT_idx, gmap)``: gather map for ``packedT`` (like ``pack_index``) and the
         gradient scatter map, both int32, all transforms concatenated."""

@@ -32,6 +32,8 @@ class TrainState:
         self.packT_idx = torch.from_numpy(pT_idx).to(dev)
         self.gmap = torch.from_numpy(gmap).to(dev)
         self.packedT = torch.zeros(pT_idx.size, dtype=torch.float32, device=dev)
+        self.n_waves = int(flow.lib.pmc_debug_train_waves())           # waves per training workgroup (compile-time)
+        self.sched = torch.from_numpy(spec.train_schedule(self.n_waves).reshape(-1).copy()).to(dev)
         self.g_total = spec.n_transforms * L["gmap_per_transform"]
         self.n_sq = (self.g_total // 4 + 255) // 256
         self.sq_partial = torch.zeros(max(self.n_sq, 256), dtype=torch.float32, device=dev)   # >= PMC_ADAMW_SCRATCH
@@ -39,7 +41,8 @@ class TrainState:
                                          pkT_per_transform=L["pkT_per_transform"],
                                          gmap_per_transform=L["gmap_per_transform"],
                                          slab_stride=self.g_total, n_sq_partial=self.sq_partial.numel(),
-                                         sq_partial=self.sq_partial.data_ptr())
+                                         sq_partial=self.sq_partial.data_ptr(), sched=self.sched.data_ptr(),
+                                         sched_waves=self.n_waves)
         self.n_slabs = 0
         self.xt_floats = (spec.n_transforms + 1) * spec.Dp * 16
         n = spec.n_params
