@@ -99,3 +99,93 @@ def test_flop_accounting_matches_survey():
     assert s.flops_inverse_naive() == 33 * 270336
     assert MAFSpec(50, 6).flops_forward_dense() == 2033664
     assert MAFSpec(128, 8, 512).flops_forward_dense() == 11534336
+
+
+@pytest.mark.parametrize("D,T,H,uni", [(2, 3, None, "affine"), (10, 3, None, "affine"), (32, 3, None, "rqs"),
+                                       (50, 6, 256, "affine"), (128, 8, 512, "affine"), (17, 2, None, "rqs")])
+@pytest.mark.parametrize("n_waves", [8, 16])
+def test_train_schedule_partitions_the_gradient_tiles(D, T, H, uni, n_waves):
+    """MAFSpec.train_schedule: per phase the waves' ranges are contiguous, disjoint and cover every
+    weight-gradient tile exactly once (host logic of the training kernel's work split)."""
+    from pocomc_amd.maf_spec import MAFSpec
+    s = MAFSpec(D, T, H, univariate=uni)
+    sched = s.train_schedule(n_waves)
+    assert sched.shape == (3, n_waves, 2) and sched.dtype == np.int32
+    n_oeff = min(s.nOT, -(-s.n_out * D // 16))
+    totals = [n_oeff * s.nT, s.nT * (s.nT + 1) // 2 if s.tri_ok else s.nT * s.nT, s.nT * s.nXT]
+    for ph in range(3):
+        start, cnt = sched[ph, :, 0], sched[ph, :, 1]
+        assert (cnt >= 0).all() and start[0] == 0
+        assert np.array_equal(start[1:], np.cumsum(cnt)[:-1])
+        assert cnt.sum() == totals[ph]
+
+
+@pytest.mark.parametrize("D,T", [(2, 3), (4, 3), (10, 3), (32, 3)])
+def test_spline_flow_packing(D, T):
+    """nsf*: 23 hyper-network outputs per feature (pocomc/flow.py:69-86, bins=8); the tight output
+    fragments and the per-rank padded copy used by the inverse sweep both hold exactly the masked W3 / b3."""
+    from pocomc_amd.maf_spec import MAFSpec, spec_by_name
+    assert spec_by_name(6, "nsf6").n_out == 23 and spec_by_name(6, "nsf6").n_transforms == 6
+    assert spec_by_name(6, "maf12").n_out == 2
+    spec = MAFSpec(D, T, univariate="rqs")
+    assert spec.n_out == 23 and spec.Op == 23 * spec.Dp and spec.nOT * 16 == spec.Op
+    flat = spec.init_params(1)
+    idx = spec.pack_index()
+    packed = np.where(idx >= 0, flat[np.maximum(idx, 0)], 0.0).astype(np.float32)
+    su = spec.slot_unit
+    lane = np.arange(64)
+    for t in range(T):
+        M3 = spec.masks(t)[3]
+        W3 = spec.view(flat, t, "W3") * M3
+        b3 = spec.view(flat, t, "b3")
+        feat_of_rank = np.argsort(spec.orders[t])
+        base = t * spec.pk_per_transform
+        f3i = packed[base + spec.pk_offsets["f3i"]: base + spec.pk_offsets["f3i"] + spec.sz_f3i].reshape(D, 2, spec.nT, 64, 4)
+        b3i = packed[base + spec.pk_offsets["b3i"]: base + spec.pk_offsets["b3i"] + spec.sz_b3i].reshape(D, 32)
+        f3 = packed[base + spec.pk_offsets["f3"]: base + spec.pk_offsets["f3"] + spec.sz_f3].reshape(spec.nOT, spec.nT, 64, 4)
+        for r in range(D):
+            feat = feat_of_rank[r]
+            np.testing.assert_array_equal(b3i[r, :23], b3[23 * feat: 23 * feat + 23])
+            assert not b3i[r, 23:].any()
+            for half in range(2):
+                j = 16 * half + (lane & 15)
+                for K in range(spec.nT):
+                    for c in range(4):
+                        i = su[16 * K + 4 * c + (lane >> 4)]
+                        ok = (j < 23) & (i >= 0)
+                        exp = np.where(ok, W3[23 * feat + np.minimum(j, 22), np.maximum(i, 0)], 0.0)
+                        np.testing.assert_array_equal(f3i[r, half, K, :, c], exp.astype(np.float32))
+        # tight layout: packed output row o = 23 * rank + j
+        for O in range(spec.nOT):
+            o = 16 * O + (lane & 15)
+            r_out, j = o // 23, o % 23
+            for K in range(spec.nT):
+                for c in range(4):
+                    i = su[16 * K + 4 * c + (lane >> 4)]
+                    ok = (r_out < D) & (i >= 0)
+                    crow = 23 * feat_of_rank[np.minimum(r_out, D - 1)] + j
+                    exp = np.where(ok, W3[crow, np.maximum(i, 0)], 0.0)
+                    np.testing.assert_array_equal(f3[O, K, :, c], exp.astype(np.float32))
+
+
+def test_plateau_scheduler_matches_torch():
+    """pocomc_amd.train.ReduceLROnPlateau is torch's scheduler as configured at flow.py:275-283."""
+    import torch
+    from pocomc_amd.train import ReduceLROnPlateau
+
+    class Opt:
+        lr = 1e-2
+
+    rng = np.random.default_rng(0)
+    metrics = np.concatenate([np.linspace(3.0, 1.0, 15), 1.0 + 0.05 * rng.random(40), np.linspace(1.0, 0.9, 10),
+                              0.9 + 0.01 * rng.random(30)])
+    p = torch.nn.Parameter(torch.zeros(1))
+    topt = torch.optim.SGD([p], lr=1e-2)
+    ref = torch.optim.lr_scheduler.ReduceLROnPlateau(topt, mode="min", factor=0.2, patience=5, threshold=1e-4,
+                                                     threshold_mode="abs", min_lr=1e-6)
+    o = Opt()
+    mine = ReduceLROnPlateau(o, patience=5)
+    for mval in metrics:
+        ref.step(float(mval))
+        mine.step(float(mval))
+        assert abs(o.lr - topt.param_groups[0]["lr"]) < 1e-15
