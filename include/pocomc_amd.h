@@ -188,6 +188,17 @@ typedef struct pmc_prior {
 int pmc_prior_logpdf(const pmc_prior_t* pr, const double* x, const int32_t* finite, double* logp, int64_t n,
                      void* stream);
 
+/* Completion word of a kernel in pinned host memory: the last workgroup to finish stores `value` to `*flag`
+ * after every workgroup's results are visible system-wide; the host then spins on the word (pmc_wait_flag)
+ * instead of waking up through the runtime's stream / event synchronisation (~10-20 us per wait). */
+typedef struct pmc_done {
+    int64_t* flag;            /* pinned, device-accessible host memory */
+    int64_t value;
+    uint32_t* ticket;         /* device, zeroed once by the caller (only kernels without their own ticket use it) */
+} pmc_done_t;
+/* spin until *flag == value; non-zero return after timeout_s seconds */
+int pmc_wait_flag(const int64_t* flag, int64_t value, double timeout_s);
+
 /* pmc_scaler_inverse and pmc_prior_logpdf in ONE launch (the step's pre-phase is a chain of small
  * latency-bound kernels; each launch costs ~15-20 us end to end): additionally
  * logp f64 [n] <- Prior.logpdf(x') on the finite rows, -inf elsewhere (mcmc.py:105-107).
@@ -198,7 +209,7 @@ int pmc_prior_logpdf(const pmc_prior_t* pr, const double* x, const int32_t* fini
 int pmc_scaler_inverse_prior(const pmc_scaler_t* s, const pmc_prior_t* prior, const float* u_in,
                              const double* u_in64, double* u_out, double* x, double* x_colmajor,
                              double* logdetj, int32_t* finite, double* logp, int32_t* finite_copy,
-                             double* logp_copy, int64_t n, void* stream);
+                             double* logp_copy, const pmc_done_t* done, int64_t n, void* stream);
 
 /* ------------------------------------------------------------ MCMC step */
 
@@ -271,7 +282,7 @@ int pmc_accept(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposa
  * prop->logl / prop->logp may likewise point into pinned host memory (read straight over PCIe). */
 int pmc_accept_armed(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposal_t* prop, double beta,
                      double nu, const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums,
-                     double* sums_copy, void* workspace, int64_t n, int32_t D, void* stream);
+                     double* sums_copy, const pmc_done_t* done, void* workspace, int64_t n, int32_t D, void* stream);
 
 /* All buffers of one step in one place, for the composite entry points below. */
 typedef struct pmc_step {
@@ -325,6 +336,9 @@ typedef struct pmc_step {
     int64_t* rng_ready;       /* host */
     void* ev_pre_done;        /* optional hipEvent_t recorded when x', finite and logp' are complete (the variates of the
                                * next step are generated behind it: wait for this event, not for the stream) */
+    int64_t* h_done;          /* pinned host int64 [2] or NULL: with host_direct, [0] <- step + 1 when pmc_step_pre's results
+                               * are in host memory, [1] <- step + 1 when pmc_step_post's are (pmc_wait_flag) */
+    uint32_t* done_ticket;    /* device uint32 [1], zeroed once */
     int32_t no_fuse;          /* 1: always launch the proposal and the flow inverse separately */
     int32_t host_direct;      /* 1: h_x (column-major, p_xT == NULL), h_fin, h_logp_out and h_mu are device-accessible
                                * pinned memory that the kernels read / write themselves -- no copies in pmc_step_pre */

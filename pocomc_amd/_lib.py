@@ -47,6 +47,10 @@ class pmc_scaler_t(C.Structure):
                 ("reserved", C.c_int32), ("sum_log_sigma", C.c_double)]
 
 
+class pmc_done_t(C.Structure):
+    _fields_ = [("flag", c_p), ("value", C.c_int64), ("ticket", c_p)]
+
+
 class pmc_prior_t(C.Structure):
     _fields_ = [("family", c_p), ("loc", c_p), ("scale", c_p), ("D", C.c_int32), ("reserved", C.c_int32)]
 
@@ -78,7 +82,8 @@ class pmc_step_t(C.Structure):
                 ("h_accept", c_p), ("ev_inv0", c_p), ("ev_inv1", c_p),
                 ("prior", c_p), ("h_logp_out", c_p),
                 ("rng_normal", c_p * 2), ("rng_gamma", c_p * 2), ("rng_uniform", c_p * 2), ("rng_ready", c_p),
-                ("ev_pre_done", c_p), ("no_fuse", C.c_int32), ("host_direct", C.c_int32)]
+                ("ev_pre_done", c_p), ("h_done", c_p), ("done_ticket", c_p),
+                ("no_fuse", C.c_int32), ("host_direct", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/pocomc_amd.h declares
@@ -100,14 +105,15 @@ SIGNATURES = {
     "pmc_scaler_forward": (C.c_int, [P(pmc_scaler_t), c_p, c_p, i64, c_p]),
     "pmc_prior_logpdf": (C.c_int, [P(pmc_prior_t), c_p, c_p, c_p, i64, c_p]),
     "pmc_scaler_inverse_prior": (C.c_int, [P(pmc_scaler_t), P(pmc_prior_t), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
-                                           c_p, c_p, i64, c_p]),
+                                           c_p, c_p, P(pmc_done_t), i64, c_p]),
+    "pmc_wait_flag": (C.c_int, [c_p, i64, f64]),
     "pmc_propose": (C.c_int, [C.c_int, c_p, c_p, c_p, c_p, c_p, f64, f64, f64, P(pmc_rng_t),
                               c_p, c_p, c_p, c_p, i64, i32, c_p]),
     "pmc_accept_workspace_bytes": (i64, [i64, i32]),
     "pmc_accept": (C.c_int, [C.c_int, C.c_int, P(pmc_state_t), P(pmc_proposal_t), f64, f64,
                              P(pmc_rng_t), c_p, c_p, c_p, c_p, i64, i32, c_p]),
     "pmc_accept_armed": (C.c_int, [C.c_int, C.c_int, P(pmc_state_t), P(pmc_proposal_t), f64, f64,
-                                   P(pmc_rng_t), c_p, c_p, c_p, c_p, c_p, i64, i32, c_p]),
+                                   P(pmc_rng_t), c_p, c_p, c_p, c_p, P(pmc_done_t), c_p, i64, i32, c_p]),
     "pmc_propose_inverse": (C.c_int, [C.c_int, c_p, c_p, c_p, c_p, f64, f64, f64, P(pmc_rng_t), c_p, c_p, c_p,
                                       P(pmc_maf_t), c_p, c_p, i64, c_p]),
     "pmc_step_pre": (C.c_int, [P(pmc_step_t), P(pmc_rng_t), f64, f64, f64, c_p]),

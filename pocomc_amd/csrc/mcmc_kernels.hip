@@ -227,7 +227,8 @@ __global__ __launch_bounds__(256) void scaler_inverse_kernel(
     pmc_scaler_t s, const float* __restrict__ u_in, const double* __restrict__ u_in64,
     double* __restrict__ u_out, double* __restrict__ x_out, double* __restrict__ x_colmajor,
     double* __restrict__ ldj_out, int32_t* __restrict__ finite_out, int64_t n, pmc_prior_t pr,
-    double* __restrict__ logp_out, int32_t* __restrict__ finite_copy, double* __restrict__ logp_copy) {
+    double* __restrict__ logp_out, int32_t* __restrict__ finite_copy, double* __restrict__ logp_copy,
+    unsigned* __restrict__ done_ticket, long long* __restrict__ done_flag, long long done_value) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int D = s.D;
     const bool keep_x = x_colmajor || logp_out;   // x' stays in LDS for the column-major copy / the fused prior
@@ -283,6 +284,20 @@ __global__ __launch_bounds__(256) void scaler_inverse_kernel(
         for (int e = tid; e < rows * D; e += 256) {
             const int j = e / rows, r = e - j * rows;
             x_colmajor[(size_t)j * n + row0 + r] = Xt[j * (SCL_ROWS + 1) + r];
+        }
+    }
+    if (done_flag) {
+        // completion word in pinned host memory: every block makes its own stores visible system-wide, draws
+        // a ticket; the last one publishes done_value (the host spins on it instead of going through the runtime)
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(done_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == gridDim.x - 1) {
+                *done_ticket = 0u;
+                __threadfence_system();
+                __hip_atomic_store(done_flag, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
@@ -347,7 +362,7 @@ __global__ __launch_bounds__(256) void accept_kernel(
     int preconditioned, int tpcn, pmc_state_t cur, pmc_proposal_t prop, double beta, double nu,
     pmc_rng_t rng, double* __restrict__ alpha_out, int32_t* __restrict__ accept_out,
     double* __restrict__ partials, unsigned* __restrict__ ticket, double* __restrict__ sums,
-    double* __restrict__ sums_copy, int64_t n, int D) {
+    double* __restrict__ sums_copy, long long* __restrict__ done_flag, long long done_value, int64_t n, int D) {
     __shared__ int flag[ACC_ROWS];
     __shared__ double colsum[8][33];
     __shared__ int is_last;
@@ -467,7 +482,14 @@ __global__ __launch_bounds__(256) void accept_kernel(
         }
         __syncthreads();
     }
-    if (tid == 0) *ticket = 0u;       // ready for the next launch (the caller zeroes it once at allocation)
+    if (done_flag) {
+        __threadfence_system();           // the sums (and every block's state updates) before the completion word
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *ticket = 0u;                     // ready for the next launch (the caller zeroes it once at allocation)
+        if (done_flag) __hip_atomic_store(done_flag, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ===========================================================================
@@ -696,13 +718,13 @@ extern "C" int pmc_scaler_inverse(const pmc_scaler_t* s, const float* u_in, cons
                                   double* x, double* x_colmajor, double* logdetj, int32_t* finite, int64_t n,
                                   void* stream) {
     return pmc_scaler_inverse_prior(s, nullptr, u_in, u_in64, u_out, x, x_colmajor, logdetj, finite, nullptr, nullptr,
-                                    nullptr, n, stream);
+                                    nullptr, nullptr, n, stream);
 }
 
 extern "C" int pmc_scaler_inverse_prior(const pmc_scaler_t* s, const pmc_prior_t* prior, const float* u_in,
                                         const double* u_in64, double* u_out, double* x, double* x_colmajor,
                                         double* logdetj, int32_t* finite, double* logp, int32_t* finite_copy,
-                                        double* logp_copy, int64_t n, void* stream) {
+                                        double* logp_copy, const pmc_done_t* done, int64_t n, void* stream) {
     if (int e = check_scaler(s)) return e;
     if (n == 0) return 0;
     if ((!u_in) == (!u_in64)) return pmc_fail("pmc_scaler_inverse: exactly one of u_in / u_in64 must be given");
@@ -723,7 +745,8 @@ extern "C" int pmc_scaler_inverse_prior(const pmc_scaler_t* s, const pmc_prior_t
     }
     hipLaunchKernelGGL(scaler_inverse_kernel, dim3((unsigned)((n + SCL_ROWS - 1) / SCL_ROWS)), dim3(256), lds,
                        (hipStream_t)stream, *s, u_in, u_in64, u_out, x, x_colmajor, logdetj, finite, n, pr_val, logp, finite_copy,
-                       logp_copy);
+                       logp_copy, done ? done->ticket : nullptr, done ? (long long*)done->flag : nullptr,
+                       done ? (long long)done->value : 0LL);
     return pmc_check_launch("scaler_inverse_kernel");
 }
 
@@ -743,7 +766,8 @@ extern "C" int64_t pmc_accept_workspace_bytes(int64_t n, int32_t D) {
 
 static int accept_impl(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposal_t* prop, double beta,
                        double nu, const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums,
-                       double* sums_copy, bool armed, void* workspace, int64_t n, int32_t D, void* stream) {
+                       double* sums_copy, bool armed, const pmc_done_t* done, void* workspace, int64_t n, int32_t D,
+                       void* stream) {
     if (!cur || !prop || !rng || !sums || !workspace || n < 0 || D < 1) return pmc_fail("pmc_accept: bad argument");
     if (!cur->u || !cur->x || !cur->logdetj || !cur->logl || !cur->logp || !prop->u || !prop->x ||
         !prop->logdetj || !prop->logl || !prop->logp)
@@ -764,7 +788,8 @@ static int accept_impl(int kind, int preconditioned, pmc_state_t* cur, const pmc
     // pmc_accept_armed skips it: the kernel leaves the word at zero itself.
     if (!armed && hipMemsetAsync(ticket, 0, sizeof(unsigned), st) != hipSuccess) return pmc_fail("pmc_accept: memset");
     hipLaunchKernelGGL(accept_kernel, dim3(nb), dim3(256), 0, st, preconditioned, tpcn, *cur, *prop, beta, nu, *rng,
-                       alpha_out, accept_out, partials, ticket, sums, sums_copy, n, (int)D);
+                       alpha_out, accept_out, partials, ticket, sums, sums_copy, done ? (long long*)done->flag : nullptr,
+                       done ? (long long)done->value : 0LL, n, (int)D);
     return pmc_check_launch("accept_kernel");
 }
 
@@ -772,14 +797,15 @@ extern "C" int pmc_accept(int kind, int preconditioned, pmc_state_t* cur, const 
                           double nu, const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums,
                           void* workspace, int64_t n, int32_t D, void* stream) {
     return accept_impl(kind, preconditioned, cur, prop, beta, nu, rng, alpha_out, accept_out, sums, nullptr, false,
-                       workspace, n, D, stream);
+                       nullptr, workspace, n, D, stream);
 }
 
 extern "C" int pmc_accept_armed(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposal_t* prop, double beta,
                                 double nu, const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums,
-                                double* sums_copy, void* workspace, int64_t n, int32_t D, void* stream) {
+                                double* sums_copy, const pmc_done_t* done, void* workspace, int64_t n, int32_t D,
+                                void* stream) {
     return accept_impl(kind, preconditioned, cur, prop, beta, nu, rng, alpha_out, accept_out, sums, sums_copy, true,
-                       workspace, n, D, stream);
+                       done, workspace, n, D, stream);
 }
 
 extern "C" int pmc_logw(const double* logl, const double* beta, const double* logz, double beta_final,

@@ -9,6 +9,7 @@
 // buffers must be pinned for the copies to be asynchronous.
 
 #include <hip/hip_runtime.h>
+#include <time.h>
 #include "pmc_internal.h"
 
 extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu, double sigma, double cn_a,
@@ -82,6 +83,8 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
     double* xT = direct ? s->h_x : s->p_xT;
     int32_t* fin2 = direct ? s->h_fin : nullptr;
     double* lp2 = (direct && pr) ? s->h_logp_out : nullptr;
+    pmc_done_t dn{s->h_done, (int64_t)rng->step + 1, s->done_ticket};
+    const pmc_done_t* done = (direct && s->h_done && s->done_ticket) ? &dn : nullptr;
     if (s->preconditioned) {
         if (!fused) {
             if (s->ev_inv0) (void)hipEventRecord((hipEvent_t)s->ev_inv0, st);
@@ -90,10 +93,10 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
             if (rc) return rc;
         }
         rc = pmc_scaler_inverse_prior(s->scaler, pr, s->p_u32, nullptr, s->p_u, s->p_x, xT, s->p_logdetj, s->p_fin, lp,
-                                      fin2, lp2, n, stream);
+                                      fin2, lp2, done, n, stream);
     } else {
         rc = pmc_scaler_inverse_prior(s->scaler, pr, nullptr, s->p_theta64, s->p_u, s->p_x, xT, s->p_logdetj, s->p_fin,
-                                      lp, fin2, lp2, n, stream);
+                                      lp, fin2, lp2, done, n, stream);
     }
     if (rc) return rc;
     if (direct) return finish();
@@ -151,9 +154,12 @@ extern "C" int pmc_step_post(const pmc_step_t* s, const pmc_rng_t* rng, double b
     prop.logdetj_flow = s->preconditioned ? s->p_ldjf : nullptr;
     prop.quad = s->quad; prop.quad_prop = s->p_quad;
     int rc;
-    if (direct)
+    if (direct) {
+        pmc_done_t dn{s->h_done ? s->h_done + 1 : nullptr, (int64_t)rng->step + 1, nullptr};
         rc = pmc_accept_armed(s->kind, s->preconditioned, &cur, &prop, beta, nu, rng, s->alpha, s->accept, s->sums,
-                              copy_sums ? s->h_sums : nullptr, s->ws, n, s->D, stream);
+                              copy_sums ? s->h_sums : nullptr, (copy_sums && s->h_done) ? &dn : nullptr, s->ws, n, s->D,
+                              stream);
+    }
     else
         rc = pmc_accept(s->kind, s->preconditioned, &cur, &prop, beta, nu, rng, s->alpha, s->accept, s->sums, s->ws, n,
                         s->D, stream);
@@ -184,6 +190,26 @@ extern "C" int pmc_event_record(void* ev, void* stream) {
     hipError_t e = hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
     return e == hipSuccess ? 0 : pmc_fail_hip(e, "hipEventRecord");
 }
+// spin on a completion word the kernels store to pinned host memory (pmc_done_t)
+extern "C" int pmc_wait_flag(const int64_t* flag, int64_t value, double timeout_s) {
+    if (!flag) return pmc_fail("pmc_wait_flag: null flag");
+    const volatile int64_t* f = flag;
+    for (long it = 0;; ++it) {
+        for (int k = 0; k < 2048; ++k) {
+            if (*f == value) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return 0; }
+            __builtin_ia32_pause();
+        }
+        if ((it & 63) == 63) {
+            static thread_local struct timespec t0;
+            struct timespec t;
+            clock_gettime(CLOCK_MONOTONIC, &t);
+            if (it == 63) t0 = t;
+            if ((double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec) > timeout_s)
+                return pmc_fail("pmc_wait_flag: timed out waiting for the device");
+        }
+    }
+}
+
 extern "C" int pmc_event_synchronize(void* ev) {
     hipError_t e = hipEventSynchronize((hipEvent_t)ev);
     return e == hipSuccess ? 0 : pmc_fail_hip(e, "hipEventSynchronize");

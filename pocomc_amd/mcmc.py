@@ -197,6 +197,13 @@ class StepEngine:
             self._step.rng_gamma[b] = self._pf_gamma[b].data_ptr()
             self._step.rng_uniform[b] = self._pf_uniform[b].data_ptr()
         self._step.ev_pre_done = self._ev_pre
+        # completion words the kernels store to pinned host memory (host_direct): the driver thread spins on
+        # them instead of waking up through the runtime
+        self.spin_wait = True
+        self.h_done = pin(2, dt=torch.int64)
+        self.h_done.zero_()
+        self._done_ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._direct_now = False
         self.prior_desc = None   # pmc_prior_t when Prior.logpdf runs on the device (set_device_prior)
         self.composite = True    # one C call before / after the host black boxes (pmc_step_pre / _post)
         # x_order 'F' on the composite path: the scaler kernel writes x', the finite mask and logp' straight
@@ -294,6 +301,9 @@ class StepEngine:
             direct = bool(self.host_direct and self.x_order == "F")
             self._step.host_direct = int(direct)
             self._step.p_xT = None if (direct or self.p_xT is None) else self.p_xT.data_ptr()
+            self._direct_now = direct and self.spin_wait
+            self._step.h_done = self.h_done.data_ptr() if self._direct_now else None
+            self._step.done_ticket = self._done_ticket.data_ptr() if self._direct_now else None
             cn_a = float((1.0 - sigma ** 2.0) ** 0.5) if self.tpcn else 0.0        # mcmc.py:85
             self._stream = _lib.stream_handle()
             _lib.check(lib.pmc_step_pre(C.byref(self._step), C.byref(self._rng_cur), float(nu), float(sigma), cn_a,
@@ -346,8 +356,12 @@ class StepEngine:
         tm = self.host_timers
         t0 = time.perf_counter() if tm is not None else 0.0
         if self._post_uploads:
-            # x', finite, logp' are complete at this event; the next step's variates are generated behind it
-            _lib.check(self.lib.pmc_event_synchronize(self._ev_pre), "pmc_event_synchronize")
+            # x', finite, logp' are complete at this event / completion word; the next step's variates are
+            # generated behind it
+            if self._direct_now:
+                _lib.check(self.lib.pmc_wait_flag(self.h_done.data_ptr(), self.step_idx + 1, 30.0), "pmc_wait_flag")
+            else:
+                _lib.check(self.lib.pmc_event_synchronize(self._ev_pre), "pmc_event_synchronize")
         else:
             torch.cuda.current_stream().synchronize()
         if tm is not None:
@@ -440,6 +454,8 @@ class StepEngine:
                 allreduce_sums(self.sums, self.group)
                 self.h_sums.copy_(self.sums, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
+            elif self._direct_now and not want_mask:        # (the accept-mask copy is an ordinary stream operation)
+                _lib.check(self.lib.pmc_wait_flag(self.h_done.data_ptr() + 8, self.step_idx + 1, 30.0), "pmc_wait_flag")
             else:
                 _lib.check(self.lib.pmc_stream_synchronize(self._stream), "pmc_stream_synchronize")
             self.step_idx += 1
@@ -512,6 +528,8 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
         eng.host_direct = bool(option_dict["host_direct"])
     if "rng_prefill" in option_dict:
         eng.rng_prefill = bool(option_dict["rng_prefill"])
+    if "spin_wait" in option_dict:
+        eng.spin_wait = bool(option_dict["spin_wait"])
     owner = getattr(log_prior, "__self__", None)
     if owner is not None and option_dict.get("device_prior", True) and hasattr(owner, "device_descriptor"):
         eng.set_device_prior(owner)                 # Prior.logpdf of uniform / normal factors on the device

@@ -215,7 +215,7 @@ def test_fused_scaler_prior_equals_the_two_launches(colmajor):
         if fused:
             _lib.check(lib.pmc_scaler_inverse_prior(C.byref(sd), C.byref(pd), _lib.ptr(u32), None, _lib.ptr(uo),
                                                     _lib.ptr(x), _lib.ptr(xT) if colmajor else None, _lib.ptr(ldj),
-                                                    _lib.ptr(fin), _lib.ptr(lp), None, None, n, _lib.stream_handle()))
+                                                    _lib.ptr(fin), _lib.ptr(lp), None, None, None, n, _lib.stream_handle()))
         else:
             _lib.check(lib.pmc_scaler_inverse(C.byref(sd), _lib.ptr(u32), None, _lib.ptr(uo), _lib.ptr(x),
                                               _lib.ptr(xT) if colmajor else None, _lib.ptr(ldj), _lib.ptr(fin), n,
