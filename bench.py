@@ -343,6 +343,21 @@ def main():
                 "fused_proposal": bool(fused),
                 "actual_tflops": actual_flops / t_inv / 1e12,
                 "actual_frac": actual_flops / t_inv / 1e12 / PEAK_F32_MFMA_TFLOPS}
+    # HBM-nominal sweeps: achieved GB/s against ~8 TB/s.  At this size every array (1.28 MB f32 /
+    # 2.56 MB f64) is cache-resident, so these kernels are launch / latency limited -- reported with that caveat.
+    b_accept = n * 4 * (6 * D + 13)                           # SURVEY figure (fp32 state)
+    b_accept_f64 = n * (8 * (4 * D + 9) + 4 * 2 * D)          # what this build moves: f64 u, x (+theta f32/f64), 9 scalars
+    b_scaler = n * (8 * D + 4)
+    sweeps = {"bound": "hbm", "peak": 8000.0, "unit": "GB/s",
+              "accept_kernel": {"avg_launch_us": us["accept_reduce"], "algorithmic_bytes": b_accept,
+                                "achieved": b_accept / us["accept_reduce"] * 1e-3,
+                                "frac": b_accept / us["accept_reduce"] * 1e-3 / 8000.0,
+                                "bytes_moved_f64_state": b_accept_f64},
+              "scaler_inverse_kernel": {"avg_launch_us": us["scaler_inverse"], "algorithmic_bytes": b_scaler,
+                                        "achieved": b_scaler / us["scaler_inverse"] * 1e-3,
+                                        "frac": b_scaler / us["scaler_inverse"] * 1e-3 / 8000.0},
+              "note": "state is cache-resident at 1e4 x 32: launch/latency bound, not bandwidth bound (SURVEY 8(d) caveat); "
+                      "durations from the instrumented pass (fine-grained launches with device-to-host copies)"}
     ms_per_step = dt / args.steps * 1e3
     value = (n * world * args.steps / dt) / 1e4
     out = {"metric": "preconditioned MCMC steps/sec (1e4 particles, 32-D)", "value": value,
@@ -355,6 +370,7 @@ def main():
                       "flow_trained_50_epochs": flow_trained, "parallelism": f"walker-sharded x{world}",
                       "inverse_algo": args.inverse, "host_threads": args.host_threads, "host_x_order": args.x_order, "prior_on_device": bool(device_prior), "accept_rate": float(ad.mean_alpha)},
            "roofline": roofline,
+           "roofline_sweeps": sweeps,
            "flow_fit": flow_fit,
            "device_only_steps_per_s": 1e6 / (us["propose"] + us["maf_inverse"] + us["scaler_inverse"]
                                              + us["accept_reduce"]),

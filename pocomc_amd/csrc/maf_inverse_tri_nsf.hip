@@ -28,6 +28,9 @@
 #define NPK 8     // K tiles prefetched per hidden tile and layer
 #define NPO 10    // K tiles of the rank's two output tiles prefetched per group
 
+// ABL (timing experiments only, wrong results): 1 = no spline solve, 2 = no output product, 4 = no hidden chain,
+// 8 = no per-rank output fragment loads
+template <int ABL>
 __global__ __launch_bounds__(64) void maf_inverse_tri_nsf_kernel(pmc_maf_t m, const float* __restrict__ in,
                                                                  float* __restrict__ out,
                                                                  float* __restrict__ ladj_out, int64_t n) {
@@ -71,7 +74,8 @@ __global__ __launch_bounds__(64) void maf_inverse_tri_nsf_kernel(pmc_maf_t m, co
                 phi_[4 * i_] = v_.x; phi_[4 * i_ + 1] = v_.y; phi_[4 * i_ + 2] = v_.z; phi_[4 * i_ + 3] = v_.w; \
             }                                                                                           \
             float xv_, l_;                                                                              \
-            rqs_inverse(phi_, Y[lidx((G), p)], xv_, l_);                                                \
+            if (ABL & 1) { xv_ = Y[lidx((G), p)] + phi_[0] + phi_[23 - 1]; l_ = phi_[8]; }              \
+            else rqs_inverse(phi_, Y[lidx((G), p)], xv_, l_);                                           \
             if (q == 0) { X[lidx((G), p)] = xv_; ladj -= l_; }                                          \
             WAVE_LDS_FENCE();                                                                           \
         }
@@ -163,12 +167,15 @@ __global__ __launch_bounds__(64) void maf_inverse_tri_nsf_kernel(pmc_maf_t m, co
                 // in flight while the hidden chain of the group runs
                 float4 po0[NPO], po1[NPO];
                 const float4* fo_ = w.f3i + ((size_t)g * 2 * nT) * 64 + lane;
+                if (!(ABL & 8)) {
 #pragma unroll
                 for (int i = 0; i < NPO; ++i)
                     if (i <= Tt) { po0[i] = fo_[i * 64]; po1[i] = fo_[(nT + i) * 64]; }
+                }
                 f32x4 o0 = bias4(w.b3i, 32 * g + 4 * q), o1 = bias4(w.b3i, 32 * g + 16 + 4 * q);
 
                 f32x4 h0, h1, h2;
+                if (!(ABL & 4)) {
                 for (int r = 0; r < 4; ++r) h0[r] = fmaxf(a0[r], 0.0f);
                 if (mine) store_rows(H0, Tt, q, p, h0);
                 WAVE_LDS_FENCE();
@@ -180,8 +187,10 @@ __global__ __launch_bounds__(64) void maf_inverse_tri_nsf_kernel(pmc_maf_t m, co
                 for (int r = 0; r < 4; ++r) h2[r] = fmaxf(a2[r] + h1[r], 0.0f);
                 if (mine) store_rows(H2, Tt, q, p, h2);
                 WAVE_LDS_FENCE();
+                }
 
                 // ---- the 23 spline parameters of rank g: left-looking over the final h2 tiles
+                if (!(ABL & 2)) {
 #pragma unroll
                 for (int i = 0; i < NPO; ++i) {
                     if (i <= Tt) {
@@ -195,6 +204,7 @@ __global__ __launch_bounds__(64) void maf_inverse_tri_nsf_kernel(pmc_maf_t m, co
                 for (int K = NPO; K <= Tt; ++K) {
                     o0 = tile_mac(o0, w.f3i + ((size_t)g * 2 * nT) * 64, H2, K, lane);
                     o1 = tile_mac(o1, w.f3i + ((size_t)g * 2 * nT + nT) * 64, H2, K, lane);
+                }
                 }
                 SOLVE_RANK(g, o0, o1)
                 const float xg = X[lidx(g, p)];
@@ -222,12 +232,24 @@ int pmc_launch_inverse_tri_nsf(const pmc_maf_t* m, const float* z, float* x, flo
     if (lds > 160 * 1024) return pmc_fail("pmc_maf_inverse: flow too wide for one wave's LDS budget (160 KiB)");
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri_nsf_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri_nsf_kernel<0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_inverse_tri_nsf_kernel)");
         lds_set = lds;
     }
-    hipLaunchKernelGGL(maf_inverse_tri_nsf_kernel, dim3((unsigned)((n + 15) / 16)), dim3(64), lds, stream, *m, z, x,
+    hipLaunchKernelGGL(maf_inverse_tri_nsf_kernel<0>, dim3((unsigned)((n + 15) / 16)), dim3(64), lds, stream, *m, z, x,
                        ladj, n);
     return pmc_check_launch("maf_inverse_tri_nsf_kernel");
+}
+
+// timing-only ablations (scripts/ablate_inverse.py nsf); NOT part of the ABI
+extern "C" int pmc_debug_inverse_nsf_ablate(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, int abl,
+                                            void* stream) {
+    const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 16 * 32) * sizeof(float);
+    const dim3 g((unsigned)((n + 15) / 16)), b(64);
+    hipStream_t st = (hipStream_t)stream;
+#define AB(V) case V: hipLaunchKernelGGL(maf_inverse_tri_nsf_kernel<V>, g, b, lds, st, *m, z, x, ladj, n); break;
+    switch (abl) { AB(0) AB(1) AB(2) AB(4) AB(8) AB(3) AB(7) AB(15) default: return pmc_fail("unknown ablation"); }
+#undef AB
+    return pmc_check_launch("maf_inverse_tri_nsf_kernel<ablate>");
 }
