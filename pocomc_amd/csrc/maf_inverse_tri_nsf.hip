@@ -45,6 +45,7 @@ __global__ __launch_bounds__(64) void maf_inverse_tri_nsf_kernel(pmc_maf_t m, co
     float* H1 = H0 + Hp * 16;
     float* H2 = H1 + Hp * 16;
     float* PAR = H2 + Hp * 16;       // [16 rows][32]: the 23 spline parameters of the current rank
+    float* TAB = PAR + 16 * 32;      // [16 rows][24]: its x / y knot tables (rqs_inverse_coop)
     const int* feat_of_rank = m.meta + 8;
     const int* rank_of_feat = m.meta + 8 + T * D;
     const int* quad_meta = m.meta + 8 + 2 * T * D;
@@ -68,14 +69,9 @@ __global__ __launch_bounds__(64) void maf_inverse_tri_nsf_kernel(pmc_maf_t m, co
             *reinterpret_cast<float4*>(pr_) = make_float4(OA0[0], OA0[1], OA0[2], OA0[3]);              \
             *reinterpret_cast<float4*>(pr_ + 16) = make_float4(OA1[0], OA1[1], OA1[2], OA1[3]);         \
             WAVE_LDS_FENCE();                                                                           \
-            float phi_[24];                                                                             \
-            _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                                          \
-                const float4 v_ = *reinterpret_cast<const float4*>(PAR + (p << 5) + (i_ << 2));         \
-                phi_[4 * i_] = v_.x; phi_[4 * i_ + 1] = v_.y; phi_[4 * i_ + 2] = v_.z; phi_[4 * i_ + 3] = v_.w; \
-            }                                                                                           \
             float xv_, l_;                                                                              \
-            if (ABL & 1) { xv_ = Y[lidx((G), p)] + phi_[0] + phi_[23 - 1]; l_ = phi_[8]; }              \
-            else rqs_inverse(phi_, Y[lidx((G), p)], xv_, l_);                                           \
+            if (ABL & 1) { xv_ = Y[lidx((G), p)] + PAR[(p << 5)] + PAR[(p << 5) + 22]; l_ = PAR[(p << 5) + 8]; } \
+            else rqs_inverse_coop(PAR + (p << 5), TAB + p * 24, q, Y[lidx((G), p)], xv_, l_);           \
             if (q == 0) { X[lidx((G), p)] = xv_; ladj -= l_; }                                          \
             WAVE_LDS_FENCE();                                                                           \
         }
@@ -191,6 +187,8 @@ __global__ __launch_bounds__(64) void maf_inverse_tri_nsf_kernel(pmc_maf_t m, co
 
                 // ---- the 23 spline parameters of rank g: left-looking over the final h2 tiles
                 if (!(ABL & 2)) {
+                // (dealing the K < Tt part of this product into the hops of the chain above was measured: the
+                // in-order queue then delays the chain's own dependent MFMAs -- 6 us slower)
 #pragma unroll
                 for (int i = 0; i < NPO; ++i) {
                     if (i <= Tt) {
@@ -228,7 +226,7 @@ __global__ __launch_bounds__(64) void maf_inverse_tri_nsf_kernel(pmc_maf_t m, co
 
 int pmc_launch_inverse_tri_nsf(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
                                hipStream_t stream) {
-    const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 16 * 32) * sizeof(float);
+    const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 16 * 32 + 16 * 24) * sizeof(float);
     if (lds > 160 * 1024) return pmc_fail("pmc_maf_inverse: flow too wide for one wave's LDS budget (160 KiB)");
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
@@ -245,7 +243,7 @@ int pmc_launch_inverse_tri_nsf(const pmc_maf_t* m, const float* z, float* x, flo
 // timing-only ablations (scripts/ablate_inverse.py nsf); NOT part of the ABI
 extern "C" int pmc_debug_inverse_nsf_ablate(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, int abl,
                                             void* stream) {
-    const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 16 * 32) * sizeof(float);
+    const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 16 * 32 + 16 * 24) * sizeof(float);
     const dim3 g((unsigned)((n + 15) / 16)), b(64);
     hipStream_t st = (hipStream_t)stream;
 #define AB(V) case V: hipLaunchKernelGGL(maf_inverse_tri_nsf_kernel<V>, g, b, lds, st, *m, z, x, ladj, n); break;

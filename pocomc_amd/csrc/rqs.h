@@ -120,6 +120,58 @@ __device__ __forceinline__ void rqs_inverse(const float* phi, float y, float& x,
     ladj = b.inside ? rqs_log(jac) : 0.0f;
 }
 
+// Inverse for the sweep kernel, where the four lanes q = 0..3 of a row would otherwise all repeat the same
+// work: lanes with even q build the x-knot table, odd q the y-knot table (the same code on different
+// parameters, so the wave does not diverge), publish them in LDS, and every lane then picks the bin and
+// the six numbers of it by (run-time) index.  par: the row's 23 parameters in LDS ([0:8] widths, [8:16]
+// heights, [16:23] derivatives), tab: 24 floats of LDS scratch of the row.  One wavefront owns the row's
+// four lanes, its DS operations execute in order.
+__device__ __forceinline__ void rqs_inverse_coop(const float* par, float* tab, int q, float y, float& x, float& ladj) {
+    const int side = q & 1;
+    float v[RQS_K], pr[RQS_K], kn[RQS_K + 1];
+    {
+        const float4 a = *reinterpret_cast<const float4*>(par + 8 * side), b = *reinterpret_cast<const float4*>(par + 8 * side + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    rqs_softmax_knots(v, pr, kn);
+    if (q < 2) {
+        float* t = tab + 12 * side;
+        *reinterpret_cast<float4*>(t) = make_float4(kn[0], kn[1], kn[2], kn[3]);
+        *reinterpret_cast<float4*>(t + 4) = make_float4(kn[4], kn[5], kn[6], kn[7]);
+        t[8] = kn[8];
+    }
+    WAVE_LDS_FENCE();
+    float yk[RQS_K + 1];
+    {
+        const float4 a = *reinterpret_cast<const float4*>(tab + 12), b = *reinterpret_cast<const float4*>(tab + 16);
+        yk[0] = a.x; yk[1] = a.y; yk[2] = a.z; yk[3] = a.w; yk[4] = b.x; yk[5] = b.y; yk[6] = b.z; yk[7] = b.w;
+        yk[8] = tab[20];
+    }
+    const bool inside = (y > yk[0]) && (y <= yk[RQS_K]);
+    int k = 0;
+    float y0 = yk[0], y1 = yk[1];
+#pragma unroll
+    for (int j = 1; j < RQS_K; ++j)
+        if (yk[j] < y) { k = j; y0 = yk[j]; y1 = yk[j + 1]; }
+    const float x0 = tab[k], x1 = tab[k + 1];
+    const float r0 = (k >= 1) ? rqs_clip1(par[2 * RQS_K + k - 1]) : 0.0f;
+    const float r1 = (k + 1 < RQS_K) ? rqs_clip1(par[2 * RQS_K + (k + 1 < RQS_K ? k : 0)]) : 0.0f;
+    const float d0 = rqs_exp(r0), d1 = rqs_exp(r1);
+    const float dx = x1 - x0, dy = y1 - y0;
+    const float s = dy * rqs_rcp(dx);
+    const float yr = inside ? y - y0 : 0.0f;
+    const float e = d0 + d1 - 2.0f * s;
+    const float qa = dy * (s - d0) + yr * e;
+    const float qb = dy * d0 - yr * e;
+    const float qc = -s * yr;
+    const float z = 2.0f * qc * rqs_rcp(-qb - __builtin_amdgcn_sqrtf(qb * qb - 4.0f * qa * qc));
+    const float u = z * (1.0f - z);
+    const float rden = rqs_rcp(s + e * u);
+    const float jac = s * s * (2.0f * s * u + d0 * (1.0f - z) * (1.0f - z) + d1 * z * z) * (rden * rden);
+    x = inside ? x0 + z * dx : y;
+    ladj = inside ? rqs_log(jac) : 0.0f;
+}
+
 // Reverse mode of F = gy * y + gl * ladj:  dphi[23] and gx = dF/dx.
 __device__ __forceinline__ void rqs_backward(const float* phi, float x, float gy, float gl, float* dphi, float& gx) {
     RqsTables t;
