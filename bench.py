@@ -82,7 +82,7 @@ def cpu_baseline(D, n, beta, flat, spec, x0, u0_unused, geo, sigma0, seed, max_s
     state = dict(u=u, x=x, logdetj=sc.inverse(u)[1], logl=rosenbrock(x), logp=prior.logpdf(x), beta=beta, blobs=None)
     funcs = dict(loglike=lambda xx: (rosenbrock(xx), None), logprior=prior.logpdf, scaler=sc, flow=flow,
                  theta_geometry=geo)
-    steps = 2
+    steps = 5                                   # ~10-15 s of host work at 1e4 x 32
     opts = dict(n_max=steps, n_steps=10 ** 9, progress_bar=None, proposal_scale=sigma0)
     np.random.seed(seed)
     t0 = time.perf_counter()
