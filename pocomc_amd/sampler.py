@@ -65,8 +65,16 @@ class Sampler:
                  transform="probit", pool=None, pytorch_threads=1, flow="nsf6", train_config=None,
                  train_frequency=None, precondition=True, dynamic=True, metric="ess", n_prior=None,
                  sample="tpcn", n_steps=None, n_max_steps=None, resample="mult", output_dir=None,
-                 output_label=None, random_state=None, n_ess=None):
+                 output_label=None, random_state=None, n_ess=None, group=None):
         # sampler.py:186-373; default flow 'nsf6' like the reference (sampler.py:169)
+        #
+        # ``group`` / an initialised torch.distributed default group with more than one rank: ONE PROCESS PER GPU.
+        # The expensive parts shard over the ranks -- every MCMC step (walkers row-sharded, one all-reduce of D+4
+        # sums per step), every likelihood call, every flow fit (data parallel, gradient all-reduce) -- while the
+        # bookkeeping of the persistent pool (log-weights, beta bisection, trimming, resampling indices) is
+        # replicated: after each mutation the ranks all-gather their rows, so every rank holds the same pool and
+        # draws the same resampling indices from the same numpy stream (seed the ranks identically:
+        # ``random_state``).  n_active must be a multiple of the number of ranks.
         if n_ess is not None:
             import warnings
             n_effective = n_ess
@@ -75,6 +83,14 @@ class Sampler:
             np.random.seed(random_state)
             torch.manual_seed(random_state)
         self.random_state = random_state
+        self.group = group
+        self.world, self.rank = 1, 0
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        except (ImportError, RuntimeError):
+            pass
         self.prior = prior
         self.log_prior = prior.logpdf
         self.sample_prior = prior.rvs
@@ -87,6 +103,8 @@ class Sampler:
             raise ValueError("At least one of n_active or n_effective must be provided.")
         self.n_active = int(n_effective / 2) if n_active is None else int(n_active)
         self.n_effective = int(2 * n_active) if n_effective is None else int(n_effective)
+        if self.world > 1 and self.n_active % self.world:
+            raise ValueError("n_active must be a multiple of the number of ranks")
         self.n_steps = int(self.n_dim // 2) if n_steps is None else int(n_steps)
         self.n_max_steps = 10 * self.n_steps if n_max_steps is None else int(n_max_steps)
         self.n_total = None
@@ -179,7 +197,7 @@ class Sampler:
                 u = self.scaler.forward(x)
                 logdetj = self.scaler.inverse(u)[1]
                 logp = self.log_prior(x)
-                logl, blobs = self._log_like(x)
+                logl, blobs = self._log_like_sharded(x)
                 self.calls += self.n_active
                 bad = np.isinf(logl)
                 if np.any(bad):                                            # sampler.py:456-468
@@ -215,6 +233,50 @@ class Sampler:
             self.save_state(Path(self.output_dir) / f"{self.output_label}_final.state")
         self.pbar.close()
 
+    # ------------------------------------------------------------ sharding
+    def _my_rows(self, n):
+        """This rank's contiguous share of ``n`` rows."""
+        return slice(self.rank * n // self.world, (self.rank + 1) * n // self.world)
+
+    def _gather_rows(self, local, n):
+        """All-gather the ranks' row shares (``_my_rows``) back into the full array, identical on every rank."""
+        if self.world == 1:
+            return local
+        import torch.distributed as dist
+        local = np.ascontiguousarray(local)
+        counts = [(r + 1) * n // self.world - r * n // self.world for r in range(self.world)]
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        mine = torch.from_numpy(local).to(dev)
+        if len(set(counts)) == 1:
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine, group=self.group)
+        else:
+            parts = []
+            for r in range(self.world):
+                buf = mine if r == self.rank else torch.empty((counts[r],) + tuple(local.shape[1:]), dtype=mine.dtype, device=dev)
+                dist.broadcast(buf, src=dist.get_global_rank(self.group, r) if self.group is not None else r, group=self.group)
+                parts.append(buf)
+        return np.concatenate([p_.cpu().numpy() for p_ in parts], axis=0)
+
+    def _sum_over_ranks(self, v):
+        if self.world == 1:
+            return v
+        import torch.distributed as dist
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        t = torch.tensor([float(v)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, group=self.group)
+        return type(v)(t.item())
+
+    def _log_like_sharded(self, x):
+        """The likelihood of all rows of ``x`` (identical on every rank), each rank evaluating its share."""
+        if self.world == 1:
+            return self._log_like(x)
+        sl = self._my_rows(len(x))
+        logl, blobs = self._log_like(x[sl])
+        if blobs is not None:
+            raise NotImplementedError("blobs are not supported by the sharded Sampler")
+        return self._gather_rows(np.asarray(logl, dtype=np.float64), len(x)), None
+
     def _ess(self, weights):
         return effective_sample_size(weights) if self.metric == "ess" else unique_sample_size(weights)
 
@@ -227,24 +289,30 @@ class Sampler:
     # -------------------------------------------------------------- mutate
     def _mutate(self, cp):
         """``sampler.py:550-634``."""
-        state = dict(u=cp["u"].copy(), x=cp["x"].copy(), logdetj=cp["logdetj"].copy(), logp=cp["logp"].copy(),
-                     logl=cp["logl"].copy(), beta=cp["beta"],
-                     blobs=cp["blobs"].copy() if self.have_blobs else None)
+        sl = self._my_rows(len(cp["u"]))                      # this rank's walkers (everything when world == 1)
+        state = dict(u=cp["u"][sl].copy(), x=cp["x"][sl].copy(), logdetj=cp["logdetj"][sl].copy(),
+                     logp=cp["logp"][sl].copy(), logl=cp["logl"][sl].copy(), beta=cp["beta"],
+                     blobs=cp["blobs"][sl].copy() if self.have_blobs else None)
+        if self.world > 1 and self.have_blobs:
+            raise NotImplementedError("blobs are not supported by the sharded Sampler")
         funcs = dict(loglike=self._log_like, logprior=self.log_prior, scaler=self.scaler, flow=self.flow,
                      u_geometry=self.u_geometry, theta_geometry=self.theta_geometry)
         opts = dict(n_max=self.n_max_steps, n_steps=self.n_steps, progress_bar=self.pbar,
                     proposal_scale=self.proposal_scale)
+        if self.world > 1:
+            opts.update(group=self.group, shard_offset=sl.start)
         kernel = {(True, "tpcn"): _mcmc.preconditioned_pcn, (True, "rwm"): _mcmc.preconditioned_rwm,
                   (False, "tpcn"): _mcmc.pcn, (False, "rwm"): _mcmc.rwm}[(bool(self.preconditioned), self.sample)]
         res = kernel(state, funcs, opts)
+        n_all = len(cp["u"])
         for k in ("u", "x", "logdetj", "logl", "logp"):
-            cp[k] = res[k].copy()
+            cp[k] = self._gather_rows(res[k], n_all).copy()
         if self.have_blobs:
             cp["blobs"] = res["blobs"].copy()
         cp["efficiency"] = res["efficiency"] / (2.38 / self.n_dim ** 0.5)
         cp["steps"] = res["steps"]
         cp["accept"] = res["accept"]
-        cp["calls"] = cp["calls"] + res["calls"]
+        cp["calls"] = cp["calls"] + self._sum_over_ranks(int(res["calls"]))
         self.calls = cp["calls"]
         self.proposal_scale = res["proposal_scale"]
         return cp
@@ -256,12 +324,19 @@ class Sampler:
         if self.preconditioned and (self.t % self.train_frequency == 0 or cp["beta"] == 1.0 or self.flow_untrained):
             self.flow_untrained = False
             c = self.train_config
-            self.flow.fit(torch.tensor(u, dtype=torch.float32), weights=torch.tensor(w, dtype=torch.float32),
+            # sharded: every rank fits on its share of the rows (strided, so that each share follows the same
+            # weight distribution); gradients and losses are all-reduced inside fit
+            ut, wt = (u, w) if self.world == 1 else (u[self.rank::self.world], w[self.rank::self.world])
+            if self.world > 1:                                 # equal shares: drop the remainder rows
+                m_ = len(u) // self.world
+                ut, wt = ut[:m_], wt[:m_]
+            self.flow.fit(torch.tensor(ut, dtype=torch.float32), weights=torch.tensor(wt, dtype=torch.float32),
                           validation_split=c["validation_split"], epochs=c["epochs"],
                           batch_size=int(np.minimum(len(u) // 2, c["batch_size"])), gaussian_scale=c["gaussian_scale"],
                           laplace_scale=c["laplace_scale"], patience=c["patience"], learning_rate=c["learning_rate"],
                           annealing=c["annealing"], noise=c["noise"], shuffle=c["shuffle"],
-                          clip_grad_norm=c["clip_grad_norm"], verbose=c["verbose"])
+                          clip_grad_norm=c["clip_grad_norm"], verbose=c["verbose"], group=self.group,
+                          sharded=self.world > 1)
             theta = self.flow.forward(torch.tensor(u, dtype=torch.float32))[0].numpy()
             self.theta_geometry.fit(theta, weights=w)
         else:
@@ -371,7 +446,7 @@ class Sampler:
         logp = self.log_prior(x_q)
         ok = np.isfinite(logp)
         x_q, logdetj, logq, logp = x_q[ok], logdetj[ok], logq[ok], logp[ok]
-        logl, _ = self._log_like(x_q)
+        logl, _ = self._log_like_sharded(x_q)
         logw = logl + logp + logdetj - logq
         logz = np.logaddexp.reduce(logw) - np.log(len(logw))
         dlogz = np.std([np.logaddexp.reduce(logw[np.random.choice(len(logw), len(logw))]) - np.log(len(logw))
@@ -415,7 +490,7 @@ class Sampler:
     # ----------------------------------------------------------- checkpoint
     def __getstate__(self):
         state = self.__dict__.copy()
-        for k in ("pool", "distribute", "pbar"):
+        for k in ("pool", "distribute", "pbar", "group"):
             state.pop(k, None)
         return state
 

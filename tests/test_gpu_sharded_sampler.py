@@ -1,0 +1,77 @@
+"""The Sampler with one process per GPU: MCMC steps, likelihood calls and flow fits
+sharded over the ranks, pool bookkeeping replicated.  The GPU box has one device, so the two ranks share
+it and talk over ``gloo``; the collectives are the ``torch.distributed`` calls that run on RCCL with one
+rank per GPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+D = 4
+COV = np.array([[1.0, 0.6, 0.0, 0.0], [0.6, 1.5, 0.3, 0.0], [0.0, 0.3, 0.8, -0.2], [0.0, 0.0, -0.2, 0.5]])
+ICOV = np.linalg.inv(COV)
+NORM = -0.5 * (D * np.log(2 * np.pi) + np.linalg.slogdet(COV)[1])
+TRUE_LOGZ = -0.5 * (D * np.log(2 * np.pi) + np.linalg.slogdet(COV + 25.0 * np.eye(D))[1])
+
+
+def loglike(x):
+    return NORM - 0.5 * np.einsum("ni,ij,nj->n", x, ICOV, x)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scipy.stats import norm
+    import pocomc_amd as pc
+    calls = [0]
+
+    def counted(x):
+        calls[0] += len(x)
+        return loglike(x)
+
+    prior = pc.Prior([norm(0.0, 5.0)] * D)
+    s = pc.Sampler(prior=prior, likelihood=counted, vectorize=True, flow="maf3", n_active=256, n_effective=512,
+                   random_state=4)
+    assert s.world == world and s.rank == rank
+    s.run(n_total=1024, n_evidence=1024, progress=False)
+    logz, err = s.evidence()
+    x, w, logl, logp = s.posterior()
+    np.savez(out % rank, logz=logz, beta=np.asarray(s.particles.get("beta")), x=x, w=w, calls=s.calls,
+             own_calls=calls[0], params=s.flow.params.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sampler(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    # replicated bookkeeping: identical temperature ladder, pool, evidence and flow on both ranks
+    assert np.array_equal(r0["beta"], r1["beta"])
+    assert np.array_equal(r0["x"], r1["x"]) and np.array_equal(r0["w"], r1["w"])
+    assert float(r0["logz"]) == float(r1["logz"])
+    assert np.array_equal(r0["params"], r1["params"])
+    # the likelihood work is shared: each rank made about half of the calls
+    assert int(r0["calls"]) == int(r1["calls"])
+    assert abs(int(r0["own_calls"]) + int(r1["own_calls"]) - int(r0["calls"])) <= 0.02 * int(r0["calls"])
+    assert 0.4 < int(r0["own_calls"]) / int(r0["calls"]) < 0.6
+    # and the answer is right
+    assert abs(float(r0["logz"]) - TRUE_LOGZ) < 0.35, (float(r0["logz"]), TRUE_LOGZ)
+    m = np.average(r0["x"], weights=r0["w"], axis=0)
+    c = np.cov(r0["x"].T, aweights=r0["w"])
+    post = np.linalg.inv(ICOV + np.eye(D) / 25.0)
+    assert np.abs(m).max() < 0.25
+    assert np.abs(c - post).max() < 0.35
