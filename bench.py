@@ -158,6 +158,8 @@ def main():
     flow.inverse_algo = {"auto": 0, "triangular": 1, "naive": 2, "triangular_v1": 3, "triangular_v2": 4, "triangular_v3": 5}[args.inverse]
     torch.manual_seed(0)                                    # same shuffles / batches on every rank
     u_fit = torch.from_numpy(scaler.forward(x_fit[:n])).float().cuda()
+    from pocomc_amd.train import _train_state
+    _train_state(flow)                                      # one-time host-side index maps / buffers of the Flow
     torch.cuda.synchronize()
     tf0 = time.perf_counter()
     hist = flow.fit(u_fit, epochs=50, batch_size=512, validation_split=0.5, patience=D, annealing=False, verbose=0)

@@ -124,6 +124,12 @@ int pmc_maf_train_epoch(const pmc_maf_t* m, const pmc_maf_train_t* tr, pmc_adamw
                         const float* w, const int64_t* perm, int64_t n, int64_t batch_size, float* loss,
                         void* stream);
 
+/* The validation pass of one epoch, flow.py:327-348, in one call: for every batch (rows perm[b0 .. b0+nb) or
+ * consecutive rows) loss += sum_n c_n * (-log_prob(x_n)) with c_n as in pmc_maf_loss_grad.
+ * logp_scratch f32 [batch_size]. */
+int pmc_maf_valid_epoch(const pmc_maf_t* m, const float* x, const float* w, const int64_t* perm, int64_t n,
+                        int64_t batch_size, float* logp_scratch, float* loss, void* stream);
+
 /* out += sum_n -(logp_n * c_n)  (validation loss, flow.py:336-341);  out += sum_n v_n. */
 int pmc_neg_weighted_sum(const float* logp, const float* w, const float* wsum, float wmul, float* out,
                          int64_t n, void* stream);

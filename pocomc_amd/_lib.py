@@ -98,6 +98,7 @@ SIGNATURES = {
     "pmc_maf_loss_grad": (C.c_int, [P(pmc_maf_t), P(pmc_maf_train_t), c_p, c_p, c_p, C.c_float, c_p, c_p, i64, c_p]),
     "pmc_maf_train_epoch": (C.c_int, [P(pmc_maf_t), P(pmc_maf_train_t), P(pmc_adamw_t), c_p, c_p, c_p, i64, i64, c_p,
                                       c_p]),
+    "pmc_maf_valid_epoch": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, i64, i64, c_p, c_p, c_p]),
     "pmc_neg_weighted_sum": (C.c_int, [c_p, c_p, c_p, C.c_float, c_p, i64, c_p]),
     "pmc_sum_f32": (C.c_int, [c_p, c_p, i64, c_p]),
     "pmc_adamw_step": (C.c_int, [c_p, c_p, c_p, c_p, i64, f64, f64, f64, f64, f64, f64, i64, c_p, c_p]),

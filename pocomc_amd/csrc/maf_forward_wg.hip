@@ -35,7 +35,8 @@ template <int NW, int UNI, int MODE>
 __global__ __launch_bounds__(64 * NW) void maf_forward_wg_kernel(pmc_maf_t m, const float* __restrict__ in,
                                                                  float* __restrict__ out,
                                                                  float* __restrict__ ladj_out,
-                                                                 float* __restrict__ logprob_out, int64_t n) {
+                                                                 float* __restrict__ logprob_out, int64_t n,
+                                                                 const int64_t* __restrict__ idx) {
     constexpr bool PROF = false;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(64 * NW) void maf_forward_wg_kernel(pmc_maf_t m, co
     for (int e = tid; e < Dp * 16; e += 64 * NW) {
         const int r = e >> 4, pp = e & 15;
         float v = 0.0f;
-        if (r < D && row0 + pp < n) v = in[(row0 + pp) * D + ford[r]];
+        if (r < D && row0 + pp < n) v = in[(idx ? idx[row0 + pp] : row0 + pp) * D + ford[r]];   // idx: row gather
         ld[lidx(r, pp)] = v;
         if (MODE) Xc[lidx(r, pp)] = 0.0f;
     }
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(64 * NW) void maf_forward_wg_kernel(pmc_maf_t m, co
                                 Xn[lidx(rank, p)] = y;
                             } else if (last) {
                                 Xn[lidx(rank, p)] = y;
-                                if (row0 + p < n) out[(row0 + p) * D + feat] = y;
+                                if (out && row0 + p < n) out[(row0 + p) * D + feat] = y;
                             } else {
                                 // the next transform's rank order
                                 Xn[lidx(rank_of_feat[(MODE ? t - 1 : t + 1) * D + feat], p)] = y;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(64 * NW) void maf_forward_wg_kernel(pmc_maf_t m, co
                                 Xn[lidx(rank, pp)] = y;
                             } else if (last) {
                                 Xn[lidx(rank, pp)] = y;
-                                if (row0 + pp < n) out[(row0 + pp) * D + feat] = y;
+                                if (out && row0 + pp < n) out[(row0 + pp) * D + feat] = y;
                             } else {
                                 Xn[lidx(rank_of_feat[(MODE ? t - 1 : t + 1) * D + feat], pp)] = y;
                             }
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(64 * NW) void maf_forward_wg_kernel(pmc_maf_t m, co
 
 template <int NW, int UNI, int MODE>
 static int launch_forward_wg(const pmc_maf_t* m, const float* x, float* z, float* ladj, float* log_prob, int64_t n,
-                             hipStream_t st) {
+                             hipStream_t st, const int64_t* idx = nullptr) {
     const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 16 * NW + (UNI ? PANEL_TILES * 256 : 0) +
                                 (MODE ? m->Dp * 16 : 0)) * sizeof(float);
     if (lds > 160 * 1024) return pmc_fail("pmc_maf_forward: flow too wide for 160 KB of LDS");
@@ -174,20 +175,20 @@ static int launch_forward_wg(const pmc_maf_t* m, const float* x, float* z, float
         lds_set = lds;
     }
     hipLaunchKernelGGL((maf_forward_wg_kernel<NW, UNI, MODE>), dim3((unsigned)((n + 15) / 16)), dim3(64 * NW), lds, st,
-                       *m, x, z, ladj, log_prob, n);
+                       *m, x, z, ladj, log_prob, n, idx);
     return pmc_check_launch("maf_forward_wg_kernel");
 }
 
 int pmc_launch_forward_wg(const pmc_maf_t* m, const float* x, float* z, float* ladj, float* log_prob, int64_t n,
-                          hipStream_t st) {
+                          hipStream_t st, const int64_t* idx) {
     // enough row sets to give every SIMD a few waves anyway -> fewer waves per set (less barrier idling)
     static const int force = getenv("PMC_FWD_NW") ? atoi(getenv("PMC_FWD_NW")) : 0;      // A/B switch
     const bool wide = force ? force == 8 : n <= 16 * 1024;
     if (m->n_out == RQS_NOUT)
-        return wide ? launch_forward_wg<8, 1, 0>(m, x, z, ladj, log_prob, n, st)
-                    : launch_forward_wg<4, 1, 0>(m, x, z, ladj, log_prob, n, st);
-    return wide ? launch_forward_wg<8, 0, 0>(m, x, z, ladj, log_prob, n, st)
-                : launch_forward_wg<4, 0, 0>(m, x, z, ladj, log_prob, n, st);
+        return wide ? launch_forward_wg<8, 1, 0>(m, x, z, ladj, log_prob, n, st, idx)
+                    : launch_forward_wg<4, 1, 0>(m, x, z, ladj, log_prob, n, st, idx);
+    return wide ? launch_forward_wg<8, 0, 0>(m, x, z, ladj, log_prob, n, st, idx)
+                : launch_forward_wg<4, 0, 0>(m, x, z, ladj, log_prob, n, st, idx);
 }
 
 // D-pass inverse through the same workgroup kernel (the only inverse of the spline flows until the

@@ -521,6 +521,31 @@ __global__ __launch_bounds__(256) void neg_weighted_sum_kernel(const float* __re
     if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// validation loss of one batch (flow.py:336-341): loss += sum_i -(logp_i * c_i), c_i = 1 or
+// w[idx_i] * wmul / sum_j w[idx_j]; ONE block, fixed order (deterministic)
+__global__ __launch_bounds__(256) void batch_nll_kernel(const float* __restrict__ logp, const float* __restrict__ w,
+                                                        const int64_t* __restrict__ idx, float wmul,
+                                                        float* __restrict__ loss, int64_t n) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    float scale = 1.0f;
+    if (w) {
+        float s = 0.0f;
+        for (int64_t i = tid; i < n; i += 256) s += w[idx ? idx[i] : i];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if ((tid & 63) == 0) red[tid >> 6] = s;
+        __syncthreads();
+        scale = wmul / ((red[0] + red[1]) + (red[2] + red[3]));
+        __syncthreads();
+    }
+    float s = 0.0f;
+    for (int64_t i = tid; i < n; i += 256) s += -(logp[i] * (w ? w[idx ? idx[i] : i] * scale : 1.0f));
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) *loss += (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ v, float* __restrict__ out, int64_t n) {
     __shared__ float red[4];
     float s = 0.0f;
@@ -652,6 +677,22 @@ extern "C" int pmc_debug_lossgrad_profile(const pmc_maf_t* m, const pmc_maf_trai
     return launch_lossgrad(m, tr, x, nullptr, nullptr, 1000.0f, grad, loss, n, (hipStream_t)stream, prof);
 }
 extern "C" int pmc_debug_train_waves(void) { return TRAIN_WAVES; }
+
+// One pass over a validation set in batches (flow.py:327-348), everything enqueued by one call.
+extern "C" int pmc_maf_valid_epoch(const pmc_maf_t* m, const float* x, const float* w, const int64_t* perm, int64_t n,
+                                   int64_t batch_size, float* logp_scratch, float* loss, void* stream) {
+    if (!m || !x || !logp_scratch || !loss || n < 0 || batch_size < 1) return pmc_fail("pmc_maf_valid_epoch: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    for (int64_t b0 = 0; b0 < n; b0 += batch_size) {
+        const int64_t nb = (n - b0 < batch_size) ? n - b0 : batch_size;
+        const float* xb = perm ? x : x + b0 * m->D;
+        const float* wb = (w && !perm) ? w + b0 : w;
+        const int64_t* ib = perm ? perm + b0 : nullptr;
+        if (int rc = pmc_launch_forward_wg(m, xb, nullptr, nullptr, logp_scratch, nb, st, ib)) return rc;
+        hipLaunchKernelGGL(batch_nll_kernel, dim3(1), dim3(256), 0, st, (const float*)logp_scratch, wb, ib, 1000.0f, loss, nb);
+    }
+    return pmc_check_launch("pmc_maf_valid_epoch");
+}
 
 extern "C" int pmc_neg_weighted_sum(const float* logp, const float* w, const float* wsum, float wmul, float* out,
                                     int64_t n, void* stream) {

@@ -12,7 +12,7 @@ int pmc_launch_inverse_tri2(const pmc_maf_t* m, const float* z, float* x, float*
                             hipStream_t stream);
 
 int pmc_launch_forward_wg(const pmc_maf_t* m, const float* x, float* z, float* ladj, float* log_prob, int64_t n,
-                          hipStream_t stream);
+                          hipStream_t stream, const int64_t* idx = nullptr);
 int pmc_launch_inverse_dpass_wg(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream);
 int pmc_launch_inverse_tri_nsf(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream);
 int pmc_launch_inverse_tri4(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream);

@@ -299,8 +299,20 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
         else:
             opt.epoch(x_train, w_train, perm, batch_size, clip_grad_norm, acc)
         vacc = acc2[1:2]
-        if validation:
-            vb = max(1, batch_size // world) if sharded else batch_size
+        if validation and not sharded:
+            # the whole validation pass in one library call (batches of the reference's DataLoader, flow.py:327-348)
+            vperm = torch.randperm(x_valid.shape[0]).to(dev) if shuffle else None
+            ts = _train_state(flow)
+            if getattr(ts, "logp_scratch", None) is None or ts.logp_scratch.numel() < batch_size:
+                ts.logp_scratch = torch.empty(int(batch_size), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(flow.lib.pmc_maf_valid_epoch(C.byref(flow._desc), _lib.ptr(x_valid),
+                                                        _lib.ptr(w_valid) if w_valid is not None else None,
+                                                        _lib.ptr(vperm) if vperm is not None else None,
+                                                        x_valid.shape[0], int(batch_size), _lib.ptr(ts.logp_scratch),
+                                                        _lib.ptr(vacc), _lib.stream_handle()), "pmc_maf_valid_epoch")
+        elif validation:
+            vb = max(1, batch_size // world)
             for idx in _batches(x_valid.shape[0], vb, shuffle):
                 idx = idx.to(dev)
                 vacc += batch_loss(flow, x_valid[idx].contiguous(),

@@ -261,3 +261,35 @@ def test_nsf_fit_learns_a_bimodal_density():
     # both modes are populated by the samples
     frac = (x[:, 0] > 0).float().mean().item()
     assert 0.3 < frac < 0.7
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("name", ["maf3", "nsf3"])
+def test_validation_epoch_call_equals_batch_by_batch(name, weighted):
+    """pmc_maf_valid_epoch (one call per validation pass, rows gathered through the permutation inside the forward
+    kernel) against the per-batch path (torch gather + forward + weighted sum) on the same batches."""
+    import ctypes as C
+    from pocomc_amd import Flow, _lib
+    from pocomc_amd.train import batch_loss, _train_state
+    rng = np.random.default_rng(8)
+    n, D, bs = 1000, 6, 256
+    f = Flow(D, name, seed=2)
+    x = torch.from_numpy((rng.normal(size=(n, D)) * 1.5).astype(np.float32)).cuda()
+    w = torch.from_numpy(rng.uniform(0.1, 1.0, size=n).astype(np.float32)).cuda() if weighted else None
+    perm = torch.from_numpy(rng.permutation(n)).cuda()
+    ref = 0.0
+    for b0 in range(0, n, bs):
+        idx = perm[b0:b0 + bs]
+        ref += float(batch_loss(f, x[idx].contiguous(), None if w is None else w[idx].contiguous()))
+    acc = torch.zeros(1, dtype=torch.float32, device="cuda")
+    scratch = torch.empty(bs, dtype=torch.float32, device="cuda")
+    _lib.check(f.lib.pmc_maf_valid_epoch(C.byref(f._desc), _lib.ptr(x), _lib.ptr(w) if w is not None else None,
+                                         _lib.ptr(perm), n, bs, _lib.ptr(scratch), _lib.ptr(acc), _lib.stream_handle()))
+    np.testing.assert_allclose(float(acc), ref, rtol=2e-6)
+    # consecutive rows (no permutation)
+    acc.zero_()
+    _lib.check(f.lib.pmc_maf_valid_epoch(C.byref(f._desc), _lib.ptr(x), _lib.ptr(w) if w is not None else None, None,
+                                         n, bs, _lib.ptr(scratch), _lib.ptr(acc), _lib.stream_handle()))
+    ref2 = sum(float(batch_loss(f, x[b0:b0 + bs].contiguous(), None if w is None else w[b0:b0 + bs].contiguous()))
+               for b0 in range(0, n, bs))
+    np.testing.assert_allclose(float(acc), ref2, rtol=2e-6)
