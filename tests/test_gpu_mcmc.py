@@ -269,3 +269,40 @@ def test_variates_drawn_ahead_equal_inline_draws():
         for k in ("u", "x", "logl", "logp", "logdetj"):
             assert np.array_equal(res[0][k], res[1][k]), (kind, k)
         assert res[0]["accept"] == res[1]["accept"]
+
+
+@pytest.mark.parametrize("name", ["tpcn_n256_d10_normal", "tpcn_n128_d6_mixed_bc"])
+def test_likelihoods_with_holes_match_the_oracle(name):
+    """Edge cases of mcmc.py:100-134: a likelihood that is -inf on part of the space and NaN on another part
+    (NaN acceptance ratios count as 0, mcmc.py:134), next to non-finite priors / proposals of the case itself.
+    Same numpy stream for the oracle (the reference's algorithm) and the product (replayed variates)."""
+    from pocomc_amd import mcmc as pmcmc
+    c = cases.MCMC_CASES[name]
+
+    def holes(base):
+        def f(x):
+            l, b = base(x)
+            l = np.array(l, dtype=np.float64, copy=True)
+            l[x[:, 0] > 0.8] = -np.inf
+            l[(x[:, 1] < -0.9) & (x[:, 0] <= 0.8)] = np.nan
+            return l, b
+        return f
+
+    out = []
+    for which in ("oracle", "product"):
+        state, funcs, opts, aux = oracle_case(name) if which == "oracle" else product_case(name)
+        funcs["loglike"] = holes(funcs["loglike"])
+        opts["n_max"] = 4
+        np.random.seed(c["seed"])
+        if which == "oracle":
+            out.append(getattr(omcmc, c["kind"])(state, funcs, opts))
+        else:
+            out.append(getattr(pmcmc, c["kind"])(state, funcs, opts, replay=omcmc.LegacyStream()))
+    o, p_ = out
+    assert o["steps"] == p_["steps"] and abs(o["calls"] - p_["calls"]) <= 2
+    # a walker never moves into a hole
+    assert np.isfinite(p_["logl"]).all()
+    same = np.isclose(o["logl"], p_["logl"], rtol=1e-6, atol=1e-8)
+    assert same.mean() > 0.97
+    close(p_["x"][same], o["x"][same], 1e-4, "x")
+    np.testing.assert_allclose(p_["accept"], o["accept"], atol=0.02)
