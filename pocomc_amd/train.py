@@ -289,11 +289,38 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
     start = time.time()
 
     n_train = x_train.shape[0]
-    acc2 = torch.zeros(2, dtype=torch.float32, device=dev)         # [train loss, val loss] of the epoch
-    for epoch in range(epochs):
+    n_valid = x_valid.shape[0] if validation else 0
+    # One epoch may be IN FLIGHT while the host looks at the previous epoch's losses (no scheduler, one GPU): the
+    # early-stop test needs every epoch's loss on the host, and waiting for it before enqueuing the next epoch
+    # leaves the GPU idle for the whole host turn-around (most of an epoch when the training set is one or two
+    # batches, the Sampler's usual case).  The speculative epoch changes nothing observable: on an early stop the
+    # best parameters are restored (flow.py:369-374), and no epoch is enqueued past `epochs`.
+    pipelined = (sched is None) and not sharded
+    slots = 2 if pipelined else 1
+    acc_d = [torch.zeros(2, dtype=torch.float32, device=dev) for _ in range(slots)]   # [train loss, val loss]
+    acc_h = [torch.zeros(2, dtype=torch.float32).pin_memory() for _ in range(slots)]
+    done = [torch.cuda.Event() for _ in range(slots)]
+    after = [torch.empty_like(flow.params) for _ in range(slots)]                    # parameters after the epoch
+    h_perm = [[torch.empty(max(n_train, 1), dtype=torch.int64).pin_memory() for _ in range(slots)],
+              [torch.empty(max(n_valid, 1), dtype=torch.int64).pin_memory() for _ in range(slots)]]
+    d_perm = [[torch.empty(max(n_train, 1), dtype=torch.int64, device=dev) for _ in range(slots)],
+              [torch.empty(max(n_valid, 1), dtype=torch.int64, device=dev) for _ in range(slots)]]
+    ts = _train_state(flow)
+    if validation and not sharded and (getattr(ts, "logp_scratch", None) is None or ts.logp_scratch.numel() < batch_size):
+        ts.logp_scratch = torch.empty(int(batch_size), dtype=torch.float32, device=dev)
+
+    def upload_perm(which, sl, n):
+        # DataLoader(shuffle=...), flow.py:251-265: a fresh permutation per pass (pinned staging, no host sync)
+        torch.randperm(n, out=h_perm[which][sl][:n])
+        d_perm[which][sl][:n].copy_(h_perm[which][sl][:n], non_blocking=True)
+        return d_perm[which][sl][:n]
+
+    def enqueue(epoch):
+        sl = epoch % slots
+        acc2 = acc_d[sl]
         acc2.zero_()
         acc = acc2[0:1]
-        perm = torch.randperm(n_train).to(dev) if shuffle else None  # DataLoader(shuffle=...), flow.py:251-265
+        perm = upload_perm(0, sl, n_train) if shuffle else None
         if sharded:
             sharded_epoch(flow, opt, x_train, w_train, perm, batch_size, clip_grad_norm, acc, group)
         else:
@@ -301,29 +328,36 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
         vacc = acc2[1:2]
         if validation and not sharded:
             # the whole validation pass in one library call (batches of the reference's DataLoader, flow.py:327-348)
-            vperm = torch.randperm(x_valid.shape[0]).to(dev) if shuffle else None
-            ts = _train_state(flow)
-            if getattr(ts, "logp_scratch", None) is None or ts.logp_scratch.numel() < batch_size:
-                ts.logp_scratch = torch.empty(int(batch_size), dtype=torch.float32, device=dev)
+            vperm = upload_perm(1, sl, n_valid) if shuffle else None
             with torch.cuda.device(dev):
                 _lib.check(flow.lib.pmc_maf_valid_epoch(C.byref(flow._desc), _lib.ptr(x_valid),
                                                         _lib.ptr(w_valid) if w_valid is not None else None,
                                                         _lib.ptr(vperm) if vperm is not None else None,
-                                                        x_valid.shape[0], int(batch_size), _lib.ptr(ts.logp_scratch),
+                                                        n_valid, int(batch_size), _lib.ptr(ts.logp_scratch),
                                                         _lib.ptr(vacc), _lib.stream_handle()), "pmc_maf_valid_epoch")
         elif validation:
             vb = max(1, batch_size // world)
-            for idx in _batches(x_valid.shape[0], vb, shuffle):
+            for idx in _batches(n_valid, vb, shuffle):
                 idx = idx.to(dev)
                 vacc += batch_loss(flow, x_valid[idx].contiguous(),
                                    None if w_valid is None else w_valid[idx].contiguous(), group, sharded)
-        n_tr, n_va = n_train, (x_valid.shape[0] if validation else 0)
         if sharded:
             # the validation loss is a sum over the ranks' shards (the training loss already is: it rode
-            # along with the gradients); the row counts are global
+            # along with the gradients)
             dist.all_reduce(acc2[1:2], group=group)
-            n_tr, n_va = n_tr * world, n_va * world
-        both = acc2.cpu().numpy()                                      # the one sync of the epoch
+        after[sl].copy_(flow.params)
+        acc_h[sl].copy_(acc2, non_blocking=True)
+        done[sl].record()
+
+    if epochs > 0:
+        enqueue(0)
+    for epoch in range(epochs):
+        sl = epoch % slots
+        if pipelined and epoch + 1 < epochs:
+            enqueue(epoch + 1)                                        # speculative: runs while we read this epoch's losses
+        done[sl].synchronize()                                        # the one wait of the epoch
+        both = acc_h[sl].numpy()
+        n_tr, n_va = (n_train * world, n_valid * world) if sharded else (n_train, n_valid)
         train_loss = float(both[0]) / max(n_tr, 1)                   # flow.py:323
         history["loss"].append(train_loss)
         if validation:
@@ -336,7 +370,7 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
                   + (", val loss: %5.2f" % val_loss if validation else ""))
         if history[monitor][-1] < best_loss:                          # flow.py:364-367
             best_loss, best_epoch = history[monitor][-1], epoch
-            best_model.copy_(flow.params)
+            best_model.copy_(after[sl])
         if epoch - best_epoch >= int(1.5 * patience):                 # flow.py:369-374
             flow.params.copy_(best_model)
             flow.repack()
@@ -344,6 +378,8 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
                 print("Finished early after %3d epochs" % best_epoch)
                 print("Best loss achieved %5.2f" % best_loss)
             break
+        if not pipelined and epoch + 1 < epochs:
+            enqueue(epoch + 1)
     if verbose > 0:
         total = time.time() - start
         print("\nTime total:     %5.2f sec" % total)
