@@ -85,6 +85,8 @@ typedef struct pmc_maf_train {
     float* xt_scratch;        /* [n_slabs][T + 1][Dp * 16] */
     float* loss_partial;      /* [n_slabs] */
     float* sq_partial;        /* [n_sq_partial] per-block sums of squared gradient entries */
+    float* act_scratch;       /* [n_slabs][T][3][Hp * 16] hidden activations kept from the forward sweep, or NULL (the
+                               * backward sweep then recomputes them) */
     const int32_t* sched;     /* device [3][sched_waves][2]: (first, count) of the weight-gradient tiles every wave of a
                                * workgroup takes in the phases {layer 3, layers 2 and 1, layer 0} (MAFSpec.train_schedule) */
     int32_t sched_waves;      /* must equal the kernel's wave count per workgroup (8) */

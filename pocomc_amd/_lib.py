@@ -28,7 +28,7 @@ class pmc_maf_train_t(C.Structure):
     _fields_ = [("packedT", c_p), ("gmap", c_p), ("pkT_per_transform", C.c_int64),
                 ("gmap_per_transform", C.c_int64),
                 ("slabs", c_p), ("slab_stride", C.c_int64), ("n_slabs", C.c_int32), ("n_sq_partial", C.c_int32),
-                ("xt_scratch", c_p), ("loss_partial", c_p), ("sq_partial", c_p),
+                ("xt_scratch", c_p), ("loss_partial", c_p), ("sq_partial", c_p), ("act_scratch", c_p),
                 ("sched", c_p), ("sched_waves", C.c_int32), ("reserved", C.c_int32), ("wsum", c_p)]
 
 

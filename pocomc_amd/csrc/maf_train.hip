@@ -142,6 +142,9 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
     const int* rank_of_feat = m.meta + 8 + T * D;
     float* slab = tr.slabs + (size_t)blockIdx.x * tr.slab_stride;
     float* xt = tr.xt_scratch + (size_t)blockIdx.x * (T + 1) * Dp * 16;
+    // hidden activations of every transform, kept from the forward sweep (the backward sweep then loads them
+    // instead of recomputing three layers); NULL: recompute
+    float* act = tr.act_scratch ? tr.act_scratch + (size_t)blockIdx.x * T * 3 * Hp * 16 : nullptr;
 
     // sum of the batch weights, the same fixed-order sum in every workgroup (flow.py:311)
     float wscale = 1.0f;
@@ -211,6 +214,10 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
             const MafView wvw = maf_view(m, t);
             float* xtn = xt + (size_t)(t + 1) * Dp * 16;
             hidden_pass_wg<TRAIN_WAVES, TRAIN_PF, PROF>(m, wvw, Xc, A, B, Cb, wv, lane, pacc, tk);
+            if (act) {                                       // A, B, Cb are contiguous in LDS: one copy
+                float4* dst = reinterpret_cast<float4*>(act + (size_t)t * 3 * Hp * 16);
+                for (int e = tid; e < 3 * Hp * 4; e += TRAIN_THREADS) dst[e] = reinterpret_cast<const float4*>(A)[e];
+            }
             LAPT(2)
             if (UNI == 0) {
                 for (int O = wv; O < nOeff; O += TRAIN_WAVES) {
@@ -292,9 +299,16 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
             const float4* xsrc = reinterpret_cast<const float4*>(xt + (size_t)t * Dp * 16);
             if (UNI == 0) {
                 for (int e = tid; e < Dp * 4; e += TRAIN_THREADS) reinterpret_cast<float4*>(E)[e] = xsrc[e];
-                lds_barrier();
-                // recompute this transform's activations and (shift, raw)
-                hidden_pass_wg<TRAIN_WAVES, TRAIN_PF, PROF>(m, wvw, E, A, B, Cb, wv, lane, pacc, tk);
+                if (act) {
+                    const float4* src = reinterpret_cast<const float4*>(act + (size_t)t * 3 * Hp * 16);
+                    for (int e = tid; e < 3 * Hp * 4; e += TRAIN_THREADS) reinterpret_cast<float4*>(A)[e] = src[e];
+                    lds_barrier();
+                } else {
+                    lds_barrier();
+                    // recompute this transform's activations
+                    hidden_pass_wg<TRAIN_WAVES, TRAIN_PF, PROF>(m, wvw, E, A, B, Cb, wv, lane, pacc, tk);
+                }
+                // (shift, raw) of the transform
                 for (int O = wv; O < nOeff; O += TRAIN_WAVES) {
                     f32x4 o = bias4(wvw.b3, 16 * O + 4 * q);
                     o = mac_range<TRAIN_PF>(o, wvw.f3 + (size_t)O * nT * 64, Cb, 0, nT, lane);
@@ -340,8 +354,14 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                 for (int e = tid; e < Dp * 4; e += TRAIN_THREADS) reinterpret_cast<float4*>(XB)[e] = xsrc[e];
                 for (int e = tid; e < Hp * 4; e += TRAIN_THREADS)
                     reinterpret_cast<float4*>(E)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-                lds_barrier();
-                hidden_pass_wg<TRAIN_WAVES, TRAIN_PF, PROF>(m, wvw, XB, A, B, Cb, wv, lane, pacc, tk);
+                if (act) {
+                    const float4* src = reinterpret_cast<const float4*>(act + (size_t)t * 3 * Hp * 16);
+                    for (int e = tid; e < 3 * Hp * 4; e += TRAIN_THREADS) reinterpret_cast<float4*>(A)[e] = src[e];
+                    lds_barrier();
+                } else {
+                    lds_barrier();
+                    hidden_pass_wg<TRAIN_WAVES, TRAIN_PF, PROF>(m, wvw, XB, A, B, Cb, wv, lane, pacc, tk);
+                }
                 LAPT(4)
                 for (int c = 0; c < nXT; ++c) {
                     const int O0 = RQS_NOUT * c;                         // first output tile of the panel
