@@ -5,11 +5,12 @@
 //                                          c_n = w_n * 1000 / sum(w_batch) (flow.py:311-312)
 //
 // A minibatch is at most 512 rows (sampler.py:289), so the step is latency bound, not throughput
-// bound.  One WORKGROUP of four wavefronts owns 16 rows: the tiles of every layer are dealt to the
-// four waves (cost-balanced over the triangular layers), the activations sit in workgroup LDS in
+// bound.  One WORKGROUP of TRAIN_WAVES (16) wavefronts owns 16 rows: the tiles of every layer are dealt to the
+// waves (cost-balanced over the triangular layers), the activations sit in workgroup LDS in
 // the MFMA operand layout of the inference kernels, and a barrier separates dependent layers.
-// Forward stores only the INPUT of every transform (global scratch, L2 resident); the backward
-// sweep recomputes one transform's activations at a time, then
+// Forward stores the input and the three hidden activations of every transform in a global scratch
+// (L2 resident; without the activation scratch the backward sweep recomputes them); the backward
+// sweep takes one transform at a time:
 //     d(shift, raw) -> dW3, db3 -> dh2 = W3^T . -> relu' -> dW2, db2 -> dh1 = da2 + W2^T da2 -> ...
 // Data-gradient products  dh = W^T da  are MFMA bursts over pre-transposed weight fragments
 // (packedT); weight-gradient tiles  dW[out][in] = sum_rows da[out][row] h[in][row]  contract over
