@@ -44,6 +44,20 @@ def rosenbrock(x):
     return -t.sum(axis=1)
 
 
+def make_target(name, D):
+    """The host likelihood of the benchmark: BASELINE configs[3] / north_star (Rosenbrock) or configs[1]
+    (correlated Gaussian, 0.95 off the diagonal: docs/source/likelihood.ipynb cell 4)."""
+    if name == "rosenbrock":
+        return rosenbrock
+    cov = 0.95 * np.ones((D, D)) + 0.05 * np.eye(D)
+    icov = np.linalg.inv(cov)
+    norm = -0.5 * (D * np.log(2.0 * np.pi) + np.linalg.slogdet(cov)[1])
+
+    def gaussian(x):
+        return norm - 0.5 * np.einsum("ij,ij->i", x @ icov, x)
+    return gaussian
+
+
 class UniformBox:
     """Host prior (used by the CPU baseline): product of U(low, high)."""
 
@@ -58,7 +72,7 @@ class UniformBox:
         return np.where(inside.all(axis=1), self.const, -np.inf)
 
 
-def cpu_baseline(D, n, beta, flat, spec, x0, u0_unused, geo, sigma0, seed, max_seconds=30.0):
+def cpu_baseline(D, n, beta, flat, spec, x0, u0_unused, geo, sigma0, seed, max_seconds=30.0, target=rosenbrock):
     """The oracle (CPU restatement of the reference's algorithm: per-step numpy float64 +
     the float32 D-pass MAF inverse) timed on the host cores, on a bounded sample."""
     from threadpoolctl import threadpool_info
@@ -79,8 +93,8 @@ def cpu_baseline(D, n, beta, flat, spec, x0, u0_unused, geo, sigma0, seed, max_s
         n_s //= 2
     x = x0[:n_s]
     u = sc.forward(x)
-    state = dict(u=u, x=x, logdetj=sc.inverse(u)[1], logl=rosenbrock(x), logp=prior.logpdf(x), beta=beta, blobs=None)
-    funcs = dict(loglike=lambda xx: (rosenbrock(xx), None), logprior=prior.logpdf, scaler=sc, flow=flow,
+    state = dict(u=u, x=x, logdetj=sc.inverse(u)[1], logl=target(x), logp=prior.logpdf(x), beta=beta, blobs=None)
+    funcs = dict(loglike=lambda xx: (target(xx), None), logprior=prior.logpdf, scaler=sc, flow=flow,
                  theta_geometry=geo)
     steps = 5                                   # ~10-15 s of host work at 1e4 x 32
     opts = dict(n_max=steps, n_steps=10 ** 9, progress_bar=None, proposal_scale=sigma0)
@@ -113,6 +127,9 @@ def main():
     ap.add_argument("--event-every", type=int, default=10,
                     help="record the HIP event pair around the flow-inverse launch on every k-th timed step (an event "
                          "pair per step costs ~5 %% of the step rate: it splits the pre-phase's back-to-back launches)")
+    ap.add_argument("--target", choices=["rosenbrock", "gaussian"], default="rosenbrock",
+                    help="host likelihood: Rosenbrock (north_star / BASELINE configs[3], default) or the 0.95-correlated "
+                         "Gaussian of configs[1]")
     ap.add_argument("--no-pin", action="store_true",
                     help="do not pin the driver thread to the core it starts on (the host likelihood is single-threaded "
                          "numpy; migrations between cores cost ~8 %% and most of the run-to-run noise)")
@@ -153,7 +170,8 @@ def main():
     x = rng.uniform(-10.0, 10.0, size=(n, D))
     u = scaler.forward(x)
     logdetj = scaler.inverse(u)[1]
-    logl, logp = rosenbrock(x), prior.logpdf(x)
+    target = make_target(args.target, D)
+    logl, logp = target(x), prior.logpdf(x)
     flow = Flow(D, args.flow, seed=0)                       # replicated weights
     flow.inverse_algo = {"auto": 0, "triangular": 1, "naive": 2, "triangular_v1": 3, "triangular_v2": 4, "triangular_v3": 5}[args.inverse]
     torch.manual_seed(0)                                    # same shuffles / batches on every rank
@@ -206,7 +224,7 @@ def main():
     eng.set_geometry(mu=geo.t_mean, cov=geo.t_cov)
     ad = Adaptation("preconditioned_pcn", D, n * world, n_steps=10 ** 9, n_max=10 ** 9, sigma0=sigma0,
                     mu0=geo.t_mean, logp2_0=-np.inf)
-    loglike = lambda xx: (rosenbrock(xx), None)
+    loglike = lambda xx: (target(xx), None)
     t_host = [0.0]
 
     t_seg = {"propose_call": 0.0, "evaluate_call": 0.0, "accept_call": 0.0, "adapt": 0.0}
@@ -257,6 +275,10 @@ def main():
                 pinned_core = None
         except (OSError, AttributeError):
             pinned_core = None
+    # the step loops run the host likelihood on the (pinned) driver thread: keep BLAS from spawning a thread per
+    # core for a 1e4 x 32 x 32 product (its spinning workers would also delay the runtime's launch path)
+    from threadpoolctl import threadpool_limits
+    blas_limit = threadpool_limits(limits=1)
     for _ in range(args.warmup):
         step()
     # ---- timed region: K steps through the composite entry points; the only instrumentation is one
@@ -302,6 +324,7 @@ def main():
         step()
     torch.cuda.synchronize()
     dt_inst = time.perf_counter() - ti0
+    blas_limit.restore_original_limits()
     if pinned_core is not None:
         os.sched_setaffinity(0, affinity0)
     if world > 1:
@@ -366,7 +389,7 @@ def main():
            "unit": "steps/s per 1e4 walkers", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32 flow (MFMA) + f64 step", "data": "synthetic",
-           "config": {"workload": f"{D}-D Rosenbrock, U(-10,10)^{D} prior, {n} walkers/GPU x {world} GPU, {args.flow} "
+           "config": {"workload": f"{D}-D {'Rosenbrock' if args.target == 'rosenbrock' else 'correlated Gaussian (0.95)'}, U(-10,10)^{D} prior, {n} walkers/GPU x {world} GPU, {args.flow} "
                                   f"(H={spec.hidden}), beta={beta}, tpCN kernel, host numpy likelihood in the loop",
                       "walkers_per_gpu": n, "global_walkers": n * world, "n_dim": D, "flow": args.flow,
                       "flow_trained_50_epochs": flow_trained, "parallelism": f"walker-sharded x{world}",
@@ -386,7 +409,8 @@ def main():
                                 **{k: v / n_inst * 1e6 for k, v in t_seg.items()}}}
     out["config"]["driver_pinned_to_core"] = pinned_core
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(D, n, beta, flow.params.cpu().numpy(), spec, x, u, geo, sigma0, seed=0)
+        out["cpu_baseline"] = cpu_baseline(D, n, beta, flow.params.cpu().numpy(), spec, x, u, geo, sigma0, seed=0,
+                                           target=target)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -355,7 +355,7 @@ extern "C" int pmc_debug_inverse4_ablate(const pmc_maf_t* m, const float* z, flo
     const dim3 g((unsigned)((n + 15) / 16)), b(64);
     hipStream_t st = (hipStream_t)stream;
 #define AB(V) case V: hipLaunchKernelGGL((maf_inverse_tri4_kernel<4, V>), g, b, lds, st, *m, z, x, ladj, n, ProposeArgs{}); break;
-    switch (abl) { AB(0) AB(1) AB(2) AB(3) AB(4) AB(8) AB(16) AB(32) AB(64) AB(12) AB(60) AB(127) default: return pmc_fail("unknown ablation"); }
+    switch (abl) { AB(0) AB(1) AB(2) AB(3) AB(4) AB(8) AB(16) AB(32) AB(64) AB(12) AB(60) AB(127) AB(21) AB(20) AB(5) default: return pmc_fail("unknown ablation"); }
 #undef AB
     return pmc_check_launch("maf_inverse_tri4_kernel<ablate>");
 }

@@ -13,7 +13,7 @@ fn.argtypes = [C.POINTER(_lib.pmc_maf_t)] + [C.c_void_p] * 3 + [C.c_int64, C.c_i
 z = torch.randn(n, D, device="cuda"); x = torch.empty_like(z); l = torch.empty(n, device="cuda")
 names = {0: "full", 1: "no right-looking out updates", 2: "no non-critical hidden updates", 3: "1+2", 4: "no bursts",
          8: "no chain", 16: "no next-tile prefetch", 32: "no tile-top fragment loads", 64: "no exp in x update",
-         12: "no bursts, no chain", 60: "no bursts/chain/prefetch/frag loads", 127: "everything off"}
+         12: "no bursts, no chain", 21: "no bursts / prefetch / right-looking out (a chain wave's share)", 20: "no bursts / prefetch", 5: "no bursts / right-looking out", 60: "no bursts/chain/prefetch/frag loads", 127: "everything off"}
 if NSF:
     names = {0: "full", 1: "no spline solve", 2: "no output product", 4: "no hidden chain", 8: "no output fragment loads",
              3: "no spline, no output product", 7: "no spline/output/chain", 15: "everything off"}
