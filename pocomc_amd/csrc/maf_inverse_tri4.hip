@@ -11,6 +11,7 @@
 //     (tens of MFMAs) hide their latency -- no second register set, no copies;
 //   * keeps the prefetch of the NEXT tile's burst fragments issued right after the bursts.
 
+#include <stdlib.h>
 #include "maf_chain_rot.h"
 #include "propose_body.h"
 
@@ -327,7 +328,17 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
     if (ladj_out && lane < 16 && row0 + p < n) ladj_out[row0 + p] = ladj;
 }
 
-int pmc_launch_inverse_tri4(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream) {
+static bool tri5_wanted(const pmc_maf_t* m, int64_t n);
+static int launch_tri5(const ProposeArgs* pa, const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
+                       hipStream_t stream);
+
+int pmc_launch_inverse_tri4(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream,
+                            int variant) {
+    if (variant == 1) return launch_tri5(nullptr, m, z, x, ladj, n, stream);
+    if (variant < 0 && tri5_wanted(m, n)) {
+        const int rc = launch_tri5(nullptr, m, z, x, ladj, n, stream);
+        if (rc >= 0) return rc;
+    }
     if (m->nOT > 8) return -1;                                     // caller falls back
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;         // 32-bit buffer offsets
     const int maxo = m->nOT <= 4 ? 4 : 8;
@@ -372,6 +383,10 @@ int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* 
     const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     ProposeArgs pa{kind, cur32, mu, inv_cov, chol, nu, sigma, cn_a, *rng, prop64, quad, quad_prop};
+    if (tri5_wanted(m, n)) {
+        const int rc = launch_tri5(&pa, m, nullptr, x, ladj, n, stream);
+        if (rc >= 0) return rc;
+    }
 #define LAUNCHF(MO, FMV)                                                                                          \
     {                                                                                                             \
         if (lds > 48 * 1024) {                                                                                    \
@@ -387,4 +402,378 @@ int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* 
     else { if (maxo == 4) LAUNCHF(4, 16) else LAUNCHF(8, 16) }
 #undef LAUNCHF
     return pmc_check_launch("maf_inverse_tri4_kernel<fused proposal>");
+}
+
+// ============================================================================================================
+// tri5: the same sweep with a BURST wave next to the chain waves.
+//
+// Ablations of tri4 (scripts/ablate_inverse.py): of its 100 us, 29 us are the left-looking bursts of the hidden
+// layers and 14 us the issue of their fragment prefetches -- work that does not depend on the chain of the tile
+// that is running.  Here a workgroup is three wavefronts: waves 0 and 1 (CHAIN waves) own 16 walkers each and keep
+// the dependent work -- the layer-0 burst against x, the per-group chain, the right-looking output updates -- and
+// wave 2 (the BURST wave) prepares, one tile ahead and for both walker sets from ONE set of weight fragments, the
+// layer-1/2 pre-activations of the next tile: everything against the tiles that are already final while the
+// chains run, the last K tile right after them.  Two LDS-only barriers per tile: A(t) "the chains of tile t
+// finished" and B(t) "the pre-activations of tile t are in the staging areas".
+// Where it pays: a workgroup lives on one CU (4 SIMDs, one such 256-VGPR wave each), so TRI5_NC = 1 runs at most
+// 512 walker sets at a time and TRI5_NC = 2 (one burst wave for two sets: 3 waves) 256 workgroups = 512 sets too.
+// Up to 8192 walkers the sweep takes ~68 us instead of tri4's ~90 us; 1e4 walkers (625 sets) need a second round
+// (140 us) where tri4's 625 single waves are all resident (100 us).  The launcher therefore picks this kernel for
+// n <= 16 * (sets resident at once) -- pocoMC's own default, n_active = 256, is deep inside that range -- and tri4
+// above it.  PMC_INVERSE_DUO=0 / 1 forces never / always (tests run both).
+// ============================================================================================================
+#define TRI5_NC 1                  // chain waves (16-walker sets) per workgroup; see the note on occupancy above
+
+template <int MAXO, int FM>
+__global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pmc_maf_t m, const float* __restrict__ in,
+                                                                              float* __restrict__ out,
+                                                                              float* __restrict__ ladj_out, int64_t n,
+                                                                              ProposeArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, p = lane & 15;
+    const int D = m.D, Dp = m.Dp, Hp = m.Hp, T = m.T, nT = m.nT, nXT = m.nXT, nOT = m.nOT;
+    const int set_floats = 2 * Dp * 16 + 3 * Hp * 16 + 3 * 256 + MAXO * 256;   // LDS of one walker set
+    const int cs = wv < TRI5_NC ? wv : 0;                                        // this chain wave's set in the workgroup
+    const int64_t set = (int64_t)blockIdx.x * TRI5_NC + cs;
+    const int64_t row0 = set * 16;
+    float* Y = smem + (size_t)cs * set_floats;
+    float* X = Y + Dp * 16;
+    float* H0 = X + Dp * 16;
+    float* H1 = H0 + Hp * 16;
+    float* H2 = H1 + Hp * 16;
+    float* S = H2 + Hp * 16;                   // staging: [3 layers][16 p][16 rows] then [MAXO][16 p][16 rows]
+    float* SO = S + 3 * 256;
+    const int* feat_of_rank = m.meta + 8;
+    const int* rank_of_feat = m.meta + 8 + T * D;
+    const int* quad_meta = m.meta + 8 + 2 * T * D;
+
+    const int oF0 = 0;
+    const int oF1 = oF0 + nT * nXT * 1024;
+    const int oF2 = oF1 + nT * nT * 1024;
+    const int oF3 = oF2 + nT * nT * 1024;
+    const int oW0 = oF3 + nOT * nT * 1024;
+    const int oB0 = oW0 + Dp * Hp * 4;
+    const int oB1 = oB0 + Hp * 4;
+    const int oB2 = oB1 + Hp * 4;
+    const int oB3 = oB2 + Hp * 4;
+    const int blk_bytes = (int)(m.pk_per_transform * 4);
+    const int vo_lane = lane << 4;
+    const int vo_R = ((q << 4) + ((((lane & 15) >> 2) + (lane & 3)) & 3)) << 4;
+    const int vo_q = q << 4;
+
+    auto lds_bar = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    if (wv < TRI5_NC) {
+        if constexpr (FM > 0) {
+            for (int e = lane; e < (Dp - D) * 16; e += 64) Y[lidx(D + (e >> 4), e & 15)] = 0.0f;
+            propose_body<FM>(pa.kind, pa.cur32, nullptr, pa.mu, pa.inv_cov, pa.chol, pa.nu, pa.sigma, pa.cn_a, pa.rng,
+                             pa.prop64, nullptr, pa.quad, pa.quad_prop, n, D, Y, rank_of_feat + (T - 1) * D, set);
+        } else {
+            load_rows(Y, in, row0, n, D, Dp, feat_of_rank + (T - 1) * D, lane);
+        }
+    } else {
+        for (int c = 0; c < TRI5_NC; ++c) {    // padding slots of the activations are read by the bursts: zero once
+            float4* z4 = reinterpret_cast<float4*>(smem + (size_t)c * set_floats + 2 * Dp * 16);
+            const int n4 = (3 * Hp * 16) >> 2;
+            for (int e = lane; e < n4; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float ladj = 0.0f;
+
+    for (int t = T - 1; t >= 0; --t) {
+        const float* blk = m.packed + (size_t)t * m.pk_per_transform;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)blk, 0, blk_bytes, 0x00020000);
+        if (wv < TRI5_NC) {
+            float4* z4 = reinterpret_cast<float4*>(X);
+            for (int e = lane; e < (Dp * 16) >> 2; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+
+        if (wv == TRI5_NC) {
+            // ------------------------------------------------------------------ BURST wave
+            // Two fragment sets, used alternately: while tile Tt is being prepared from one set, the fragments
+            // of tile Tt+1 are already on their way into the other (nothing else hides their L2 latency here).
+            float4 pfA1[PK4], pfA2[PK4], pfB1[PK4], pfB2[PK4];
+            float4 lA1, lA2, lB1, lB2, bA1, bA2, bB1, bB2;
+            int4 dA, dB;
+            bool natural_end = true;
+#define SW_PREFETCH(TT, P1, P2)                                                                                  \
+            switch ((TT) < PK4 ? (TT) : PK4) {                                                                    \
+                case 1: prefetch_tile<1>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
+                case 2: prefetch_tile<2>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
+                case 3: prefetch_tile<3>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
+                case 4: prefetch_tile<4>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
+                case 5: prefetch_tile<5>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
+                case 6: prefetch_tile<6>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
+                case 7: prefetch_tile<7>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
+                case 8: prefetch_tile<8>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
+                default: break;                                                                                  \
+            }
+#define SW_BURST(NK, P1, P2, AA1, AA2, HH0, HH1)                                                                 \
+            switch ((NK) < PK4 ? (NK) : PK4) {                                                                    \
+                case 1: burst_tile<1>(AA1, AA2, P1, P2, HH0, HH1, lane); break;                                  \
+                case 2: burst_tile<2>(AA1, AA2, P1, P2, HH0, HH1, lane); break;                                  \
+                case 3: burst_tile<3>(AA1, AA2, P1, P2, HH0, HH1, lane); break;                                  \
+                case 4: burst_tile<4>(AA1, AA2, P1, P2, HH0, HH1, lane); break;                                  \
+                case 5: burst_tile<5>(AA1, AA2, P1, P2, HH0, HH1, lane); break;                                  \
+                case 6: burst_tile<6>(AA1, AA2, P1, P2, HH0, HH1, lane); break;                                  \
+                case 7: burst_tile<7>(AA1, AA2, P1, P2, HH0, HH1, lane); break;                                  \
+                case 8: burst_tile<8>(AA1, AA2, P1, P2, HH0, HH1, lane); break;                                  \
+                default: break;                                                                                  \
+            }
+            // everything tile TT needs from global memory: fragments against tiles 0..TT-1 (the last one, K = TT-1,
+            // once more in registers of its own: a run-time index into the set would go through scratch), biases,
+            // degree words
+#define FETCH_TILE(TT, P1, P2, L1, L2, Bb1, Bb2, DGW)                                                            \
+            if ((TT) < nT) {                                                                                     \
+                SW_PREFETCH(TT, P1, P2)                                                                          \
+                if ((TT) > 0) { L1 = bload4(rs, vo_lane, oF1 + ((TT) * nT + (TT) - 1) * 1024);                    \
+                                L2 = bload4(rs, vo_lane, oF2 + ((TT) * nT + (TT) - 1) * 1024); }                  \
+                Bb1 = bload4(rs, vo_q, oB1 + 64 * (TT)); Bb2 = bload4(rs, vo_q, oB2 + 64 * (TT));                \
+                DGW = *reinterpret_cast<const int4*>(quad_meta + 4 * (TT));                                      \
+            }
+#define HELPER_TILE(TT, P1, P2, L1, L2, Bb1, Bb2, DGW, NP1, NP2, NL1, NL2, NB1, NB2, NDG)                         \
+            {                                                                                                    \
+                const int Tt = (TT);                                                                             \
+                FETCH_TILE(Tt + 1, NP1, NP2, NL1, NL2, NB1, NB2, NDG)                                            \
+                f32x4 a1[TRI5_NC], a2[TRI5_NC];                                                                  \
+                _Pragma("unroll") for (int c = 0; c < TRI5_NC; ++c) {                                            \
+                    a1[c][0] = Bb1.x; a1[c][1] = Bb1.y; a1[c][2] = Bb1.z; a1[c][3] = Bb1.w;                      \
+                    a2[c][0] = Bb2.x; a2[c][1] = Bb2.y; a2[c][2] = Bb2.z; a2[c][3] = Bb2.w;                      \
+                }                                                                                                \
+                /* everything that is final while the chains of tile Tt-1 still run: K <= Tt-2 */                \
+                _Pragma("unroll") for (int c = 0; c < TRI5_NC; ++c) {                                            \
+                    const float* h0_ = smem + (size_t)c * set_floats + 2 * Dp * 16;                              \
+                    const float* h1_ = h0_ + Hp * 16;                                                            \
+                    SW_BURST(Tt - 1, P1, P2, a1[c], a2[c], h0_, h1_)                                             \
+                    for (int K = PK4; K < Tt - 1; ++K) {                                                         \
+                        const float4 w1 = bload4(rs, vo_lane, oF1 + (Tt * nT + K) * 1024);                        \
+                        const float4 w2 = bload4(rs, vo_lane, oF2 + (Tt * nT + K) * 1024);                        \
+                        const float4 b1 = *reinterpret_cast<const float4*>(h0_ + (K << 8) + (lane << 2));        \
+                        const float4 b2 = *reinterpret_cast<const float4*>(h1_ + (K << 8) + (lane << 2));        \
+                        a1[c] = MFMA(w1.x, b1.x, a1[c]); a2[c] = MFMA(w2.x, b2.x, a2[c]);                        \
+                        a1[c] = MFMA(w1.y, b1.y, a1[c]); a2[c] = MFMA(w2.y, b2.y, a2[c]);                        \
+                        a1[c] = MFMA(w1.z, b1.z, a1[c]); a2[c] = MFMA(w2.z, b2.z, a2[c]);                        \
+                        a1[c] = MFMA(w1.w, b1.w, a1[c]); a2[c] = MFMA(w2.w, b2.w, a2[c]);                        \
+                    }                                                                                            \
+                }                                                                                                \
+                if (Tt > 0) lds_bar();                                    /* A(Tt-1): tile Tt-1 is final now */   \
+                int4 dg = DGW;                                                                                   \
+                dg.x &= 0xffff; dg.y &= 0xffff; dg.z &= 0xffff; dg.w &= 0xffff;                                  \
+                if (dg.x >= D && dg.y >= D && dg.z >= D && dg.w >= D) { natural_end = false; break; }           \
+                _Pragma("unroll") for (int c = 0; c < TRI5_NC; ++c) {                                            \
+                    float* base_ = smem + (size_t)c * set_floats;                                                \
+                    if (Tt > 0) {                                                                                \
+                        const int K = Tt - 1;                                                                    \
+                        const float* h0_ = base_ + 2 * Dp * 16;                                                  \
+                        const float* h1_ = h0_ + Hp * 16;                                                        \
+                        const float4 b1 = *reinterpret_cast<const float4*>(h0_ + (K << 8) + (lane << 2));        \
+                        const float4 b2 = *reinterpret_cast<const float4*>(h1_ + (K << 8) + (lane << 2));        \
+                        a1[c] = MFMA(L1.x, b1.x, a1[c]); a2[c] = MFMA(L2.x, b2.x, a2[c]);                        \
+                        a1[c] = MFMA(L1.y, b1.y, a1[c]); a2[c] = MFMA(L2.y, b2.y, a2[c]);                        \
+                        a1[c] = MFMA(L1.z, b1.z, a1[c]); a2[c] = MFMA(L2.z, b2.z, a2[c]);                        \
+                        a1[c] = MFMA(L1.w, b1.w, a1[c]); a2[c] = MFMA(L2.w, b2.w, a2[c]);                        \
+                    }                                                                                            \
+                    float* sp = base_ + 2 * Dp * 16 + 3 * Hp * 16 + (p << 4) + (q << 2);                         \
+                    *reinterpret_cast<float4*>(sp + 256) = make_float4(a1[c][0], a1[c][1], a1[c][2], a1[c][3]);  \
+                    *reinterpret_cast<float4*>(sp + 512) = make_float4(a2[c][0], a2[c][1], a2[c][2], a2[c][3]);  \
+                }                                                                                                \
+                lds_bar();                                                /* B(Tt) */                            \
+            }
+            lA1 = lA2 = lB1 = lB2 = bA1 = bA2 = bB1 = bB2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            dA = dB = make_int4(0, 0, 0, 0);
+            FETCH_TILE(0, pfA1, pfA2, lA1, lA2, bA1, bA2, dA)
+            for (int T2 = 0; T2 < nT; T2 += 2) {
+                HELPER_TILE(T2, pfA1, pfA2, lA1, lA2, bA1, bA2, dA, pfB1, pfB2, lB1, lB2, bB1, bB2, dB)
+                if (T2 + 1 >= nT) break;
+                HELPER_TILE(T2 + 1, pfB1, pfB2, lB1, lB2, bB1, bB2, dB, pfA1, pfA2, lA1, lA2, bA1, bA2, dA)
+            }
+#undef HELPER_TILE
+#undef FETCH_TILE
+#undef SW_BURST
+#undef SW_PREFETCH
+            if (natural_end) lds_bar();                               // A(nT-1)
+        } else {
+            // ------------------------------------------------------------------ CHAIN waves
+            ChainRot<MAXO> s;
+#pragma unroll
+            for (int O = 0; O < MAXO; ++O) {
+                const float4 bb = (O < nOT) ? bload4(rs, vo_q, oB3 + 64 * O) : make_float4(0.f, 0.f, 0.f, 0.f);
+                s.oN[O][0] = bb.x; s.oN[O][1] = bb.y; s.oN[O][2] = bb.z; s.oN[O][3] = bb.w;
+            }
+            {
+                const float* b3 = blk + (oB3 >> 2);
+                const float shift = b3[0], ls = fast_ls(b3[1]);
+                const float xv = (Y[lidx(0, p)] - shift) * fast_exp_neg(ls);
+                ladj -= ls;
+                if (q == 0) X[lidx(0, p)] = xv;
+            }
+            WAVE_LDS_FENCE();
+            float4 pf0[PX4], pb0;
+#define PREFETCH5(TT)                                                                                          \
+            {                                                                                                  \
+                const int TT_ = (TT);                                                                          \
+                _Pragma("unroll") for (int i_ = 0; i_ < PX4; ++i_)                                             \
+                    if (i_ < nXT) pf0[i_] = bload4(rs, vo_lane, oF0 + (TT_ * nXT + i_) * 1024);                 \
+                pb0 = bload4(rs, vo_q, oB0 + 64 * TT_);                                                        \
+            }
+            PREFETCH5(0);
+            int4 dg_next = *reinterpret_cast<const int4*>(quad_meta);
+            for (int Tt = 0; Tt < nT; ++Tt) {
+                int4 dg = dg_next;
+                dg.x &= 0xffff; dg.y &= 0xffff; dg.z &= 0xffff; dg.w &= 0xffff;
+                if (dg.x >= D && dg.y >= D && dg.z >= D && dg.w >= D) break;       // padding tiles
+                const int pat = 1 | ((dg.y != dg.x) << 1) | ((dg.z != dg.y) << 2) | ((dg.w != dg.z) << 3);
+                {
+                    const bool ny = dg.y != dg.x, nz = dg.z != dg.y, nw = dg.w != dg.z;
+                    s.g[0] = dg.x;
+                    s.g[1] = ny ? dg.y : (nz ? dg.z : (nw ? dg.w : D));
+                    s.g[2] = ny ? (nz ? dg.z : (nw ? dg.w : D)) : ((nz && nw) ? dg.w : D);
+                    s.g[3] = (ny && nz && nw) ? dg.w : D;
+                }
+                const int soD1 = oF1 + (Tt * nT + Tt) * 1024, soD2 = oF2 + (Tt * nT + Tt) * 1024;
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    s.wd1[jt] = bload4(rs, vo_R + 64 * jt, soD1);
+                    s.wd2[jt] = bload4(rs, vo_R + 64 * jt, soD2);
+                }
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    const int g_even = s.g[2 * sl], g_odd = s.g[2 * sl + 1];
+                    const int gsel = (lane & 2) ? g_odd : g_even;
+                    const bool ok = gsel < D;
+                    const int gg = ok ? gsel : 0;
+                    const int vo = ((((gg >> 3) * nT) << 6) + (q << 4) + 2 * (gg & 7) + (lane & 1)) << 4;
+                    const float4 v = bload4(rs, vo, oF3 + Tt * 1024);
+                    s.wo[sl] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int O = 0; O < MAXO; ++O)
+                    s.f3n[O] = (O < nOT) ? bload4(rs, vo_lane, oF3 + (O * nT + Tt) * 1024) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int gg = s.g[i] < D ? s.g[i] : 0;
+#pragma unroll
+                    for (int jt = i + 1; jt < 4; ++jt)
+                        s.w0r[i][jt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                            rs, q << 2, oW0 + (gg * Hp + 16 * Tt + 4 * jt) * 4, 0));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s.yv[i] = Y[lidx(s.g[i] < D ? s.g[i] : 0, p)];
+
+                // layer 0 against x (final up to the previous tile's ranks)
+                f32x4 a0;
+                a0[0] = pb0.x; a0[1] = pb0.y; a0[2] = pb0.z; a0[3] = pb0.w;
+#pragma unroll
+                for (int i = 0; i < PX4; ++i) {
+                    if (i < nXT) {
+                        const float4 b = *reinterpret_cast<const float4*>(X + (i << 8) + (lane << 2));
+                        a0 = MFMA(pf0[i].x, b.x, a0); a0 = MFMA(pf0[i].y, b.y, a0);
+                        a0 = MFMA(pf0[i].z, b.z, a0); a0 = MFMA(pf0[i].w, b.w, a0);
+                    }
+                }
+                for (int Xt = PX4; Xt < nXT; ++Xt) {
+                    const float4 a = bload4(rs, vo_lane, oF0 + (Tt * nXT + Xt) * 1024);
+                    const float4 b = *reinterpret_cast<const float4*>(X + (Xt << 8) + (lane << 2));
+                    a0 = MFMA(a.x, b.x, a0); a0 = MFMA(a.y, b.y, a0); a0 = MFMA(a.z, b.z, a0); a0 = MFMA(a.w, b.w, a0);
+                }
+                {
+                    float* sp = S + (p << 4) + (q << 2);
+                    *reinterpret_cast<float4*>(sp) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+                    float* so = SO + (p << 4) + (q << 2);
+#pragma unroll
+                    for (int O = 0; O < MAXO; ++O)
+                        *reinterpret_cast<float4*>(so + O * 256) = make_float4(s.oN[O][0], s.oN[O][1], s.oN[O][2], s.oN[O][3]);
+                }
+                lds_bar();                                            // B(Tt): layers 1/2 of this tile are staged
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    s.a0[jt] = S[(p << 4) + (jt << 2) + q];
+                    s.p1[jt] = S[256 + (p << 4) + (jt << 2) + q];
+                    s.p2[jt] = S[512 + (p << 4) + (jt << 2) + q];
+                    s.a1[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    s.a2[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                s.outR[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                s.outR[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int gg = s.g[i] < D ? s.g[i] : 0;
+                    s.po[i] = *reinterpret_cast<const float2*>(SO + (gg >> 3) * 256 + (p << 4) + 2 * (gg & 7));
+                }
+                switch (pat) {
+#define CASE(P) case P: chain_group_rot<P, 0, 1, MAXO, 0>(s, H0, H1, H2, X, Tt, D, nOT, q, p, ladj); break;
+                    CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
+#undef CASE
+                }
+                if (Tt + 1 < nT) {
+                    PREFETCH5(Tt + 1);
+                    dg_next = *reinterpret_cast<const int4*>(quad_meta + 4 * (Tt + 1));
+                }
+                switch (pat) {
+#define CASE(P) case P: chain_group_rot<P, 1, 4, MAXO, 0>(s, H0, H1, H2, X, Tt, D, nOT, q, p, ladj); break;
+                    CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
+#undef CASE
+                    default: break;
+                }
+                lds_bar();                                            // A(Tt): this tile is final
+            }
+#undef PREFETCH5
+        }
+        __syncthreads();
+        const bool last = (t == 0);
+        if (wv < TRI5_NC)
+            rerank_or_store(X, Y, out, row0, n, D, Dp, feat_of_rank + t * D,
+                            last ? nullptr : rank_of_feat + (t - 1) * D, lane);
+        __syncthreads();
+    }
+    if (wv < TRI5_NC && ladj_out && lane < 16 && row0 + p < n) ladj_out[row0 + p] = ladj;
+}
+
+// -1: automatic (by size), 0: never, 1: always
+static int tri5_mode() {
+    static const int mode = getenv("PMC_INVERSE_DUO") ? atoi(getenv("PMC_INVERSE_DUO")) : -1;
+    return mode;
+}
+
+static bool tri5_wanted(const pmc_maf_t* m, int64_t n) {
+    const int mode = tri5_mode();
+    if (mode >= 0) return mode != 0;
+    const int maxo = m->nOT <= 4 ? 4 : 8;
+    const size_t lds = (size_t)TRI5_NC * (2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
+    if (lds > 160 * 1024) return false;
+    const int64_t by_lds = (int64_t)((160 * 1024) / lds), by_simd = 4 / (TRI5_NC + 1);
+    const int64_t resident_sets = 256 * TRI5_NC * (by_lds < by_simd ? by_lds : by_simd);
+    return (n + 15) / 16 <= resident_sets;
+}
+
+// same contract as pmc_launch_propose_inverse_tri4 / pmc_launch_inverse_tri4 (pa == nullptr: plain inverse of z)
+static int launch_tri5(const ProposeArgs* pa, const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
+                       hipStream_t stream) {
+    if (m->n_out != 2 || !m->tri_ok || m->nOT > 8 || m->D > 64) return -1;
+    if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
+    const int maxo = m->nOT <= 4 ? 4 : 8;
+    const size_t lds = (size_t)TRI5_NC * (2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
+    if (lds > 160 * 1024) return -1;
+    const ProposeArgs none{};
+    const int64_t nsets = (n + 15) / 16;
+    const unsigned grid = (unsigned)((nsets + TRI5_NC - 1) / TRI5_NC);
+#define LAUNCH5(MO, FMV)                                                                                          \
+    {                                                                                                             \
+        if (lds > 48 * 1024) {                                                                                    \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri5_kernel<MO, FMV>),   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+            if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_inverse_tri5_kernel)");          \
+        }                                                                                                         \
+        hipLaunchKernelGGL((maf_inverse_tri5_kernel<MO, FMV>), dim3(grid), dim3(64 * (TRI5_NC + 1)), lds,          \
+                           stream, *m, z, x, ladj, n, pa ? *pa : none);                                           \
+    }
+    if (!pa) { if (maxo == 4) LAUNCH5(4, 0) else LAUNCH5(8, 0) }
+    else if (m->D <= 16) { if (maxo == 4) LAUNCH5(4, 4) else LAUNCH5(8, 4) }
+    else if (m->D <= 32) { if (maxo == 4) LAUNCH5(4, 8) else LAUNCH5(8, 8) }
+    else { if (maxo == 4) LAUNCH5(4, 16) else LAUNCH5(8, 16) }
+#undef LAUNCH5
+    return pmc_check_launch("maf_inverse_tri5_kernel");
 }

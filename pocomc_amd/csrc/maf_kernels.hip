@@ -354,6 +354,11 @@ extern "C" int pmc_maf_inverse(const pmc_maf_t* m, const float* z, float* x, flo
             if (rc >= 0) return rc;
         }
         return pmc_launch_inverse_tri2(m, z, x, ladj, n, lds, (hipStream_t)stream);
+    } else if (algo == PMC_INVERSE_TRIANGULAR_SOLO || algo == PMC_INVERSE_TRIANGULAR_DUO) {
+        if (!m->tri_ok) return pmc_fail("pmc_maf_inverse: triangular sweep needs degree groups <= one tile");
+        const int rc = pmc_launch_inverse_tri4(m, z, x, ladj, n, (hipStream_t)stream, algo == PMC_INVERSE_TRIANGULAR_DUO);
+        if (rc >= 0) return rc;
+        return pmc_fail("pmc_maf_inverse: this sweep needs D <= 64 and its tiles in 160 KiB of LDS");
     } else if (algo == PMC_INVERSE_TRIANGULAR_V3) {
         if (!m->tri_ok) return pmc_fail("pmc_maf_inverse: triangular sweep needs degree groups <= one tile");
         const int rc = pmc_launch_inverse_tri3(m, z, x, ladj, n, (hipStream_t)stream);

@@ -63,11 +63,11 @@ __device__ __forceinline__ void propose_body(
     const double* __restrict__ mu, const double* __restrict__ inv_cov, const double* __restrict__ chol,
     double nu, double sigma, double cn_a, const pmc_rng_t& rng, double* __restrict__ prop64,
     float* __restrict__ prop32, double* __restrict__ quad, double* __restrict__ quad_prop,
-    int64_t n, int D, float* y_lds, const int* __restrict__ rank_of_feat) {
+    int64_t n, int D, float* y_lds, const int* __restrict__ rank_of_feat, int64_t set = -1) {
 #pragma clang fp contract(off)
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int q = lane >> 4, p = lane & 15;
-    const int64_t k_w = (int64_t)blockIdx.x * 16 + p;          // this lane's walker
+    const int64_t k_w = (set < 0 ? (int64_t)blockIdx.x : set) * 16 + p;    // this lane's walker (set: 16-walker set index)
     const bool live = k_w < n;
     const int64_t gidx = rng.offset + k_w;
     const bool tpcn = (kind == PMC_KIND_TPCN);

@@ -52,7 +52,8 @@ def test_inverse_matches_oracle(D, T, n):
     f, o = make(D, T)
     z = (np.random.default_rng(7 + n).normal(size=(n, D)) * 1.2).astype(np.float32)
     xo, lo = o.inverse(z)                       # the reference's D-pass algorithm
-    for algo in ([1, 4, 3, 2] + ([5] if f.spec.nOT <= 8 else []) if f.spec.tri_ok else [2]):
+    small = f.spec.nOT <= 8 and 2 * f.spec.Dp + 3 * f.spec.Hp + 176 <= 2560       # D <= 64, tiles fit the LDS
+    for algo in ([1, 4, 3, 2] + ([5, 6, 7] if small else []) if f.spec.tri_ok else [2]):
         f.inverse_algo = algo
         x, l = f.inverse(torch.from_numpy(z))
         close(x.numpy(), xo)
@@ -60,6 +61,26 @@ def test_inverse_matches_oracle(D, T, n):
     f.inverse_algo = 0
     x, l = f.inverse(torch.from_numpy(z))
     close(x.numpy(), xo)
+
+
+@pytest.mark.parametrize("n", [1, 17, 4096, 10000])
+@pytest.mark.parametrize("D,T", [(32, 3), (10, 6), (64, 3)])
+def test_one_and_two_wave_sweeps_agree(D, T, n):
+    """PMC_INVERSE_TRIANGULAR_SOLO (one wavefront per 16 rows) and _DUO (chain + burst wavefront) compute the same
+    sums (the duo kernel adds the hidden-layer partial sums in a different order): agreement to fp32 round-off;
+    AUTO is bit for bit one of the two, chosen by size."""
+    f, _ = make(D, T)
+    z = torch.randn(n, D, generator=torch.Generator().manual_seed(n))
+    out = {}
+    for algo in (6, 7, 0):
+        f.inverse_algo = algo
+        out[algo] = [t.numpy() for t in f.inverse(z)]
+    f.inverse_algo = 0
+    close(out[7][0], out[6][0], 5e-6)
+    close(out[7][1], out[6][1], 5e-6)
+    pick = 7 if n <= 8192 else 6
+    np.testing.assert_array_equal(out[0][0], out[pick][0])
+    np.testing.assert_array_equal(out[0][1], out[pick][1])
 
 
 def test_triangular_equals_naive_on_device():
