@@ -133,6 +133,12 @@ def main():
     ap.add_argument("--no-pin", action="store_true",
                     help="do not pin the driver thread to the core it starts on (the host likelihood is single-threaded "
                          "numpy; migrations between cores cost ~8 %% and most of the run-to-run noise)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="adapt sigma / mu on the host and enqueue every pre-step after the sums of the step before "
+                         "(default: adaptation on the device, the next pre-step is enqueued behind the accept)")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="row ranges of the walker set stepped as a pipeline (mcmc.LanedEngine: the device works on one "
+                         "lane while the host evaluates the likelihood of another); 1 = the whole set at once")
     ap.add_argument("--flow", default="maf3", help="maf3 | maf6 | maf12 | nsf3 | nsf6 | nsf12 (BASELINE configs use maf3)")
     ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "triangular_v1", "triangular_v2", "triangular_v3"], default="auto")
     args = ap.parse_args()
@@ -141,7 +147,7 @@ def main():
     import torch.distributed as dist
     from pocomc_amd import Flow, Reparameterize
     from pocomc_amd.geometry import Geometry
-    from pocomc_amd.mcmc import StepEngine, Adaptation
+    from pocomc_amd.mcmc import StepEngine, LanedEngine, Adaptation
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -224,6 +230,25 @@ def main():
     eng.set_geometry(mu=geo.t_mean, cov=geo.t_cov)
     ad = Adaptation("preconditioned_pcn", D, n * world, n_steps=10 ** 9, n_max=10 ** 9, sigma0=sigma0,
                     mu0=geo.t_mean, logp2_0=-np.inf)
+    # the timed region steps the same walkers as a pipeline of row ranges (what mcmc._run does from 4096 walkers
+    # on); `eng` (the whole set at once) stays for the instrumented passes below
+    leng = None
+    pipelined = (not args.no_pipeline) and args.x_order == "F" and D <= 256
+    if args.lanes > 1:
+        # numpy's buffered iterator copies a strided operand (x[:, ::2] of the likelihood) through a buffer when
+        # the inner loop is shorter than its buffer size (8192 elements): 25 instead of 16.5 ns/row for calls on
+        # fewer than 8192 rows (scripts/hosttest.py).  A lane of 5008 rows stays on the direct path with 1024.
+        np.setbufsize(1024)
+    if args.lanes > 1 or pipelined:
+        leng = LanedEngine("preconditioned_pcn", n, D, flow, scaler, lanes=args.lanes, group=None,
+                           shard_offset=rank * n, seed=20240928, x_order=args.x_order, streams=not pipelined)
+        if device_prior:
+            leng.set_device_prior(pc_prior)
+        leng.load_state(u, x, logdetj, logl, logp)
+        leng.set_geometry(mu=geo.t_mean, cov=geo.t_cov)
+        ad_l = Adaptation("preconditioned_pcn", D, n * world, n_steps=10 ** 9, n_max=10 ** 9, sigma0=sigma0,
+                          mu0=geo.t_mean, logp2_0=-np.inf)
+        assert leng.can_pipeline() == pipelined
     loglike = lambda xx: (target(xx), None)
     t_host = [0.0]
 
@@ -243,6 +268,26 @@ def main():
         td = time.perf_counter()
         t_seg["propose_call"] += th - ta; t_seg["evaluate_call"] += tb - th
         t_seg["accept_call"] += tc - tb; t_seg["adapt"] += td - tc
+
+    t_lseg = {"step_call": 0.0, "adapt": 0.0}
+
+    def step_laned():
+        ta = time.perf_counter()
+        if pipelined:
+            # sigma / mu adapted on the device, the next pre-steps enqueued before the host sees the sums
+            _, sums = leng.step_pipelined(beta, nu, ad_l.coefficients(), n * world, pc_prior.logpdf, loglike)
+            tb = time.perf_counter()
+            ad_l.update(sums)
+        else:
+            _, sums = leng.step(ad_l.sigma, nu, beta, pc_prior.logpdf, loglike)
+            tb = time.perf_counter()
+            ad_l.update(sums)
+            leng.set_mu(ad_l.mu)
+        tc = time.perf_counter()
+        t_lseg["step_call"] += tb - ta; t_lseg["adapt"] += tc - tb
+
+    timed_step = step_laned if leng is not None else step
+    roof_eng = leng.lanes[0] if leng is not None else eng          # the launch the live event pair brackets
 
     def barrier():
         if world > 1:
@@ -279,8 +324,16 @@ def main():
     # core for a 1e4 x 32 x 32 product (its spinning workers would also delay the runtime's launch path)
     from threadpoolctl import threadpool_limits
     blas_limit = threadpool_limits(limits=1)
+    if leng is not None and pipelined:
+        leng.start_pipeline(float(ad_l.sigma), ad_l.mu, nu)      # the pre-steps of the first step
     for _ in range(args.warmup):
         step()
+        if leng is not None:
+            step_laned()
+    for k in t_seg:
+        t_seg[k] = 0.0
+    for k in t_lseg:
+        t_lseg[k] = 0.0
     # ---- timed region: K steps through the composite entry points; the only instrumentation is one
     #      HIP event pair per step around the flow-inverse launch (recorded inside pmc_step_pre, on the
     #      stream the kernel is launched on)
@@ -290,14 +343,28 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         if k % args.event_every == 0:
-            eng._step.ev_inv0, eng._step.ev_inv1 = ev_pairs[k]
+            roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = ev_pairs[k]
         else:
-            eng._step.ev_inv0, eng._step.ev_inv1 = None, None
-        step()
+            roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = None, None
+        timed_step()
     barrier()
     dt = time.perf_counter() - t0
-    eng._step.ev_inv0, eng._step.ev_inv1 = None, None
-    seg_timed = {k: v / args.steps * 1e6 for k, v in t_seg.items()}
+    roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = None, None
+    seg_timed = {k: v / args.steps * 1e6 for k, v in (t_lseg if leng is not None else t_seg).items()}
+    laned_host = None
+    if leng is not None:                                    # same pipeline again with host timers
+        leng.host_timers = {"wait_device": 0.0, "prior": 0.0, "likelihood": 0.0}
+        for k in t_lseg:
+            t_lseg[k] = 0.0
+        n_lt = max(20, min(args.steps, 100))
+        for _ in range(n_lt):
+            step_laned()
+        torch.cuda.synchronize()
+        laned_host = {**{k: v / n_lt * 1e6 for k, v in leng.host_timers.items()},
+                      **{k: v / n_lt * 1e6 for k, v in t_lseg.items()}}
+        leng.host_timers = None
+        if pipelined:
+            leng.finish_pipeline()
     inv_us_live = float(np.mean([lib.pmc_event_elapsed_ms(a, b) for a, b in ev_pairs[::args.event_every]])) * 1e3
     for a, b in ev_pairs:
         lib.pmc_event_destroy(a); lib.pmc_event_destroy(b)
@@ -338,8 +405,9 @@ def main():
     us = {"propose": seg(0, 1), "maf_inverse": seg(1, 2), "scaler_inverse": seg(2, 3), "d2h_x": seg(3, 4),
           "accept_reduce": seg(5, 6)}
     spec = flow.spec
-    algo_flops = n * spec.flops_inverse_naive()                   # (D+1)*F_fwd per walker
-    actual_flops = n * 2 * spec.macs_masked()                     # what the triangular sweep needs
+    n_launch = roof_eng.n                                         # walkers of the launch the event pair brackets
+    algo_flops = n_launch * spec.flops_inverse_naive()            # (D+1)*F_fwd per walker
+    actual_flops = n_launch * 2 * spec.macs_masked()              # what the triangular sweep needs
     us["maf_inverse_timed_region"] = inv_us_live            # HIP events inside the timed region
     t_inv = inv_us_live * 1e-6
     fused = eng.pre and spec.univariate == "affine" and spec.tri_ok and spec.nOT <= 8 and args.inverse in ("auto", "triangular")
@@ -347,13 +415,15 @@ def main():
                    "maf_inverse_tri_nsf_kernel" if spec.univariate == "rqs" else
                    {"triangular_v1": "maf_inverse_tri_kernel", "triangular_v2": "maf_inverse_tri2_kernel",
                     "triangular_v3": "maf_inverse_tri3_kernel"}.get(
-                       args.inverse, "maf_inverse_tri4_kernel" if spec.nOT <= 8 else "maf_inverse_tri2_kernel"))
+                       args.inverse, ("maf_inverse_tri5_kernel" if n_launch <= 8192 else "maf_inverse_tri4_kernel")
+                       if spec.nOT <= 8 else "maf_inverse_tri2_kernel"))
     # HBM bytes per launch of the dominant kernel: PMC passes cannot run inside this process, the value
     # is the committed rocprofv3 measurement of this very command (profiles/r01_c_rocprof_summary.txt)
     traffic = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if n == 10000 and D == 32 and args.inverse == "auto" and args.flow == "maf3" and pm.get("kernel", "").startswith(roof_kernel):
+        if (n == 10000 and D == 32 and args.inverse == "auto" and args.flow == "maf3"
+                and pm.get("kernel", "").startswith(roof_kernel) and pm.get("walkers_per_launch", 10000) == n_launch):
             traffic = {"hbm_bytes_per_launch": pm["hbm_bytes_per_launch"], "unit": "B", "source": pm["source"],
                        "correction": pm["correction"]}
     except (OSError, KeyError, ValueError):
@@ -362,6 +432,7 @@ def main():
     roofline = {"bound": "mfma", "kernel": roof_kernel, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                 "avg_launch_us": inv_us_live, "launches_timed": len(ev_pairs[::args.event_every]),
+                "walkers_per_launch": n_launch,
                 "note": "achieved = SURVEY 8(d) naive-equivalent flops ((D+1)*F_fwd per walker) / launch time; the "
                         "triangular sweep executes only the masked MACs once, so frac > 1 is an algorithmic gain"
                         + ("; the launch also proposes theta' for its walkers (fused proposal prologue, ~15 us)" if fused else ""),
@@ -393,6 +464,8 @@ def main():
                                   f"(H={spec.hidden}), beta={beta}, tpCN kernel, host numpy likelihood in the loop",
                       "walkers_per_gpu": n, "global_walkers": n * world, "n_dim": D, "flow": args.flow,
                       "flow_trained_50_epochs": flow_trained, "parallelism": f"walker-sharded x{world}",
+                      "lanes": len(leng.lanes) if leng is not None else 1,
+                      "pipelined_device_adaptation": bool(pipelined and leng is not None),
                       "inverse_algo": args.inverse, "host_threads": args.host_threads, "host_x_order": args.x_order, "prior_on_device": bool(device_prior), "accept_rate": float(ad.mean_alpha)},
            "roofline": roofline,
            "roofline_sweeps": sweeps,
@@ -404,6 +477,7 @@ def main():
                                          + us["accept_reduce"], wall=ms_per_step * 1e3,
                                          instrumented_pass_wall=dt_inst / n_inst * 1e6),
            "timed_region_host_us_per_step": seg_timed,
+           "laned_path_host_us_per_step": laned_host,
            "composite_path_host_us_per_step": composite_host,
            "host_us_per_step": {**{k: v / n_inst * 1e6 for k, v in eng.host_timers.items()},
                                 **{k: v / n_inst * 1e6 for k, v in t_seg.items()}}}

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PMC_ABI_VERSION 2
+#define PMC_ABI_VERSION 3
 
 const char* pmc_last_error(void);
 int pmc_abi_version(void);
@@ -352,7 +352,25 @@ typedef struct pmc_step {
     int32_t no_fuse;          /* 1: always launch the proposal and the flow inverse separately */
     int32_t host_direct;      /* 1: h_x (column-major, p_xT == NULL), h_fin, h_logp_out and h_mu are device-accessible
                                * pinned memory that the kernels read / write themselves -- no copies in pmc_step_pre */
+    /* Adaptation on the device (mcmc.py:152-156 and the variants :314-318, :476-480, :627-631): with adapt_state
+     * non-NULL, pmc_step_post lets the accept kernel's last block update  {sigma, (1-sigma^2)^0.5, mu[D]}  from the
+     * step's sums, and pmc_step_pre reads sigma / cn_a / mu from there instead of its arguments and h_mu -- so
+     * the host can enqueue pmc_step_pre(k+1) right behind pmc_step_post(k) without waiting for the sums.  The
+     * step-dependent factors are passed in (they depend on the step number only); the arithmetic keeps numpy's
+     * operation order, so a host that applies the same update to the same sums holds the same sigma and mu. */
+    double* adapt_state;      /* device f64 [2 + D] or NULL */
+    int32_t adapt_mode;       /* PMC_ADAPT_* ; 0: the accept kernel leaves adapt_state alone */
+    int32_t adapt_pad;
+    double adapt_c_sigma;     /* 1/(i+1)^0.75 (tpCN kinds) or 1/(i+1) (RWM kinds) of the update that follows this step */
+    double adapt_c_mu;        /* 1/(i+1) */
+    double adapt_cap;         /* min(2.38/sqrt(D), 0.99) */
+    double adapt_n_total;     /* number of walkers the sums run over */
 } pmc_step_t;
+
+#define PMC_ADAPT_TPCN 1      /* sigma <- |min(sigma + c (mean alpha - 0.234), cap)|      (mcmc.py:152, :476) */
+#define PMC_ADAPT_PRWM 2      /* sigma <- sigma + c (mean alpha - 0.234)                   (mcmc.py:314) */
+#define PMC_ADAPT_RWM 3       /* sigma <- |sigma + c (mean alpha - 0.234)|                 (mcmc.py:627) */
+#define PMC_ADAPT_MU 8        /* or-ed in: mu <- mu + c_mu (float32(mean theta) - mu)      (mcmc.py:156) */
 
 /* The Philox variates of one step into arrays, exactly the values the kernels draw inline for the same
  * (seed, step, offset): normal f64 [n][D] (stream 1, pair j/2), gamma f64 [n] = standard gamma of shape
@@ -374,6 +392,14 @@ int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu, double si
 /* mcmc.py:124-156 in one call: H2D logl', logp' -> accept + reductions -> [D2H sums, accept mask]. */
 int pmc_step_post(const pmc_step_t* s, const pmc_rng_t* rng, double beta, double nu, int want_mask,
                   int copy_sums, void* stream);
+/* The adaptation of pmc_step_t.adapt_state as a launch of its own, for walker sets whose sums come in parts
+ * (row ranges stepped one after the other, mcmc.LanedEngine; ranks, after the all-reduce):
+ *   total[j] = parts[0][j] + parts[1][j] + ...   (j < D + 4, n_parts <= 8, added in this order)
+ * -> total_out (device, may be NULL) and h_sums (pinned host, may be NULL); then, if adapt_state != NULL, the
+ * update selected by adapt_mode (PMC_ADAPT_*) with the factors of pmc_step_t.adapt_*; finally done->flag. */
+int pmc_adapt_update(const double* const* parts, int32_t n_parts, int32_t D, double* total_out, double* h_sums,
+                     double* adapt_state, int32_t adapt_mode, double c_sigma, double c_mu, double cap, double n_total,
+                     const pmc_done_t* done, void* stream);
 int pmc_stream_synchronize(void* stream);
 /* hipEvent helpers for the host language (live kernel timing inside bench.py). */
 void* pmc_event_create(void);

@@ -83,7 +83,10 @@ class pmc_step_t(C.Structure):
                 ("prior", c_p), ("h_logp_out", c_p),
                 ("rng_normal", c_p * 2), ("rng_gamma", c_p * 2), ("rng_uniform", c_p * 2), ("rng_ready", c_p),
                 ("ev_pre_done", c_p), ("h_done", c_p), ("done_ticket", c_p),
-                ("no_fuse", C.c_int32), ("host_direct", C.c_int32)]
+                ("no_fuse", C.c_int32), ("host_direct", C.c_int32),
+                ("adapt_state", C.c_void_p), ("adapt_mode", C.c_int32), ("adapt_pad", C.c_int32),
+                ("adapt_c_sigma", C.c_double), ("adapt_c_mu", C.c_double), ("adapt_cap", C.c_double),
+                ("adapt_n_total", C.c_double)]
 
 
 # name -> (restype, argtypes); every symbol include/pocomc_amd.h declares
@@ -91,6 +94,8 @@ i32, i64, f64 = C.c_int32, C.c_int64, C.c_double
 P = C.POINTER
 SIGNATURES = {
     "pmc_last_error": (C.c_char_p, []),
+    "pmc_adapt_update": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "pmc_abi_version": (C.c_int, []),
     "pmc_maf_pack": (C.c_int, [c_p, c_p, c_p, i64, c_p]),
     "pmc_maf_forward": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, c_p, i64, c_p]),
@@ -158,7 +163,7 @@ def load():
         fn = getattr(lib, name)            # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.pmc_abi_version() != 2:
+    if lib.pmc_abi_version() != 3:
         raise PocomcAmdError("libpocomc_amd.so: ABI version mismatch")
     _lib = lib
     return lib

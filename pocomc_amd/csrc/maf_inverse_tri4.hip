@@ -29,6 +29,28 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rs, int voff, in
 // Straight-line burst of hidden tile TT against tiles 0..TT-1 (TT is a compile-time constant):
 // every LDS read is issued up front and two independent accumulators per layer keep the MFMAs
 // back to back (a dependent v_mfma_f32_16x16x4_f32 waits 40 cycles, an independent one issues after 32).
+// (burst_tile_open leaves the two partial sums apart: the two-wave kernel adds its last K tile before folding them,
+// so that both kernels round alike)
+template <int TT>
+__device__ __forceinline__ void burst_tile_open(f32x4& a1, f32x4& a2, f32x4& c1, f32x4& c2, const float4 (&pf1)[PK4],
+                                                const float4 (&pf2)[PK4], const float* H0, const float* H1, int lane) {
+    if constexpr (TT > 0) {
+        float4 b1[TT], b2[TT];
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            b1[i] = *reinterpret_cast<const float4*>(H0 + (i << 8) + (lane << 2));
+            b2[i] = *reinterpret_cast<const float4*>(H1 + (i << 8) + (lane << 2));
+        }
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            a1 = MFMA(pf1[i].x, b1[i].x, a1); a2 = MFMA(pf2[i].x, b2[i].x, a2);
+            c1 = MFMA(pf1[i].y, b1[i].y, c1); c2 = MFMA(pf2[i].y, b2[i].y, c2);
+            a1 = MFMA(pf1[i].z, b1[i].z, a1); a2 = MFMA(pf2[i].z, b2[i].z, a2);
+            c1 = MFMA(pf1[i].w, b1[i].w, c1); c2 = MFMA(pf2[i].w, b2[i].w, c2);
+        }
+    }
+}
+
 template <int TT>
 __device__ __forceinline__ void burst_tile(f32x4& a1, f32x4& a2, const float4 (&pf1)[PK4], const float4 (&pf2)[PK4],
                                            const float* H0, const float* H1, int lane) {
@@ -71,6 +93,7 @@ struct ProposeArgs {
     double nu, sigma, cn_a;
     pmc_rng_t rng;
     double* prop64; double* quad; double* quad_prop;
+    const double* adapt;          // pmc_step_t.adapt_state or NULL: {sigma, cn_a, mu[D]} on the device
 };
 
 // ABL: timing-only ablations (see maf_chain_rot.h); 4 = no bursts, 8 = no chain, 16 = no next-tile prefetch,
@@ -116,8 +139,9 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
 
     if constexpr (FM > 0) {
         for (int e = lane; e < (Dp - D) * 16; e += 64) Y[lidx(D + (e >> 4), e & 15)] = 0.0f;
-        propose_body<FM>(pa.kind, pa.cur32, nullptr, pa.mu, pa.inv_cov, pa.chol, pa.nu, pa.sigma, pa.cn_a, pa.rng,
-                         pa.prop64, nullptr, pa.quad, pa.quad_prop, n, D, Y, rank_of_feat + (T - 1) * D);
+        const double sg = pa.adapt ? pa.adapt[0] : pa.sigma, ca = pa.adapt ? pa.adapt[1] : pa.cn_a;
+        propose_body<FM>(pa.kind, pa.cur32, nullptr, pa.adapt ? pa.adapt + 2 : pa.mu, pa.inv_cov, pa.chol, pa.nu, sg, ca,
+                         pa.rng, pa.prop64, nullptr, pa.quad, pa.quad_prop, n, D, Y, rank_of_feat + (T - 1) * D);
     } else {
         load_rows(Y, in, row0, n, D, Dp, feat_of_rank + (T - 1) * D, lane);
     }
@@ -376,13 +400,13 @@ extern "C" int pmc_debug_inverse4_ablate(const pmc_maf_t* m, const float* z, flo
 int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* mu, const double* inv_cov,
                                     const double* chol, double nu, double sigma, double cn_a, const pmc_rng_t* rng,
                                     double* prop64, double* quad, double* quad_prop, const pmc_maf_t* m, float* x,
-                                    float* ladj, int64_t n, hipStream_t stream) {
+                                    float* ladj, int64_t n, hipStream_t stream, const double* adapt) {
     if (m->n_out != 2 || !m->tri_ok || m->nOT > 8 || m->D > 64) return -1;
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
     const int maxo = m->nOT <= 4 ? 4 : 8;
     const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
     if (lds > 160 * 1024) return -1;
-    ProposeArgs pa{kind, cur32, mu, inv_cov, chol, nu, sigma, cn_a, *rng, prop64, quad, quad_prop};
+    ProposeArgs pa{kind, cur32, mu, inv_cov, chol, nu, sigma, cn_a, *rng, prop64, quad, quad_prop, adapt};
     if (tri5_wanted(m, n)) {
         const int rc = launch_tri5(&pa, m, nullptr, x, ladj, n, stream);
         if (rc >= 0) return rc;
@@ -468,8 +492,10 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     if (wv < TRI5_NC) {
         if constexpr (FM > 0) {
             for (int e = lane; e < (Dp - D) * 16; e += 64) Y[lidx(D + (e >> 4), e & 15)] = 0.0f;
-            propose_body<FM>(pa.kind, pa.cur32, nullptr, pa.mu, pa.inv_cov, pa.chol, pa.nu, pa.sigma, pa.cn_a, pa.rng,
-                             pa.prop64, nullptr, pa.quad, pa.quad_prop, n, D, Y, rank_of_feat + (T - 1) * D, set);
+            const double sg = pa.adapt ? pa.adapt[0] : pa.sigma, ca = pa.adapt ? pa.adapt[1] : pa.cn_a;
+            propose_body<FM>(pa.kind, pa.cur32, nullptr, pa.adapt ? pa.adapt + 2 : pa.mu, pa.inv_cov, pa.chol, pa.nu, sg,
+                             ca, pa.rng, pa.prop64, nullptr, pa.quad, pa.quad_prop, n, D, Y, rank_of_feat + (T - 1) * D,
+                             set);
         } else {
             load_rows(Y, in, row0, n, D, Dp, feat_of_rank + (T - 1) * D, lane);
         }
@@ -511,16 +537,16 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                 case 8: prefetch_tile<8>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
                 default: break;                                                                                  \
             }
-#define SW_BURST(NK, P1, P2, AA1, AA2, HH0, HH1)                                                                 \
+#define SW_BURST(NK, P1, P2, AA1, AA2, CC1, CC2, HH0, HH1)                                                       \
             switch ((NK) < PK4 ? (NK) : PK4) {                                                                    \
-                case 1: burst_tile<1>(AA1, AA2, P1, P2, HH0, HH1, lane); break;                                  \
-                case 2: burst_tile<2>(AA1, AA2, P1, P2, HH0, HH1, lane); break;                                  \
-                case 3: burst_tile<3>(AA1, AA2, P1, P2, HH0, HH1, lane); break;                                  \
-                case 4: burst_tile<4>(AA1, AA2, P1, P2, HH0, HH1, lane); break;                                  \
-                case 5: burst_tile<5>(AA1, AA2, P1, P2, HH0, HH1, lane); break;                                  \
-                case 6: burst_tile<6>(AA1, AA2, P1, P2, HH0, HH1, lane); break;                                  \
-                case 7: burst_tile<7>(AA1, AA2, P1, P2, HH0, HH1, lane); break;                                  \
-                case 8: burst_tile<8>(AA1, AA2, P1, P2, HH0, HH1, lane); break;                                  \
+                case 1: burst_tile_open<1>(AA1, AA2, CC1, CC2, P1, P2, HH0, HH1, lane); break;                   \
+                case 2: burst_tile_open<2>(AA1, AA2, CC1, CC2, P1, P2, HH0, HH1, lane); break;                   \
+                case 3: burst_tile_open<3>(AA1, AA2, CC1, CC2, P1, P2, HH0, HH1, lane); break;                   \
+                case 4: burst_tile_open<4>(AA1, AA2, CC1, CC2, P1, P2, HH0, HH1, lane); break;                   \
+                case 5: burst_tile_open<5>(AA1, AA2, CC1, CC2, P1, P2, HH0, HH1, lane); break;                   \
+                case 6: burst_tile_open<6>(AA1, AA2, CC1, CC2, P1, P2, HH0, HH1, lane); break;                   \
+                case 7: burst_tile_open<7>(AA1, AA2, CC1, CC2, P1, P2, HH0, HH1, lane); break;                   \
+                case 8: burst_tile_open<8>(AA1, AA2, CC1, CC2, P1, P2, HH0, HH1, lane); break;                   \
                 default: break;                                                                                  \
             }
             // everything tile TT needs from global memory: fragments against tiles 0..TT-1 (the last one, K = TT-1,
@@ -538,25 +564,31 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
             {                                                                                                    \
                 const int Tt = (TT);                                                                             \
                 FETCH_TILE(Tt + 1, NP1, NP2, NL1, NL2, NB1, NB2, NDG)                                            \
-                f32x4 a1[TRI5_NC], a2[TRI5_NC];                                                                  \
+                /* same order of additions as tri4: partial sums (a: x,z terms; c: y,w terms) over the first      */ \
+                /* min(Tt, PK4) K tiles, folded, then the K tiles beyond PK4 one after the other                  */ \
+                f32x4 a1[TRI5_NC], a2[TRI5_NC], c1[TRI5_NC], c2[TRI5_NC];                                        \
                 _Pragma("unroll") for (int c = 0; c < TRI5_NC; ++c) {                                            \
                     a1[c][0] = Bb1.x; a1[c][1] = Bb1.y; a1[c][2] = Bb1.z; a1[c][3] = Bb1.w;                      \
                     a2[c][0] = Bb2.x; a2[c][1] = Bb2.y; a2[c][2] = Bb2.z; a2[c][3] = Bb2.w;                      \
+                    c1[c] = f32x4{0.f, 0.f, 0.f, 0.f}; c2[c] = f32x4{0.f, 0.f, 0.f, 0.f};                        \
                 }                                                                                                \
                 /* everything that is final while the chains of tile Tt-1 still run: K <= Tt-2 */                \
                 _Pragma("unroll") for (int c = 0; c < TRI5_NC; ++c) {                                            \
                     const float* h0_ = smem + (size_t)c * set_floats + 2 * Dp * 16;                              \
                     const float* h1_ = h0_ + Hp * 16;                                                            \
-                    SW_BURST(Tt - 1, P1, P2, a1[c], a2[c], h0_, h1_)                                             \
-                    for (int K = PK4; K < Tt - 1; ++K) {                                                         \
-                        const float4 w1 = bload4(rs, vo_lane, oF1 + (Tt * nT + K) * 1024);                        \
-                        const float4 w2 = bload4(rs, vo_lane, oF2 + (Tt * nT + K) * 1024);                        \
-                        const float4 b1 = *reinterpret_cast<const float4*>(h0_ + (K << 8) + (lane << 2));        \
-                        const float4 b2 = *reinterpret_cast<const float4*>(h1_ + (K << 8) + (lane << 2));        \
-                        a1[c] = MFMA(w1.x, b1.x, a1[c]); a2[c] = MFMA(w2.x, b2.x, a2[c]);                        \
-                        a1[c] = MFMA(w1.y, b1.y, a1[c]); a2[c] = MFMA(w2.y, b2.y, a2[c]);                        \
-                        a1[c] = MFMA(w1.z, b1.z, a1[c]); a2[c] = MFMA(w2.z, b2.z, a2[c]);                        \
-                        a1[c] = MFMA(w1.w, b1.w, a1[c]); a2[c] = MFMA(w2.w, b2.w, a2[c]);                        \
+                    SW_BURST(Tt - 1, P1, P2, a1[c], a2[c], c1[c], c2[c], h0_, h1_)                               \
+                    if (Tt - 1 >= PK4) {                                                                         \
+                        for (int r = 0; r < 4; ++r) { a1[c][r] += c1[c][r]; a2[c][r] += c2[c][r]; }              \
+                        for (int K = PK4; K < Tt - 1; ++K) {                                                     \
+                            const float4 w1 = bload4(rs, vo_lane, oF1 + (Tt * nT + K) * 1024);                    \
+                            const float4 w2 = bload4(rs, vo_lane, oF2 + (Tt * nT + K) * 1024);                    \
+                            const float4 b1 = *reinterpret_cast<const float4*>(h0_ + (K << 8) + (lane << 2));    \
+                            const float4 b2 = *reinterpret_cast<const float4*>(h1_ + (K << 8) + (lane << 2));    \
+                            a1[c] = MFMA(w1.x, b1.x, a1[c]); a2[c] = MFMA(w2.x, b2.x, a2[c]);                    \
+                            a1[c] = MFMA(w1.y, b1.y, a1[c]); a2[c] = MFMA(w2.y, b2.y, a2[c]);                    \
+                            a1[c] = MFMA(w1.z, b1.z, a1[c]); a2[c] = MFMA(w2.z, b2.z, a2[c]);                    \
+                            a1[c] = MFMA(w1.w, b1.w, a1[c]); a2[c] = MFMA(w2.w, b2.w, a2[c]);                    \
+                        }                                                                                        \
                     }                                                                                            \
                 }                                                                                                \
                 if (Tt > 0) lds_bar();                                    /* A(Tt-1): tile Tt-1 is final now */   \
@@ -571,10 +603,18 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                         const float* h1_ = h0_ + Hp * 16;                                                        \
                         const float4 b1 = *reinterpret_cast<const float4*>(h0_ + (K << 8) + (lane << 2));        \
                         const float4 b2 = *reinterpret_cast<const float4*>(h1_ + (K << 8) + (lane << 2));        \
-                        a1[c] = MFMA(L1.x, b1.x, a1[c]); a2[c] = MFMA(L2.x, b2.x, a2[c]);                        \
-                        a1[c] = MFMA(L1.y, b1.y, a1[c]); a2[c] = MFMA(L2.y, b2.y, a2[c]);                        \
-                        a1[c] = MFMA(L1.z, b1.z, a1[c]); a2[c] = MFMA(L2.z, b2.z, a2[c]);                        \
-                        a1[c] = MFMA(L1.w, b1.w, a1[c]); a2[c] = MFMA(L2.w, b2.w, a2[c]);                        \
+                        if (K < PK4) {                                                                           \
+                            a1[c] = MFMA(L1.x, b1.x, a1[c]); a2[c] = MFMA(L2.x, b2.x, a2[c]);                    \
+                            c1[c] = MFMA(L1.y, b1.y, c1[c]); c2[c] = MFMA(L2.y, b2.y, c2[c]);                    \
+                            a1[c] = MFMA(L1.z, b1.z, a1[c]); a2[c] = MFMA(L2.z, b2.z, a2[c]);                    \
+                            c1[c] = MFMA(L1.w, b1.w, c1[c]); c2[c] = MFMA(L2.w, b2.w, c2[c]);                    \
+                            for (int r = 0; r < 4; ++r) { a1[c][r] += c1[c][r]; a2[c][r] += c2[c][r]; }          \
+                        } else {                                                                                 \
+                            a1[c] = MFMA(L1.x, b1.x, a1[c]); a2[c] = MFMA(L2.x, b2.x, a2[c]);                    \
+                            a1[c] = MFMA(L1.y, b1.y, a1[c]); a2[c] = MFMA(L2.y, b2.y, a2[c]);                    \
+                            a1[c] = MFMA(L1.z, b1.z, a1[c]); a2[c] = MFMA(L2.z, b2.z, a2[c]);                    \
+                            a1[c] = MFMA(L1.w, b1.w, a1[c]); a2[c] = MFMA(L2.w, b2.w, a2[c]);                    \
+                        }                                                                                        \
                     }                                                                                            \
                     float* sp = base_ + 2 * Dp * 16 + 3 * Hp * 16 + (p << 4) + (q << 2);                         \
                     *reinterpret_cast<float4*>(sp + 256) = make_float4(a1[c][0], a1[c][1], a1[c][2], a1[c][3]);  \

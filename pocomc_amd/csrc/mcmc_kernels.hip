@@ -27,8 +27,9 @@ __global__ __launch_bounds__(PROP_ROWS) void propose_kernel(
     const double* __restrict__ mu, const double* __restrict__ inv_cov, const double* __restrict__ chol,
     double nu, double sigma, double cn_a, pmc_rng_t rng, double* __restrict__ prop64,
     float* __restrict__ prop32, double* __restrict__ quad, double* __restrict__ quad_prop,
-    int64_t n, int D) {
+    int64_t n, int D, const double* __restrict__ adapt) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (adapt) { sigma = adapt[0]; cn_a = adapt[1]; mu = adapt + 2; }   // pmc_step_t.adapt_state
     const int LD = PROP_ROWS + 1;
     double* dif = sm;                 // [D][LD]  theta - mu (tpCN) or theta (RWM)
     double* zz = sm + (size_t)D * LD; // [D][LD]  z, overwritten by the proposal
@@ -358,11 +359,32 @@ __device__ __forceinline__ double block_sum_256(double v, double* red, int tid) 
 // walkers; then all four waves copy the accepted rows (independent, unrolled loads) and take the
 // column sums on the fly.  The last block to arrive (agent-scope release -> ticket -> acquire) folds
 // the per-block partials in a fixed order, so the result is deterministic and needs no second launch.
+__device__ __forceinline__ void adapt_apply(const pmc_adapt_args& ad, const double* sums, int tid, int D) {
+    // numpy's expressions of mcmc.py:152-156 in their operation order, no contraction
+#pragma clang fp contract(off)
+    if (tid == 0) {
+        const double mean_alpha = sums[0] / ad.n_total;
+        const double sg = ad.state[0];
+        double sn = sg + ad.c_sigma * (mean_alpha - 0.234);
+        const int how = ad.mode & 7;
+        if (how == PMC_ADAPT_TPCN) sn = fabs(fmin(sn, ad.cap));
+        else if (how == PMC_ADAPT_RWM) sn = fabs(sn);
+        ad.state[0] = sn;
+        ad.state[1] = (how == PMC_ADAPT_TPCN) ? sqrt(1.0 - sn * sn) : 0.0;          // (1 - sigma^2)^0.5, mcmc.py:85
+    }
+    if ((ad.mode & PMC_ADAPT_MU) && tid < D) {
+        const float mean_theta = (float)(sums[4 + tid] / ad.n_total);              // np.mean of the float32 theta
+        const double m = ad.state[2 + tid];
+        ad.state[2 + tid] = m + ad.c_mu * ((double)mean_theta - m);
+    }
+}
+
 __global__ __launch_bounds__(256) void accept_kernel(
     int preconditioned, int tpcn, pmc_state_t cur, pmc_proposal_t prop, double beta, double nu,
     pmc_rng_t rng, double* __restrict__ alpha_out, int32_t* __restrict__ accept_out,
     double* __restrict__ partials, unsigned* __restrict__ ticket, double* __restrict__ sums,
-    double* __restrict__ sums_copy, long long* __restrict__ done_flag, long long done_value, int64_t n, int D) {
+    double* __restrict__ sums_copy, long long* __restrict__ done_flag, long long done_value, int64_t n, int D,
+    pmc_adapt_args ad) {
     __shared__ int flag[ACC_ROWS];
     __shared__ double colsum[8][33];
     __shared__ int is_last;
@@ -482,6 +504,7 @@ __global__ __launch_bounds__(256) void accept_kernel(
         }
         __syncthreads();
     }
+    if (ad.state && ad.mode) adapt_apply(ad, sums, tid, D);   // pmc_step_t.adapt_state: the proposal of the next step
     if (done_flag) {
         __threadfence_system();           // the sums (and every block's state updates) before the completion word
         __syncthreads();
@@ -640,15 +663,23 @@ extern "C" int pmc_propose(int kind, const float* cur32, const double* cur64, co
                            const double* inv_cov, const double* chol, double nu, double sigma, double cn_a,
                            const pmc_rng_t* rng, double* prop64, float* prop32, double* quad,
                            double* quad_prop, int64_t n, int32_t D, void* stream) {
+    return pmc_propose_adapt(kind, cur32, cur64, mu, inv_cov, chol, nu, sigma, cn_a, rng, prop64, prop32, quad, quad_prop,
+                             n, D, stream, nullptr);
+}
+
+int pmc_propose_adapt(int kind, const float* cur32, const double* cur64, const double* mu, const double* inv_cov,
+                      const double* chol, double nu, double sigma, double cn_a, const pmc_rng_t* rng, double* prop64,
+                      float* prop32, double* quad, double* quad_prop, int64_t n, int32_t D, void* stream,
+                      const double* adapt) {
     if (n == 0) return 0;
     if ((!cur32) == (!cur64)) return pmc_fail("pmc_propose: exactly one of cur32 / cur64 must be given");
     if (!chol || !rng || n < 0 || D < 1) return pmc_fail("pmc_propose: bad argument");
-    if (kind == PMC_KIND_TPCN && (!mu || !inv_cov)) return pmc_fail("pmc_propose: tpCN needs mu and inv_cov");
+    if (kind == PMC_KIND_TPCN && ((!mu && !adapt) || !inv_cov)) return pmc_fail("pmc_propose: tpCN needs mu and inv_cov");
     if (kind != PMC_KIND_TPCN && kind != PMC_KIND_RWM) return pmc_fail("pmc_propose: unknown kind");
     if (!prop64 && !prop32) return pmc_fail("pmc_propose: no output");
     {   // f64 matrix-core kernel (D <= 128); the LDS-staged VALU kernel below covers larger D
         const int rc = pmc_launch_propose_mfma(kind, cur32, cur64, mu, inv_cov, chol, nu, sigma, cn_a, rng, prop64,
-                                               prop32, quad, quad_prop, n, D, (hipStream_t)stream);
+                                               prop32, quad, quad_prop, n, D, (hipStream_t)stream, adapt);
         if (rc >= 0) return rc;
     }
     const size_t lds = (size_t)2 * D * (PROP_ROWS + 1) * sizeof(double);
@@ -660,7 +691,7 @@ extern "C" int pmc_propose(int kind, const float* cur32, const double* cur64, co
     }
     hipLaunchKernelGGL(propose_kernel, dim3((unsigned)((n + PROP_ROWS - 1) / PROP_ROWS)), dim3(PROP_ROWS), lds,
                        (hipStream_t)stream, kind, cur32, cur64, mu, inv_cov, chol, nu, sigma, cn_a, *rng,
-                       prop64, prop32, quad, quad_prop, n, (int)D);
+                       prop64, prop32, quad, quad_prop, n, (int)D, adapt);
     return pmc_check_launch("propose_kernel");
 }
 
@@ -767,7 +798,7 @@ extern "C" int64_t pmc_accept_workspace_bytes(int64_t n, int32_t D) {
 static int accept_impl(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposal_t* prop, double beta,
                        double nu, const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums,
                        double* sums_copy, bool armed, const pmc_done_t* done, void* workspace, int64_t n, int32_t D,
-                       void* stream) {
+                       void* stream, const pmc_adapt_args* adapt = nullptr) {
     if (!cur || !prop || !rng || !sums || !workspace || n < 0 || D < 1) return pmc_fail("pmc_accept: bad argument");
     if (!cur->u || !cur->x || !cur->logdetj || !cur->logl || !cur->logp || !prop->u || !prop->x ||
         !prop->logdetj || !prop->logl || !prop->logp)
@@ -789,7 +820,7 @@ static int accept_impl(int kind, int preconditioned, pmc_state_t* cur, const pmc
     if (!armed && hipMemsetAsync(ticket, 0, sizeof(unsigned), st) != hipSuccess) return pmc_fail("pmc_accept: memset");
     hipLaunchKernelGGL(accept_kernel, dim3(nb), dim3(256), 0, st, preconditioned, tpcn, *cur, *prop, beta, nu, *rng,
                        alpha_out, accept_out, partials, ticket, sums, sums_copy, done ? (long long*)done->flag : nullptr,
-                       done ? (long long)done->value : 0LL, n, (int)D);
+                       done ? (long long)done->value : 0LL, n, (int)D, adapt ? *adapt : pmc_adapt_args{});
     return pmc_check_launch("accept_kernel");
 }
 
@@ -806,6 +837,53 @@ extern "C" int pmc_accept_armed(int kind, int preconditioned, pmc_state_t* cur, 
                                 void* stream) {
     return accept_impl(kind, preconditioned, cur, prop, beta, nu, rng, alpha_out, accept_out, sums, sums_copy, true,
                        done, workspace, n, D, stream);
+}
+
+struct AdaptParts { const double* p[8]; };
+
+__global__ __launch_bounds__(256) void adapt_update_kernel(AdaptParts parts, int n_parts, int D, double* total_out,
+                                                           double* h_sums, pmc_adapt_args ad, long long* done_flag,
+                                                           long long done_value) {
+    __shared__ double tot[260];
+    const int tid = threadIdx.x;
+    for (int j = tid; j < D + 4; j += 256) {
+        double t = parts.p[0][j];
+        for (int k = 1; k < n_parts; ++k) t += parts.p[k][j];
+        tot[j] = t;
+        if (total_out) total_out[j] = t;
+        if (h_sums) h_sums[j] = t;
+    }
+    __syncthreads();
+    if (ad.state && ad.mode) adapt_apply(ad, tot, tid, D);
+    if (done_flag) {
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done_flag, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+extern "C" int pmc_adapt_update(const double* const* parts, int32_t n_parts, int32_t D, double* total_out, double* h_sums,
+                                double* adapt_state, int32_t adapt_mode, double c_sigma, double c_mu, double cap,
+                                double n_total, const pmc_done_t* done, void* stream) {
+    if (!parts || n_parts < 1 || n_parts > 8 || D < 1 || D > 256) return pmc_fail("pmc_adapt_update: bad argument");
+    AdaptParts ap{};
+    for (int k = 0; k < n_parts; ++k) {
+        if (!parts[k]) return pmc_fail("pmc_adapt_update: null part");
+        ap.p[k] = parts[k];
+    }
+    pmc_adapt_args ad{adapt_state, adapt_state ? adapt_mode : 0, c_sigma, c_mu, cap, n_total};
+    hipLaunchKernelGGL(adapt_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ap, (int)n_parts, (int)D, total_out,
+                       h_sums, ad, done ? (long long*)done->flag : nullptr, done ? (long long)done->value : 0LL);
+    return pmc_check_launch("adapt_update_kernel");
+}
+
+int pmc_accept_adapt(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposal_t* prop, double beta, double nu,
+                     const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums, double* sums_copy,
+                     const pmc_done_t* done, void* workspace, int64_t n, int32_t D, void* stream,
+                     const pmc_adapt_args* adapt) {
+    if (adapt && adapt->state && adapt->mode && D > 256) return pmc_fail("pmc_accept: device adaptation needs D <= 256");
+    return accept_impl(kind, preconditioned, cur, prop, beta, nu, rng, alpha_out, accept_out, sums, sums_copy, true,
+                       done, workspace, n, D, stream, adapt);
 }
 
 extern "C" int pmc_logw(const double* logl, const double* beta, const double* logz, double beta_final,

@@ -19,11 +19,26 @@ int pmc_launch_inverse_tri4(const pmc_maf_t* m, const float* z, float* x, float*
 int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* mu, const double* inv_cov,
                                     const double* chol, double nu, double sigma, double cn_a, const pmc_rng_t* rng,
                                     double* prop64, double* quad, double* quad_prop, const pmc_maf_t* m, float* x,
-                                    float* ladj, int64_t n, hipStream_t stream);
+                                    float* ladj, int64_t n, hipStream_t stream, const double* adapt = nullptr);
 int pmc_launch_inverse_tri3(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream);
 int pmc_launch_propose_mfma(int kind, const float* cur32, const double* cur64, const double* mu,
                             const double* inv_cov, const double* chol, double nu, double sigma, double cn_a,
                             const pmc_rng_t* rng, double* prop64, float* prop32, double* quad, double* quad_prop,
-                            int64_t n, int32_t D, hipStream_t stream);
+                            int64_t n, int32_t D, hipStream_t stream, const double* adapt = nullptr);
+// pmc_propose with sigma / cn_a / mu taken from pmc_step_t.adapt_state (device) when adapt != NULL
+int pmc_propose_adapt(int kind, const float* cur32, const double* cur64, const double* mu, const double* inv_cov,
+                      const double* chol, double nu, double sigma, double cn_a, const pmc_rng_t* rng, double* prop64,
+                      float* prop32, double* quad, double* quad_prop, int64_t n, int32_t D, void* stream,
+                      const double* adapt);
+// what the accept kernel's last block does with the sums (pmc_step_t.adapt_*)
+struct pmc_adapt_args {
+    double* state;
+    int mode;
+    double c_sigma, c_mu, cap, n_total;
+};
+int pmc_accept_adapt(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposal_t* prop, double beta, double nu,
+                     const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums, double* sums_copy,
+                     const pmc_done_t* done, void* workspace, int64_t n, int32_t D, void* stream,
+                     const pmc_adapt_args* adapt);
 
 #endif

@@ -52,7 +52,9 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
     // host_direct: the kernels read mu from / write x', finite, logp' to pinned host memory themselves
     const bool direct = s->host_direct && !s->p_xT;
     const double* mu = s->mu;
-    if (tpcn && s->h_mu) {
+    // adaptation on the device: sigma, cn_a and mu come from adapt_state (pmc_step_post keeps it up to date)
+    const double* adapt = (s->adapt_state && s->adapt_mode) ? s->adapt_state : nullptr;
+    if (!adapt && tpcn && s->h_mu) {
         if (direct) mu = s->h_mu;
         else if (hipMemcpyAsync((void*)s->mu, s->h_mu, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
             return pmc_fail("pmc_step_pre: H2D mu");
@@ -65,16 +67,16 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
         if (s->ev_inv0) (void)hipEventRecord((hipEvent_t)s->ev_inv0, st);
         rc = pmc_launch_propose_inverse_tri4(s->kind, s->cur.theta32, mu, s->inv_cov, s->chol, nu, sigma, cn_a, rng,
                                              s->p_theta64, tpcn ? s->quad : nullptr, tpcn ? s->p_quad : nullptr, s->maf,
-                                             s->p_u32, s->p_ldjf, n, st);
+                                             s->p_u32, s->p_ldjf, n, st, adapt);
         if (rc > 0) return rc;
         fused = (rc == 0);
         if (fused && s->ev_inv1) (void)hipEventRecord((hipEvent_t)s->ev_inv1, st);
     }
     if (!fused) {
-        rc = pmc_propose(s->kind, s->preconditioned ? s->cur.theta32 : nullptr, s->preconditioned ? nullptr : s->cur.u,
-                         mu, s->inv_cov, s->chol, nu, sigma, cn_a, rng, s->p_theta64,
-                         s->preconditioned ? s->p_theta32 : nullptr, tpcn ? s->quad : nullptr,
-                         tpcn ? s->p_quad : nullptr, n, D, stream);
+        rc = pmc_propose_adapt(s->kind, s->preconditioned ? s->cur.theta32 : nullptr,
+                               s->preconditioned ? nullptr : s->cur.u, mu, s->inv_cov, s->chol, nu, sigma, cn_a, rng,
+                               s->p_theta64, s->preconditioned ? s->p_theta32 : nullptr, tpcn ? s->quad : nullptr,
+                               tpcn ? s->p_quad : nullptr, n, D, stream, adapt);
         if (rc) return rc;
     }
     // scaler inverse and (when it runs on the device) Prior.logpdf share one launch
@@ -156,10 +158,14 @@ extern "C" int pmc_step_post(const pmc_step_t* s, const pmc_rng_t* rng, double b
     int rc;
     if (direct) {
         pmc_done_t dn{s->h_done ? s->h_done + 1 : nullptr, (int64_t)rng->step + 1, nullptr};
-        rc = pmc_accept_armed(s->kind, s->preconditioned, &cur, &prop, beta, nu, rng, s->alpha, s->accept, s->sums,
+        pmc_adapt_args ad{s->adapt_state, s->adapt_state ? s->adapt_mode : 0, s->adapt_c_sigma, s->adapt_c_mu,
+                          s->adapt_cap, s->adapt_n_total};
+        rc = pmc_accept_adapt(s->kind, s->preconditioned, &cur, &prop, beta, nu, rng, s->alpha, s->accept, s->sums,
                               copy_sums ? s->h_sums : nullptr, (copy_sums && s->h_done) ? &dn : nullptr, s->ws, n, s->D,
-                              stream);
+                              stream, &ad);
     }
+    else if (s->adapt_state && s->adapt_mode)
+        return pmc_fail("pmc_step_post: adaptation on the device needs host_direct");
     else
         rc = pmc_accept(s->kind, s->preconditioned, &cur, &prop, beta, nu, rng, s->alpha, s->accept, s->sums, s->ws, n,
                         s->D, stream);

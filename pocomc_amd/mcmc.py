@@ -35,6 +35,9 @@ PMC_KIND_TPCN, PMC_KIND_RWM = 0, 1
 # --------------------------------------------------------------------------
 # host-side scalar logic, shared with the CPU tests of the sharded path
 # --------------------------------------------------------------------------
+PMC_ADAPT_TPCN, PMC_ADAPT_PRWM, PMC_ADAPT_RWM, PMC_ADAPT_MU = 1, 2, 3, 8          # include/pocomc_amd.h
+
+
 class Adaptation:
     """sigma / mu adaptation and the plateau stop of one kernel call
     (``mcmc.py:152-180`` and the variants ``:314-336``, ``:476-502``, ``:627-650``).
@@ -55,6 +58,22 @@ class Adaptation:
         self.cnt = 0
         self.i = 0
         self.mean_alpha = 0.0
+
+    def coefficients(self):
+        """What the update that follows the step now in flight multiplies with: ``(mode, c_sigma, c_mu, cap)`` for
+        the device-side copy of this update (``pmc_step_t.adapt_*``).  Same expressions as in :meth:`update`, so
+        host and device hold the same sigma and mu bit for bit."""
+        i = self.i + 1
+        cap = float(np.minimum(2.38 / self.D ** 0.5, 0.99))
+        if self.tpcn:
+            mode, c = PMC_ADAPT_TPCN, 1 / (i + 1) ** 0.75
+        elif self.kind == "preconditioned_rwm":
+            mode, c = PMC_ADAPT_PRWM, 1 / (i + 1)
+        else:
+            mode, c = PMC_ADAPT_RWM, 1 / (i + 1)
+        if self.kind == "preconditioned_pcn":
+            mode |= PMC_ADAPT_MU
+        return mode, float(c), 1.0 / (i + 1.0), cap
 
     def update(self, sums):
         """``sums`` = [sum alpha, sum(logl+logp), sum(logl+logp+logdetj), n_accept, sum theta_j...].
@@ -204,6 +223,10 @@ class StepEngine:
         self.h_done.zero_()
         self._done_ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self._direct_now = False
+        # adaptation on the device (pmc_step_t.adapt_state): {sigma, cn_a, mu[D]}; see run_pipelined
+        self.adapt_state = f64(D + 2)
+        self._h_adapt = pin(D + 2)
+        self.device_adapt = False
         self.prior_desc = None   # pmc_prior_t when Prior.logpdf runs on the device (set_device_prior)
         self.composite = True    # one C call before / after the host black boxes (pmc_step_pre / _post)
         # x_order 'F' on the composite path: the scaler kernel writes x', the finite mask and logp' straight
@@ -213,6 +236,7 @@ class StepEngine:
         self.step_idx = 0
         self.host_threads = 1    # >1: evaluate the black boxes on row chunks in a thread pool
         self._pool = None
+        self.stream = None       # torch.cuda.Stream of the composite path (LanedEngine); None: the current one
         self.events = None       # bench.py: list of per-step HIP event tuples when not None
         self.host_timers = None  # bench.py: dict of accumulated host seconds when not None
 
@@ -286,15 +310,33 @@ class StepEngine:
         return _lib.pmc_rng_t(gamma=None, normal=None, uniform=None, seed=self.seed, step=self.step_idx,
                               offset=self.offset)
 
-    def propose(self, sigma, nu=0.0, replay=None):
-        """propose -> flow inverse -> scaler inverse, then start the D2H of x'."""
+    def can_pipeline(self):
+        """Adaptation on the device + the next pre-step enqueued behind the accept: composite path with the
+        kernels reading / writing pinned host memory themselves."""
+        return bool(self.composite and self.events is None and self.host_direct and self.x_order == "F"
+                    and self.spin_wait and self.D <= 256)
+
+    def adapt_upload(self, sigma, mu=None):
+        """Start value of the device-side adaptation state (sigma, (1-sigma^2)^0.5, mu)."""
+        a = self._h_adapt.numpy()
+        a[0] = sigma
+        a[1] = (1.0 - sigma ** 2.0) ** 0.5 if self.tpcn else 0.0
+        a[2:] = 0.0 if mu is None else mu
+        self.adapt_state.copy_(self._h_adapt, non_blocking=True)
+        self._step.adapt_state = self.adapt_state.data_ptr()
+        self.device_adapt = True
+
+    def propose(self, sigma, nu=0.0, replay=None, step=None):
+        """propose -> flow inverse -> scaler inverse, then start the D2H of x'.  ``step``: the step number the
+        launch belongs to when it is enqueued ahead of time (run_pipelined), default: the current one."""
         lib, n, D = self.lib, self.n, self.D
         if self.composite and self.events is None:
             if replay is not None:
                 self._rng_cur = self._rng(replay)
             else:
-                self._rng_fast.step = self.step_idx
+                self._rng_fast.step = self.step_idx if step is None else int(step)
                 self._rng_cur = self._rng_fast
+            self._step.adapt_mode = 1 if self.device_adapt else 0         # (pre: any non-zero mode = read the state)
             if self.pre:
                 self._step.inverse_algo = self.flow.inverse_algo
             self._step.rng_ready = C.cast(C.pointer(self._rng_ready), C.c_void_p) if self.rng_prefill else None
@@ -304,8 +346,11 @@ class StepEngine:
             self._direct_now = direct and self.spin_wait
             self._step.h_done = self.h_done.data_ptr() if self._direct_now else None
             self._step.done_ticket = self._done_ticket.data_ptr() if self._direct_now else None
-            cn_a = float((1.0 - sigma ** 2.0) ** 0.5) if self.tpcn else 0.0        # mcmc.py:85
-            self._stream = _lib.stream_handle()
+            if self.device_adapt:
+                sigma, cn_a = 0.0, 0.0                      # the kernels read adapt_state instead
+            else:
+                cn_a = float((1.0 - sigma ** 2.0) ** 0.5) if self.tpcn else 0.0    # mcmc.py:85
+            self._stream = self.stream.cuda_stream if self.stream is not None else _lib.stream_handle()
             _lib.check(lib.pmc_step_pre(C.byref(self._step), C.byref(self._rng_cur), float(nu), float(sigma), cn_a,
                                         self._stream), "pmc_step_pre")
             self._post_uploads = True
@@ -443,23 +488,43 @@ class StepEngine:
             if self.prior_desc is None:
                 self.p_logp.copy_(self.h_logp, non_blocking=True)
 
+    def accept_enqueue(self, beta, nu=0.0, want_mask=False, host_sums=True, adapt=None, n_total=None):
+        """Composite path: enqueue the Metropolis accept + this engine's sums behind the host's logl' (no wait).
+        ``adapt`` = Adaptation.coefficients(): the kernel's last block also updates the device-side sigma / mu."""
+        assert self._post_uploads
+        self._want_mask = bool(want_mask)
+        self._host_sums = bool(host_sums)
+        if adapt is not None and self.device_adapt:
+            st = self._step
+            st.adapt_mode, st.adapt_c_sigma, st.adapt_c_mu, st.adapt_cap = adapt
+            st.adapt_n_total = float(self.n if n_total is None else n_total)
+        else:
+            self._step.adapt_mode = 0
+        _lib.check(self.lib.pmc_step_post(C.byref(self._step), C.byref(self._rng_cur), float(beta), float(nu),
+                                          int(want_mask), int(host_sums), self._stream), "pmc_step_post")
+
+    def accept_wait(self):
+        """Wait for what accept_enqueue started; returns this engine's host sums (valid with host_sums=True)."""
+        if self._direct_now and self._host_sums and not self._want_mask:   # (the mask copy is a stream operation)
+            _lib.check(self.lib.pmc_wait_flag(self.h_done.data_ptr() + 8, self.step_idx + 1, 30.0), "pmc_wait_flag")
+        else:
+            _lib.check(self.lib.pmc_stream_synchronize(self._stream), "pmc_stream_synchronize")
+        self.step_idx += 1
+        return self._np_sums
+
     def accept_reduce(self, beta, nu=0.0, want_mask=False):
         """Metropolis accept + global sums; returns the (all-reduced) host copy."""
         if self._post_uploads:
             import torch.distributed as dist
             sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
-            _lib.check(self.lib.pmc_step_post(C.byref(self._step), C.byref(self._rng_cur), float(beta), float(nu),
-                                              int(want_mask), int(not sharded), self._stream), "pmc_step_post")
+            self.accept_enqueue(beta, nu, want_mask, host_sums=not sharded)
             if sharded:
                 allreduce_sums(self.sums, self.group)
                 self.h_sums.copy_(self.sums, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
-            elif self._direct_now and not want_mask:        # (the accept-mask copy is an ordinary stream operation)
-                _lib.check(self.lib.pmc_wait_flag(self.h_done.data_ptr() + 8, self.step_idx + 1, 30.0), "pmc_wait_flag")
-            else:
-                _lib.check(self.lib.pmc_stream_synchronize(self._stream), "pmc_stream_synchronize")
-            self.step_idx += 1
-            return self._np_sums
+                self.step_idx += 1
+                return self._np_sums
+            return self.accept_wait()
         kind = PMC_KIND_TPCN if self.tpcn else PMC_KIND_RWM
         timed = self.events is not None
         with torch.cuda.device(self.device):
@@ -484,6 +549,172 @@ class StepEngine:
 
 
 # --------------------------------------------------------------------------
+class LanedEngine:
+    """One walker set as K contiguous row ranges (lanes), each a StepEngine on its own HIP stream.
+
+    The rows of a step are independent between the proposal and the accept (``mcmc.py:77-141``: per-walker
+    loops and a row-wise likelihood); only the adaptation (``:152-156``) needs all of them.  So while the host
+    evaluates the likelihood of lane k, the device still works on the proposals of lane k+1 and on the accept
+    of lane k-1: the step costs  device(lane 0) + likelihood(all rows) + accept(last lane)  instead of
+    device(all) + likelihood(all) + accept(all).  The Philox counters are keyed on the global walker index
+    (``shard_offset``), so a laned step draws exactly the variates of the un-laned one; the only difference is
+    the order in which the D+4 sums are added (last bits of mean(alpha), mean(theta))."""
+
+    def __init__(self, kind, n, n_dim, flow, scaler, lanes=2, group=None, shard_offset=0, seed=0, x_order="C",
+                 streams=True):
+        """``streams=False``: all lanes on the current stream, one after the other (the pipelined mode:
+        :meth:`start_pipeline` / :meth:`step_pipelined`)."""
+        n = int(n)
+        lanes = max(1, min(int(lanes), (n + 15) // 16))
+        per = ((n + lanes - 1) // lanes + 15) // 16 * 16          # whole 16-row sets per lane
+        self.bounds = [(min(k * per, n), min((k + 1) * per, n)) for k in range(lanes)]
+        self.bounds = [b for b in self.bounds if b[1] > b[0]]
+        self.n, self.D, self.group = n, int(n_dim), group
+        self.device = _lib.require_gpu()
+        self.lanes = []
+        for k, (lo, hi) in enumerate(self.bounds):
+            if streams:
+                st = torch.cuda.Stream(device=self.device, priority=-1 if k == 0 else 0)   # lane 0 is waited for first
+                with torch.cuda.stream(st):
+                    e = StepEngine(kind, hi - lo, n_dim, flow, scaler, group=group,
+                                   shard_offset=int(shard_offset) + lo, seed=seed, x_order=x_order)
+                e.stream = st
+            else:
+                e = StepEngine(kind, hi - lo, n_dim, flow, scaler, group=group, shard_offset=int(shard_offset) + lo,
+                               seed=seed, x_order=x_order)
+            self.lanes.append(e)
+        self.lib = self.lanes[0].lib
+        self.tpcn, self.pre = self.lanes[0].tpcn, self.lanes[0].pre
+        self._tot = torch.zeros(self.D + 4, dtype=torch.float64, device=self.device)
+        self._h_tot = torch.zeros(self.D + 4, dtype=torch.float64).pin_memory()
+        self._ev = [torch.cuda.Event() for _ in self.lanes]
+        self.host_timers = None
+        self._h_flag = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self._flag_value = 0
+        self._parts = (C.c_void_p * len(self.lanes))(*[e.sums.data_ptr() for e in self.lanes])
+        self._tot_part = (C.c_void_p * 1)(self._tot.data_ptr())
+
+    def _each(self, fn):
+        out = []
+        for e in self.lanes:
+            if e.stream is None:
+                out.append(fn(e))
+            else:
+                with torch.cuda.stream(e.stream):
+                    out.append(fn(e))
+        return out
+
+    def configure(self, **kw):
+        for e in self.lanes:
+            for k, v in kw.items():
+                setattr(e, k, v)
+
+    def load_state(self, u, x, logdetj, logl, logp):
+        for e, (lo, hi) in zip(self.lanes, self.bounds):
+            self_stream = torch.cuda.current_stream(self.device) if e.stream is None else e.stream
+            with torch.cuda.stream(self_stream):
+                e.load_state(u[lo:hi], x[lo:hi], logdetj[lo:hi], logl[lo:hi], logp[lo:hi])
+        torch.cuda.synchronize(self.device)
+
+    def can_pipeline(self):
+        return all(e.stream is None and e.can_pipeline() for e in self.lanes)
+
+    # ------------------------------------------------------------------ pipelined mode (one stream)
+    def start_pipeline(self, sigma, mu, nu):
+        """Adaptation state to the device, pre-steps of the first step into the queue."""
+        first = self.lanes[0]
+        first.adapt_upload(sigma, mu)
+        for e in self.lanes[1:]:
+            e._step.adapt_state = first.adapt_state.data_ptr()       # one state for all lanes
+            e.device_adapt = True
+        for e in self.lanes:
+            e.host_timers = self.host_timers
+            e.propose(None, nu)
+
+    def step_pipelined(self, beta, nu, coefficients, n_total, log_prior, log_like, more=True):
+        """One step: per lane  wait x' -> likelihood -> enqueue accept;  then one launch adds the lane sums (and,
+        between two of them, the ranks all-reduce), adapts sigma / mu on the device and hands the sums to the host;
+        the pre-steps of the next step are enqueued behind it before the host waits for those sums."""
+        import torch.distributed as dist
+        sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        lib, D, K = self.lib, self.D, len(self.lanes)
+        calls = 0
+        for e in self.lanes:
+            e.host_timers = self.host_timers
+            calls += e.evaluate(log_prior, log_like)[0]
+            e.accept_enqueue(beta, nu, host_sums=False)
+        stream = self.lanes[0]._stream
+        mode, c_sigma, c_mu, cap = coefficients
+        self._flag_value += 1
+        done = _lib.pmc_done_t(flag=self._h_flag.data_ptr(), value=self._flag_value, ticket=None)
+        state = self.lanes[0].adapt_state.data_ptr()
+        if sharded:
+            _lib.check(lib.pmc_adapt_update(self._parts, K, D, self._tot.data_ptr(), None, None, 0, 0.0, 0.0, 0.0, 1.0,
+                                            None, stream), "pmc_adapt_update")
+            allreduce_sums(self._tot, self.group)
+            _lib.check(lib.pmc_adapt_update(self._tot_part, 1, D, None, self._h_tot.data_ptr(), state, mode, c_sigma,
+                                            c_mu, cap, float(n_total), C.byref(done), stream), "pmc_adapt_update")
+        else:
+            _lib.check(lib.pmc_adapt_update(self._parts, K, D, None, self._h_tot.data_ptr(), state, mode, c_sigma, c_mu,
+                                            cap, float(n_total), C.byref(done), stream), "pmc_adapt_update")
+        if more:
+            for e in self.lanes:
+                e.propose(None, nu, step=e.step_idx + 1)
+        _lib.check(lib.pmc_wait_flag(self._h_flag.data_ptr(), self._flag_value, 30.0), "pmc_wait_flag")
+        for e in self.lanes:
+            e.step_idx += 1
+        return calls, self._h_tot.numpy()
+
+    def finish_pipeline(self):
+        _lib.check(self.lib.pmc_stream_synchronize(self.lanes[0]._stream), "pmc_stream_synchronize")
+
+    def set_geometry(self, mu=None, cov=None):
+        self._each(lambda e: e.set_geometry(mu=mu, cov=cov))
+        torch.cuda.synchronize(self.device)
+
+    def set_device_prior(self, prior):
+        return all(self._each(lambda e: e.set_device_prior(prior)))
+
+    def set_mu(self, mu):
+        for e in self.lanes:
+            e.set_mu(mu)                                   # composite path: a write to the lane's pinned h_mu
+
+    def step(self, sigma, nu, beta, log_prior, log_like):
+        """One MCMC step of all lanes; returns (likelihood calls, global sums on the host)."""
+        import torch.distributed as dist
+        sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        # (the composite entry points take the lane's stream explicitly: no stream context on this path)
+        for e in self.lanes:                               # all proposals are in flight before the first wait
+            e.host_timers = self.host_timers
+            e.propose(sigma, nu)
+        calls = 0
+        for e in self.lanes:
+            calls += e.evaluate(log_prior, log_like)[0]
+            e.accept_enqueue(beta, nu, host_sums=not sharded)
+        if sharded:
+            # lane sums -> one vector -> all-reduce over the ranks -> host
+            main = torch.cuda.current_stream(self.device)
+            for e, ev in zip(self.lanes, self._ev):
+                ev.record(e.stream)
+                main.wait_event(ev)
+            torch.stack([e.sums for e in self.lanes]).sum(0, out=self._tot)
+            allreduce_sums(self._tot, self.group)
+            self._h_tot.copy_(self._tot, non_blocking=True)
+            main.synchronize()
+            for e in self.lanes:
+                e.step_idx += 1
+            return calls, self._h_tot.numpy()
+        tot = None
+        for e in self.lanes:
+            sk = e.accept_wait()
+            tot = sk.copy() if tot is None else tot + sk
+        return calls, tot
+
+    def download(self):
+        parts = [e.download() for e in self.lanes]
+        return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+
+
 def _global_count(n, group):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -521,15 +752,31 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
                                              + int(np.random.randint(0, 2 ** 31 - 1)))
     n_walkers, n_dim = x.shape
 
-    eng = StepEngine(kind, n_walkers, n_dim, flow, scaler, group=group,
-                     shard_offset=option_dict.get("shard_offset", 0), seed=seed,
-                     x_order=option_dict.get("x_order", "C"))
-    if "host_direct" in option_dict:
-        eng.host_direct = bool(option_dict["host_direct"])
-    if "rng_prefill" in option_dict:
-        eng.rng_prefill = bool(option_dict["rng_prefill"])
-    if "spin_wait" in option_dict:
-        eng.spin_wait = bool(option_dict["spin_wait"])
+    import torch.distributed as dist
+    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    x_order = option_dict.get("x_order", "C")
+    # lanes > 1: row ranges whose device work overlaps the host likelihood of the others (LanedEngine); opt-in,
+    # it pays when the likelihood is expensive next to the device's share of a step
+    lanes = int(option_dict.get("lanes") or 1)
+    if have_blobs or trace is not None or replay is not None:
+        lanes = 1                                   # (blobs / traces / replayed variates: whole-set bookkeeping)
+    # pipelined: sigma / mu adapted on the device, the pre-step of step k+1 enqueued behind the accept of step k
+    # (needs the kernels to read / write the pinned host buffers themselves: x_order 'F')
+    want_pipe = (option_dict.get("pipeline", True) and x_order == "F" and not have_blobs and trace is None
+                 and replay is None and all(option_dict.get(k, True) for k in ("host_direct", "spin_wait")))
+    if lanes > 1 or (sharded and want_pipe):
+        eng = LanedEngine(kind, n_walkers, n_dim, flow, scaler, lanes=lanes, group=group,
+                          shard_offset=option_dict.get("shard_offset", 0), seed=seed, x_order=x_order,
+                          streams=not want_pipe)
+        tune = eng.configure
+    else:
+        eng = StepEngine(kind, n_walkers, n_dim, flow, scaler, group=group,
+                         shard_offset=option_dict.get("shard_offset", 0), seed=seed, x_order=x_order)
+        tune = lambda **kw: [setattr(eng, k, v) for k, v in kw.items()]
+    laned = isinstance(eng, LanedEngine)
+    for key in ("host_direct", "rng_prefill", "spin_wait"):
+        if key in option_dict:
+            tune(**{key: bool(option_dict[key])})
     owner = getattr(log_prior, "__self__", None)
     if owner is not None and option_dict.get("device_prior", True) and hasattr(owner, "device_descriptor"):
         eng.set_device_prior(owner)                 # Prior.logpdf of uniform / normal factors on the device
@@ -551,21 +798,41 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
                     geometry.t_mean if tpcn else None, (init[1] if tpcn else init[2]) / n_total)
 
     n_calls = 0
+    pipelined = want_pipe and eng.can_pipeline() and (laned or not sharded)
+    if pipelined and laned:
+        eng.start_pipeline(float(ad.sigma), ad.mu, nu)
+    elif pipelined:
+        # adaptation on the device: the pre-step of step k+1 is enqueued right behind the accept of step k and
+        # runs while the host still waits for / digests the sums of step k (which it needs for the stop rule only)
+        eng.adapt_upload(float(ad.sigma), ad.mu)
+        eng.propose(ad.sigma, nu)
     while True:
         rp = None
         if replay is not None:
             replay.begin_step()
             rp = dict(gamma=replay.std_gamma((n_dim + nu) / 2, n_walkers) if tpcn else None,
                       z=replay.normal(n_walkers, n_dim), u=replay.uniform(n_walkers))
-        eng.propose(ad.sigma, nu, rp)
-        calls, blobs_prime = eng.evaluate(log_prior, log_like, have_blobs, blobs)
+        if pipelined and laned:
+            calls, sums = eng.step_pipelined(beta, nu, ad.coefficients(), n_total, log_prior, log_like,
+                                             more=ad.i + 1 < n_max)
+        elif pipelined:
+            calls, _ = eng.evaluate(log_prior, log_like)
+            eng.accept_enqueue(beta, nu, adapt=ad.coefficients(), n_total=n_total)
+            if ad.i + 1 < n_max:                         # (the last permitted step has no successor)
+                eng.propose(None, nu, step=eng.step_idx + 1)
+            sums = eng.accept_wait()
+        elif laned:
+            calls, sums = eng.step(ad.sigma, nu, beta, log_prior, log_like)
+        else:
+            eng.propose(ad.sigma, nu, rp)
+            calls, blobs_prime = eng.evaluate(log_prior, log_like, have_blobs, blobs)
+            sums = eng.accept_reduce(beta, nu, want_mask=have_blobs or trace is not None)
         n_calls += calls
-        sums = eng.accept_reduce(beta, nu, want_mask=have_blobs or trace is not None)
         if have_blobs:
             mask = eng.h_accept.numpy().astype(bool)
             blobs[mask] = blobs_prime[mask]
         stop = ad.update(sums)
-        if kind == "preconditioned_pcn":
+        if kind == "preconditioned_pcn" and not pipelined:
             eng.set_mu(ad.mu)
         if trace is not None:
             trace.append(dict(alpha=eng.alpha.cpu().numpy(), accept=eng.h_accept.numpy().astype(bool).copy(),
@@ -579,6 +846,12 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
                                            logP=sums[1] / n_total, eff=ad.sigma / (2.38 / np.sqrt(n_dim))))
         if stop:
             break
+    if pipelined:
+        # a pre-step launched ahead of a plateau stop is still in flight; it touches proposal buffers only
+        if laned:
+            eng.finish_pipeline()
+        else:
+            _lib.check(eng.lib.pmc_stream_synchronize(eng._stream), "pmc_stream_synchronize")
 
     out = eng.download()
     return dict(u=out["u"], x=out["x"], logdetj=out["logdetj"], logl=out["logl"], logp=out["logp"], blobs=blobs,

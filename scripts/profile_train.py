@@ -8,8 +8,9 @@ import torch
 from pocomc_amd import Flow, _lib
 from pocomc_amd.train import _train_state
 
-n, D = int(sys.argv[1]) if len(sys.argv) > 1 else 512, 32
-f = Flow(D, "maf3", seed=0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+D = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+f = Flow(D, sys.argv[3] if len(sys.argv) > 3 else "maf3", seed=0)
 ts = _train_state(f)
 ts.repack(f)
 ts.ensure_slabs(n)

@@ -64,11 +64,11 @@ def test_inverse_matches_oracle(D, T, n):
 
 
 @pytest.mark.parametrize("n", [1, 17, 4096, 10000])
-@pytest.mark.parametrize("D,T", [(32, 3), (10, 6), (64, 3)])
-def test_one_and_two_wave_sweeps_agree(D, T, n):
-    """PMC_INVERSE_TRIANGULAR_SOLO (one wavefront per 16 rows) and _DUO (chain + burst wavefront) compute the same
-    sums (the duo kernel adds the hidden-layer partial sums in a different order): agreement to fp32 round-off;
-    AUTO is bit for bit one of the two, chosen by size."""
+@pytest.mark.parametrize("D,T", [(32, 3), (10, 6), (64, 3), (64, 6)])
+def test_one_and_two_wave_sweeps_agree_bit_for_bit(D, T, n):
+    """PMC_INVERSE_TRIANGULAR_SOLO (one wavefront per 16 rows) and _DUO (chain + burst wavefront) add the same
+    terms in the same order: identical x and log-determinant, so what AUTO picks by size (and with it the
+    sharding of the walkers over GPUs or lanes) does not show in the results."""
     f, _ = make(D, T)
     z = torch.randn(n, D, generator=torch.Generator().manual_seed(n))
     out = {}
@@ -76,11 +76,9 @@ def test_one_and_two_wave_sweeps_agree(D, T, n):
         f.inverse_algo = algo
         out[algo] = [t.numpy() for t in f.inverse(z)]
     f.inverse_algo = 0
-    close(out[7][0], out[6][0], 5e-6)
-    close(out[7][1], out[6][1], 5e-6)
-    pick = 7 if n <= 8192 else 6
-    np.testing.assert_array_equal(out[0][0], out[pick][0])
-    np.testing.assert_array_equal(out[0][1], out[pick][1])
+    for a in (7, 0):
+        np.testing.assert_array_equal(out[a][0], out[6][0])
+        np.testing.assert_array_equal(out[a][1], out[6][1])
 
 
 def test_triangular_equals_naive_on_device():

@@ -271,6 +271,133 @@ def test_variates_drawn_ahead_equal_inline_draws():
         assert res[0]["accept"] == res[1]["accept"]
 
 
+@pytest.mark.parametrize("flow_name", ["maf3", "nsf3"])
+@pytest.mark.parametrize("kind", ["preconditioned_pcn", "preconditioned_rwm", "pcn", "rwm"])
+@pytest.mark.parametrize("N,n_max", [(600, 9), (50, 1), (1000, 2)])
+def test_device_side_adaptation_equals_host_side(kind, N, n_max, flow_name):
+    """Pipelined kernel call (sigma / mu adapted by the accept kernel's last block, the pre-step of step k+1
+    enqueued behind the accept of step k) against the plain call that adapts on the host between the steps:
+    same Philox variates, same update expressions -- the only difference is sqrt(1 - sigma^2) on the device
+    against Python's (1 - sigma**2)**0.5 (identical unless pow() is off by an ulp)."""
+    from scipy.stats import uniform
+    import pocomc_amd as pc
+    from pocomc_amd import mcmc as pmcmc
+    from pocomc_amd.geometry import Geometry
+    import torch
+    D = 7
+    prior = pc.Prior([uniform(-5, 10)] * D)
+    rng = np.random.default_rng(N)
+    scaler = pc.Reparameterize(D, bounds=prior.bounds)
+    scaler.fit(prior.rvs(2000))
+    x = rng.uniform(-4, 4, size=(N, D))
+    u = scaler.forward(x)
+    like = lambda xx: (-0.5 * np.sum(xx ** 2, axis=1), None)
+    flow = pc.Flow(D, flow_name, seed=0)
+    geo = Geometry()
+    geo.fit(flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64))
+    geo.normal_cov = np.cov(u.T)
+    res = []
+    for pipe in (False, True):
+        state = dict(u=u.copy(), x=x.copy(), logdetj=scaler.inverse(u)[1], logl=like(x)[0], logp=prior.logpdf(x),
+                     beta=0.5, blobs=None)
+        funcs = dict(loglike=like, logprior=prior.logpdf, scaler=scaler, flow=flow, theta_geometry=geo, u_geometry=geo)
+        opts = dict(n_max=n_max, n_steps=10 ** 6, progress_bar=None, proposal_scale=2.38 / D ** 0.5, seed=11,
+                    x_order="F", pipeline=pipe)
+        res.append(getattr(pmcmc, kind)(state, funcs, opts))
+    a, b = res
+    assert a["calls"] == b["calls"] and a["steps"] == b["steps"] == n_max
+    assert a["proposal_scale"] == b["proposal_scale"] and a["accept"] == b["accept"]
+    same = np.isclose(a["u"], b["u"], rtol=1e-9, atol=1e-12).all(axis=1)
+    assert same.mean() >= 0.995, same.mean()
+    for k in ("x", "logl", "logp", "logdetj"):
+        np.testing.assert_allclose(a[k][same], b[k][same], rtol=1e-8, atol=1e-10, err_msg=k)
+
+
+def test_plateau_stop_with_a_pre_step_in_flight():
+    """The stop rule of mcmc.py:171-180 fires while the next pre-step is already enqueued: the call returns the
+    state of the last accepted step, and a second call on the same inputs gives the same answer."""
+    from scipy.stats import uniform
+    import pocomc_amd as pc
+    from pocomc_amd import mcmc as pmcmc
+    from pocomc_amd.geometry import Geometry
+    import torch
+    D, N = 5, 300
+    prior = pc.Prior([uniform(-5, 10)] * D)
+    rng = np.random.default_rng(3)
+    scaler = pc.Reparameterize(D, bounds=prior.bounds)
+    scaler.fit(prior.rvs(2000))
+    x = rng.normal(size=(N, D)) * 0.3                     # already at the mode: logP stops improving at once
+    u = scaler.forward(x)
+    like = lambda xx: (-0.5 * np.sum(xx ** 2, axis=1), None)
+    flow = pc.Flow(D, "maf3", seed=0)
+    geo = Geometry()
+    geo.fit(flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64))
+    out = []
+    for pipe in (True, True, False):
+        state = dict(u=u.copy(), x=x.copy(), logdetj=scaler.inverse(u)[1], logl=like(x)[0], logp=prior.logpdf(x),
+                     beta=1.0, blobs=None)
+        funcs = dict(loglike=like, logprior=prior.logpdf, scaler=scaler, flow=flow, theta_geometry=geo)
+        opts = dict(n_max=500, n_steps=2, progress_bar=None, proposal_scale=2.38 / D ** 0.5, seed=5, x_order="F",
+                    pipeline=pipe)
+        out.append(pmcmc.preconditioned_pcn(state, funcs, opts))
+    assert 1 < out[0]["steps"] < 500
+    assert out[0]["steps"] == out[1]["steps"] == out[2]["steps"]
+    for k in ("u", "x", "logl"):
+        assert np.array_equal(out[0][k], out[1][k])
+        np.testing.assert_allclose(out[0][k], out[2][k], rtol=1e-8, atol=1e-10)
+    assert np.array_equal(like(out[0]["x"])[0], out[0]["logl"])
+
+
+@pytest.mark.parametrize("x_order", ["C", "F"])
+@pytest.mark.parametrize("kind", ["preconditioned_pcn", "preconditioned_rwm", "pcn", "rwm"])
+@pytest.mark.parametrize("N,lanes", [(600, 2), (1000, 3), (40, 2)])
+def test_laned_kernel_call_equals_the_whole_set_call(kind, N, lanes, x_order):
+    """mcmc.LanedEngine (row ranges of the walkers stepped as a pipeline, device work of one range behind the
+    host likelihood of another) draws the same Philox variates as the whole-set call -- they are keyed on the
+    walker index -- and differs from it only in the order the D+4 sums are added: same trajectory up to the
+    last bits of sigma / mu."""
+    from scipy.stats import uniform
+    import pocomc_amd as pc
+    from pocomc_amd import mcmc as pmcmc
+    from pocomc_amd.geometry import Geometry
+    import torch
+    D = 7
+    prior = pc.Prior([uniform(-5, 10)] * D)
+    rng = np.random.default_rng(N)
+    scaler = pc.Reparameterize(D, bounds=prior.bounds)
+    scaler.fit(prior.rvs(2000))
+    x = rng.uniform(-4, 4, size=(N, D))
+    u = scaler.forward(x)
+    seen = []
+
+    def like(xx):
+        seen.append(len(xx))
+        return -0.5 * np.sum(xx ** 2, axis=1), None
+    flow = pc.Flow(D, "maf3", seed=0)
+    geo = Geometry()
+    geo.fit(flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64))
+    geo.normal_cov = np.cov(u.T)
+    res = []
+    for ln in (1, lanes):
+        state = dict(u=u.copy(), x=x.copy(), logdetj=scaler.inverse(u)[1], logl=like(x)[0], logp=prior.logpdf(x),
+                     beta=0.5, blobs=None)
+        funcs = dict(loglike=like, logprior=prior.logpdf, scaler=scaler, flow=flow, theta_geometry=geo, u_geometry=geo)
+        opts = dict(n_max=6, n_steps=10 ** 6, progress_bar=None, proposal_scale=2.38 / D ** 0.5, seed=11, lanes=ln,
+                    x_order=x_order)
+        del seen[:]
+        res.append(getattr(pmcmc, kind)(state, funcs, opts))
+        assert sum(seen) == res[-1]["calls"]
+        assert len(seen) == 6 * ln                     # one likelihood call per lane and step
+    a, b = res
+    assert a["calls"] == b["calls"] and a["steps"] == b["steps"] == 6
+    np.testing.assert_allclose(a["proposal_scale"], b["proposal_scale"], rtol=1e-12)
+    np.testing.assert_allclose(a["accept"], b["accept"], rtol=1e-12)
+    same = np.isclose(a["u"], b["u"], rtol=1e-9, atol=1e-12).all(axis=1)
+    assert same.mean() >= 0.995, same.mean()
+    for k in ("x", "logl", "logp", "logdetj"):
+        np.testing.assert_allclose(a[k][same], b[k][same], rtol=1e-8, atol=1e-10, err_msg=k)
+
+
 @pytest.mark.parametrize("name", ["tpcn_n256_d10_normal", "tpcn_n128_d6_mixed_bc"])
 def test_likelihoods_with_holes_match_the_oracle(name):
     """Edge cases of mcmc.py:100-134: a likelihood that is -inf on part of the space and NaN on another part

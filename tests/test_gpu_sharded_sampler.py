@@ -75,3 +75,64 @@ def test_two_rank_sampler(tmp_path):
     post = np.linalg.inv(ICOV + np.eye(D) / 25.0)
     assert np.abs(m).max() < 0.25
     assert np.abs(c - post).max() < 0.35
+
+
+def _kernel_case():
+    from scipy.stats import uniform
+    import torch
+    import pocomc_amd as pc
+    from pocomc_amd.geometry import Geometry
+    Dk, N = 6, 640
+    prior = pc.Prior([uniform(-5, 10)] * Dk)
+    rng = np.random.default_rng(12)
+    scaler = pc.Reparameterize(Dk, bounds=prior.bounds)
+    scaler.fit(rng.uniform(-5, 5, size=(2000, Dk)))
+    x = rng.uniform(-4, 4, size=(N, Dk))
+    u = scaler.forward(x)
+    like = lambda xx: (-0.5 * np.sum(xx ** 2, axis=1), None)
+    flow = pc.Flow(Dk, "maf3", seed=0)
+    geo = Geometry()
+    geo.fit(flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64))
+    return prior, scaler, x, u, like, flow, geo
+
+
+def _kernel_call(lo, hi, lanes, group_opts):
+    from pocomc_amd import mcmc as pmcmc
+    prior, scaler, x, u, like, flow, geo = _kernel_case()
+    sl = slice(lo, hi)
+    state = dict(u=u[sl].copy(), x=x[sl].copy(), logdetj=scaler.inverse(u[sl])[1], logl=like(x[sl])[0],
+                 logp=prior.logpdf(x[sl]), beta=0.5, blobs=None)
+    funcs = dict(loglike=like, logprior=prior.logpdf, scaler=scaler, flow=flow, theta_geometry=geo)
+    opts = dict(n_max=6, n_steps=10 ** 6, progress_bar=None, proposal_scale=2.38 / 6 ** 0.5, seed=21, x_order="F",
+                lanes=lanes, **group_opts)
+    return pmcmc.preconditioned_pcn(state, funcs, opts)
+
+
+def _kernel_worker(rank, world, port, out, lanes):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = rank * 320, (rank + 1) * 320
+    r = _kernel_call(lo, hi, lanes, dict(group=None, shard_offset=lo))
+    np.savez(out % rank, u=r["u"], logl=r["logl"], sigma=r["proposal_scale"], accept=r["accept"], steps=r["steps"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_two_rank_pipelined_kernel_call_equals_one_rank(tmp_path, lanes):
+    """Walkers sharded over two ranks, adaptation on the device (lane sums -> all-reduce -> sigma / mu update,
+    the next pre-step enqueued behind it): the same trajectory as the whole set on one rank, up to the order
+    in which the sums are added."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "k%d.npz")
+    mp.spawn(_kernel_worker, args=(2, _free_port(), out, lanes), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    whole = _kernel_call(0, 640, 1, {})
+    assert float(r0["sigma"]) == float(r1["sigma"]) and int(r0["steps"]) == int(r1["steps"]) == whole["steps"] == 6
+    np.testing.assert_allclose(float(r0["sigma"]), whole["proposal_scale"], rtol=1e-12)
+    np.testing.assert_allclose(float(r0["accept"]), whole["accept"], rtol=1e-12)
+    u2 = np.concatenate([r0["u"], r1["u"]])
+    same = np.isclose(u2, whole["u"], rtol=1e-9, atol=1e-12).all(axis=1)
+    assert same.mean() >= 0.995, same.mean()
+    np.testing.assert_allclose(np.concatenate([r0["logl"], r1["logl"]])[same], whole["logl"][same], rtol=1e-8)
