@@ -638,11 +638,17 @@ class LanedEngine:
         import torch.distributed as dist
         sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         lib, D, K = self.lib, self.D, len(self.lanes)
+        tm = self.host_timers
+        clock = time.perf_counter
         calls = 0
         for e in self.lanes:
-            e.host_timers = self.host_timers
+            e.host_timers = tm
             calls += e.evaluate(log_prior, log_like)[0]
+            t0 = clock() if tm is not None else 0.0
             e.accept_enqueue(beta, nu, host_sums=False)
+            if tm is not None:
+                tm["enqueue_accept"] = tm.get("enqueue_accept", 0.0) + clock() - t0
+        t0 = clock() if tm is not None else 0.0
         stream = self.lanes[0]._stream
         mode, c_sigma, c_mu, cap = coefficients
         self._flag_value += 1
@@ -657,10 +663,17 @@ class LanedEngine:
         else:
             _lib.check(lib.pmc_adapt_update(self._parts, K, D, None, self._h_tot.data_ptr(), state, mode, c_sigma, c_mu,
                                             cap, float(n_total), C.byref(done), stream), "pmc_adapt_update")
+        t1 = clock() if tm is not None else 0.0
         if more:
             for e in self.lanes:
                 e.propose(None, nu, step=e.step_idx + 1)
+        t2 = clock() if tm is not None else 0.0
         _lib.check(lib.pmc_wait_flag(self._h_flag.data_ptr(), self._flag_value, 30.0), "pmc_wait_flag")
+        if tm is not None:
+            t3 = clock()
+            tm["enqueue_adapt"] = tm.get("enqueue_adapt", 0.0) + t1 - t0
+            tm["enqueue_next_pre"] = tm.get("enqueue_next_pre", 0.0) + t2 - t1
+            tm["wait_sums"] = tm.get("wait_sums", 0.0) + t3 - t2
         for e in self.lanes:
             e.step_idx += 1
         return calls, self._h_tot.numpy()

@@ -65,7 +65,10 @@ class Sampler:
                  transform="probit", pool=None, pytorch_threads=1, flow="nsf6", train_config=None,
                  train_frequency=None, precondition=True, dynamic=True, metric="ess", n_prior=None,
                  sample="tpcn", n_steps=None, n_max_steps=None, resample="mult", output_dir=None,
-                 output_label=None, random_state=None, n_ess=None, group=None):
+                 output_label=None, random_state=None, n_ess=None, group=None, mcmc_options=None):
+        # ``mcmc_options``: extra keys for the MCMC kernels' option_dict (pocomc_amd/mcmc.py), e.g.
+        # dict(x_order='F') hands the likelihood x as a Fortran-ordered (n, D) array and switches the kernel call to
+        # its pipelined form (adaptation on the device), dict(lanes=2) steps the walkers as two row ranges.
         # sampler.py:186-373; default flow 'nsf6' like the reference (sampler.py:169)
         #
         # ``group`` / an initialised torch.distributed default group with more than one rank: ONE PROCESS PER GPU.
@@ -84,6 +87,7 @@ class Sampler:
             torch.manual_seed(random_state)
         self.random_state = random_state
         self.group = group
+        self.mcmc_options = dict(mcmc_options or {})
         self.world, self.rank = 1, 0
         try:
             import torch.distributed as dist
@@ -299,6 +303,7 @@ class Sampler:
                      u_geometry=self.u_geometry, theta_geometry=self.theta_geometry)
         opts = dict(n_max=self.n_max_steps, n_steps=self.n_steps, progress_bar=self.pbar,
                     proposal_scale=self.proposal_scale)
+        opts.update(self.mcmc_options)
         if self.world > 1:
             opts.update(group=self.group, shard_offset=sl.start)
         kernel = {(True, "tpcn"): _mcmc.preconditioned_pcn, (True, "rwm"): _mcmc.preconditioned_rwm,

@@ -57,8 +57,10 @@ def test_save_load_resume(tmp_path):
     assert np.isfinite(s3.evidence()[0])
 
 
-@pytest.mark.parametrize("sample,precondition", [("tpcn", True), ("rwm", True), ("tpcn", False)])
-def test_gaussian_posterior_and_evidence(sample, precondition):
+@pytest.mark.parametrize("sample,precondition,mcmc_options",
+                         [("tpcn", True, None), ("rwm", True, None), ("tpcn", False, None),
+                          ("tpcn", True, dict(x_order="F")), ("rwm", False, dict(x_order="F", lanes=2))])
+def test_gaussian_posterior_and_evidence(sample, precondition, mcmc_options):
     """6-D Gaussian likelihood N(mu, 0.5^2) inside U(-5,5)^6: logZ = -6 log 10 analytically
     (likelihood normalised), posterior mean mu, std 0.5."""
     import pocomc_amd as pc
@@ -69,7 +71,7 @@ def test_gaussian_posterior_and_evidence(sample, precondition):
         return np.sum(-0.5 * ((x - mu) / sd) ** 2 - np.log(sd) - 0.5 * np.log(2 * np.pi), axis=1)
     s = pc.Sampler(prior=prior, likelihood=loglike, vectorize=True, flow="maf3", sample=sample,
                    precondition=precondition, random_state=1, n_effective=512, n_active=256,
-                   train_config={"epochs": 200})
+                   train_config={"epochs": 200}, mcmc_options=mcmc_options)   # x_order 'F': pipelined kernel calls
     s.run(progress=False, n_total=2048, n_evidence=2048 if precondition else 0)
     x, w, logl, logp = s.posterior()
     m = np.average(x, axis=0, weights=w)
