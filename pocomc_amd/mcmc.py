@@ -346,6 +346,7 @@ class StepEngine:
             self._direct_now = direct and self.spin_wait
             self._step.h_done = self.h_done.data_ptr() if self._direct_now else None
             self._step.done_ticket = self._done_ticket.data_ptr() if self._direct_now else None
+            self._step.ev_pre_done = None if self._direct_now else self._ev_pre     # (the completion word replaces it)
             if self.device_adapt:
                 sigma, cn_a = 0.0, 0.0                      # the kernels read adapt_state instead
             else:

@@ -1,0 +1,70 @@
+"""Summary of the rocprofv3 passes of scripts/collect_profile.sh: per-kernel durations from the kernel trace and the
+mean PMC counters per launch; writes <dir>/../<tag>_traffic.json with the HBM bytes per launch of the step's
+dominant kernel (FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 counts 64-byte fetches in FETCH_SIZE at half weight,
+hence 2 x FETCH_SIZE -- /opt/skills/guides/MI355X_MICROARCH.md, HBM section)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out, tag, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
+short = lambda n: n.split("(")[0][:64] if not n.startswith("void ") else n[5:].split("(")[0][:64]
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(out, pattern), recursive=True)
+    return f[0] if f else None
+
+
+print(f"# {tag}: rocprofv3 on MI355X of `{cmd}`")
+print("# pass 1: --kernel-trace --stats ; passes 2-4: --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_* (separate runs)")
+ks = one("kt/**/*kernel_stats.csv")
+if ks:
+    print("\n## kernel-trace stats")
+    print(f"{'kernel':64s} {'calls':>7s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>7s}")
+    for r in csv.DictReader(open(ks)):
+        print(f"{short(r['Name']):64s} {int(r['Calls']):7d} {float(r['AverageNs']) / 1e3:10.2f} "
+              f"{float(r['MinNs']) / 1e3:10.2f} {float(r['MaxNs']) / 1e3:10.2f} {float(r['Percentage']):7.2f}")
+kt = one("kt/**/*kernel_trace.csv")
+if kt:
+    # the step kernels of the timed region by launch size (lanes launch the same kernel on fewer rows)
+    by = defaultdict(list)
+    for r in csv.DictReader(open(kt)):
+        n = short(r["Kernel_Name"])
+        if any(w in n for w in ("tri4", "tri5", "tri_nsf", "scaler_inverse", "accept_kernel", "rng_fill", "adapt_update")):
+            by[(n, r.get("Grid_Size") or r.get("Grid_Size_X", "?"))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    print("\n## step kernels by launch size (grid = work-items)")
+    print(f"{'kernel':64s} {'grid':>9s} {'calls':>7s} {'avg_us':>10s}")
+    for (n, g), v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+        print(f"{n:64s} {g:>9s} {len(v):7d} {sum(v) / len(v):10.2f}")
+pmc = defaultdict(lambda: defaultdict(list))
+grids = {}
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    f = one(f"{sub}/**/*counter_collection.csv")
+    if not f:
+        continue
+    for r in csv.DictReader(open(f)):
+        key = (short(r["Kernel_Name"]), r.get("Grid_Size", "?"))
+        pmc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("\n## PMC counters, mean per launch (kernel, grid)")
+want = ("tri4", "tri5", "tri_nsf", "scaler_inverse", "accept_kernel", "lossgrad", "forward_wg")
+traffic = None
+for key in sorted(pmc, key=lambda k: -len(pmc[k].get("SQ_WAVE_CYCLES", []))):
+    if not any(w in key[0] for w in want):
+        continue
+    print(f"{key[0]}  grid={key[1]}")
+    m = {c: sum(v) / len(v) for c, v in pmc[key].items()}
+    for c in sorted(m):
+        print(f"    {c:32s} {m[c]:16.1f}   ({len(pmc[key][c])} launches)")
+    if ("tri5" in key[0] or "tri4" in key[0]) and "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+        cand = {"kernel": key[0], "grid": key[1], "launches": len(pmc[key]["FETCH_SIZE"]),
+                "FETCH_SIZE_KB": m["FETCH_SIZE"], "WRITE_SIZE_KB": m["WRITE_SIZE"],
+                "hbm_bytes_per_launch": (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0,
+                "correction": "2x FETCH_SIZE (gfx950), separate --pmc passes",
+                "source": f"profiles/{tag}_summary.txt"}
+        if traffic is None or cand["launches"] > traffic["launches"]:
+            traffic = cand
+if traffic:
+    json.dump(traffic, open(os.path.join(os.path.dirname(out.rstrip('/')), f"{tag}_traffic.json"), "w"), indent=1)
