@@ -95,6 +95,8 @@ typedef struct pmc_maf_train {
     int32_t reserved;
     const float* wsum;        /* NULL: c_n uses the sum of THIS call's weights; else f32 [1] (device) with the sum of
                                * the whole batch's weights, e.g. all-reduced over the ranks of a sharded batch */
+    float* par_scratch;       /* spline flows: [n_slabs][T][nXT][23][256] the hyper-network's output panels kept from the
+                               * forward sweep, or NULL (the backward sweep then multiplies them out again) */
 } pmc_maf_train_t;
 
 /* One minibatch of Flow.fit, pocomc/flow.py:297-323: loss and parameter gradient.

@@ -29,7 +29,8 @@ class pmc_maf_train_t(C.Structure):
                 ("gmap_per_transform", C.c_int64),
                 ("slabs", c_p), ("slab_stride", C.c_int64), ("n_slabs", C.c_int32), ("n_sq_partial", C.c_int32),
                 ("xt_scratch", c_p), ("loss_partial", c_p), ("sq_partial", c_p), ("act_scratch", c_p),
-                ("sched", c_p), ("sched_waves", C.c_int32), ("reserved", C.c_int32), ("wsum", c_p)]
+                ("sched", c_p), ("sched_waves", C.c_int32), ("reserved", C.c_int32), ("wsum", c_p),
+                ("par_scratch", c_p)]
 
 
 class pmc_adamw_t(C.Structure):

@@ -100,15 +100,24 @@ __device__ __forceinline__ void bias_put(float* __restrict__ dst, f32x4 v, int l
     }
 }
 
-// out-layer panel of ranks [16c, 16c+16) of a spline flow: output tiles 23c .. 23c+22 -> P (local tile index)
+// out-layer panel of ranks [16c, 16c+16) of a spline flow: output tiles 23c .. 23c+22 -> P (local tile index).
+// keep != NULL: the panel (23 tiles of 256 floats, one float4 per lane and tile) is also written there for the
+// backward sweep; from != NULL: it is read back from there instead of being multiplied out.
 __device__ __forceinline__ void rqs_panel_train(const pmc_maf_t& m, const MafView& w, const float* H2, float* P, int c,
-                                                int wv, int lane) {
+                                                int wv, int lane, float* keep = nullptr, const float* from = nullptr) {
     const int q = lane >> 4, p = lane & 15;
     for (int i = wv; i < RQS_NOUT; i += TRAIN_WAVES) {
         const int O = RQS_NOUT * c + i;
         if (16 * O >= RQS_NOUT * m.D) continue;              // padding rows: never read
-        f32x4 o = bias4(w.b3, 16 * O + 4 * q);
-        o = mac_range<TRAIN_PF>(o, w.f3 + (size_t)O * m.nT * 64, H2, 0, m.nT, lane);
+        f32x4 o;
+        if (from) {
+            const float4 v = reinterpret_cast<const float4*>(from)[i * 64 + lane];
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        } else {
+            o = bias4(w.b3, 16 * O + 4 * q);
+            o = mac_range<TRAIN_PF>(o, w.f3 + (size_t)O * m.nT * 64, H2, 0, m.nT, lane);
+            if (keep) reinterpret_cast<float4*>(keep)[i * 64 + lane] = make_float4(o[0], o[1], o[2], o[3]);
+        }
         store_rows(P, i, q, p, o);
     }
 }
@@ -146,6 +155,7 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
     // hidden activations of every transform, kept from the forward sweep (the backward sweep then loads them
     // instead of recomputing three layers); NULL: recompute
     float* act = tr.act_scratch ? tr.act_scratch + (size_t)blockIdx.x * T * 3 * Hp * 16 : nullptr;
+    float* par = (UNI == 1 && tr.par_scratch) ? tr.par_scratch + (size_t)blockIdx.x * T * m.nXT * RQS_NOUT * 256 : nullptr;
 
     // sum of the batch weights, the same fixed-order sum in every workgroup (flow.py:311)
     float wscale = 1.0f;
@@ -240,7 +250,8 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                 }
             } else {
                 for (int c = 0; c < nXT; ++c) {
-                    rqs_panel_train(m, wvw, Cb, P, c, wv, lane);
+                    rqs_panel_train(m, wvw, Cb, P, c, wv, lane,
+                                    par ? par + ((size_t)t * nXT + c) * RQS_NOUT * 256 : nullptr);
                     lds_barrier();
                     for (int e = tid; e < 256; e += TRAIN_THREADS) {
                         const int rr = e >> 4, pp = e & 15, rank = 16 * c + rr;
@@ -367,7 +378,8 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                 for (int c = 0; c < nXT; ++c) {
                     const int O0 = RQS_NOUT * c;                         // first output tile of the panel
                     const int nO = min(RQS_NOUT, nOeff - O0);            // its tiles with real rows
-                    rqs_panel_train(m, wvw, Cb, P, c, wv, lane);
+                    rqs_panel_train(m, wvw, Cb, P, c, wv, lane, nullptr,
+                                    par ? par + ((size_t)t * nXT + c) * RQS_NOUT * 256 : nullptr);
                     PHASE_END(4)
                     // spline backward in place: P -> dP, G -> direct dL/dx term
                     for (int e = tid; e < 256; e += TRAIN_THREADS) {
@@ -392,10 +404,22 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                     }
                     for (int i = wv; i < nO; i += TRAIN_WAVES)
                         bias_put(slab + tv.gb3 + 16 * (O0 + i) + 4 * q, rows_of(P, i, q, p), lane, first);
-                    for (int i = wv, Ol = 0, K = wv; i < nO * nT; i += TRAIN_WAVES, K += TRAIN_WAVES) {
-                        while (K >= nT) { K -= nT; ++Ol; }
-                        slab_put4(slab + tv.g3 + (((size_t)(O0 + Ol) * nT + K) * 64 + lane) * 4,
-                                  outer_tile(P, Ol, Cb, K, lane), first);
+                    {
+                        // dW3 tiles (Ol, K) of the panel.  The waves wv < nT just multiplied a whole tile of E (nO K
+                        // steps each): with fewer hidden tiles than waves they take only qh weight-gradient tiles
+                        // (a tile costs about two K steps), the free waves share the rest.
+                        const int n_light = nO * nT;
+                        int first_i = wv, stride = TRAIN_WAVES, last_i = n_light;
+                        if (nT < TRAIN_WAVES) {
+                            const int qh = max(0, ((nT * nO + 2 * n_light) / TRAIN_WAVES - nO) / 2);
+                            if (wv < nT) { stride = nT; last_i = min(n_light, nT * qh); }
+                            else { first_i = nT * qh + (wv - nT); stride = TRAIN_WAVES - nT; }
+                        }
+                        for (int i = first_i; i < last_i; i += stride) {
+                            const int Ol = i / nT, K = i - Ol * nT;
+                            slab_put4(slab + tv.g3 + (((size_t)(O0 + Ol) * nT + K) * 64 + lane) * 4,
+                                      outer_tile(P, Ol, Cb, K, lane), first);
+                        }
                     }
                     PHASE_END(6)
                 }

@@ -46,6 +46,7 @@ class TrainState:
         self.n_slabs = 0
         self.xt_floats = (spec.n_transforms + 1) * spec.Dp * 16
         self.act_floats = spec.n_transforms * 3 * spec.Hp * 16
+        self.par_floats = spec.n_transforms * spec.nXT * 23 * 256 if spec.univariate == "rqs" else 0
         n = spec.n_params
         # masked entries stay 0 for ever; one extra element carries the batch loss through the
         # gradient all-reduce of sharded training
@@ -63,11 +64,13 @@ class TrainState:
         self.slabs = torch.empty(need * self.g_total, dtype=torch.float32, device=dev)
         self.xt_scratch = torch.empty(need * self.xt_floats, dtype=torch.float32, device=dev)
         self.act_scratch = torch.empty(need * self.act_floats, dtype=torch.float32, device=dev)
+        self.par_scratch = torch.empty(max(1, need * self.par_floats), dtype=torch.float32, device=dev)
         self.loss_partial = torch.zeros(need, dtype=torch.float32, device=dev)
         self.n_slabs = need
         self.desc.slabs = self.slabs.data_ptr()
         self.desc.xt_scratch = self.xt_scratch.data_ptr()
         self.desc.act_scratch = self.act_scratch.data_ptr()
+        self.desc.par_scratch = self.par_scratch.data_ptr() if self.par_floats else None
         self.desc.loss_partial = self.loss_partial.data_ptr()
         self.desc.n_slabs = need
 
