@@ -418,14 +418,15 @@ def main():
                        args.inverse, ("maf_inverse_tri5_kernel" if n_launch <= 8192 else "maf_inverse_tri4_kernel")
                        if spec.nOT <= 8 else "maf_inverse_tri2_kernel"))
     # HBM bytes per launch of the dominant kernel: PMC passes cannot run inside this process, the value
-    # is the committed rocprofv3 measurement of this very command (profiles/r01_c_rocprof_summary.txt)
+    # is the committed rocprofv3 measurement of this very command (scripts/collect_profile.sh -> profiles/r01_f_*)
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_f_traffic.json")))
         if (n == 10000 and D == 32 and args.inverse == "auto" and args.flow == "maf3"
                 and pm.get("kernel", "").startswith(roof_kernel) and pm.get("walkers_per_launch", 10000) == n_launch):
             traffic = {"hbm_bytes_per_launch": pm["hbm_bytes_per_launch"], "unit": "B", "source": pm["source"],
-                       "correction": pm["correction"]}
+                       "correction": pm["correction"], "algorithmic_bytes": pm.get("algorithmic_bytes", {}).get("total"),
+                       "note": pm.get("note")}
     except (OSError, KeyError, ValueError):
         pass
     achieved = algo_flops / t_inv / 1e12

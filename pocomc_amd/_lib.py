@@ -159,6 +159,14 @@ def load():
         raise PocomcAmdError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  pocomc_amd has no CPU fallback.")
+    # torch's HIP runtime first: a process that loads this library (its fat binaries register with the runtime at
+    # load time) before torch has initialised the device ends up with "no ROCm-capable device" at the first launch
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)            # AttributeError if the library lacks a declared symbol
