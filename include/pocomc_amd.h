@@ -106,6 +106,8 @@ typedef struct pmc_maf_train {
  * grad f32 [n_params] in the canonical layout is OVERWRITTEN at every unmasked entry (masked
  * entries are never touched: allocate it zeroed); loss f32 [1] is ACCUMULATED.
  * tr->sq_partial receives the per-block sums of squares that pmc_maf_train_epoch clips with. */
+/* Wavefronts per training workgroup for this flow: the n_waves pmc_maf_train_t.sched must be built for. */
+int pmc_maf_train_waves(const pmc_maf_t* m);
 int pmc_maf_loss_grad(const pmc_maf_t* m, const pmc_maf_train_t* tr, const float* x, const float* w,
                       const int64_t* idx, float wmul, float* grad, float* loss, int64_t n, void* stream);
 

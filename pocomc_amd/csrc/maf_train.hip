@@ -5,7 +5,7 @@
 //                                          c_n = w_n * 1000 / sum(w_batch) (flow.py:311-312)
 //
 // A minibatch is at most 512 rows (sampler.py:289), so the step is latency bound, not throughput
-// bound.  One WORKGROUP of TRAIN_WAVES (16) wavefronts owns 16 rows: the tiles of every layer are dealt to the
+// bound.  One WORKGROUP of TRAIN_WAVES (16; 8 for narrow spline flows) wavefronts owns 16 rows: the tiles of every layer are dealt to the
 // waves (cost-balanced over the triangular layers), the activations sit in workgroup LDS in
 // the MFMA operand layout of the inference kernels, and a barrier separates dependent layers.
 // Forward stores the input and the three hidden activations of every transform in a global scratch
@@ -39,9 +39,17 @@
 #define TRAIN_WARM_L2 0      // measured neutral on MI355X (the phases are not L2-miss bound)
 #endif
 #ifndef TRAIN_WAVES
-#define TRAIN_WAVES 16
+#define TRAIN_WAVES 16              // waves of a training workgroup ...
 #endif
-#define TRAIN_THREADS (64 * TRAIN_WAVES)
+// ... except for narrow spline flows (hidden width <= 64): their layers have fewer tiles than that many waves, the
+// spline evaluation runs on four waves either way, and a barrier over 8 waves is cheaper -- measured on MI355X per
+// 256-row batch: nsf6 D=4 142 -> 113 us, D=10 157 -> 135 us, D=20 272 -> 243 us (D=32, H=128: 227 -> 256 us, so not
+// there; the affine flows do not care).  With half the waves a wave has 256 registers: 8 fragments in flight.
+#define TRAIN_WAVES_NARROW 8
+#define TRAIN_PF_NARROW 8
+static int train_waves_of(const pmc_maf_t& m) {
+    return (m.n_out == RQS_NOUT && m.nT <= 6) ? TRAIN_WAVES_NARROW : TRAIN_WAVES;     // hidden width <= 64
+}
 
 struct TrainView {
     const float4* f0T; const float4* f1T; const float4* f2T; const float4* f3T;
@@ -103,10 +111,11 @@ __device__ __forceinline__ void bias_put(float* __restrict__ dst, f32x4 v, int l
 // out-layer panel of ranks [16c, 16c+16) of a spline flow: output tiles 23c .. 23c+22 -> P (local tile index).
 // keep != NULL: the panel (23 tiles of 256 floats, one float4 per lane and tile) is also written there for the
 // backward sweep; from != NULL: it is read back from there instead of being multiplied out.
+template <int NW, int PF>
 __device__ __forceinline__ void rqs_panel_train(const pmc_maf_t& m, const MafView& w, const float* H2, float* P, int c,
                                                 int wv, int lane, float* keep = nullptr, const float* from = nullptr) {
     const int q = lane >> 4, p = lane & 15;
-    for (int i = wv; i < RQS_NOUT; i += TRAIN_WAVES) {
+    for (int i = wv; i < RQS_NOUT; i += NW) {
         const int O = RQS_NOUT * c + i;
         if (16 * O >= RQS_NOUT * m.D) continue;              // padding rows: never read
         f32x4 o;
@@ -115,7 +124,7 @@ __device__ __forceinline__ void rqs_panel_train(const pmc_maf_t& m, const MafVie
             o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
         } else {
             o = bias4(w.b3, 16 * O + 4 * q);
-            o = mac_range<TRAIN_PF>(o, w.f3 + (size_t)O * m.nT * 64, H2, 0, m.nT, lane);
+            o = mac_range<PF>(o, w.f3 + (size_t)O * m.nT * 64, H2, 0, m.nT, lane);
             if (keep) reinterpret_cast<float4*>(keep)[i * 64 + lane] = make_float4(o[0], o[1], o[2], o[3]);
         }
         store_rows(P, i, q, p, o);
@@ -123,8 +132,8 @@ __device__ __forceinline__ void rqs_panel_train(const pmc_maf_t& m, const MafVie
 }
 
 // UNI 0: affine univariate (MAF), 2 outputs per feature.  UNI 1: 8-bin spline (NSF), 23 outputs.
-template <bool PROF, int UNI>
-__global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m, pmc_maf_train_t tr,
+template <int NW, int PF, bool PROF, int UNI>
+__global__ __launch_bounds__(64 * NW) void maf_lossgrad_kernel(pmc_maf_t m, pmc_maf_train_t tr,
                                                                      const float* __restrict__ x,
                                                                      const float* __restrict__ w,
                                                                      const int64_t* __restrict__ idx, float wmul,
@@ -146,8 +155,8 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
     float* P = E + Hp * 16;                   // [Psz]
     float* Gb = P + Psz;                      // [Dp*16]
     float* CC = Gb + Dp * 16;                 // [16] per-row loss coefficient
-    float* RED = CC + 16;                     // [16 * TRAIN_WAVES]
-    float* XB = RED + 16 * TRAIN_WAVES;       // UNI 1: [Dp*16] the transform's input during its backward sweep
+    float* RED = CC + 16;                     // [16 * NW]
+    float* XB = RED + 16 * NW;       // UNI 1: [Dp*16] the transform's input during its backward sweep
     const int* feat_of_rank = m.meta + 8;
     const int* rank_of_feat = m.meta + 8 + T * D;
     float* slab = tr.slabs + (size_t)blockIdx.x * tr.slab_stride;
@@ -163,12 +172,12 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
         wscale = wmul / *tr.wsum;
     } else if (w) {
         float s = 0.0f;
-        for (int64_t i = tid; i < n; i += TRAIN_THREADS) s += w[idx ? idx[i] : i];
+        for (int64_t i = tid; i < n; i += (64 * NW)) s += w[idx ? idx[i] : i];
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0) RED[wv] = s;
         __syncthreads();
         float tot = 0.0f;
-        for (int k = 0; k < TRAIN_WAVES; ++k) tot += RED[k];
+        for (int k = 0; k < NW; ++k) tot += RED[k];
         wscale = wmul / tot;
         __syncthreads();
     }
@@ -182,15 +191,15 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
         const int per_xcd = max(1, (int)((gridDim.x + 7) >> 3));
         const int share = min((int)(blockIdx.x >> 3), per_xcd - 1);
         const int64_t lines_a = ((int64_t)T * m.pk_per_transform * 4) >> 7, lines_b = ((int64_t)T * tr.pkT_per_transform * 4) >> 7;
-        for (int64_t l = (int64_t)share * TRAIN_THREADS + tid; l < lines_a + lines_b; l += (int64_t)per_xcd * TRAIN_THREADS)
+        for (int64_t l = (int64_t)share * (64 * NW) + tid; l < lines_a + lines_b; l += (int64_t)per_xcd * (64 * NW))
             warm += (l < lines_a) ? m.packed[l << 5] : tr.packedT[(l - lines_a) << 5];
     }
 
     // contiguous ranges of weight-gradient tiles per phase (layer 3 | layers 2,1 | layer 0), balanced on the host
     // against the data-gradient tiles the dealing rules give each wave (MAFSpec.train_schedule)
-    const int dw3_start = tr.sched[(0 * TRAIN_WAVES + wv) * 2], dw3_count = tr.sched[(0 * TRAIN_WAVES + wv) * 2 + 1];
-    const int dwt_start = tr.sched[(1 * TRAIN_WAVES + wv) * 2], dwt_count = tr.sched[(1 * TRAIN_WAVES + wv) * 2 + 1];
-    const int dw0_start = tr.sched[(2 * TRAIN_WAVES + wv) * 2], dw0_count = tr.sched[(2 * TRAIN_WAVES + wv) * 2 + 1];
+    const int dw3_start = tr.sched[(0 * NW + wv) * 2], dw3_count = tr.sched[(0 * NW + wv) * 2 + 1];
+    const int dwt_start = tr.sched[(1 * NW + wv) * 2], dwt_count = tr.sched[(1 * NW + wv) * 2 + 1];
+    const int dw0_start = tr.sched[(2 * NW + wv) * 2], dw0_count = tr.sched[(2 * NW + wv) * 2 + 1];
 
     float loss_acc = 0.0f;
     bool first = true;
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
         }
         float* Xc = E;
         float* Xn = Gb;
-        for (int e = tid; e < Dp * 16; e += TRAIN_THREADS) {
+        for (int e = tid; e < Dp * 16; e += (64 * NW)) {
             const int r = e >> 4, pp = e & 15;
             float v = 0.0f;
             if (r < D && row0 + pp < n) {
@@ -224,16 +233,16 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
         for (int t = 0; t < T; ++t) {
             const MafView wvw = maf_view(m, t);
             float* xtn = xt + (size_t)(t + 1) * Dp * 16;
-            hidden_pass_wg<TRAIN_WAVES, TRAIN_PF, PROF>(m, wvw, Xc, A, B, Cb, wv, lane, pacc, tk);
+            hidden_pass_wg<NW, PF, PROF>(m, wvw, Xc, A, B, Cb, wv, lane, pacc, tk);
             if (act) {                                       // A, B, Cb are contiguous in LDS: one copy
                 float4* dst = reinterpret_cast<float4*>(act + (size_t)t * 3 * Hp * 16);
-                for (int e = tid; e < 3 * Hp * 4; e += TRAIN_THREADS) dst[e] = reinterpret_cast<const float4*>(A)[e];
+                for (int e = tid; e < 3 * Hp * 4; e += (64 * NW)) dst[e] = reinterpret_cast<const float4*>(A)[e];
             }
             LAPT(2)
             if (UNI == 0) {
-                for (int O = wv; O < nOeff; O += TRAIN_WAVES) {
+                for (int O = wv; O < nOeff; O += NW) {
                     f32x4 o = bias4(wvw.b3, 16 * O + 4 * q);
-                    o = mac_range<TRAIN_PF>(o, wvw.f3 + (size_t)O * nT * 64, Cb, 0, nT, lane);
+                    o = mac_range<PF>(o, wvw.f3 + (size_t)O * nT * 64, Cb, 0, nT, lane);
                     for (int s = 0; s < 2; ++s) {
                         const int rank = 8 * O + 2 * q + s;
                         if (rank < D) {
@@ -250,10 +259,10 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                 }
             } else {
                 for (int c = 0; c < nXT; ++c) {
-                    rqs_panel_train(m, wvw, Cb, P, c, wv, lane,
+                    rqs_panel_train<NW, PF>(m, wvw, Cb, P, c, wv, lane,
                                     par ? par + ((size_t)t * nXT + c) * RQS_NOUT * 256 : nullptr);
                     lds_barrier();
-                    for (int e = tid; e < 256; e += TRAIN_THREADS) {
+                    for (int e = tid; e < 256; e += (64 * NW)) {
                         const int rr = e >> 4, pp = e & 15, rank = 16 * c + rr;
                         if (rank < D) {
                             float phi[RQS_NOUT];
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                     lds_barrier();
                 }
             }
-            for (int e = tid; e < (Dp - D) * 16; e += TRAIN_THREADS) {
+            for (int e = tid; e < (Dp - D) * 16; e += (64 * NW)) {
                 Xn[lidx(D + (e >> 4), e & 15)] = 0.0f;
                 xtn[lidx(D + (e >> 4), e & 15)] = 0.0f;
             }
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                 for (int r = q; r < D; r += 4) { const float z = Z[lidx(r, p)]; ss += z * z; }
                 ss = quad_sum(ss);
                 float lt = 0.0f;
-                for (int k = 0; k < TRAIN_WAVES; ++k) lt += RED[16 * k + p];
+                for (int k = 0; k < NW; ++k) lt += RED[16 * k + p];
                 float term = 0.0f;
                 if (row0 + p < n) term = -CC[p] * ((-0.5f * ss - 0.9189385332046727f * (float)D) + lt);
                 term += __shfl_xor(term, 1); term += __shfl_xor(term, 2);
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
             }
             __syncthreads();                             // Z may be Gb itself: finish reading it first
             // dL/dz = c * z
-            for (int e = tid; e < Dp * 16; e += TRAIN_THREADS) {
+            for (int e = tid; e < Dp * 16; e += (64 * NW)) {
                 const int r = e >> 4, pp = e & 15;
                 Gb[lidx(r, pp)] = (r < D) ? CC[pp] * Z[lidx(r, pp)] : 0.0f;
             }
@@ -310,25 +319,25 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
             const TrainView tv = train_view(m, tr, t);
             const float4* xsrc = reinterpret_cast<const float4*>(xt + (size_t)t * Dp * 16);
             if (UNI == 0) {
-                for (int e = tid; e < Dp * 4; e += TRAIN_THREADS) reinterpret_cast<float4*>(E)[e] = xsrc[e];
+                for (int e = tid; e < Dp * 4; e += (64 * NW)) reinterpret_cast<float4*>(E)[e] = xsrc[e];
                 if (act) {
                     const float4* src = reinterpret_cast<const float4*>(act + (size_t)t * 3 * Hp * 16);
-                    for (int e = tid; e < 3 * Hp * 4; e += TRAIN_THREADS) reinterpret_cast<float4*>(A)[e] = src[e];
+                    for (int e = tid; e < 3 * Hp * 4; e += (64 * NW)) reinterpret_cast<float4*>(A)[e] = src[e];
                     lds_barrier();
                 } else {
                     lds_barrier();
                     // recompute this transform's activations
-                    hidden_pass_wg<TRAIN_WAVES, TRAIN_PF, PROF>(m, wvw, E, A, B, Cb, wv, lane, pacc, tk);
+                    hidden_pass_wg<NW, PF, PROF>(m, wvw, E, A, B, Cb, wv, lane, pacc, tk);
                 }
                 // (shift, raw) of the transform
-                for (int O = wv; O < nOeff; O += TRAIN_WAVES) {
+                for (int O = wv; O < nOeff; O += NW) {
                     f32x4 o = bias4(wvw.b3, 16 * O + 4 * q);
-                    o = mac_range<TRAIN_PF>(o, wvw.f3 + (size_t)O * nT * 64, Cb, 0, nT, lane);
+                    o = mac_range<PF>(o, wvw.f3 + (size_t)O * nT * 64, Cb, 0, nT, lane);
                     store_rows(P, O, q, p, o);
                 }
                 PHASE_END(4)
                 // element-wise part: y = x e^{ls} + shift,  L += -c * sum ls   (in place: P -> dP, G -> direct dx)
-                for (int e = tid; e < Dp * 16; e += TRAIN_THREADS) {
+                for (int e = tid; e < Dp * 16; e += (64 * NW)) {
                     const int r = e >> 4, pp = e & 15;
                     float gs = 0.0f, gr = 0.0f, gx = 0.0f;
                     if (r < D) {
@@ -347,14 +356,14 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                 }
                 PHASE_END(5)
                 // ---- layer 3: da2 = relu'(h2) . W3^T dP -> E ; dW3, db3, db2
-                for (int K = wv; K < nT; K += TRAIN_WAVES) {
+                for (int K = wv; K < nT; K += NW) {
                     f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                    a = mac_range<TRAIN_PF>(a, tv.f3T + (size_t)K * nOT * 64, P, 0, nOeff, lane);
+                    a = mac_range<PF>(a, tv.f3T + (size_t)K * nOT * 64, P, 0, nOeff, lane);
                     a = relu_gate(a, Cb, K, q, p);
                     store_rows(E, K, q, p, a);
                     bias_put(slab + tv.gb2 + 16 * K + 4 * q, a, lane, first);
                 }
-                for (int O = wv; O < nOeff; O += TRAIN_WAVES)
+                for (int O = wv; O < nOeff; O += NW)
                     bias_put(slab + tv.gb3 + 16 * O + 4 * q, rows_of(P, O, q, p), lane, first);
                 for (int i = dw3_start, O = 0, K = dw3_start; i < dw3_start + dw3_count; ++i, ++K) {
                     while (K >= nT) { K -= nT; ++O; }              // (O, K) of tile i without a division
@@ -363,26 +372,26 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                 PHASE_END(6)
             } else {
                 // x_t -> XB (kept for the whole spline sweep), E <- 0 (accumulates W3^T dP over the panels)
-                for (int e = tid; e < Dp * 4; e += TRAIN_THREADS) reinterpret_cast<float4*>(XB)[e] = xsrc[e];
-                for (int e = tid; e < Hp * 4; e += TRAIN_THREADS)
+                for (int e = tid; e < Dp * 4; e += (64 * NW)) reinterpret_cast<float4*>(XB)[e] = xsrc[e];
+                for (int e = tid; e < Hp * 4; e += (64 * NW))
                     reinterpret_cast<float4*>(E)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (act) {
                     const float4* src = reinterpret_cast<const float4*>(act + (size_t)t * 3 * Hp * 16);
-                    for (int e = tid; e < 3 * Hp * 4; e += TRAIN_THREADS) reinterpret_cast<float4*>(A)[e] = src[e];
+                    for (int e = tid; e < 3 * Hp * 4; e += (64 * NW)) reinterpret_cast<float4*>(A)[e] = src[e];
                     lds_barrier();
                 } else {
                     lds_barrier();
-                    hidden_pass_wg<TRAIN_WAVES, TRAIN_PF, PROF>(m, wvw, XB, A, B, Cb, wv, lane, pacc, tk);
+                    hidden_pass_wg<NW, PF, PROF>(m, wvw, XB, A, B, Cb, wv, lane, pacc, tk);
                 }
                 LAPT(4)
                 for (int c = 0; c < nXT; ++c) {
                     const int O0 = RQS_NOUT * c;                         // first output tile of the panel
                     const int nO = min(RQS_NOUT, nOeff - O0);            // its tiles with real rows
-                    rqs_panel_train(m, wvw, Cb, P, c, wv, lane, nullptr,
+                    rqs_panel_train<NW, PF>(m, wvw, Cb, P, c, wv, lane, nullptr,
                                     par ? par + ((size_t)t * nXT + c) * RQS_NOUT * 256 : nullptr);
                     PHASE_END(4)
                     // spline backward in place: P -> dP, G -> direct dL/dx term
-                    for (int e = tid; e < 256; e += TRAIN_THREADS) {
+                    for (int e = tid; e < 256; e += (64 * NW)) {
                         const int rr = e >> 4, pp = e & 15, rank = 16 * c + rr;
                         if (rank < D) {
                             float phi[RQS_NOUT], dphi[RQS_NOUT];
@@ -397,23 +406,23 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                     }
                     PHASE_END(5)
                     // W3^T dP of this panel into E (every wave owns whole tiles of E), db3, dW3
-                    for (int K = wv; K < nT; K += TRAIN_WAVES) {
+                    for (int K = wv; K < nT; K += NW) {
                         f32x4 a = rows_of(E, K, q, p);
-                        a = mac_range<TRAIN_PF>(a, tv.f3T + ((size_t)K * nOT + O0) * 64, P, 0, nO, lane);
+                        a = mac_range<PF>(a, tv.f3T + ((size_t)K * nOT + O0) * 64, P, 0, nO, lane);
                         store_rows(E, K, q, p, a);
                     }
-                    for (int i = wv; i < nO; i += TRAIN_WAVES)
+                    for (int i = wv; i < nO; i += NW)
                         bias_put(slab + tv.gb3 + 16 * (O0 + i) + 4 * q, rows_of(P, i, q, p), lane, first);
                     {
                         // dW3 tiles (Ol, K) of the panel.  The waves wv < nT just multiplied a whole tile of E (nO K
                         // steps each): with fewer hidden tiles than waves they take only qh weight-gradient tiles
                         // (a tile costs about two K steps), the free waves share the rest.
                         const int n_light = nO * nT;
-                        int first_i = wv, stride = TRAIN_WAVES, last_i = n_light;
-                        if (nT < TRAIN_WAVES) {
-                            const int qh = max(0, ((nT * nO + 2 * n_light) / TRAIN_WAVES - nO) / 2);
+                        int first_i = wv, stride = NW, last_i = n_light;
+                        if (nT < NW) {
+                            const int qh = max(0, ((nT * nO + 2 * n_light) / NW - nO) / 2);
                             if (wv < nT) { stride = nT; last_i = min(n_light, nT * qh); }
-                            else { first_i = nT * qh + (wv - nT); stride = TRAIN_WAVES - nT; }
+                            else { first_i = nT * qh + (wv - nT); stride = NW - nT; }
                         }
                         for (int i = first_i; i < last_i; i += stride) {
                             const int Ol = i / nT, K = i - Ol * nT;
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
                     PHASE_END(6)
                 }
                 // da2 = relu'(h2) . (W3^T dP), db2
-                for (int K = wv; K < nT; K += TRAIN_WAVES) {
+                for (int K = wv; K < nT; K += NW) {
                     f32x4 a = relu_gate(rows_of(E, K, q, p), Cb, K, q, p);
                     store_rows(E, K, q, p, a);
                     bias_put(slab + tv.gb2 + 16 * K + 4 * q, a, lane, first);
@@ -433,10 +442,10 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
             }
             // ---- layer 2: da1 = relu'(h1) . (da2 + W2^T da2) -> C ; dW2 (da2 x h1), db1
             for (int it = 0;; ++it) {                              // the tiles this wave owns, most expensive first
-                const int Ti = snake_item<TRAIN_WAVES>(wv, it);
+                const int Ti = snake_item<NW>(wv, it);
                 if (Ti >= nT) break;
                 f32x4 a = rows_of(E, Ti, q, p);
-                a = mac_range<TRAIN_PF>(a, tv.f2T + (size_t)Ti * nT * 64, E, (m.tri_ok ? Ti : 0), nT, lane);
+                a = mac_range<PF>(a, tv.f2T + (size_t)Ti * nT * 64, E, (m.tri_ok ? Ti : 0), nT, lane);
                 a = relu_gate(a, B, Ti, q, p);
                 store_rows(Cb, Ti, q, p, a);
                 bias_put(slab + tv.gb1 + 16 * Ti + 4 * q, a, lane, first);
@@ -453,15 +462,15 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
             PHASE_END(7)
             // ---- layer 1: da0 = relu'(h0) . (da1 + W1^T da1) -> E ; dW1 (da1 x h0), db0 ; x_t -> B
             for (int it = 0;; ++it) {
-                const int Ti = snake_item<TRAIN_WAVES>(wv, it);
+                const int Ti = snake_item<NW>(wv, it);
                 if (Ti >= nT) break;
                 f32x4 a = rows_of(Cb, Ti, q, p);
-                a = mac_range<TRAIN_PF>(a, tv.f1T + (size_t)Ti * nT * 64, Cb, (m.tri_ok ? Ti : 0), nT, lane);
+                a = mac_range<PF>(a, tv.f1T + (size_t)Ti * nT * 64, Cb, (m.tri_ok ? Ti : 0), nT, lane);
                 a = relu_gate(a, A, Ti, q, p);
                 store_rows(E, Ti, q, p, a);
                 bias_put(slab + tv.gb0 + 16 * Ti + 4 * q, a, lane, first);
             }
-            for (int e = tid; e < Dp * 4; e += TRAIN_THREADS) reinterpret_cast<float4*>(B)[e] = xsrc[e];
+            for (int e = tid; e < Dp * 4; e += (64 * NW)) reinterpret_cast<float4*>(B)[e] = xsrc[e];
             {   // weight-gradient tiles (To, Ti <= To) in row-major order: this wave's contiguous range
                 int To = 0, Ti = dwt_start;
                 for (int i = 0; i < dwt_count; ++i, ++Ti) {
@@ -474,9 +483,9 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
             PHASE_END(8)
             // ---- layer 0: dW0 (da0 x x), dx = direct + W0^T da0 -> P
             if (t > 0) {
-                for (int Xi = wv; Xi < nXT; Xi += TRAIN_WAVES) {
+                for (int Xi = wv; Xi < nXT; Xi += NW) {
                     f32x4 a = rows_of(Gb, Xi, q, p);
-                    a = mac_range<TRAIN_PF>(a, tv.f0T + (size_t)Xi * nT * 64, E, 0, nT, lane);
+                    a = mac_range<PF>(a, tv.f0T + (size_t)Xi * nT * 64, E, 0, nT, lane);
                     store_rows(P, Xi, q, p, a);
                 }
             }
@@ -490,7 +499,7 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
             PHASE_END(9)
             if (t > 0) {
                 // re-rank for transform t-1 (its output order)
-                for (int e = tid; e < Dp * 16; e += TRAIN_THREADS) {
+                for (int e = tid; e < Dp * 16; e += (64 * NW)) {
                     const int r = e >> 4, pp = e & 15;
                     if (r < D) Gb[lidx(rank_of_feat[(t - 1) * D + feat_of_rank[t * D + r]], pp)] = P[lidx(r, pp)];
                 }
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(TRAIN_THREADS) void maf_lossgrad_kernel(pmc_maf_t m
     if (tid == 0) tr.loss_partial[blockIdx.x] = loss_acc;
     if (PROF && lane == 0) {
         pacc[0] = TICKT() - t_begin;
-        long long* o = prof + ((size_t)blockIdx.x * TRAIN_WAVES + wv) * 16;
+        long long* o = prof + ((size_t)blockIdx.x * NW + wv) * 16;
         for (int i = 0; i < 16; ++i) o[i] = pacc[i];
     }
 }
@@ -657,12 +666,12 @@ __global__ __launch_bounds__(256) void pack2_kernel(const float* __restrict__ fl
 static size_t train_lds_bytes(const pmc_maf_t& m) {
     if (m.n_out == RQS_NOUT)
         return (size_t)(4 * m.Hp * 16 + RQS_NOUT * 256 + 2 * m.Dp * 16 + 16 + 16 * TRAIN_WAVES) * sizeof(float);
-    return (size_t)(4 * m.Hp * 16 + 2 * m.Dp * 16 + m.Dp * 16 + 16 + 16 * TRAIN_WAVES) * sizeof(float);
+    return (size_t)(4 * m.Hp * 16 + 2 * m.Dp * 16 + m.Dp * 16 + 16 + 16 * TRAIN_WAVES) * sizeof(float);   // (sized for 16 waves)
 }
 
 static int train_check(const pmc_maf_t* m, const pmc_maf_train_t* tr, const char* who) {
     if (!m || !tr || !tr->packedT || !tr->gmap || !tr->slabs || !tr->xt_scratch || !tr->loss_partial ||
-        !tr->sq_partial || !tr->sched || tr->sched_waves != TRAIN_WAVES || tr->n_slabs < 1 || tr->slab_stride < (int64_t)m->T * tr->gmap_per_transform ||
+        !tr->sq_partial || !tr->sched || tr->sched_waves != train_waves_of(*m) || tr->n_slabs < 1 || tr->slab_stride < (int64_t)m->T * tr->gmap_per_transform ||
         (tr->slab_stride & 3))
         return pmc_fail((std::string(who) + ": incomplete training image").c_str());
     return 0;
@@ -676,11 +685,13 @@ static int launch_lossgrad(const pmc_maf_t* m, const pmc_maf_train_t* tr, const 
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
         hipError_t e = hipSuccess;
-        const void* ks[4] = {reinterpret_cast<const void*>(maf_lossgrad_kernel<false, 0>),
-                             reinterpret_cast<const void*>(maf_lossgrad_kernel<true, 0>),
-                             reinterpret_cast<const void*>(maf_lossgrad_kernel<false, 1>),
-                             reinterpret_cast<const void*>(maf_lossgrad_kernel<true, 1>)};
-        for (int i = 0; i < 4 && e == hipSuccess; ++i)
+        const void* ks[6] = {reinterpret_cast<const void*>(maf_lossgrad_kernel<TRAIN_WAVES, TRAIN_PF, false, 0>),
+                             reinterpret_cast<const void*>(maf_lossgrad_kernel<TRAIN_WAVES, TRAIN_PF, true, 0>),
+                             reinterpret_cast<const void*>(maf_lossgrad_kernel<TRAIN_WAVES, TRAIN_PF, false, 1>),
+                             reinterpret_cast<const void*>(maf_lossgrad_kernel<TRAIN_WAVES, TRAIN_PF, true, 1>),
+                             reinterpret_cast<const void*>(maf_lossgrad_kernel<TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, false, 1>),
+                             reinterpret_cast<const void*>(maf_lossgrad_kernel<TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, true, 1>)};
+        for (int i = 0; i < 6 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_lossgrad_kernel)");
         lds_set = lds;
@@ -688,18 +699,14 @@ static int launch_lossgrad(const pmc_maf_t* m, const pmc_maf_train_t* tr, const 
     const int64_t nsets = (n + 15) / 16;
     const int n_wg = (int)(nsets < tr->n_slabs ? nsets : tr->n_slabs);
     const bool rqs = (m->n_out == RQS_NOUT);
-    if (prof && rqs)
-        hipLaunchKernelGGL((maf_lossgrad_kernel<true, 1>), dim3((unsigned)n_wg), dim3(TRAIN_THREADS), lds, st, *m, *tr, x,
-                           w, idx, wmul, n, prof);
-    else if (prof)
-        hipLaunchKernelGGL((maf_lossgrad_kernel<true, 0>), dim3((unsigned)n_wg), dim3(TRAIN_THREADS), lds, st, *m, *tr, x,
-                           w, idx, wmul, n, prof);
-    else if (rqs)
-        hipLaunchKernelGGL((maf_lossgrad_kernel<false, 1>), dim3((unsigned)n_wg), dim3(TRAIN_THREADS), lds, st, *m, *tr, x,
-                           w, idx, wmul, n, (long long*)nullptr);
-    else
-        hipLaunchKernelGGL((maf_lossgrad_kernel<false, 0>), dim3((unsigned)n_wg), dim3(TRAIN_THREADS), lds, st, *m, *tr, x,
-                           w, idx, wmul, n, (long long*)nullptr);
+    const bool narrow = train_waves_of(*m) == TRAIN_WAVES_NARROW;
+#define LG(NWV, PFV, PR, UN)                                                                                       \
+    hipLaunchKernelGGL((maf_lossgrad_kernel<NWV, PFV, PR, UN>), dim3((unsigned)n_wg), dim3(64 * NWV), lds, st, *m, *tr, x, \
+                       w, idx, wmul, n, prof)
+    if (narrow) { if (prof) LG(TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, true, 1); else LG(TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, false, 1); }
+    else if (rqs) { if (prof) LG(TRAIN_WAVES, TRAIN_PF, true, 1); else LG(TRAIN_WAVES, TRAIN_PF, false, 1); }
+    else { if (prof) LG(TRAIN_WAVES, TRAIN_PF, true, 0); else LG(TRAIN_WAVES, TRAIN_PF, false, 0); }
+#undef LG
     const int64_t g_total = (int64_t)m->T * tr->gmap_per_transform;
     const int64_t blocks = (g_total / 4 + 255) / 256;
     if (blocks > tr->n_sq_partial) return pmc_fail("pmc_maf_loss_grad: sq_partial too small");
@@ -722,6 +729,8 @@ extern "C" int pmc_debug_lossgrad_profile(const pmc_maf_t* m, const pmc_maf_trai
     return launch_lossgrad(m, tr, x, nullptr, nullptr, 1000.0f, grad, loss, n, (hipStream_t)stream, prof);
 }
 extern "C" int pmc_debug_train_waves(void) { return TRAIN_WAVES; }
+// waves per training workgroup for this flow = the n_waves of pmc_maf_train_t.sched (MAFSpec.train_schedule)
+extern "C" int pmc_maf_train_waves(const pmc_maf_t* m) { return m ? train_waves_of(*m) : TRAIN_WAVES; }
 
 // One pass over a validation set in batches (flow.py:327-348), everything enqueued by one call.
 extern "C" int pmc_maf_valid_epoch(const pmc_maf_t* m, const float* x, const float* w, const int64_t* perm, int64_t n,

@@ -32,7 +32,7 @@ class TrainState:
         self.packT_idx = torch.from_numpy(pT_idx).to(dev)
         self.gmap = torch.from_numpy(gmap).to(dev)
         self.packedT = torch.zeros(pT_idx.size, dtype=torch.float32, device=dev)
-        self.n_waves = int(flow.lib.pmc_debug_train_waves())           # waves per training workgroup (compile-time)
+        self.n_waves = int(flow.lib.pmc_maf_train_waves(C.byref(flow._desc)))   # waves per training workgroup
         self.sched = torch.from_numpy(spec.train_schedule(self.n_waves).reshape(-1).copy()).to(dev)
         self.g_total = spec.n_transforms * L["gmap_per_transform"]
         self.n_sq = (self.g_total // 4 + 255) // 256

@@ -14,8 +14,9 @@ def log_likelihood(x):
 
 
 flow = sys.argv[1] if len(sys.argv) > 1 else "nsf6"
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 t0 = time.time()
-sampler = pc.Sampler(prior=prior, likelihood=log_likelihood, vectorize=True, random_state=0, flow=flow)
+sampler = pc.Sampler(prior=prior, likelihood=log_likelihood, vectorize=True, random_state=seed, flow=flow)
 sampler.run(progress=False)
 dt = time.time() - t0
 samples, weights, logl, logp = sampler.posterior()
