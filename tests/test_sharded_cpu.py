@@ -131,3 +131,40 @@ def test_sharded_ess_and_logz_equal_the_oracle_on_the_whole_pool():
     for r in range(2):
         np.testing.assert_allclose(out[r][0], ess_ref, rtol=1e-12)
         np.testing.assert_allclose(out[r][1], logz_ref, rtol=1e-12)
+
+
+@pytest.mark.parametrize("kind", ["preconditioned_pcn", "preconditioned_rwm", "pcn", "rwm"])
+def test_adaptation_coefficients_reproduce_the_host_update(kind):
+    """What the device-side adaptation is given (``Adaptation.coefficients``: mode, 1/(i+1)^0.75 or 1/(i+1), 1/(i+1),
+    cap) and the expressions it evaluates (``adapt_apply`` in csrc/mcmc_kernels.hip, restated here in numpy float64
+    in the same order) give bit for bit the sigma and mu of ``Adaptation.update`` (mcmc.py:152-156, :314, :476, :627)."""
+    from pocomc_amd.mcmc import Adaptation, PMC_ADAPT_MU, PMC_ADAPT_PRWM, PMC_ADAPT_RWM, PMC_ADAPT_TPCN
+    D, N = 7, 1000
+    rng = np.random.default_rng(3)
+    mu0 = rng.normal(size=D) if kind == "preconditioned_pcn" else None
+    ad = Adaptation(kind, D, N, n_steps=10 ** 9, n_max=10 ** 9, sigma0=0.9, mu0=mu0, logp2_0=-np.inf)
+    sigma = np.float64(ad.sigma)
+    mu = None if mu0 is None else np.array(mu0)
+    for step in range(40):
+        sums = np.concatenate([[rng.uniform(0, N), rng.normal() * N, rng.normal() * N, rng.integers(0, N)],
+                               rng.normal(size=D) * N])
+        mode, c_sigma, c_mu, cap = ad.coefficients()
+        # the device's arithmetic
+        mean_alpha = sums[0] / np.float64(N)
+        sn = sigma + np.float64(c_sigma) * (mean_alpha - 0.234)
+        how = mode & 7
+        if how == PMC_ADAPT_TPCN:
+            sn = np.abs(np.minimum(sn, np.float64(cap)))
+        elif how == PMC_ADAPT_RWM:
+            sn = np.abs(sn)
+        else:
+            assert how == PMC_ADAPT_PRWM
+        sigma = sn
+        if mode & PMC_ADAPT_MU:
+            mean_theta = (sums[4:4 + D] / np.float64(N)).astype(np.float32)
+            mu = mu + np.float64(c_mu) * (mean_theta.astype(np.float64) - mu)
+        ad.update(sums)
+        assert np.float64(ad.sigma) == sigma, step
+        if mu is not None:
+            assert np.array_equal(ad.mu, mu), step
+    assert (mu is not None) == (kind == "preconditioned_pcn")
