@@ -17,6 +17,7 @@ The particle state is resident in HBM when the timed region starts.
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -415,7 +416,8 @@ def main():
                    "maf_inverse_tri_nsf_kernel" if spec.univariate == "rqs" else
                    {"triangular_v1": "maf_inverse_tri_kernel", "triangular_v2": "maf_inverse_tri2_kernel",
                     "triangular_v3": "maf_inverse_tri3_kernel"}.get(
-                       args.inverse, ("maf_inverse_tri5_kernel" if n_launch <= 8192 else "maf_inverse_tri4_kernel")
+                       args.inverse, ("maf_inverse_tri5_kernel" if lib.pmc_debug_inverse_uses_duo(
+                           ctypes.byref(flow._desc), n_launch) else "maf_inverse_tri4_kernel")
                        if spec.nOT <= 8 else "maf_inverse_tri2_kernel"))
     # HBM bytes per launch of the dominant kernel: PMC passes cannot run inside this process, the value
     # is the committed rocprofv3 measurement of this very command (scripts/collect_profile.sh -> profiles/r01_f_*)

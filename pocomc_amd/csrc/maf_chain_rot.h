@@ -39,7 +39,7 @@ struct ChainRot {
 // X / ladj side effects are masked; the right-looking output updates are unconditional too (the
 // fragments of output tiles whose ranks are all below g are exact zeros).
 template <int PAT, int I, int END, int MAXO, int ABL = 0>
-__device__ __forceinline__ void chain_group_rot(ChainRot<MAXO>& s, float* H0, float* H1, float* H2, float* X,
+__device__ __forceinline__ void chain_group_rot(ChainRot<MAXO>& s, float* H0, float* H1, float* X,
                                                 int Tt, int D, int nOT, int q, int p, float& ladj) {
     constexpr int NG = pat_ngroups(PAT);
     if constexpr (I < NG && I < END) {
@@ -61,7 +61,7 @@ __device__ __forceinline__ void chain_group_rot(ChainRot<MAXO>& s, float* H0, fl
 #pragma unroll
             for (int c = c0; c <= c1; ++c) s.a2[jt] = MFMA(comp(s.wd2[jt], c), h1[c], s.a2[jt]);
 #pragma unroll
-        for (int c = c0; c <= c1; ++c) { h2[c] = fmaxf((s.a2[c][0] + s.p2[c]) + h1[c], 0.0f); H2[hw + c] = h2[c]; }
+        for (int c = c0; c <= c1; ++c) h2[c] = fmaxf((s.a2[c][0] + s.p2[c]) + h1[c], 0.0f);   // (used from registers only)
         constexpr int slot = I >> 1;
 #pragma unroll
         for (int c = c0; c <= c1; ++c) s.outR[slot] = MFMA(comp(s.wo[slot], c), h2[c], s.outR[slot]);
@@ -83,7 +83,7 @@ __device__ __forceinline__ void chain_group_rot(ChainRot<MAXO>& s, float* H0, fl
 #pragma unroll
                 for (int c = c0; c <= c1; ++c) s.oN[O] = MFMA(comp(s.f3n[O], c), h2[c], s.oN[O]);
         }
-        chain_group_rot<PAT, I + 1, END, MAXO, ABL>(s, H0, H1, H2, X, Tt, D, nOT, q, p, ladj);
+        chain_group_rot<PAT, I + 1, END, MAXO, ABL>(s, H0, H1, X, Tt, D, nOT, q, p, ladj);
     }
 }
 

@@ -112,8 +112,7 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
     float* X = Y + Dp * 16;
     float* H0 = X + Dp * 16;
     float* H1 = H0 + Hp * 16;
-    float* H2 = H1 + Hp * 16;
-    float* S = H2 + Hp * 16;                   // staging: [3 layers][16 p][16 rows] then [MAXO][16 p][16 rows]
+    float* S = H1 + Hp * 16;                   // staging: [3 layers][16 p][16 rows] then [MAXO][16 p][16 rows]
     float* SO = S + 3 * 256;
     const int* feat_of_rank = m.meta + 8;
     const int* rank_of_feat = m.meta + 8 + T * D;
@@ -147,7 +146,7 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
     }
     {   // padding slots of the activations are read by the bursts (times zero weights): zero once
         float4* z4 = reinterpret_cast<float4*>(H0);
-        const int n4 = (3 * Hp * 16) >> 2;
+        const int n4 = (2 * Hp * 16) >> 2;
         for (int e = lane; e < n4; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float ladj = 0.0f;
@@ -325,7 +324,7 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
             // they would sit between the chain and its own fragments), then the remaining groups
             if (!(ABL & 8))
             switch (pat) {
-#define CASE(P) case P: chain_group_rot<P, 0, 1, MAXO, ABL>(s, H0, H1, H2, X, Tt, D, nOT, q, p, ladj); break;
+#define CASE(P) case P: chain_group_rot<P, 0, 1, MAXO, ABL>(s, H0, H1, X, Tt, D, nOT, q, p, ladj); break;
                 CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
 #undef CASE
             }
@@ -335,7 +334,7 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
             }
             if (!(ABL & 8))
             switch (pat) {
-#define CASE(P) case P: chain_group_rot<P, 1, 4, MAXO, ABL>(s, H0, H1, H2, X, Tt, D, nOT, q, p, ladj); break;
+#define CASE(P) case P: chain_group_rot<P, 1, 4, MAXO, ABL>(s, H0, H1, X, Tt, D, nOT, q, p, ladj); break;
                 CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
 #undef CASE
                 default: break;
@@ -366,7 +365,7 @@ int pmc_launch_inverse_tri4(const pmc_maf_t* m, const float* z, float* x, float*
     if (m->nOT > 8) return -1;                                     // caller falls back
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;         // 32-bit buffer offsets
     const int maxo = m->nOT <= 4 ? 4 : 8;
-    const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
+    const size_t lds = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
     if (lds > 160 * 1024) return -1;
 #define LAUNCH(MO)                                                                                               \
     {                                                                                                            \
@@ -386,7 +385,7 @@ int pmc_launch_inverse_tri4(const pmc_maf_t* m, const float* z, float* x, float*
 // timing-only ablations of the D <= 32 instance (scripts/ablate_inverse.py); NOT part of the ABI
 extern "C" int pmc_debug_inverse4_ablate(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, int abl,
                                          void* stream) {
-    const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + 4 * 256) * sizeof(float);
+    const size_t lds = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + 4 * 256) * sizeof(float);
     const dim3 g((unsigned)((n + 15) / 16)), b(64);
     hipStream_t st = (hipStream_t)stream;
 #define AB(V) case V: hipLaunchKernelGGL((maf_inverse_tri4_kernel<4, V>), g, b, lds, st, *m, z, x, ladj, n, ProposeArgs{}); break;
@@ -404,7 +403,7 @@ int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* 
     if (m->n_out != 2 || !m->tri_ok || m->nOT > 8 || m->D > 64) return -1;
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
     const int maxo = m->nOT <= 4 ? 4 : 8;
-    const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
+    const size_t lds = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     ProposeArgs pa{kind, cur32, mu, inv_cov, chol, nu, sigma, cn_a, *rng, prop64, quad, quad_prop, adapt};
     if (tri5_wanted(m, n)) {
@@ -458,7 +457,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, p = lane & 15;
     const int D = m.D, Dp = m.Dp, Hp = m.Hp, T = m.T, nT = m.nT, nXT = m.nXT, nOT = m.nOT;
-    const int set_floats = 2 * Dp * 16 + 3 * Hp * 16 + 3 * 256 + MAXO * 256;   // LDS of one walker set
+    const int set_floats = 2 * Dp * 16 + 2 * Hp * 16 + 3 * 256 + MAXO * 256;   // LDS of one walker set
     const int cs = wv < TRI5_NC ? wv : 0;                                        // this chain wave's set in the workgroup
     const int64_t set = (int64_t)blockIdx.x * TRI5_NC + cs;
     const int64_t row0 = set * 16;
@@ -466,8 +465,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     float* X = Y + Dp * 16;
     float* H0 = X + Dp * 16;
     float* H1 = H0 + Hp * 16;
-    float* H2 = H1 + Hp * 16;
-    float* S = H2 + Hp * 16;                   // staging: [3 layers][16 p][16 rows] then [MAXO][16 p][16 rows]
+    float* S = H1 + Hp * 16;                   // staging: [3 layers][16 p][16 rows] then [MAXO][16 p][16 rows]
     float* SO = S + 3 * 256;
     const int* feat_of_rank = m.meta + 8;
     const int* rank_of_feat = m.meta + 8 + T * D;
@@ -502,7 +500,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     } else {
         for (int c = 0; c < TRI5_NC; ++c) {    // padding slots of the activations are read by the bursts: zero once
             float4* z4 = reinterpret_cast<float4*>(smem + (size_t)c * set_floats + 2 * Dp * 16);
-            const int n4 = (3 * Hp * 16) >> 2;
+            const int n4 = (2 * Hp * 16) >> 2;
             for (int e = lane; e < n4; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
@@ -616,7 +614,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                             a1[c] = MFMA(L1.w, b1.w, a1[c]); a2[c] = MFMA(L2.w, b2.w, a2[c]);                    \
                         }                                                                                        \
                     }                                                                                            \
-                    float* sp = base_ + 2 * Dp * 16 + 3 * Hp * 16 + (p << 4) + (q << 2);                         \
+                    float* sp = base_ + 2 * Dp * 16 + 2 * Hp * 16 + (p << 4) + (q << 2);                         \
                     *reinterpret_cast<float4*>(sp + 256) = make_float4(a1[c][0], a1[c][1], a1[c][2], a1[c][3]);  \
                     *reinterpret_cast<float4*>(sp + 512) = make_float4(a2[c][0], a2[c][1], a2[c][2], a2[c][3]);  \
                 }                                                                                                \
@@ -744,7 +742,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                     s.po[i] = *reinterpret_cast<const float2*>(SO + (gg >> 3) * 256 + (p << 4) + 2 * (gg & 7));
                 }
                 switch (pat) {
-#define CASE(P) case P: chain_group_rot<P, 0, 1, MAXO, 0>(s, H0, H1, H2, X, Tt, D, nOT, q, p, ladj); break;
+#define CASE(P) case P: chain_group_rot<P, 0, 1, MAXO, 0>(s, H0, H1, X, Tt, D, nOT, q, p, ladj); break;
                     CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
 #undef CASE
                 }
@@ -753,7 +751,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                     dg_next = *reinterpret_cast<const int4*>(quad_meta + 4 * (Tt + 1));
                 }
                 switch (pat) {
-#define CASE(P) case P: chain_group_rot<P, 1, 4, MAXO, 0>(s, H0, H1, H2, X, Tt, D, nOT, q, p, ladj); break;
+#define CASE(P) case P: chain_group_rot<P, 1, 4, MAXO, 0>(s, H0, H1, X, Tt, D, nOT, q, p, ladj); break;
                     CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
 #undef CASE
                     default: break;
@@ -782,11 +780,25 @@ static bool tri5_wanted(const pmc_maf_t* m, int64_t n) {
     const int mode = tri5_mode();
     if (mode >= 0) return mode != 0;
     const int maxo = m->nOT <= 4 ? 4 : 8;
-    const size_t lds = (size_t)TRI5_NC * (2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
-    if (lds > 160 * 1024) return false;
-    const int64_t by_lds = (int64_t)((160 * 1024) / lds), by_simd = 4 / (TRI5_NC + 1);
-    const int64_t resident_sets = 256 * TRI5_NC * (by_lds < by_simd ? by_lds : by_simd);
-    return (n + 15) / 16 <= resident_sets;
+    const size_t lds1 = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);   // one walker set
+    if (lds1 * TRI5_NC > 160 * 1024) return false;
+    // rounds a launch needs: workgroups resident per CU are bounded by the LDS (both kernels keep one set's tiles
+    // per chain wave) and by the SIMDs (one 256-register wave each: 4 lone waves or 4 / (TRI5_NC + 1) groups).
+    // The two-wave kernel takes ~0.75 of the lone wave's time per round.
+    const int64_t by_lds4 = (int64_t)((160 * 1024) / lds1), by_lds5 = (int64_t)((160 * 1024) / (lds1 * TRI5_NC));
+    const int64_t res4 = 256 * (by_lds4 < 4 ? by_lds4 : 4);
+    const int64_t wg5 = by_lds5 < 4 / (TRI5_NC + 1) ? by_lds5 : 4 / (TRI5_NC + 1);
+    const int64_t res5 = 256 * TRI5_NC * wg5;
+    if (res4 < 1 || res5 < 1) return false;
+    const int64_t sets = (n + 15) / 16;
+    const int64_t r4 = (sets + res4 - 1) / res4, r5 = (sets + res5 - 1) / res5;
+    return 3 * r5 < 4 * r4;
+}
+
+// which of the two D <= 64 sweeps PMC_INVERSE_AUTO launches for n rows (bench.py names the kernel it times with it)
+extern "C" int pmc_debug_inverse_uses_duo(const pmc_maf_t* m, int64_t n) {
+    if (!m || m->n_out != 2 || !m->tri_ok || m->nOT > 8 || m->D > 64) return 0;
+    return tri5_wanted(m, n) ? 1 : 0;
 }
 
 // same contract as pmc_launch_propose_inverse_tri4 / pmc_launch_inverse_tri4 (pa == nullptr: plain inverse of z)
@@ -795,7 +807,7 @@ static int launch_tri5(const ProposeArgs* pa, const pmc_maf_t* m, const float* z
     if (m->n_out != 2 || !m->tri_ok || m->nOT > 8 || m->D > 64) return -1;
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
     const int maxo = m->nOT <= 4 ? 4 : 8;
-    const size_t lds = (size_t)TRI5_NC * (2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
+    const size_t lds = (size_t)TRI5_NC * (2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     const ProposeArgs none{};
     const int64_t nsets = (n + 15) / 16;

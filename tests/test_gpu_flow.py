@@ -52,7 +52,7 @@ def test_inverse_matches_oracle(D, T, n):
     f, o = make(D, T)
     z = (np.random.default_rng(7 + n).normal(size=(n, D)) * 1.2).astype(np.float32)
     xo, lo = o.inverse(z)                       # the reference's D-pass algorithm
-    small = f.spec.nOT <= 8 and 2 * f.spec.Dp + 3 * f.spec.Hp + 176 <= 2560       # D <= 64, tiles fit the LDS
+    small = f.spec.nOT <= 8 and 2 * f.spec.Dp + 3 * f.spec.Hp + 176 <= 2560       # D <= 64, tiles fit the LDS (pmc_maf_inverse checks the 3-layer budget)
     for algo in ([1, 4, 3, 2] + ([5, 6, 7] if small else []) if f.spec.tri_ok else [2]):
         f.inverse_algo = algo
         x, l = f.inverse(torch.from_numpy(z))
@@ -79,6 +79,11 @@ def test_one_and_two_wave_sweeps_agree_bit_for_bit(D, T, n):
     for a in (7, 0):
         np.testing.assert_array_equal(out[a][0], out[6][0])
         np.testing.assert_array_equal(out[a][1], out[6][1])
+    import ctypes as C
+    from pocomc_amd import _lib
+    duo = _lib.load().pmc_debug_inverse_uses_duo(C.byref(f._desc), n)
+    if (D, T) == (32, 3):          # 41 KB of LDS per walker set: 512 two-wave groups or 768 lone waves at a time
+        assert duo == (1 if n <= 8192 else 0)
 
 
 def test_triangular_equals_naive_on_device():
