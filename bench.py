@@ -137,9 +137,11 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="adapt sigma / mu on the host and enqueue every pre-step after the sums of the step before "
                          "(default: adaptation on the device, the next pre-step is enqueued behind the accept)")
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=0,
                     help="row ranges of the walker set stepped as a pipeline (mcmc.LanedEngine: the device works on one "
-                         "lane while the host evaluates the likelihood of another); 1 = the whole set at once")
+                         "lane while the host evaluates the likelihood of another); 1 = the whole set at once; 0 (default) = "
+                         "2 for the affine flows (a lane's proposal + sweep launch is shorter than the whole set's), 1 for "
+                         "the spline flows (their sweep takes the same time for 5e3 and 1e4 walkers)")
     ap.add_argument("--flow", default="maf3", help="maf3 | maf6 | maf12 | nsf3 | nsf6 | nsf12 (BASELINE configs use maf3)")
     ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "triangular_v1", "triangular_v2", "triangular_v3"], default="auto")
     args = ap.parse_args()
@@ -233,6 +235,8 @@ def main():
                     mu0=geo.t_mean, logp2_0=-np.inf)
     # the timed region steps the same walkers as a pipeline of row ranges (what mcmc._run does from 4096 walkers
     # on); `eng` (the whole set at once) stays for the instrumented passes below
+    if args.lanes <= 0:
+        args.lanes = 2 if (flow.spec.univariate == "affine" and flow.spec.tri_ok and flow.spec.nOT <= 8 and D <= 64) else 1
     leng = None
     pipelined = (not args.no_pipeline) and args.x_order == "F" and D <= 256
     if args.lanes > 1:
