@@ -91,7 +91,7 @@ typedef struct pmc_maf_train {
                                * backward sweep then recomputes them) */
     const int32_t* sched;     /* device [3][sched_waves][2]: (first, count) of the weight-gradient tiles every wave of a
                                * workgroup takes in the phases {layer 3, layers 2 and 1, layer 0} (MAFSpec.train_schedule) */
-    int32_t sched_waves;      /* must equal the kernel's wave count per workgroup (8) */
+    int32_t sched_waves;      /* must equal pmc_maf_train_waves(m), the wave count of the training workgroup for this flow */
     int32_t reserved;
     const float* wsum;        /* NULL: c_n uses the sum of THIS call's weights; else f32 [1] (device) with the sum of
                                * the whole batch's weights, e.g. all-reduced over the ranks of a sharded batch */
@@ -369,6 +369,10 @@ typedef struct pmc_step {
     double adapt_c_mu;        /* 1/(i+1) */
     double adapt_cap;         /* min(2.38/sqrt(D), 0.99) */
     double adapt_n_total;     /* number of walkers the sums run over */
+    const double* adapt_other[7];  /* device [D+4] sums of the other row ranges of the walker set (their accepts precede this
+                               * one on the stream): added to this step's sums before the update and before the host copy */
+    int32_t adapt_n_other;
+    int32_t adapt_pad2;
 } pmc_step_t;
 
 #define PMC_ADAPT_TPCN 1      /* sigma <- |min(sigma + c (mean alpha - 0.234), cap)|      (mcmc.py:152, :476) */

@@ -87,7 +87,8 @@ class pmc_step_t(C.Structure):
                 ("no_fuse", C.c_int32), ("host_direct", C.c_int32),
                 ("adapt_state", C.c_void_p), ("adapt_mode", C.c_int32), ("adapt_pad", C.c_int32),
                 ("adapt_c_sigma", C.c_double), ("adapt_c_mu", C.c_double), ("adapt_cap", C.c_double),
-                ("adapt_n_total", C.c_double)]
+                ("adapt_n_total", C.c_double), ("adapt_other", C.c_void_p * 7), ("adapt_n_other", C.c_int32),
+                ("adapt_pad2", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/pocomc_amd.h declares
@@ -132,7 +133,6 @@ SIGNATURES = {
     "pmc_event_record": (C.c_int, [c_p, c_p]),
     "pmc_event_elapsed_ms": (C.c_float, [c_p, c_p]),
     "pmc_event_synchronize": (C.c_int, [c_p]),
-    "pmc_debug_train_waves": (C.c_int, []),
     "pmc_rng_fill": (C.c_int, [P(pmc_rng_t), f64, c_p, c_p, c_p, i64, i32, c_p]),
     "pmc_event_destroy": (None, [c_p]),
     "pmc_logw": (C.c_int, [c_p, c_p, c_p, f64, c_p, i32, i64, c_p]),

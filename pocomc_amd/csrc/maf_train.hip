@@ -728,7 +728,6 @@ extern "C" int pmc_debug_lossgrad_profile(const pmc_maf_t* m, const pmc_maf_trai
     if (train_check(m, tr, "pmc_debug_lossgrad_profile")) return 1;
     return launch_lossgrad(m, tr, x, nullptr, nullptr, 1000.0f, grad, loss, n, (hipStream_t)stream, prof);
 }
-extern "C" int pmc_debug_train_waves(void) { return TRAIN_WAVES; }
 // waves per training workgroup for this flow = the n_waves of pmc_maf_train_t.sched (MAFSpec.train_schedule)
 extern "C" int pmc_maf_train_waves(const pmc_maf_t* m) { return m ? train_waves_of(*m) : TRAIN_WAVES; }
 

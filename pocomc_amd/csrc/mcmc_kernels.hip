@@ -504,7 +504,19 @@ __global__ __launch_bounds__(256) void accept_kernel(
         }
         __syncthreads();
     }
-    if (ad.state && ad.mode) adapt_apply(ad, sums, tid, D);   // pmc_step_t.adapt_state: the proposal of the next step
+    if (ad.n_other > 0) {
+        // this launch closes a walker set stepped as row ranges: total = these sums + the other ranges' (their
+        // accept kernels precede this one on the stream); the host copy and the adaptation see the total
+        __shared__ double total[260];
+        for (int j = tid; j < W; j += 256) {
+            double t = sums[j];
+            for (int k = 0; k < ad.n_other; ++k) t += ad.other[k][j];
+            total[j] = t;
+            if (sums_copy) sums_copy[j] = t;
+        }
+        __syncthreads();
+        if (ad.state && ad.mode) adapt_apply(ad, total, tid, D);
+    } else if (ad.state && ad.mode) adapt_apply(ad, sums, tid, D);   // pmc_step_t.adapt_state: the proposal of the next step
     if (done_flag) {
         __threadfence_system();           // the sums (and every block's state updates) before the completion word
         __syncthreads();
@@ -871,7 +883,7 @@ extern "C" int pmc_adapt_update(const double* const* parts, int32_t n_parts, int
         if (!parts[k]) return pmc_fail("pmc_adapt_update: null part");
         ap.p[k] = parts[k];
     }
-    pmc_adapt_args ad{adapt_state, adapt_state ? adapt_mode : 0, c_sigma, c_mu, cap, n_total};
+    pmc_adapt_args ad{adapt_state, adapt_state ? adapt_mode : 0, c_sigma, c_mu, cap, n_total, {}, 0};
     hipLaunchKernelGGL(adapt_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ap, (int)n_parts, (int)D, total_out,
                        h_sums, ad, done ? (long long*)done->flag : nullptr, done ? (long long)done->value : 0LL);
     return pmc_check_launch("adapt_update_kernel");
@@ -881,7 +893,8 @@ int pmc_accept_adapt(int kind, int preconditioned, pmc_state_t* cur, const pmc_p
                      const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums, double* sums_copy,
                      const pmc_done_t* done, void* workspace, int64_t n, int32_t D, void* stream,
                      const pmc_adapt_args* adapt) {
-    if (adapt && adapt->state && adapt->mode && D > 256) return pmc_fail("pmc_accept: device adaptation needs D <= 256");
+    if (adapt && ((adapt->state && adapt->mode) || adapt->n_other) && D > 256)
+        return pmc_fail("pmc_accept: device adaptation needs D <= 256");
     return accept_impl(kind, preconditioned, cur, prop, beta, nu, rng, alpha_out, accept_out, sums, sums_copy, true,
                        done, workspace, n, D, stream, adapt);
 }

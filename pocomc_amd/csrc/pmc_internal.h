@@ -35,6 +35,8 @@ struct pmc_adapt_args {
     double* state;
     int mode;
     double c_sigma, c_mu, cap, n_total;
+    const double* other[7];     // sums of the other row ranges (pmc_step_t.adapt_other)
+    int n_other;
 };
 int pmc_accept_adapt(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposal_t* prop, double beta, double nu,
                      const pmc_rng_t* rng, double* alpha_out, int32_t* accept_out, double* sums, double* sums_copy,

@@ -159,7 +159,13 @@ extern "C" int pmc_step_post(const pmc_step_t* s, const pmc_rng_t* rng, double b
     if (direct) {
         pmc_done_t dn{s->h_done ? s->h_done + 1 : nullptr, (int64_t)rng->step + 1, nullptr};
         pmc_adapt_args ad{s->adapt_state, s->adapt_state ? s->adapt_mode : 0, s->adapt_c_sigma, s->adapt_c_mu,
-                          s->adapt_cap, s->adapt_n_total};
+                          s->adapt_cap, s->adapt_n_total, {}, 0};
+        if (s->adapt_n_other < 0 || s->adapt_n_other > 7) return pmc_fail("pmc_step_post: adapt_n_other out of range");
+        for (int k = 0; k < s->adapt_n_other; ++k) {
+            if (!s->adapt_other[k]) return pmc_fail("pmc_step_post: null adapt_other");
+            ad.other[k] = s->adapt_other[k];
+        }
+        ad.n_other = s->adapt_n_other;
         rc = pmc_accept_adapt(s->kind, s->preconditioned, &cur, &prop, beta, nu, rng, s->alpha, s->accept, s->sums,
                               copy_sums ? s->h_sums : nullptr, (copy_sums && s->h_done) ? &dn : nullptr, s->ws, n, s->D,
                               stream, &ad);

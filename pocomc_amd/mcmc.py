@@ -489,18 +489,24 @@ class StepEngine:
             if self.prior_desc is None:
                 self.p_logp.copy_(self.h_logp, non_blocking=True)
 
-    def accept_enqueue(self, beta, nu=0.0, want_mask=False, host_sums=True, adapt=None, n_total=None):
+    def accept_enqueue(self, beta, nu=0.0, want_mask=False, host_sums=True, adapt=None, n_total=None, others=()):
         """Composite path: enqueue the Metropolis accept + this engine's sums behind the host's logl' (no wait).
-        ``adapt`` = Adaptation.coefficients(): the kernel's last block also updates the device-side sigma / mu."""
+        ``adapt`` = Adaptation.coefficients(): the kernel's last block also updates the device-side sigma / mu.
+        ``others``: engines over the other row ranges of the walker set whose accepts are already enqueued on this
+        stream -- the kernel adds their sums to its own before the update and the host copy."""
         assert self._post_uploads
         self._want_mask = bool(want_mask)
         self._host_sums = bool(host_sums)
+        st = self._step
         if adapt is not None and self.device_adapt:
-            st = self._step
             st.adapt_mode, st.adapt_c_sigma, st.adapt_c_mu, st.adapt_cap = adapt
             st.adapt_n_total = float(self.n if n_total is None else n_total)
         else:
-            self._step.adapt_mode = 0
+            st.adapt_mode = 0
+        if len(others) != st.adapt_n_other or any(st.adapt_other[k] != o.sums.data_ptr() for k, o in enumerate(others)):
+            for k, o in enumerate(others):
+                st.adapt_other[k] = o.sums.data_ptr()
+            st.adapt_n_other = len(others)
         _lib.check(self.lib.pmc_step_post(C.byref(self._step), C.byref(self._rng_cur), float(beta), float(nu),
                                           int(want_mask), int(host_sums), self._stream), "pmc_step_post")
 
@@ -642,42 +648,49 @@ class LanedEngine:
         tm = self.host_timers
         clock = time.perf_counter
         calls = 0
+        last = self.lanes[-1]
         for e in self.lanes:
             e.host_timers = tm
             calls += e.evaluate(log_prior, log_like)[0]
             t0 = clock() if tm is not None else 0.0
-            e.accept_enqueue(beta, nu, host_sums=False)
+            if e is last and not sharded:
+                # the last range's accept closes the set: total sums, sigma / mu update, sums + completion word to the host
+                e.accept_enqueue(beta, nu, host_sums=True, adapt=coefficients, n_total=n_total, others=self.lanes[:-1])
+            else:
+                e.accept_enqueue(beta, nu, host_sums=False)
             if tm is not None:
                 tm["enqueue_accept"] = tm.get("enqueue_accept", 0.0) + clock() - t0
         t0 = clock() if tm is not None else 0.0
         stream = self.lanes[0]._stream
-        mode, c_sigma, c_mu, cap = coefficients
-        self._flag_value += 1
-        done = _lib.pmc_done_t(flag=self._h_flag.data_ptr(), value=self._flag_value, ticket=None)
-        state = self.lanes[0].adapt_state.data_ptr()
         if sharded:
+            # lane sums -> one vector -> all-reduce over the ranks -> sigma / mu update, sums + completion word to the host
+            mode, c_sigma, c_mu, cap = coefficients
+            self._flag_value += 1
+            done = _lib.pmc_done_t(flag=self._h_flag.data_ptr(), value=self._flag_value, ticket=None)
+            state = self.lanes[0].adapt_state.data_ptr()
             _lib.check(lib.pmc_adapt_update(self._parts, K, D, self._tot.data_ptr(), None, None, 0, 0.0, 0.0, 0.0, 1.0,
                                             None, stream), "pmc_adapt_update")
             allreduce_sums(self._tot, self.group)
             _lib.check(lib.pmc_adapt_update(self._tot_part, 1, D, None, self._h_tot.data_ptr(), state, mode, c_sigma,
                                             c_mu, cap, float(n_total), C.byref(done), stream), "pmc_adapt_update")
-        else:
-            _lib.check(lib.pmc_adapt_update(self._parts, K, D, None, self._h_tot.data_ptr(), state, mode, c_sigma, c_mu,
-                                            cap, float(n_total), C.byref(done), stream), "pmc_adapt_update")
         t1 = clock() if tm is not None else 0.0
         if more:
             for e in self.lanes:
                 e.propose(None, nu, step=e.step_idx + 1)
         t2 = clock() if tm is not None else 0.0
-        _lib.check(lib.pmc_wait_flag(self._h_flag.data_ptr(), self._flag_value, 30.0), "pmc_wait_flag")
+        if sharded:
+            _lib.check(lib.pmc_wait_flag(self._h_flag.data_ptr(), self._flag_value, 30.0), "pmc_wait_flag")
+            sums = self._h_tot.numpy()
+        else:
+            sums = last.accept_wait()                       # (increments the last lane's step counter)
         if tm is not None:
             t3 = clock()
             tm["enqueue_adapt"] = tm.get("enqueue_adapt", 0.0) + t1 - t0
             tm["enqueue_next_pre"] = tm.get("enqueue_next_pre", 0.0) + t2 - t1
             tm["wait_sums"] = tm.get("wait_sums", 0.0) + t3 - t2
-        for e in self.lanes:
+        for e in (self.lanes if sharded else self.lanes[:-1]):
             e.step_idx += 1
-        return calls, self._h_tot.numpy()
+        return calls, sums
 
     def finish_pipeline(self):
         _lib.check(self.lib.pmc_stream_synchronize(self.lanes[0]._stream), "pmc_stream_synchronize")
