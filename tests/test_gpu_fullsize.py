@@ -71,6 +71,7 @@ def _engine(N, D, seed=77, offset=0, flow=None):
     eng.set_device_prior(prior)
     eng.load_state(u[sl], x[sl], scaler.inverse(u[sl])[1], like(x[sl])[0], prior.logpdf(x[sl]))
     eng.set_geometry(mu=geo.t_mean, cov=geo.t_cov)
+    eng.scaler = scaler
     return eng, prior, like, geo
 
 
@@ -121,6 +122,53 @@ def test_proposals_do_not_depend_on_the_sharding():
         torch.cuda.synchronize()
         assert np.array_equal(part.p_theta64.cpu().numpy(), ref_theta[off:off + N_FULL // 2])
         assert np.array_equal(part.p_x.cpu().numpy(), ref_x[off:off + N_FULL // 2])
+
+
+def test_pipelined_two_lane_steps_equal_whole_set_steps_at_full_size():
+    """bench.py's timed region -- 1e4 x 32 walkers stepped as two row ranges, sigma / mu adapted on the device, the
+    next pre-steps enqueued behind the accepts -- against whole-set steps adapted on the host: the same Philox
+    variates and (bit-identical) sweep kernels, so after 4 steps the same walkers moved to the same places; the
+    sums, sigma and mu agree to the order of the additions."""
+    from pocomc_amd.mcmc import Adaptation, LanedEngine
+    D = 32
+    flow = _flow(D, "maf3")
+    whole, prior, like, geo = _engine(N_FULL, D, flow=flow)
+    nu, beta, sigma0 = float(geo.t_nu), 0.5, 2.38 / D ** 0.5
+    mk = lambda: Adaptation("preconditioned_pcn", D, N_FULL, n_steps=10 ** 9, n_max=10 ** 9, sigma0=sigma0,
+                            mu0=geo.t_mean, logp2_0=-np.inf)
+    start = whole.download()
+    ad_w = mk()
+    sums_w = []
+    for _ in range(4):
+        whole.propose(ad_w.sigma, nu)
+        whole.evaluate(prior.logpdf, like)
+        sums_w.append(whole.accept_reduce(beta, nu).copy())
+        ad_w.update(sums_w[-1])
+        whole.set_mu(ad_w.mu)
+    end_w = whole.download()
+
+    lanes = LanedEngine("preconditioned_pcn", N_FULL, D, flow, whole.scaler, lanes=2, seed=77, x_order="F",
+                        streams=False)
+    assert lanes.set_device_prior(prior) and lanes.can_pipeline()
+    assert [e.n for e in lanes.lanes] == [5008, 4992]
+    lanes.load_state(start["u"], start["x"], start["logdetj"], start["logl"], start["logp"])
+    # (the whole-set engine started from the same arrays: _engine loads them before any step)
+    lanes.set_geometry(mu=geo.t_mean, cov=geo.t_cov)
+    ad_l = mk()
+    lanes.start_pipeline(float(ad_l.sigma), ad_l.mu, nu)
+    for k in range(4):
+        calls, sums = lanes.step_pipelined(beta, nu, ad_l.coefficients(), N_FULL, prior.logpdf, like, more=k < 3)
+        assert calls == N_FULL
+        np.testing.assert_allclose(sums, sums_w[k], rtol=1e-9, atol=1e-9)
+        ad_l.update(sums)
+    lanes.finish_pipeline()
+    np.testing.assert_allclose(ad_l.sigma, ad_w.sigma, rtol=1e-12)
+    np.testing.assert_allclose(ad_l.mu, ad_w.mu, rtol=1e-12, atol=1e-14)
+    end_l = lanes.download()
+    same = np.isclose(end_l["u"], end_w["u"], rtol=1e-9, atol=1e-12).all(axis=1)
+    assert same.mean() > 0.999, same.mean()
+    moved = ~np.isclose(end_w["u"], start["u"]).all(axis=1)
+    assert 0.3 < moved.mean() < 1.0
 
 
 def test_pool_statistics_trim_and_resample_at_full_size():
