@@ -225,6 +225,7 @@ def main():
     eng = StepEngine("preconditioned_pcn", n, D, flow, scaler, group=None, shard_offset=rank * n, seed=20240928,
                      x_order=args.x_order)
     eng.host_threads = args.host_threads
+    host_cores = None
     from scipy.stats import uniform as sp_uniform
     from pocomc_amd import Prior
     pc_prior = Prior([sp_uniform(-10.0, 20.0)] * D)                   # pocoMC's own prior object
@@ -239,10 +240,11 @@ def main():
         args.lanes = 2 if (flow.spec.univariate == "affine" and flow.spec.tri_ok and flow.spec.nOT <= 8 and D <= 64) else 1
     leng = None
     pipelined = (not args.no_pipeline) and args.x_order == "F" and D <= 256
-    if args.lanes > 1:
+    if args.lanes > 1 or args.host_threads > 1:
         # numpy's buffered iterator copies a strided operand (x[:, ::2] of the likelihood) through a buffer when
         # the inner loop is shorter than its buffer size (8192 elements): 25 instead of 16.5 ns/row for calls on
-        # fewer than 8192 rows (scripts/hosttest.py).  A lane of 5008 rows stays on the direct path with 1024.
+        # fewer than 8192 rows (scripts/hosttest.py).  A lane of 5008 rows (a thread's chunk of 2500) stays on the
+        # direct path with 1024.
         np.setbufsize(1024)
     if args.lanes > 1 or pipelined:
         leng = LanedEngine("preconditioned_pcn", n, D, flow, scaler, lanes=args.lanes, group=None,
@@ -317,10 +319,16 @@ def main():
                 cand = [c for c in range(lo, hi + 1) if c in affinity0]
                 if cand:
                     pinned_core = cand[(4 + 2 * local) % len(cand)]
+                    # cores for the likelihood's helper threads: the next ones of the same node
+                    i0 = cand.index(pinned_core)
+                    host_cores = [cand[(i0 + 1 + j) % len(cand)] for j in range(max(0, args.host_threads - 1))]
             except (OSError, ValueError, AttributeError):
                 pass
             if pinned_core in affinity0:
                 os.sched_setaffinity(0, {pinned_core})
+                if args.host_threads > 1:
+                    for e_ in [eng] + (leng.lanes if leng is not None else []):
+                        e_.host_threads, e_.host_cores = args.host_threads, host_cores
             else:
                 pinned_core = None
         except (OSError, AttributeError):

@@ -107,6 +107,32 @@ class Adaptation:
         return i >= self.n_max
 
 
+_POOLS = {}
+
+
+def _host_pool(n_threads, cores=None):
+    """Thread pool for the host black boxes (numpy releases the GIL in its loops); one pool per (size, cores) for the
+    process.  ``cores``: pin worker i to cores[i] -- threads created by a pinned driver thread would otherwise
+    inherit its one-core affinity mask."""
+    import itertools
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    key = (int(n_threads), None if cores is None else tuple(cores))
+    if key not in _POOLS:
+        counter = itertools.count()
+
+        def pin():
+            if cores is not None:
+                try:
+                    os.sched_setaffinity(0, {cores[next(counter) % len(cores)]})
+                except OSError:
+                    pass
+        pool = ThreadPoolExecutor(max_workers=max(1, int(n_threads)), initializer=pin)
+        list(pool.map(lambda _: time.sleep(0.01), range(max(1, int(n_threads)))))      # start every worker now
+        _POOLS[key] = pool
+    return _POOLS[key]
+
+
 def allreduce_sums(sums_dev, group=None):
     """Sum the per-shard reductions over all ranks (no-op without a process group)."""
     import torch.distributed as dist
@@ -234,7 +260,8 @@ class StepEngine:
         self.host_direct = (x_order == "F")
         self._post_uploads = False
         self.step_idx = 0
-        self.host_threads = 1    # >1: evaluate the black boxes on row chunks in a thread pool
+        self.host_threads = 1    # >1: evaluate the black boxes on row chunks, this thread + (host_threads - 1) pool threads
+        self.host_cores = None   # optional list of cores the pool's threads are pinned to (one each)
         self._pool = None
         self.stream = None       # torch.cuda.Stream of the composite path (LanedEngine); None: the current one
         self.events = None       # bench.py: list of per-step HIP event tuples when not None
@@ -433,8 +460,7 @@ class StepEngine:
             # rows are independent for a vectorised likelihood (the reference itself calls it on
             # arbitrary compacted subsets, mcmc.py:106,117): evaluate row chunks concurrently
             if self._pool is None:
-                from concurrent.futures import ThreadPoolExecutor
-                self._pool = ThreadPoolExecutor(max_workers=self.host_threads)
+                self._pool = _host_pool(self.host_threads - 1, self.host_cores)
             k = self.host_threads
             bounds = [(i * n // k, (i + 1) * n // k) for i in range(k)]
 
@@ -452,7 +478,9 @@ class StepEngine:
                 ll[ok] = log_like(xs[ok])[0]
                 logl_prime[lo:hi] = ll
                 return int(ok.sum())
-            calls = sum(self._pool.map(work, bounds))
+            # the calling thread takes the last chunk itself, the pool's threads the others
+            futs = [self._pool.submit(work, b) for b in bounds[:-1]]
+            calls = work(bounds[-1]) + sum(f.result() for f in futs)
             self._upload_logs()
             return calls, None
         if fin_i.all():
@@ -804,6 +832,10 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
     for key in ("host_direct", "rng_prefill", "spin_wait"):
         if key in option_dict:
             tune(**{key: bool(option_dict[key])})
+    if option_dict.get("host_threads", 1) > 1:
+        # opt-in: the black boxes are called concurrently on row chunks from this many threads (they must be
+        # thread-safe; the reference calls them on the calling thread only)
+        tune(host_threads=int(option_dict["host_threads"]), host_cores=option_dict.get("host_cores"))
     owner = getattr(log_prior, "__self__", None)
     if owner is not None and option_dict.get("device_prior", True) and hasattr(owner, "device_descriptor"):
         eng.set_device_prior(owner)                 # Prior.logpdf of uniform / normal factors on the device

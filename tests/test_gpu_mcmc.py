@@ -313,6 +313,45 @@ def test_device_side_adaptation_equals_host_side(kind, N, n_max, flow_name):
         np.testing.assert_allclose(a[k][same], b[k][same], rtol=1e-8, atol=1e-10, err_msg=k)
 
 
+def test_host_threads_give_the_same_call():
+    """option host_threads: the likelihood is evaluated on row chunks by several threads (numpy releases the GIL);
+    rows are independent, so the kernel call is bit for bit the single-threaded one."""
+    from scipy.stats import uniform
+    import threading
+    import pocomc_amd as pc
+    from pocomc_amd import mcmc as pmcmc
+    from pocomc_amd.geometry import Geometry
+    import torch
+    D, N = 6, 900
+    prior = pc.Prior([uniform(-5, 10)] * D)
+    rng = np.random.default_rng(8)
+    scaler = pc.Reparameterize(D, bounds=prior.bounds)
+    scaler.fit(prior.rvs(2000))
+    x = rng.uniform(-4, 4, size=(N, D))
+    u = scaler.forward(x)
+    seen = set()
+
+    def like(xx):
+        seen.add(threading.get_ident())
+        return -0.5 * np.sum(xx ** 2, axis=1), None
+    flow = pc.Flow(D, "maf3", seed=0)
+    geo = Geometry()
+    geo.fit(flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64))
+    res = []
+    for th in (1, 3):
+        state = dict(u=u.copy(), x=x.copy(), logdetj=scaler.inverse(u)[1], logl=like(x)[0], logp=prior.logpdf(x),
+                     beta=0.5, blobs=None)
+        funcs = dict(loglike=like, logprior=prior.logpdf, scaler=scaler, flow=flow, theta_geometry=geo)
+        opts = dict(n_max=5, n_steps=10 ** 6, progress_bar=None, proposal_scale=2.38 / D ** 0.5, seed=3, x_order="F",
+                    host_threads=th)
+        seen.clear()
+        res.append(pmcmc.preconditioned_pcn(state, funcs, opts))
+        assert (len(seen) == 1) if th == 1 else (1 < len(seen) <= th)     # (a quick worker may take two chunks)
+    for k in ("u", "x", "logl", "logp", "logdetj"):
+        assert np.array_equal(res[0][k], res[1][k]), k
+    assert res[0]["calls"] == res[1]["calls"]
+
+
 def test_plateau_stop_with_a_pre_step_in_flight():
     """The stop rule of mcmc.py:171-180 fires while the next pre-step is already enqueued: the call returns the
     state of the last accepted step, and a second call on the same inputs gives the same answer."""
