@@ -142,6 +142,7 @@ def main():
                          "lane while the host evaluates the likelihood of another); 1 = the whole set at once; 0 (default) = "
                          "2 for the affine flows (a lane's proposal + sweep launch is shorter than the whole set's), 1 for "
                          "the spline flows (their sweep takes the same time for 5e3 and 1e4 walkers)")
+    ap.add_argument("--first-lane", type=float, default=None, help="fraction of the walkers in the first of two lanes")
     ap.add_argument("--flow", default="maf3", help="maf3 | maf6 | maf12 | nsf3 | nsf6 | nsf12 (BASELINE configs use maf3)")
     ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "triangular_v1", "triangular_v2", "triangular_v3"], default="auto")
     args = ap.parse_args()
@@ -248,7 +249,8 @@ def main():
         np.setbufsize(1024)
     if args.lanes > 1 or pipelined:
         leng = LanedEngine("preconditioned_pcn", n, D, flow, scaler, lanes=args.lanes, group=None,
-                           shard_offset=rank * n, seed=20240928, x_order=args.x_order, streams=not pipelined)
+                           shard_offset=rank * n, seed=20240928, x_order=args.x_order, streams=not pipelined,
+                           first_fraction=args.first_lane)
         if device_prior:
             leng.set_device_prior(pc_prior)
         leng.load_state(u, x, logdetj, logl, logp)

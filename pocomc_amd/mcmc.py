@@ -596,13 +596,18 @@ class LanedEngine:
     the order in which the D+4 sums are added (last bits of mean(alpha), mean(theta))."""
 
     def __init__(self, kind, n, n_dim, flow, scaler, lanes=2, group=None, shard_offset=0, seed=0, x_order="C",
-                 streams=True):
+                 streams=True, first_fraction=None):
         """``streams=False``: all lanes on the current stream, one after the other (the pipelined mode:
         :meth:`start_pipeline` / :meth:`step_pipelined`)."""
         n = int(n)
         lanes = max(1, min(int(lanes), (n + 15) // 16))
         per = ((n + lanes - 1) // lanes + 15) // 16 * 16          # whole 16-row sets per lane
         self.bounds = [(min(k * per, n), min((k + 1) * per, n)) for k in range(lanes)]
+        if first_fraction is not None and lanes == 2:
+            # two lanes of unequal size: the step costs device(lane 0) + max(likelihood(all), device(lane 1) +
+            # likelihood(lane 1)); a somewhat larger first lane balances the two terms
+            cut = min(n, max(16, int(round(n * float(first_fraction) / 16.0)) * 16))
+            self.bounds = [(0, cut), (cut, n)]
         self.bounds = [b for b in self.bounds if b[1] > b[0]]
         self.n, self.D, self.group = n, int(n_dim), group
         self.device = _lib.require_gpu()
