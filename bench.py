@@ -447,7 +447,9 @@ def main():
         pass
     achieved = algo_flops / t_inv / 1e12
     roofline = {"bound": "mfma", "kernel": roof_kernel, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                "traffic": None if traffic is None else traffic["hbm_bytes_per_launch"],     # HBM bytes per launch (PMC)
+                "traffic_detail": traffic,
                 "avg_launch_us": inv_us_live, "launches_timed": len(ev_pairs[::args.event_every]),
                 "walkers_per_launch": n_launch,
                 "note": "achieved = SURVEY 8(d) naive-equivalent flops ((D+1)*F_fwd per walker) / launch time; the "
