@@ -121,6 +121,11 @@ typedef struct pmc_adamw {
     double lr, beta1, beta2, eps, weight_decay;
     double max_norm;          /* clip_grad_norm_ (flow.py:318); <= 0 disables */
     int64_t step;             /* optimizer steps taken so far; advanced by the call */
+    /* optional inverse of pack_idx / packT_idx in CSR form: the image positions parameter i is copied to are
+     * scatter_dst[scatter_ptr[i] .. scatter_ptr[i+1]), position d < n_packed in `packed`, d - n_packed in `packedT`.
+     * With both non-NULL the AdamW kernel refreshes the two images itself (no separate gather launch per step). */
+    const int32_t* scatter_ptr;   /* device int32 [n_params + 1] */
+    const int32_t* scatter_dst;   /* device int32 [scatter_ptr[n_params]] */
 } pmc_adamw_t;
 
 /* One epoch of the training loop, pocomc/flow.py:297-323: for every batch of `batch_size` rows

@@ -38,7 +38,8 @@ class pmc_adamw_t(C.Structure):
                 ("pack_idx", c_p), ("packed", c_p), ("n_packed", C.c_int64),
                 ("packT_idx", c_p), ("packedT", c_p), ("n_packedT", C.c_int64),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
-                ("weight_decay", C.c_double), ("max_norm", C.c_double), ("step", C.c_int64)]
+                ("weight_decay", C.c_double), ("max_norm", C.c_double), ("step", C.c_int64),
+                ("scatter_ptr", c_p), ("scatter_dst", c_p)]
 
 
 class pmc_scaler_t(C.Structure):

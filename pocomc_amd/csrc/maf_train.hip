@@ -627,7 +627,9 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __rest
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ mo, float* __restrict__ vo, int64_t n,
                                                     float lr, float b1, float b2, float eps, float wd, float max_norm,
-                                                    float bc1, float bc2, const float* __restrict__ sq_part, int n_part) {
+                                                    float bc1, float bc2, const float* __restrict__ sq_part, int n_part,
+                                                    const int* __restrict__ sc_ptr, const int* __restrict__ sc_dst,
+                                                    float* __restrict__ img_a, int n_a, float* __restrict__ img_b) {
     // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
     __shared__ float red[4];
     float coef = 1.0f;
@@ -648,6 +650,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         const float v1 = b2 * vo[e] + (1.0f - b2) * gr * gr;
         pv -= step * m1 / (sqrtf(v1) * rs2 + eps);
         p[e] = pv; mo[e] = m1; vo[e] = v1;
+        if (sc_ptr) {
+            // refresh of the kernel images (pmc_adamw_t.scatter_*): every place this parameter is packed to
+            for (int k = sc_ptr[e], k1 = sc_ptr[e + 1]; k < k1; ++k) {
+                const int d = sc_dst[k];
+                if (d < n_a) img_a[d] = pv; else img_b[d - n_a] = pv;
+            }
+        }
     }
 }
 
@@ -767,12 +776,13 @@ extern "C" int pmc_sum_f32(const float* v, float* out, int64_t n, void* stream) 
 
 static void launch_adamw(float* params, const float* grad, float* m1, float* m2, int64_t n, double lr, double beta1,
                          double beta2, double eps, double wd, double max_norm, int64_t step, const float* sq_part,
-                         int n_part, hipStream_t st) {
+                         int n_part, hipStream_t st, const int* sc_ptr = nullptr, const int* sc_dst = nullptr,
+                         float* img_a = nullptr, int n_a = 0, float* img_b = nullptr) {
     int64_t grid = (n + 255) / 256; if (grid > 512) grid = 512;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, st, params, grad, m1, m2, n, (float)lr,
                        (float)beta1, (float)beta2, (float)eps, (float)wd, (float)max_norm, (float)bc1, (float)bc2,
-                       sq_part, n_part);
+                       sq_part, n_part, sc_ptr, sc_dst, img_a, n_a, img_b);
 }
 
 extern "C" int pmc_adamw_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
@@ -806,12 +816,17 @@ extern "C" int pmc_maf_train_epoch(const pmc_maf_t* m, const pmc_maf_train_t* tr
         const float* wb = (w && !perm) ? w + b0 : w;
         if (launch_lossgrad(m, tr, xb, wb, perm ? perm + b0 : nullptr, 1000.0f, opt->grad, loss, nb, st)) return 1;
         opt->step += 1;
+        const bool scatter = opt->scatter_ptr && opt->scatter_dst && opt->n_packed < 0x7fffffffLL;
         launch_adamw(opt->params, opt->grad, opt->exp_avg, opt->exp_avg_sq, opt->n_params, opt->lr, opt->beta1,
-                     opt->beta2, opt->eps, opt->weight_decay, opt->max_norm, opt->step, tr->sq_partial, n_part, st);
-        const int64_t tot = opt->n_packed + opt->n_packedT;
-        int64_t grid = (tot + 255) / 256; if (grid > 2048) grid = 2048;
-        hipLaunchKernelGGL(pack2_kernel, dim3((unsigned)grid), dim3(256), 0, st, opt->params, opt->pack_idx,
-                           opt->packed, opt->n_packed, opt->packT_idx, opt->packedT, opt->n_packedT);
+                     opt->beta2, opt->eps, opt->weight_decay, opt->max_norm, opt->step, tr->sq_partial, n_part, st,
+                     scatter ? opt->scatter_ptr : nullptr, opt->scatter_dst, opt->packed, (int)opt->n_packed,
+                     opt->packedT);
+        if (!scatter) {
+            const int64_t tot = opt->n_packed + opt->n_packedT;
+            int64_t grid = (tot + 255) / 256; if (grid > 2048) grid = 2048;
+            hipLaunchKernelGGL(pack2_kernel, dim3((unsigned)grid), dim3(256), 0, st, opt->params, opt->pack_idx,
+                               opt->packed, opt->n_packed, opt->packT_idx, opt->packedT, opt->n_packedT);
+        }
     }
     return pmc_check_launch("pmc_maf_train_epoch");
 }

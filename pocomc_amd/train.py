@@ -74,6 +74,22 @@ class TrainState:
         self.desc.loss_partial = self.loss_partial.data_ptr()
         self.desc.n_slabs = need
 
+    def scatter_maps(self, flow):
+        """CSR inverse of the two pack maps (``pmc_adamw_t.scatter_*``): where every parameter sits in the forward /
+        inverse image (``Flow._packed``) and in the transposed training image (``packedT``)."""
+        if getattr(self, "_scatter", None) is None:
+            a = flow._pack_idx.cpu().numpy().astype(np.int64)
+            b = self.packT_idx.cpu().numpy().astype(np.int64)
+            src = np.concatenate([a, b])                       # parameter index of every image position, -1 = padding
+            pos = np.nonzero(src >= 0)[0]
+            order = np.argsort(src[pos], kind="stable")
+            dst = pos[order].astype(np.int32)
+            counts = np.bincount(src[pos], minlength=flow.params.numel())
+            ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+            dev = flow.params.device
+            self._scatter = (torch.from_numpy(ptr).to(dev), torch.from_numpy(dst).to(dev))
+        return self._scatter
+
     def repack(self, flow):
         with torch.cuda.device(flow.device):
             _lib.check(flow.lib.pmc_maf_pack(_lib.ptr(flow.params), _lib.ptr(self.packT_idx), _lib.ptr(self.packedT),
@@ -156,13 +172,15 @@ class AdamW:
         f = self.flow
         ts = _train_state(f)
         ts.ensure_slabs(batch_size)
+        sc_ptr, sc_dst = ts.scatter_maps(f)
         c = _lib.pmc_adamw_t(params=f.params.data_ptr(), grad=ts.grad.data_ptr(), exp_avg=self.m.data_ptr(),
                              exp_avg_sq=self.v.data_ptr(), n_params=f.params.numel(),
                              pack_idx=f._pack_idx.data_ptr(), packed=f._packed.data_ptr(), n_packed=f._packed.numel(),
                              packT_idx=ts.packT_idx.data_ptr(), packedT=ts.packedT.data_ptr(),
                              n_packedT=ts.packedT.numel(), lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
                              eps=self.eps, weight_decay=self.wd,
-                             max_norm=float(max_norm) if max_norm is not None else 0.0, step=self.t)
+                             max_norm=float(max_norm) if max_norm is not None else 0.0, step=self.t,
+                             scatter_ptr=sc_ptr.data_ptr(), scatter_dst=sc_dst.data_ptr())
         with torch.cuda.device(f.device):
             _lib.check(f.lib.pmc_maf_train_epoch(C.byref(f._desc), C.byref(ts.desc), C.byref(c), _lib.ptr(x),
                                                  _lib.ptr(w) if w is not None else None,
