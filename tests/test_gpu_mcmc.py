@@ -271,6 +271,53 @@ def test_variates_drawn_ahead_equal_inline_draws():
         assert res[0]["accept"] == res[1]["accept"]
 
 
+@pytest.mark.parametrize("lanes", [1, 2])
+@pytest.mark.parametrize("kind", ["preconditioned_pcn", "rwm"])
+def test_pipelined_call_with_holes_in_the_likelihood(kind, lanes):
+    """-inf and NaN regions of the likelihood and proposals outside the prior's support (mcmc.py:100-121, :134) on
+    the pipelined paths (device-side adaptation, lanes): the same call as with host-side adaptation on the whole
+    set, rejected proposals included."""
+    from scipy.stats import uniform
+    import pocomc_amd as pc
+    from pocomc_amd import mcmc as pmcmc
+    from pocomc_amd.geometry import Geometry
+    import torch
+    D, N = 5, 800
+    prior = pc.Prior([uniform(-3, 6)] * D)                 # narrow support: many proposals fall outside
+    rng = np.random.default_rng(17)
+    scaler = pc.Reparameterize(D, bounds=np.array([[-10.0, 10.0]] * D))   # wider than the support: x' leaves it
+    x = rng.uniform(-2.5, 2.5, size=(N, D))
+    scaler.fit(x)
+    u = scaler.forward(x)
+
+    def like(xx):
+        ll = -0.5 * np.sum(xx ** 2, axis=1)
+        ll = np.where(xx[:, 0] > 1.5, -np.inf, ll)
+        ll = np.where(xx[:, 1] < -1.8, np.nan, ll)
+        return ll, None
+    logl0 = np.nan_to_num(like(x)[0], nan=-1e3, neginf=-1e3)
+    flow = pc.Flow(D, "maf3", seed=0)
+    geo = Geometry()
+    geo.fit(flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64))
+    geo.normal_cov = np.cov(u.T)
+    res = []
+    for opts_extra in (dict(pipeline=False), dict(lanes=lanes)):
+        state = dict(u=u.copy(), x=x.copy(), logdetj=scaler.inverse(u)[1], logl=logl0.copy(), logp=prior.logpdf(x),
+                     beta=0.7, blobs=None)
+        funcs = dict(loglike=like, logprior=prior.logpdf, scaler=scaler, flow=flow, theta_geometry=geo, u_geometry=geo)
+        opts = dict(n_max=6, n_steps=10 ** 6, progress_bar=None, proposal_scale=2.38 / D ** 0.5, seed=4, x_order="F",
+                    **opts_extra)
+        res.append(getattr(pmcmc, kind)(state, funcs, opts))
+    a, b = res
+    assert a["calls"] == b["calls"] < 6 * N                # some proposals never reached the likelihood
+    np.testing.assert_allclose(a["accept"], b["accept"], rtol=1e-12)
+    same = np.isclose(a["u"], b["u"], rtol=1e-9, atol=1e-12).all(axis=1)
+    assert same.mean() >= 0.995
+    assert np.isfinite(b["logl"]).all() and np.isfinite(b["logp"]).all()     # nothing invalid was accepted
+    moved = ~np.isclose(b["x"], x).all(axis=1)
+    assert moved.any() and (b["x"][moved, 0] <= 1.5).all() and (np.abs(b["x"]) <= 3).all()
+
+
 @pytest.mark.parametrize("flow_name", ["maf3", "nsf3"])
 @pytest.mark.parametrize("kind", ["preconditioned_pcn", "preconditioned_rwm", "pcn", "rwm"])
 @pytest.mark.parametrize("N,n_max", [(600, 9), (50, 1), (1000, 2)])
