@@ -224,7 +224,10 @@ __device__ __forceinline__ double prior_term(const pmc_prior_t& pr, int j, doubl
     return (-(z * z) / 2.0 - LOG_SQRT_2PI) - log(sc);
 }
 
-__global__ __launch_bounds__(256) void scaler_inverse_kernel(
+// SCL_THREADS threads per block: the probit / logit maps are long dependent f64 chains, so the block's 64 x D elements
+// are spread over as many lanes as a block can have (four elements per lane at D = 32 instead of eight; 1024 threads would halve the registers of a lane and spill)
+#define SCL_THREADS 512
+__global__ __launch_bounds__(SCL_THREADS) void scaler_inverse_kernel(
     pmc_scaler_t s, const float* __restrict__ u_in, const double* __restrict__ u_in64,
     double* __restrict__ u_out, double* __restrict__ x_out, double* __restrict__ x_colmajor,
     double* __restrict__ ldj_out, int32_t* __restrict__ finite_out, int64_t n, pmc_prior_t pr,
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void scaler_inverse_kernel(
     const int rows = (int)min((int64_t)SCL_ROWS, n - row0);
     if (tid < SCL_ROWS) rowfin[tid] = 1;
     __syncthreads();
-    for (int e = tid; e < rows * D; e += 256) {
+    for (int e = tid; e < rows * D; e += SCL_THREADS) {
         const int r = e / D, j = e - r * D;
         const int64_t g = (row0 + r) * D + j;
         double u = u_in ? (double)u_in[g] : u_in64[g];
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256) void scaler_inverse_kernel(
     }
     if (x_colmajor) {
         // host copy of x' in column-major order ((n, D) Fortran array on the host): coalesced along rows
-        for (int e = tid; e < rows * D; e += 256) {
+        for (int e = tid; e < rows * D; e += SCL_THREADS) {
             const int j = e / rows, r = e - j * rows;
             x_colmajor[(size_t)j * n + row0 + r] = Xt[j * (SCL_ROWS + 1) + r];
         }
@@ -786,7 +789,7 @@ extern "C" int pmc_scaler_inverse_prior(const pmc_scaler_t* s, const pmc_prior_t
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(scaler_inverse_kernel)");
     }
-    hipLaunchKernelGGL(scaler_inverse_kernel, dim3((unsigned)((n + SCL_ROWS - 1) / SCL_ROWS)), dim3(256), lds,
+    hipLaunchKernelGGL(scaler_inverse_kernel, dim3((unsigned)((n + SCL_ROWS - 1) / SCL_ROWS)), dim3(SCL_THREADS), lds,
                        (hipStream_t)stream, *s, u_in, u_in64, u_out, x, x_colmajor, logdetj, finite, n, pr_val, logp, finite_copy,
                        logp_copy, done ? done->ticket : nullptr, done ? (long long*)done->flag : nullptr,
                        done ? (long long)done->value : 0LL);
