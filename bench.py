@@ -241,12 +241,13 @@ def main():
         args.lanes = 2 if (flow.spec.univariate == "affine" and flow.spec.tri_ok and flow.spec.nOT <= 8 and D <= 64) else 1
     leng = None
     pipelined = (not args.no_pipeline) and args.x_order == "F" and D <= 256
+    bufsize0 = None
     if args.lanes > 1 or args.host_threads > 1:
         # numpy's buffered iterator copies a strided operand (x[:, ::2] of the likelihood) through a buffer when
         # the inner loop is shorter than its buffer size (8192 elements): 25 instead of 16.5 ns/row for calls on
         # fewer than 8192 rows (scripts/hosttest.py).  A lane of 5008 rows (a thread's chunk of 2500) stays on the
         # direct path with 1024.
-        np.setbufsize(1024)
+        bufsize0 = np.setbufsize(1024)
     if args.lanes > 1 or pipelined:
         leng = LanedEngine("preconditioned_pcn", n, D, flow, scaler, lanes=args.lanes, group=None,
                            shard_offset=rank * n, seed=20240928, x_order=args.x_order, streams=not pipelined,
@@ -407,6 +408,8 @@ def main():
     torch.cuda.synchronize()
     dt_inst = time.perf_counter() - ti0
     blas_limit.restore_original_limits()
+    if bufsize0 is not None:
+        np.setbufsize(bufsize0)
     if pinned_core is not None:
         os.sched_setaffinity(0, affinity0)
     if world > 1:
