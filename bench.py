@@ -476,6 +476,49 @@ def main():
                                         "frac": b_scaler / us["scaler_inverse"] * 1e-3 / 8000.0},
               "note": "state is cache-resident at 1e4 x 32: launch/latency bound, not bandwidth bound (SURVEY 8(d) caveat); "
                       "durations from the instrumented pass (fine-grained launches with device-to-host copies)"}
+    # resample sweep (sampler.py:680-715) on a config-4 sized persistent pool: multinomial indices + gather of 1e4 rows
+    # out of 8e4 pooled particles, f64 state (what this build moves; SURVEY counts 4 B elements)
+    try:
+        P_pool = 8 * n
+        g = torch.Generator(device="cuda").manual_seed(5)
+        pu = torch.randn(P_pool, D, dtype=torch.float64, device="cuda", generator=g)
+        px = torch.randn(P_pool, D, dtype=torch.float64, device="cuda", generator=g)
+        ps = [torch.randn(P_pool, dtype=torch.float64, device="cuda", generator=g) for _ in range(3)]
+        wts = torch.rand(P_pool, dtype=torch.float64, device="cuda", generator=g); wts /= wts.sum()
+        unif = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+        cdf = torch.empty(P_pool, dtype=torch.float64, device="cuda")
+        ridx = torch.empty(n, dtype=torch.int64, device="cuda")
+        ou, ox = torch.empty(n, D, dtype=torch.float64, device="cuda"), torch.empty(n, D, dtype=torch.float64, device="cuda")
+        os_ = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(3)]
+        from pocomc_amd import _lib as _L
+        st_h = _L.stream_handle()
+
+        def resample_once():
+            _L.check(lib.pmc_resample_multinomial(_L.ptr(wts), P_pool, _L.ptr(unif), n, _L.ptr(cdf), _L.ptr(ridx), st_h))
+
+        def gather_once():
+            _L.check(lib.pmc_gather(_L.ptr(ridx), n, D, _L.ptr(pu), _L.ptr(px), _L.ptr(ps[0]), _L.ptr(ps[1]), _L.ptr(ps[2]),
+                                    _L.ptr(ou), _L.ptr(ox), _L.ptr(os_[0]), _L.ptr(os_[1]), _L.ptr(os_[2]), st_h))
+
+        def timed(fn, reps=50):
+            for _ in range(5):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e3
+        t_res, t_gat = timed(resample_once), timed(gather_once)
+        b_gather = n * (2 * D + 3) * 8 * 2 + n * 8                       # rows read + written (f64) + indices
+        sweeps["resample_gather"] = {"pool": P_pool, "rows_out": n, "indices_us": t_res, "gather_us": t_gat,
+                                     "algorithmic_bytes": 4 * n * (3 * D + 3), "bytes_moved_f64_state": b_gather,
+                                     "achieved": b_gather / t_gat * 1e-3, "frac": b_gather / t_gat * 1e-3 / 8000.0,
+                                     "note": "achieved / frac use the f64 bytes this build moves for the gather launch"}
+        del pu, px, ps, ou, ox, os_, cdf
+    except Exception as exc:                                              # (a sub-metric must not take the bench down)
+        sweeps["resample_gather"] = {"error": repr(exc)}
     ms_per_step = dt / args.steps * 1e3
     value = (n * world * args.steps / dt) / 1e4
     out = {"metric": "preconditioned MCMC steps/sec (1e4 particles, 32-D)", "value": value,
