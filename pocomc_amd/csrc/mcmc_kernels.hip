@@ -632,7 +632,8 @@ __global__ __launch_bounds__(256) void gather_kernel(const int64_t* __restrict__
 #define CUMSUM_CHUNK 4096
 __global__ __launch_bounds__(256) void serial_cumsum_kernel(const double* __restrict__ w, int64_t P,
                                                             double* __restrict__ cdf, int normalise) {
-    __shared__ double buf[CUMSUM_CHUNK];
+    __shared__ double buf[CUMSUM_CHUNK];      // the chunk's weights
+    __shared__ double acc[CUMSUM_CHUNK];      // its running sums (a second array: reads never wait for the writes)
     __shared__ double carry;
     if (threadIdx.x == 0) carry = 0.0;
     for (int64_t base = 0; base < P; base += CUMSUM_CHUNK) {
@@ -642,17 +643,20 @@ __global__ __launch_bounds__(256) void serial_cumsum_kernel(const double* __rest
         if (threadIdx.x == 0) {
             double c = carry;
             int i = 0;
-            for (; i + 8 <= m; i += 8) {
-                const double a0 = buf[i], a1 = buf[i + 1], a2 = buf[i + 2], a3 = buf[i + 3];
-                const double a4 = buf[i + 4], a5 = buf[i + 5], a6 = buf[i + 6], a7 = buf[i + 7];
-                c += a0; buf[i] = c; c += a1; buf[i + 1] = c; c += a2; buf[i + 2] = c; c += a3; buf[i + 3] = c;
-                c += a4; buf[i + 4] = c; c += a5; buf[i + 5] = c; c += a6; buf[i + 6] = c; c += a7; buf[i + 7] = c;
+            for (; i + 16 <= m; i += 16) {
+                double a[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a[k] = buf[i + k];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { c += a[k]; a[k] = c; }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[i + k] = a[k];
             }
-            for (; i < m; ++i) { c += buf[i]; buf[i] = c; }
+            for (; i < m; ++i) { c += buf[i]; acc[i] = c; }
             carry = c;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < m; i += 256) cdf[base + i] = buf[i];
+        for (int i = threadIdx.x; i < m; i += 256) cdf[base + i] = acc[i];
         __syncthreads();
     }
     (void)normalise;
