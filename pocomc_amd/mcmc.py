@@ -108,6 +108,22 @@ class Adaptation:
 
 
 _POOLS = {}
+_PINNED_FREE = {}
+
+
+def _pinned_take(shape, dtype):
+    """A pinned host tensor of this shape / dtype from the free list (contents undefined), or a new one."""
+    free = _PINNED_FREE.get((shape, dtype))
+    if free:
+        return free.pop()
+    return torch.empty(*shape, dtype=dtype).pin_memory()
+
+
+def _pinned_give(t):
+    """Back to the free list (the engine that held it has synchronised with the device)."""
+    free = _PINNED_FREE.setdefault((tuple(t.shape), t.dtype), [])
+    if len(free) < 8:
+        free.append(t)
 
 
 def _host_pool(n_threads, cores=None):
@@ -187,7 +203,14 @@ class StepEngine:
         # replay variates
         self.r_gamma, self.r_normal, self.r_uniform = f64(n), f64(n, D), f64(n)
         # pinned host mirrors
-        pin = lambda *s, dt=torch.float64: torch.empty(*s, dtype=dt).pin_memory()
+        # pinned host mirrors come from a process-wide free list: page-locking costs ~1 ms per buffer, and the
+        # Sampler builds an engine per kernel call
+        self._pins = []
+
+        def pin(*s, dt=torch.float64):
+            t = _pinned_take(tuple(int(v) for v in s), dt)
+            self._pins.append(t)
+            return t
         assert x_order in ("C", "F")
         self.x_order = x_order
         self.p_xT = f64(D, n) if x_order == "F" else None
@@ -268,6 +291,10 @@ class StepEngine:
         self.host_timers = None  # bench.py: dict of accumulated host seconds when not None
 
     def __del__(self):
+        if getattr(self, "_recycle", False):       # (only after the owner synchronised with the device: mcmc._run)
+            for t in getattr(self, "_pins", ()):
+                _pinned_give(t)
+        self._pins = []
         ev = getattr(self, "_ev_pre", None)
         if ev:
             try:
@@ -917,7 +944,9 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
         else:
             _lib.check(eng.lib.pmc_stream_synchronize(eng._stream), "pmc_stream_synchronize")
 
-    out = eng.download()
+    out = eng.download()                               # (synchronises: nothing of this call is in flight any more)
+    for e_ in (eng.lanes if laned else [eng]):
+        e_._recycle = True
     return dict(u=out["u"], x=out["x"], logdetj=out["logdetj"], logl=out["logl"], logp=out["logp"], blobs=blobs,
                 efficiency=ad.sigma, accept=ad.mean_alpha, steps=ad.i, calls=n_calls, proposal_scale=ad.sigma)
 

@@ -38,6 +38,11 @@ class Particles:
         return tools.compute_logw_and_logz(self.get("logl"), self.get("beta"), self.get("logz"),
                                            beta_final, normalize)
 
+    def pool_weights(self):
+        """The history on the device for a series of trials at different ``beta_final`` (``tools.PoolWeights``)."""
+        from . import tools
+        return tools.PoolWeights(self.get("logl"), self.get("beta"), self.get("logz"))
+
     def compute_results(self):
         """``particles.py:233-302``."""
         if self.results_dict is None:

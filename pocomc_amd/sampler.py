@@ -335,14 +335,15 @@ class Sampler:
             if self.world > 1:                                 # equal shares: drop the remainder rows
                 m_ = len(u) // self.world
                 ut, wt = ut[:m_], wt[:m_]
-            self.flow.fit(torch.tensor(ut, dtype=torch.float32), weights=torch.tensor(wt, dtype=torch.float32),
+            as32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+            self.flow.fit(as32(ut), weights=as32(wt),
                           validation_split=c["validation_split"], epochs=c["epochs"],
                           batch_size=int(np.minimum(len(u) // 2, c["batch_size"])), gaussian_scale=c["gaussian_scale"],
                           laplace_scale=c["laplace_scale"], patience=c["patience"], learning_rate=c["learning_rate"],
                           annealing=c["annealing"], noise=c["noise"], shuffle=c["shuffle"],
                           clip_grad_norm=c["clip_grad_norm"], verbose=c["verbose"], group=self.group,
                           sharded=self.world > 1)
-            theta = self.flow.forward(torch.tensor(u, dtype=torch.float32))[0].numpy()
+            theta = self.flow.forward(as32(u))[0].numpy()
             self.theta_geometry.fit(theta, weights=w)
         else:
             self.u_geometry.fit(u, weights=w)
@@ -368,10 +369,11 @@ class Sampler:
         beta_prev = self.particles.get("beta", index=-1)
         beta_max, beta_min = 1.0, np.copy(beta_prev)
 
+        # the history stays on the device for the whole bisection: a trial is two launches and four doubles back
+        pool = self.particles.pool_weights()
+
         def weights_and_ess(beta):
-            logw, _ = self.particles.compute_logw_and_logz(beta)
-            wts = np.exp(logw - np.max(logw))
-            return wts, self._ess(wts)
+            return None, (pool.ess(beta) if self.metric == "ess" else pool.uss(beta))
 
         w_prev, ess_prev = weights_and_ess(beta_prev)
         w_max, ess_max = weights_and_ess(beta_max)
@@ -380,20 +382,20 @@ class Sampler:
             logz = self.particles.get("logz", index=-1)
         elif ess_max >= self.n_effective:
             beta, ess_est = beta_max, ess_max
-            _, logz = self.particles.compute_logw_and_logz(beta)
+            _, logz = pool.logw_and_logz(beta)
         else:
             while True:
                 beta = (beta_max + beta_min) * 0.5
                 _, ess_est = weights_and_ess(beta)
                 if np.abs(ess_est - self.n_effective) < 0.01 * self.n_effective or beta == 1.0:
-                    _, logz = self.particles.compute_logw_and_logz(beta)
+                    _, logz = pool.logw_and_logz(beta)
                     break
                 elif ess_est < self.n_effective:
                     beta_max = beta
                 else:
                     beta_min = beta
         self.pbar.update_stats(dict(beta=beta, ESS=int(ess_est), logZ=logz))
-        logw, _ = self.particles.compute_logw_and_logz(beta)
+        logw, _ = pool.logw_and_logz(beta)
         weights = np.exp(logw - np.max(logw))
         weights /= np.sum(weights)
         if self.dynamic:                                                   # sampler.py:783-790

@@ -84,6 +84,57 @@ def compute_logw_and_logz(logl, beta, logz, beta_final=1.0, normalize=True):
     return logw, logz_new
 
 
+class PoolWeights:
+    """The persistent pool's ``logl`` (T, N), ``beta`` (T,) and ``logz`` (T,) resident on the device for one
+    ``Sampler._reweight``: the beta bisection (``sampler.py:739-777``) evaluates the mixture log-weights
+    (``particles.py:215-231``) and their ESS a dozen times on the SAME history, so every trial is two launches
+    (``pmc_logw``, ``pmc_logw_stats``) and four doubles back, instead of an upload of the history, a download of
+    the log-weights and a second round trip for the ESS."""
+
+    def __init__(self, logl, beta, logz):
+        self.lib = _lib.load()
+        logl = np.asarray(logl, dtype=np.float64)
+        self.T, self.N = logl.shape
+        self.P = self.T * self.N
+        self.ld, self.bd, self.zd = _up(logl), _up(beta), _up(logz)
+        dev = self.ld.device
+        self.lw = torch.empty(self.P, dtype=torch.float64, device=dev)
+        self.stats_d = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.ws = torch.empty(int(self.lib.pmc_reduce_workspace_bytes(self.P)), dtype=torch.uint8, device=dev)
+        self.h_stats = torch.zeros(4, dtype=torch.float64).pin_memory()
+
+    def stats(self, beta_final, k=0):
+        """``[max, sum exp(logw-max), sum exp(2(logw-max)), sum 1-(1-w)^k]`` of the log-weights at ``beta_final``."""
+        lib = self.lib
+        with torch.cuda.device(self.lw.device):
+            st = _lib.stream_handle()
+            _lib.check(lib.pmc_logw(_lib.ptr(self.ld), _lib.ptr(self.bd), _lib.ptr(self.zd), float(beta_final),
+                                    _lib.ptr(self.lw), self.T, self.N, st), "pmc_logw")
+            _lib.check(lib.pmc_logw_stats(_lib.ptr(self.lw), self.P, int(k), _lib.ptr(self.stats_d), _lib.ptr(self.ws),
+                                          st), "pmc_logw_stats")
+            self.h_stats.copy_(self.stats_d, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        return self.h_stats.numpy().copy()
+
+    def ess(self, beta_final):
+        """``effective_sample_size(exp(logw - max))`` (tools.py:56-71) at ``beta_final``."""
+        st = self.stats(beta_final)
+        return (st[1] * st[1]) / st[2]
+
+    def uss(self, beta_final, k=None):
+        """``unique_sample_size`` (tools.py:74-93) at ``beta_final``."""
+        return self.stats(beta_final, k=self.P if k is None else int(k))[3]
+
+    def logw_and_logz(self, beta_final, normalize=True):
+        """``Particles.compute_logw_and_logz`` (particles.py:215-231): host log-weights and logZ."""
+        st = self.stats(beta_final)
+        lse = st[0] + np.log(st[1])
+        logw = self.lw.cpu().numpy()
+        if normalize:
+            logw -= lse
+        return logw, lse - np.log(self.P)
+
+
 def trim_weights(samples, weights, ess=0.99, bins=1000):
     """``pocomc/tools.py:10-53`` (normalises ``weights`` in place like the reference).  The
     threshold search runs on the GPU (``pmc_trim_threshold``); the final mask / renormalisation

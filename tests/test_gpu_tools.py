@@ -81,6 +81,36 @@ def test_logw_logz(gold):
         np.testing.assert_allclose(lw2, g[f"particles/logw_raw_b{bf}"], rtol=1e-13, atol=1e-13)
 
 
+def test_pool_weights_trials_equal_the_reference_chain(gold):
+    """tools.PoolWeights keeps the history on the device for the beta bisection (sampler.py:739-777): the log-weights
+    of a trial match the golden vectors of Particles.compute_logw_and_logz, its ESS / USS the reference's chain
+    compute_logw_and_logz -> exp(logw - max) -> effective_sample_size / unique_sample_size on the host."""
+    from pocomc_amd import tools
+    g = gold["tools"]
+    pool = tools.PoolWeights(g["particles/logl"], g["particles/beta"], g["particles/logz"])
+    for bf in (0.3, 1.0):
+        lw, lz = pool.logw_and_logz(bf)
+        np.testing.assert_allclose(lw, g[f"particles/logw_b{bf}"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(lz, g[f"particles/logz_b{bf}"], rtol=1e-12, atol=1e-12)
+        w = np.exp(g[f"particles/logw_b{bf}"] - np.max(g[f"particles/logw_b{bf}"]))
+        wn = w / w.sum()
+        np.testing.assert_allclose(pool.ess(bf), 1.0 / np.sum(wn * wn), rtol=1e-12)          # tools.py:56-71
+        np.testing.assert_allclose(pool.uss(bf), np.sum(1.0 - (1.0 - wn) ** len(wn)), rtol=1e-10)   # tools.py:74-93
+    # a large random history, against the per-call functions
+    rng = np.random.default_rng(4)
+    T, N = 9, 2000
+    logl = rng.normal(size=(T, N)) * 4 - 30
+    beta = np.sort(rng.uniform(0, 1, size=T)); beta[0] = 0.0
+    logz = np.cumsum(rng.normal(size=T))
+    pool = tools.PoolWeights(logl, beta, logz)
+    for bf in (0.0, 0.41, 1.0):
+        lw, lz = tools.compute_logw_and_logz(logl, beta, logz, bf)
+        lw2, lz2 = pool.logw_and_logz(bf)
+        np.testing.assert_array_equal(lw, lw2)
+        assert lz == lz2
+        np.testing.assert_allclose(pool.ess(bf), tools.effective_sample_size(np.exp(lw - lw.max())), rtol=1e-12)
+
+
 def test_gather():
     from pocomc_amd import tools
     rng = np.random.default_rng(0)
