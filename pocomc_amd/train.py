@@ -280,13 +280,15 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
         raise ValueError("x has the wrong number of columns")
     w = None if weights is None else torch.as_tensor(weights).to(torch.float32)
 
-    if shuffle:                                                     # flow.py:234-238
-        rand_indx = torch.randperm(n_samples)
-        x = x[rand_indx.to(x.device)]
+    x = x.to(dev)
+    w = None if w is None else w.to(dev)
+    if shuffle:                                                     # flow.py:234-238 (the permutation still comes
+        rand_indx = torch.randperm(n_samples).to(dev)               # from torch's CPU generator; rows move on the device)
+        x = x[rand_indx]
         if w is not None:
-            w = w[rand_indx.to(w.device)]
-    x = x.to(dev).contiguous()
-    w = None if w is None else w.to(dev).contiguous()
+            w = w[rand_indx]
+    x = x.contiguous()
+    w = None if w is None else w.contiguous()
 
     if validation_split > 0.0:                                      # flow.py:247-259
         cut = int(validation_split * n_samples)
@@ -322,11 +324,13 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
     pipelined = (sched is None) and not sharded
     slots = 2 if pipelined else 1
     acc_d = [torch.zeros(2, dtype=torch.float32, device=dev) for _ in range(slots)]   # [train loss, val loss]
-    acc_h = [torch.zeros(2, dtype=torch.float32).pin_memory() for _ in range(slots)]
+    from .mcmc import _pinned_take, _pinned_give
+    acc_h = [_pinned_take((2,), torch.float32).zero_() for _ in range(slots)]
     done = [torch.cuda.Event() for _ in range(slots)]
     after = [torch.empty_like(flow.params) for _ in range(slots)]                    # parameters after the epoch
-    h_perm = [[torch.empty(max(n_train, 1), dtype=torch.int64).pin_memory() for _ in range(slots)],
-              [torch.empty(max(n_valid, 1), dtype=torch.int64).pin_memory() for _ in range(slots)]]
+    # (pinned staging from the process-wide free list: page-locking a buffer costs about a millisecond)
+    h_perm = [[_pinned_take((max(n_train, 1),), torch.int64) for _ in range(slots)],
+              [_pinned_take((max(n_valid, 1),), torch.int64) for _ in range(slots)]]
     d_perm = [[torch.empty(max(n_train, 1), dtype=torch.int64, device=dev) for _ in range(slots)],
               [torch.empty(max(n_valid, 1), dtype=torch.int64, device=dev) for _ in range(slots)]]
     ts = _train_state(flow)
@@ -408,4 +412,8 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
         total = time.time() - start
         print("\nTime total:     %5.2f sec" % total)
         print("Time per epoch: %5.2f sec" % (total / epochs))
+    # a speculative epoch may still be copying its permutations / losses: wait before the staging goes back
+    torch.cuda.current_stream().synchronize()
+    for t in acc_h + h_perm[0] + h_perm[1]:
+        _pinned_give(t)
     return history
