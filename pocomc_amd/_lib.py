@@ -181,11 +181,17 @@ def load():
     return lib
 
 
+_gpu_seen = False
+
+
 def require_gpu():
+    global _gpu_seen
     import torch
-    if not torch.cuda.is_available():
-        raise PocomcAmdError("pocomc_amd needs an AMD MI355X (gfx950) visible to PyTorch-ROCm; "
-                             "there is no CPU fallback")
+    if not _gpu_seen:                      # (is_available() re-counts the devices on every call)
+        if not torch.cuda.is_available():
+            raise PocomcAmdError("pocomc_amd needs an AMD MI355X (gfx950) visible to PyTorch-ROCm; "
+                                 "there is no CPU fallback")
+        _gpu_seen = True
     return torch.device("cuda", torch.cuda.current_device())
 
 
