@@ -345,7 +345,8 @@ def main():
                 lo = int(first.split("-")[0]); hi = int(first.split("-")[-1])
                 cand = [c for c in range(lo, hi + 1) if c in affinity0]
                 if cand:
-                    pinned_core = cand[(4 + 2 * local) % len(cand)]
+                    pinned_core = cand[(4 + 2 * rank) % len(cand)]      # (rank, not local: ranks that share a GPU in the
+                                                                          #  functional test must not share a core)
                     # cores for the likelihood's helper threads: the next ones of the same node
                     i0 = cand.index(pinned_core)
                     host_cores = [cand[(i0 + 1 + j) % len(cand)] for j in range(max(0, args.host_threads - 1))]
