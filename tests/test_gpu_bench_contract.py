@@ -1,0 +1,38 @@
+"""bench.py prints ONE JSON line with the fields the driver's contract names (metric / value / unit / n_gpus / steps /
+warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config + roofline + cpu_baseline)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("extra", [[], ["--lanes", "1", "--no-pipeline"], ["--flow", "nsf3"]])
+def test_bench_line_follows_the_contract(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--particles", "1024", "--steps", "6", "--warmup", "2"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["value"] > 0 and abs(d["ms_per_step"] - 1024 / 1e4 / d["value"] * 1e3) < 1e-6 * d["ms_per_step"] + 1e-9
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 * max(1.0, r["frac"])
+    assert r["traffic"] is None or r["traffic"] > 0          # (PMC bytes only for the profiled headline launch size)
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1
