@@ -272,6 +272,7 @@ class StepEngine:
         self.h_done.zero_()
         self._done_ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self._direct_now = False
+        self._pre_cfg = None     # switches the composite pre-step's struct fields were last written for
         # adaptation on the device (pmc_step_t.adapt_state): {sigma, cn_a, mu[D]}; see run_pipelined
         self.adapt_state = f64(D + 2)
         self._h_adapt = pin(D + 2)
@@ -391,16 +392,20 @@ class StepEngine:
                 self._rng_fast.step = self.step_idx if step is None else int(step)
                 self._rng_cur = self._rng_fast
             self._step.adapt_mode = 1 if self.device_adapt else 0         # (pre: any non-zero mode = read the state)
-            if self.pre:
-                self._step.inverse_algo = self.flow.inverse_algo
-            self._step.rng_ready = C.cast(C.pointer(self._rng_ready), C.c_void_p) if self.rng_prefill else None
-            direct = bool(self.host_direct and self.x_order == "F")
-            self._step.host_direct = int(direct)
-            self._step.p_xT = None if (direct or self.p_xT is None) else self.p_xT.data_ptr()
-            self._direct_now = direct and self.spin_wait
-            self._step.h_done = self.h_done.data_ptr() if self._direct_now else None
-            self._step.done_ticket = self._done_ticket.data_ptr() if self._direct_now else None
-            self._step.ev_pre_done = None if self._direct_now else self._ev_pre     # (the completion word replaces it)
+            # the rest of the struct depends on the engine's switches only: written when one of them changed
+            cfg = (self.flow.inverse_algo if self.pre else 0, self.rng_prefill, self.host_direct, self.spin_wait)
+            if cfg != self._pre_cfg:
+                self._pre_cfg = cfg
+                if self.pre:
+                    self._step.inverse_algo = self.flow.inverse_algo
+                self._step.rng_ready = C.cast(C.pointer(self._rng_ready), C.c_void_p) if self.rng_prefill else None
+                direct = bool(self.host_direct and self.x_order == "F")
+                self._step.host_direct = int(direct)
+                self._step.p_xT = None if (direct or self.p_xT is None) else self.p_xT.data_ptr()
+                self._direct_now = direct and self.spin_wait
+                self._step.h_done = self.h_done.data_ptr() if self._direct_now else None
+                self._step.done_ticket = self._done_ticket.data_ptr() if self._direct_now else None
+                self._step.ev_pre_done = None if self._direct_now else self._ev_pre     # (the completion word replaces it)
             if self.device_adapt:
                 sigma, cn_a = 0.0, 0.0                      # the kernels read adapt_state instead
             else:
