@@ -185,6 +185,25 @@ def main():
     if os.environ.get("PMC_BENCH_SHARE_GPU"):
         local = 0
     torch.cuda.set_device(local)
+    # everything this process allocates and every thread it starts from here on stays on the NUMA node the GPU hangs
+    # off (its PCI device's local_cpulist): pinned host buffers are first-touched where their allocator runs, and the
+    # step loops below read them from a core of that node
+    node_cpus = None
+    if not args.no_pin:
+        try:
+            pr = torch.cuda.get_device_properties(local)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            cl = open(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read().strip()
+            cpus = set()
+            for part in cl.split(","):
+                lo_, _, hi_ = part.partition("-")
+                cpus.update(range(int(lo_), int(hi_ or lo_) + 1))
+            cpus &= os.sched_getaffinity(0)
+            if cpus:
+                os.sched_setaffinity(0, cpus)
+                node_cpus = sorted(cpus)
+        except (OSError, ValueError, AttributeError):
+            node_cpus = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -336,22 +355,14 @@ def main():
         try:
             import ctypes
             pinned_core = ctypes.CDLL("libc.so.6").sched_getcpu()
-            # prefer a core of the NUMA node the GPU hangs off (its PCI device's local_cpulist)
-            try:
-                pr = torch.cuda.get_device_properties(local)
-                bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
-                cl = open(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read().strip()
-                first = cl.split(",")[0]
-                lo = int(first.split("-")[0]); hi = int(first.split("-")[-1])
-                cand = [c for c in range(lo, hi + 1) if c in affinity0]
-                if cand:
-                    pinned_core = cand[(4 + 2 * rank) % len(cand)]      # (rank, not local: ranks that share a GPU in the
+            # a core of the NUMA node the GPU hangs off (node_cpus, set up at the start)
+            cand = [c for c in (node_cpus or []) if c in affinity0]
+            if cand:
+                pinned_core = cand[(4 + 2 * rank) % len(cand)]          # (rank, not local: ranks that share a GPU in the
                                                                           #  functional test must not share a core)
-                    # cores for the likelihood's helper threads: the next ones of the same node
-                    i0 = cand.index(pinned_core)
-                    host_cores = [cand[(i0 + 1 + j) % len(cand)] for j in range(max(0, args.host_threads - 1))]
-            except (OSError, ValueError, AttributeError):
-                pass
+                # cores for the likelihood's helper threads: the next ones of the same node
+                i0 = cand.index(pinned_core)
+                host_cores = [cand[(i0 + 1 + j) % len(cand)] for j in range(max(0, args.host_threads - 1))]
             if pinned_core in affinity0:
                 os.sched_setaffinity(0, {pinned_core})
                 if args.host_threads > 1:
