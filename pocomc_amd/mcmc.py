@@ -721,6 +721,12 @@ class LanedEngine:
             if e is last and not sharded:
                 # the last range's accept closes the set: total sums, sigma / mu update, sums + completion word to the host
                 e.accept_enqueue(beta, nu, host_sums=True, adapt=coefficients, n_total=n_total, others=self.lanes[:-1])
+            elif e is last:
+                # sharded: the last range's accept adds the ranges of this rank into the vector the ranks all-reduce
+                # (its "host copy" of the sums points at that device vector)
+                if e._step.h_sums != self._tot.data_ptr():
+                    e._step.h_sums = self._tot.data_ptr()
+                e.accept_enqueue(beta, nu, host_sums=True, others=self.lanes[:-1])
             else:
                 e.accept_enqueue(beta, nu, host_sums=False)
             if tm is not None:
@@ -728,13 +734,12 @@ class LanedEngine:
         t0 = clock() if tm is not None else 0.0
         stream = self.lanes[0]._stream
         if sharded:
-            # lane sums -> one vector -> all-reduce over the ranks -> sigma / mu update, sums + completion word to the host
+            # (this rank's total is in self._tot) -> all-reduce over the ranks -> sigma / mu update, sums + completion word
+            # to the host
             mode, c_sigma, c_mu, cap = coefficients
             self._flag_value += 1
             done = _lib.pmc_done_t(flag=self._h_flag.data_ptr(), value=self._flag_value, ticket=None)
             state = self.lanes[0].adapt_state.data_ptr()
-            _lib.check(lib.pmc_adapt_update(self._parts, K, D, self._tot.data_ptr(), None, None, 0, 0.0, 0.0, 0.0, 1.0,
-                                            None, stream), "pmc_adapt_update")
             allreduce_sums(self._tot, self.group)
             _lib.check(lib.pmc_adapt_update(self._tot_part, 1, D, None, self._h_tot.data_ptr(), state, mode, c_sigma,
                                             c_mu, cap, float(n_total), C.byref(done), stream), "pmc_adapt_update")
