@@ -116,6 +116,17 @@ MCMC_CASES = {
     "prwm_n128_d8_uniform":  dict(kind="preconditioned_rwm", N=128, D=8,  T=3, beta=0.6, nu=5.0, prior="uniform", target="rosenbrock", seed=4, n_max=4),
     "pcn_n128_d8_uniform":   dict(kind="pcn",                N=128, D=8,  T=3, beta=0.6, nu=5.0, prior="uniform", target="rosenbrock", seed=5, n_max=4),
     "rwm_n128_d8_normal":    dict(kind="rwm",                N=128, D=8,  T=3, beta=0.9, nu=5.0, prior="normal",  target="gauss",      seed=6, n_max=4),
+    # round 2: three more cases per M2 kernel (N >= 256, D in {10, 32}) and BASELINE config 3 (50-D bimodal mixture, maf6)
+    "prwm_n256_d10_normal":  dict(kind="preconditioned_rwm", N=256, D=10, T=3, beta=1.0, nu=5.0, prior="normal",  target="gauss",      seed=7, n_max=5),
+    "prwm_n320_d32_uniform": dict(kind="preconditioned_rwm", N=320, D=32, T=3, beta=0.5, nu=5.0, prior="uniform", target="corr",       seed=8, n_max=3),
+    "prwm_n256_d10_mixed":   dict(kind="preconditioned_rwm", N=256, D=10, T=3, beta=0.4, nu=5.0, prior="mixed",   target="gauss",      seed=9, n_max=4),
+    "pcn_n256_d10_normal":   dict(kind="pcn",                N=256, D=10, T=3, beta=1.0, nu=1e6, prior="normal",  target="gauss",      seed=10, n_max=5),
+    "pcn_n320_d32_uniform":  dict(kind="pcn",                N=320, D=32, T=3, beta=0.5, nu=5.0, prior="uniform", target="corr",       seed=11, n_max=3),
+    "pcn_n256_d10_mixed":    dict(kind="pcn",                N=256, D=10, T=3, beta=0.4, nu=3.5, prior="mixed",   target="gauss",      seed=12, n_max=4),
+    "rwm_n256_d10_uniform":  dict(kind="rwm",                N=256, D=10, T=3, beta=0.8, nu=5.0, prior="uniform", target="rosenbrock", seed=13, n_max=5),
+    "rwm_n320_d32_uniform":  dict(kind="rwm",                N=320, D=32, T=3, beta=0.5, nu=5.0, prior="uniform", target="corr",       seed=14, n_max=3),
+    "rwm_n256_d10_mixed":    dict(kind="rwm",                N=256, D=10, T=3, beta=0.4, nu=5.0, prior="mixed",   target="gauss",      seed=15, n_max=4),
+    "tpcn_n256_d50_bimodal": dict(kind="preconditioned_pcn", N=256, D=50, T=6, beta=0.5, nu=5.0, prior="uniform", target="bimodal",    seed=16, n_max=2),
 }
 
 
@@ -131,7 +142,7 @@ def build_case(name, scaler_cls):
              "normal": lambda: NormalPrior(3.0, D),
              "mixed": lambda: HalfBoundPrior(D)}[c["prior"]]()
     target = {"rosenbrock": rosenbrock, "gauss": std_gauss,
-              "corr": make_corr_gauss(D)}[c["target"]]
+              "corr": make_corr_gauss(D), "bimodal": make_bimodal(D)}[c["target"]]
     scaler = scaler_cls(D, bounds=prior.bounds, periodic=c.get("periodic"),
                         reflective=c.get("reflective"))
     x_fit = prior.rvs(4 * N, rng)

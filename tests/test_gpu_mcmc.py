@@ -31,6 +31,35 @@ def close(a, b, tol=TOL, what=""):
     np.testing.assert_allclose(a[fin], b[fin], rtol=tol, atol=tol * scale, err_msg=what)
 
 
+def rel_rows(a, b):
+    """Relative error per walker.  (N, D) arrays: ``max_j |a_ij - b_ij| / max_j |b_ij|`` (a walker's coordinates
+    are one vector: coordinates that happen to be near zero are measured against the walker's own size, not
+    against the largest element of the whole array); (N,) arrays: ``|a_i - b_i| / |b_i|``.  Non-finite entries
+    must coincide and count as zero error."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    fin = np.isfinite(b)
+    assert (np.isfinite(a) == fin).all() and ((a == b) | fin).all()
+    d = np.where(fin, np.abs(np.where(fin, a, 0.0) - np.where(fin, b, 0.0)), 0.0)
+    ref = np.where(fin, np.abs(b), 0.0)
+    if a.ndim == 2:
+        d, ref = d.max(axis=1), ref.max(axis=1)
+    return d / np.maximum(ref, np.finfo(np.float64).tiny)
+
+
+def close_rel(a, b, tol=TOL, what="", cancel=None):
+    """Pure relative comparison (north star: 1e-5 relative fp32), walker by walker -- no absolute slack scaled by
+    the array's largest element.  ``cancel``: for a quantity that is a SUM of terms of either sign (a log-determinant
+    of the float32 flow can pass through zero), the per-walker size of the sum's terms; the error is then measured
+    against ``max(|b_i|, cancel_i)`` -- stated per call, never a global maximum."""
+    r = rel_rows(a, b)
+    if cancel is not None:
+        b = np.asarray(b, np.float64)
+        fin = np.isfinite(b)
+        r = r * np.where(fin, np.abs(b), 0.0) / np.maximum(np.where(fin, np.abs(b), 0.0), np.asarray(cancel, np.float64))
+    assert r.max() <= tol, f"{what}: max relative error {r.max():.3e} > {tol:g} ({int((r > tol).sum())} of {r.size} walkers)"
+    return float(r.max())
+
+
 def product_case(name):
     """The case with the product's scaler and flow."""
     from pocomc_amd import Flow, Reparameterize
@@ -88,6 +117,7 @@ def test_step_teacher_forced(name):
     mu = np.array(geo.t_mean, dtype=float)
     prev = None
     n_flips = 0
+    worst = {}
     for i, tr in enumerate(trace):
         if prev is not None:
             # teacher forcing: start every step from the oracle's state
@@ -103,35 +133,63 @@ def test_step_teacher_forced(name):
         elif pre:
             # the theta the device derived from u must be the oracle's
             th0, l0 = omcmc.flow_numpy_wrapper(funcs["flow"]).forward(state["u"])
-            close(eng.theta32.cpu().numpy(), th0, what="theta0")
-            close(eng.ldjf.cpu().numpy(), l0, what="logdetj_flow0")
+            close_rel(eng.theta32.cpu().numpy(), th0, TOL, "theta0")
+            close_rel(eng.ldjf.cpu().numpy(), l0, TOL, "logdetj_flow0", cancel=1.0)
             eng.theta32.copy_(torch.from_numpy(th0)); eng.ldjf.copy_(torch.from_numpy(l0))
         if tpcn:
             eng.set_mu(mu)
         rec = rng.record[i]
         eng.propose(sigma, nu, dict(gamma=rec.get("gamma"), z=rec["z"], u=rec["u"]))
-        close(eng.p_theta64.cpu().numpy(), tr["theta_prime"], 1e-12 if not pre else 1e-6, "theta_prime")
-        close(eng.p_u.cpu().numpy(), tr["u_prime"], TOL, "u_prime")
-        close(eng.p_x.cpu().numpy(), tr["x_prime"], TOL, "x_prime")
-        close(eng.p_logdetj.cpu().numpy(), tr["logdetj_prime"], TOL, "logdetj_prime")
+        # ---- proposal: pure relative per walker (north star 1e-5; theta' itself is float64 arithmetic).  Log-determinants
+        # are compared as determinants: |d log| <= 1e-5 where |log| < 1 (the sum of the flow's log-scales passes through zero)
+        worst["theta_prime"] = max(worst.get("theta_prime", 0), close_rel(
+            eng.p_theta64.cpu().numpy(), tr["theta_prime"], 1e-12 if not pre else 2e-7, "theta_prime"))
+        worst["u_prime"] = max(worst.get("u_prime", 0), close_rel(eng.p_u.cpu().numpy(), tr["u_prime"], TOL, "u_prime"))
+        worst["x_prime"] = max(worst.get("x_prime", 0), close_rel(eng.p_x.cpu().numpy(), tr["x_prime"], TOL, "x_prime"))
+        worst["logdetj_prime"] = max(worst.get("logdetj_prime", 0), close_rel(
+            eng.p_logdetj.cpu().numpy(), tr["logdetj_prime"], TOL, "logdetj_prime", cancel=1.0))
         if pre:
-            close(eng.p_ldjf.cpu().numpy(), tr["logdetj_flow_prime"], TOL, "logdetj_flow_prime")
+            worst["logdetj_flow_prime"] = max(worst.get("logdetj_flow_prime", 0), close_rel(
+                eng.p_ldjf.cpu().numpy(), tr["logdetj_flow_prime"], TOL, "logdetj_flow_prime", cancel=1.0))
         calls, _ = eng.evaluate(pfuncs["logprior"], pfuncs["loglike"])
-        fin = np.isfinite(tr["logl_prime"])
         assert abs(calls - int(tr["finite"].sum())) <= 1
+        cur = eng.download()                                  # the state the accept kernel starts from
+        cur_ldjf = eng.ldjf.cpu().numpy().astype(np.float64) if pre else None
         sums = eng.accept_reduce(c["beta"], nu, want_mask=True)
         alpha = eng.alpha.cpu().numpy()
         acc = eng.h_accept.numpy().astype(bool)
-        # alpha: relative agreement where it is not saturated
+        # ---- M1d: alpha is mcmc.py:124-134 applied to what the device holds (its own x', the host's logl'/logp' for
+        # that x'): float64 arithmetic, checked to 1e-9 relative.  Against the oracle's alpha the difference is the
+        # likelihood's response to a 1e-7-relative change of x' (Rosenbrock: d logl ~ 1e4 |dx|), not kernel error:
+        # |d log alpha| <= 2e-3 is asserted below as well.
+        p_logl, p_logp = eng.p_logl.cpu().numpy(), eng.p_logp.cpu().numpy()
+        expo = (p_logl * c["beta"] - cur["logl"] * c["beta"] + p_logp - cur["logp"]
+                + eng.p_logdetj.cpu().numpy() - cur["logdetj"])
+        if pre:
+            expo = expo + eng.p_ldjf.cpu().numpy().astype(np.float64) - cur_ldjf
+        if tpcn:
+            A = -(D + nu) / 2 * np.log(1 + eng.p_quad.cpu().numpy() / nu)
+            B = -(D + nu) / 2 * np.log(1 + eng.quad.cpu().numpy() / nu)
+            expo = expo - A + B
+        with np.errstate(over="ignore", invalid="ignore"):
+            alpha_chk = np.minimum(1.0, np.exp(expo))
+        alpha_chk[np.isnan(alpha_chk)] = 0.0
+        np.testing.assert_allclose(alpha, alpha_chk, rtol=1e-9, atol=1e-300)
         np.testing.assert_allclose(alpha, tr["alpha"], rtol=2e-3, atol=2e-5)
-        ambiguous = np.abs(rec["u"] - tr["alpha"]) < 1e-3 * np.maximum(tr["alpha"], 1e-3)
+        # ---- M1e: the decision is exactly u_rand < alpha; it differs from the oracle's only where u_rand lies between
+        # the two alphas.  Flip budget: 2 per case over all steps (expected: sum |alpha_dev - alpha_oracle| ~ 0.1)
+        assert np.array_equal(acc, rec["u"] < alpha), f"step {i}: decision != (u < alpha)"
         flips = acc != tr["accept"]
-        assert not (flips & ~ambiguous).any(), f"step {i}: unexplained accept flips"
+        lo_, hi_ = np.minimum(alpha, tr["alpha"]), np.maximum(alpha, tr["alpha"])
+        assert ((rec["u"][flips] >= lo_[flips]) & (rec["u"][flips] <= hi_[flips])).all()
         n_flips += int(flips.sum())
         ok = ~flips
         post = eng.download()
         for k in ("u", "x", "logdetj", "logl", "logp"):
-            close(post[k][ok], tr[k][ok], TOL, f"post {k}")
+            # non-flipped walkers: pure 1e-5 relative (accepted ones carry the device's proposal, the others the oracle's
+            # own previous state bit for bit)
+            worst["post_" + k] = max(worst.get("post_" + k, 0), close_rel(
+                post[k][ok], tr[k][ok], TOL, f"post {k}", cancel=None if k in ("u", "x") else 1.0))
         if not flips.any():
             np.testing.assert_allclose(sums[0] / N, tr["alpha"].mean(), rtol=1e-4, atol=1e-6)
             np.testing.assert_allclose(sums[1] / N, (tr["logl"] + tr["logp"]).mean(), rtol=1e-5, atol=1e-5)
@@ -139,6 +197,7 @@ def test_step_teacher_forced(name):
             moved = tr["theta"] if pre else tr["u"]
             np.testing.assert_allclose(sums[4:4 + D] / N, moved.mean(axis=0, dtype=np.float64), rtol=1e-4, atol=1e-5)
         prev = tr
+    print(f"{name}: accept flips {n_flips} / {N * len(trace)}; worst relative errors {worst}")
     assert n_flips <= 2
 
 
@@ -159,13 +218,32 @@ def test_kernel_call_matches_reference_golden(name, golden_dir):
         if not same_path:
             continue
         assert abs(res["calls"] - int(g[f"{tag}/calls"])) <= 2
-        # a flipped marginal decision perturbs sigma for everybody afterwards: demand that
-        # (almost) every particle followed the reference's trajectory
-        for k in ("x", "logl"):
-            a, b = res[k], g[f"{tag}/{k}"]
-            fin = np.isfinite(b)
-            rel = np.abs(a - b)[fin] / np.maximum(1.0, np.abs(b[fin]))
-            assert (rel < 1e-3).mean() > 0.97, f"{tag}/{k}: {(rel < 1e-3).mean()}"
+        # Walker by walker against the reference's final state, pure relative (rel_rows).  A walker is OFF the
+        # reference's trajectory only through an accept flip (u_rand between the float32 flow's alpha and the
+        # reference's: teacher-forced test above).  Budget, stated: in a ONE-step call (n_max = 1) at most 2
+        # walkers may be off at 1e-5 relative.  In a longer call every walker's step k+1 proposal is scaled by
+        # sigma_{k+1} = f(mean alpha_k) (mcmc.py:152-156): the float32 flow's noise in alpha (and any flip, 1/N)
+        # reaches ALL walkers through sigma and mu, so the set follows the reference at ~1e-3, not 1e-5; the
+        # step-by-step 1e-5 statement for those steps is the teacher-forced test.
+        off = np.zeros(len(res["x"]), dtype=bool)
+        worst = 0.0
+        for k in ("u", "x", "logdetj", "logl", "logp"):
+            r = rel_rows(res[k], g[f"{tag}/{k}"])
+            if res[k].ndim == 1:                       # logs: compared as densities / determinants below |log| = 1
+                r = r * np.abs(g[f"{tag}/{k}"]) / np.maximum(np.abs(g[f"{tag}/{k}"]), 1.0)
+                r = np.where(np.isfinite(r), r, 0.0)
+            off |= r > TOL
+            worst = max(worst, float(r[~off].max()) if (~off).any() else 0.0)
+        print(f"{tag}: {int(off.sum())} of {off.size} walkers off the reference trajectory at {TOL:g} relative "
+              f"(worst of the others {worst:.2e}); sigma ratio {res['proposal_scale'] / float(g[f'{tag}/proposal_scale']) - 1.0:.2e}")
+        if n_max == 1:
+            assert off.sum() <= 2, f"{tag}: {int(off.sum())} walkers off the reference trajectory"
+        else:
+            for k in ("x", "logl"):
+                a, b = res[k], g[f"{tag}/{k}"]
+                fin = np.isfinite(b)
+                rel = np.abs(a - b)[fin] / np.maximum(1.0, np.abs(b[fin]))
+                assert (rel < 1e-3).mean() > 0.97, f"{tag}/{k}: {(rel < 1e-3).mean()}"
         np.testing.assert_allclose(res["accept"], g[f"{tag}/accept"], atol=0.02)
         np.testing.assert_allclose(res["proposal_scale"], g[f"{tag}/proposal_scale"], rtol=5e-3)
 
