@@ -32,6 +32,20 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dens
 PEAK_HBM_GBS = 8000.0
 
 
+def kernel_source_hash(root=ROOT):
+    """sha256 over the HIP sources and headers the library is built from: ties a committed PMC measurement
+    (profiles/*_traffic.json) to the kernels it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(root, "pocomc_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    h.update(open(os.path.join(root, "include", "pocomc_amd.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def rosenbrock(x):
     """README.md:53-55 formula, written with two temporaries instead of eight (same values)."""
     a, b = x[:, ::2], x[:, 1::2]
@@ -90,23 +104,21 @@ def cpu_baseline(D, n, beta, flat, spec, x0, u0_unused, geo, sigma0, seed, max_s
     t_probe = time.perf_counter()
     maf.inverse(np.zeros((256, D), np.float32))
     per_row = (time.perf_counter() - t_probe) / 256
-    while n_s > 500 and per_row * n_s * 3 > max_seconds:
+    while n_s > 500 and per_row * n_s * 20 > max_seconds:
         n_s //= 2
     x = x0[:n_s]
     u = sc.forward(x)
     state = dict(u=u, x=x, logdetj=sc.inverse(u)[1], logl=target(x), logp=prior.logpdf(x), beta=beta, blobs=None)
     funcs = dict(loglike=lambda xx: (target(xx), None), logprior=prior.logpdf, scaler=sc, flow=flow,
                  theta_geometry=geo)
-    steps = 3                                   # per thread count ~4-8 s of host work at 1e4 x 32
-    opts = dict(n_max=steps, n_steps=10 ** 9, progress_bar=None, proposal_scale=sigma0)
     import torch
     from threadpoolctl import threadpool_limits
     max_threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
     nt0 = torch.get_num_threads()
-    by_threads = {}
-    # 1 thread is the reference's default (pytorch_threads=1, sampler.py:168); more threads only pay for the
-    # float32 matrix products of the flow (1e4 x 128 x 128), and too many of them cost more than they give
-    for th in sorted({1, min(8, max_threads), min(32, max_threads), max_threads}):
+    by_threads, steps_by_threads, secs_by_threads = {}, {}, {}
+
+    def run(th, steps):
+        opts = dict(n_max=steps, n_steps=10 ** 9, progress_bar=None, proposal_scale=sigma0)
         torch.set_num_threads(th)
         with threadpool_limits(limits=th):
             np.random.seed(seed)
@@ -115,7 +127,19 @@ def cpu_baseline(D, n, beta, flat, spec, x0, u0_unused, geo, sigma0, seed, max_s
             t0 = time.perf_counter()
             res = omcmc.preconditioned_pcn(st, funcs, opts)
             dt = time.perf_counter() - t0
-        by_threads[th] = res["steps"] / dt * (n_s / 1e4)     # steps/s of a 1e4-walker population
+        return res["steps"], dt
+
+    # (a) 1 thread = the reference's default (pytorch_threads=1, sampler.py:168), (b) all host cores; both
+    # printed.  20 steps each; the all-cores leg (BLAS threads only pay for the float32 products of the flow, and 256 of
+    # them cost more than they give) is time-boxed to ~20 s through a 2-step probe, never below 5 steps.
+    for th in sorted({1, max_threads}):
+        steps = 20
+        if th > 1:
+            k, dt = run(th, 2)
+            steps = int(min(20, max(5, (max_seconds * 0.66) / (dt / k))))
+        k, dt = run(th, steps)
+        by_threads[th] = k / dt * (n_s / 1e4)               # steps/s of a 1e4-walker population
+        steps_by_threads[th], secs_by_threads[th] = k, dt
     torch.set_num_threads(nt0)
     threads = max(by_threads, key=by_threads.get)
     value = by_threads[threads]
@@ -128,11 +152,33 @@ def cpu_baseline(D, n, beta, flat, spec, x0, u0_unused, geo, sigma0, seed, max_s
     except OSError:
         pass
     return {"value": value, "unit": "steps/s (1e4 walkers, 32-D)", "cores": int(threads), "kind": "port",
-            "sample": f"{res['steps']} steps of {n_s} walkers per thread count (oracle: numpy f64 step + f32 D-pass MAF "
-                      f"inverse; best of {sorted(by_threads)} threads = {threads}, host cpu_count={os.cpu_count()}), "
-                      "scaled linearly to 1e4 walkers",
+            "sample": f"{steps_by_threads[threads]} steps of {n_s} walkers (oracle: numpy f64 step + f32 D-pass MAF inverse, "
+                      f"{threads} BLAS/torch thread(s)); the other thread count is reported next to it "
+                      f"(host cpu_count={os.cpu_count()}); scaled linearly to 1e4 walkers",
             "cpu_model": model, "host_cpu_count": os.cpu_count(),
+            "threads_1": {"steps_per_s": by_threads[1], "steps": steps_by_threads[1], "seconds": secs_by_threads[1]},
+            "threads_all": {"threads": int(max_threads), "steps_per_s": by_threads[max_threads],
+                            "steps": steps_by_threads[max_threads], "seconds": secs_by_threads[max_threads]},
             "steps_per_s_by_threads": {str(k): v for k, v in sorted(by_threads.items())}}
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` without a launcher: re-exec under ``torch.distributed.run`` with one rank per
+    GPU (RCCL).  On a box with fewer GPUs than N the ranks share device 0 over gloo -- a functional check of the
+    N > 1 code path, flagged ``shared_gpu`` in the output line."""
+    import socket
+    import subprocess
+    import torch
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.device_count() < args.gpus:
+        env["PMC_BENCH_BACKEND"], env["PMC_BENCH_SHARE_GPU"] = "gloo", "1"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -170,6 +216,8 @@ def main():
     ap.add_argument("--flow", default="maf3", help="maf3 | maf6 | maf12 | nsf3 | nsf6 | nsf12 (BASELINE configs use maf3)")
     ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "triangular_v1", "triangular_v2", "triangular_v3"], default="auto")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -472,31 +520,41 @@ def main():
                        args.inverse, ("maf_inverse_tri5_kernel" if lib.pmc_debug_inverse_uses_duo(
                            ctypes.byref(flow._desc), n_launch) else "maf_inverse_tri4_kernel")
                        if spec.nOT <= 8 else "maf_inverse_tri2_kernel"))
-    # HBM bytes per launch of the dominant kernel: PMC passes cannot run inside this process, the value
-    # is the committed rocprofv3 measurement of this very command (scripts/collect_profile.sh -> profiles/r01_f_*)
+    # HBM bytes per launch of the dominant kernel: PMC passes cannot run inside this process; the value is the
+    # committed rocprofv3 measurement of this very command (scripts/collect_profile.sh -> profiles/*_traffic.json),
+    # used only when it was taken on the kernel sources this run was built from (their hash is stored with it) and
+    # for the same kernel / walkers per launch -- otherwise null
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_f_traffic.json")))
-        if (n == 10000 and D == 32 and args.inverse == "auto" and args.flow == "maf3"
-                and pm.get("kernel", "").startswith(roof_kernel) and pm.get("walkers_per_launch", 10000) == n_launch):
-            traffic = {"hbm_bytes_per_launch": pm["hbm_bytes_per_launch"], "unit": "B", "source": pm["source"],
-                       "correction": pm["correction"], "algorithmic_bytes": pm.get("algorithmic_bytes", {}).get("total"),
-                       "note": pm.get("note")}
-    except (OSError, KeyError, ValueError):
+        src_hash = kernel_source_hash(ROOT)
+        for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True):
+            pm = json.load(open(os.path.join(ROOT, "profiles", cand)))
+            if (pm.get("kernel_source_hash") == src_hash and n == 10000 and D == 32 and args.inverse == "auto"
+                    and args.flow == "maf3" and pm.get("kernel", "").startswith(roof_kernel)
+                    and pm.get("walkers_per_launch", 10000) == n_launch):
+                traffic = {"hbm_bytes_per_launch": pm["hbm_bytes_per_launch"], "unit": "B", "source": pm["source"],
+                           "correction": pm["correction"], "algorithmic_bytes": pm.get("algorithmic_bytes", {}).get("total"),
+                           "kernel_source_hash": src_hash, "note": pm.get("note")}
+                break
+    except (OSError, KeyError, ValueError, ImportError):
         pass
-    achieved = algo_flops / t_inv / 1e12
+    # the roofline fraction is what the kernel EXECUTES (the masked multiply-adds, once) over the f32 MFMA peak; the
+    # SURVEY 8(d) naive-equivalent figure ((D+1) dense passes per transform, which this algorithm does not perform) is
+    # kept as a side key
+    achieved = actual_flops / t_inv / 1e12
     roofline = {"bound": "mfma", "kernel": roof_kernel, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                 "traffic": None if traffic is None else traffic["hbm_bytes_per_launch"],     # HBM bytes per launch (PMC)
                 "traffic_detail": traffic,
                 "avg_launch_us": inv_us_live, "launches_timed": len(ev_pairs[::args.event_every]),
                 "walkers_per_launch": n_launch,
-                "note": "achieved = SURVEY 8(d) naive-equivalent flops ((D+1)*F_fwd per walker) / launch time; the "
-                        "triangular sweep executes only the masked MACs once, so frac > 1 is an algorithmic gain"
-                        + ("; the launch also proposes theta' for its walkers (fused proposal prologue, ~15 us)" if fused else ""),
+                "flops_per_launch": actual_flops,
+                "note": "achieved = executed flops (2 x the unmasked multiply-adds of the flow, each once: the triangular "
+                        "sweep) / launch time, measured with a HIP event pair inside the timed region"
+                        + ("; the launch also proposes theta' for its walkers (fused proposal prologue)" if fused else ""),
                 "fused_proposal": bool(fused),
-                "actual_tflops": actual_flops / t_inv / 1e12,
-                "actual_frac": actual_flops / t_inv / 1e12 / PEAK_F32_MFMA_TFLOPS}
+                "naive_equivalent": {"flops_per_launch": algo_flops, "tflops": algo_flops / t_inv / 1e12,
+                                     "note": "SURVEY 8(d) F_inv = (D+1) F_fwd per walker: zuko's D-pass algorithm, not executed"}}
     # HBM-nominal sweeps: achieved GB/s against ~8 TB/s.  At this size every array (1.28 MB f32 /
     # 2.56 MB f64) is cache-resident, so these kernels are launch / latency limited -- reported with that caveat.
     b_accept = n * 4 * (6 * D + 13)                           # SURVEY figure (fp32 state)
@@ -567,7 +625,11 @@ def main():
                       "flow_trained_50_epochs": flow_trained, "parallelism": f"walker-sharded x{world}",
                       "lanes": len(leng.lanes) if leng is not None else 1,
                       "pipelined_device_adaptation": bool(pipelined and leng is not None),
-                      "inverse_algo": args.inverse, "host_threads": args.host_threads, "host_x_order": args.x_order, "prior_on_device": bool(device_prior), "accept_rate": float(ad.mean_alpha)},
+                      "inverse_algo": args.inverse, "host_threads": args.host_threads, "host_x_order": args.x_order, "prior_on_device": bool(device_prior),
+                      "accept_rate": float((ad_l if leng is not None else ad).mean_alpha),
+                      "backend": (dist.get_backend() if world > 1 else None),
+                      "ranks_reported_by_backend": (dist.get_world_size() if world > 1 else 1),
+                      "shared_gpu": bool(os.environ.get("PMC_BENCH_SHARE_GPU"))},
            "roofline": roofline,
            "roofline_sweeps": sweeps,
            "flow_fit": flow_fit,

@@ -216,7 +216,7 @@ extern "C" int pmc_wait_flag(const int64_t* flag, int64_t value, double timeout_
             struct timespec t;
             clock_gettime(CLOCK_MONOTONIC, &t);
             if (it == 63) t0 = t;
-            if ((double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec) > timeout_s)
+            if (timeout_s > 0.0 && (double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec) > timeout_s)
                 return pmc_fail("pmc_wait_flag: timed out waiting for the device");
         }
     }

@@ -39,7 +39,7 @@ def torch_double_to_float(x: torch.Tensor, warn: bool = True) -> torch.Tensor:
 class Flow:
     """Masked autoregressive flow resident on one MI355X."""
 
-    def __init__(self, n_dim, flow="maf3", device=None, seed=None):
+    def __init__(self, n_dim, flow="nsf3", device=None, seed=None):       # default as pocomc/flow.py:46
         self.n_dim = int(n_dim)
         if isinstance(flow, MAFSpec):
             spec = flow

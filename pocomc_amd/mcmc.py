@@ -107,6 +107,12 @@ class Adaptation:
         return i >= self.n_max
 
 
+# How long the driver thread spins on a completion word before it gives up (seconds; <= 0: for ever).  In the sharded
+# pipelined step the word sits behind the all-reduce, i.e. behind the slowest rank's host likelihood: a run with an
+# expensive or imbalanced likelihood sets this through option_dict["wait_timeout"] / PMC_WAIT_TIMEOUT.
+import os as _os
+WAIT_TIMEOUT_S = float(_os.environ.get("PMC_WAIT_TIMEOUT", "600"))
+
 _POOLS = {}
 _PINNED_FREE = {}
 
@@ -464,7 +470,7 @@ class StepEngine:
             # x', finite, logp' are complete at this event / completion word; the next step's variates are
             # generated behind it
             if self._direct_now:
-                _lib.check(self.lib.pmc_wait_flag(self.h_done.data_ptr(), self.step_idx + 1, 30.0), "pmc_wait_flag")
+                _lib.check(self.lib.pmc_wait_flag(self.h_done.data_ptr(), self.step_idx + 1, WAIT_TIMEOUT_S), "pmc_wait_flag")
             else:
                 _lib.check(self.lib.pmc_event_synchronize(self._ev_pre), "pmc_event_synchronize")
         else:
@@ -573,7 +579,7 @@ class StepEngine:
     def accept_wait(self):
         """Wait for what accept_enqueue started; returns this engine's host sums (valid with host_sums=True)."""
         if self._direct_now and self._host_sums and not self._want_mask:   # (the mask copy is a stream operation)
-            _lib.check(self.lib.pmc_wait_flag(self.h_done.data_ptr() + 8, self.step_idx + 1, 30.0), "pmc_wait_flag")
+            _lib.check(self.lib.pmc_wait_flag(self.h_done.data_ptr() + 8, self.step_idx + 1, WAIT_TIMEOUT_S), "pmc_wait_flag")
         else:
             _lib.check(self.lib.pmc_stream_synchronize(self._stream), "pmc_stream_synchronize")
         self.step_idx += 1
@@ -749,7 +755,7 @@ class LanedEngine:
                 e.propose(None, nu, step=e.step_idx + 1)
         t2 = clock() if tm is not None else 0.0
         if sharded:
-            _lib.check(lib.pmc_wait_flag(self._h_flag.data_ptr(), self._flag_value, 30.0), "pmc_wait_flag")
+            _lib.check(lib.pmc_wait_flag(self._h_flag.data_ptr(), self._flag_value, WAIT_TIMEOUT_S), "pmc_wait_flag")
             sums = self._h_tot.numpy()
         else:
             sums = last.accept_wait()                       # (increments the last lane's step counter)
@@ -871,6 +877,9 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
                          shard_offset=option_dict.get("shard_offset", 0), seed=seed, x_order=x_order)
         tune = lambda **kw: [setattr(eng, k, v) for k, v in kw.items()]
     laned = isinstance(eng, LanedEngine)
+    if option_dict.get("wait_timeout") is not None:
+        global WAIT_TIMEOUT_S
+        WAIT_TIMEOUT_S = float(option_dict["wait_timeout"])
     for key in ("host_direct", "rng_prefill", "spin_wait"):
         if key in option_dict:
             tune(**{key: bool(option_dict[key])})

@@ -9,6 +9,9 @@ import os
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash                               # noqa: E402
+
 out, tag, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
 short = lambda n: n.split("(")[0][:64] if not n.startswith("void ") else n[5:].split("(")[0][:64]
 
@@ -33,7 +36,7 @@ if kt:
     by = defaultdict(list)
     for r in csv.DictReader(open(kt)):
         n = short(r["Kernel_Name"])
-        if any(w in n for w in ("tri4", "tri5", "tri_nsf", "scaler_inverse", "accept_kernel", "rng_fill", "adapt_update")):
+        if any(w in n for w in ("tri4", "tri5", "tri6", "tri_nsf", "scaler_inverse", "accept_kernel", "rng_fill", "adapt_update")):
             by[(n, r.get("Grid_Size") or r.get("Grid_Size_X", "?"))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print("\n## step kernels by launch size (grid = work-items)")
     print(f"{'kernel':64s} {'grid':>9s} {'calls':>7s} {'avg_us':>10s}")
@@ -49,7 +52,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         key = (short(r["Kernel_Name"]), r.get("Grid_Size", "?"))
         pmc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("\n## PMC counters, mean per launch (kernel, grid)")
-want = ("tri4", "tri5", "tri_nsf", "scaler_inverse", "accept_kernel", "lossgrad", "forward_wg")
+want = ("tri4", "tri5", "tri6", "tri_nsf", "scaler_inverse", "accept_kernel", "lossgrad", "forward_wg")
 traffic = None
 for key in sorted(pmc, key=lambda k: -len(pmc[k].get("SQ_WAVE_CYCLES", []))):
     if not any(w in key[0] for w in want):
@@ -58,12 +61,12 @@ for key in sorted(pmc, key=lambda k: -len(pmc[k].get("SQ_WAVE_CYCLES", []))):
     m = {c: sum(v) / len(v) for c, v in pmc[key].items()}
     for c in sorted(m):
         print(f"    {c:32s} {m[c]:16.1f}   ({len(pmc[key][c])} launches)")
-    if ("tri5" in key[0] or "tri4" in key[0]) and "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+    if any(w in key[0] for w in ("tri6", "tri5", "tri4")) and "FETCH_SIZE" in m and "WRITE_SIZE" in m:
         cand = {"kernel": key[0], "grid": key[1], "launches": len(pmc[key]["FETCH_SIZE"]),
                 "FETCH_SIZE_KB": m["FETCH_SIZE"], "WRITE_SIZE_KB": m["WRITE_SIZE"],
                 "hbm_bytes_per_launch": (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0,
                 "correction": "2x FETCH_SIZE (gfx950), separate --pmc passes",
-                "source": f"profiles/{tag}_summary.txt"}
+                "source": f"profiles/{tag}_summary.txt", "kernel_source_hash": kernel_source_hash()}
         if traffic is None or cand["launches"] > traffic["launches"]:
             traffic = cand
 if traffic:

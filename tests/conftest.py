@@ -9,6 +9,9 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 if GOLDEN not in sys.path:
     sys.path.insert(0, GOLDEN)
+HERE = os.path.join(ROOT, "tests")
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)                 # tests/parity.py (comparison helpers)
 
 
 def pytest_configure(config):

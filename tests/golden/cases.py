@@ -130,19 +130,40 @@ MCMC_CASES = {
 }
 
 
+def make_funnel(D):
+    """Neal's funnel as a likelihood (SURVEY.md 8(d) cfg 5): x0 ~ N(0, 3^2), x_i ~ N(0, e^{x0})."""
+    def f(x):
+        x0 = x[:, 0]
+        return (-x0 ** 2 / 18.0 - 0.5 * np.sum(x[:, 1:] ** 2, axis=1) * np.exp(-x0) - 0.5 * (D - 1) * x0)
+    return f
+
+
+# BASELINE-size cases that the reference's per-walker Python loops / the D-pass oracle inverse do not finish in
+# seconds: no golden vectors, the tests pin them through the oracle with a verified inverse (test_gpu_config.py)
+BIG_CASES = {
+    # config 5: 128-D funnel, 5000 walkers per GPU, 8-transform MAF, H = 512
+    "tpcn_n5000_d128_funnel": dict(kind="preconditioned_pcn", N=5000, D=128, T=8, beta=0.5, nu=5.0, prior="uniform30", target="funnel", seed=21, n_max=2),
+    # config 3 at its size: 50-D bimodal mixture, 1e4 walkers, maf6
+    "tpcn_n10000_d50_bimodal": dict(kind="preconditioned_pcn", N=10000, D=50, T=6, beta=0.5, nu=5.0, prior="uniform", target="bimodal", seed=22, n_max=2),
+    # config 2: 32-D correlated Gaussian, 1e4 walkers, maf3
+    "tpcn_n10000_d32_corr": dict(kind="preconditioned_pcn", N=10000, D=32, T=3, beta=0.5, nu=5.0, prior="uniform", target="corr", seed=23, n_max=2),
+}
+
+
 def build_case(name, scaler_cls):
     """Instantiate a case: returns ``(state_dict, function_dict, option_dict, aux)``.
 
     ``scaler_cls`` is the ``Reparameterize`` class to use (the reference's when
     generating goldens, the oracle's / the product's in tests)."""
-    c = MCMC_CASES[name]
+    c = MCMC_CASES[name] if name in MCMC_CASES else BIG_CASES[name]
     N, D = c["N"], c["D"]
     rng = np.random.default_rng(1000 + c["seed"])
     prior = {"uniform": lambda: UniformPrior(-10.0, 10.0, D),
+             "uniform30": lambda: UniformPrior(-30.0, 30.0, D),
              "normal": lambda: NormalPrior(3.0, D),
              "mixed": lambda: HalfBoundPrior(D)}[c["prior"]]()
     target = {"rosenbrock": rosenbrock, "gauss": std_gauss,
-              "corr": make_corr_gauss(D), "bimodal": make_bimodal(D)}[c["target"]]
+              "corr": make_corr_gauss(D), "bimodal": make_bimodal(D), "funnel": make_funnel(D)}[c["target"]]
     scaler = scaler_cls(D, bounds=prior.bounds, periodic=c.get("periodic"),
                         reflective=c.get("reflective"))
     x_fit = prior.rvs(4 * N, rng)

@@ -22,42 +22,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
-def close(a, b, tol=TOL, what=""):
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    fin = np.isfinite(b)
-    assert (np.isfinite(a) == fin).all(), what
-    assert ((a == b) | fin).all(), what                     # same +-inf
-    scale = max(1.0, float(np.abs(b[fin]).max()) if fin.any() else 1.0)
-    np.testing.assert_allclose(a[fin], b[fin], rtol=tol, atol=tol * scale, err_msg=what)
-
-
-def rel_rows(a, b):
-    """Relative error per walker.  (N, D) arrays: ``max_j |a_ij - b_ij| / max_j |b_ij|`` (a walker's coordinates
-    are one vector: coordinates that happen to be near zero are measured against the walker's own size, not
-    against the largest element of the whole array); (N,) arrays: ``|a_i - b_i| / |b_i|``.  Non-finite entries
-    must coincide and count as zero error."""
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    fin = np.isfinite(b)
-    assert (np.isfinite(a) == fin).all() and ((a == b) | fin).all()
-    d = np.where(fin, np.abs(np.where(fin, a, 0.0) - np.where(fin, b, 0.0)), 0.0)
-    ref = np.where(fin, np.abs(b), 0.0)
-    if a.ndim == 2:
-        d, ref = d.max(axis=1), ref.max(axis=1)
-    return d / np.maximum(ref, np.finfo(np.float64).tiny)
-
-
-def close_rel(a, b, tol=TOL, what="", cancel=None):
-    """Pure relative comparison (north star: 1e-5 relative fp32), walker by walker -- no absolute slack scaled by
-    the array's largest element.  ``cancel``: for a quantity that is a SUM of terms of either sign (a log-determinant
-    of the float32 flow can pass through zero), the per-walker size of the sum's terms; the error is then measured
-    against ``max(|b_i|, cancel_i)`` -- stated per call, never a global maximum."""
-    r = rel_rows(a, b)
-    if cancel is not None:
-        b = np.asarray(b, np.float64)
-        fin = np.isfinite(b)
-        r = r * np.where(fin, np.abs(b), 0.0) / np.maximum(np.where(fin, np.abs(b), 0.0), np.asarray(cancel, np.float64))
-    assert r.max() <= tol, f"{what}: max relative error {r.max():.3e} > {tol:g} ({int((r > tol).sum())} of {r.size} walkers)"
-    return float(r.max())
+from parity import close, rel_rows, close_rel                      # noqa: E402
 
 
 def product_case(name):
@@ -87,22 +52,47 @@ def test_inputs_built_with_device_scaler_match_golden(name, golden_dir):
         np.testing.assert_allclose(state[k], g[f"mcmc/{name}/in/{k}"], rtol=1e-11, atol=1e-11, err_msg=k)
 
 
+class VerifiedInverse(TorchFlowAdapter):
+    """For sizes where zuko's D-pass inverse (``oracle.maf.OracleMAF.inverse``: (D+1) dense passes per transform) does
+    not finish in seconds: the inverse comes from the device and is VERIFIED by the oracle before the oracle's step
+    uses it -- a bijection's inverse is right iff the oracle's forward map takes it back to the input
+    (``tests/test_flow.py:88``) and the log-determinants are opposite (``:164``)."""
+
+    def __init__(self, maf, product_flow, tol=TOL):
+        super().__init__(maf)
+        self.product_flow, self.tol, self.worst = product_flow, tol, 0.0
+
+    def inverse(self, theta):
+        x, l = self.product_flow.inverse(theta)
+        back, lf = self.maf.forward(x.numpy())
+        # the forward map amplifies an error of x by the flow's Jacobian; measured per walker against |theta|
+        self.worst = max(self.worst, close_rel(back, theta.numpy(), 10 * self.tol, "oracle.forward(device inverse)"))
+        close_rel(-lf, l.numpy(), 10 * self.tol, "ladj antisymmetry", cancel=1.0)
+        return x, l
+
+
 @pytest.mark.parametrize("name", list(cases.MCMC_CASES))
 def test_step_teacher_forced(name):
+    teacher_forced(name)
+
+
+def teacher_forced(name, verified_inverse=False):
     from pocomc_amd.mcmc import StepEngine
-    c = cases.MCMC_CASES[name]
+    c = cases.MCMC_CASES[name] if name in cases.MCMC_CASES else cases.BIG_CASES[name]
     kind = c["kind"]
     pre = kind.startswith("preconditioned")
     tpcn = kind in ("preconditioned_pcn", "pcn")
     # oracle run with trace and recorded variates
     state, funcs, opts, aux = oracle_case(name)
+    pstate, pfuncs, popts, paux = product_case(name)
+    if verified_inverse:
+        funcs["flow"] = VerifiedInverse(funcs["flow"].maf, pfuncs["flow"])
     rng = omcmc.LegacyStream()
     trace = []
     np.random.seed(c["seed"])
     getattr(omcmc, kind)(state, funcs, opts, rng=rng, trace=trace)
     assert len(trace) >= 1
 
-    pstate, pfuncs, popts, paux = product_case(name)
     N, D = c["N"], c["D"]
     geo = pfuncs["theta_geometry"]
     eng = StepEngine(kind, N, D, pfuncs["flow"] if pre else None, pfuncs["scaler"])
