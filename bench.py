@@ -214,7 +214,7 @@ def main():
                          "the spline flows (their sweep takes the same time for 5e3 and 1e4 walkers)")
     ap.add_argument("--first-lane", type=float, default=None, help="fraction of the walkers in the first of two lanes")
     ap.add_argument("--flow", default="maf3", help="maf3 | maf6 | maf12 | nsf3 | nsf6 | nsf12 (BASELINE configs use maf3)")
-    ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "triangular_v1", "triangular_v2", "triangular_v3"], default="auto")
+    ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "solo", "duo", "lane"], default="auto")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
@@ -274,7 +274,7 @@ def main():
     target = make_target(args.target, D)
     logl, logp = target(x), prior.logpdf(x)
     flow = Flow(D, args.flow, seed=0)                       # replicated weights
-    flow.inverse_algo = {"auto": 0, "triangular": 1, "naive": 2, "triangular_v1": 3, "triangular_v2": 4, "triangular_v3": 5}[args.inverse]
+    flow.inverse_algo = {"auto": 0, "triangular": 1, "naive": 2, "solo": 6, "duo": 7, "lane": 8}[args.inverse]
     torch.manual_seed(0)                                    # same shuffles / batches on every rank
     u_fit = torch.from_numpy(scaler.forward(x_fit[:n])).float().cuda()
     from pocomc_amd.train import _train_state
@@ -513,13 +513,12 @@ def main():
     us["maf_inverse_timed_region"] = inv_us_live            # HIP events inside the timed region
     t_inv = inv_us_live * 1e-6
     fused = eng.pre and spec.univariate == "affine" and spec.tri_ok and spec.nOT <= 8 and args.inverse in ("auto", "triangular")
+    duo = bool(lib.pmc_debug_inverse_uses_duo(ctypes.byref(flow._desc), n_launch))
     roof_kernel = ("maf_dense_kernel<1>" if (args.inverse == "naive" or not spec.tri_ok) else
                    "maf_inverse_tri_nsf_kernel" if spec.univariate == "rqs" else
-                   {"triangular_v1": "maf_inverse_tri_kernel", "triangular_v2": "maf_inverse_tri2_kernel",
-                    "triangular_v3": "maf_inverse_tri3_kernel"}.get(
-                       args.inverse, ("maf_inverse_tri5_kernel" if lib.pmc_debug_inverse_uses_duo(
-                           ctypes.byref(flow._desc), n_launch) else "maf_inverse_tri4_kernel")
-                       if spec.nOT <= 8 else "maf_inverse_tri2_kernel"))
+                   "maf_inverse_tri6_kernel" if (args.inverse == "lane" or spec.nOT > 8 or os.environ.get("PMC_INVERSE_LANE", "0") != "0") else
+                   "maf_inverse_tri4_kernel" if args.inverse == "solo" else
+                   "maf_inverse_tri5_kernel" if (args.inverse == "duo" or duo) else "maf_inverse_tri4_kernel")
     # HBM bytes per launch of the dominant kernel: PMC passes cannot run inside this process; the value is the
     # committed rocprofv3 measurement of this very command (scripts/collect_profile.sh -> profiles/*_traffic.json),
     # used only when it was taken on the kernel sources this run was built from (their hash is stored with it) and

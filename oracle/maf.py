@@ -176,6 +176,18 @@ class OracleMAF:
             ladj = (ladj + l.sum(axis=1, dtype=F32)).astype(F32)
         return x, ladj
 
+    def ladj_abs_terms(self, x):
+        """``sum_j |ladj term_j|`` of ``forward(x)`` per row, in float64 (test infrastructure): the size of the terms
+        the log-determinant sums.  The terms have either sign, so two valid float32 evaluations of the sum (zuko's, this
+        file's, a kernel's) agree to ``eps * sum|terms|``, not to ``eps * |sum|``: parity tests measure a
+        log-determinant's error against this figure (the condition of the sum), never against a global maximum."""
+        x = np.asarray(x, dtype=F32)
+        acc = np.zeros(len(x), dtype=np.float64)
+        for t in range(self.spec.n_transforms):
+            x, l = self._fwd(t, x)
+            acc += np.abs(l.astype(np.float64)).sum(axis=1)
+        return acc
+
     def inverse(self, z):
         """latent -> data, ``(x, ladj)``; ``pocomc/flow.py:116-132``.  ``ladj`` is
         the log-determinant of the inverse map (= ``-ladj_forward(x)``)."""

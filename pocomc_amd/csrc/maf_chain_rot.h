@@ -1,6 +1,6 @@
 // Register-resident chain of the triangular MAF inverse, ROTATED R layout (used by tri4).
 //
-// R layout (maf_chain.h): the A operand of a chain MFMA carries the 4 rows of one quad replicated
+// R layout: the A operand of a chain MFMA carries the 4 rows of one quad replicated
 // over the 16 tile rows, so every lane holds all 4 values of the quad for its walker.  A lane,
 // however, only ever USES one of them: lane (q, p) supplies row k = q of the B operand of the next
 // hop and adds the residual of that same row.  Rotating the replication -- tile row i = 4*qi + r

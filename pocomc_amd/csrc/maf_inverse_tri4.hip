@@ -83,19 +83,6 @@ __device__ __forceinline__ void prefetch_tile(float4 (&pf1)[PK4], float4 (&pf2)[
     }
 }
 
-// Proposal arguments of the fused variant (pmc_propose_inverse): the wave first proposes theta' for its 16
-// walkers (propose_body.h) straight into the sweep's LDS input -- one launch and one global round trip less
-// per MCMC step.
-struct ProposeArgs {
-    int kind;
-    const float* cur32;
-    const double* mu; const double* inv_cov; const double* chol;
-    double nu, sigma, cn_a;
-    pmc_rng_t rng;
-    double* prop64; double* quad; double* quad_prop;
-    const double* adapt;          // pmc_step_t.adapt_state or NULL: {sigma, cn_a, mu[D]} on the device
-};
-
 // ABL: timing-only ablations (see maf_chain_rot.h); 4 = no bursts, 8 = no chain, 16 = no next-tile prefetch,
 // 32 = no tile-top fragment loads.  FM: 0 = plain inverse of `in`; 4 / 8 / 16 = fused proposal with D <= 4 FM.
 template <int MAXO, int ABL, int FM = 0>
@@ -355,18 +342,31 @@ static bool tri5_wanted(const pmc_maf_t* m, int64_t n);
 static int launch_tri5(const ProposeArgs* pa, const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
                        hipStream_t stream);
 
+// PMC_INVERSE_LANE=0: AUTO keeps to the register-chain sweeps of this file (A/B runs); default: the lane-per-walker
+// sweep (maf_inverse_tri6.hip) wherever it covers the flow
+static bool lane_sweep_enabled() {
+    static const bool on = !(getenv("PMC_INVERSE_LANE") && atoi(getenv("PMC_INVERSE_LANE")) == 0);
+    return on;
+}
+
 int pmc_launch_inverse_tri4(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream,
                             int variant) {
+    if (variant < 0 && lane_sweep_enabled()) {
+        const int rc = pmc_launch_tri6(nullptr, m, z, x, ladj, n, stream);
+        if (rc >= 0) return rc;
+    }
     if (variant == 1) return launch_tri5(nullptr, m, z, x, ladj, n, stream);
     if (variant < 0 && tri5_wanted(m, n)) {
         const int rc = launch_tri5(nullptr, m, z, x, ladj, n, stream);
         if (rc >= 0) return rc;
     }
-    if (m->nOT > 8) return -1;                                     // caller falls back
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;         // 32-bit buffer offsets
     const int maxo = m->nOT <= 4 ? 4 : 8;
     const size_t lds = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
-    if (lds > 160 * 1024) return -1;
+    if (m->nOT > 8 || lds > 160 * 1024) {
+        // wide flows (D > 64): lane-per-walker sweep; -1 if that does not cover the flow either (caller falls back)
+        return variant < 0 ? pmc_launch_tri6(nullptr, m, z, x, ladj, n, stream) : -1;
+    }
 #define LAUNCH(MO)                                                                                               \
     {                                                                                                            \
         if (lds > 48 * 1024) {                                                                                   \
@@ -382,18 +382,6 @@ int pmc_launch_inverse_tri4(const pmc_maf_t* m, const float* z, float* x, float*
     return pmc_check_launch("maf_inverse_tri4_kernel");
 }
 
-// timing-only ablations of the D <= 32 instance (scripts/ablate_inverse.py); NOT part of the ABI
-extern "C" int pmc_debug_inverse4_ablate(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, int abl,
-                                         void* stream) {
-    const size_t lds = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + 4 * 256) * sizeof(float);
-    const dim3 g((unsigned)((n + 15) / 16)), b(64);
-    hipStream_t st = (hipStream_t)stream;
-#define AB(V) case V: hipLaunchKernelGGL((maf_inverse_tri4_kernel<4, V>), g, b, lds, st, *m, z, x, ladj, n, ProposeArgs{}); break;
-    switch (abl) { AB(0) AB(1) AB(2) AB(3) AB(4) AB(8) AB(16) AB(32) AB(64) AB(12) AB(60) AB(127) AB(21) AB(20) AB(5) default: return pmc_fail("unknown ablation"); }
-#undef AB
-    return pmc_check_launch("maf_inverse_tri4_kernel<ablate>");
-}
-
 // Proposal (mcmc.py:77-85) + flow inverse (mcmc.py:88) in one launch; -1 when this flow / size is not covered by
 // the fused instances (the caller then launches pmc_propose and pmc_maf_inverse).
 int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* mu, const double* inv_cov,
@@ -406,6 +394,10 @@ int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* 
     const size_t lds = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     ProposeArgs pa{kind, cur32, mu, inv_cov, chol, nu, sigma, cn_a, *rng, prop64, quad, quad_prop, adapt};
+    if (lane_sweep_enabled()) {
+        const int rc = pmc_launch_tri6(&pa, m, nullptr, x, ladj, n, stream);
+        if (rc >= 0) return rc;
+    }
     if (tri5_wanted(m, n)) {
         const int rc = launch_tri5(&pa, m, nullptr, x, ladj, n, stream);
         if (rc >= 0) return rc;

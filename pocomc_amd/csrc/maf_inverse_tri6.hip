@@ -1,0 +1,579 @@
+// Triangular-sweep MAF inverse, LANE-PER-WALKER chain (pocomc/flow.py:116-132, called every MCMC step: mcmc.py:88).
+//
+// What rocprof said about the register-chain kernels (profiles/r01_f_summary.txt, maf_inverse_tri5_kernel): 52 % of the
+// issued MFMA work was padding -- the chain's 16x16x4 MFMAs carry the 4 rows of one quad replicated over the 16 tile
+// rows -- and the sweep was a latency chain of ~2000 cycles per degree group for 16 walkers per wavefront.  Here
+//
+//   * the CHAIN wavefront owns up to 64 walkers, one per lane, and does everything that is sequential along the degree
+//     groups with v_mfma_f32_4x4x1_16b_f32: D_i[lane] += A[4*abid + i] * B[lane] -- the B operand is the activation
+//     register itself (no replication, no cross-lane move), the A operand one VGPR per 4 x 16 weight block
+//     (lane l = W[row l & 3][k slot l >> 2], broadcast with cbsz = 4 / abid = k slot).  It multiplies only the
+//     diagonal tile of the hidden layers, the layer-0 columns of the newest ranks and the output rows of its own ranks;
+//   * three HELPER wavefronts (one per layer: hidden 1, hidden 2, layer 0 + output) multiply everything LEFT of the
+//     diagonal tile with dense v_mfma_f32_16x16x4_f32 against tiles that are already final, for all the walker
+//     subsets of the workgroup from one set of weight fragments, and stage the partial pre-activations in LDS;
+//   * the four wavefronts are coupled by monotonic LDS words ("tiles < v of layer l are final", "partials of tile v-1
+//     are staged") instead of workgroup barriers: a wave's DS operations execute in order, so a data store followed
+//     by the word's store needs no wait, and each helper starts on a tile as soon as ITS input layer is final --
+//     h0 of a tile's last group is known three dependent hops before the tile ends.
+//
+// Same arithmetic as the other sweeps up to the order of additions (float32; parity vs oracle 1e-5 relative).
+#include <stdlib.h>
+#include <type_traits>
+#include "maf_chain.h"
+#include "propose_body.h"
+
+typedef unsigned int u32x4_t6 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t6 __attribute__((ext_vector_type(2)));
+
+namespace tri6 {
+
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    const u32x4_t6 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float2 bload2(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    const u32x2_t6 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+
+template <int AB>
+__device__ __forceinline__ f32x4 M4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, AB, 0);
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(f);
+    }
+}
+
+// ---- LDS words ----------------------------------------------------------------------------------------------------
+enum { F_H0 = 0, F_H1, F_H2, F_X, F_P0, F_P1, F_P2, F_P3, F_COUNT = 8 };
+
+__device__ __forceinline__ void publish(int* flags, int which, int value) {
+    asm volatile("" ::: "memory");                       // data stores stay before the word's store (DS ops are in order)
+    *reinterpret_cast<volatile int*>(flags + which) = value;
+}
+__device__ __forceinline__ void wait_for(const int* flags, int which, int value) {
+    const volatile int* f = reinterpret_cast<const volatile int*>(flags + which);
+    while (*f < value) {}                                 // (an LDS round trip per poll is pause enough)
+    asm volatile("" ::: "memory");
+}
+
+constexpr int SPAD = 20;                                  // floats per walker row of a staging tile (16 + 4: conflict-free b128)
+
+struct ChainState {
+    f32x4 a0[4], a0n[4], acc1[4], acc2[4], o[2];
+    float4 w1, w2, w0, w0n;                               // A operands: component = out quad
+    float2 w3;                                            // A operands of the two group pairs' output rows
+    float yv[4];
+    int g[4];
+};
+
+// Speculative hand-over read: the word and the staged data are read in ONE LDS round trip (DS operations of a wave
+// execute in order and the writer stored the data before the word, so data read after a word that already shows
+// `value` are the staged ones); only if the word is behind does the wave poll and read again.
+template <class LOAD>
+__device__ __forceinline__ void take(const int* flags, int which, int value, LOAD&& load) {
+    const int seen = *reinterpret_cast<const volatile int*>(flags + which);
+    load();
+    asm volatile("" ::: "memory");
+    if (seen < value) {
+        wait_for(flags, which, value);
+        load();
+    }
+}
+
+// One degree group of the tile (quads c0..c1), then the next (compile-time recursion over the quad pattern).
+// Order of the MFMAs: the matrix pipe of a lone wave executes in order, 15 cycles per 4x4x1 (scripts/micro/mfma4x4.hip),
+// and the group's critical path is  h0 -> [own block of layer 1] -> h1 -> [own block of layer 2] -> h2 -> [own output
+// rows] -> x -> [layer-0 column of the next quad].  The blocks that feed LATER quads are issued in the gaps the VALU
+// epilogues of that path leave (about four MFMAs each); what does not fit follows at the end of the group.
+template <int PAT, int I>
+__device__ __forceinline__ void chain_group6(ChainState& s, float* H0, float* H1, float* H2, float* X, int* flags,
+                                             const float* SP1, const float* SP2, const float* SP3, int T, int D,
+                                             int gen, int sub_off_sp, int p, bool writer, float& ladj) {
+    constexpr int NG = pat_ngroups(PAT);
+    if constexpr (I < NG) {
+        constexpr int c0 = pat_start(PAT, I), c1 = pat_end(PAT, I);
+        constexpr bool last = (I == NG - 1);
+        constexpr int nx = c1 + 1;                        // first quad after this group
+        const int g = s.g[I];
+        const bool live = g < D;
+        const int hw = (T << 8) + (p << 2);               // + (unit << 6) + quad
+        f32x4 h0[4], h1[4], h2[4];
+        // blocks of layer L (1 / 2) from this group's quads into out quads [A0, A1)
+#define BLOCKS(ACC, W, HV, A0, A1)                                                                                  \
+        sfor<c0, c1 + 1>([&](auto bb) __attribute__((always_inline)) {                                              \
+            constexpr int b = decltype(bb)::value;                                                                  \
+            sfor<0, 4>([&](auto kk) __attribute__((always_inline)) {                                                \
+                constexpr int k = decltype(kk)::value;                                                              \
+                sfor<(A0), (A1)>([&](auto aa) __attribute__((always_inline)) {                                      \
+                    constexpr int a = decltype(aa)::value;                                                          \
+                    s.ACC[a] = M4<4 * b + k>(comp(s.W, a), HV[b][k], s.ACC[a]);                                     \
+                });                                                                                                 \
+            });                                                                                                     \
+        });
+        // ---- layer 0
+        sfor<c0, c1 + 1>([&](auto cc) __attribute__((always_inline)) {
+            constexpr int c = decltype(cc)::value;
+            for (int r = 0; r < 4; ++r) h0[c][r] = fmaxf(s.a0[c][r], 0.0f);
+            if (writer) for (int r = 0; r < 4; ++r) H0[hw + (r << 6) + c] = h0[c][r];
+        });
+        if constexpr (last) publish(flags, F_H0, gen + T + 1);
+        if constexpr (I == 0) {                           // partial pre-activations of layer 1 (tiles left of this one)
+            float4 v[4];
+            take(flags, F_P1, gen + T + 1, [&]() __attribute__((always_inline)) {
+                for (int a = 0; a < 4; ++a) v[a] = *reinterpret_cast<const float4*>(SP1 + sub_off_sp + 4 * a);
+            });
+            for (int a = 0; a < 4; ++a) s.acc1[a] = f32x4{v[a].x, v[a].y, v[a].z, v[a].w};
+        }
+        BLOCKS(acc1, w1, h0, c0, c1 + 1)                  // critical: own quads
+        if constexpr (nx < 4) { BLOCKS(acc1, w1, h0, nx, nx + 1) }          // gap: the next quad
+        // ---- layer 1
+        sfor<c0, c1 + 1>([&](auto cc) __attribute__((always_inline)) {
+            constexpr int c = decltype(cc)::value;
+            for (int r = 0; r < 4; ++r) h1[c][r] = fmaxf(s.acc1[c][r] + h0[c][r], 0.0f);
+            if (writer) for (int r = 0; r < 4; ++r) H1[hw + (r << 6) + c] = h1[c][r];
+        });
+        if constexpr (last) publish(flags, F_H1, gen + T + 1);
+        if constexpr (I == 0) {
+            float4 v[4];
+            take(flags, F_P2, gen + T + 1, [&]() __attribute__((always_inline)) {
+                for (int a = 0; a < 4; ++a) v[a] = *reinterpret_cast<const float4*>(SP2 + sub_off_sp + 4 * a);
+            });
+            for (int a = 0; a < 4; ++a) s.acc2[a] = f32x4{v[a].x, v[a].y, v[a].z, v[a].w};
+        }
+        BLOCKS(acc2, w2, h1, c0, c1 + 1)
+        if constexpr (nx < 4) { BLOCKS(acc2, w2, h1, nx, nx + 1) }
+        // ---- layer 2
+        sfor<c0, c1 + 1>([&](auto cc) __attribute__((always_inline)) {
+            constexpr int c = decltype(cc)::value;
+            for (int r = 0; r < 4; ++r) h2[c][r] = fmaxf(s.acc2[c][r] + h1[c][r], 0.0f);
+            if (writer) for (int r = 0; r < 4; ++r) H2[hw + (r << 6) + c] = h2[c][r];
+        });
+        if constexpr (last) publish(flags, F_H2, gen + T + 1);
+        // ---- output rows of this tile's ranks: (shift, raw) of groups (0,1) in o[0], (2,3) in o[1]
+        if constexpr (I == 0) {
+            const int O0 = (s.g[0] < D ? s.g[0] : 0) >> 3;
+            float2 po[4];
+            take(flags, F_P3, gen + T + 1, [&]() __attribute__((always_inline)) {
+                for (int i = 0; i < 4; ++i) {
+                    const int gg = s.g[i] < D ? s.g[i] : 0;
+                    const int slot = ((gg >> 3) != O0) ? 1 : 0;
+                    po[i] = *reinterpret_cast<const float2*>(SP3 + slot * (64 * SPAD) + sub_off_sp + 2 * (gg & 7));
+                }
+            });
+            s.o[0] = f32x4{po[0].x, po[0].y, po[1].x, po[1].y};
+            s.o[1] = f32x4{po[2].x, po[2].y, po[3].x, po[3].y};
+        }
+        constexpr int slot = I >> 1;
+        sfor<c0, c1 + 1>([&](auto bb) __attribute__((always_inline)) {
+            constexpr int b = decltype(bb)::value;
+            sfor<0, 4>([&](auto kk) __attribute__((always_inline)) {
+                constexpr int k = decltype(kk)::value;
+                s.o[slot] = M4<4 * b + k>(slot ? s.w3.y : s.w3.x, h2[b][k], s.o[slot]);
+            });
+        });
+        if constexpr (slot == 0 && NG > 2) {              // gap: the same quads into the rows of groups 2, 3
+            sfor<c0, c1 + 1>([&](auto bb) __attribute__((always_inline)) {
+                constexpr int b = decltype(bb)::value;
+                sfor<0, 4>([&](auto kk) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kk)::value;
+                    s.o[1] = M4<4 * b + k>(s.w3.y, h2[b][k], s.o[1]);
+                });
+            });
+        }
+        const float shift = s.o[slot][2 * (I & 1)];
+        const float ls = fast_ls(s.o[slot][2 * (I & 1) + 1]);
+        float xg = (s.yv[I] - shift) * fast_exp_neg(ls);
+        xg = live ? xg : 0.0f;
+        ladj -= live ? ls : 0.0f;
+        if (writer && live) X[lidx(g, p)] = xg;
+        if constexpr (last) publish(flags, F_X, gen + T + 1);
+        // ---- layer-0 column of the new rank: the next quad first (k slot 4 + I of this tile's window, or, after the
+        // tile's last group, k slot I of the next tile's), then everything that feeds later quads
+        if constexpr (nx < 4) s.a0[nx] = M4<4 + I>(comp(s.w0, nx), xg, s.a0[nx]);
+        s.a0n[0] = M4<I>(comp(s.w0n, 0), xg, s.a0n[0]);
+        if constexpr (nx + 1 < 4) { BLOCKS(acc1, w1, h0, nx + 1, 4) BLOCKS(acc2, w2, h1, nx + 1, 4) }
+        sfor<nx + 1, 4>([&](auto aa) __attribute__((always_inline)) {
+            constexpr int a = decltype(aa)::value;
+            s.a0[a] = M4<4 + I>(comp(s.w0, a), xg, s.a0[a]);
+        });
+        sfor<1, 4>([&](auto aa) __attribute__((always_inline)) {
+            constexpr int a = decltype(aa)::value;
+            s.a0n[a] = M4<I>(comp(s.w0n, a), xg, s.a0n[a]);
+        });
+#undef BLOCKS
+        chain_group6<PAT, I + 1>(s, H0, H1, H2, X, flags, SP1, SP2, SP3, T, D, gen, sub_off_sp, p, writer, ladj);
+    }
+}
+
+}  // namespace tri6
+
+// NS: 16-walker subsets per workgroup (1, 2 or 4); FM: 0 = plain inverse of `in`, 4 / 8 / 16 = fused proposal, D <= 4 FM.
+template <int NS, int FM>
+__global__ __launch_bounds__(256) void maf_inverse_tri6_kernel(pmc_maf_t m, const float* __restrict__ in,
+                                                               float* __restrict__ out, float* __restrict__ ladj_out,
+                                                               int64_t n, ProposeArgs pa) {
+    using namespace tri6;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, p = lane & 15;
+    const int D = m.D, Dp = m.Dp, Hp = m.Hp, Tn = m.T, nT = m.nT, nXT = m.nXT, nOT = m.nOT;
+    // ---- LDS map
+    const int szY = Dp * 16, szH = Hp * 16;
+    float* Yb = smem;                                    // [NS][szY]
+    float* Xb = Yb + NS * szY;                           // [NS][szY]
+    float* H0b = Xb + NS * szY;                          // [NS][szH]
+    float* H1b = H0b + NS * szH;
+    float* H2b = H1b + NS * szH;
+    float* SP0 = H2b + NS * szH;                         // [2 parities][NS][16][SPAD]
+    float* SP1 = SP0 + 2 * NS * 16 * SPAD;
+    float* SP2 = SP1 + 2 * NS * 16 * SPAD;
+    float* SP3 = SP2 + 2 * NS * 16 * SPAD;               // [2 parities][2 output tiles][64 (4 subsets max)][SPAD]
+    int* flags = reinterpret_cast<int*>(SP3 + 2 * 2 * 64 * SPAD);
+    const int* feat_of_rank = m.meta + 8;
+    const int* rank_of_feat = m.meta + 8 + Tn * D;
+    const int* quad_meta = m.meta + 8 + 2 * Tn * D;
+
+    const int oF0 = 0;
+    const int oF1 = oF0 + nT * nXT * 1024;
+    const int oF2 = oF1 + nT * nT * 1024;
+    const int oF3 = oF2 + nT * nT * 1024;
+    const int oW0 = oF3 + nOT * nT * 1024;
+    const int oB0 = oW0 + Dp * Hp * 4;
+    const int oB1 = oB0 + Hp * 4;
+    const int oB2 = oB1 + Hp * 4;
+    const int oB3 = oB2 + Hp * 4;
+    const int oCW1 = oB3 + nOT * 64;
+    const int oCW2 = oCW1 + nT * 1024;
+    const int oCW0 = oCW2 + nT * 1024;
+    const int oCW3 = oCW0 + nT * 1024;
+    const int oF0C = oCW3 + nT * 512;
+    const int blk_bytes = (int)(m.pk_per_transform * 4);
+    const int vo_lane = lane << 4, vo_q = q << 4;
+    (void)oF0; (void)oW0;
+
+    const int64_t set0 = (int64_t)blockIdx.x * NS;       // first 16-walker set of this workgroup
+    if (threadIdx.x < F_COUNT) flags[threadIdx.x] = 0;
+    // ---- input: proposals (fused) or rows of `in`, one subset per wavefront
+    for (int sb = wv; sb < NS; sb += 4) {
+        float* Y = Yb + sb * szY;
+        if constexpr (FM > 0) {
+            for (int e = lane; e < (Dp - D) * 16; e += 64) Y[lidx(D + (e >> 4), e & 15)] = 0.0f;
+            const double sg = pa.adapt ? pa.adapt[0] : pa.sigma, ca = pa.adapt ? pa.adapt[1] : pa.cn_a;
+            propose_body<FM>(pa.kind, pa.cur32, nullptr, pa.adapt ? pa.adapt + 2 : pa.mu, pa.inv_cov, pa.chol, pa.nu, sg,
+                             ca, pa.rng, pa.prop64, nullptr, pa.quad, pa.quad_prop, n, D, Y, rank_of_feat + (Tn - 1) * D,
+                             set0 + sb);
+        } else {
+            load_rows(Y, in, (set0 + sb) * 16, n, D, Dp, feat_of_rank + (Tn - 1) * D, lane);
+        }
+    }
+    float ladj = 0.0f;
+    // chain lanes: subset (lane >> 4) % NS, walker p; lanes beyond 16 NS shadow the first ones and do not write
+    const int csub = (lane >> 4) % NS;
+    const bool writer = lane < 16 * NS;
+    const int sub_sp = (csub * 16 + p) * SPAD;            // this lane's row inside a staging tile
+
+    int gen = 1;                                         // (words start at 0: nothing is published)
+    for (int t = Tn - 1; t >= 0; --t, gen += 256) {
+        const float* blk = m.packed + (size_t)t * m.pk_per_transform;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)blk, 0, blk_bytes, 0x00020000);
+        {   // unknown ranks are zeros (the helpers multiply whole tiles)
+            float4* z4 = reinterpret_cast<float4*>(Xb);
+            for (int e = threadIdx.x; e < (NS * szY) >> 2; e += 256) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+
+        if (wv == 0) {
+            // ================================================================== CHAIN
+            ChainState s;
+            float* H0 = H0b + csub * szH; float* H1 = H1b + csub * szH; float* H2 = H2b + csub * szH;
+            float* X = Xb + csub * szY;
+            const float* Y = Yb + csub * szY;
+            // rank 0 reads nothing: bias only
+            float x0;
+            {
+                const float* b3 = blk + (oB3 >> 2);
+                const float shift = b3[0], ls = fast_ls(b3[1]);
+                x0 = (Y[lidx(0, p)] - shift) * fast_exp_neg(ls);
+                ladj -= ls;
+                if (writer) X[lidx(0, p)] = x0;
+            }
+            publish(flags, F_X, gen + 0);
+            float4 w1n = bload4(rs, vo_lane, oCW1), w2n = bload4(rs, vo_lane, oCW2), w0nn = bload4(rs, vo_lane, oCW0);
+            float2 w3n = bload2(rs, lane << 3, oCW3);
+            int4 dg_next = *reinterpret_cast<const int4*>(quad_meta);
+            for (int a = 0; a < 4; ++a) s.a0n[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // rank 0 is "group 0 of the tile before tile 0": k slot 0 of tile 0's window
+            sfor<0, 4>([&](auto aa) __attribute__((always_inline)) {
+                constexpr int a = decltype(aa)::value;
+                s.a0n[a] = M4<0>(comp(w0nn, a), x0, s.a0n[a]);
+            });
+            for (int T = 0; T < nT; ++T) {
+                int4 dg = dg_next;
+                dg.x &= 0xffff; dg.y &= 0xffff; dg.z &= 0xffff; dg.w &= 0xffff;
+                if (dg.x >= D && dg.y >= D && dg.z >= D && dg.w >= D) break;       // padding tiles
+                const int pat = 1 | ((dg.y != dg.x) << 1) | ((dg.z != dg.y) << 2) | ((dg.w != dg.z) << 3);
+                {
+                    const bool ny = dg.y != dg.x, nz = dg.z != dg.y, nw = dg.w != dg.z;
+                    s.g[0] = dg.x;
+                    s.g[1] = ny ? dg.y : (nz ? dg.z : (nw ? dg.w : D));
+                    s.g[2] = ny ? (nz ? dg.z : (nw ? dg.w : D)) : ((nz && nw) ? dg.w : D);
+                    s.g[3] = (ny && nz && nw) ? dg.w : D;
+                }
+                long long* pf = (pa.prof && blockIdx.x == 0) ? pa.prof + ((size_t)((Tn - 1 - t) * nT + T) * 4 + 0) * 4 : nullptr;
+                if (pf && lane == 0) pf[0] = clock64();
+                s.w1 = w1n; s.w2 = w2n; s.w0 = w0nn; s.w3 = w3n;
+                if (T + 1 < nT) {
+                    w1n = bload4(rs, vo_lane, oCW1 + (T + 1) * 1024);
+                    w2n = bload4(rs, vo_lane, oCW2 + (T + 1) * 1024);
+                    w0nn = bload4(rs, vo_lane, oCW0 + (T + 1) * 1024);
+                    w3n = bload2(rs, lane << 3, oCW3 + (T + 1) * 512);
+                    dg_next = *reinterpret_cast<const int4*>(quad_meta + 4 * (T + 1));
+                } else {
+                    w0nn = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                s.w0n = w0nn;
+                for (int i = 0; i < 4; ++i) s.yv[i] = Y[lidx(s.g[i] < D ? s.g[i] : 0, p)];
+                // layer-0 partials of everything the helper multiplied (ranks before the previous tile's) + what the
+                // chain accumulated for this tile while it ran the previous one
+                {
+                    const float* sp = SP0 + (T & 1) * (NS * 16 * SPAD) + sub_sp;
+                    float4 v[4];
+                    take(flags, F_P0, gen + T + 1, [&]() __attribute__((always_inline)) {
+                        for (int a = 0; a < 4; ++a) v[a] = *reinterpret_cast<const float4*>(sp + 4 * a);
+                    });
+                    for (int a = 0; a < 4; ++a) {
+                        s.a0[a] = f32x4{v[a].x + s.a0n[a][0], v[a].y + s.a0n[a][1], v[a].z + s.a0n[a][2], v[a].w + s.a0n[a][3]};
+                        s.a0n[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                if (pf && lane == 0) pf[1] = clock64();
+                const float* sp1 = SP1 + (T & 1) * (NS * 16 * SPAD);
+                const float* sp2 = SP2 + (T & 1) * (NS * 16 * SPAD);
+                const float* sp3 = SP3 + (T & 1) * (2 * 64 * SPAD);
+                switch (pat) {
+#define CASE(P) case P: chain_group6<P, 0>(s, H0, H1, H2, X, flags, sp1, sp2, sp3, T, D, gen, sub_sp, p, writer, ladj); break;
+                    CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
+#undef CASE
+                }
+                if (pf && lane == 0) pf[2] = clock64();
+            }
+        } else {
+            // ================================================================== HELPERS
+            // wv 1: hidden layer 1 (reads H0), wv 2: hidden layer 2 (reads H1), wv 3: layer 0 (cut) + output rows (reads X, H2)
+            const float* Hin = wv == 1 ? H0b : (wv == 2 ? H1b : H2b);
+            const int oF = wv == 1 ? oF1 : oF2, oB = wv == 1 ? oB1 : oB2;
+            float* SP = wv == 1 ? SP1 : SP2;
+            const int f_in = wv == 1 ? F_H0 : (wv == 2 ? F_H1 : F_H2);
+            const int f_out = wv == 1 ? F_P1 : F_P2;
+            int known = gen;                              // tiles < known - gen of the input layer are final
+            auto need = [&](int K) {                       // tile K of the input layer must be final
+                if (known < gen + K + 1) { wait_for(flags, f_in, gen + K + 1); known = *reinterpret_cast<volatile int*>(flags + f_in); }
+            };
+            // acc/acd[sb] += sum_{K < T} frag[K] . Hin[sb][K]: four weight fragments in flight (a helper has nothing else to
+            // hide an L2 round trip with), tile K of the input layer awaited right before its use
+#define KLOOP(BASE)                                                                                                 \
+            {                                                                                                       \
+                const int base_ = (BASE);                                                                           \
+                float4 fr[4];                                                                                       \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+                    fr[j] = j < T ? bload4(rs, vo_lane, base_ + j * 1024) : make_float4(0.f, 0.f, 0.f, 0.f);        \
+                for (int K0 = 0; K0 < T; K0 += 4) {                                                                 \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
+                        const int K = K0 + j;                                                                       \
+                        if (K < T) {                                                                                \
+                            const float4 w = fr[j];                                                                 \
+                            if (K + 4 < T) fr[j] = bload4(rs, vo_lane, base_ + (K + 4) * 1024);                     \
+                            if (pf && lane == 0 && K == T - 1) pf[1] = clock64();                                   \
+                            need(K);                                                                                \
+                            if (pf && lane == 0 && K == T - 1) pf[2] = clock64();                                   \
+                            _Pragma("unroll") for (int sb = 0; sb < NS; ++sb) {                                     \
+                                const float4 b = *reinterpret_cast<const float4*>(Hin + sb * szH + (K << 8) + (lane << 2)); \
+                                acc[sb] = MFMA(w.x, b.x, acc[sb]); acd[sb] = MFMA(w.y, b.y, acd[sb]);               \
+                                acc[sb] = MFMA(w.z, b.z, acc[sb]); acd[sb] = MFMA(w.w, b.w, acd[sb]);               \
+                            }                                                                                       \
+                        }                                                                                           \
+                    }                                                                                               \
+                }                                                                                                   \
+            }
+            if (wv == 3) {
+                // layer-0 partial of tile 0: bias only (cut = 0)
+                const float4 b0 = bload4(rs, vo_q, oB0);
+                for (int sb = 0; sb < NS; ++sb)
+                    *reinterpret_cast<float4*>(SP0 + (sb * 16 + p) * SPAD + 4 * q) = b0;
+                publish(flags, F_P0, gen + 1);
+            }
+            for (int T = 0; T < nT; ++T) {
+                int4 dg = *reinterpret_cast<const int4*>(quad_meta + 4 * T);
+                dg.x &= 0xffff; dg.y &= 0xffff; dg.z &= 0xffff; dg.w &= 0xffff;
+                if (dg.x >= D && dg.y >= D && dg.z >= D && dg.w >= D) break;
+                long long* pf = (pa.prof && blockIdx.x == 0) ? pa.prof + ((size_t)((Tn - 1 - t) * nT + T) * 4 + wv) * 4 : nullptr;
+                if (pf && lane == 0) pf[0] = clock64();
+                if (wv != 3) {
+                    const float4 bb = bload4(rs, vo_q, oB + 64 * T);
+                    f32x4 acc[NS], acd[NS];
+                    for (int sb = 0; sb < NS; ++sb) { acc[sb] = f32x4{bb.x, bb.y, bb.z, bb.w}; acd[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                    KLOOP(oF + (T * nT) * 1024)
+                    float* sp = SP + (T & 1) * (NS * 16 * SPAD);
+#pragma unroll
+                    for (int sb = 0; sb < NS; ++sb)
+                        *reinterpret_cast<float4*>(sp + (sb * 16 + p) * SPAD + 4 * q) =
+                            make_float4(acc[sb][0] + acd[sb][0], acc[sb][1] + acd[sb][1], acc[sb][2] + acd[sb][2], acc[sb][3] + acd[sb][3]);
+                    publish(flags, f_out, gen + T + 1);
+                    if (pf && lane == 0) pf[3] = clock64();
+                } else {
+                    // ---- output partials of this tile's ranks: output tile(s) O = rank >> 3 against h2 of tiles < T
+                    int gfirst = dg.x, glast = dg.x;
+                    if (dg.y < D) glast = dg.y;
+                    if (dg.z < D) glast = dg.z;
+                    if (dg.w < D) glast = dg.w;
+                    const int O0 = gfirst >> 3, O1 = glast >> 3;
+                    float* sp3 = SP3 + (T & 1) * (2 * 64 * SPAD);
+                    for (int so = 0; so <= (O1 != O0 ? 1 : 0); ++so) {
+                        const int O = O0 + so;
+                        const float4 bb = bload4(rs, vo_q, oB3 + 64 * O);
+                        f32x4 acc[NS], acd[NS];
+                        for (int sb = 0; sb < NS; ++sb) { acc[sb] = f32x4{bb.x, bb.y, bb.z, bb.w}; acd[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                        KLOOP(oF3 + (O * nT) * 1024)
+#pragma unroll
+                        for (int sb = 0; sb < NS; ++sb)
+                            *reinterpret_cast<float4*>(sp3 + so * (64 * SPAD) + (sb * 16 + p) * SPAD + 4 * q) =
+                                make_float4(acc[sb][0] + acd[sb][0], acc[sb][1] + acd[sb][1], acc[sb][2] + acd[sb][2], acc[sb][3] + acd[sb][3]);
+                    }
+                    publish(flags, F_P3, gen + T + 1);
+                    if (pf && lane == 0) pf[1] = clock64();
+                    // ---- layer-0 partial of the NEXT tile: ranks before this tile's own (f0c), final once tile T-1 is
+                    if (T + 1 < nT) {
+                        wait_for(flags, F_X, gen + T);                    // tile T-1 complete (T = 0: rank 0 is there)
+                        const float4 b0 = bload4(rs, vo_q, oB0 + 64 * (T + 1));
+                        f32x4 acc[NS];
+                        for (int sb = 0; sb < NS; ++sb) acc[sb] = f32x4{b0.x, b0.y, b0.z, b0.w};
+                        {
+                            const int base_ = oF0C + ((T + 1) * nXT) * 1024;
+                            float4 fr[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                fr[j] = j < nXT ? bload4(rs, vo_lane, base_ + j * 1024) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            for (int X0 = 0; X0 < nXT; X0 += 4) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const int Xt = X0 + j;
+                                    if (Xt < nXT) {
+                                        const float4 w = fr[j];
+                                        if (Xt + 4 < nXT) fr[j] = bload4(rs, vo_lane, base_ + (Xt + 4) * 1024);
+#pragma unroll
+                                        for (int sb = 0; sb < NS; ++sb) {
+                                            const float4 b = *reinterpret_cast<const float4*>(Xb + sb * szY + (Xt << 8) + (lane << 2));
+                                            acc[sb] = MFMA(w.x, b.x, acc[sb]); acc[sb] = MFMA(w.y, b.y, acc[sb]);
+                                            acc[sb] = MFMA(w.z, b.z, acc[sb]); acc[sb] = MFMA(w.w, b.w, acc[sb]);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        float* sp0 = SP0 + ((T + 1) & 1) * (NS * 16 * SPAD);
+#pragma unroll
+                        for (int sb = 0; sb < NS; ++sb)
+                            *reinterpret_cast<float4*>(sp0 + (sb * 16 + p) * SPAD + 4 * q) = make_float4(acc[sb][0], acc[sb][1], acc[sb][2], acc[sb][3]);
+                        publish(flags, F_P0, gen + T + 2);
+                        if (pf && lane == 0) pf[3] = clock64();
+                    }
+                }
+            }
+        }
+#undef KLOOP
+        __syncthreads();
+        const bool lastT = (t == 0);
+        for (int sb = wv; sb < NS; sb += 4)
+            rerank_or_store(Xb + sb * szY, Yb + sb * szY, out, (set0 + sb) * 16, n, D, Dp, feat_of_rank + t * D,
+                            lastT ? nullptr : rank_of_feat + (t - 1) * D, lane);
+        __syncthreads();
+    }
+    if (wv == 0 && ladj_out && writer) {
+        const int64_t row = set0 * 16 + lane;
+        if (row < n) ladj_out[row] = ladj;
+    }
+}
+
+static size_t tri6_lds_bytes(const pmc_maf_t* m, int ns) {
+    return (size_t)(ns * (2 * m->Dp * 16 + 3 * m->Hp * 16) + 3 * 2 * ns * 16 * tri6::SPAD + 2 * 2 * 64 * tri6::SPAD) * sizeof(float)
+           + tri6::F_COUNT * sizeof(int);
+}
+
+// walker subsets per workgroup: as few as keep the launch in one round (a chain wavefront takes the same time for 16
+// and for 64 walkers; the helpers' share grows with the subsets), as many as the LDS admits otherwise
+static int tri6_subsets(const pmc_maf_t* m, int64_t n) {
+    static const int forced = getenv("PMC_TRI6_SUBSETS") ? atoi(getenv("PMC_TRI6_SUBSETS")) : 0;
+    int best = 0;
+    for (int ns = 1; ns <= 4; ns *= 2) {
+        const size_t lds = tri6_lds_bytes(m, ns);
+        if (lds > 160 * 1024) break;
+        if (forced == ns) return ns;
+        best = ns;
+        const int64_t per_cu = (int64_t)((160 * 1024) / lds) < 2 ? (int64_t)((160 * 1024) / lds) : 2;   // 4 waves each, one chain per SIMD pair
+        if ((n + 16 * ns - 1) / (16 * ns) <= 256 * per_cu) break;
+    }
+    return best;
+}
+
+// same contract as pmc_launch_inverse_tri4 / pmc_launch_propose_inverse_tri4 (pa == nullptr: plain inverse of z);
+// -1: this flow is not covered (spline flows, degree groups wider than a tile, tiles beyond the LDS)
+int pmc_launch_tri6(const ProposeArgs* pa, const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
+                    hipStream_t stream) {
+    if (m->n_out != 2 || !m->tri_ok) return -1;
+    if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
+    if (pa && m->D > 64) return -1;
+    const int ns = tri6_subsets(m, n);
+    if (ns == 0) return -1;
+    const size_t lds = tri6_lds_bytes(m, ns);
+    const ProposeArgs none{};
+    const unsigned grid = (unsigned)((n + 16 * ns - 1) / (16 * ns));
+#define LAUNCH6(NSV, FMV)                                                                                          \
+    {                                                                                                              \
+        if (lds > 48 * 1024) {                                                                                     \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri6_kernel<NSV, FMV>),   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+            if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_inverse_tri6_kernel)");           \
+        }                                                                                                          \
+        hipLaunchKernelGGL((maf_inverse_tri6_kernel<NSV, FMV>), dim3(grid), dim3(256), lds, stream, *m, z, x, ladj, \
+                           n, pa ? *pa : none);                                                                    \
+    }
+#define LAUNCH6F(FMV)                                                                                              \
+    { if (ns == 1) LAUNCH6(1, FMV) else if (ns == 2) LAUNCH6(2, FMV) else LAUNCH6(4, FMV) }
+    if (!pa) LAUNCH6F(0)
+    else if (m->D <= 16) LAUNCH6F(4)
+    else if (m->D <= 32) LAUNCH6F(8)
+    else LAUNCH6F(16)
+#undef LAUNCH6F
+#undef LAUNCH6
+    return pmc_check_launch("maf_inverse_tri6_kernel");
+}
+
+// measurement only (scripts/profile_tri6.py): cycle stamps of workgroup 0 -- prof[transform * nT + tile][wave 0..3][4]
+extern "C" int pmc_debug_tri6_profile(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, long long* prof,
+                                      void* stream) {
+    ProposeArgs pa{};
+    pa.prof = prof;
+    // (FM = 0 instances read nothing else of pa)
+    const int ns = tri6_subsets(m, n);
+    if (ns == 0 || m->n_out != 2 || !m->tri_ok) return pmc_fail("pmc_debug_tri6_profile: flow not covered");
+    const size_t lds = tri6_lds_bytes(m, ns);
+    const unsigned grid = (unsigned)((n + 16 * ns - 1) / (16 * ns));
+#define LP(NSV)                                                                                                    \
+    {                                                                                                              \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri6_kernel<NSV, 0>), \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        hipLaunchKernelGGL((maf_inverse_tri6_kernel<NSV, 0>), dim3(grid), dim3(256), lds, (hipStream_t)stream, *m, z, x, \
+                           ladj, n, pa);                                                                           \
+    }
+    if (ns == 1) LP(1) else if (ns == 2) LP(2) else LP(4)
+#undef LP
+    return pmc_check_launch("maf_inverse_tri6_kernel<profile>");
+}

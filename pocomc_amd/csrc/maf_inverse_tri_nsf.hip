@@ -1,7 +1,7 @@
 // Triangular-sweep inverse of the neural spline flows (pocomc/mcmc.py:88 -> flow.py:116-132 with
 // flow = nsf3 | nsf6 | nsf12).
 //
-// Same sweep as the affine kernels (maf_inverse_tri2.hip): hidden units sorted by autoregressive
+// Same sweep as the affine kernels (maf_inverse_tri4.hip): hidden units sorted by autoregressive
 // degree make the masked weights block lower-triangular, so instead of zuko's D fixed-point passes
 // of the full hyper-network the inverse is ONE pass over the degree groups -- per hidden tile a
 // left-looking burst against everything already final, then per degree group the dependent chain
@@ -238,16 +238,4 @@ int pmc_launch_inverse_tri_nsf(const pmc_maf_t* m, const float* z, float* x, flo
     hipLaunchKernelGGL(maf_inverse_tri_nsf_kernel<0>, dim3((unsigned)((n + 15) / 16)), dim3(64), lds, stream, *m, z, x,
                        ladj, n);
     return pmc_check_launch("maf_inverse_tri_nsf_kernel");
-}
-
-// timing-only ablations (scripts/ablate_inverse.py nsf); NOT part of the ABI
-extern "C" int pmc_debug_inverse_nsf_ablate(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, int abl,
-                                            void* stream) {
-    const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 16 * 32 + 16 * 24) * sizeof(float);
-    const dim3 g((unsigned)((n + 15) / 16)), b(64);
-    hipStream_t st = (hipStream_t)stream;
-#define AB(V) case V: hipLaunchKernelGGL(maf_inverse_tri_nsf_kernel<V>, g, b, lds, st, *m, z, x, ladj, n); break;
-    switch (abl) { AB(0) AB(1) AB(2) AB(4) AB(8) AB(3) AB(7) AB(15) default: return pmc_fail("unknown ablation"); }
-#undef AB
-    return pmc_check_launch("maf_inverse_tri_nsf_kernel<ablate>");
 }

@@ -27,6 +27,7 @@
 // whose degree groups exceed one tile.
 
 #include "maf_common.h"
+#include "propose_body.h"
 
 // ---------------------------------------------------------------------------
 // Dense pass of the hyper-network of one transform for 16 particles:
@@ -139,128 +140,6 @@ __global__ __launch_bounds__(64) void maf_dense_kernel(pmc_maf_t m, const float*
 }
 
 // ---------------------------------------------------------------------------
-// triangular-sweep inverse
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void maf_inverse_tri_kernel(pmc_maf_t m, const float* __restrict__ in,
-                                                             float* __restrict__ out,
-                                                             float* __restrict__ ladj_out, int64_t n) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x;
-    const int q = lane >> 4, p = lane & 15;
-    const int64_t row0 = (int64_t)blockIdx.x * 16;
-    const int D = m.D, Dp = m.Dp, Hp = m.Hp, T = m.T, nT = m.nT, nXT = m.nXT;
-    float* Y = smem;                 // input of the transform being inverted, by rank
-    float* X = Y + Dp * 16;          // its output, filled rank after rank
-    float* H0 = X + Dp * 16;
-    float* H1 = H0 + Hp * 16;
-    float* H2 = H1 + Hp * 16;
-    const int* feat_of_rank = m.meta + 8;
-    const int* rank_of_feat = m.meta + 8 + T * D;
-    const int* quad_meta = m.meta + 8 + 2 * T * D;
-
-    load_rows(Y, in, row0, n, D, Dp, feat_of_rank + (T - 1) * D, lane);
-    float ladj = 0.0f;               // per-lane partial: owner lanes add their ranks
-
-    for (int t = T - 1; t >= 0; --t) {
-        const MafView w = maf_view(m, t);
-        // zero X and the activations: bursts read whole tiles, unknown == 0
-        {
-            float4* z4 = reinterpret_cast<float4*>(X);
-            const int n4 = (Dp * 16 + 3 * Hp * 16) >> 2;
-            for (int e = lane; e < n4; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        __syncthreads();
-
-        int o_cur = 0;
-        f32x4 oacc = bias4(w.b3, 4 * q);
-        float xg;
-        // ---- rank 0 reads nothing: bias only
-        {
-            const float yv = Y[lidx(0, p)];
-            const float ls = soft_ls(oacc[1]);
-            xg = (yv - oacc[0]) / expf(ls);
-            if (q == 0) { X[lidx(0, p)] = xg; ladj -= ls; }
-        }
-        __syncthreads();
-
-        for (int Tt = 0; Tt < nT; ++Tt) {
-            int4 dg = *reinterpret_cast<const int4*>(quad_meta + 4 * Tt);
-            dg.x &= 0xffff; dg.y &= 0xffff; dg.z &= 0xffff; dg.w &= 0xffff;
-            if (dg.x >= D && dg.y >= D && dg.z >= D && dg.w >= D) break;       // padding tiles
-
-            // ---- bursts against everything that is already final
-            f32x4 a0 = bias4(w.b0, 16 * Tt + 4 * q);
-            for (int Xt = 0; Xt < nXT; ++Xt) a0 = tile_mac(a0, w.f0 + (size_t)Tt * nXT * 64, X, Xt, lane);
-            f32x4 a1 = bias4(w.b1, 16 * Tt + 4 * q);
-            f32x4 a2 = bias4(w.b2, 16 * Tt + 4 * q);
-            for (int K = 0; K < Tt; ++K) {
-                a1 = tile_mac(a1, w.f1 + (size_t)Tt * nT * 64, H0, K, lane);
-                a2 = tile_mac(a2, w.f2 + (size_t)Tt * nT * 64, H1, K, lane);
-            }
-            const float4 d1 = w.f1[((size_t)Tt * nT + Tt) * 64 + lane];
-            const float4 d2 = w.f2[((size_t)Tt * nT + Tt) * 64 + lane];
-
-            // ---- the degree groups of this tile, one after the other
-            int j0 = 0;
-            while (j0 < 4) {
-                const int g = sel4i(dg, j0);
-                int j1 = j0;
-                while (j1 + 1 < 4 && sel4i(dg, j1 + 1) == g) ++j1;
-                if (g >= D) { j0 = j1 + 1; continue; }
-                const bool mine = (q >= j0) && (q <= j1);
-                const int hb = (Tt << 8) + (lane << 2);          // B-operand base of this tile
-
-                f32x4 h0, h1, h2;
-                for (int r = 0; r < 4; ++r) h0[r] = fmaxf(a0[r], 0.0f);
-                if (mine) store_rows(H0, Tt, q, p, h0);
-                __syncthreads();
-                for (int j = j0; j <= j1; ++j) a1 = MFMA(sel4(d1, j), H0[hb + j], a1);
-                for (int r = 0; r < 4; ++r) h1[r] = fmaxf(a1[r] + h0[r], 0.0f);
-                if (mine) store_rows(H1, Tt, q, p, h1);
-                __syncthreads();
-                for (int j = j0; j <= j1; ++j) a2 = MFMA(sel4(d2, j), H1[hb + j], a2);
-                for (int r = 0; r < 4; ++r) h2[r] = fmaxf(a2[r] + h1[r], 0.0f);
-                if (mine) store_rows(H2, Tt, q, p, h2);
-                __syncthreads();
-
-                // ---- (shift, raw) of rank g
-                if ((g & 7) == 0) {
-                    o_cur = g >> 3;                               // new output tile: left-looking burst
-                    oacc = bias4(w.b3, 16 * o_cur + 4 * q);
-                    for (int K = 0; K <= Tt; ++K) oacc = tile_mac(oacc, w.f3 + (size_t)o_cur * nT * 64, H2, K, lane);
-                } else {
-                    const float4 d3 = w.f3[((size_t)o_cur * nT + Tt) * 64 + lane];
-                    for (int j = j0; j <= j1; ++j) oacc = MFMA(sel4(d3, j), H2[hb + j], oacc);
-                }
-                {
-                    const int s = g & 1, qo = (g & 7) >> 1;
-                    const float shift = s ? oacc[2] : oacc[0];
-                    const float ls = soft_ls(s ? oacc[3] : oacc[1]);
-                    const float yv = Y[lidx(g, p)];
-                    const float xv = (yv - shift) / expf(ls);
-                    if (q == qo) { X[lidx(g, p)] = xv; ladj -= ls; }
-                }
-                __syncthreads();
-                xg = X[lidx(g, p)];
-                // ---- rank-1 update of this tile's layer-0 pre-activations
-                {
-                    const float4 wv = *reinterpret_cast<const float4*>(w.w0n + (size_t)g * Hp + 16 * Tt + 4 * q);
-                    a0[0] += wv.x * xg; a0[1] += wv.y * xg; a0[2] += wv.z * xg; a0[3] += wv.w * xg;
-                }
-                j0 = j1 + 1;
-            }
-        }
-        __syncthreads();
-        const bool last = (t == 0);
-        rerank_or_store(X, Y, out, row0, n, D, Dp, feat_of_rank + t * D,
-                        last ? nullptr : rank_of_feat + (t - 1) * D, lane);
-        __syncthreads();
-    }
-    ladj = quad_sum(ladj);
-    if (ladj_out && lane < 16 && row0 + p < n) ladj_out[row0 + p] = ladj;
-}
-
-// ---------------------------------------------------------------------------
 // packing: packed[i] = idx[i] >= 0 ? flat[idx[i]] : 0
 // ---------------------------------------------------------------------------
 __global__ void maf_pack_kernel(const float* __restrict__ flat, const int32_t* __restrict__ idx,
@@ -344,39 +223,27 @@ extern "C" int pmc_maf_inverse(const pmc_maf_t* m, const float* z, float* x, flo
         if (algo == PMC_INVERSE_NAIVE) return pmc_launch_inverse_dpass_wg(m, z, x, ladj, n, (hipStream_t)stream);
         return pmc_fail("pmc_maf_inverse: spline flows know PMC_INVERSE_TRIANGULAR and PMC_INVERSE_NAIVE");
     }
+    const int asked = algo;
     if (algo == PMC_INVERSE_AUTO) algo = m->tri_ok ? PMC_INVERSE_TRIANGULAR : PMC_INVERSE_NAIVE;
     if (algo == PMC_INVERSE_TRIANGULAR) {
         if (!m->tri_ok) return pmc_fail("pmc_maf_inverse: triangular sweep needs degree groups <= one tile");
-        const size_t lds = maf_lds_bytes(*m, 2);
-        if (lds > 160 * 1024) return pmc_fail("MAF too wide for one wave's LDS budget (160 KiB)");
-        {   // register-resident chain (output tiles <= 8, i.e. D <= 64); otherwise the LDS-hop sweep
-            const int rc = pmc_launch_inverse_tri4(m, z, x, ladj, n, (hipStream_t)stream);
-            if (rc >= 0) return rc;
-        }
-        return pmc_launch_inverse_tri2(m, z, x, ladj, n, lds, (hipStream_t)stream);
+        // register-chain sweeps for output tiles <= 8 (D <= 64), the lane-per-walker sweep for the wider flows
+        const int rc = pmc_launch_inverse_tri4(m, z, x, ladj, n, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+        if (asked != PMC_INVERSE_AUTO) return pmc_fail("pmc_maf_inverse: the triangular sweeps need their tiles in 160 KiB of LDS");
+        algo = PMC_INVERSE_NAIVE;                                   // (AUTO: the D-pass algorithm covers what is left)
     } else if (algo == PMC_INVERSE_TRIANGULAR_SOLO || algo == PMC_INVERSE_TRIANGULAR_DUO) {
         if (!m->tri_ok) return pmc_fail("pmc_maf_inverse: triangular sweep needs degree groups <= one tile");
+        if (m->nOT > 8) return pmc_fail("pmc_maf_inverse: this sweep needs D <= 64 and its tiles in 160 KiB of LDS");
         const int rc = pmc_launch_inverse_tri4(m, z, x, ladj, n, (hipStream_t)stream, algo == PMC_INVERSE_TRIANGULAR_DUO);
         if (rc >= 0) return rc;
         return pmc_fail("pmc_maf_inverse: this sweep needs D <= 64 and its tiles in 160 KiB of LDS");
-    } else if (algo == PMC_INVERSE_TRIANGULAR_V3) {
-        if (!m->tri_ok) return pmc_fail("pmc_maf_inverse: triangular sweep needs degree groups <= one tile");
-        const int rc = pmc_launch_inverse_tri3(m, z, x, ladj, n, (hipStream_t)stream);
+    } else if (algo == PMC_INVERSE_TRIANGULAR_LANE) {
+        const int rc = pmc_launch_tri6(nullptr, m, z, x, ladj, n, (hipStream_t)stream);
         if (rc >= 0) return rc;
-        return pmc_fail("pmc_maf_inverse: the register-resident sweep needs D <= 64");
-    } else if (algo == PMC_INVERSE_TRIANGULAR_V2) {
-        if (!m->tri_ok) return pmc_fail("pmc_maf_inverse: triangular sweep needs degree groups <= one tile");
-        const size_t lds = maf_lds_bytes(*m, 2);
-        if (lds > 160 * 1024) return pmc_fail("MAF too wide for one wave's LDS budget (160 KiB)");
-        return pmc_launch_inverse_tri2(m, z, x, ladj, n, lds, (hipStream_t)stream);
-    } else if (algo == PMC_INVERSE_TRIANGULAR_V1) {
-        if (!m->tri_ok) return pmc_fail("pmc_maf_inverse: triangular sweep needs degree groups <= one tile");
-        const size_t lds = maf_lds_bytes(*m, 2);
-        if (int e = set_lds(maf_inverse_tri_kernel, lds)) return e;
-        hipLaunchKernelGGL(maf_inverse_tri_kernel, dim3((unsigned)((n + 15) / 16)), dim3(64), lds,
-                           (hipStream_t)stream, *m, z, x, ladj, n);
-        return pmc_check_launch("maf_inverse_tri_kernel");
-    } else if (algo == PMC_INVERSE_NAIVE) {
+        return pmc_fail("pmc_maf_inverse: the lane-per-walker sweep needs an affine flow whose degree groups fit a tile");
+    }
+    if (algo == PMC_INVERSE_NAIVE) {
         const size_t lds = maf_lds_bytes(*m, 3);
         if (int e = set_lds(maf_dense_kernel<1>, lds)) return e;
         hipLaunchKernelGGL(maf_dense_kernel<1>, dim3((unsigned)((n + 15) / 16)), dim3(64), lds,

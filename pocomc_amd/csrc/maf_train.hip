@@ -830,52 +830,3 @@ extern "C" int pmc_maf_train_epoch(const pmc_maf_t* m, const pmc_maf_train_t* tr
     }
     return pmc_check_launch("pmc_maf_train_epoch");
 }
-
-// ---------------------------------------------------------------------------
-// latency probe (scripts/profile_train.py --probe; not part of the ABI)
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void latency_probe_kernel(const float4* __restrict__ wts, long long* out) {
-    __shared__ __attribute__((aligned(16))) float lds[16 * 256];
-    const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 16 * 256; i += blockDim.x) lds[i] = 0.001f * i;
-    __syncthreads();
-    long long t[10];
-    const float4* f = wts + (size_t)blockIdx.x * 64 * 64 + lane;
-    t[0] = __builtin_readcyclecounter();
-    float4 a = f[0];
-    asm volatile("s_waitcnt vmcnt(0)" :: "v"(a.x) : "memory");
-    t[1] = __builtin_readcyclecounter();                       // cold load
-    float4 b = f[0];
-    asm volatile("s_waitcnt vmcnt(0)" :: "v"(b.x) : "memory");
-    t[2] = __builtin_readcyclecounter();                       // same line again
-    float4 c0 = f[64], c1 = f[128], c2 = f[192], c3 = f[256];
-    asm volatile("s_waitcnt vmcnt(0)" :: "v"(c0.x), "v"(c1.x), "v"(c2.x), "v"(c3.x) : "memory");
-    t[3] = __builtin_readcyclecounter();                       // 4 new lines in flight
-    f32x4 acc = {a.x, b.y, c0.z, c1.w};
-#pragma unroll
-    for (int i = 0; i < 36; ++i) acc = MFMA(c2.x, c3.y, acc);
-    asm volatile("s_nop 0" :: "v"(acc[0]));
-    t[4] = __builtin_readcyclecounter();                       // 36 dependent MFMAs
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const float4 bb = *reinterpret_cast<const float4*>(lds + (k << 8) + (lane << 2));
-        acc = MFMA(c0.x, bb.x, acc); acc = MFMA(c0.y, bb.y, acc); acc = MFMA(c0.z, bb.z, acc); acc = MFMA(c0.w, bb.w, acc);
-    }
-    asm volatile("s_nop 0" :: "v"(acc[0]));
-    t[5] = __builtin_readcyclecounter();                       // 9 x (ds_read_b128 + 4 MFMA)
-    __syncthreads();
-    t[6] = __builtin_readcyclecounter();                       // one barrier
-    lds_barrier();
-    t[7] = __builtin_readcyclecounter();                       // one LDS-only barrier
-    if (lane == 0) {
-        long long* o = out + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8;
-        for (int i = 0; i < 7; ++i) o[i] = t[i + 1] - t[i];
-        o[7] = (long long)acc[1];
-    }
-}
-
-extern "C" int pmc_debug_latency_probe(const float* wts, long long* out, int blocks, void* stream) {
-    hipLaunchKernelGGL(latency_probe_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(wts), out);
-    return pmc_check_launch("latency_probe_kernel");
-}

@@ -8,8 +8,6 @@
 int pmc_fail(const char* msg);
 int pmc_fail_hip(hipError_t e, const char* what);
 int pmc_check_launch(const char* what);
-int pmc_launch_inverse_tri2(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, size_t lds,
-                            hipStream_t stream);
 
 int pmc_launch_forward_wg(const pmc_maf_t* m, const float* x, float* z, float* ladj, float* log_prob, int64_t n,
                           hipStream_t stream, const int64_t* idx = nullptr);
@@ -20,7 +18,6 @@ int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* 
                                     const double* chol, double nu, double sigma, double cn_a, const pmc_rng_t* rng,
                                     double* prop64, double* quad, double* quad_prop, const pmc_maf_t* m, float* x,
                                     float* ladj, int64_t n, hipStream_t stream, const double* adapt = nullptr);
-int pmc_launch_inverse_tri3(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream);
 int pmc_launch_propose_mfma(int kind, const float* cur32, const double* cur64, const double* mu,
                             const double* inv_cov, const double* chol, double nu, double sigma, double cn_a,
                             const pmc_rng_t* rng, double* prop64, float* prop32, double* quad, double* quad_prop,

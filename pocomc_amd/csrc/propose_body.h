@@ -154,4 +154,22 @@ __device__ __forceinline__ void propose_body(
     }
 }
 
+// Proposal arguments of the fused variant (pmc_propose_inverse): the wave first proposes theta' for its 16
+// walkers (propose_body.h) straight into the sweep's LDS input -- one launch and one global round trip less
+// per MCMC step.
+struct ProposeArgs {
+    int kind;
+    const float* cur32;
+    const double* mu; const double* inv_cov; const double* chol;
+    double nu, sigma, cn_a;
+    pmc_rng_t rng;
+    double* prop64; double* quad; double* quad_prop;
+    const double* adapt;          // pmc_step_t.adapt_state or NULL: {sigma, cn_a, mu[D]} on the device
+    long long* prof;              // measurement only (scripts/profile_tri6.py): cycle stamps of workgroup 0, or NULL
+};
+
+// lane-per-walker sweep (maf_inverse_tri6.hip); pa == nullptr: plain inverse of z.  -1: flow not covered
+int pmc_launch_tri6(const ProposeArgs* pa, const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
+                    hipStream_t stream);
+
 #endif

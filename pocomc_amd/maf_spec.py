@@ -224,6 +224,15 @@ class MAFSpec:
             self.sz_f3i = D * 2 * nT * 256       # [rank][half][ktile][lane][4]
             self.sz_b3i = D * 32                 # [rank][32]
             parts += [("f3i", self.sz_f3i), ("b3i", self.sz_b3i)]
+        else:
+            # chain image of the lane-per-walker inverse sweep (csrc/maf_inverse_tri6.hip): A operands of
+            # v_mfma_f32_4x4x1_16b_f32 -- lane l holds W[out quad row l & 3][k slot l >> 2], one VGPR = a 4 x 16 block --
+            # for the diagonal tile of the hidden layers (cw1, cw2: [tile][lane][out quad]), the layer-0 columns of the
+            # ranks the previous and the own tile produce (cw0: k slots 0-3 / 4-7) and the output rows of the own
+            # tile's ranks (cw3: [tile][lane][pair of groups]); f0c = f0 with the columns of those ranks zeroed (what
+            # the helper wavefront multiplies while the chain adds the newest ranks from registers)
+            parts += [("cw1", nT * 256), ("cw2", nT * 256), ("cw0", nT * 256), ("cw3", nT * 128),
+                      ("f0c", self.sz_f0)]
         off = 0
         self.pk_offsets = {}
         for name, sz in parts:
@@ -314,6 +323,38 @@ class MAFSpec:
             put("f0", f0); put("f1", f12["W1"]); put("f2", f12["W2"]); put("f3", f3)
             put("w0n", w0n); put("b0", bidx("b0")); put("b1", bidx("b1")); put("b2", bidx("b2"))
             put("b3", b3)
+            if self.univariate == "affine":
+                ci, ck = lane & 3, lane >> 2                # 4x4x1 A operand: row within the out quad, k slot
+                tg = self.tile_groups()                      # per tile: degrees of its groups (in order)
+                cw1 = np.full((nT, 64, 4), -1, dtype=np.int64)
+                cw2 = np.full((nT, 64, 4), -1, dtype=np.int64)
+                cw0 = np.full((nT, 64, 4), -1, dtype=np.int64)
+                cw3 = np.full((nT, 64, 2), -1, dtype=np.int64)
+                f0c = np.full((nT, nXT, 64, 4), -1, dtype=np.int64)
+                for T in range(nT):
+                    in_unit = su[16 * T + ck]
+                    prev = [0] if T == 0 else tg[T - 1]      # ranks produced before this tile's chain starts its own
+                    own = tg[T]
+                    win = np.full(16, -1, dtype=np.int64)    # rank of every k slot of the layer-0 window
+                    win[:len(prev)] = prev
+                    win[4:4 + len(own)] = own
+                    wfeat = np.where(win >= 0, feat_of_rank[np.clip(win, 0, D - 1)], -1)
+                    for a in range(4):
+                        out_unit = su[16 * T + 4 * a + ci]
+                        cw1[T, :, a] = cidx("W1", out_unit, in_unit, H, M1)
+                        cw2[T, :, a] = cidx("W2", out_unit, in_unit, H, M2)
+                        cw0[T, :, a] = cidx("W0", out_unit, wfeat[ck], D, M0)
+                    for sl in range(2):
+                        gi = 2 * sl + (ci >> 1)              # group of the tile this row belongs to
+                        rk = np.array([own[g] if g < len(own) else -1 for g in gi])
+                        crow = np.where(rk >= 0, self.n_out * feat_of_rank[np.clip(rk, 0, D - 1)] + (ci & 1), -1)
+                        cw3[T, :, sl] = cidx("W3", crow, in_unit, H, M3)
+                    cut = 0 if T == 0 else (prev[0] if len(prev) else D)   # first rank the chain adds itself
+                    for X in range(nXT):
+                        for c in range(4):
+                            r_in = 16 * X + 4 * c + lk
+                            f0c[T, X, :, c] = np.where(r_in < cut, f0[T, X, :, c], -1)
+                put("cw1", cw1); put("cw2", cw2); put("cw0", cw0); put("cw3", cw3); put("f0c", f0c)
             if self.univariate == "rqs":
                 NO = self.n_out
                 f3i = np.full((D, 2, nT, 64, 4), -1, dtype=np.int64)
@@ -330,6 +371,18 @@ class MAFSpec:
                     b3i[r, :NO] = base_c + off3 + NO * feat + np.arange(NO)
                 put("f3i", f3i); put("b3i", b3i)
         return idx.astype(np.int32)
+
+    def tile_groups(self):
+        """Per hidden tile: the degrees (= the ranks they produce) of its degree groups, in slot order."""
+        out = []
+        for T in range(self.nT):
+            dq = self.quad_deg[4 * T:4 * T + 4]
+            g = []
+            for d in dq:
+                if d < self.n_dim and (not g or g[-1] != d):
+                    g.append(int(d))
+            out.append(g)
+        return out
 
     def device_meta(self) -> np.ndarray:
         """int32 metadata consumed by the kernels.

@@ -20,7 +20,8 @@ def rel_rows(a, b):
     must coincide and count as zero error."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     fin = np.isfinite(b)
-    assert (np.isfinite(a) == fin).all() and ((a == b) | fin).all()
+    assert (np.isfinite(a) == fin).all(), "finite masks differ"
+    assert ((a == b) | fin | (np.isnan(a) & np.isnan(b))).all(), "different infinities"
     d = np.where(fin, np.abs(np.where(fin, a, 0.0) - np.where(fin, b, 0.0)), 0.0)
     ref = np.where(fin, np.abs(b), 0.0)
     if a.ndim == 2:
@@ -37,6 +38,8 @@ def close_rel(a, b, tol=TOL, what="", cancel=None):
     if cancel is not None:
         b = np.asarray(b, np.float64)
         fin = np.isfinite(b)
-        r = r * np.where(fin, np.abs(b), 0.0) / np.maximum(np.where(fin, np.abs(b), 0.0), np.asarray(cancel, np.float64))
+        cancel = np.broadcast_to(np.asarray(cancel, np.float64), b.shape)
+        cancel = np.where(np.isfinite(cancel), cancel, 0.0)
+        r = r * np.where(fin, np.abs(b), 0.0) / np.maximum(np.maximum(np.where(fin, np.abs(b), 0.0), cancel), np.finfo(np.float64).tiny)
     assert r.max() <= tol, f"{what}: max relative error {r.max():.3e} > {tol:g} ({int((r > tol).sum())} of {r.size} walkers)"
     return float(r.max())

@@ -189,3 +189,106 @@ def test_plateau_scheduler_matches_torch():
         ref.step(float(mval))
         mine.step(float(mval))
         assert abs(o.lr - topt.param_groups[0]["lr"]) < 1e-15
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The chain image of the lane-per-walker inverse sweep (MAFSpec.pack_index: cw1 / cw2 / cw0 / cw3 / f0c), checked on the
+# CPU by walking csrc/maf_inverse_tri6.hip's decomposition in numpy: helpers multiply the tiles left of the diagonal
+# (f1 / f2 / f3 fragments, f0c for the ranks before the previous tile's), the chain the diagonal tile, the layer-0
+# columns of the previous and own tile's ranks (window k slots 0-3 / 4-7) and the output rows of its own ranks.
+def _tri6_emulate(spec, flat, z):
+    import numpy as np
+    from pocomc_amd.maf_spec import LOG_SLOPE
+    D, nT, nXT, nOT, Hp, Dp = spec.n_dim, spec.nT, spec.nXT, spec.nOT, spec.Hp, spec.Dp
+    idx = spec.pack_index()
+    packed = np.where(idx >= 0, flat[np.maximum(idx, 0)], 0.0).astype(np.float64)
+    lane = np.arange(64)
+    li, lk = lane & 15, lane >> 4
+    ci, ck = lane & 3, lane >> 2
+    n = len(z)
+    y = np.asarray(z, np.float64)
+    ladj = np.zeros(n)
+    tg = spec.tile_groups()
+    for t in reversed(range(spec.n_transforms)):
+        P = packed[t * spec.pk_per_transform:(t + 1) * spec.pk_per_transform]
+        po = spec.pk_offsets
+        sec = lambda name, shape: P[po[name]:po[name] + int(np.prod(shape))].reshape(shape)
+
+        def frag_block(f):           # [lane][4] -> dense 16 x 16 block, rows = out slot, cols = in slot
+            B = np.zeros((16, 16))
+            for c in range(4):
+                B[li, 4 * c + lk] = f[:, c]
+            return B
+        f1, f2 = sec("f1", (nT, nT, 64, 4)), sec("f2", (nT, nT, 64, 4))
+        f3, f0c = sec("f3", (nOT, nT, 64, 4)), sec("f0c", (nT, nXT, 64, 4))
+        cw1, cw2, cw0 = sec("cw1", (nT, 64, 4)), sec("cw2", (nT, 64, 4)), sec("cw0", (nT, 64, 4))
+        cw3 = sec("cw3", (nT, 64, 2))
+        b0, b1, b2, b3 = sec("b0", (Hp,)), sec("b1", (Hp,)), sec("b2", (Hp,)), sec("b3", (spec.Op,))
+
+        def chain_block(cw):         # [lane][4 out quads] -> dense 16 (out slot) x 16 (k slot)
+            B = np.zeros((16, 16))
+            for a in range(4):
+                B[4 * a + ci, ck] = cw[:, a]
+            return B
+        rank = spec.orders[t]
+        yr = np.zeros((n, Dp)); yr[:, rank] = y                       # by rank
+        x = np.zeros((n, Dp))
+        H0, H1, H2 = (np.zeros((n, Hp)) for _ in range(3))
+        soft = lambda raw: raw / (1.0 + np.abs(raw / LOG_SLOPE))
+        ls0 = soft(b3[1]); x[:, 0] = (yr[:, 0] - b3[0]) * np.exp(-ls0); ladj -= ls0
+        a0n = np.zeros((n, 16))
+        a0n += np.outer(x[:, 0], chain_block(cw0[0])[:, 0])           # rank 0 = k slot 0 of tile 0's window
+        for T in range(nT):
+            own = tg[T]
+            if not own:
+                break
+            # helper: layer 0 (ranks before the previous tile's), hidden layers and output rows left of the diagonal tile
+            a0 = b0[16 * T:16 * T + 16] + sum(x[:, 16 * X:16 * X + 16] @ frag_block(f0c[T, X]).T for X in range(nXT)) + a0n
+            a0n = np.zeros((n, 16))
+            p1 = b1[16 * T:16 * T + 16] + sum(H0[:, 16 * K:16 * K + 16] @ frag_block(f1[T, K]).T for K in range(T))
+            p2 = b2[16 * T:16 * T + 16] + sum(H1[:, 16 * K:16 * K + 16] @ frag_block(f2[T, K]).T for K in range(T))
+            W1d, W2d, W0w = chain_block(cw1[T]), chain_block(cw2[T]), chain_block(cw0[T])
+            W0n = chain_block(cw0[T + 1]) if T + 1 < nT else np.zeros((16, 16))
+            W3d = np.zeros((8, 16))                                   # rows (group, out) x k slot
+            for sl in range(2):
+                W3d[4 * sl + ci, ck] = cw3[T][:, sl]
+            qd = spec.quad_deg[4 * T:4 * T + 4]
+            for I, d in enumerate(own):
+                quads = [j for j in range(4) if qd[j] == d]
+                sl_ = np.concatenate([np.arange(4 * j, 4 * j + 4) for j in quads])
+                h0 = np.maximum(a0[:, sl_], 0.0); H0[:, 16 * T + sl_] = h0
+                p1 = p1 + h0 @ W1d[:, sl_].T                          # own block + blocks into the later quads
+                h1 = np.maximum(p1[:, sl_] + h0, 0.0); H1[:, 16 * T + sl_] = h1
+                p2 = p2 + h1 @ W2d[:, sl_].T
+                h2 = np.maximum(p2[:, sl_] + h1, 0.0); H2[:, 16 * T + sl_] = h2
+                O = d >> 3
+                rows = [2 * (d & 7), 2 * (d & 7) + 1]
+                p3 = b3[16 * O + np.array(rows)] + sum(
+                    H2[:, 16 * K:16 * K + 16] @ frag_block(f3[O, K])[rows].T for K in range(T))
+                # own tile: every group of the tile that is done so far (incl. this one) feeds the rows through cw3
+                done = np.concatenate([np.arange(4 * j, 4 * j + 4) for j in range(4) if qd[j] <= d and qd[j] < D])
+                p3 = p3 + H2[:, 16 * T + done] @ W3d[2 * I:2 * I + 2][:, done].T
+                ls = soft(p3[:, 1])
+                xg = (yr[:, d] - p3[:, 0]) * np.exp(-ls)
+                ladj -= ls
+                x[:, d] = xg
+                a0 = a0 + np.outer(xg, W0w[:, 4 + I])                 # later quads of this tile
+                a0n = a0n + np.outer(xg, W0n[:, I])                   # the next tile
+        y = x[:, rank]                                                # back to feature order
+    return y, ladj
+
+
+@pytest.mark.parametrize("D,T", [(3, 2), (4, 3), (5, 3), (10, 3), (17, 2), (32, 3), (50, 2)])
+def test_chain_image_of_the_lane_sweep_reproduces_the_inverse(D, T):
+    import numpy as np
+    from oracle.maf import OracleMAF
+    from pocomc_amd.maf_spec import MAFSpec
+    spec = MAFSpec(D, T)
+    if not spec.tri_ok:
+        pytest.skip("degree groups wider than a tile")
+    flat = (spec.init_params(5) * np.float32(1.2)).astype(np.float32)
+    z = (np.random.default_rng(D).normal(size=(12, D)) * 1.2).astype(np.float32)
+    xo, lo = OracleMAF(spec, flat).inverse(z)
+    x, l = _tri6_emulate(spec, flat, z)
+    np.testing.assert_allclose(x, xo, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(l, lo, rtol=2e-5, atol=2e-5)
