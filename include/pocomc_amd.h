@@ -440,6 +440,45 @@ int64_t pmc_trim_workspace_bytes(int64_t P);
 int pmc_trim_threshold(const double* w, int64_t P, double ess, int32_t bins, double* result,
                        void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- SMC bookkeeping on a pool that stays in HBM (csrc/pool.hip) ------------------------------------------------ */
+
+/* Importance weights of Sampler._reweight, sampler.py:779-781: w = exp(logw - max) / sum.
+ * stats f64 [>= 2] on the device: { max, sum exp(logw - max) } as left by pmc_logw_stats. */
+int pmc_weights_from_logw(const double* logw, int64_t P, const double* stats, double* w, void* stream);
+
+/* out f64 [1] (device) <- sum of a f64 [n], added in a fixed order (np.sum of a weight vector: tools.py:34, :168). */
+int pmc_sum_f64(const double* a, int64_t n, double* out, void* stream);
+
+/* trim_weights, tools.py:38-41, after pmc_trim_threshold: keep the samples with w >= *threshold in their order,
+ * idx_out i64 [<= P] <- their indices, w_out f64 [<= P] <- their renormalised weights, count i64 [1] <- how many
+ * (threshold, count: device memory).  workspace: pmc_trim_select_workspace_bytes(P). */
+int64_t pmc_trim_select_workspace_bytes(int64_t P);
+int pmc_trim_select(const double* w, int64_t P, const double* threshold, int64_t* idx_out, double* w_out,
+                    int64_t* count, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* First and second moments of the rows x[idx[r]], r < n (idx NULL: rows 0..n-1), with weights w (NULL: ones):
+ * v f64 [2] <- { V1 = sum w, V2 = sum w^2 }, mean f64 [D] <- sum w x / V1, S f64 [D][D] <- sum w (x - mean)(x - mean)^T.
+ * Everything np.average / np.cov(aweights=w) / np.var of Geometry.fit (geometry.py:44-49) and the start values of
+ * fit_mvstud (student.py:46-47) need.  Rows float64 (x) or float32 (x32: theta, the float32 output of the flow).
+ * Ordered reductions.  workspace: pmc_moments_workspace_bytes(D). */
+int64_t pmc_moments_workspace_bytes(int32_t D);
+int pmc_moments(const double* x, const float* x32, const int64_t* idx, const double* w, int64_t n, int32_t D,
+                double* mean, double* S, double* v, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* np.median(data, 1) of student.py:45 over the rows x[idx[r]] (idx NULL: rows 0..n-1): one segmented radix sort;
+ * for an even n the mean of the two middle elements in the input's precision (np.mean of a float32 pair is a
+ * float32).  med64 f64 [D] for float64 rows, med32 f32 [D] for float32 rows.
+ * workspace: pmc_column_medians_workspace_bytes(n, D, is_f32). */
+int64_t pmc_column_medians_workspace_bytes(int64_t n, int32_t D, int32_t is_f32);
+int pmc_column_medians(const double* x, const float* x32, const int64_t* idx, int64_t n, int32_t D, double* med64,
+                       float* med32, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Bootstrap of the evidence estimate, Sampler._compute_evidence, sampler.py:905-911:
+ * out[b] = logsumexp(logw[choice(n, n)]) - log(n) for b < B, the draws from Philox keyed by (seed, b, draw).
+ * stats f64 [>= 1] on the device: stats[0] = max(logw) (pmc_logw_stats). */
+int pmc_bootstrap_logz(const double* logw, int64_t n, const double* stats, int64_t B, uint64_t seed, double* out,
+                       void* stream);
+
 /* Sampler._resample gather, sampler.py:707-713: dst[i] = src[idx[i]] for the five arrays. */
 int pmc_gather(const int64_t* idx, int64_t n_out, int32_t D, const double* u, const double* x,
                const double* logdetj, const double* logl, const double* logp, double* u_out,

@@ -134,6 +134,15 @@ SIGNATURES = {
     "pmc_event_record": (C.c_int, [c_p, c_p]),
     "pmc_event_elapsed_ms": (C.c_float, [c_p, c_p]),
     "pmc_event_synchronize": (C.c_int, [c_p]),
+    "pmc_sum_f64": (C.c_int, [c_p, i64, c_p, c_p]),
+    "pmc_weights_from_logw": (C.c_int, [c_p, i64, c_p, c_p, c_p]),
+    "pmc_trim_select_workspace_bytes": (C.c_int64, [i64]),
+    "pmc_trim_select": (C.c_int, [c_p, i64, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
+    "pmc_moments_workspace_bytes": (C.c_int64, [i32]),
+    "pmc_moments": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, c_p, c_p, c_p, c_p, i64, c_p]),
+    "pmc_column_medians_workspace_bytes": (C.c_int64, [i64, i32, i32]),
+    "pmc_column_medians": (C.c_int, [c_p, c_p, c_p, i64, i32, c_p, c_p, c_p, i64, c_p]),
+    "pmc_bootstrap_logz": (C.c_int, [c_p, i64, c_p, i64, C.c_uint64, c_p, c_p]),
     "pmc_rng_fill": (C.c_int, [P(pmc_rng_t), f64, c_p, c_p, c_p, i64, i32, c_p]),
     "pmc_event_destroy": (None, [c_p]),
     "pmc_logw": (C.c_int, [c_p, c_p, c_p, f64, c_p, i32, i64, c_p]),

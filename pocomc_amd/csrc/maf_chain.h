@@ -5,6 +5,11 @@
 
 #include "maf_common.h"
 
+// The sweeps of this family (one / two wavefronts per 16 rows, lane-per-walker) promise bit-identical results whatever
+// kernel a launch size selects: no implicit contraction -- fused multiply-adds are written out (fmaf) where wanted, so
+// that two kernels compiled from the same expressions cannot round differently.
+#pragma clang fp contract(off)
+
 __device__ __forceinline__ float selq(const f32x4& v, int q) {
     return q == 0 ? v[0] : (q == 1 ? v[1] : (q == 2 ? v[2] : v[3]));
 }
@@ -16,7 +21,7 @@ __device__ __forceinline__ float comp(const float4& v, int c) {   // c is a comp
 // (about 1 ulp each) instead of three IEEE divisions and expf -- this sits on the dependent chain of every
 // rank.  The difference to the dense kernels' IEEE forms is ~1e-7 relative (tests allow 1e-5).
 __device__ __forceinline__ float fast_ls(float raw) {
-    return raw * __builtin_amdgcn_rcpf(1.0f + fabsf(raw) * 0.14476482730108395f);    // 1/|log(1e-3)|
+    return raw * __builtin_amdgcn_rcpf(fmaf(fabsf(raw), 0.14476482730108395f, 1.0f));    // 1/|log(1e-3)|
 }
 __device__ __forceinline__ float fast_exp_neg(float ls) {
     return __builtin_amdgcn_exp2f(ls * -1.4426950408889634f);

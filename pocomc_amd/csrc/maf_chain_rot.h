@@ -76,7 +76,7 @@ __device__ __forceinline__ void chain_group_rot(ChainRot<MAXO>& s, float* H0, fl
         ladj -= live ? ls : 0.0f;
         if (q == 0 && live) X[lidx(g, p)] = xg;
 #pragma unroll
-        for (int jt = c1 + 1; jt < 4; ++jt) s.a0[jt] += s.w0r[I][jt] * xg;
+        for (int jt = c1 + 1; jt < 4; ++jt) s.a0[jt] = fmaf(s.w0r[I][jt], xg, s.a0[jt]);
         if (!(ABL & 1)) {
 #pragma unroll
             for (int O = 0; O < MAXO; ++O)

@@ -317,7 +317,10 @@ class StepEngine:
 
     # ---------------------------------------------------------------- setup
     def load_state(self, u, x, logdetj, logl, logp):
-        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+        """numpy arrays or (device) tensors: a walker set that already lives in HBM (the Sampler's pool) is copied
+        device to device."""
+        up = lambda a: (a.to(torch.float64) if isinstance(a, torch.Tensor)
+                        else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)))
         self.u.copy_(up(u)); self.x.copy_(up(x))
         self.logdetj.copy_(up(logdetj)); self.logl.copy_(up(logl)); self.logp.copy_(up(logp))
         if self.pre:
@@ -616,8 +619,9 @@ class StepEngine:
         self.step_idx += 1
         return self._np_sums
 
-    def download(self):
-        g = lambda t: t.cpu().numpy()
+    def download(self, device=False):
+        """The walker state as numpy arrays, or (``device=True``) as the engine's own device tensors."""
+        g = (lambda t: t) if device else (lambda t: t.cpu().numpy())
         return dict(u=g(self.u), x=g(self.x), logdetj=g(self.logdetj), logl=g(self.logl), logp=g(self.logp))
 
 
@@ -813,9 +817,10 @@ class LanedEngine:
             tot = sk.copy() if tot is None else tot + sk
         return calls, tot
 
-    def download(self):
-        parts = [e.download() for e in self.lanes]
-        return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    def download(self, device=False):
+        parts = [e.download(device) for e in self.lanes]
+        cat = torch.cat if device else np.concatenate
+        return {k: cat([p[k] for p in parts]) for k in parts[0]}
 
 
 def _global_count(n, group):
@@ -828,11 +833,16 @@ def _global_count(n, group):
 def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
     pre = kind.startswith("preconditioned")
     tpcn = kind in ("preconditioned_pcn", "pcn")
-    u = np.copy(state_dict.get("u"))
-    x = np.copy(state_dict.get("x"))
-    logdetj = np.copy(state_dict.get("logdetj"))
-    logl = np.copy(state_dict.get("logl"))
-    logp = np.copy(state_dict.get("logp"))
+    # numpy arrays (the reference's contract: inputs are copied, mcmc.py:31-35) or device tensors (the Sampler's
+    # pool: the engine copies them into its own buffers on the device; with option_dict["device_state"] the
+    # results stay there too)
+    on_device = isinstance(state_dict.get("u"), torch.Tensor)
+    cp = (lambda a: a) if on_device else np.copy
+    u = cp(state_dict.get("u"))
+    x = cp(state_dict.get("x"))
+    logdetj = cp(state_dict.get("logdetj"))
+    logl = cp(state_dict.get("logl"))
+    logp = cp(state_dict.get("logp"))
     beta = state_dict.get("beta")
     blobs = state_dict.get("blobs")
     have_blobs = blobs is not None
@@ -900,8 +910,13 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
 
     n_total = _global_count(n_walkers, group)
     # stop metric before the first step (mcmc.py:70 / :243), global over the shards
-    init = torch.tensor([0.0, float(np.sum(logl + logp)), float(np.sum(logl + logp + logdetj))] + [0.0] * (n_dim + 1),
-                        dtype=torch.float64, device=eng.device)
+    if on_device:
+        from .tools import device_sum
+        s_l, s_p, s_j = device_sum(logl.contiguous()), device_sum(logp.contiguous()), device_sum(logdetj.contiguous())
+        first = [0.0, s_l + s_p, s_l + s_p + s_j]
+    else:
+        first = [0.0, float(np.sum(logl + logp)), float(np.sum(logl + logp + logdetj))]
+    init = torch.tensor(first + [0.0] * (n_dim + 1), dtype=torch.float64, device=eng.device)
     allreduce_sums(init, group)
     init = init.cpu().numpy()
     ad = Adaptation(kind, n_dim, n_total, n_steps, n_max, option_dict.get("proposal_scale"),
@@ -963,7 +978,10 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
         else:
             _lib.check(eng.lib.pmc_stream_synchronize(eng._stream), "pmc_stream_synchronize")
 
-    out = eng.download()                               # (synchronises: nothing of this call is in flight any more)
+    keep = bool(option_dict.get("device_state", False))
+    if keep:
+        torch.cuda.synchronize(eng.device)             # (nothing of this call is in flight any more)
+    out = eng.download(device=keep)                    # (the numpy download synchronises by itself)
     for e_ in (eng.lanes if laned else [eng]):
         e_._recycle = True
     return dict(u=out["u"], x=out["x"], logdetj=out["logdetj"], logl=out["logl"], logp=out["logp"], blobs=blobs,

@@ -1,12 +1,25 @@
-"""``Sampler`` -- the SMC orchestrator with the surface of ``pocomc.sampler.Sampler``
-(``pocomc/sampler.py:27-1062``): same constructor arguments and defaults, ``run``,
-``posterior``, ``evidence``, ``results``, ``save_state`` / ``load_state``.
+"""``Sampler`` -- preconditioned SMC around a particle pool that never leaves the GPU.
 
-Host logic only: the beta bisection, dynamic ESS, bookkeeping and the user's prior / likelihood
-callbacks stay in Python exactly as in the reference; every array operation on the hot path is a
-call into the gfx950 kernels -- ``mcmc.*`` (mutate), ``Flow.fit / forward / sample`` (train,
-evidence), ``tools.compute_logw_and_logz / effective_sample_size / unique_sample_size /
-trim_weights / *_resample`` (reweight, resample), ``Reparameterize`` (warm-up).
+Drop-in surface of ``pocomc.sampler.Sampler``: the constructor's arguments and defaults (``pocomc/sampler.py:154-185``,
+derived values ``:244-360``) and the methods ``run``, ``posterior``, ``evidence``, ``results``, ``save_state`` /
+``load_state``.  The body is this build's own orchestration:
+
+* the history of ``u, x, logdetj, logl, logp`` lives in HBM (``particles.Particles``); one SMC iteration is
+
+      temper   beta by bisection on the ESS of the mixture weights, evaluated on the resident ``logl`` (two launches
+               and four doubles per trial); importance weights, dynamic ESS and trimming on the device
+      fit      the flow on the surviving rows (gathered on the device), then the geometry of theta (``pool.hip``)
+      draw     resampling indices on the device from numpy's uniforms, one ``pmc_gather`` into the walker state
+      mutate   the MCMC kernel call on device-resident walkers; its result is appended to the pool device to device
+
+  -- particle rows cross PCIe only where the contract demands it: ``x'`` to the host likelihood inside the kernel
+  call, prior draws in, posterior out;
+* one process per GPU (``group`` / an initialised ``torch.distributed`` group): walkers, likelihood calls and flow fits
+  are sharded over the ranks, the pool bookkeeping is replicated (every rank holds the same pool and draws the same
+  indices from the same seeded numpy stream), see ``DESIGN.md`` section 6;
+* the evidence estimate (``sampler.py:869-920``) bootstraps its error on the device (``pmc_bootstrap_logz``).
+
+Reference lines are cited where a formula or a default is taken from them.
 """
 from __future__ import annotations
 
@@ -16,34 +29,34 @@ from pathlib import Path
 import numpy as np
 import torch
 
+from . import _lib
 from . import mcmc as _mcmc
 from .flow import Flow
 from .geometry import Geometry
-from .particles import Particles
+from .particles import Particles, ROW_KEYS
 from .scaler import Reparameterize
-from .tools import (compute_logw_and_logz, effective_sample_size, multinomial_resample, systematic_resample,
-                    trim_weights, unique_sample_size)
+from .tools import multinomial_resample, systematic_resample, unique_sample_size
+
+_KERNELS = {(True, "tpcn"): _mcmc.preconditioned_pcn, (True, "rwm"): _mcmc.preconditioned_rwm,
+            (False, "tpcn"): _mcmc.pcn, (False, "rwm"): _mcmc.rwm}
 
 
 class FunctionWrapper:
-    """``pocomc/tools.py:227-264``."""
+    """``pocomc/tools.py:227-264``: the likelihood with its extra arguments bound."""
 
     def __init__(self, f, args, kwargs):
-        self.f = f
-        self.args = [] if args is None else args
-        self.kwargs = {} if kwargs is None else kwargs
+        self.f, self.args, self.kwargs = f, ([] if args is None else args), ({} if kwargs is None else kwargs)
 
     def __call__(self, x):
         return self.f(x, *self.args, **self.kwargs)
 
 
 class _Progress:
-    """Minimal stand-in for the tqdm bar of ``tools.py:189-224`` (same ``info`` dict / methods)."""
+    """One line per SMC iteration instead of the tqdm bar of ``tools.py:189-224`` (same ``info`` dict / methods; the
+    MCMC kernels update it every step like ``mcmc.py:159-167``)."""
 
     def __init__(self, show=True, initial=0):
-        self.info = {}
-        self.show = show
-        self.n = initial
+        self.info, self.show, self.n = {}, show, initial
 
     def update_stats(self, info):
         self.info = {**self.info, **info}
@@ -59,6 +72,72 @@ class _Progress:
         pass
 
 
+class _Ranks:
+    """The ranks of a one-process-per-GPU run and the three exchanges the Sampler needs between them."""
+
+    def __init__(self, group):
+        self.group, self.world, self.rank = group, 1, 0
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        except (ImportError, RuntimeError):
+            pass
+
+    def _dev(self):
+        import torch.distributed as dist
+        return (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl"
+                else torch.device("cpu"))
+
+    def share(self, n):
+        """This rank's contiguous rows of ``n``."""
+        return slice(self.rank * n // self.world, (self.rank + 1) * n // self.world)
+
+    def gather_rows(self, local, n):
+        """All-gather of the ranks' shares (tensors or numpy arrays) into the full array, identical on every rank."""
+        if self.world == 1:
+            return local
+        import torch.distributed as dist
+        as_np = not isinstance(local, torch.Tensor)
+        mine = (torch.from_numpy(np.ascontiguousarray(local)) if as_np else local.contiguous())
+        home = mine.device
+        mine = mine.to(self._dev())
+        counts = [(r + 1) * n // self.world - r * n // self.world for r in range(self.world)]
+        if len(set(counts)) == 1:
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine, group=self.group)
+        else:
+            parts = []
+            for r in range(self.world):
+                buf = mine if r == self.rank else torch.empty((counts[r],) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+                dist.broadcast(buf, src=dist.get_global_rank(self.group, r) if self.group is not None else r, group=self.group)
+                parts.append(buf)
+        full = torch.cat(parts, dim=0)
+        return full.cpu().numpy() if as_np else full.to(home)
+
+    def total(self, v):
+        if self.world == 1:
+            return v
+        import torch.distributed as dist
+        t = torch.tensor([float(v)], dtype=torch.float64, device=self._dev())
+        dist.all_reduce(t, group=self.group)
+        return type(v)(t.item())
+
+    def same_everywhere(self, t, src=0):
+        """Broadcast a tensor from rank ``src`` (in place)."""
+        if self.world > 1:
+            import torch.distributed as dist
+            buf = t.to(self._dev())
+            dist.broadcast(buf, src=dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
+            t.copy_(buf.to(t.device))
+        return t
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier(group=self.group)
+
+
 class Sampler:
     def __init__(self, prior, likelihood, n_dim=None, n_effective=512, n_active=256, likelihood_args=None,
                  likelihood_kwargs=None, vectorize=False, blobs_dtype=None, periodic=None, reflective=None,
@@ -66,168 +145,141 @@ class Sampler:
                  train_frequency=None, precondition=True, dynamic=True, metric="ess", n_prior=None,
                  sample="tpcn", n_steps=None, n_max_steps=None, resample="mult", output_dir=None,
                  output_label=None, random_state=None, n_ess=None, group=None, mcmc_options=None):
-        # ``mcmc_options``: extra keys for the MCMC kernels' option_dict (pocomc_amd/mcmc.py), e.g.
-        # dict(x_order='F') hands the likelihood x as a Fortran-ordered (n, D) array and switches the kernel call to
-        # its pipelined form (adaptation on the device), dict(lanes=2) steps the walkers as two row ranges.
-        # sampler.py:186-373; default flow 'nsf6' like the reference (sampler.py:169)
-        #
-        # ``group`` / an initialised torch.distributed default group with more than one rank: ONE PROCESS PER GPU.
-        # The expensive parts shard over the ranks -- every MCMC step (walkers row-sharded, one all-reduce of D+4
-        # sums per step), every likelihood call, every flow fit (data parallel, gradient all-reduce) -- while the
-        # bookkeeping of the persistent pool (log-weights, beta bisection, trimming, resampling indices) is
-        # replicated: after each mutation the ranks all-gather their rows, so every rank holds the same pool and
-        # draws the same resampling indices from the same numpy stream (seed the ranks identically:
-        # ``random_state``).  n_active must be a multiple of the number of ranks.
+        """Arguments and defaults of ``pocomc/sampler.py:154-185``, plus
+
+        ``group``         a ``torch.distributed`` process group (default: the initialised default group): one process
+                          per GPU, ``n_active`` a multiple of the number of ranks, ``random_state`` required (the ranks
+                          replicate the pool bookkeeping from the same numpy / torch streams);
+        ``mcmc_options``  extra keys of the MCMC kernels' ``option_dict`` (``pocomc_amd/mcmc.py``), e.g.
+                          ``dict(x_order='F')`` (Fortran-ordered ``x`` for the likelihood, pipelined kernel call),
+                          ``dict(lanes=2)``.
+
+        Supported ``train_config`` keys: those of ``sampler.py:287-299`` (``validation_split, epochs, batch_size,
+        patience, learning_rate, annealing, gaussian_scale, laplace_scale, noise, shuffle, clip_grad_norm, verbose``).
+        """
         if n_ess is not None:
             import warnings
             n_effective = n_ess
             warnings.warn("n_ess is deprecated. Use n_effective instead.", DeprecationWarning, stacklevel=2)
+        self.ranks = _Ranks(group)
+        if self.ranks.world > 1 and random_state is None:
+            raise ValueError("a sharded Sampler (one process per GPU) needs random_state: every rank replicates the "
+                             "pool bookkeeping from the same numpy / torch random streams")
         if random_state is not None:
             np.random.seed(random_state)
             torch.manual_seed(random_state)
         self.random_state = random_state
-        self.group = group
         self.mcmc_options = dict(mcmc_options or {})
-        self.world, self.rank = 1, 0
-        try:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized():
-                self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        except (ImportError, RuntimeError):
-            pass
+
         self.prior = prior
-        self.log_prior = prior.logpdf
-        self.sample_prior = prior.rvs
-        self.bounds = prior.bounds
+        self.log_prior, self.sample_prior, self.bounds = prior.logpdf, prior.rvs, prior.bounds
         self.log_likelihood = FunctionWrapper(likelihood, likelihood_args, likelihood_kwargs)
-        self.blobs_dtype = blobs_dtype
-        self.have_blobs = blobs_dtype is not None
+        self.blobs_dtype, self.have_blobs = blobs_dtype, blobs_dtype is not None
         self.n_dim = prior.dim if n_dim is None else int(n_dim)
         if n_active is None and n_effective is None:
             raise ValueError("At least one of n_active or n_effective must be provided.")
         self.n_active = int(n_effective / 2) if n_active is None else int(n_active)
         self.n_effective = int(2 * n_active) if n_effective is None else int(n_effective)
-        if self.world > 1 and self.n_active % self.world:
+        if self.n_active % self.ranks.world:
             raise ValueError("n_active must be a multiple of the number of ranks")
-        self.n_steps = int(self.n_dim // 2) if n_steps is None else int(n_steps)
-        self.n_max_steps = 10 * self.n_steps if n_max_steps is None else int(n_max_steps)
-        self.n_total = None
-        self.n_evidence = None
-        self.particles = Particles(n_active, n_dim)
-        self.t = 0
-        self.pool = pool
-        if pool is None:
-            self.distribute = map
-        elif isinstance(pool, int) and pool > 1:
+        D = self.n_dim
+        self.n_steps = D // 2 if n_steps is None else int(n_steps)                       # sampler.py:244
+        self.n_max_steps = 10 * self.n_steps if n_max_steps is None else int(n_max_steps)   # :250
+        self.vectorize = vectorize
+        if vectorize and self.have_blobs:
+            raise ValueError("Cannot vectorize likelihood with blobs.")
+        self.pool, self.distribute = pool, map
+        if isinstance(pool, int) and pool > 1:
             from multiprocess import Pool
             self.pool = Pool(pool)
             self.distribute = self.pool.map
-        else:
+        elif pool is not None and not isinstance(pool, int):
             self.distribute = pool.map
-        self.vectorize = vectorize
-        if self.vectorize and self.have_blobs:
-            raise ValueError("Cannot vectorize likelihood with blobs.")
-        self.u_geometry = Geometry()
-        self.theta_geometry = Geometry()
-        self.flow = Flow(self.n_dim, flow)
+
+        for name, value, allowed in (("transform", transform, ("probit", "logit")), ("metric", metric, ("ess", "uss")),
+                                     ("sample", sample, ("tpcn", "rwm")), ("resample", resample, ("mult", "syst"))):
+            if value not in allowed:
+                raise ValueError(f"Invalid {name} {value}. Options are {' or '.join(repr(a) for a in allowed)}.")
+        self.metric, self.sample, self.resample, self.dynamic = metric, sample, resample, dynamic
+        self.preconditioned = precondition
+
+        self.flow = Flow(D, flow)
+        if self.ranks.world > 1:                       # replicated weights: every rank starts from rank 0's init
+            self.ranks.same_everywhere(self.flow.params)
+            self.flow.repack()
         self.train_config = dict(validation_split=0.5, epochs=5000, batch_size=np.minimum(self.n_effective // 2, 512),
-                                 patience=int(self.n_dim), learning_rate=1e-3, annealing=False, gaussian_scale=None,
-                                 laplace_scale=None, noise=None, shuffle=True, clip_grad_norm=1.0, verbose=0)
-        if train_config is not None:
-            self.train_config.update(train_config)
-        self.train_frequency = (np.maximum(self.n_effective // (self.n_active * 2), 1)
-                                if train_frequency is None else int(train_frequency))
+                                 patience=D, learning_rate=1e-3, annealing=False, gaussian_scale=None,
+                                 laplace_scale=None, noise=None, shuffle=True, clip_grad_norm=1.0, verbose=0)   # :287-299
+        self.train_config.update(train_config or {})
+        self.train_frequency = (np.maximum(self.n_effective // (self.n_active * 2), 1) if train_frequency is None
+                                else int(train_frequency))                                                       # :305
         self.flow_untrained = True
-        if transform not in ["probit", "logit"]:
-            raise ValueError(f"Invalid transform {transform}. Options are 'probit' or 'logit'.")
-        self.scaler = Reparameterize(self.n_dim, bounds=self.bounds, periodic=periodic, reflective=reflective,
-                                     transform=transform)
+        self.scaler = Reparameterize(D, bounds=self.bounds, periodic=periodic, reflective=reflective, transform=transform)
+        self.u_geometry, self.theta_geometry = Geometry(), Geometry()
+        self.proposal_scale = 2.38 / D ** 0.5                                                                    # :350
+        self.dynamic_ratio = unique_sample_size(np.ones(self.n_effective), k=self.n_active) / self.n_active      # :340
+        self.n_prior = (int(2 * np.maximum(self.n_effective // self.n_active, 1) * self.n_active) if n_prior is None
+                        else int(np.maximum(n_prior / self.n_active, 1) * self.n_active))                       # :360
         self.output_dir = Path("states") if output_dir is None else output_dir
         self.output_label = "pmc" if output_label is None else output_label
-        self.preconditioned = precondition
-        if metric not in ["ess", "uss"]:
-            raise ValueError(f"Invalid metric {metric}. Options are 'ess' or 'uss'.")
-        self.metric = metric
-        self.dynamic = dynamic
-        self.dynamic_ratio = unique_sample_size(np.ones(self.n_effective), k=self.n_active) / self.n_active
-        if sample not in ["tpcn", "rwm"]:
-            raise ValueError(f"Invalid sample {sample}. Options are 'tpcn' or 'rwm'.")
-        self.sample = sample
-        self.proposal_scale = 2.38 / self.n_dim ** 0.5
-        if resample not in ["mult", "syst"]:
-            raise ValueError(f"Invalid resample {resample}. Options are 'mult' or 'syst'.")
-        self.resample = resample
-        self.n_prior = (int(2 * np.maximum(self.n_effective // self.n_active, 1) * self.n_active) if n_prior is None
-                        else int(np.maximum(n_prior / self.n_active, 1) * self.n_active))
-        self.prior_samples = None
-        self.logz = None
-        self.logz_err = None
-        self.current_particles = None
-        self.warmup = True
-        self.calls = 0
-        self.progress = None
-        self.pbar = None
 
-    # ------------------------------------------------------------------ run
+        self.particles = Particles(self.n_active, D)
+        self.walkers = None            # the current walker set: dict of device tensors (+ host blobs) and scalars
+        self.prior_samples = None
+        self.logz = self.logz_err = None
+        self.t, self.calls, self.warmup = 0, 0, True
+        self.n_total = self.n_evidence = None
+        self.progress = self.pbar = None
+
+    # ranks, as the reference-style attributes
+    @property
+    def world(self):
+        return self.ranks.world
+
+    @property
+    def rank(self):
+        return self.ranks.rank
+
+    @property
+    def group(self):
+        return self.ranks.group
+
+    # ---------------------------------------------------------------------------------------------------- run
     def run(self, n_total=4096, n_evidence=4096, progress=True, resume_state_path=None, save_every=None):
-        """``sampler.py:375-524``."""
+        """``sampler.py:375-524``: warm-up on prior draws, SMC iterations until beta = 1 and the pool's ESS reaches
+        ``n_total``, evidence."""
         if resume_state_path is not None:
             self.load_state(resume_state_path)
-            t0 = self.t
-            self.progress = progress
-            self.pbar = _Progress(self.progress, initial=t0)
+        t0 = self.t
+        self.progress = progress
+        self.pbar = _Progress(progress, initial=t0 if resume_state_path is not None else 0)
+        if resume_state_path is not None:
             self.pbar.update_stats(dict(calls=self.particles.get("calls", -1), beta=self.particles.get("beta", -1),
                                         logZ=self.particles.get("logz", -1)))
         else:
-            t0 = self.t
-            self.progress = progress
-            self.pbar = _Progress(self.progress)
-            self.pbar.update_stats(dict(beta=0.0, calls=self.calls, ESS=self.n_effective, logZ=0.0, logP=0.0,
-                                        acc=0.0, steps=0, eff=0.0))
-        self.n_total = int(n_total)
-        self.n_evidence = int(n_evidence)
+            self.pbar.update_stats(dict(beta=0.0, calls=self.calls, ESS=self.n_effective, logZ=0.0, logP=0.0, acc=0.0,
+                                        steps=0, eff=0.0))
+        self.n_total, self.n_evidence = int(n_total), int(n_evidence)
 
-        def maybe_save():
+        def checkpoint():
             if save_every is not None and (self.t - t0) % int(save_every) == 0 and self.t != t0:
                 self.save_state(Path(self.output_dir) / f"{self.output_label}_{self.t}.state")
 
         if self.prior_samples is None:
             self.prior_samples = self.sample_prior(self.n_prior)
             self.scaler.fit(self.prior_samples)
-        if self.warmup:                                                    # sampler.py:442-489
+        if self.warmup:
             for i in range(self.n_prior // self.n_active):
-                maybe_save()
-                x = self.prior_samples[i * self.n_active:(i + 1) * self.n_active]
-                u = self.scaler.forward(x)
-                logdetj = self.scaler.inverse(u)[1]
-                logp = self.log_prior(x)
-                logl, blobs = self._log_like_sharded(x)
-                self.calls += self.n_active
-                bad = np.isinf(logl)
-                if np.any(bad):                                            # sampler.py:456-468
-                    idx_all = np.arange(len(x))
-                    src = np.random.choice(idx_all[~bad], size=int(bad.sum()), replace=True)
-                    for arr in (x, u, logdetj, logp, logl) + ((blobs,) if self.have_blobs else ()):
-                        arr[idx_all[bad]] = arr[src]
-                self.current_particles = dict(u=u, x=x, logl=logl, logp=logp, logdetj=logdetj,
-                                              logw=-1e300 * np.ones(self.n_active), blobs=blobs, iter=self.t,
-                                              calls=self.calls, steps=1, efficiency=1.0, ess=self.n_effective,
-                                              accept=1.0, beta=0.0, logz=0.0)
-                self.particles.update(self.current_particles)
-                self.pbar.update_stats(dict(calls=self.calls, beta=0.0, ESS=int(self.n_effective), logZ=0.0,
-                                            logP=np.mean(logp + logl), acc=1.0, steps=1, eff=1.0))
-                self.pbar.update_iter()
-                self.t += 1
+                checkpoint()
+                self._warm_up(self.prior_samples[i * self.n_active:(i + 1) * self.n_active])
             self.warmup = False
-
-        while self._not_termination(self.current_particles):               # sampler.py:492-510
-            maybe_save()
-            self.current_particles = self._reweight(self.current_particles)
-            self.current_particles = self._train(self.current_particles)
-            self.current_particles = self._resample(self.current_particles)
-            self.current_particles = self._mutate(self.current_particles)
-            self.particles.update(self.current_particles)
-
+        while self._more():
+            checkpoint()
+            sel = self._temper()
+            self._fit(sel)
+            self._draw(sel)
+            self._mutate()
+            self.particles.update(self.walkers)
         if self.n_evidence > 0 and self.preconditioned:
             self._compute_evidence(self.n_evidence)
         else:
@@ -237,193 +289,171 @@ class Sampler:
             self.save_state(Path(self.output_dir) / f"{self.output_label}_final.state")
         self.pbar.close()
 
-    # ------------------------------------------------------------ sharding
-    def _my_rows(self, n):
-        """This rank's contiguous share of ``n`` rows."""
-        return slice(self.rank * n // self.world, (self.rank + 1) * n // self.world)
+    def _warm_up(self, x):
+        """One block of prior draws into the pool at beta = 0 (``sampler.py:442-489``); rows with an infinite
+        likelihood are replaced by copies of finite ones (``:456-468``)."""
+        u = self.scaler.forward(x)
+        logdetj = self.scaler.inverse(u)[1]
+        logp = self.log_prior(x)
+        logl, blobs = self._log_like_all(x)
+        self.calls += self.n_active
+        bad = np.isinf(logl)
+        if np.any(bad):
+            rows = np.arange(len(x))
+            src = np.random.choice(rows[~bad], size=int(bad.sum()), replace=True)
+            for arr in (x, u, logdetj, logp, logl) + ((blobs,) if self.have_blobs else ()):
+                arr[rows[bad]] = arr[src]
+        self.walkers = dict(u=u, x=x, logl=logl, logp=logp, logdetj=logdetj, blobs=blobs, iter=self.t, calls=self.calls,
+                            steps=1, efficiency=1.0, ess=self.n_effective, accept=1.0, beta=0.0, logz=0.0)
+        self.particles.update(self.walkers)
+        self.pbar.update_stats(dict(calls=self.calls, beta=0.0, ESS=int(self.n_effective), logZ=0.0,
+                                    logP=np.mean(logp + logl), acc=1.0, steps=1, eff=1.0))
+        self.pbar.update_iter()
+        self.t += 1
 
-    def _gather_rows(self, local, n):
-        """All-gather the ranks' row shares (``_my_rows``) back into the full array, identical on every rank."""
-        if self.world == 1:
-            return local
-        import torch.distributed as dist
-        local = np.ascontiguousarray(local)
-        counts = [(r + 1) * n // self.world - r * n // self.world for r in range(self.world)]
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
-        mine = torch.from_numpy(local).to(dev)
-        if len(set(counts)) == 1:
-            parts = [torch.empty_like(mine) for _ in range(self.world)]
-            dist.all_gather(parts, mine, group=self.group)
-        else:
-            parts = []
-            for r in range(self.world):
-                buf = mine if r == self.rank else torch.empty((counts[r],) + tuple(local.shape[1:]), dtype=mine.dtype, device=dev)
-                dist.broadcast(buf, src=dist.get_global_rank(self.group, r) if self.group is not None else r, group=self.group)
-                parts.append(buf)
-        return np.concatenate([p_.cpu().numpy() for p_ in parts], axis=0)
+    def _pool_size(self, stats):
+        """ESS (``tools.py:56-71``) or USS (``tools.py:74-93``) of the pool's weights from ``logw_stats``."""
+        return (stats[1] * stats[1]) / stats[2] if self.metric == "ess" else stats[3]
 
-    def _sum_over_ranks(self, v):
-        if self.world == 1:
-            return v
-        import torch.distributed as dist
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
-        t = torch.tensor([float(v)], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, group=self.group)
-        return type(v)(t.item())
-
-    def _log_like_sharded(self, x):
-        """The likelihood of all rows of ``x`` (identical on every rank), each rank evaluating its share."""
-        if self.world == 1:
-            return self._log_like(x)
-        sl = self._my_rows(len(x))
-        logl, blobs = self._log_like(x[sl])
-        if blobs is not None:
-            raise NotImplementedError("blobs are not supported by the sharded Sampler")
-        return self._gather_rows(np.asarray(logl, dtype=np.float64), len(x)), None
-
-    def _ess(self, weights):
-        return effective_sample_size(weights) if self.metric == "ess" else unique_sample_size(weights)
-
-    def _not_termination(self, current_particles):
+    def _more(self):
         """``sampler.py:526-548``."""
-        logw, _ = self.particles.compute_logw_and_logz(1.0)
-        ess = self._ess(np.exp(logw - np.max(logw)))
-        return 1.0 - current_particles.get("beta") >= 1e-4 or ess < self.n_total
+        P = self.particles
+        st = P.logw_stats(1.0, k=P.P if self.metric == "uss" else 0)
+        return 1.0 - self.walkers.get("beta") >= 1e-4 or self._pool_size(st) < self.n_total
 
-    # -------------------------------------------------------------- mutate
-    def _mutate(self, cp):
-        """``sampler.py:550-634``."""
-        sl = self._my_rows(len(cp["u"]))                      # this rank's walkers (everything when world == 1)
-        state = dict(u=cp["u"][sl].copy(), x=cp["x"][sl].copy(), logdetj=cp["logdetj"][sl].copy(),
-                     logp=cp["logp"][sl].copy(), logl=cp["logl"][sl].copy(), beta=cp["beta"],
-                     blobs=cp["blobs"][sl].copy() if self.have_blobs else None)
-        if self.world > 1 and self.have_blobs:
-            raise NotImplementedError("blobs are not supported by the sharded Sampler")
-        funcs = dict(loglike=self._log_like, logprior=self.log_prior, scaler=self.scaler, flow=self.flow,
-                     u_geometry=self.u_geometry, theta_geometry=self.theta_geometry)
-        opts = dict(n_max=self.n_max_steps, n_steps=self.n_steps, progress_bar=self.pbar,
-                    proposal_scale=self.proposal_scale)
-        opts.update(self.mcmc_options)
-        if self.world > 1:
-            opts.update(group=self.group, shard_offset=sl.start)
-        kernel = {(True, "tpcn"): _mcmc.preconditioned_pcn, (True, "rwm"): _mcmc.preconditioned_rwm,
-                  (False, "tpcn"): _mcmc.pcn, (False, "rwm"): _mcmc.rwm}[(bool(self.preconditioned), self.sample)]
-        res = kernel(state, funcs, opts)
-        n_all = len(cp["u"])
-        for k in ("u", "x", "logdetj", "logl", "logp"):
-            cp[k] = self._gather_rows(res[k], n_all).copy()
-        if self.have_blobs:
-            cp["blobs"] = res["blobs"].copy()
-        cp["efficiency"] = res["efficiency"] / (2.38 / self.n_dim ** 0.5)
-        cp["steps"] = res["steps"]
-        cp["accept"] = res["accept"]
-        cp["calls"] = cp["calls"] + self._sum_over_ranks(int(res["calls"]))
-        self.calls = cp["calls"]
-        self.proposal_scale = res["proposal_scale"]
-        return cp
+    # ------------------------------------------------------------------------------------------------- temper
+    def _temper(self):
+        """Next inverse temperature, importance weights and the trimmed pool (``sampler.py:717-805``), all on the
+        resident history.  Returns the selection ``(idx, weights)`` as device tensors."""
+        self.t += 1
+        self.pbar.update_iter()
+        P = self.particles
+        hist = P._history()
+        k_uss = P.P if self.metric == "uss" else 0
+        size_at = lambda b: self._pool_size(P.logw_stats(b, k=k_uss, history=hist))
+        logz_at = lambda st: st[0] + np.log(st[1]) - np.log(P.P)
 
-    # --------------------------------------------------------------- train
-    def _train(self, cp):
-        """``sampler.py:636-678``."""
-        u, w = cp["u"], cp["weights"]
-        if self.preconditioned and (self.t % self.train_frequency == 0 or cp["beta"] == 1.0 or self.flow_untrained):
+        lo = float(P.get("beta", index=-1))
+        ess_lo, ess_hi = size_at(lo), size_at(1.0)
+        if ess_lo <= self.n_effective:                     # the pool cannot afford a colder target yet
+            beta, ess, logz = lo, ess_lo, P.get("logz", index=-1)
+        elif ess_hi >= self.n_effective:                   # the posterior itself is affordable
+            beta, ess = 1.0, ess_hi
+            logz = logz_at(P.logw_stats(1.0, history=hist))
+        else:                                              # bisection on [previous beta, 1], sampler.py:765-777
+            hi = 1.0
+            while True:
+                beta = (hi + lo) * 0.5
+                ess = size_at(beta)
+                if np.abs(ess - self.n_effective) < 0.01 * self.n_effective or beta == 1.0:
+                    logz = logz_at(P.logw_stats(beta, history=hist))
+                    break
+                if ess < self.n_effective:
+                    hi = beta
+                else:
+                    lo = beta
+        self.pbar.update_stats(dict(beta=beta, ESS=int(ess), logZ=logz))
+        st = P.logw_stats(beta, k=self.n_active if self.dynamic else 0, history=hist)     # (leaves logw at beta resident)
+        if self.dynamic:                                                                  # sampler.py:783-790
+            n_unique = st[3]
+            if n_unique < self.n_active * (0.95 * self.dynamic_ratio):
+                self.n_effective = int(self.n_active / n_unique * self.n_effective)
+            elif n_unique > self.n_active * np.minimum(1.05 * self.dynamic_ratio, 1.0):
+                self.n_effective = int(n_unique / self.n_active * self.n_effective)
+        _, idx, w = P.select(ess=0.99, bins=1000)                                         # trim_weights, :792
+        self.walkers.update(logz=logz, beta=beta, ess=ess)
+        return idx, w
+
+    # ---------------------------------------------------------------------------------------------------- fit
+    def _fit(self, sel):
+        """Flow and geometry on the selected rows (``sampler.py:636-678``)."""
+        idx, w = sel
+        u = self.particles.rows("u")[idx]                  # (row gather on the device)
+        beta = self.walkers["beta"]
+        if self.preconditioned and (self.t % self.train_frequency == 0 or beta == 1.0 or self.flow_untrained):
             self.flow_untrained = False
             c = self.train_config
-            # sharded: every rank fits on its share of the rows (strided, so that each share follows the same
-            # weight distribution); gradients and losses are all-reduced inside fit
-            ut, wt = (u, w) if self.world == 1 else (u[self.rank::self.world], w[self.rank::self.world])
-            if self.world > 1:                                 # equal shares: drop the remainder rows
-                m_ = len(u) // self.world
-                ut, wt = ut[:m_], wt[:m_]
-            as32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
-            self.flow.fit(as32(ut), weights=as32(wt),
-                          validation_split=c["validation_split"], epochs=c["epochs"],
-                          batch_size=int(np.minimum(len(u) // 2, c["batch_size"])), gaussian_scale=c["gaussian_scale"],
+            u32, w32 = u.to(torch.float32), w.to(torch.float32)
+            if self.world > 1:
+                # data parallel: every rank fits on a strided share of the rows (equal shares; the remainder rows are
+                # dropped), gradients and losses are all-reduced inside fit
+                m = len(u32) // self.world
+                ut, wt = u32[self.rank::self.world][:m], w32[self.rank::self.world][:m]
+            else:
+                ut, wt = u32, w32
+            self.flow.fit(ut, weights=wt, validation_split=c["validation_split"], epochs=c["epochs"],
+                          batch_size=int(np.minimum(len(u32) // 2, c["batch_size"])), gaussian_scale=c["gaussian_scale"],
                           laplace_scale=c["laplace_scale"], patience=c["patience"], learning_rate=c["learning_rate"],
                           annealing=c["annealing"], noise=c["noise"], shuffle=c["shuffle"],
                           clip_grad_norm=c["clip_grad_norm"], verbose=c["verbose"], group=self.group,
                           sharded=self.world > 1)
-            theta = self.flow.forward(as32(u))[0].numpy()
+            theta = self.flow.forward(u32)[0]              # float32 on the device (tools.py:336-340)
             self.theta_geometry.fit(theta, weights=w)
         else:
             self.u_geometry.fit(u, weights=w)
-        return cp
 
-    # ------------------------------------------------------------ resample
-    def _resample(self, cp):
-        """``sampler.py:680-715``."""
-        w = cp["weights"]
+    # --------------------------------------------------------------------------------------------------- draw
+    def _draw(self, sel):
+        """``n_active`` walkers from the selection (``sampler.py:680-715``): indices on the device from numpy's
+        uniforms (``np.random.choice(p=w)`` / the systematic scheme), one gather out of the pool."""
+        idx, w = sel
         if self.resample == "mult":
-            idx = multinomial_resample(self.n_active, w)           # = np.random.choice(len(w), n_active, p=w)
+            pick = multinomial_resample(self.n_active, w, device_indices=True)
         else:
-            idx = systematic_resample(self.n_active, weights=w)
-        for k in ("u", "x", "logdetj", "logl", "logp") + (("blobs",) if self.have_blobs else ()):
-            cp[k] = cp[k][idx]
-        return cp
+            pick = systematic_resample(self.n_active, weights=w, device_indices=True)
+        rows = idx[pick]
+        self.walkers.update(self.particles.take(rows))
+        if self.have_blobs:
+            self.walkers["blobs"] = self.particles.get("blobs", flat=True)[rows.cpu().numpy()]
 
-    # ------------------------------------------------------------ reweight
-    def _reweight(self, cp):
-        """``sampler.py:717-805``: next beta by bisection on the ESS of the mixture weights."""
-        self.t += 1
-        self.pbar.update_iter()
-        beta_prev = self.particles.get("beta", index=-1)
-        beta_max, beta_min = 1.0, np.copy(beta_prev)
+    # ------------------------------------------------------------------------------------------------- mutate
+    def _mutate(self):
+        """One MCMC kernel call on the walkers (``sampler.py:550-634``).  Sharded: every rank moves its rows and the
+        ranks exchange the results, so that all hold the same walker set again."""
+        w, n = self.walkers, self.n_active
+        sl = self.ranks.share(n)
+        state = {k: w[k][sl] for k in ROW_KEYS}
+        state.update(beta=w["beta"], blobs=w["blobs"][sl].copy() if self.have_blobs else None)
+        funcs = dict(loglike=self._log_like, logprior=self.log_prior, scaler=self.scaler, flow=self.flow,
+                     u_geometry=self.u_geometry, theta_geometry=self.theta_geometry)
+        opts = dict(n_max=self.n_max_steps, n_steps=self.n_steps, progress_bar=self.pbar,
+                    proposal_scale=self.proposal_scale, device_state=True)
+        opts.update(self.mcmc_options)
+        if self.world > 1:
+            opts.update(group=self.group, shard_offset=sl.start)
+        res = _KERNELS[(bool(self.preconditioned), self.sample)](state, funcs, opts)
+        for k in ROW_KEYS:
+            w[k] = self.ranks.gather_rows(res[k], n)
+        if self.have_blobs:
+            w["blobs"] = self._gather_blobs(res["blobs"], n)
+        self.calls = w["calls"] = self.calls + self.ranks.total(int(res["calls"]))
+        w.update(efficiency=res["efficiency"] / (2.38 / self.n_dim ** 0.5), steps=res["steps"], accept=res["accept"],
+                 iter=self.t)
+        self.proposal_scale = res["proposal_scale"]
 
-        # the history stays on the device for the whole bisection: a trial is two launches and four doubles back
-        pool = self.particles.pool_weights()
+    def _gather_blobs(self, local, n):
+        """The ranks' blobs (host arrays of any dtype) in walker order."""
+        if self.world == 1:
+            return local.copy()
+        import torch.distributed as dist
+        parts = [None] * self.world
+        dist.all_gather_object(parts, local, group=self.group)
+        return np.concatenate(parts, axis=0)
 
-        def weights_and_ess(beta):
-            return None, (pool.ess(beta) if self.metric == "ess" else pool.uss(beta))
-
-        w_prev, ess_prev = weights_and_ess(beta_prev)
-        w_max, ess_max = weights_and_ess(beta_max)
-        if ess_prev <= self.n_effective:
-            beta, ess_est = beta_prev, ess_prev
-            logz = self.particles.get("logz", index=-1)
-        elif ess_max >= self.n_effective:
-            beta, ess_est = beta_max, ess_max
-            _, logz = pool.logw_and_logz(beta)
-        else:
-            while True:
-                beta = (beta_max + beta_min) * 0.5
-                _, ess_est = weights_and_ess(beta)
-                if np.abs(ess_est - self.n_effective) < 0.01 * self.n_effective or beta == 1.0:
-                    _, logz = pool.logw_and_logz(beta)
-                    break
-                elif ess_est < self.n_effective:
-                    beta_max = beta
-                else:
-                    beta_min = beta
-        self.pbar.update_stats(dict(beta=beta, ESS=int(ess_est), logZ=logz))
-        logw, _ = pool.logw_and_logz(beta)
-        weights = np.exp(logw - np.max(logw))
-        weights /= np.sum(weights)
-        if self.dynamic:                                                   # sampler.py:783-790
-            n_unique_active = unique_sample_size(weights, k=self.n_active)
-            if n_unique_active < self.n_active * (0.95 * self.dynamic_ratio):
-                self.n_effective = int(self.n_active / n_unique_active * self.n_effective)
-            elif n_unique_active > self.n_active * np.minimum(1.05 * self.dynamic_ratio, 1.0):
-                self.n_effective = int(n_unique_active / self.n_active * self.n_effective)
-        idx, weights = trim_weights(np.arange(len(weights)), weights, ess=0.99, bins=1000)
-        for k in ("u", "x", "logdetj", "logl", "logp") + (("blobs",) if self.have_blobs else ()):
-            cp[k] = self.particles.get(k, index=None, flat=True)[idx]
-        cp["logz"], cp["beta"], cp["weights"], cp["ess"] = logz, beta, weights, ess_est
-        return cp
-
-    # ----------------------------------------------------------- likelihood
+    # --------------------------------------------------------------------------------------------- likelihood
     def _log_like(self, x):
-        """``sampler.py:807-861``."""
+        """``sampler.py:807-861``: vectorised call, or a map over the rows whose extra returns become blobs."""
         if self.vectorize:
             return self.log_likelihood(x), None
         results = list(self.distribute(self.log_likelihood, x))
         try:
-            blob = [l[1:] for l in results if len(l) > 1]
-            if not len(blob):
+            blob = [r[1:] for r in results if len(r) > 1]
+            if not blob:
                 raise IndexError
-            logl = np.array([float(l[0]) for l in results])
+            logl = np.array([float(r[0]) for r in results])
             self.have_blobs = True
         except (IndexError, TypeError):
-            return np.array([float(l) for l in results]), None
+            return np.array([float(r) for r in results]), None
         if self.blobs_dtype is not None:
             dt = self.blobs_dtype
         else:
@@ -434,59 +464,80 @@ class Sampler:
             if dt.kind in "US":
                 dt = np.dtype("object")
         blob = np.array(blob, dtype=dt)
-        shape = blob.shape[1:]
-        if len(shape):
-            axes = np.arange(len(shape))[np.array(shape) == 1] + 1
-            if len(axes):
-                blob = np.squeeze(blob, tuple(axes))
+        axes = [a + 1 for a, s in enumerate(blob.shape[1:]) if s == 1]
+        if axes:
+            blob = np.squeeze(blob, tuple(axes))
         return logl, blob
 
-    # ------------------------------------------------------------- evidence
+    def _log_like_all(self, x):
+        """The likelihood of all rows of ``x`` (identical on every rank), each rank evaluating its share."""
+        if self.world == 1:
+            return self._log_like(x)
+        sl = self.ranks.share(len(x))
+        logl, blobs = self._log_like(x[sl])
+        logl = self.ranks.gather_rows(np.asarray(logl, dtype=np.float64), len(x))
+        return logl, (None if blobs is None else self._gather_blobs(blobs, len(x)))
+
+    # ----------------------------------------------------------------------------------------------- evidence
     def evidence(self):
         return self.logz, self.logz_err
 
     def _compute_evidence(self, n=5_000):
-        """``sampler.py:869-920``: importance sampling with the flow as proposal."""
+        """Importance sampling with the flow as proposal (``sampler.py:869-920``): ``x_q`` goes to the host for the
+        likelihood (the black box lives there); the error is the spread of ``max(n, 1000)`` bootstrap replicates of
+        the estimate, drawn and reduced on the device."""
         theta_q, logq = self.flow.sample(n)
-        theta_q, logq = theta_q.cpu().numpy().astype(np.float64), logq.cpu().numpy().astype(np.float64)
-        x_q, logdetj = self.scaler.inverse(theta_q)
+        x_q, logdetj = self.scaler.inverse(theta_q.cpu().numpy().astype(np.float64))
+        logq = logq.cpu().numpy().astype(np.float64)
         logp = self.log_prior(x_q)
         ok = np.isfinite(logp)
         x_q, logdetj, logq, logp = x_q[ok], logdetj[ok], logq[ok], logp[ok]
-        logl, _ = self._log_like_sharded(x_q)
+        logl, _ = self._log_like_all(x_q)
         logw = logl + logp + logdetj - logq
-        logz = np.logaddexp.reduce(logw) - np.log(len(logw))
-        dlogz = np.std([np.logaddexp.reduce(logw[np.random.choice(len(logw), len(logw))]) - np.log(len(logw))
-                        for _ in range(np.maximum(n, 1000))])
-        self.calls += len(logw)
+        m = len(logw)
+        lib, dev = _lib.load(), self.flow.device
+        lw = torch.from_numpy(np.ascontiguousarray(logw)).to(dev)
+        stats = torch.zeros(4, dtype=torch.float64, device=dev)
+        ws = torch.empty(int(lib.pmc_reduce_workspace_bytes(m)), dtype=torch.uint8, device=dev)
+        B = int(np.maximum(n, 1000))
+        reps = torch.empty(B, dtype=torch.float64, device=dev)
+        seed = int(np.random.randint(0, 2 ** 31 - 1)) * 2 ** 31 + int(np.random.randint(0, 2 ** 31 - 1))
+        with torch.cuda.device(dev):
+            st = _lib.stream_handle()
+            _lib.check(lib.pmc_logw_stats(_lib.ptr(lw), m, 0, _lib.ptr(stats), _lib.ptr(ws), st), "pmc_logw_stats")
+            _lib.check(lib.pmc_bootstrap_logz(_lib.ptr(lw), m, _lib.ptr(stats), B, seed, _lib.ptr(reps), st), "pmc_bootstrap_logz")
+        s = stats.cpu().numpy()
+        logz = s[0] + np.log(s[1]) - np.log(m)
+        dlogz = float(np.std(reps.cpu().numpy()))
+        self.calls += m
         self.pbar.update_stats(dict(calls=self.calls))
         self.logz, self.logz_err = logz, dlogz
         return logz, dlogz
 
-    # ------------------------------------------------------------ posterior
+    # ---------------------------------------------------------------------------------------------- posterior
     def posterior(self, resample=False, return_blobs=False, trim_importance_weights=True, return_logw=False,
                   ess_trim=0.99, bins_trim=1_000):
-        """``sampler.py:937-1010``."""
+        """``sampler.py:937-1010``: the pool as weighted posterior samples (numpy out)."""
         if return_blobs and not self.have_blobs:
             raise ValueError("No blobs available.")
-        samples = self.particles.get("x", flat=True)
-        logl = self.particles.get("logl", flat=True)
-        logp = self.particles.get("logp", flat=True)
-        blobs = self.particles.get("blobs", flat=True) if return_blobs else None
-        logw, _ = self.particles.compute_logw_and_logz(1.0)
-        weights = np.exp(logw)
+        P = self.particles
+        P.logw_stats(1.0)
         if trim_importance_weights:
-            idx, weights = trim_weights(np.arange(len(samples)), weights, ess=ess_trim, bins=bins_trim)
-            samples, logl, logp, logw = samples[idx], logl[idx], logp[idx], logw[idx]
-            if return_blobs:
-                blobs = blobs[idx]
+            _, idx, w = P.select(ess=ess_trim, bins=bins_trim)
+        else:
+            w, _, _ = P.select(ess=ess_trim, bins=bins_trim)
+            idx = torch.arange(P.P, device=w.device)
+        st = P._h_stats.numpy()
+        logw = (P._lw[:P.P] - (st[0] + np.log(st[1])))[idx].cpu().numpy()
+        idx_h = idx.cpu().numpy()
+        samples, logl, logp = (P.get(k, flat=True)[idx_h] for k in ("x", "logl", "logp"))
+        weights = w.cpu().numpy()
+        blobs = P.get("blobs", flat=True)[idx_h] if return_blobs else None
         if resample:
-            if self.resample == "mult":
-                idx = multinomial_resample(len(samples), weights)
-            else:
-                idx = systematic_resample(len(weights), weights=weights)
-            out = (samples[idx], logl[idx], logp[idx])
-            return out + ((blobs[idx],) if return_blobs else ())
+            pick = (multinomial_resample(len(samples), weights) if self.resample == "mult"
+                    else systematic_resample(len(weights), weights=weights))
+            out = (samples[pick], logl[pick], logp[pick])
+            return out + ((blobs[pick],) if return_blobs else ())
         out = (samples, logw if return_logw else weights, logl, logp)
         return out + ((blobs,) if return_blobs else ())
 
@@ -494,28 +545,37 @@ class Sampler:
     def results(self):
         return self.particles.compute_results()
 
-    # ----------------------------------------------------------- checkpoint
+    # --------------------------------------------------------------------------------------------- checkpoints
+    _VOLATILE = ("pool", "distribute", "pbar", "ranks", "progress")
+
     def __getstate__(self):
-        state = self.__dict__.copy()
-        for k in ("pool", "distribute", "pbar", "group"):
-            state.pop(k, None)
+        """Plain arrays and numbers (the pool and the walkers are downloaded, the flow is its parameter vector); nothing
+        that belongs to THIS process -- ranks, process group, worker pool, progress line -- is saved."""
+        state = {k: v for k, v in self.__dict__.items() if k not in self._VOLATILE}
+        if state.get("walkers") is not None:
+            state["walkers"] = {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in state["walkers"].items()}
         return state
 
     def save_state(self, path):
-        """``sampler.py:1023-1049``: dill dump to ``*.temp``, fsync, atomic rename."""
+        """``sampler.py:1023-1049``: dill dump to ``*.temp``, fsync, atomic rename -- written by rank 0 only; the other
+        ranks wait for the file."""
         import dill
-        print(f"Saving PMC state to {path}")
-        Path(path).parent.mkdir(exist_ok=True)
-        temp_path = Path(path).with_suffix(".temp")
-        with open(temp_path, "wb") as f:
-            dill.dump(file=f, obj=self.__getstate__())
-            f.flush()
-            os.fsync(f.fileno())
-        os.rename(temp_path, path)
+        if self.rank == 0:
+            print(f"Saving PMC state to {path}")
+            Path(path).parent.mkdir(exist_ok=True)
+            temp_path = Path(path).with_suffix(".temp")
+            with open(temp_path, "wb") as f:
+                dill.dump(file=f, obj=self.__getstate__())
+                f.flush()
+                os.fsync(f.fileno())
+            os.rename(temp_path, path)
+        self.ranks.barrier()
 
     def load_state(self, path):
-        """``sampler.py:1051-1061``."""
+        """``sampler.py:1051-1061``; ranks / group / pools stay those of the loading process."""
         import dill
         with open(path, "rb") as f:
             state = dill.load(file=f)
-        self.__dict__ = {**self.__dict__, **state}
+        for k in self._VOLATILE:
+            state.pop(k, None)
+        self.__dict__.update(state)

@@ -186,36 +186,67 @@ def increment_logz(logw):
     return st[0] + np.log(st[1])
 
 
-def systematic_resample(size, weights, random_state=None, offset=None):
-    """``pocomc/tools.py:136-186``; indices are bit-exact with the reference."""
+def device_sum(a_d):
+    """``np.sum`` of a float64 device vector, added in a fixed order on the device."""
+    lib = _lib.load()
+    out = torch.empty(1, dtype=torch.float64, device=a_d.device)
+    with torch.cuda.device(a_d.device):
+        _lib.check(lib.pmc_sum_f64(_lib.ptr(a_d), a_d.numel(), _lib.ptr(out), _lib.stream_handle()), "pmc_sum_f64")
+    return float(out.item())
+
+
+def systematic_resample(size, weights, random_state=None, offset=None, device_indices=False):
+    """``pocomc/tools.py:136-186``; indices are bit-exact with the reference.  ``weights`` may be a float64 device
+    tensor (the pool's weights); ``device_indices=True`` leaves the indices on the device."""
     lib = _lib.load()
     if random_state is not None:
         np.random.seed(random_state)
-    if abs(np.sum(weights) - 1.) > SQRTEPS:
-        weights = np.array(weights) / np.sum(weights)
+    if isinstance(weights, torch.Tensor):
+        wd = weights.to(_dev(), torch.float64).contiguous()
+        total = device_sum(wd)
+        if abs(total - 1.) > SQRTEPS:
+            wd = wd / total
+    else:
+        if abs(np.sum(weights) - 1.) > SQRTEPS:
+            weights = np.array(weights) / np.sum(weights)
+        wd = _up(weights)
     if offset is None:
         offset = np.random.random()
-    wd = _up(weights)
     cdf = torch.empty_like(wd)
     idx = torch.empty(int(size), dtype=torch.int64, device=wd.device)
     with torch.cuda.device(wd.device):
         _lib.check(lib.pmc_resample_systematic(_lib.ptr(wd), wd.numel(), float(offset), int(size), _lib.ptr(cdf),
                                                _lib.ptr(idx), _lib.stream_handle()), "pmc_resample_systematic")
-    return idx.cpu().numpy()
+    return idx if device_indices else idx.cpu().numpy()
 
 
-def multinomial_resample(size, weights, uniforms=None):
-    """``np.random.choice(len(w), size, p=w)`` of ``pocomc/sampler.py:703``."""
+def multinomial_resample(size, weights, uniforms=None, device_indices=False):
+    """``np.random.choice(len(w), size, p=w)`` of ``pocomc/sampler.py:703`` (same uniforms from numpy's legacy stream,
+    same ``cdf.searchsorted(u, 'right')``), with numpy's validation of ``p`` (``ValueError`` for NaN / negative /
+    non-normalised probabilities).  ``weights`` may be a float64 device tensor."""
     lib = _lib.load()
+    if isinstance(weights, torch.Tensor):
+        wd = weights.to(_dev(), torch.float64).contiguous()
+        total = device_sum(wd)                      # (NaN weights make the total NaN; negative ones: logw_stats)
+    else:
+        weights = np.asarray(weights, dtype=np.float64)
+        if np.any(weights < 0):
+            raise ValueError("probabilities are not non-negative")
+        wd = _up(weights)
+        total = float(np.sum(weights))
+    if not np.isfinite(total):
+        raise ValueError("probabilities contain NaN")
+    if abs(total - 1.) > SQRTEPS:
+        raise ValueError("probabilities do not sum to 1")
     if uniforms is None:
         uniforms = np.random.random_sample(int(size))
-    wd, ud = _up(weights), _up(uniforms)
+    ud = _up(uniforms)
     cdf = torch.empty_like(wd)
     idx = torch.empty(int(size), dtype=torch.int64, device=wd.device)
     with torch.cuda.device(wd.device):
         _lib.check(lib.pmc_resample_multinomial(_lib.ptr(wd), wd.numel(), _lib.ptr(ud), int(size), _lib.ptr(cdf),
                                                 _lib.ptr(idx), _lib.stream_handle()), "pmc_resample_multinomial")
-    return idx.cpu().numpy()
+    return idx if device_indices else idx.cpu().numpy()
 
 
 def gather(idx, u, x, logdetj, logl, logp):

@@ -288,3 +288,117 @@ def test_step_outputs_written_straight_to_pinned_host_memory():
     for k in ("u", "x", "logl", "logp", "logdetj"):
         assert np.array_equal(res[0][k], res[1][k])
     assert res[0]["steps"] == res[1]["steps"] == 6 and res[0]["accept"] == res[1]["accept"]
+
+
+# ------------------------------------------------------------------------------------------------ pool on the device
+def test_geometry_on_the_device_matches_the_reference(golden_dir):
+    """Geometry.fit (geometry.py:31-59 + student.py:43-60) from the device reductions against the vectors the
+    reference produced: unweighted and weighted (systematic resampling inside, np.random.seed(11) like the generator)."""
+    import torch
+    from pocomc_amd.geometry import Geometry
+    g = np.load(f"{golden_dir}/tools_reference.npz")
+    th = g["geometry/theta"]
+    for src in (th, torch.from_numpy(th).cuda()):                        # host array and device-resident sample
+        G = Geometry()
+        G.fit(src)
+        np.testing.assert_allclose(G.t_mean, g["geometry/t_mean"], rtol=1e-12)
+        np.testing.assert_allclose(G.t_cov, g["geometry/t_cov"], rtol=1e-10, atol=1e-13)
+        assert G.t_nu == float(g["geometry/t_nu"]) == 1e6
+        np.testing.assert_allclose(G.normal_mean, g["geometry/normal_mean"], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(G.normal_cov, g["geometry/normal_cov"], rtol=1e-10, atol=1e-13)
+    np.random.seed(11)
+    G2 = Geometry()
+    G2.fit(th, weights=g["geometry/w"])
+    np.testing.assert_allclose(G2.t_mean, g["geometry/w_t_mean"], rtol=1e-12)
+    np.testing.assert_allclose(G2.t_cov, g["geometry/w_t_cov"], rtol=1e-10, atol=1e-13)
+    assert G2.t_nu == float(g["geometry/w_t_nu"])
+    np.testing.assert_allclose(G2.normal_cov, g["geometry/w_normal_cov"], rtol=1e-10, atol=1e-13)
+
+
+@pytest.mark.parametrize("n,D,f32", [(1, 3, False), (2, 3, False), (601, 5, False), (1000, 32, True), (20000, 50, True), (4097, 128, False)])
+def test_moments_and_medians_match_numpy(n, D, f32):
+    import torch
+    from pocomc_amd.geometry import moments, column_medians
+    rng = np.random.default_rng(n + D)
+    x = rng.standard_t(4.0, size=(n, D)) * rng.uniform(0.5, 3.0, size=D) + rng.normal(size=D)
+    x = x.astype(np.float32 if f32 else np.float64)
+    w = rng.uniform(0.1, 1.0, n)
+    idx = rng.integers(0, n, size=max(n // 2, 1))
+    xd, wd, idd = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda(), torch.from_numpy(idx).cuda()
+    x64 = x.astype(np.float64)
+    mean, S, v1, v2 = moments(xd, None, wd)
+    np.testing.assert_allclose(mean, np.average(x64, axis=0, weights=w), rtol=1e-12, atol=1e-13)
+    c = x64 - np.average(x64, axis=0, weights=w)
+    np.testing.assert_allclose(S, (c * w[:, None]).T @ c, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose([v1, v2], [w.sum(), (w * w).sum()], rtol=1e-13)
+    mean_i, S_i, _, _ = moments(xd, idd)
+    xs = x64[idx]
+    np.testing.assert_allclose(mean_i, xs.mean(axis=0), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(S_i, (xs - xs.mean(0)).T @ (xs - xs.mean(0)), rtol=1e-10, atol=1e-10)
+    np.testing.assert_array_equal(column_medians(xd), np.median(x, axis=0))              # bit-exact (same elements)
+    np.testing.assert_array_equal(column_medians(xd, idd), np.median(x[idx], axis=0))
+
+
+def test_pool_select_equals_reference_trim_and_weights(golden_dir):
+    """Particles.select: importance weights (sampler.py:779-781) and trim_weights (tools.py:10-53) on the resident pool
+    against the reference's vectors (persistent-sampling history of the golden generator)."""
+    from pocomc_amd.particles import Particles
+    from oracle import tools as otools
+    g = np.load(f"{golden_dir}/tools_reference.npz")
+    logl, beta, logz = g["particles/logl"], g["particles/beta"], g["particles/logz"]
+    T, N = logl.shape
+    P = Particles(N, 5)
+    rng = np.random.default_rng(0)
+    rows = {k: rng.normal(size=(T, N, 5) if k in ("u", "x") else (T, N)) for k in ("u", "x", "logdetj", "logp")}
+    for t in range(T):
+        P.update(dict(u=rows["u"][t], x=rows["x"][t], logdetj=rows["logdetj"][t], logp=rows["logp"][t], logl=logl[t],
+                      beta=beta[t], logz=logz[t], iter=t, calls=0, steps=1, efficiency=1.0, ess=1.0, accept=1.0))
+    for bf in (0.3, 1.0):
+        lw, lz = P.compute_logw_and_logz(bf)
+        np.testing.assert_allclose(lw, g[f"particles/logw_b{bf}"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(lz, g[f"particles/logz_b{bf}"], rtol=1e-13)
+        P.logw_stats(bf)
+        w, idx, wt = P.select(ess=0.99, bins=1000)
+        w_ref = np.exp(g[f"particles/logw_b{bf}"] - g[f"particles/logw_b{bf}"].max()); w_ref /= w_ref.sum()
+        np.testing.assert_allclose(w.cpu().numpy(), w_ref, rtol=1e-12)
+        idx_ref, wt_ref = otools.trim_weights(np.arange(len(w_ref)), w_ref.copy(), ess=0.99, bins=1000)   # pinned to the reference
+        np.testing.assert_array_equal(idx.cpu().numpy(), idx_ref)
+        np.testing.assert_allclose(wt.cpu().numpy(), wt_ref, rtol=1e-12)
+        got = P.take(idx[:7])
+        for k in ("u", "x", "logdetj", "logp"):
+            np.testing.assert_array_equal(got[k].cpu().numpy(), rows[k].reshape((T * N,) + rows[k].shape[2:])[idx_ref[:7]])
+    # the pool grows past its first allocation and keeps its rows
+    for t in range(40):
+        P.update(dict(u=rows["u"][0], x=rows["x"][0], logdetj=rows["logdetj"][0], logp=rows["logp"][0], logl=logl[0],
+                      beta=1.0, logz=0.0, iter=t, calls=0, steps=1, efficiency=1.0, ess=1.0, accept=1.0))
+    np.testing.assert_array_equal(P.get("logl")[:T], logl)
+    assert P.get("u", flat=True).shape == ((T + 40) * N, 5)
+
+
+def test_bootstrap_of_the_evidence_estimate():
+    """pmc_bootstrap_logz (sampler.py:905-911): every replicate is logsumexp of n draws with replacement - log n; mean
+    and spread agree with numpy's bootstrap of the same log-weights."""
+    import ctypes as C
+    import torch
+    from pocomc_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    n, B = 4096, 4096
+    logw = rng.normal(size=n) * 2.0 - 30.0
+    lw = torch.from_numpy(logw).cuda()
+    stats = torch.zeros(4, dtype=torch.float64, device="cuda")
+    ws = torch.empty(int(lib.pmc_reduce_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
+    reps = torch.empty(B, dtype=torch.float64, device="cuda")
+    st = _lib.stream_handle()
+    _lib.check(lib.pmc_logw_stats(_lib.ptr(lw), n, 0, _lib.ptr(stats), _lib.ptr(ws), st))
+    _lib.check(lib.pmc_bootstrap_logz(_lib.ptr(lw), n, _lib.ptr(stats), B, 12345, _lib.ptr(reps), st))
+    r = reps.cpu().numpy()
+    ref = np.array([np.logaddexp.reduce(logw[rng.integers(0, n, n)]) - np.log(n) for _ in range(2000)])
+    full = np.logaddexp.reduce(logw) - np.log(n)
+    assert np.isfinite(r).all()
+    assert abs(r.mean() - ref.mean()) < 4 * ref.std() / np.sqrt(2000) + 4 * r.std() / np.sqrt(B)
+    assert abs(r.std() / ref.std() - 1) < 0.1
+    assert abs(r.mean() - full) < 0.2 * r.std() + 0.02
+    reps2 = torch.empty(B, dtype=torch.float64, device="cuda")
+    _lib.check(lib.pmc_bootstrap_logz(_lib.ptr(lw), n, _lib.ptr(stats), B, 12345, _lib.ptr(reps2), st))
+    assert torch.equal(reps, reps2)                                                   # deterministic in the seed
