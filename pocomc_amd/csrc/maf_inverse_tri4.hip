@@ -342,10 +342,13 @@ static bool tri5_wanted(const pmc_maf_t* m, int64_t n);
 static int launch_tri5(const ProposeArgs* pa, const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
                        hipStream_t stream);
 
-// PMC_INVERSE_LANE=0: AUTO keeps to the register-chain sweeps of this file (A/B runs); default: the lane-per-walker
-// sweep (maf_inverse_tri6.hip) wherever it covers the flow
+// PMC_INVERSE_LANE=1: AUTO takes the lane-per-walker sweep (maf_inverse_tri6.hip) wherever it covers the flow (A/B
+// runs).  Default: the register-chain sweeps of this file where they apply (output tiles <= 8, i.e. D <= 64: measured
+// 68-72 us against 84-96 us for up to 8192 rows of maf3 @ D = 32, 768 against 1461 us at D = 50 / maf6), the
+// lane-per-walker sweep for the wider flows (D = 128, 8 transforms: 2.0 ms against 3.4 ms of the LDS-hop sweep it
+// replaced).
 static bool lane_sweep_enabled() {
-    static const bool on = !(getenv("PMC_INVERSE_LANE") && atoi(getenv("PMC_INVERSE_LANE")) == 0);
+    static const bool on = getenv("PMC_INVERSE_LANE") && atoi(getenv("PMC_INVERSE_LANE")) != 0;
     return on;
 }
 
