@@ -135,6 +135,23 @@ int pmc_maf_train_epoch(const pmc_maf_t* m, const pmc_maf_train_t* tr, pmc_adamw
                         const float* w, const int64_t* perm, int64_t n, int64_t batch_size, float* loss,
                         void* stream);
 
+/* Options of Flow.fit.
+ * Weight regularisation, flow.py:314-315 with regularization_loss :387-421 as its docstring defines it (the function
+ * itself lacks its `return`, so the reference raises TypeError when the option is set): the batch loss gains
+ *   R = sum over the hyper-networks' weight matrices of |W| / laplace_scale + W^2 / (2 gaussian_scale^2)
+ * (a scale <= 0 switches its term off).  loss f32 [1] += mult * R; grad (or NULL) += dR/dparams, to be called between
+ * the loss/gradient of a batch and its clipped optimizer step.  is_weight u8 [n]: 1 for entries of weight matrices
+ * (masked-out ones included: they are entries of zuko's `weight` parameters too), 0 for biases.
+ * scratch f32 [PMC_ADAMW_SCRATCH]. */
+int pmc_weight_penalty(const float* params, const uint8_t* is_weight, float* grad, int64_t n, double laplace_scale,
+                       double gaussian_scale, float mult, float* loss, float* scratch, void* stream);
+/* Noise augmentation, flow.py:305 / :334: out f32 [n][D] = x + scale * N(0, 1), Philox keyed by (seed, pass, row). */
+int pmc_add_noise_f32(const float* x, int64_t n, int32_t D, float scale, uint64_t seed, uint64_t pass, float* out,
+                      void* stream);
+/* out f32 [1] = mean_j ||x[row] - x[j]||: what flow.py:241-245 scales the noise with (its `torch.mean(min_dist)` is
+ * the mean of the LAST row's distance vector, not of the nearest-neighbour distances computed above it). */
+int pmc_mean_distance_f32(const float* x, int64_t n, int32_t D, int64_t row, float* out, void* stream);
+
 /* The validation pass of one epoch, flow.py:327-348, in one call: for every batch (rows perm[b0 .. b0+nb) or
  * consecutive rows) loss += sum_n c_n * (-log_prob(x_n)) with c_n as in pmc_maf_loss_grad.
  * logp_scratch f32 [batch_size]. */
@@ -472,6 +489,11 @@ int pmc_moments(const double* x, const float* x32, const int64_t* idx, const dou
 int64_t pmc_column_medians_workspace_bytes(int64_t n, int32_t D, int32_t is_f32);
 int pmc_column_medians(const double* x, const float* x32, const int64_t* idx, int64_t n, int32_t D, double* med64,
                        float* med32, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The full affine map of Reparameterize(diagonal=False), scaler.py:288-292 / :308-313, on rows f64 [n][D]:
+ * mode 0: out = mu + M in (M = L: _inverse_affine), mode 1: out = M (in - mu) (M = L^-1: _forward_affine).  in != out. */
+int pmc_affine_rows(const double* M, const double* mu, const double* in, double* out, int64_t n, int32_t D,
+                    int32_t mode, void* stream);
 
 /* Bootstrap of the evidence estimate, Sampler._compute_evidence, sampler.py:905-911:
  * out[b] = logsumexp(logw[choice(n, n)]) - log(n) for b < B, the draws from Philox keyed by (seed, b, draw).

@@ -830,3 +830,100 @@ extern "C" int pmc_maf_train_epoch(const pmc_maf_t* m, const pmc_maf_train_t* tr
     }
     return pmc_check_launch("pmc_maf_train_epoch");
 }
+
+// ---------------------------------------------------------------------------
+// Flow.fit options: weight regularisation (flow.py:314-315, :387-421) and noise augmentation (flow.py:240-245, :304-307)
+// ---------------------------------------------------------------------------
+#include "philox.h"
+
+// R = sum_{weight entries} |p| / laplace + p^2 / (2 gaussian^2); grad (optional) += dR/dp.  256 blocks, contiguous
+// chunks, partials summed in block order by penalty_final_kernel.
+__global__ __launch_bounds__(256) void penalty_kernel(const float* __restrict__ p, const uint8_t* __restrict__ is_w,
+                                                      float* __restrict__ grad, int64_t n, float inv_b, float inv_s2,
+                                                      float* __restrict__ part) {
+    __shared__ float red[4];
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    float r = 0.0f;
+    for (int64_t e = lo + threadIdx.x; e < hi; e += 256) {
+        if (is_w[e]) {
+            const float v = p[e];
+            r += fabsf(v) * inv_b + 0.5f * v * v * inv_s2;
+            if (grad) grad[e] += (v > 0.0f ? inv_b : (v < 0.0f ? -inv_b : 0.0f)) + v * inv_s2;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void penalty_final_kernel(const float* __restrict__ part, int n_part, float mult, float* __restrict__ loss) {
+    if (threadIdx.x == 0) {
+        float s = 0.0f;
+        for (int i = 0; i < n_part; ++i) s += part[i];
+        *loss += mult * s;
+    }
+}
+
+extern "C" int pmc_weight_penalty(const float* params, const uint8_t* is_weight, float* grad, int64_t n,
+                                  double laplace_scale, double gaussian_scale, float mult, float* loss,
+                                  float* scratch, void* stream) {
+    if (!params || !is_weight || !loss || !scratch || n < 1) return pmc_fail("pmc_weight_penalty: bad argument");
+    const float inv_b = laplace_scale > 0.0 ? (float)(1.0 / laplace_scale) : 0.0f;
+    const float inv_s2 = gaussian_scale > 0.0 ? (float)(1.0 / (gaussian_scale * gaussian_scale)) : 0.0f;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(penalty_kernel, dim3(PMC_ADAMW_SCRATCH), dim3(256), 0, st, params, is_weight, grad, n, inv_b, inv_s2, scratch);
+    hipLaunchKernelGGL(penalty_final_kernel, dim3(1), dim3(64), 0, st, (const float*)scratch, (int)PMC_ADAMW_SCRATCH, mult, loss);
+    return pmc_check_launch("penalty_kernel");
+}
+
+// out = x + scale * N(0, 1): torch.randn_like noise of flow.py:305 / :334, Philox keyed by (seed, pass, row, pair)
+__global__ __launch_bounds__(256) void add_noise_kernel(const float* __restrict__ x, int64_t n, int D, float scale,
+                                                        uint64_t seed, uint64_t pass, float* __restrict__ out) {
+    const int half = (D + 1) / 2;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n * half; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / half; const int j = (int)(e % half) * 2;
+        Philox ph(seed, pass, (uint64_t)r, 4);
+        ph.ctr[0] = (uint32_t)(j >> 1);
+        double a, b;
+        ph.normal2(a, b);
+        out[r * D + j] = x[r * D + j] + scale * (float)a;
+        if (j + 1 < D) out[r * D + j + 1] = x[r * D + j + 1] + scale * (float)b;
+    }
+}
+
+extern "C" int pmc_add_noise_f32(const float* x, int64_t n, int32_t D, float scale, uint64_t seed, uint64_t pass,
+                                 float* out, void* stream) {
+    if (!x || !out || n < 1 || D < 1) return pmc_fail("pmc_add_noise_f32: bad argument");
+    int64_t grid = (n * ((D + 1) / 2) + 255) / 256; if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, n, (int)D, scale, seed, pass, out);
+    return pmc_check_launch("add_noise_kernel");
+}
+
+// out[0] = mean_j || x[row] - x[j] ||_2   (flow.py:241-245: the quantity the reference's noise scale is built from)
+__global__ __launch_bounds__(1024) void mean_distance_kernel(const float* __restrict__ x, int64_t n, int D, int64_t row,
+                                                             float* __restrict__ out) {
+    __shared__ float part[1024];
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    float s = 0.0f;
+    for (int64_t j = lo; j < hi; ++j) {
+        float d2 = 0.0f;
+        for (int k = 0; k < D; ++k) { const float d = x[row * D + k] - x[j * D + k]; d2 += d * d; }
+        s += sqrtf(d2);
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0] / (float)n;
+}
+
+extern "C" int pmc_mean_distance_f32(const float* x, int64_t n, int32_t D, int64_t row, float* out, void* stream) {
+    if (!x || !out || n < 1 || D < 1 || row < 0 || row >= n) return pmc_fail("pmc_mean_distance_f32: bad argument");
+    hipLaunchKernelGGL(mean_distance_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, (int)D, row, out);
+    return pmc_check_launch("mean_distance_kernel");
+}

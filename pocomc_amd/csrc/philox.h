@@ -10,6 +10,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// A variate must not depend on the translation unit that draws it (pmc_rng_fill, the proposal kernel, the proposal as
+// prologue of the flow-inverse kernels all promise the same bits): no implicit contraction in this header and after it.
+#pragma clang fp contract(off)
+
 struct Philox {
     uint32_t key[2];
     uint32_t ctr[4];

@@ -340,3 +340,29 @@ extern "C" int pmc_bootstrap_logz(const double* logw, int64_t n, const double* s
     hipLaunchKernelGGL(bootstrap_lse_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, logw, n, stats, seed, out);
     return pmc_check_launch("bootstrap_lse_kernel");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Full affine map of Reparameterize(diagonal=False), scaler.py:288-292 / :308-313, row by row:
+//   mode 0: out = mu + M in   (M = L, the Cholesky factor of cov(u))      mode 1: out = M (in - mu)   (M = L^-1)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void affine_rows_kernel(const double* __restrict__ M, const double* __restrict__ mu,
+                                                          const double* __restrict__ in, double* __restrict__ out,
+                                                          int64_t n, int D, int mode) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n * D; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / D; const int i = (int)(e % D);
+        const double* row = in + r * D;
+        double s = 0.0;
+        if (mode == 0) { for (int j = 0; j < D; ++j) s += M[i * D + j] * row[j]; s = mu[i] + s; }
+        else { for (int j = 0; j < D; ++j) s += M[i * D + j] * (row[j] - mu[j]); }
+        out[e] = s;
+    }
+}
+
+extern "C" int pmc_affine_rows(const double* M, const double* mu, const double* in, double* out, int64_t n, int32_t D,
+                               int32_t mode, void* stream) {
+    if (!M || !mu || !in || !out || in == out || n < 1 || D < 1 || (mode != 0 && mode != 1))
+        return pmc_fail("pmc_affine_rows: bad argument");
+    int64_t grid = (n * D + 255) / 256; if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(affine_rows_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, M, mu, in, out, n, (int)D, (int)mode);
+    return pmc_check_launch("affine_rows_kernel");
+}

@@ -47,12 +47,11 @@ class Reparameterize:
         if transform not in ["logit", "probit"]:
             raise ValueError("Please provide a valid transformation function (e.g. logit or probit)")
         self.transform = transform
-        if not diagonal:
-            raise NotImplementedError("only the diagonal affine map the Sampler uses is built")
         self.scale = scale
         self.diagonal = diagonal
         self.mu = None
         self.sigma = None
+        self.cov = self.L = self.L_inv = self.log_det_L = None               # diagonal=False: scaler.py:175-178
         lo_f, hi_f = np.isfinite(self.low), np.isfinite(self.high)            # scaler.py:463-489
         self.mask_none = ~lo_f & ~hi_f
         self.mask_right = ~lo_f & hi_f
@@ -111,6 +110,9 @@ class Reparameterize:
 
     def device_descriptor(self):
         """Descriptor (and the tensors it points to) for the MCMC engine."""
+        if not self.diagonal:
+            raise NotImplementedError("the MCMC step kernels fuse the DIAGONAL affine map (what pocomc's Sampler "
+                                      "configures, sampler.py:320-327); diagonal=False scalers transform arrays only")
         if self._desc is None:
             self._desc, self._dev = self._descriptor()
         return self._desc
@@ -123,8 +125,24 @@ class Reparameterize:
         self.mu, self.sigma = None, None
         u = self._forward_device(x, scale=False)
         self.mu = np.mean(u, axis=0)
-        self.sigma = np.std(u, axis=0)
+        if self.diagonal:
+            self.sigma = np.std(u, axis=0)
+        else:                                                                # scaler.py:175-178
+            self.cov = np.cov(u.T)
+            self.L = np.linalg.cholesky(self.cov)
+            self.L_inv = np.linalg.inv(self.L)
+            self.log_det_L = np.linalg.slogdet(self.L)[1]
         self._desc = None
+
+    def _affine_rows(self, M, a, mode):
+        """``mu + L a`` (mode 0) or ``L^-1 (a - mu)`` (mode 1) row by row on the device (``pmc_affine_rows``)."""
+        up = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).to(self.device)
+        Md, mud, ad = up(M), up(self.mu), up(a)
+        out = torch.empty_like(ad)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pmc_affine_rows(_lib.ptr(Md), _lib.ptr(mud), _lib.ptr(ad), _lib.ptr(out), ad.shape[0],
+                                                self.ndim, mode, _lib.stream_handle()), "pmc_affine_rows")
+        return out.cpu().numpy()
 
     def _forward_device(self, x, scale=None):
         desc, dev = self._descriptor(scale)
@@ -140,12 +158,19 @@ class Reparameterize:
         x = np.asarray(x, dtype=np.float64)
         if check_input:
             assert_array_within_interval(x, self.low, self.high)
-        return self._forward_device(x)
+        if self.diagonal or not self.scale or self.mu is None:
+            return self._forward_device(x)
+        return self._affine_rows(self.L_inv, self._forward_device(x, scale=False), 1)      # scaler.py:199-200, :291-292
 
     def inverse(self, u):
         """``scaler.py:204-226``: ``(x, log_det_J)`` (no boundary conditions here,
         exactly like the reference method)."""
-        desc, dev = self._descriptor()
+        full = (not self.diagonal) and self.scale and self.mu is not None
+        if self.device is None:
+            self.device = _lib.require_gpu()
+        if full:
+            u = self._affine_rows(self.L, u, 0)                               # scaler.py:219, :311-313
+        desc, dev = self._descriptor(scale=False if full else None)
         desc.bc = None
         ud = torch.from_numpy(np.ascontiguousarray(u, dtype=np.float64)).to(self.device)
         n = ud.shape[0]
@@ -157,4 +182,7 @@ class Reparameterize:
             _lib.check(self.lib.pmc_scaler_inverse(C.byref(desc), None, _lib.ptr(ud), _lib.ptr(uo), _lib.ptr(xo),
                                                    None, _lib.ptr(ldj), _lib.ptr(fin), n, _lib.stream_handle()),
                        "pmc_scaler_inverse")
-        return xo.cpu().numpy(), ldj.cpu().numpy()
+        ldj = ldj.cpu().numpy()
+        if full:
+            ldj = self.log_det_L * np.ones(len(ldj)) + ldj                    # scaler.py:220-221
+        return xo.cpu().numpy(), ldj

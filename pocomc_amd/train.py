@@ -217,7 +217,22 @@ def _dist_world(group):
     return 1
 
 
-def sharded_epoch(flow, opt, x, w, perm, batch_size, max_norm, loss_acc, group):
+def _weight_flags(flow):
+    """uint8 [n_params]: 1 for the entries of the hyper-networks' weight matrices (what ``parameter_name.endswith('weight')``
+    selects at ``flow.py:409-411`` -- masked-out entries included), 0 for biases."""
+    ts = _train_state(flow)
+    if getattr(ts, "weight_flags", None) is None:
+        spec = flow.spec
+        f = np.zeros(spec.n_params, dtype=np.uint8)
+        for t in range(spec.n_transforms):
+            for name in ("W0", "W1", "W2", "W3"):
+                off, sz = spec.offsets[name]
+                f[t * spec.params_per_transform + off: t * spec.params_per_transform + off + sz] = 1
+        ts.weight_flags = torch.from_numpy(f).to(flow.device)
+    return ts.weight_flags
+
+
+def sharded_epoch(flow, opt, x, w, perm, batch_size, max_norm, loss_acc, group, penalty=None):
     """One epoch of data-parallel training: every rank holds a shard of the
     training rows; a global batch of ``batch_size`` rows is ``batch_size / world`` local rows per rank.
     Per batch: [all-reduce of the weight sum] -> local loss/gradient -> ONE all-reduce of
@@ -251,6 +266,8 @@ def sharded_epoch(flow, opt, x, w, perm, batch_size, max_norm, loss_acc, group):
             ts.desc.wsum = None
         dist.all_reduce(ts.grad_ext, group=group)
         loss_acc += ts.grad_ext[-1:]
+        if penalty is not None:                   # the same penalty on every rank, once per global batch
+            penalty(ts.grad, loss_acc)
         opt.step(max_norm)
 
 
@@ -269,10 +286,6 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
     global batch; gradients and losses are all-reduced (RCCL on the GPUs) so that every rank takes
     the same optimizer steps and the same early-stopping decisions."""
     from .flow import torch_double_to_float
-    if laplace_scale is not None or gaussian_scale is not None:
-        raise NotImplementedError("weight regularisation (flow.py:387-421) is not built; the Sampler leaves it off")
-    if noise is not None:
-        raise NotImplementedError("noise augmentation (flow.py:240-245) is not built; the Sampler leaves it off")
     x = torch_double_to_float(torch.as_tensor(x))
     dev = flow.device
     n_samples, n_dim = x.shape
@@ -304,6 +317,23 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
         sharded = world > 1
     if sharded:
         import torch.distributed as dist
+    # ---- options (flow.py:240-245, :304-307, :314-315): see pmc_weight_penalty / pmc_add_noise_f32 in the header
+    penalty = None
+    if laplace_scale is not None or gaussian_scale is not None:
+        penalty = (float(laplace_scale or 0.0), float(gaussian_scale or 0.0), _weight_flags(flow))
+    noise_scale, noise_seed = None, 0
+    if noise is not None:
+        # flow.py:241-245: `mean_min_dist = torch.mean(min_dist)` -- the mean of the LAST row's distances to all rows
+        # (the nearest-neighbour distances `min_dists` computed in the loop above it are never used); its loop raises
+        # for a row without a positive distance, like torch.min of an empty tensor
+        if n_samples < 2:
+            raise RuntimeError("min(): Expected reduction dim to be specified for input.numel() == 0.")
+        md = torch.zeros(1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(flow.lib.pmc_mean_distance_f32(_lib.ptr(x), n_samples, n_dim, n_samples - 1, _lib.ptr(md),
+                                                      _lib.stream_handle()), "pmc_mean_distance_f32")
+        noise_scale = float(noise) * float(md.item())
+        noise_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) * 2 ** 31 + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
     opt = AdamW(flow, learning_rate, weight_decay)
     sched = ReduceLROnPlateau(opt, patience) if annealing else None
     _train_state(flow).repack(flow)
@@ -343,22 +373,61 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
         d_perm[which][sl][:n].copy_(h_perm[which][sl][:n], non_blocking=True)
         return d_perm[which][sl][:n]
 
+    noisy = None
+    if noise_scale is not None:
+        noisy = [[torch.empty_like(x_train) for _ in range(slots)],
+                 [torch.empty_like(x_valid) if validation else None for _ in range(slots)]]
+
+    def with_noise(which, sl, epoch, src):
+        """Fresh noise on every row of a pass (the reference draws it per batch of every epoch, flow.py:305 / :334)."""
+        if noisy is None:
+            return src
+        dst = noisy[which][sl]
+        with torch.cuda.device(dev):
+            _lib.check(flow.lib.pmc_add_noise_f32(_lib.ptr(src), src.shape[0], n_dim, noise_scale, noise_seed,
+                                                  2 * epoch + which, _lib.ptr(dst), _lib.stream_handle()), "pmc_add_noise_f32")
+        return dst
+
+    def add_penalty(grad, loss, mult=1.0):
+        b, g, flags = penalty
+        with torch.cuda.device(dev):
+            _lib.check(flow.lib.pmc_weight_penalty(_lib.ptr(flow.params), _lib.ptr(flags), _lib.ptr(grad) if grad is not None else None,
+                                                   flow.params.numel(), b, g, float(mult), _lib.ptr(loss),
+                                                   _lib.ptr(ts.sq_partial), _lib.stream_handle()), "pmc_weight_penalty")
+
+    def penalised_epoch(xs, ws, perm, acc):
+        """Batch by batch (flow.py:301-321) with the penalty's gradient added before the clip (flow.py:314-318)."""
+        n = xs.shape[0]
+        for b0 in range(0, n, int(batch_size)):
+            nb = min(int(batch_size), n - b0)
+            idx = perm[b0:b0 + nb] if perm is not None else None
+            xb = xs if idx is not None else xs[b0:b0 + nb]
+            wb = None if ws is None else (ws if idx is not None else ws[b0:b0 + nb])
+            acc += loss_and_grad(flow, xb, wb, idx)
+            add_penalty(ts.grad, acc)
+            opt.step(clip_grad_norm)
+
     def enqueue(epoch):
         sl = epoch % slots
         acc2 = acc_d[sl]
         acc2.zero_()
         acc = acc2[0:1]
         perm = upload_perm(0, sl, n_train) if shuffle else None
+        xs = with_noise(0, sl, epoch, x_train)
         if sharded:
-            sharded_epoch(flow, opt, x_train, w_train, perm, batch_size, clip_grad_norm, acc, group)
+            sharded_epoch(flow, opt, xs, w_train, perm, batch_size, clip_grad_norm, acc, group,
+                          penalty=add_penalty if penalty is not None else None)
+        elif penalty is not None:
+            penalised_epoch(xs, w_train, perm, acc)
         else:
-            opt.epoch(x_train, w_train, perm, batch_size, clip_grad_norm, acc)
+            opt.epoch(xs, w_train, perm, batch_size, clip_grad_norm, acc)
         vacc = acc2[1:2]
+        x_valid_e = with_noise(1, sl, epoch, x_valid) if validation else None
         if validation and not sharded:
             # the whole validation pass in one library call (batches of the reference's DataLoader, flow.py:327-348)
             vperm = upload_perm(1, sl, n_valid) if shuffle else None
             with torch.cuda.device(dev):
-                _lib.check(flow.lib.pmc_maf_valid_epoch(C.byref(flow._desc), _lib.ptr(x_valid),
+                _lib.check(flow.lib.pmc_maf_valid_epoch(C.byref(flow._desc), _lib.ptr(x_valid_e),
                                                         _lib.ptr(w_valid) if w_valid is not None else None,
                                                         _lib.ptr(vperm) if vperm is not None else None,
                                                         n_valid, int(batch_size), _lib.ptr(ts.logp_scratch),
@@ -367,12 +436,16 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
             vb = max(1, batch_size // world)
             for idx in _batches(n_valid, vb, shuffle):
                 idx = idx.to(dev)
-                vacc += batch_loss(flow, x_valid[idx].contiguous(),
+                vacc += batch_loss(flow, x_valid_e[idx].contiguous(),
                                    None if w_valid is None else w_valid[idx].contiguous(), group, sharded)
         if sharded:
             # the validation loss is a sum over the ranks' shards (the training loss already is: it rode
             # along with the gradients)
             dist.all_reduce(acc2[1:2], group=group)
+        if validation and penalty is not None:
+            # flow.py:342-343: every validation batch's loss carries the penalty
+            vb = int(batch_size) if not sharded else max(1, int(batch_size) // world)
+            add_penalty(None, vacc, mult=-(-n_valid // vb))
         after[sl].copy_(flow.params)
         acc_h[sl].copy_(acc2, non_blocking=True)
         done[sl].record()

@@ -120,6 +120,28 @@ def main():
     np.savez_compressed(os.path.join(HERE, "scaler_reference.npz"), **out)
     print("scaler_reference.npz:", len(out), "arrays")
 
+    # full (non-diagonal) affine map, scaler.py:172-178 / :288-313 (round 2; its own file, the vectors above stay as they are)
+    out = {}
+    rs = np.random.RandomState(5)
+    D, n = 6, 200
+    mix = np.eye(D) + 0.4 * rs.randn(D, D)
+    for transform in ("probit", "logit"):
+        for bname, bounds in (("none", np.tile(np.array([[-np.inf, np.inf]]), (D, 1))),
+                              ("both", np.tile(np.array([[-3.0, 4.0]]), (D, 1)))):
+            x = rs.randn(n, D) @ mix.T if bname == "none" else rs.uniform(-3.0, 4.0, size=(n, D))
+            sc = ref["scaler"].Reparameterize(D, bounds, transform=transform, diagonal=False)
+            sc.fit(x)
+            u = sc.forward(x)
+            xr, ldj = sc.inverse(u)
+            u_far = rs.randn(n, D) * 2.0
+            xf, ldjf = sc.inverse(u_far)
+            tag = f"scaler_full/{transform}/{bname}"
+            for k, v in (("bounds", bounds), ("x", x), ("mu", sc.mu), ("L", sc.L), ("log_det_L", np.asarray(sc.log_det_L)),
+                         ("u", u), ("x_rt", xr), ("ldj", ldj), ("u_far", u_far), ("x_far", xf), ("ldj_far", ldjf)):
+                out[f"{tag}/{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "scaler_full_reference.npz"), **out)
+    print("scaler_full_reference.npz:", len(out), "arrays")
+
     # ------------------------------------------------------------------- tools
     out = {}
     T = ref["tools"]

@@ -402,3 +402,28 @@ def test_bootstrap_of_the_evidence_estimate():
     reps2 = torch.empty(B, dtype=torch.float64, device="cuda")
     _lib.check(lib.pmc_bootstrap_logz(_lib.ptr(lw), n, _lib.ptr(stats), B, 12345, _lib.ptr(reps2), st))
     assert torch.equal(reps, reps2)                                                   # deterministic in the seed
+
+
+@pytest.mark.parametrize("transform", ["probit", "logit"])
+@pytest.mark.parametrize("bname", ["none", "both"])
+def test_full_affine_scaler_matches_reference(transform, bname, golden_dir):
+    """Reparameterize(diagonal=False) (scaler.py:172-178, :288-313) against vectors from the reference."""
+    import pocomc_amd as pc
+    from oracle.scaler import Reparameterize as OracleScaler
+    g = np.load(f"{golden_dir}/scaler_full_reference.npz")
+    tag = f"scaler_full/{transform}/{bname}"
+    for cls in (OracleScaler, pc.Reparameterize):
+        sc = cls(6, g[f"{tag}/bounds"], transform=transform, diagonal=False)
+        sc.fit(g[f"{tag}/x"])
+        np.testing.assert_allclose(sc.mu, g[f"{tag}/mu"], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(sc.L, g[f"{tag}/L"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(sc.log_det_L, g[f"{tag}/log_det_L"], rtol=1e-10)
+        np.testing.assert_allclose(sc.forward(g[f"{tag}/x"]), g[f"{tag}/u"], rtol=1e-8, atol=1e-9)
+        xr, ldj = sc.inverse(g[f"{tag}/u"])
+        np.testing.assert_allclose(xr, g[f"{tag}/x_rt"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(ldj, g[f"{tag}/ldj"], rtol=1e-10, atol=1e-10)
+        xf, ldjf = sc.inverse(g[f"{tag}/u_far"])
+        np.testing.assert_allclose(xf, g[f"{tag}/x_far"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(ldjf, g[f"{tag}/ldj_far"], rtol=1e-10, atol=1e-10)
+    with pytest.raises(NotImplementedError):
+        sc.device_descriptor()                      # the MCMC step kernels fuse the diagonal map only

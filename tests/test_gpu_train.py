@@ -293,3 +293,79 @@ def test_validation_epoch_call_equals_batch_by_batch(name, weighted):
     ref2 = sum(float(batch_loss(f, x[b0:b0 + bs].contiguous(), None if w is None else w[b0:b0 + bs].contiguous()))
                for b0 in range(0, n, bs))
     np.testing.assert_allclose(float(acc), ref2, rtol=2e-6)
+
+
+# ---------------------------------------------------------------------------------------------- Flow.fit options
+def test_weight_penalty_value_and_gradient():
+    """pmc_weight_penalty: R = sum |W| / b + W^2 / (2 s^2) over the weight matrices (flow.py:387-421 as documented) and
+    dR/dparams added to a gradient; biases untouched."""
+    import ctypes as C
+    from pocomc_amd import Flow, _lib
+    from pocomc_amd.train import _weight_flags, _train_state
+    f = Flow(5, "maf3", seed=2)
+    flags = _weight_flags(f)
+    p = f.params
+    lib = f.lib
+    ts = _train_state(f)
+    grad = torch.full_like(p, 0.25)
+    loss = torch.zeros(1, dtype=torch.float32, device="cuda")
+    b, s = 0.7, 1.3
+    _lib.check(lib.pmc_weight_penalty(_lib.ptr(p), _lib.ptr(flags), _lib.ptr(grad), p.numel(), b, s, 2.0, _lib.ptr(loss),
+                                      _lib.ptr(ts.sq_partial), _lib.stream_handle()))
+    pw = p.cpu().numpy().astype(np.float64)
+    fl = flags.cpu().numpy().astype(bool)
+    R = np.sum(np.abs(pw[fl]) / b + pw[fl] ** 2 / (2 * s * s))
+    np.testing.assert_allclose(loss.item(), 2.0 * R, rtol=2e-6)
+    want = np.full(pw.shape, 0.25)
+    want[fl] += np.sign(pw[fl]) / b + pw[fl] / (s * s)
+    np.testing.assert_allclose(grad.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+    # every weight matrix entry is flagged, no bias is
+    spec = f.spec
+    n_w = spec.n_transforms * sum(spec.offsets[k][1] for k in ("W0", "W1", "W2", "W3"))
+    assert fl.sum() == n_w
+
+
+def test_fit_with_regularisation_shrinks_the_weights_and_reports_the_penalised_loss():
+    from pocomc_amd import Flow
+    torch.manual_seed(0)
+    x = torch.randn(600, 4) * torch.tensor([1.0, 0.3, 2.0, 0.7]) + 0.5
+    norms = {}
+    for key, kw in (("plain", {}), ("l1", dict(laplace_scale=0.05)), ("l2", dict(gaussian_scale=0.2)),
+                    ("both", dict(laplace_scale=0.05, gaussian_scale=0.2))):
+        f = Flow(4, "maf3", seed=1)
+        torch.manual_seed(1)
+        h = f.fit(x, epochs=30, batch_size=200, validation_split=0.8, patience=1000, annealing=False, **kw)
+        assert np.isfinite(h["loss"]).all() and np.isfinite(h["val_loss"]).all() and len(h["loss"]) == 30
+        from pocomc_amd.train import _weight_flags
+        fl = _weight_flags(f).cpu().numpy().astype(bool)
+        norms[key] = (float(np.abs(f.params.cpu().numpy()[fl]).sum()), h["loss"][-1])
+    assert norms["l1"][0] < 0.8 * norms["plain"][0] and norms["both"][0] < norms["l2"][0] < norms["plain"][0]
+    assert norms["l1"][1] > norms["plain"][1]                     # the reported loss carries the penalty (flow.py:314-321)
+
+
+def test_fit_with_noise_augmentation():
+    """flow.py:240-245, :304-307: Gaussian noise of scale noise * mean_j |x_last - x_j| on every pass; the fit still learns
+    (a broadened density), and the noise kernel has the stated law."""
+    import ctypes as C
+    from pocomc_amd import Flow, _lib
+    from scipy import stats
+    lib = _lib.load()
+    x = torch.randn(4000, 6, device="cuda")
+    out = torch.empty_like(x)
+    _lib.check(lib.pmc_add_noise_f32(_lib.ptr(x), 4000, 6, 0.5, 77, 3, _lib.ptr(out), _lib.stream_handle()))
+    d = ((out - x) / 0.5).cpu().numpy().ravel()
+    assert stats.kstest(d, "norm").pvalue > 1e-3
+    out2 = torch.empty_like(x)
+    _lib.check(lib.pmc_add_noise_f32(_lib.ptr(x), 4000, 6, 0.5, 77, 4, _lib.ptr(out2), _lib.stream_handle()))
+    assert not torch.equal(out, out2)                              # a fresh draw per pass
+    md = torch.zeros(1, device="cuda")
+    _lib.check(lib.pmc_mean_distance_f32(_lib.ptr(x), 4000, 6, 3999, _lib.ptr(md), _lib.stream_handle()))
+    ref = torch.linalg.norm(x[-1] - x, dim=1).mean().item()        # flow.py:243-245: mean of the LAST row's distances
+    np.testing.assert_allclose(md.item(), ref, rtol=1e-5)
+    torch.manual_seed(0)
+    data = torch.randn(800, 3) * 0.5 + 1.0
+    f = Flow(3, "maf3", seed=0)
+    h = f.fit(data, epochs=40, batch_size=200, validation_split=0.8, noise=0.2, annealing=False, patience=1000)
+    assert np.isfinite(h["loss"]).all() and h["loss"][-1] < h["loss"][0]
+    with pytest.raises(RuntimeError):
+        Flow(3, "maf3", seed=0).fit(torch.randn(1, 3), epochs=1, noise=0.1)
