@@ -62,7 +62,23 @@ for key in sorted(pmc, key=lambda k: -len(pmc[k].get("SQ_WAVE_CYCLES", []))):
     for c in sorted(m):
         print(f"    {c:32s} {m[c]:16.1f}   ({len(pmc[key][c])} launches)")
     if any(w in key[0] for w in ("tri6", "tri5", "tri4")) and "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+        try:
+            g_items = int(key[1])
+        except ValueError:
+            g_items = 0
+        # walkers of the launch from its grid (work-items): 16 walkers per 64-lane wave (tri4), per 128 threads (tri5)
+        per16 = 128 if "tri5" in key[0] else 64
+        walkers = g_items // per16 * 16 if ("tri5" in key[0] or "tri4" in key[0]) else None
+        D_, io = 32, None
+        if walkers:
+            # fused proposal + inverse at D = 32 (bench default): theta (f32) in; theta' (f64), u' (f32), ladj, two
+            # quadratic forms out; the weight sections the register-chain sweeps read, once
+            io = {"walker_io": walkers * (4 * D_ + 8 * D_ + 4 * D_ + 4 + 16), "weights_once": 3 * 60400 * 4}
+            io["total"] = io["walker_io"] + io["weights_once"]
         cand = {"kernel": key[0], "grid": key[1], "launches": len(pmc[key]["FETCH_SIZE"]),
+                "walkers_per_launch": walkers, "algorithmic_bytes": io,
+                "note": "FETCH_SIZE / WRITE_SIZE are per-launch means of separate --pmc passes; the weight image is pulled "
+                        "once per XCD L2 (8 x), walker data is touched once",
                 "FETCH_SIZE_KB": m["FETCH_SIZE"], "WRITE_SIZE_KB": m["WRITE_SIZE"],
                 "hbm_bytes_per_launch": (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0,
                 "correction": "2x FETCH_SIZE (gfx950), separate --pmc passes",
