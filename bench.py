@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same table: dense bf16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -204,6 +205,7 @@ def main():
     ap.add_argument("--particles", type=int, default=10000, help="walkers per GPU")
     ap.add_argument("--dim", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-flow-bench", action="store_true", help="skip the config-5 flow sub-metric (f32 vs bf16 log_prob)")
     ap.add_argument("--host-threads", type=int, default=1, help="host threads evaluating the prior/likelihood")
     ap.add_argument("--host-prior", action="store_true",
                     help="evaluate Prior.logpdf on the host (default: on the device, it is a product of scipy.stats "
@@ -608,7 +610,7 @@ def main():
             _L.check(lib.pmc_gather(_L.ptr(ridx), n, D, _L.ptr(pu), _L.ptr(px), _L.ptr(ps[0]), _L.ptr(ps[1]), _L.ptr(ps[2]),
                                     _L.ptr(ou), _L.ptr(ox), _L.ptr(os_[0]), _L.ptr(os_[1]), _L.ptr(os_[2]), st_h))
 
-        def timed(fn, reps=50):
+        def timed(fn, reps=10):
             for _ in range(5):
                 fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -627,6 +629,34 @@ def main():
         del pu, px, ps, ou, ox, os_, cdf
     except Exception as exc:                                              # (a sub-metric must not take the bench down)
         sweeps["resample_gather"] = {"error": repr(exc)}
+    # BASELINE configs[4] flow (128-D, 8 transforms, H = 512; "8-layer MAF bf16"): log_prob on 5000 rows per GPU with the
+    # float32 and the bf16 matrix-core kernels -- rows/s and executed-flop fraction of the respective dense MFMA peak
+    flow_cfg5 = None
+    if rank == 0 and not args.no_flow_bench:
+        try:
+            from pocomc_amd.maf_spec import MAFSpec
+            sp5 = MAFSpec(128, 8)
+            x5 = torch.randn(5000, 128, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+            flow_cfg5 = {"workload": "log_prob of 5000 rows, 128-D MAF, 8 transforms, H=512 (BASELINE configs[4] per-GPU shard)",
+                         "flops_per_row_executed": 2 * sp5.macs_masked(), "flops_per_row_dense": sp5.flops_forward_dense()}
+            for prec, peak in (("f32", PEAK_F32_MFMA_TFLOPS), ("bf16", PEAK_BF16_MFMA_TFLOPS)):
+                f5 = Flow(128, sp5, seed=0, precision=prec)
+                for _ in range(3):
+                    f5.log_prob(x5)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    f5.log_prob(x5)
+                e1.record()
+                torch.cuda.synchronize()
+                us5 = e0.elapsed_time(e1) / 10 * 1e3
+                tf = 5000 * 2 * sp5.macs_masked() / us5 / 1e6
+                flow_cfg5[prec] = {"us_per_call": us5, "rows_per_s": 5000 / us5 * 1e6, "achieved_tflops": tf, "peak_tflops": peak,
+                                   "frac": tf / peak, "dense_equivalent_tflops": 5000 * sp5.flops_forward_dense() / us5 / 1e6}
+                del f5
+            flow_cfg5["speedup_bf16"] = flow_cfg5["f32"]["us_per_call"] / flow_cfg5["bf16"]["us_per_call"]
+        except Exception as exc:                                          # (a sub-metric must not take the bench down)
+            flow_cfg5 = {"error": repr(exc)}
     ms_per_step = dt / args.steps * 1e3
     value = (n * world * args.steps / dt) / 1e4
     out = {"metric": "preconditioned MCMC steps/sec (1e4 particles, 32-D)", "value": value,
@@ -647,6 +677,7 @@ def main():
            "roofline": roofline,
            "roofline_sweeps": sweeps,
            "flow_fit": flow_fit,
+           "flow_config5": flow_cfg5,
            "device_only_steps_per_s": 1e6 / (us["propose"] + us["maf_inverse"] + us["scaler_inverse"]
                                              + us["accept_reduce"]),
            "breakdown_us_per_step": dict(us, host_prior_likelihood=t_host[0] / n_inst * 1e6,

@@ -64,6 +64,17 @@ int pmc_maf_pack(const float* flat, const int32_t* pack_idx, float* packed, int6
 int pmc_maf_forward(const pmc_maf_t* m, const float* x, float* z, float* ladj, float* log_prob,
                     int64_t n, void* stream);
 
+/* bf16 matrix-core variant of pmc_maf_forward for the affine flows (BASELINE config 5: "8-layer MAF bf16"):
+ * v_mfma_f32_16x16x32_bf16 with fp32 accumulation, the univariate map and the log-determinant in fp32.  The weight
+ * fragments are a bf16 image of the fp32 master parameters: image u16 [T * image_per_transform], built by
+ * pmc_maf_pack_bf16 through MAFSpec.pack_index_bf16 (image[i] = bf16(flat[idx[i]]) or 0; round to nearest even);
+ * biases are read from the fp32 image of `m`.  idx i64 [n] or NULL: row gather like pmc_maf_loss_grad.
+ * Precision: activations and weights carry 8 mantissa bits -- the parity tests state the tolerance against the fp32
+ * oracle. */
+int pmc_maf_pack_bf16(const float* flat, const int32_t* pack_idx, uint16_t* image, int64_t n, void* stream);
+int pmc_maf_forward_bf16(const pmc_maf_t* m, const uint16_t* image, int64_t image_per_transform, const float* x,
+                         float* z, float* ladj, float* log_prob, int64_t n, const int64_t* idx, void* stream);
+
 /* Flow.inverse, pocomc/flow.py:116-132: latent -> data with the log-determinant of the
  * inverse map.  z,x f32 [n][D]; ladj f32 [n] or NULL. */
 int pmc_maf_inverse(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,

@@ -104,6 +104,8 @@ SIGNATURES = {
     "pmc_abi_version": (C.c_int, []),
     "pmc_maf_pack": (C.c_int, [c_p, c_p, c_p, i64, c_p]),
     "pmc_maf_forward": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, c_p, i64, c_p]),
+    "pmc_maf_pack_bf16": (C.c_int, [c_p, c_p, c_p, i64, c_p]),
+    "pmc_maf_forward_bf16": (C.c_int, [P(pmc_maf_t), c_p, i64, c_p, c_p, c_p, c_p, i64, c_p, c_p]),
     "pmc_maf_inverse": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, i64, C.c_int, c_p]),
     "pmc_maf_loss_grad": (C.c_int, [P(pmc_maf_t), P(pmc_maf_train_t), c_p, c_p, c_p, C.c_float, c_p, c_p, i64, c_p]),
     "pmc_maf_train_epoch": (C.c_int, [P(pmc_maf_t), P(pmc_maf_train_t), P(pmc_adamw_t), c_p, c_p, c_p, i64, i64, c_p,

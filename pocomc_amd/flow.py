@@ -39,7 +39,10 @@ def torch_double_to_float(x: torch.Tensor, warn: bool = True) -> torch.Tensor:
 class Flow:
     """Masked autoregressive flow resident on one MI355X."""
 
-    def __init__(self, n_dim, flow="nsf3", device=None, seed=None):       # default as pocomc/flow.py:46
+    def __init__(self, n_dim, flow="nsf3", device=None, seed=None, precision="f32"):   # default flow as pocomc/flow.py:46
+        """``precision="bf16"`` (affine flows): ``forward`` / ``log_prob`` run on the bf16 matrix cores with fp32
+        accumulation (``csrc/maf_forward_bf16.hip``; BASELINE config 5 names this precision); parameters, training,
+        the inverse and the univariate maps stay float32.  Default: float32 everywhere, like the reference."""
         self.n_dim = int(n_dim)
         if isinstance(flow, MAFSpec):
             spec = flow
@@ -67,6 +70,12 @@ class Flow:
             nT=spec.nT, nXT=spec.nXT, nOT=spec.nOT, pk_per_transform=spec.pk_per_transform,
             tri_ok=int(spec.tri_ok), n_out=spec.n_out)
         self.inverse_algo = 0          # PMC_INVERSE_AUTO
+        if precision not in ("f32", "bf16"):
+            raise ValueError("precision must be 'f32' or 'bf16'")
+        if precision == "bf16" and spec.univariate != "affine":
+            raise NotImplementedError("the bf16 kernels are built for the affine flows")
+        self.precision = precision
+        self._bf16 = None              # (gather map, image, elements per transform), built on first use
         self.repack()
 
     # ---------------------------------------------------------- checkpoints
@@ -75,11 +84,12 @@ class Flow:
         sampler.py:1023-1049)."""
         return {"n_dim": self.n_dim,
                 "spec": (self.spec.n_dim, self.spec.n_transforms, self.spec.hidden, self.spec.univariate, self.spec.bins),
-                "params": self.params.detach().cpu().numpy(), "inverse_algo": self.inverse_algo}
+                "params": self.params.detach().cpu().numpy(), "inverse_algo": self.inverse_algo,
+                "precision": self.precision}
 
     def __setstate__(self, st):
         spec = MAFSpec(*st["spec"])
-        self.__init__(st["n_dim"], spec)
+        self.__init__(st["n_dim"], spec, precision=st.get("precision", "f32"))
         self.set_params(st["params"])
         self.inverse_algo = st.get("inverse_algo", 0)
 
@@ -90,6 +100,34 @@ class Flow:
             _lib.check(self.lib.pmc_maf_pack(_lib.ptr(self.params), _lib.ptr(self._pack_idx),
                                              _lib.ptr(self._packed), self._packed.numel(),
                                              _lib.stream_handle()), "pmc_maf_pack")
+            if getattr(self, "_bf16", None) is not None:
+                idx, img, _ = self._bf16
+                _lib.check(self.lib.pmc_maf_pack_bf16(_lib.ptr(self.params), _lib.ptr(idx), _lib.ptr(img), img.numel(),
+                                                      _lib.stream_handle()), "pmc_maf_pack_bf16")
+
+    def _bf16_image(self):
+        """The bf16 fragment image of the current parameters (kept in step by ``repack``)."""
+        if self._bf16 is None:
+            idx = torch.from_numpy(self.spec.pack_index_bf16()).to(self.device)
+            img = torch.zeros(idx.numel(), dtype=torch.int16, device=self.device)
+            self._bf16 = (idx, img, self.spec.bf16_layout()["per_transform"])
+            self.repack()
+        return self._bf16
+
+    def _forward_call(self, xd, z, ladj, lp, n):
+        with torch.cuda.device(self.device):
+            if self.precision == "bf16":
+                _, img, per_t = self._bf16_image()
+                _lib.check(self.lib.pmc_maf_forward_bf16(C.byref(self._desc), _lib.ptr(img), per_t, _lib.ptr(xd),
+                                                         _lib.ptr(z) if z is not None else None,
+                                                         _lib.ptr(ladj) if ladj is not None else None,
+                                                         _lib.ptr(lp) if lp is not None else None, n, None,
+                                                         _lib.stream_handle()), "pmc_maf_forward_bf16")
+            else:
+                _lib.check(self.lib.pmc_maf_forward(C.byref(self._desc), _lib.ptr(xd), _lib.ptr(z),
+                                                    _lib.ptr(ladj) if ladj is not None else None,
+                                                    _lib.ptr(lp) if lp is not None else None, n, _lib.stream_handle()),
+                           "pmc_maf_forward")
 
     def set_params(self, flat):
         flat = torch.as_tensor(flat, dtype=torch.float32).reshape(-1)
@@ -120,9 +158,7 @@ class Flow:
         n = xd.shape[0]
         z = torch.empty_like(xd)
         ladj = torch.empty(n, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.pmc_maf_forward(C.byref(self._desc), _lib.ptr(xd), _lib.ptr(z), _lib.ptr(ladj),
-                                                None, n, _lib.stream_handle()), "pmc_maf_forward")
+        self._forward_call(xd, z, ladj, None, n)
         return z.to(src), ladj.to(src)
 
     __call__ = forward
@@ -146,9 +182,7 @@ class Flow:
         n = xd.shape[0]
         z = torch.empty_like(xd)
         lp = torch.empty(n, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.pmc_maf_forward(C.byref(self._desc), _lib.ptr(xd), _lib.ptr(z), None,
-                                                _lib.ptr(lp), n, _lib.stream_handle()), "pmc_maf_forward")
+        self._forward_call(xd, z, None, lp, n)
         return lp.to(src)
 
     @torch.no_grad()

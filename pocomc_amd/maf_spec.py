@@ -399,6 +399,76 @@ class MAFSpec:
         r_o_f = np.concatenate(self.orders).astype(np.int32)
         return np.concatenate([hdr, f_o_r, r_o_f, self.quad_meta]).astype(np.int32)
 
+    # ------------------------------------------------------- bf16 forward image
+    def bf16_layout(self):
+        """Sizes / offsets (in bf16 elements, per transform) of the weight fragments of the bf16 forward kernel
+        (``csrc/maf_forward_bf16.hip``): A operands of ``v_mfma_f32_16x16x32_bf16`` -- lane l holds row ``l & 15`` of the
+        16-row out tile and the 8 consecutive k ``8 (l >> 4) .. + 7`` of a 32-wide k tile --
+        ``g0 [nT][nX2]``, ``g1 / g2 [nT][nK2]``, ``g3 [nOT][nK2]``, each ``[64 lanes][8]``; biases stay float32 (they are
+        read from the float32 image)."""
+        nX2, nK2 = -(-self.Dp // 32), -(-self.Hp // 32)
+        sz = {"g0": self.nT * nX2 * 512, "g1": self.nT * nK2 * 512, "g2": self.nT * nK2 * 512, "g3": self.nOT * nK2 * 512}
+        off, o = {}, 0
+        for k, v in sz.items():
+            off[k] = o
+            o += v
+        return dict(nX2=nX2, nK2=nK2, sz=sz, off=off, per_transform=o)
+
+    def pack_index_bf16(self) -> np.ndarray:
+        """int32 gather map of the bf16 fragment image: ``image[i] = bf16(flat[idx[i]]) if idx[i] >= 0 else 0``."""
+        D, H = self.n_dim, self.hidden
+        L = self.bf16_layout()
+        nX2, nK2, nT, nOT = L["nX2"], L["nK2"], self.nT, self.nOT
+        idx = np.full(L["per_transform"] * self.n_transforms, -1, dtype=np.int64)
+        lane = np.arange(64)
+        li, lg = lane & 15, lane >> 4
+        su = self.slot_unit
+        for t in range(self.n_transforms):
+            base_c = t * self.params_per_transform
+            rank = self.orders[t]
+            feat_of_rank = np.argsort(rank)
+            M0, M1, M2, M3 = self.masks(t)
+
+            def cidx(name, row, col, ncol, mask):
+                off, _ = self.offsets[name]
+                ok = (row >= 0) & (col >= 0)
+                r = np.where(ok, row, 0)
+                c = np.where(ok, col, 0)
+                ok = ok & mask[r, c]
+                return np.where(ok, base_c + off + r * ncol + c, -1)
+
+            def in_slot(k):                       # canonical hidden unit of packed slot k (or -1)
+                return np.where(k < self.Hp, su[np.minimum(k, self.Hp - 1)], -1)
+
+            g0 = np.full((nT, nX2, 64, 8), -1, dtype=np.int64)
+            g1 = np.full((nT, nK2, 64, 8), -1, dtype=np.int64)
+            g2 = np.full((nT, nK2, 64, 8), -1, dtype=np.int64)
+            g3 = np.full((nOT, nK2, 64, 8), -1, dtype=np.int64)
+            for T in range(nT):
+                out_unit = su[16 * T + li]
+                for X in range(nX2):
+                    for e in range(8):
+                        r_in = 32 * X + 8 * lg + e
+                        feat = np.where(r_in < D, feat_of_rank[np.minimum(r_in, D - 1)], -1)
+                        g0[T, X, :, e] = cidx("W0", out_unit, feat, D, M0)
+                for K in range(nK2):
+                    for e in range(8):
+                        iu = in_slot(32 * K + 8 * lg + e)
+                        g1[T, K, :, e] = cidx("W1", out_unit, iu, H, M1)
+                        g2[T, K, :, e] = cidx("W2", out_unit, iu, H, M2)
+            for O in range(nOT):
+                orow = 16 * O + li
+                r_out, sft = orow // self.n_out, orow % self.n_out
+                crow = np.where(r_out < D, self.n_out * feat_of_rank[np.minimum(r_out, D - 1)] + sft, -1)
+                for K in range(nK2):
+                    for e in range(8):
+                        g3[O, K, :, e] = cidx("W3", crow, in_slot(32 * K + 8 * lg + e), H, M3)
+            b = t * L["per_transform"]
+            for name, arr in (("g0", g0), ("g1", g1), ("g2", g2), ("g3", g3)):
+                a = arr.reshape(-1)
+                idx[b + L["off"][name]: b + L["off"][name] + a.size] = a
+        return idx.astype(np.int32)
+
     # ------------------------------------------------------------- training
     def train_layout(self):
         """Sizes of the training-side device arrays, per transform.
