@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpocomc_amd.so")
+LIB_PATH = os.environ.get("PMC_LIBRARY") or os.path.join(_HERE, "libpocomc_amd.so")    # (PMC_LIBRARY: A/B builds)
 
 c_p = C.c_void_p
 

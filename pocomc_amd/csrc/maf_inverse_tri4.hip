@@ -441,6 +441,9 @@ int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* 
 // above it.  PMC_INVERSE_DUO=0 / 1 forces never / always (tests run both).
 // ============================================================================================================
 #define TRI5_NC 1                  // chain waves (16-walker sets) per workgroup; see the note on occupancy above
+#ifndef TRI5_ABL
+#define TRI5_ABL 0                 // timing experiments only (maf_chain_rot.h): results are wrong when != 0
+#endif
 
 template <int MAXO, int FM>
 __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pmc_maf_t m, const float* __restrict__ in,
@@ -666,6 +669,8 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                     s.g[2] = ny ? (nz ? dg.z : (nw ? dg.w : D)) : ((nz && nw) ? dg.w : D);
                     s.g[3] = (ny && nz && nw) ? dg.w : D;
                 }
+                long long* pf = (pa.prof && blockIdx.x == 0) ? pa.prof + ((size_t)(T - 1 - t) * nT + Tt) * 8 : nullptr;
+                if (pf && lane == 0) pf[0] = clock64();
                 const int soD1 = oF1 + (Tt * nT + Tt) * 1024, soD2 = oF2 + (Tt * nT + Tt) * 1024;
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
@@ -695,6 +700,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) s.yv[i] = Y[lidx(s.g[i] < D ? s.g[i] : 0, p)];
+                if (pf && lane == 0) pf[1] = clock64();
 
                 // layer 0 against x (final up to the previous tile's ranks)
                 f32x4 a0;
@@ -720,7 +726,9 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                     for (int O = 0; O < MAXO; ++O)
                         *reinterpret_cast<float4*>(so + O * 256) = make_float4(s.oN[O][0], s.oN[O][1], s.oN[O][2], s.oN[O][3]);
                 }
+                if (pf && lane == 0) pf[2] = clock64();
                 lds_bar();                                            // B(Tt): layers 1/2 of this tile are staged
+                if (pf && lane == 0) pf[3] = clock64();
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
                     s.a0[jt] = S[(p << 4) + (jt << 2) + q];
@@ -736,8 +744,9 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                     const int gg = s.g[i] < D ? s.g[i] : 0;
                     s.po[i] = *reinterpret_cast<const float2*>(SO + (gg >> 3) * 256 + (p << 4) + 2 * (gg & 7));
                 }
+                if (pf && lane == 0) pf[4] = clock64();
                 switch (pat) {
-#define CASE(P) case P: chain_group_rot<P, 0, 1, MAXO, 0>(s, H0, H1, X, Tt, D, nOT, q, p, ladj); break;
+#define CASE(P) case P: chain_group_rot<P, 0, 1, MAXO, TRI5_ABL>(s, H0, H1, X, Tt, D, nOT, q, p, ladj); break;
                     CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
 #undef CASE
                 }
@@ -746,12 +755,14 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                     dg_next = *reinterpret_cast<const int4*>(quad_meta + 4 * (Tt + 1));
                 }
                 switch (pat) {
-#define CASE(P) case P: chain_group_rot<P, 1, 4, MAXO, 0>(s, H0, H1, X, Tt, D, nOT, q, p, ladj); break;
+#define CASE(P) case P: chain_group_rot<P, 1, 4, MAXO, TRI5_ABL>(s, H0, H1, X, Tt, D, nOT, q, p, ladj); break;
                     CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
 #undef CASE
                     default: break;
                 }
+                if (pf && lane == 0) pf[5] = clock64();
                 lds_bar();                                            // A(Tt): this tile is final
+                if (pf && lane == 0) pf[6] = clock64();
             }
 #undef PREFETCH5
         }
@@ -817,10 +828,18 @@ static int launch_tri5(const ProposeArgs* pa, const pmc_maf_t* m, const float* z
         hipLaunchKernelGGL((maf_inverse_tri5_kernel<MO, FMV>), dim3(grid), dim3(64 * (TRI5_NC + 1)), lds,          \
                            stream, *m, z, x, ladj, n, pa ? *pa : none);                                           \
     }
-    if (!pa) { if (maxo == 4) LAUNCH5(4, 0) else LAUNCH5(8, 0) }
+    if (!pa || !pa->cur32) { if (maxo == 4) LAUNCH5(4, 0) else LAUNCH5(8, 0) }       // (pa without a walker state: the profile entry)
     else if (m->D <= 16) { if (maxo == 4) LAUNCH5(4, 4) else LAUNCH5(8, 4) }
     else if (m->D <= 32) { if (maxo == 4) LAUNCH5(4, 8) else LAUNCH5(8, 8) }
     else { if (maxo == 4) LAUNCH5(4, 16) else LAUNCH5(8, 16) }
 #undef LAUNCH5
     return pmc_check_launch("maf_inverse_tri5_kernel");
+}
+
+// measurement only (scripts/profile_tri5.py): cycle stamps of the chain wave of workgroup 0 -- prof[transform * nT + tile][8]
+extern "C" int pmc_debug_tri5_profile(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, long long* prof,
+                                      void* stream) {
+    ProposeArgs pa{};
+    pa.prof = prof;
+    return launch_tri5(&pa, m, z, x, ladj, n, (hipStream_t)stream) < 0 ? pmc_fail("pmc_debug_tri5_profile: flow not covered") : 0;
 }

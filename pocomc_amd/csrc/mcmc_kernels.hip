@@ -17,7 +17,9 @@
 
 #define PROP_ROWS 64          // particles per block in propose_kernel (one wave)
 #define ACC_ROWS 64           // particles per block in accept_kernel
+#ifndef SCL_ROWS
 #define SCL_ROWS 64           // particles per block in the scaler kernels
+#endif
 
 // ===========================================================================
 // proposal: mcmc.py:77-85 (tpCN), :251-253 / :561-563 (RWM)
