@@ -120,6 +120,42 @@ int pmc_maf_train_waves(const pmc_maf_t* m);
 int pmc_maf_loss_grad(const pmc_maf_t* m, const pmc_maf_train_t* tr, const float* x, const float* w,
                       const int64_t* idx, float wmul, float* grad, float* loss, int64_t n, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * bf16 matrix-core training of the wide affine flows (BASELINE config 5: D = 128, 8 transforms, H = 512; flow.py:297-323
+ * with the hyper-networks of flow.py:46-90).  A 512-row batch is too few rows for "one workgroup per 16 rows": the
+ * layers are dense products [out x in] . [in x rows] on v_mfma_f32_16x16x32_bf16, a workgroup per 32 x 32 output tile
+ * (its four wavefronts split the contraction), one launch per dependent layer (8 T + 4 per 512 rows).  fp32 master parameters, fp32
+ * accumulation, fp32 univariate map / log-determinant / loss; activations and their gradients are stored as bf16 in
+ * both orientations ([row][unit] feeds the next layer and the data gradients, [unit][row] the weight gradients).
+ *
+ * image  u16 [T * image_per_transform]: per transform, row-major and zero where masked / padded,
+ *          W0f [HK][DK]  W0b = W0f^T  W1f [HK][HK]  W1b  W2f  W2b  W3f [OK][HK] (row 2 * feature + {shift, raw})  W3b
+ *          with hidden units in slot order (MAFSpec.slot_unit), features in canonical order,
+ *          DK = ceil32(D), HK = ceil32(Hp), OK = 2 * DK;
+ * image_idx i32, same shape: canonical index of every element or -1 (MAFSpec.wide_index(); it is both the gather map
+ *          that builds the image -- pmc_maf_pack_bf16 -- and, in its W?f parts, the scatter map of the weight gradients);
+ * bias   f32 [T * bias_per_transform]: b0 b1 b2 [HK each] b3 [OK] in the same orders, bias_idx i32 likewise
+ *          (pmc_maf_pack builds it);
+ * scratch: pmc_maf_wide_scratch_bytes(m) bytes of device memory; wsum as in pmc_maf_train_t.
+ * pmc_maf_wide_refresh re-derives image and bias from the parameters (after every optimizer step). */
+typedef struct pmc_maf_wide {
+    uint16_t* image; const int32_t* image_idx; int64_t image_per_transform;
+    float* bias; const int32_t* bias_idx; int64_t bias_per_transform;
+    void* scratch; int64_t scratch_bytes;
+    const float* wsum;
+} pmc_maf_wide_t;
+int64_t pmc_maf_wide_scratch_bytes(const pmc_maf_t* m);
+int pmc_maf_wide_refresh(const pmc_maf_t* m, const pmc_maf_wide_t* wd, const float* params, void* stream);
+/* Same contract as pmc_maf_loss_grad (loss accumulated, grad overwritten at the unmasked entries); affine flows only. */
+int pmc_maf_loss_grad_bf16(const pmc_maf_t* m, const pmc_maf_wide_t* wd, const float* x, const float* w,
+                           const int64_t* idx, float wmul, float* grad, float* loss, int64_t n, void* stream);
+/* pmc_maf_train_epoch with the bf16 loss / gradient: per batch  loss+grad -> clip -> AdamW -> refresh of the bf16 image
+ * (the fp32 kernel images of opt are NOT refreshed: repack them once after the fit).  sq_scratch f32 [PMC_ADAMW_SCRATCH]. */
+struct pmc_adamw;
+int pmc_maf_train_epoch_bf16(const pmc_maf_t* m, const pmc_maf_wide_t* wd, struct pmc_adamw* opt, const float* x,
+                             const float* w, const int64_t* perm, int64_t n, int64_t batch_size, float* loss,
+                             float* sq_scratch, void* stream);
+
 /* Optimizer state of pmc_maf_train_epoch: torch.optim.AdamW (flow.py:268) on the canonical
  * parameter vector + the two kernel images that are refreshed after every step. */
 typedef struct pmc_adamw {

@@ -33,6 +33,12 @@ class pmc_maf_train_t(C.Structure):
                 ("par_scratch", c_p)]
 
 
+class pmc_maf_wide_t(C.Structure):
+    _fields_ = [("image", c_p), ("image_idx", c_p), ("image_per_transform", C.c_int64),
+                ("bias", c_p), ("bias_idx", c_p), ("bias_per_transform", C.c_int64),
+                ("scratch", c_p), ("scratch_bytes", C.c_int64), ("wsum", c_p)]
+
+
 class pmc_adamw_t(C.Structure):
     _fields_ = [("params", c_p), ("grad", c_p), ("exp_avg", c_p), ("exp_avg_sq", c_p), ("n_params", C.c_int64),
                 ("pack_idx", c_p), ("packed", c_p), ("n_packed", C.c_int64),
@@ -110,6 +116,11 @@ SIGNATURES = {
     "pmc_maf_loss_grad": (C.c_int, [P(pmc_maf_t), P(pmc_maf_train_t), c_p, c_p, c_p, C.c_float, c_p, c_p, i64, c_p]),
     "pmc_maf_train_epoch": (C.c_int, [P(pmc_maf_t), P(pmc_maf_train_t), P(pmc_adamw_t), c_p, c_p, c_p, i64, i64, c_p,
                                       c_p]),
+    "pmc_maf_wide_scratch_bytes": (C.c_int64, [P(pmc_maf_t)]),
+    "pmc_maf_wide_refresh": (C.c_int, [P(pmc_maf_t), P(pmc_maf_wide_t), c_p, c_p]),
+    "pmc_maf_loss_grad_bf16": (C.c_int, [P(pmc_maf_t), P(pmc_maf_wide_t), c_p, c_p, c_p, C.c_float, c_p, c_p, i64, c_p]),
+    "pmc_maf_train_epoch_bf16": (C.c_int, [P(pmc_maf_t), P(pmc_maf_wide_t), P(pmc_adamw_t), c_p, c_p, c_p, i64, i64, c_p,
+                                           c_p, c_p]),
     "pmc_maf_valid_epoch": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, i64, i64, c_p, c_p, c_p]),
     "pmc_neg_weighted_sum": (C.c_int, [c_p, c_p, c_p, C.c_float, c_p, i64, c_p]),
     "pmc_sum_f32": (C.c_int, [c_p, c_p, i64, c_p]),

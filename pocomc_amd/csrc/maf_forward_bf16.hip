@@ -9,22 +9,9 @@
 // kernels need four MFMAs and the same bytes for 16 x 16 x 16), activations take half the LDS.
 #include <stdlib.h>
 #include "maf_wg.h"
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#include "bf16.h"
 
 namespace fbf {
-
-__device__ __forceinline__ unsigned short to_bf16(float v) {           // round to nearest even
-    const unsigned u = __float_as_uint(v);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
-    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-__device__ __forceinline__ float from_bf16(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-
-__device__ __forceinline__ f32x4 mfma_bf(const uint4& a, const uint4& b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b),
-                                                   c, 0, 0, 0);
-}
 
 // acc += sum_{K2 in [0, n)} frag[K2] . act[K2]   (frag: [K2][lane] 16-byte records in global memory, act: the same in LDS),
 // PF fragments in flight, two accumulators

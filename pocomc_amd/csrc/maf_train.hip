@@ -785,6 +785,17 @@ static void launch_adamw(float* params, const float* grad, float* m1, float* m2,
                        sq_part, n_part, sc_ptr, sc_dst, img_a, n_a, img_b);
 }
 
+// (for maf_train_bf16.hip) sum-of-squares partials + clipped AdamW step without image refresh
+int pmc_launch_clip_adamw(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                          double beta1, double beta2, double eps, double wd, double max_norm, int64_t step,
+                          float* sq_scratch, hipStream_t st) {
+    const int n_part = PMC_ADAMW_SCRATCH;
+    if (max_norm > 0.0)
+        hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(n_part), dim3(256), 0, st, grad, sq_scratch, n);
+    launch_adamw(params, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, wd, max_norm, step, sq_scratch, n_part, st);
+    return pmc_check_launch("adamw_kernel");
+}
+
 extern "C" int pmc_adamw_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                               double lr, double beta1, double beta2, double eps, double weight_decay,
                               double max_norm, int64_t step, float* sq_scratch, void* stream) {

@@ -22,6 +22,9 @@ int pmc_launch_propose_mfma(int kind, const float* cur32, const double* cur64, c
                             const double* inv_cov, const double* chol, double nu, double sigma, double cn_a,
                             const pmc_rng_t* rng, double* prop64, float* prop32, double* quad, double* quad_prop,
                             int64_t n, int32_t D, hipStream_t stream, const double* adapt = nullptr);
+int pmc_launch_clip_adamw(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                          double beta1, double beta2, double eps, double wd, double max_norm, int64_t step,
+                          float* sq_scratch, hipStream_t st);
 // pmc_propose with sigma / cn_a / mu taken from pmc_step_t.adapt_state (device) when adapt != NULL
 int pmc_propose_adapt(int kind, const float* cur32, const double* cur64, const double* mu, const double* inv_cov,
                       const double* chol, double nu, double sigma, double cn_a, const pmc_rng_t* rng, double* prop64,

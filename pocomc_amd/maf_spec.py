@@ -469,6 +469,55 @@ class MAFSpec:
                 idx[b + L["off"][name]: b + L["off"][name] + a.size] = a
         return idx.astype(np.int32)
 
+    # ------------------------------------------- bf16 training image (wide flows)
+    def wide_layout(self):
+        """Sizes of the row-major bf16 weight image of ``csrc/maf_train_bf16.hip`` (elements per transform):
+        ``W0f [HK][DK]  W0b = W0f^T  W1f [HK][HK]  W1b  W2f  W2b  W3f [OK][HK]  W3b`` and of its float32 bias image
+        ``b0 b1 b2 [HK]  b3 [OK]``; hidden units in slot order, features in canonical order, W3 rows ``2 feature + s``."""
+        DK, HK = _ceil_to(self.n_dim, 32), _ceil_to(self.Hp, 32)
+        OK = 2 * DK
+        return dict(DK=DK, HK=HK, OK=OK, per_transform=2 * (HK * DK + 2 * HK * HK + OK * HK),
+                    bias_per_transform=3 * HK + OK)
+
+    def wide_index(self):
+        """``(image_idx, bias_idx)`` int32: canonical index of every element of the two images, -1 where masked or
+        padded.  ``image[i] = bf16(flat[idx[i]])``; the ``W?f`` parts double as the scatter map of the weight gradients."""
+        if self.univariate != "affine":
+            raise NotImplementedError("the bf16 training image is built for the affine flows")
+        D, H = self.n_dim, self.hidden
+        L = self.wide_layout()
+        DK, HK, OK = L["DK"], L["HK"], L["OK"]
+        su = np.full(HK, -1, dtype=np.int64)
+        su[:self.Hp] = self.slot_unit
+        hv = su >= 0
+        u = np.where(hv, su, 0)
+        feat = np.arange(DK)
+        fv = feat < D
+        fc = np.where(fv, feat, 0)
+        orow = np.arange(OK)                                  # 2 feature + s
+        ov = (orow // 2) < D
+        oc = np.where(ov, orow, 0)
+        img = np.full(self.n_transforms * L["per_transform"], -1, dtype=np.int64)
+        bias = np.full(self.n_transforms * L["bias_per_transform"], -1, dtype=np.int64)
+        for t in range(self.n_transforms):
+            base = t * self.params_per_transform
+            M0, M1, M2, M3 = self.masks(t)
+            off = {k: base + v[0] for k, v in self.offsets.items()}
+            w0 = np.where(hv[:, None] & fv[None, :] & M0[u][:, fc], off["W0"] + u[:, None] * D + fc[None, :], -1)
+            w1 = np.where(hv[:, None] & hv[None, :] & M1[u][:, u], off["W1"] + u[:, None] * H + u[None, :], -1)
+            w2 = np.where(hv[:, None] & hv[None, :] & M2[u][:, u], off["W2"] + u[:, None] * H + u[None, :], -1)
+            w3 = np.where(ov[:, None] & hv[None, :] & M3[oc][:, u], off["W3"] + oc[:, None] * H + u[None, :], -1)
+            parts = [w0, w0.T, w1, w1.T, w2, w2.T, w3, w3.T]
+            o = t * L["per_transform"]
+            for a in parts:
+                img[o:o + a.size] = np.ascontiguousarray(a).reshape(-1)
+                o += a.size
+            ob = t * L["bias_per_transform"]
+            for k, name in enumerate(("b0", "b1", "b2")):
+                bias[ob + k * HK: ob + (k + 1) * HK] = np.where(hv, off[name] + u, -1)
+            bias[ob + 3 * HK: ob + 3 * HK + OK] = np.where(ov, off["b3"] + oc, -1)
+        return img.astype(np.int32), bias.astype(np.int32)
+
     # ------------------------------------------------------------- training
     def train_layout(self):
         """Sizes of the training-side device arrays, per transform.

@@ -25,8 +25,23 @@ MAX_SLABS = 64      # workgroups per loss/gradient launch (16 rows each; larger 
 class TrainState:
     """Training-side device buffers of one Flow (built on first ``fit``)."""
 
-    def __init__(self, flow):
+    def __init__(self, flow, light=False):
+        """``light``: only what every engine needs (gradient, scalars); the bf16 engine keeps its own images
+        (:class:`WideState`) and never touches the float32 training image."""
         spec, dev = flow.spec, flow.device
+        n = spec.n_params
+        # masked entries stay 0 for ever; one extra element carries the batch loss through the
+        # gradient all-reduce of sharded training
+        self.grad_ext = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self.grad = self.grad_ext[:n]
+        self.wsum = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.scal = torch.zeros(4, dtype=torch.float32, device=dev)      # [loss, spare...]
+        self.light = bool(light)
+        self.n_slabs = 0
+        if light:
+            self.sq_partial = torch.zeros(256, dtype=torch.float32, device=dev)       # PMC_ADAMW_SCRATCH
+            self.desc = None
+            return
         L = spec.train_layout()
         pT_idx, gmap = spec.train_index()
         self.packT_idx = torch.from_numpy(pT_idx).to(dev)
@@ -43,17 +58,9 @@ class TrainState:
                                          slab_stride=self.g_total, n_sq_partial=self.sq_partial.numel(),
                                          sq_partial=self.sq_partial.data_ptr(), sched=self.sched.data_ptr(),
                                          sched_waves=self.n_waves)
-        self.n_slabs = 0
         self.xt_floats = (spec.n_transforms + 1) * spec.Dp * 16
         self.act_floats = spec.n_transforms * 3 * spec.Hp * 16
         self.par_floats = spec.n_transforms * spec.nXT * 23 * 256 if spec.univariate == "rqs" else 0
-        n = spec.n_params
-        # masked entries stay 0 for ever; one extra element carries the batch loss through the
-        # gradient all-reduce of sharded training
-        self.grad_ext = torch.zeros(n + 1, dtype=torch.float32, device=dev)
-        self.grad = self.grad_ext[:n]
-        self.wsum = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.scal = torch.zeros(4, dtype=torch.float32, device=dev)      # [loss, spare...]
 
     def ensure_slabs(self, n_rows):
         """One gradient slab + one scratch block per concurrently running workgroup."""
@@ -91,24 +98,84 @@ class TrainState:
         return self._scatter
 
     def repack(self, flow):
+        if self.light:
+            return
         with torch.cuda.device(flow.device):
             _lib.check(flow.lib.pmc_maf_pack(_lib.ptr(flow.params), _lib.ptr(self.packT_idx), _lib.ptr(self.packedT),
                                              self.packedT.numel(), _lib.stream_handle()), "pmc_maf_pack(T)")
 
 
 def _train_state(flow):
-    if getattr(flow, "_train", None) is None:
-        flow._train = TrainState(flow)
+    want_light = _wide_state(flow) is not None
+    ts = getattr(flow, "_train", None)
+    if ts is None or (ts.light and not want_light):
+        flow._train = TrainState(flow, light=want_light)
     return flow._train
 
 
-def loss_and_grad(flow, xb, wb=None, idx=None):
+WIDE_MIN_HIDDEN = 256       # precision="bf16" flows at least this wide train on the bf16 matrix cores
+
+
+class WideState:
+    """Device side of ``csrc/maf_train_bf16.hip`` (``pmc_maf_wide_t``): the row-major bf16 weight image with its index
+    map, the float32 bias image and the activation scratch."""
+
+    def __init__(self, flow):
+        spec, dev, lib = flow.spec, flow.device, flow.lib
+        L = spec.wide_layout()
+        img_idx, bias_idx = spec.wide_index()
+        self.image_idx = torch.from_numpy(img_idx).to(dev)
+        self.bias_idx = torch.from_numpy(bias_idx).to(dev)
+        self.image = torch.zeros(img_idx.size, dtype=torch.int16, device=dev)
+        self.bias = torch.zeros(bias_idx.size, dtype=torch.float32, device=dev)
+        nbytes = int(lib.pmc_maf_wide_scratch_bytes(C.byref(flow._desc)))
+        self.scratch = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self.sq = torch.zeros(256, dtype=torch.float32, device=dev)      # PMC_ADAMW_SCRATCH
+        self.desc = _lib.pmc_maf_wide_t(image=self.image.data_ptr(), image_idx=self.image_idx.data_ptr(),
+                                        image_per_transform=L["per_transform"], bias=self.bias.data_ptr(),
+                                        bias_idx=self.bias_idx.data_ptr(), bias_per_transform=L["bias_per_transform"],
+                                        scratch=self.scratch.data_ptr(), scratch_bytes=nbytes, wsum=None)
+
+    def refresh(self, flow):
+        with torch.cuda.device(flow.device):
+            _lib.check(flow.lib.pmc_maf_wide_refresh(C.byref(flow._desc), C.byref(self.desc), _lib.ptr(flow.params),
+                                                     _lib.stream_handle()), "pmc_maf_wide_refresh")
+
+
+def _wide_state(flow):
+    """The bf16 training engine of this flow, or None (float32 kernels): ``precision="bf16"`` affine flows of hidden
+    width >= WIDE_MIN_HIDDEN; ``flow.train_engine = "f32" | "bf16"`` overrides the width rule."""
+    engine = getattr(flow, "train_engine", None)
+    if engine == "f32" or getattr(flow, "precision", "f32") != "bf16" or flow.spec.univariate != "affine":
+        if engine == "bf16":
+            raise ValueError("train_engine='bf16' needs an affine flow with precision='bf16'")
+        return None
+    if engine != "bf16" and flow.spec.hidden < WIDE_MIN_HIDDEN:
+        return None
+    if getattr(flow, "_wide", None) is None:
+        flow._wide = WideState(flow)
+    return flow._wide
+
+
+def loss_and_grad(flow, xb, wb=None, idx=None, refresh=True):
     """Loss of one batch (device scalar tensor) and its gradient (in ``flow._train.grad``).
-    ``idx`` (int64, device) selects the batch rows out of ``xb`` / ``wb``."""
+    ``idx`` (int64, device) selects the batch rows out of ``xb`` / ``wb``.  (``refresh=False``: the caller keeps the
+    bf16 training image in step with the parameters itself.)"""
     ts = _train_state(flow)
     n = xb.shape[0] if idx is None else idx.numel()
-    ts.ensure_slabs(n)
     ts.scal.zero_()
+    ws = _wide_state(flow)
+    if ws is not None:
+        if refresh:
+            ws.refresh(flow)
+        with torch.cuda.device(flow.device):
+            _lib.check(flow.lib.pmc_maf_loss_grad_bf16(C.byref(flow._desc), C.byref(ws.desc), _lib.ptr(xb),
+                                                       _lib.ptr(wb) if wb is not None else None,
+                                                       _lib.ptr(idx) if idx is not None else None,
+                                                       1000.0, _lib.ptr(ts.grad), _lib.ptr(ts.scal), n,
+                                                       _lib.stream_handle()), "pmc_maf_loss_grad_bf16")
+        return ts.scal[0]
+    ts.ensure_slabs(n)
     with torch.cuda.device(flow.device):
         _lib.check(flow.lib.pmc_maf_loss_grad(C.byref(flow._desc), C.byref(ts.desc), _lib.ptr(xb),
                                               _lib.ptr(wb) if wb is not None else None,
@@ -150,6 +217,9 @@ class AdamW:
         self.m = torch.zeros_like(flow.params)
         self.v = torch.zeros_like(flow.params)
         self.t = 0
+        ws = _wide_state(flow)
+        if ws is not None:
+            ws.refresh(flow)
 
     def step(self, max_norm):
         """One clipped step on the gradient in ``flow._train.grad``, then refresh both kernel images."""
@@ -163,7 +233,11 @@ class AdamW:
                                             _lib.ptr(ts.sq_partial), _lib.stream_handle()),
                        "pmc_adamw_step")
         f.repack()
-        ts.repack(f)
+        ws = _wide_state(f)
+        if ws is not None:
+            ws.refresh(f)
+        else:
+            ts.repack(f)
 
     def epoch(self, x, w, perm, batch_size, max_norm, loss_acc):
         """``flow.py:297-323`` for one epoch in a single library call: every batch's loss/gradient,
@@ -171,6 +245,22 @@ class AdamW:
         accumulates the batch losses."""
         f = self.flow
         ts = _train_state(f)
+        ws = _wide_state(f)
+        if ws is not None:
+            c = _lib.pmc_adamw_t(params=f.params.data_ptr(), grad=ts.grad.data_ptr(), exp_avg=self.m.data_ptr(),
+                                 exp_avg_sq=self.v.data_ptr(), n_params=f.params.numel(), lr=self.lr,
+                                 beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd,
+                                 max_norm=float(max_norm) if max_norm is not None else 0.0, step=self.t)
+            with torch.cuda.device(f.device):
+                _lib.check(f.lib.pmc_maf_train_epoch_bf16(C.byref(f._desc), C.byref(ws.desc), C.byref(c), _lib.ptr(x),
+                                                          _lib.ptr(w) if w is not None else None,
+                                                          _lib.ptr(perm) if perm is not None else None,
+                                                          x.shape[0], int(batch_size), _lib.ptr(loss_acc),
+                                                          _lib.ptr(ws.sq), _lib.stream_handle()),
+                           "pmc_maf_train_epoch_bf16")
+            self.t = int(c.step)
+            f.repack()                      # the float32 / fragment images follow once per epoch (validation, inference)
+            return
         ts.ensure_slabs(batch_size)
         sc_ptr, sc_dst = ts.scatter_maps(f)
         c = _lib.pmc_adamw_t(params=f.params.data_ptr(), grad=ts.grad.data_ptr(), exp_avg=self.m.data_ptr(),
@@ -243,7 +333,9 @@ def sharded_epoch(flow, opt, x, w, perm, batch_size, max_norm, loss_acc, group, 
     world = dist.get_world_size(group)
     lb = max(1, int(batch_size) // world)
     n = x.shape[0]
-    ts.ensure_slabs(lb)
+    wide = _wide_state(flow)
+    if wide is None:
+        ts.ensure_slabs(lb)
     st = _lib.stream_handle()
     for b0 in range(0, n, lb):
         nb = min(lb, n - b0)
@@ -256,14 +348,22 @@ def sharded_epoch(flow, opt, x, w, perm, batch_size, max_norm, loss_acc, group, 
                 wsel = w[idx] if idx is not None else wb
                 _lib.check(flow.lib.pmc_sum_f32(_lib.ptr(wsel), _lib.ptr(ts.wsum), nb, st), "pmc_sum_f32")
                 dist.all_reduce(ts.wsum, group=group)
-                ts.desc.wsum = ts.wsum.data_ptr()
+                (wide or ts).desc.wsum = ts.wsum.data_ptr()
             ts.grad_ext[-1:].zero_()
-            _lib.check(flow.lib.pmc_maf_loss_grad(C.byref(flow._desc), C.byref(ts.desc), _lib.ptr(xb),
-                                                  _lib.ptr(wb) if wb is not None else None,
-                                                  _lib.ptr(idx) if idx is not None else None, 1000.0,
-                                                  _lib.ptr(ts.grad), C.c_void_p(ts.grad_ext.data_ptr() + 4 * ts.grad.numel()),
-                                                  nb, st), "pmc_maf_loss_grad")
-            ts.desc.wsum = None
+            if wide is not None:
+                _lib.check(flow.lib.pmc_maf_loss_grad_bf16(C.byref(flow._desc), C.byref(wide.desc), _lib.ptr(xb),
+                                                           _lib.ptr(wb) if wb is not None else None,
+                                                           _lib.ptr(idx) if idx is not None else None, 1000.0,
+                                                           _lib.ptr(ts.grad),
+                                                           C.c_void_p(ts.grad_ext.data_ptr() + 4 * ts.grad.numel()),
+                                                           nb, st), "pmc_maf_loss_grad_bf16")
+            else:
+                _lib.check(flow.lib.pmc_maf_loss_grad(C.byref(flow._desc), C.byref(ts.desc), _lib.ptr(xb),
+                                                      _lib.ptr(wb) if wb is not None else None,
+                                                      _lib.ptr(idx) if idx is not None else None, 1000.0,
+                                                      _lib.ptr(ts.grad), C.c_void_p(ts.grad_ext.data_ptr() + 4 * ts.grad.numel()),
+                                                      nb, st), "pmc_maf_loss_grad")
+            (wide or ts).desc.wsum = None
         dist.all_reduce(ts.grad_ext, group=group)
         loss_acc += ts.grad_ext[-1:]
         if penalty is not None:                   # the same penalty on every rank, once per global batch
@@ -403,7 +503,7 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
             idx = perm[b0:b0 + nb] if perm is not None else None
             xb = xs if idx is not None else xs[b0:b0 + nb]
             wb = None if ws is None else (ws if idx is not None else ws[b0:b0 + nb])
-            acc += loss_and_grad(flow, xb, wb, idx)
+            acc += loss_and_grad(flow, xb, wb, idx, refresh=False)
             add_penalty(ts.grad, acc)
             opt.step(clip_grad_norm)
 
