@@ -168,19 +168,22 @@ __device__ __forceinline__ WideView wide_view(const pmc_maf_wide_t& wd, const Wi
 
 // gradient of the hyper-network's outputs of transform t at (row n, feature f) from dL/dy (flow.py:309-312 through the
 // affine map y = x e^{ls} + shift, ls = soft-clipped raw): d shift = gy, d raw = (gy x e^{ls} - c_n) / den^2
-__device__ __forceinline__ void emit_do(const WideBufs& b, const WideDims& d, int t, int n, int f, float gy, float c) {
+__device__ __forceinline__ void emit_do_vals(const WideBufs& b, const WideDims& d, int n, int f, float gy, float c,
+                                             float xv, float ls, float dd) {
     using namespace fbf;
     float gs = 0.0f, gr = 0.0f;
     if (f < d.D) {
-        const size_t e = ((size_t)t * WIDE_NB + n) * d.DK + f;
-        const float xv = b.X[e], el = expf(b.LS[e]);
         gs = gy;
-        gr = (gy * xv * el - c) * b.DD[e];
+        gr = (gy * xv * expf(ls) - c) * dd;
     }
     const u16 hs = to_bf16(gs), hr = to_bf16(gr);
     *reinterpret_cast<unsigned*>(b.DO + (size_t)n * d.OK + 2 * f) = (unsigned)hs | ((unsigned)hr << 16);
     b.DOT[(size_t)(2 * f) * WIDE_NB + n] = hs;
     b.DOT[(size_t)(2 * f + 1) * WIDE_NB + n] = hr;
+}
+__device__ __forceinline__ void emit_do(const WideBufs& b, const WideDims& d, int t, int n, int f, float gy, float c) {
+    const size_t e = ((size_t)t * WIDE_NB + n) * d.DK + f;
+    emit_do_vals(b, d, n, f, gy, c, b.X[e], b.LS[e], b.DD[e]);
 }
 
 // bias gradient: rows [r0, r0 + 16) of a [unit][row] bf16 array summed over the batch rows, into the canonical gradient
@@ -203,13 +206,17 @@ __device__ __forceinline__ void bias_rows(const u16* __restrict__ AT, int r0, in
 }
 
 // weight-gradient tile into the canonical gradient through the image's index map
-__device__ __forceinline__ void scatter_dw(const int* __restrict__ imap, int ldi, int mrow, int col, const f32x4& v,
-                                           float* __restrict__ grad, bool first) {
+struct DwIdx { int gi[4]; };
+__device__ __forceinline__ DwIdx dw_index(const int* __restrict__ imap, int ldi, int mrow, int col) {
+    DwIdx x;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int gi = imap[(size_t)(mrow + r) * ldi + col];
-        if (gi >= 0) grad[gi] = first ? v[r] : grad[gi] + v[r];
-    }
+    for (int r = 0; r < 4; ++r) x.gi[r] = imap[(size_t)(mrow + r) * ldi + col];
+    return x;
+}
+__device__ __forceinline__ void scatter_dw(const DwIdx& x, const f32x4& v, float* __restrict__ grad, bool first) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (x.gi[r] >= 0) grad[x.gi[r]] = first ? v[r] : grad[x.gi[r]] + v[r];
 }
 
 // One PHASE of a chunk of <= WIDE_NB rows = one launch (a dependent kernel boundary costs ~1.5 us on this machine, a
@@ -285,8 +292,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void maf_wide_phase_kernel(WideArgs a
         const int m0 = (it / nNT) << 5, n0 = (it % nNT) << 5;
         const int mr = m0 + 16 * mi + 4 * g, nc = n0 + 16 * ni + p;
         if constexpr (PH == PH_F0) {                               // h0 = relu(W0 x + b0)
+            const float4 bb = *reinterpret_cast<const float4*>(v.b0 + mr);     // (epilogue operands first: in flight with the tile's)
             f32x4 c = tile_product(v.W0f, DK, XBt, DK, m0, n0, DK, red, wv, lane);
-            const float4 bb = *reinterpret_cast<const float4*>(v.b0 + mr);
             c[0] = fmaxf(c[0] + bb.x, 0.f); c[1] = fmaxf(c[1] + bb.y, 0.f);
             c[2] = fmaxf(c[2] + bb.z, 0.f); c[3] = fmaxf(c[3] + bb.w, 0.f);
             put4(H0, HK, H0T, NB, nc, mr, c);
@@ -297,17 +304,18 @@ __global__ __launch_bounds__(WIDE_THREADS) void maf_wide_phase_kernel(WideArgs a
             u16* HoutT = a.layer == 1 ? H1T : H2T;
             const u16* Wf = a.layer == 1 ? v.W1f : v.W2f;
             const float* bl = a.layer == 1 ? v.b1 : v.b2;
-            f32x4 c = tile_product(Wf, HK, Hin, HK, m0, n0, HK, red, wv, lane);
             const float4 bb = *reinterpret_cast<const float4*>(bl + mr);
             const f32x4 h = get4(Hin, HK, nc, mr);
+            f32x4 c = tile_product(Wf, HK, Hin, HK, m0, n0, HK, red, wv, lane);
             c[0] = fmaxf((c[0] + bb.x) + h[0], 0.f); c[1] = fmaxf((c[1] + bb.y) + h[1], 0.f);
             c[2] = fmaxf((c[2] + bb.z) + h[2], 0.f); c[3] = fmaxf((c[3] + bb.w) + h[3], 0.f);
             put4(Hout, HK, HoutT, NB, nc, mr, c);
         }
         if constexpr (PH == PH_F3) {                               // output layer + univariate affine map (fp32)
-            const f32x4 c = tile_product(v.W3f, HK, H2, HK, m0, n0, HK, red, wv, lane);
             const float4 bb = *reinterpret_cast<const float4*>(v.b3 + mr);
             const int f0 = mr >> 1;
+            const float2 xin = *reinterpret_cast<const float2*>(b.X + ((size_t)t * NB + nc) * DK + f0);
+            const f32x4 c = tile_product(v.W3f, HK, H2, HK, m0, n0, HK, red, wv, lane);
             float y[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void maf_wide_phase_kernel(WideArgs a
                     const float den = 1.0f + fabsf(raw / PMC_LOG_SLOPE);
                     ls = raw / den;
                     dd = 1.0f / (den * den);
-                    y[s] = b.X[e] * expf(ls) + shift;
+                    y[s] = (s ? xin.y : xin.x) * expf(ls) + shift;
                 }
                 b.LS[e] = ls;
                 b.DD[e] = dd;
@@ -375,17 +383,18 @@ __global__ __launch_bounds__(WIDE_THREADS) void maf_wide_phase_kernel(WideArgs a
             const WideView vn = wide_view(a.wd, d, t + 1 < T ? t + 1 : tv);
             if (it < nA) {
                 const int m0 = (it / nNT) << 5, n0 = (it % nNT) << 5;
-                f32x4 c = tile_product(v.W3b, OK, b.DO, OK, m0, n0, OK, red, wv, lane);
                 const int mr = m0 + 16 * mi + 4 * g, nc = n0 + 16 * ni + p;
                 const f32x4 h = get4(H2, HK, nc, mr);
+                f32x4 c = tile_product(v.W3b, OK, b.DO, OK, m0, n0, OK, red, wv, lane);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) c[r] = h[r] > 0.f ? c[r] : 0.f;
                 put4(DA2, HK, DA2T, NB, nc, mr, c);
             } else if (it < nA + nW) {
                 const int j = it - nA, nKT = DK >> 5;
                 const int m0 = (j / nKT) << 5, n0 = (j % nKT) << 5;
+                const DwIdx gx_ = dw_index(vn.I0, DK, m0 + 16 * mi + 4 * g, n0 + 16 * ni + p);
                 const f32x4 c = tile_product(DA0T, NB, b.XBT + (size_t)(t + 1) * DK * NB, NB, m0, n0, NBc, red, wv, lane);
-                scatter_dw(vn.I0, DK, m0 + 16 * mi + 4 * g, n0 + 16 * ni + p, c, grad, first);
+                scatter_dw(gx_, c, grad, first);
             } else {
                 bias_rows(DA0T, (it - nA - nW) << 4, NBc, vn.ib0, grad, first, wv, lane);
             }
@@ -394,17 +403,18 @@ __global__ __launch_bounds__(WIDE_THREADS) void maf_wide_phase_kernel(WideArgs a
             const int nA = (HK >> 5) * nNT, nW = (OK >> 5) * (HK >> 5), nB3 = OK >> 4;
             if (it < nA) {
                 const int m0 = (it / nNT) << 5, n0 = (it % nNT) << 5;
-                f32x4 c = tile_product(v.W2b, HK, DA2, HK, m0, n0, HK, red, wv, lane);
                 const int mr = m0 + 16 * mi + 4 * g, nc = n0 + 16 * ni + p;
                 const f32x4 h = get4(H1, HK, nc, mr), dp = get4(DA2, HK, nc, mr);
+                f32x4 c = tile_product(v.W2b, HK, DA2, HK, m0, n0, HK, red, wv, lane);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) c[r] = h[r] > 0.f ? c[r] + dp[r] : 0.f;
                 put4(DA1, HK, DA1T, NB, nc, mr, c);
             } else if (it < nA + nW) {
                 const int j = it - nA, nKT = HK >> 5;
                 const int m0 = (j / nKT) << 5, n0 = (j % nKT) << 5;
+                const DwIdx gx_ = dw_index(v.I3, HK, m0 + 16 * mi + 4 * g, n0 + 16 * ni + p);
                 const f32x4 c = tile_product(b.DOT, NB, H2T, NB, m0, n0, NBc, red, wv, lane);
-                scatter_dw(v.I3, HK, m0 + 16 * mi + 4 * g, n0 + 16 * ni + p, c, grad, first);
+                scatter_dw(gx_, c, grad, first);
             } else if (it < nA + nW + nB3) {
                 bias_rows(b.DOT, (it - nA - nW) << 4, NBc, v.ib3, grad, first, wv, lane);
             } else {
@@ -415,17 +425,18 @@ __global__ __launch_bounds__(WIDE_THREADS) void maf_wide_phase_kernel(WideArgs a
             const int nA = (HK >> 5) * nNT, nW = (HK >> 5) * (HK >> 5);
             if (it < nA) {
                 const int m0 = (it / nNT) << 5, n0 = (it % nNT) << 5;
-                f32x4 c = tile_product(v.W1b, HK, DA1, HK, m0, n0, HK, red, wv, lane);
                 const int mr = m0 + 16 * mi + 4 * g, nc = n0 + 16 * ni + p;
                 const f32x4 h = get4(H0, HK, nc, mr), dp = get4(DA1, HK, nc, mr);
+                f32x4 c = tile_product(v.W1b, HK, DA1, HK, m0, n0, HK, red, wv, lane);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) c[r] = h[r] > 0.f ? c[r] + dp[r] : 0.f;
                 put4(DA0, HK, DA0T, NB, nc, mr, c);
             } else if (it < nA + nW) {
                 const int j = it - nA, nKT = HK >> 5;
                 const int m0 = (j / nKT) << 5, n0 = (j % nKT) << 5;
+                const DwIdx gx_ = dw_index(v.I2, HK, m0 + 16 * mi + 4 * g, n0 + 16 * ni + p);
                 const f32x4 c = tile_product(DA2T, NB, H1T, NB, m0, n0, NBc, red, wv, lane);
-                scatter_dw(v.I2, HK, m0 + 16 * mi + 4 * g, n0 + 16 * ni + p, c, grad, first);
+                scatter_dw(gx_, c, grad, first);
             } else {
                 bias_rows(DA1T, (it - nA - nW) << 4, NBc, v.ib1, grad, first, wv, lane);
             }
@@ -434,25 +445,30 @@ __global__ __launch_bounds__(WIDE_THREADS) void maf_wide_phase_kernel(WideArgs a
             const int nA = (DK >> 5) * nNT;   // transform's output gradients   ||   dW1
             if (it < nA) {
                 const int m0 = (it / nNT) << 5, n0 = (it % nNT) << 5;
-                const f32x4 c = tile_product(v.W0b, HK, DA0, HK, m0, n0, HK, red, wv, lane);
                 const int mr = m0 + 16 * mi + 4 * g, nc = n0 + 16 * ni + p;
                 const float cn = b.C[nc];
+                const float4 gold = *reinterpret_cast<const float4*>(b.G + (size_t)nc * DK + mr);
+                const float4 lsv = *reinterpret_cast<const float4*>(b.LS + ((size_t)t * NB + nc) * DK + mr);
+                const size_t ep = ((size_t)(t > 0 ? t - 1 : 0) * NB + nc) * DK + mr;      // the previous transform's x, ls, 1 / den^2
+                const float4 px = *reinterpret_cast<const float4*>(b.X + ep), pl = *reinterpret_cast<const float4*>(b.LS + ep),
+                             pd = *reinterpret_cast<const float4*>(b.DD + ep);
+                const f32x4 c = tile_product(v.W0b, HK, DA0, HK, m0, n0, HK, red, wv, lane);
+                const float go[4] = {gold.x, gold.y, gold.z, gold.w}, lv[4] = {lsv.x, lsv.y, lsv.z, lsv.w};
+                const float pxv[4] = {px.x, px.y, px.z, px.w}, plv[4] = {pl.x, pl.y, pl.z, pl.w}, pdv[4] = {pd.x, pd.y, pd.z, pd.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int f = mr + r;
                     float gx = 0.0f;
-                    if (f < D) {
-                        const size_t e = ((size_t)t * NB + nc) * DK + f;
-                        gx = c[r] + b.G[(size_t)nc * DK + f] * expf(b.LS[e]);
-                    }
+                    if (f < D) gx = c[r] + go[r] * expf(lv[r]);
                     b.G[(size_t)nc * DK + f] = gx;
-                    if (t > 0) emit_do(b, d, t - 1, nc, f, gx, cn);
+                    if (t > 0) emit_do_vals(b, d, nc, f, gx, cn, pxv[r], plv[r], pdv[r]);
                 }
             } else {
                 const int j = it - nA, nKT = HK >> 5;
                 const int m0 = (j / nKT) << 5, n0 = (j % nKT) << 5;
+                const DwIdx gx_ = dw_index(v.I1, HK, m0 + 16 * mi + 4 * g, n0 + 16 * ni + p);
                 const f32x4 c = tile_product(DA1T, NB, H0T, NB, m0, n0, NBc, red, wv, lane);
-                scatter_dw(v.I1, HK, m0 + 16 * mi + 4 * g, n0 + 16 * ni + p, c, grad, first);
+                scatter_dw(gx_, c, grad, first);
             }
         }
     }
