@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void neg_weighted_sum_kernel(const float* __re
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) *out += (red[0] + red[1]) + (red[2] + red[3]);      // ONE block: a fixed order of additions
 }
 
 // validation loss of one batch (flow.py:336-341): loss += sum_i -(logp_i * c_i), c_i = 1 or
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ v, f
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) *out += (red[0] + red[1]) + (red[2] + red[3]);      // ONE block: a fixed order of additions
 }
 
 // ---------------------------------------------------------------------------
@@ -760,8 +760,7 @@ extern "C" int pmc_neg_weighted_sum(const float* logp, const float* w, const flo
                                     int64_t n, void* stream) {
     if (!logp || !out || n < 0 || (w && !wsum)) return pmc_fail("pmc_neg_weighted_sum: bad argument");
     if (n == 0) return 0;
-    int64_t grid = (n + 255) / 256; if (grid > 256) grid = 256;
-    hipLaunchKernelGGL(neg_weighted_sum_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, logp, w, wsum,
+    hipLaunchKernelGGL(neg_weighted_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp, w, wsum,
                        wmul, out, n);
     return pmc_check_launch("neg_weighted_sum_kernel");
 }
@@ -769,8 +768,7 @@ extern "C" int pmc_neg_weighted_sum(const float* logp, const float* w, const flo
 extern "C" int pmc_sum_f32(const float* v, float* out, int64_t n, void* stream) {
     if (!v || !out || n < 0) return pmc_fail("pmc_sum_f32: bad argument");
     if (n == 0) return 0;
-    int64_t grid = (n + 255) / 256; if (grid > 256) grid = 256;
-    hipLaunchKernelGGL(sum_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, v, out, n);
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, v, out, n);
     return pmc_check_launch("sum_kernel");
 }
 

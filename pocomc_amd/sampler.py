@@ -203,7 +203,10 @@ class Sampler:
         self.metric, self.sample, self.resample, self.dynamic = metric, sample, resample, dynamic
         self.preconditioned = precondition
 
-        self.flow = Flow(D, flow)
+        # (a ready Flow -- e.g. Flow(D, MAFSpec(D, 8), precision="bf16") -- is taken as it is, like the reference takes a zuko flow)
+        self.flow = flow if isinstance(flow, Flow) else Flow(D, flow)
+        if self.flow.n_dim != D:
+            raise ValueError("flow has the wrong number of dimensions")
         if self.ranks.world > 1:                       # replicated weights: every rank starts from rank 0's init
             self.ranks.same_everywhere(self.flow.params)
             self.flow.repack()
