@@ -52,7 +52,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         key = (short(r["Kernel_Name"]), r.get("Grid_Size", "?"))
         pmc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("\n## PMC counters, mean per launch (kernel, grid)")
-want = ("tri4", "tri5", "tri6", "tri_nsf", "scaler_inverse", "accept_kernel", "lossgrad", "forward_wg")
+want = ("tri4", "tri5", "tri6", "tri_nsf", "scaler_inverse", "accept_kernel", "lossgrad", "forward_wg", "wide_phase", "forward_bf16")
 traffic = None
 for key in sorted(pmc, key=lambda k: -len(pmc[k].get("SQ_WAVE_CYCLES", []))):
     if not any(w in key[0] for w in want):
