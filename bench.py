@@ -483,6 +483,22 @@ def main():
         if pipelined:
             leng.finish_pipeline()
     inv_us_live = float(np.mean([lib.pmc_event_elapsed_ms(a, b) for a, b in ev_pairs[::args.event_every]])) * 1e3
+    # the same launch without the scaler epilogue (pmc_step_t.no_fuse bit 1: the scaler as a launch of its own), a few
+    # untimed steps: what the sweep alone takes -- side key of the roofline object
+    inv_us_sweep_only = None
+    scaler_epilogue = int(roof_eng._step.no_fuse) & 3 == 0
+    if scaler_epilogue:
+        roof_eng._step.no_fuse = int(roof_eng._step.no_fuse) | 2
+        extra = [(lib.pmc_event_create(), lib.pmc_event_create()) for _ in range(10)]
+        for pair in extra:
+            roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = pair
+            timed_step()
+        torch.cuda.synchronize()
+        roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = None, None
+        roof_eng._step.no_fuse = int(roof_eng._step.no_fuse) & ~2
+        inv_us_sweep_only = float(np.mean([lib.pmc_event_elapsed_ms(a, b) for a, b in extra[2:]])) * 1e3
+        for a, b in extra:
+            lib.pmc_event_destroy(a); lib.pmc_event_destroy(b)
     for a, b in ev_pairs:
         lib.pmc_event_destroy(a); lib.pmc_event_destroy(b)
     # ---- composite path again with host timers only (no HIP events): where the host thread's time goes
@@ -567,8 +583,16 @@ def main():
                 "flops_per_launch": actual_flops,
                 "note": "achieved = executed flops (2 x the unmasked multiply-adds of the flow, each once: the triangular "
                         "sweep) / launch time, measured with a HIP event pair inside the timed region"
-                        + ("; the launch also proposes theta' for its walkers (fused proposal prologue)" if fused else ""),
+                        + ("; the launch also proposes theta' for its walkers (fused proposal prologue)" if fused else "")
+                        + ("; and applies the scaler + prior to them and stores x' to pinned host memory over PCIe (fused "
+                           "epilogue, ~1.3 MB per launch at ~40 GB/s): that part of the launch executes no flow flops -- "
+                           "sweep_only is the same launch without it" if (fused and inv_us_sweep_only) else ""),
                 "fused_proposal": bool(fused),
+                "fused_scaler_epilogue": bool(fused and inv_us_sweep_only),
+                "sweep_only": None if not (fused and inv_us_sweep_only) else
+                {"avg_launch_us": inv_us_sweep_only, "achieved": actual_flops / inv_us_sweep_only / 1e6,
+                 "frac": actual_flops / inv_us_sweep_only / 1e6 / PEAK_F32_MFMA_TFLOPS,
+                 "note": "proposal + sweep without the scaler epilogue (10 untimed steps with pmc_step_t.no_fuse = 2)"},
                 "naive_equivalent": {"flops_per_launch": algo_flops, "tflops": algo_flops / t_inv / 1e12,
                                      "note": "SURVEY 8(d) F_inv = (D+1) F_fwd per walker: zuko's D-pass algorithm, not executed"}}
     # HBM-nominal sweeps: achieved GB/s against ~8 TB/s.  At this size every array (1.28 MB f32 /

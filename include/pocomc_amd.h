@@ -420,7 +420,8 @@ typedef struct pmc_step {
     int64_t* h_done;          /* pinned host int64 [2] or NULL: with host_direct, [0] <- step + 1 when pmc_step_pre's results
                                * are in host memory, [1] <- step + 1 when pmc_step_post's are (pmc_wait_flag) */
     uint32_t* done_ticket;    /* device uint32 [1], zeroed once */
-    int32_t no_fuse;          /* 1: always launch the proposal and the flow inverse separately */
+    int32_t no_fuse;          /* bit 0: launch the proposal and the flow inverse separately; bit 1: keep the scaler (+ prior)
+                               * a launch of its own instead of the epilogue of the fused proposal + inverse launch */
     int32_t host_direct;      /* 1: h_x (column-major, p_xT == NULL), h_fin, h_logp_out and h_mu are device-accessible
                                * pinned memory that the kernels read / write themselves -- no copies in pmc_step_pre */
     /* Adaptation on the device (mcmc.py:152-156 and the variants :314-318, :476-480, :627-631): with adapt_state

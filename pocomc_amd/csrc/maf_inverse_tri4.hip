@@ -336,6 +336,13 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
         __syncthreads();
     }
     if (ladj_out && lane < 16 && row0 + p < n) ladj_out[row0 + p] = ladj;
+    if constexpr (FM > 0) {
+        // the scaler (+ prior) on the 16 walkers while they are in LDS (X: by rank of the first transform); the
+        // activation tiles are free now and serve as its scratch
+        if (pa.epi.on)
+            scaler_epilogue(pa.epi, X, rank_of_feat, reinterpret_cast<double*>(H0), row0, n, D, lane, 64,
+                            [](int r, int pp) { return lidx(r, pp); });
+    }
 }
 
 static bool tri5_wanted(const pmc_maf_t* m, int64_t n);
@@ -390,13 +397,19 @@ int pmc_launch_inverse_tri4(const pmc_maf_t* m, const float* z, float* x, float*
 int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* mu, const double* inv_cov,
                                     const double* chol, double nu, double sigma, double cn_a, const pmc_rng_t* rng,
                                     double* prop64, double* quad, double* quad_prop, const pmc_maf_t* m, float* x,
-                                    float* ladj, int64_t n, hipStream_t stream, const double* adapt) {
+                                    float* ladj, int64_t n, hipStream_t stream, const double* adapt,
+                                    const ScalerEpi* epi, int* epi_done) {
+    if (epi_done) *epi_done = 0;
     if (m->n_out != 2 || !m->tri_ok || m->nOT > 8 || m->D > 64) return -1;
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
     const int maxo = m->nOT <= 4 ? 4 : 8;
     const size_t lds = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     ProposeArgs pa{kind, cur32, mu, inv_cov, chol, nu, sigma, cn_a, *rng, prop64, quad, quad_prop, adapt};
+    // the scaler as the sweep's epilogue: its scratch aliases the two activation arrays of the walker set
+    const bool epi_ok = epi && epi_done && epi->s.D == m->D && !lane_sweep_enabled() &&
+                        scaler_epilogue_lds_bytes(m->D) <= (size_t)2 * m->Hp * 16 * sizeof(float);
+    if (epi_ok) { pa.epi = *epi; pa.epi.on = 1; *epi_done = 1; }
     if (lane_sweep_enabled()) {
         const int rc = pmc_launch_tri6(&pa, m, nullptr, x, ladj, n, stream);
         if (rc >= 0) return rc;
@@ -774,6 +787,11 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
         __syncthreads();
     }
     if (wv < TRI5_NC && ladj_out && lane < 16 && row0 + p < n) ladj_out[row0 + p] = ladj;
+    if constexpr (FM > 0 && TRI5_NC == 1) {
+        if (pa.epi.on)                                 // both wavefronts: 16 walkers x D elements over 128 threads
+            scaler_epilogue(pa.epi, X, rank_of_feat, reinterpret_cast<double*>(H0), row0, n, D, (int)threadIdx.x,
+                            64 * (TRI5_NC + 1), [](int r, int pp) { return lidx(r, pp); });
+    }
 }
 
 // -1: automatic (by size), 0: never, 1: always

@@ -107,124 +107,7 @@ __global__ __launch_bounds__(PROP_ROWS) void propose_kernel(
     }
 }
 
-// ===========================================================================
-// scaler: Reparameterize.inverse / forward (scaler.py:180-226, :293-425)
-// ===========================================================================
-#define LOG_SQRT_2PI 0.91893853320467267   // np.log(np.sqrt(2.0*np.pi))
-#define SQRT2 1.4142135623730951           // np.sqrt(2.0)
-
-struct ScalerDev {
-    pmc_scaler_t s;
-};
-
-// numpy's pairwise summation (umath loops, PW_BLOCKSIZE = 128), so that the row sum of
-// the Jacobian terms (scaler.py:270) is accumulated in numpy's order
-__device__ __forceinline__ double np_pairwise_leaf(const double* a, int n) {   // n <= 128
-    if (n < 8) {
-        double res = 0.0;
-        for (int i = 0; i < n; ++i) res += a[i];
-        return res;
-    }
-    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
-    int i;
-    for (i = 8; i < n - (n % 8); i += 8) {
-        r0 += a[i + 0]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
-        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
-    }
-    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; ++i) res += a[i];
-    return res;
-}
-
-// numpy splits n > 128 in halves (first half rounded down to a multiple of 8), recursively;
-// three explicit levels cover n <= 1024 without a device-side call stack
-template <int LEVEL>
-__device__ __forceinline__ double np_pairwise_sum_l(const double* a, int n) {
-    if (n <= 128) return np_pairwise_leaf(a, n);
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    if constexpr (LEVEL > 0) return np_pairwise_sum_l<LEVEL - 1>(a, n2) + np_pairwise_sum_l<LEVEL - 1>(a + n2, n - n2);
-    else return np_pairwise_leaf(a, n2) + np_pairwise_leaf(a + n2, n - n2);
-}
-
-__device__ __forceinline__ double np_pairwise_sum(const double* a, int n) { return np_pairwise_sum_l<2>(a, n); }
-
-// bounded <- unbounded for one element; t is the (affine-transformed) input.  scaler.py:329-425
-__device__ __forceinline__ void bound_inverse(const pmc_scaler_t& s, int j, double t, double& x, double& J) {
-    {
-        const int kind = s.kind[j];
-        if (kind == 0) { x = t; J = 0.0; }
-        else if (kind == 1) { x = exp(t) + s.low[j]; J = t; }
-        else if (kind == 2) { x = s.high[j] - exp(t); J = t; }
-        else {
-            const double w = s.high[j] - s.low[j];
-            if (s.logit) {
-                // p = exp(-logaddexp(0, -t))
-                const double mt = -t;
-                double lae;
-                if (mt == 0.0) lae = 0.6931471805599453;
-                else if (0.0 - mt > 0.0) lae = 0.0 + log1p(exp(-(0.0 - mt)));
-                else lae = mt + log1p(exp(0.0 - mt));
-                const double p = exp(-lae);
-                x = p * w + s.low[j];
-                J = (s.log_width[j] + log(p)) + log(1.0 - p);
-            } else {
-                const double p = (erf(t / SQRT2) + 1.0) / 2.0;
-                x = p * w + s.low[j];
-                J = (s.log_width[j] + (-(t * t) / 2.0)) - LOG_SQRT_2PI;
-            }
-        }
-    }
-}
-
-// unbounded <- bounded (scaler.py:228-247, :315-400), then the affine part (:273-289)
-__device__ __forceinline__ double bound_forward(const pmc_scaler_t& s, int j, double x) {
-    double u;
-    {
-        const int kind = s.kind[j];
-        if (kind == 0) u = x;
-        else if (kind == 1) u = log(x - s.low[j]);
-        else if (kind == 2) u = log(s.high[j] - x);
-        else {
-            const double p = (x - s.low[j]) / (s.high[j] - s.low[j]);
-            if (s.logit) u = log(p / (1.0 - p));
-            else u = SQRT2 * erfinv(2.0 * p - 1.0);
-        }
-        if (s.scale) u = (u - s.mu[j]) / s.sigma[j];
-    }
-    return u;
-}
-
-// periodic wrap / reflective fold (scaler.py:109-157).  The reference loops "while
-// outside"; a non-finite x would never leave that loop, the device bounds it.
-__device__ __forceinline__ double apply_bc(const pmc_scaler_t& s, int j, double x) {
-    const int bc = s.bc[j];
-    if (bc == 0) return x;
-    const double lo = s.low[j], hi = s.high[j];
-    {
-        if (bc & 1) {
-            for (int it = 0; it < 4096 && x > hi; ++it) x = lo + x - hi;
-            for (int it = 0; it < 4096 && x < lo; ++it) x = hi + x - lo;
-        }
-        if (bc & 2) {
-            for (int it = 0; it < 4096 && x > hi; ++it) x = hi - x + hi;
-            for (int it = 0; it < 4096 && x < lo; ++it) x = lo + lo - x;
-        }
-    }
-    return x;
-}
-
-// one factor of Prior.logpdf (pocomc/prior.py:70-100), shared by prior_logpdf_kernel and the fused scaler kernel
-__device__ __forceinline__ double prior_term(const pmc_prior_t& pr, int j, double xv) {
-    const double loc = pr.loc[j], sc = pr.scale[j];
-    if (pr.family[j] == PMC_PRIOR_UNIFORM) {
-        // scipy uniform(loc, scale).logpdf: -log(scale) on [loc, loc+scale], -inf outside
-        return (xv >= loc && xv <= loc + sc) ? -log(sc) : -INFINITY;
-    }
-    // scipy norm(loc, scale).logpdf: _norm_logpdf((x-loc)/scale) - log(scale)
-    const double z = (xv - loc) / sc;
-    return (-(z * z) / 2.0 - LOG_SQRT_2PI) - log(sc);
-}
+#include "scaler_body.h"
 
 // SCL_THREADS threads per block: the probit / logit maps are long dependent f64 chains, so the block's 64 x D elements
 // are spread over as many lanes as a block can have (four elements per lane at D = 32 instead of eight; 1024 threads would halve the registers of a lane and spill)

@@ -17,7 +17,8 @@ int pmc_launch_inverse_tri4(const pmc_maf_t* m, const float* z, float* x, float*
 int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* mu, const double* inv_cov,
                                     const double* chol, double nu, double sigma, double cn_a, const pmc_rng_t* rng,
                                     double* prop64, double* quad, double* quad_prop, const pmc_maf_t* m, float* x,
-                                    float* ladj, int64_t n, hipStream_t stream, const double* adapt = nullptr);
+                                    float* ladj, int64_t n, hipStream_t stream, const double* adapt = nullptr,
+                                    const struct ScalerEpi* epi = nullptr, int* epi_done = nullptr);   // (scaler_body.h)
 int pmc_launch_propose_mfma(int kind, const float* cur32, const double* cur64, const double* mu,
                             const double* inv_cov, const double* chol, double nu, double sigma, double cn_a,
                             const pmc_rng_t* rng, double* prop64, float* prop32, double* quad, double* quad_prop,

@@ -157,6 +157,8 @@ __device__ __forceinline__ void propose_body(
 // Proposal arguments of the fused variant (pmc_propose_inverse): the wave first proposes theta' for its 16
 // walkers (propose_body.h) straight into the sweep's LDS input -- one launch and one global round trip less
 // per MCMC step.
+#include "scaler_body.h"
+
 struct ProposeArgs {
     int kind;
     const float* cur32;
@@ -166,6 +168,7 @@ struct ProposeArgs {
     double* prop64; double* quad; double* quad_prop;
     const double* adapt;          // pmc_step_t.adapt_state or NULL: {sigma, cn_a, mu[D]} on the device
     long long* prof;              // measurement only (scripts/profile_tri6.py): cycle stamps of workgroup 0, or NULL
+    ScalerEpi epi;                // epi.on: the scaler (+ prior) runs as the sweep's epilogue (scaler_body.h)
 };
 
 // lane-per-walker sweep (maf_inverse_tri6.hip); pa == nullptr: plain inverse of z.  -1: flow not covered

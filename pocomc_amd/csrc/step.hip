@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <time.h>
 #include "pmc_internal.h"
+#include "scaler_body.h"
 
 extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu, double sigma, double cn_a,
                             void* stream) {
@@ -61,15 +62,39 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
     }
     int rc;
     bool fused = false;
-    if (s->preconditioned && !s->no_fuse &&
+    int scaled = 0;                                  // the sweep's epilogue applied the scaler (+ prior) as well
+    // scaler inverse and (when it runs on the device) Prior.logpdf: one launch, or the epilogue of the fused sweep
+    const pmc_prior_t* pr = s->prior;
+    double* lp = pr ? s->p_logp : nullptr;
+    double* xT = direct ? s->h_x : s->p_xT;
+    int32_t* fin2 = direct ? s->h_fin : nullptr;
+    double* lp2 = (direct && pr) ? s->h_logp_out : nullptr;
+    pmc_done_t dn{s->h_done, (int64_t)rng->step + 1, s->done_ticket};
+    const pmc_done_t* done = (direct && s->h_done && s->done_ticket) ? &dn : nullptr;
+    if (s->preconditioned && !(s->no_fuse & 1) &&
         (s->inverse_algo == PMC_INVERSE_AUTO || s->inverse_algo == PMC_INVERSE_TRIANGULAR)) {
-        // proposal + flow inverse in one launch (affine flows, D <= 64)
+        // proposal + flow inverse (+ scaler) in one launch (affine flows, D <= 64); no_fuse & 2 keeps the scaler apart
+        ScalerEpi epi{};
+        const bool want_epi = !(s->no_fuse & 2) && s->scaler && s->scaler->low && s->scaler->high && s->scaler->kind &&
+                              s->scaler->log_width && (!s->scaler->scale || (s->scaler->mu && s->scaler->sigma)) &&
+                              (!pr || (pr->family && pr->loc && pr->scale && pr->D == D));
+        if (want_epi) {
+            epi.s = *s->scaler;
+            epi.have_prior = pr ? 1 : 0;
+            if (pr) epi.pr = *pr;
+            epi.u_out = s->p_u; epi.x_out = s->p_x; epi.x_colmajor = xT; epi.ldj_out = s->p_logdetj;
+            epi.finite_out = s->p_fin; epi.logp_out = lp; epi.finite_copy = fin2; epi.logp_copy = lp2;
+            epi.done_ticket = done ? done->ticket : nullptr;
+            epi.done_flag = done ? (long long*)done->flag : nullptr;
+            epi.done_value = done ? (long long)done->value : 0LL;
+        }
         if (s->ev_inv0) (void)hipEventRecord((hipEvent_t)s->ev_inv0, st);
         rc = pmc_launch_propose_inverse_tri4(s->kind, s->cur.theta32, mu, s->inv_cov, s->chol, nu, sigma, cn_a, rng,
                                              s->p_theta64, tpcn ? s->quad : nullptr, tpcn ? s->p_quad : nullptr, s->maf,
-                                             s->p_u32, s->p_ldjf, n, st, adapt);
+                                             s->p_u32, s->p_ldjf, n, st, adapt, want_epi ? &epi : nullptr, &scaled);
         if (rc > 0) return rc;
         fused = (rc == 0);
+        if (!fused) scaled = 0;
         if (fused && s->ev_inv1) (void)hipEventRecord((hipEvent_t)s->ev_inv1, st);
     }
     if (!fused) {
@@ -79,15 +104,9 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
                                tpcn ? s->p_quad : nullptr, n, D, stream, adapt);
         if (rc) return rc;
     }
-    // scaler inverse and (when it runs on the device) Prior.logpdf share one launch
-    const pmc_prior_t* pr = s->prior;
-    double* lp = pr ? s->p_logp : nullptr;
-    double* xT = direct ? s->h_x : s->p_xT;
-    int32_t* fin2 = direct ? s->h_fin : nullptr;
-    double* lp2 = (direct && pr) ? s->h_logp_out : nullptr;
-    pmc_done_t dn{s->h_done, (int64_t)rng->step + 1, s->done_ticket};
-    const pmc_done_t* done = (direct && s->h_done && s->done_ticket) ? &dn : nullptr;
-    if (s->preconditioned) {
+    if (scaled) {
+        rc = 0;
+    } else if (s->preconditioned) {
         if (!fused) {
             if (s->ev_inv0) (void)hipEventRecord((hipEvent_t)s->ev_inv0, st);
             rc = pmc_maf_inverse(s->maf, s->p_theta32, s->p_u32, s->p_ldjf, n, s->inverse_algo, stream);

@@ -21,6 +21,7 @@ every rank.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -255,7 +256,8 @@ class StepEngine:
             sums=self.sums.data_ptr(), ws=self.ws.data_ptr(),
             h_mu=self.h_mu.data_ptr() if self.tpcn else None, h_x=self.h_x.data_ptr(), h_fin=self.h_fin.data_ptr(),
             h_logl=self.h_logl.data_ptr(), h_logp=self.h_logp.data_ptr(), h_sums=self.h_sums.data_ptr(),
-            h_accept=self.h_accept.data_ptr())
+            h_accept=self.h_accept.data_ptr(),
+            no_fuse=int(os.environ.get("PMC_NO_FUSE", "0")))     # A/B: bit 0 separate proposal / inverse, bit 1 separate scaler
         self._rng_fast = _lib.pmc_rng_t(gamma=None, normal=None, uniform=None, seed=self.seed, step=0,
                                         offset=self.offset)
         # throughput mode: the Philox variates of step k+1 are generated behind step k's kernels, while the host
