@@ -292,3 +292,56 @@ def test_chain_image_of_the_lane_sweep_reproduces_the_inverse(D, T):
     x, l = _tri6_emulate(spec, flat, z)
     np.testing.assert_allclose(x, xo, rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(l, lo, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("D,T,H", [(16, 2, 64), (50, 3, 256), (128, 2, 512)])
+def test_bf16_training_image_covers_every_unmasked_parameter_once(D, T, H):
+    """``MAFSpec.wide_index`` (gather map of the row-major bf16 image of ``csrc/maf_train_bf16.hip`` and scatter map of
+    its weight gradients): every unmasked weight sits once in its ``W`` part and once in its ``W^T`` part at the
+    transposed position, every bias once, masked entries nowhere; the emulated forward pass through the image equals
+    the canonical masked matrices."""
+    from pocomc_amd.maf_spec import MAFSpec
+    spec = MAFSpec(D, T, hidden=H)
+    L = spec.wide_layout()
+    img, bias = spec.wide_index()
+    assert img.size == T * L["per_transform"] and bias.size == T * L["bias_per_transform"]
+    m = spec.mask_flat()
+    is_bias = np.zeros(spec.n_params, dtype=bool)
+    for t in range(T):
+        for k in ("b0", "b1", "b2", "b3"):
+            o, sz = spec.offsets[k]
+            is_bias[t * spec.params_per_transform + o: t * spec.params_per_transform + o + sz] = True
+    cnt = np.bincount(img[img >= 0], minlength=spec.n_params)
+    cb = np.bincount(bias[bias >= 0], minlength=spec.n_params)
+    assert np.all(cnt[(m > 0) & ~is_bias] == 2) and np.all(cnt[(m == 0) | is_bias] == 0)
+    assert np.all(cb[is_bias] == 1) and np.all(cb[~is_bias] == 0)
+    DK, HK, OK = L["DK"], L["HK"], L["OK"]
+    flat = spec.init_params(1)
+    vals = np.where(img >= 0, flat[np.maximum(img, 0)], 0.0)
+    bv = np.where(bias >= 0, flat[np.maximum(bias, 0)], 0.0)
+    su = np.full(HK, -1)
+    su[:spec.Hp] = spec.slot_unit
+    live = su >= 0
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=D).astype(np.float32)
+    for t in range(T):
+        o = t * L["per_transform"]
+        W0f = vals[o:o + HK * DK].reshape(HK, DK); o += HK * DK
+        W0b = vals[o:o + DK * HK].reshape(DK, HK); o += DK * HK
+        W1f = vals[o:o + HK * HK].reshape(HK, HK); o += HK * HK
+        W1b = vals[o:o + HK * HK].reshape(HK, HK); o += 2 * HK * HK + HK * HK      # (skip W2f, W2b)
+        W3f = vals[o:o + OK * HK].reshape(OK, HK); o += OK * HK
+        W3b = vals[o:o + HK * OK].reshape(HK, OK)
+        assert np.array_equal(W0b, W0f.T) and np.array_equal(W1b, W1f.T) and np.array_equal(W3b, W3f.T)
+        M0, M1, M2, M3 = spec.masks(t)
+        W0 = spec.view(flat, t, "W0") * M0
+        b0 = spec.view(flat, t, "b0")
+        h_img = W0f[:, :D] @ x + bv[t * L["bias_per_transform"]: t * L["bias_per_transform"] + HK]
+        h_ref = W0 @ x + b0
+        np.testing.assert_allclose(h_img[live], h_ref[su[live]], rtol=1e-6, atol=1e-6)
+        assert np.all(h_img[~live] == 0.0)
+        W3 = spec.view(flat, t, "W3") * M3                                 # rows 2 * feature + s
+        hh = rng.normal(size=H).astype(np.float32)
+        hs = np.zeros(HK, dtype=np.float32)
+        hs[live] = hh[su[live]]
+        np.testing.assert_allclose((W3f @ hs)[:2 * D], W3 @ hh, rtol=1e-5, atol=1e-5)
