@@ -207,6 +207,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flow-bench", action="store_true", help="skip the config-5 flow sub-metric (f32 vs bf16 log_prob)")
     ap.add_argument("--host-threads", type=int, default=1, help="host threads evaluating the prior/likelihood")
+    ap.add_argument("--host-prefetch", type=int, default=1,
+                    help="helper threads that warm the cache with x' for the likelihood (csrc/host_prefetch.hip; they run "
+                         "nothing of the likelihood, which stays on the driver thread; 0 = off)")
     ap.add_argument("--host-prior", action="store_true",
                     help="evaluate Prior.logpdf on the host (default: on the device, it is a product of scipy.stats "
                          "uniform factors, not a black box)")
@@ -433,6 +436,12 @@ def main():
                 if args.host_threads > 1:
                     for e_ in [eng] + (leng.lanes if leng is not None else []):
                         e_.host_threads, e_.host_cores = args.host_threads, host_cores
+                if args.host_prefetch > 0:
+                    from pocomc_amd.mcmc import host_prefetch
+                    pf_cores = [cand[(i0 + 1 + j) % len(cand)] for j in range(args.host_prefetch)]
+                    pf = host_prefetch(eng.lib, args.host_prefetch, pf_cores)
+                    for e_ in [eng] + (leng.lanes if leng is not None else []):
+                        e_.prefetcher = pf
             else:
                 pinned_core = None
         except (OSError, AttributeError):
@@ -714,7 +723,7 @@ def main():
                       "flow_trained_50_epochs": flow_trained, "parallelism": f"walker-sharded x{world}",
                       "lanes": len(leng.lanes) if leng is not None else 1,
                       "pipelined_device_adaptation": bool(pipelined and leng is not None),
-                      "inverse_algo": args.inverse, "host_threads": args.host_threads, "host_x_order": args.x_order, "prior_on_device": bool(device_prior),
+                      "inverse_algo": args.inverse, "host_threads": args.host_threads, "host_prefetch_threads": args.host_prefetch, "host_x_order": args.x_order, "prior_on_device": bool(device_prior),
                       "accept_rate": float((ad_l if leng is not None else ad).mean_alpha),
                       "backend": (dist.get_backend() if world > 1 else None),
                       "ranks_reported_by_backend": (dist.get_world_size() if world > 1 else 1),

@@ -280,6 +280,16 @@ typedef struct pmc_done {
 /* spin until *flag == value; non-zero return after timeout_s seconds */
 int pmc_wait_flag(const int64_t* flag, int64_t value, double timeout_s);
 
+/* Cache warmer for the likelihood's input (host side only; csrc/host_prefetch.hip).  n_threads helper threads, pinned to
+ * cpus[i] (or unpinned when cpus == NULL) -- cores that share the L3 with the thread that calls the likelihood.  A job:
+ * wait until the completion word *flag (i64, pinned host memory, written by the kernels as for pmc_wait_flag) reaches
+ * value, then read buf[0 .. bytes) once, back to front, so that the likelihood finds x' in the cache hierarchy instead of
+ * in DRAM.  Best effort: jobs are dropped when the helpers are more than 16 behind, a job gives up after timeout_s. */
+void* pmc_prefetcher_create(int32_t n_threads, const int32_t* cpus);
+int pmc_prefetcher_submit(void* prefetcher, const void* flag, int64_t value, const void* buf, int64_t bytes,
+                          double timeout_s);
+void pmc_prefetcher_destroy(void* prefetcher);
+
 /* pmc_scaler_inverse and pmc_prior_logpdf in ONE launch (the step's pre-phase is a chain of small
  * latency-bound kernels; each launch costs ~15-20 us end to end): additionally
  * logp f64 [n] <- Prior.logpdf(x') on the finite rows, -inf elsewhere (mcmc.py:105-107).

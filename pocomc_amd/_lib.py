@@ -121,6 +121,9 @@ SIGNATURES = {
     "pmc_maf_loss_grad_bf16": (C.c_int, [P(pmc_maf_t), P(pmc_maf_wide_t), c_p, c_p, c_p, C.c_float, c_p, c_p, i64, c_p]),
     "pmc_maf_train_epoch_bf16": (C.c_int, [P(pmc_maf_t), P(pmc_maf_wide_t), P(pmc_adamw_t), c_p, c_p, c_p, i64, i64, c_p,
                                            c_p, c_p]),
+    "pmc_prefetcher_create": (C.c_void_p, [C.c_int32, c_p]),
+    "pmc_prefetcher_submit": (C.c_int, [c_p, c_p, i64, c_p, i64, f64]),
+    "pmc_prefetcher_destroy": (None, [c_p]),
     "pmc_maf_valid_epoch": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, i64, i64, c_p, c_p, c_p]),
     "pmc_neg_weighted_sum": (C.c_int, [c_p, c_p, c_p, C.c_float, c_p, i64, c_p]),
     "pmc_sum_f32": (C.c_int, [c_p, c_p, i64, c_p]),

@@ -1,0 +1,124 @@
+// Host-side cache warmer for the likelihood's input (no device code in this file).
+//
+// The step hands x' to the user's likelihood in pinned host memory that the GPU has just written over PCIe: every line
+// is a DRAM miss for the calling thread (measured on the GPU box's EPYC 9575F: the numpy Rosenbrock of the benchmark
+// takes 68 us per 5008 x 32 rows on warm data, ~95 us on the freshly written buffer).  A helper thread -- pinned to a
+// core that shares the L3 with the driver thread -- waits for the same completion word the driver waits for and reads
+// the buffer once, back to front, so that the likelihood's own passes find the lines in the L3 / in the neighbour's L2
+// instead of in DRAM.  Best effort and invisible to the results: nothing is written, a late helper only wastes its time.
+#include <pthread.h>
+#include <sched.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <time.h>
+#include <atomic>
+#include <immintrin.h>
+#include "../../include/pocomc_amd.h"
+
+namespace {
+
+struct Job { const volatile int64_t* flag; int64_t value; const char* buf; int64_t bytes; double timeout_s; };
+
+constexpr int RING = 16;
+
+struct Worker {
+    pthread_t th;
+    std::atomic<uint64_t> head{0}, tail{0};          // jobs submitted / finished
+    Job ring[RING];
+    int cpu = -1, idx = 0, n = 1;
+    std::atomic<int> stop{0};
+    volatile uint64_t sink = 0;
+};
+
+struct Prefetcher { int n; Worker* w; };
+
+double now_s() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+void* worker_main(void* arg) {
+    Worker* w = static_cast<Worker*>(arg);
+    if (w->cpu >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(w->cpu, &set);
+        (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+    }
+    uint64_t idle = 0;
+    while (!w->stop.load(std::memory_order_relaxed)) {
+        const uint64_t t = w->tail.load(std::memory_order_relaxed);
+        if (t == w->head.load(std::memory_order_acquire)) {
+            // nothing to do: spin for a while (a step is a few hundred microseconds), then doze
+            if (++idle < 200000) { _mm_pause(); continue; }
+            timespec ts{0, 50000};
+            nanosleep(&ts, nullptr);
+            continue;
+        }
+        idle = 0;
+        const Job j = w->ring[t % RING];
+        const double t0 = now_s();
+        bool ready = true;
+        for (uint64_t spins = 0; *j.flag < j.value; ++spins) {
+            _mm_pause();
+            if (w->stop.load(std::memory_order_relaxed)) { ready = false; break; }
+            if ((spins & 4095) == 4095 && now_s() - t0 > j.timeout_s) { ready = false; break; }
+        }
+        if (ready) {
+            // 4 KB pieces from the end of the buffer, dealt to the helpers in turn; one read per 64-byte line
+            const int64_t pieces = (j.bytes + 4095) / 4096;
+            uint64_t s = 0;
+            for (int64_t p = pieces - 1 - w->idx; p >= 0; p -= w->n) {
+                const int64_t lo = p * 4096, hi = (lo + 4096 < j.bytes) ? lo + 4096 : j.bytes;
+                for (int64_t o = hi - 1; o >= lo; o -= 64) s += (unsigned char)j.buf[o];
+            }
+            w->sink += s;
+        }
+        w->tail.store(t + 1, std::memory_order_release);
+    }
+    return nullptr;
+}
+
+}  // namespace
+
+extern "C" void* pmc_prefetcher_create(int32_t n_threads, const int32_t* cpus) {
+    if (n_threads < 1 || n_threads > 64) return nullptr;
+    Prefetcher* p = new Prefetcher{n_threads, new Worker[n_threads]};
+    for (int i = 0; i < n_threads; ++i) {
+        p->w[i].cpu = cpus ? cpus[i] : -1;
+        p->w[i].idx = i;
+        p->w[i].n = n_threads;
+        if (pthread_create(&p->w[i].th, nullptr, worker_main, &p->w[i]) != 0) {
+            for (int k = 0; k < i; ++k) { p->w[k].stop.store(1); pthread_join(p->w[k].th, nullptr); }
+            delete[] p->w;
+            delete p;
+            return nullptr;
+        }
+    }
+    return p;
+}
+
+extern "C" int pmc_prefetcher_submit(void* handle, const void* flag, int64_t value, const void* buf, int64_t bytes,
+                                     double timeout_s) {
+    Prefetcher* p = static_cast<Prefetcher*>(handle);
+    if (!p || !flag || !buf || bytes <= 0) return 1;
+    for (int i = 0; i < p->n; ++i) {
+        Worker& w = p->w[i];
+        const uint64_t h = w.head.load(std::memory_order_relaxed);
+        if (h - w.tail.load(std::memory_order_acquire) >= RING) continue;      // helper far behind: skip this one
+        w.ring[h % RING] = Job{static_cast<const volatile int64_t*>(flag), value, static_cast<const char*>(buf), bytes,
+                               timeout_s > 0 ? timeout_s : 1.0};
+        w.head.store(h + 1, std::memory_order_release);
+    }
+    return 0;
+}
+
+extern "C" void pmc_prefetcher_destroy(void* handle) {
+    Prefetcher* p = static_cast<Prefetcher*>(handle);
+    if (!p) return;
+    for (int i = 0; i < p->n; ++i) p->w[i].stop.store(1);
+    for (int i = 0; i < p->n; ++i) pthread_join(p->w[i].th, nullptr);
+    delete[] p->w;
+    delete p;
+}

@@ -294,6 +294,7 @@ class StepEngine:
         self.step_idx = 0
         self.host_threads = 1    # >1: evaluate the black boxes on row chunks, this thread + (host_threads - 1) pool threads
         self.host_cores = None   # optional list of cores the pool's threads are pinned to (one each)
+        self.prefetcher = None   # handle of pmc_prefetcher_create (shared by the lanes of a walker set), see host_prefetch()
         self._pool = None
         self.stream = None       # torch.cuda.Stream of the composite path (LanedEngine); None: the current one
         self.events = None       # bench.py: list of per-step HIP event tuples when not None
@@ -424,6 +425,10 @@ class StepEngine:
             self._stream = self.stream.cuda_stream if self.stream is not None else _lib.stream_handle()
             _lib.check(lib.pmc_step_pre(C.byref(self._step), C.byref(self._rng_cur), float(nu), float(sigma), cn_a,
                                         self._stream), "pmc_step_pre")
+            if self.prefetcher is not None and self._direct_now:
+                # helper threads read x' once as soon as the completion word of this pre-step shows up
+                lib.pmc_prefetcher_submit(self.prefetcher, self.h_done.data_ptr(), int(self._rng_cur.step) + 1,
+                                          self.h_x.data_ptr(), n * D * 8, 1.0)
             self._post_uploads = True
             return
         self._post_uploads = False
@@ -832,6 +837,24 @@ def _global_count(n, group):
     return n
 
 
+_PREFETCHERS = {}
+
+
+def host_prefetch(lib, n_threads, cores=None):
+    """Process-wide cache warmer (``csrc/host_prefetch.hip``): ``n_threads`` helper threads pinned to ``cores`` (cores
+    that share the L3 with the thread that calls the likelihood) read every x' the kernels hand to the host once, as
+    soon as it is complete.  Option ``host_prefetch`` / ``host_prefetch_cores`` of the kernels; the handle lives as long
+    as the process."""
+    key = (int(n_threads), tuple(cores) if cores else None)
+    if key not in _PREFETCHERS:
+        arr = (C.c_int32 * n_threads)(*[int(c) for c in cores][:n_threads]) if cores and len(cores) >= n_threads else None
+        h = lib.pmc_prefetcher_create(int(n_threads), arr)
+        if not h:
+            raise RuntimeError("pmc_prefetcher_create failed")
+        _PREFETCHERS[key] = h
+    return _PREFETCHERS[key]
+
+
 def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
     pre = kind.startswith("preconditioned")
     tpcn = kind in ("preconditioned_pcn", "pcn")
@@ -899,6 +922,8 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
         # opt-in: the black boxes are called concurrently on row chunks from this many threads (they must be
         # thread-safe; the reference calls them on the calling thread only)
         tune(host_threads=int(option_dict["host_threads"]), host_cores=option_dict.get("host_cores"))
+    if int(option_dict.get("host_prefetch") or 0) > 0:
+        tune(prefetcher=host_prefetch(eng.lib, int(option_dict["host_prefetch"]), option_dict.get("host_prefetch_cores")))
     owner = getattr(log_prior, "__self__", None)
     if owner is not None and option_dict.get("device_prior", True) and hasattr(owner, "device_descriptor"):
         eng.set_device_prior(owner)                 # Prior.logpdf of uniform / normal factors on the device

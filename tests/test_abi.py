@@ -345,3 +345,25 @@ def test_bf16_training_image_covers_every_unmasked_parameter_once(D, T, H):
         hs = np.zeros(HK, dtype=np.float32)
         hs[live] = hh[su[live]]
         np.testing.assert_allclose((W3f @ hs)[:2 * D], W3 @ hh, rtol=1e-5, atol=1e-5)
+
+
+def test_host_prefetcher_runs_a_job_and_shuts_down():
+    """``pmc_prefetcher_*`` (host code only): a helper thread waits for a completion word and reads a buffer; the call
+    sequence create / submit / flag / destroy returns, nothing is written to the buffer."""
+    import ctypes as C
+    import time
+    from pocomc_amd import _lib
+    lib = _lib.load()                       # (loading and host-only entry points need no GPU)
+    h = lib.pmc_prefetcher_create(2, None)
+    assert h
+    flag = np.zeros(1, dtype=np.int64)
+    buf = np.arange(100003, dtype=np.float64)
+    ref = buf.copy()
+    for step in range(1, 4):
+        assert lib.pmc_prefetcher_submit(h, flag.ctypes.data, step, buf.ctypes.data, buf.nbytes, 0.5) == 0
+        flag[0] = step
+    assert lib.pmc_prefetcher_submit(h, flag.ctypes.data, 99, buf.ctypes.data, buf.nbytes, 0.05) == 0    # never signalled: times out
+    time.sleep(0.2)
+    lib.pmc_prefetcher_destroy(h)
+    assert np.array_equal(buf, ref)
+    assert lib.pmc_prefetcher_submit(None, flag.ctypes.data, 1, buf.ctypes.data, 8, 0.1) != 0

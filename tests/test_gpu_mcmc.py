@@ -483,6 +483,39 @@ def test_scaler_epilogue_of_the_sweep_equals_the_scaler_launch(monkeypatch, N, l
         assert np.array_equal(a[k], b[k]), k
 
 
+def test_cache_warmer_threads_do_not_touch_the_results():
+    """option host_prefetch: helper threads read x' behind the completion word (csrc/host_prefetch.hip) -- same call bit for bit."""
+    from scipy.stats import uniform
+    import pocomc_amd as pc
+    from pocomc_amd import mcmc as pmcmc
+    from pocomc_amd.geometry import Geometry
+    import torch
+    D, N = 8, 700
+    prior = pc.Prior([uniform(-5, 10)] * D)
+    rng = np.random.default_rng(2)
+    scaler = pc.Reparameterize(D, bounds=prior.bounds)
+    scaler.fit(prior.rvs(2000))
+    x = rng.uniform(-4, 4, size=(N, D))
+    u = scaler.forward(x)
+    like = lambda xx: (-0.5 * np.sum(xx ** 2, axis=1), None)
+    flow = pc.Flow(D, "maf3", seed=0)
+    geo = Geometry()
+    geo.fit(flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64))
+    geo.normal_cov = np.cov(u.T)
+    res = []
+    for k in (0, 2):
+        state = dict(u=u.copy(), x=x.copy(), logdetj=scaler.inverse(u)[1], logl=like(x)[0], logp=prior.logpdf(x),
+                     beta=0.5, blobs=None)
+        funcs = dict(loglike=like, logprior=prior.logpdf, scaler=scaler, flow=flow, theta_geometry=geo, u_geometry=geo)
+        opts = dict(n_max=8, n_steps=10 ** 6, progress_bar=None, proposal_scale=2.38 / D ** 0.5, seed=4, x_order="F",
+                    lanes=2, host_prefetch=k)
+        res.append(pmcmc.preconditioned_pcn(state, funcs, opts))
+    a, b = res
+    assert a["calls"] == b["calls"] and a["accept"] == b["accept"]
+    for key in ("u", "x", "logl", "logp", "logdetj"):
+        assert np.array_equal(a[key], b[key]), key
+
+
 def test_host_threads_give_the_same_call():
     """option host_threads: the likelihood is evaluated on row chunks by several threads (numpy releases the GIL);
     rows are independent, so the kernel call is bit for bit the single-threaded one."""
