@@ -904,6 +904,7 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
                  and replay is None and all(option_dict.get(k, True) for k in ("host_direct", "spin_wait")))
     if lanes > 1 or (sharded and want_pipe):
         eng = LanedEngine(kind, n_walkers, n_dim, flow, scaler, lanes=lanes, group=group,
+                          first_fraction=option_dict.get("first_lane"),
                           shard_offset=option_dict.get("shard_offset", 0), seed=seed, x_order=x_order,
                           streams=not want_pipe)
         tune = eng.configure
