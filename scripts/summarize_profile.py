@@ -74,11 +74,15 @@ for key in sorted(pmc, key=lambda k: -len(pmc[k].get("SQ_WAVE_CYCLES", []))):
             # fused proposal + inverse at D = 32 (bench default): theta (f32) in; theta' (f64), u' (f32), ladj, two
             # quadratic forms out; the weight sections the register-chain sweeps read, once
             io = {"walker_io": walkers * (4 * D_ + 8 * D_ + 4 * D_ + 4 + 16), "weights_once": 3 * 60400 * 4}
-            io["total"] = io["walker_io"] + io["weights_once"]
+            if ", 8>" in key[0] or ", 16>" in key[0] or ", 4>" in key[0]:
+                # the fused launch of the step also applies the scaler + prior (epilogue): u', x' (f64) to device memory,
+                # x' column-major + finite + logp' to pinned host memory, logdetj / finite / logp' on the device
+                io["scaler_epilogue_out"] = walkers * (3 * 8 * D_ + 8 + 4 + 8 + 4 + 8)
+            io["total"] = sum(io.values())
         cand = {"kernel": key[0], "grid": key[1], "launches": len(pmc[key]["FETCH_SIZE"]),
                 "walkers_per_launch": walkers, "algorithmic_bytes": io,
                 "note": "FETCH_SIZE / WRITE_SIZE are per-launch means of separate --pmc passes; the weight image is pulled "
-                        "once per XCD L2 (8 x), walker data is touched once",
+                        "once per XCD L2 (8 x), walker data is touched once; WRITE_SIZE includes the epilogue's stores to pinned host memory",
                 "FETCH_SIZE_KB": m["FETCH_SIZE"], "WRITE_SIZE_KB": m["WRITE_SIZE"],
                 "hbm_bytes_per_launch": (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0,
                 "correction": "2x FETCH_SIZE (gfx950), separate --pmc passes",
