@@ -13,6 +13,8 @@
 
 #include <stdlib.h>
 #include "maf_chain_rot.h"
+
+#define DG_WORDS(m) ((m)->nT * 4 + 4)      // LDS words of the tiles' degree table (4 per tile, padded)
 #include "propose_body.h"
 
 #define PX4 2
@@ -136,6 +138,11 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
         const int n4 = (2 * Hp * 16) >> 2;
         for (int e = lane; e < n4; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // the tiles' degree words in LDS: read from global memory in the middle of a tile they cost the chain a whole L2
+    // round trip (the wait also covers the fragment prefetches issued just before)
+    int* DGT = reinterpret_cast<int*>(SO + MAXO * 256);
+    for (int e = lane; e < nT * 4; e += 64) DGT[e] = quad_meta[e];
+    __syncthreads();
     float ladj = 0.0f;
 
     for (int t = T - 1; t >= 0; --t) {
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
             pb2 = bload4(rs, vo_q, oB2 + 64 * TT_);                                                            \
         }
         PREFETCH4(0);
-        int4 dg_next = *reinterpret_cast<const int4*>(quad_meta);
+        int4 dg_next = *reinterpret_cast<const int4*>(DGT);
 
         for (int Tt = 0; Tt < nT; ++Tt) {
             int4 dg = dg_next;
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
             }
             if (Tt + 1 < nT) {
                 PREFETCH4(Tt + 1);
-                dg_next = *reinterpret_cast<const int4*>(quad_meta + 4 * (Tt + 1));
+                dg_next = *reinterpret_cast<const int4*>(DGT + 4 * (Tt + 1));
             }
             if (!(ABL & 8))
             switch (pat) {
@@ -372,7 +379,7 @@ int pmc_launch_inverse_tri4(const pmc_maf_t* m, const float* z, float* x, float*
     }
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;         // 32-bit buffer offsets
     const int maxo = m->nOT <= 4 ? 4 : 8;
-    const size_t lds = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
+    const size_t lds = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256 + DG_WORDS(m)) * sizeof(float);
     if (m->nOT > 8 || lds > 160 * 1024) {
         // wide flows (D > 64): lane-per-walker sweep; -1 if that does not cover the flow either (caller falls back)
         return variant < 0 ? pmc_launch_tri6(nullptr, m, z, x, ladj, n, stream) : -1;
@@ -403,7 +410,7 @@ int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* 
     if (m->n_out != 2 || !m->tri_ok || m->nOT > 8 || m->D > 64) return -1;
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
     const int maxo = m->nOT <= 4 ? 4 : 8;
-    const size_t lds = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
+    const size_t lds = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256 + DG_WORDS(m)) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     ProposeArgs pa{kind, cur32, mu, inv_cov, chol, nu, sigma, cn_a, *rng, prop64, quad, quad_prop, adapt};
     // the scaler as the sweep's epilogue: its scratch aliases the two activation arrays of the walker set
@@ -515,6 +522,13 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
             for (int e = lane; e < n4; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    if (pa.prof && lane == 0 && blockIdx.x < 64)         // (measurement only: which SIMD / CU every wavefront landed on)
+        pa.prof[(size_t)T * nT * 8 + blockIdx.x * 2 + wv] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    // the tiles' degree words in LDS (see maf_inverse_tri4_kernel); filled by the burst wave, visible after the first
+    // __syncthreads() of the transform loop
+    int* DGT = reinterpret_cast<int*>(smem + (size_t)TRI5_NC * set_floats);
+    if (wv == TRI5_NC)
+        for (int e = lane; e < nT * 4; e += 64) DGT[e] = quad_meta[e];
     float ladj = 0.0f;
 
     for (int t = T - 1; t >= 0; --t) {
@@ -567,7 +581,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                 if ((TT) > 0) { L1 = bload4(rs, vo_lane, oF1 + ((TT) * nT + (TT) - 1) * 1024);                    \
                                 L2 = bload4(rs, vo_lane, oF2 + ((TT) * nT + (TT) - 1) * 1024); }                  \
                 Bb1 = bload4(rs, vo_q, oB1 + 64 * (TT)); Bb2 = bload4(rs, vo_q, oB2 + 64 * (TT));                \
-                DGW = *reinterpret_cast<const int4*>(quad_meta + 4 * (TT));                                      \
+                DGW = *reinterpret_cast<const int4*>(DGT + 4 * (TT));                                            \
             }
 #define HELPER_TILE(TT, P1, P2, L1, L2, Bb1, Bb2, DGW, NP1, NP2, NL1, NL2, NB1, NB2, NDG)                         \
             {                                                                                                    \
@@ -669,7 +683,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                 pb0 = bload4(rs, vo_q, oB0 + 64 * TT_);                                                        \
             }
             PREFETCH5(0);
-            int4 dg_next = *reinterpret_cast<const int4*>(quad_meta);
+            int4 dg_next = *reinterpret_cast<const int4*>(DGT);
             for (int Tt = 0; Tt < nT; ++Tt) {
                 int4 dg = dg_next;
                 dg.x &= 0xffff; dg.y &= 0xffff; dg.z &= 0xffff; dg.w &= 0xffff;
@@ -684,6 +698,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                 }
                 long long* pf = (pa.prof && blockIdx.x == 0) ? pa.prof + ((size_t)(T - 1 - t) * nT + Tt) * 8 : nullptr;
                 if (pf && lane == 0) pf[0] = clock64();
+                if (!(TRI5_ABL & 16) || Tt == 0) {     // (ablation 16: the chain fragments of the transform's first tile for all)
                 const int soD1 = oF1 + (Tt * nT + Tt) * 1024, soD2 = oF2 + (Tt * nT + Tt) * 1024;
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
@@ -710,6 +725,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                     for (int jt = i + 1; jt < 4; ++jt)
                         s.w0r[i][jt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
                             rs, q << 2, oW0 + (gg * Hp + 16 * Tt + 4 * jt) * 4, 0));
+                }
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) s.yv[i] = Y[lidx(s.g[i] < D ? s.g[i] : 0, p)];
@@ -763,9 +779,10 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                     CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
 #undef CASE
                 }
+                if (pf && lane == 0) pf[7] = clock64();
                 if (Tt + 1 < nT) {
                     PREFETCH5(Tt + 1);
-                    dg_next = *reinterpret_cast<const int4*>(quad_meta + 4 * (Tt + 1));
+                    dg_next = *reinterpret_cast<const int4*>(DGT + 4 * (Tt + 1));
                 }
                 switch (pat) {
 #define CASE(P) case P: chain_group_rot<P, 1, 4, MAXO, TRI5_ABL>(s, H0, H1, X, Tt, D, nOT, q, p, ladj); break;
@@ -804,7 +821,7 @@ static bool tri5_wanted(const pmc_maf_t* m, int64_t n) {
     const int mode = tri5_mode();
     if (mode >= 0) return mode != 0;
     const int maxo = m->nOT <= 4 ? 4 : 8;
-    const size_t lds1 = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);   // one walker set
+    const size_t lds1 = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256 + DG_WORDS(m)) * sizeof(float);   // one walker set
     if (lds1 * TRI5_NC > 160 * 1024) return false;
     // rounds a launch needs: workgroups resident per CU are bounded by the LDS (both kernels keep one set's tiles
     // per chain wave) and by the SIMDs (one 256-register wave each: 4 lone waves or 4 / (TRI5_NC + 1) groups).
@@ -831,7 +848,7 @@ static int launch_tri5(const ProposeArgs* pa, const pmc_maf_t* m, const float* z
     if (m->n_out != 2 || !m->tri_ok || m->nOT > 8 || m->D > 64) return -1;
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
     const int maxo = m->nOT <= 4 ? 4 : 8;
-    const size_t lds = (size_t)TRI5_NC * (2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256) * sizeof(float);
+    const size_t lds = ((size_t)TRI5_NC * (2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256) + DG_WORDS(m)) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     const ProposeArgs none{};
     const int64_t nsets = (n + 15) / 16;

@@ -15,7 +15,7 @@ fn.argtypes = [C.POINTER(_lib.pmc_maf_t), C.c_void_p, C.c_void_p, C.c_void_p, C.
 z = torch.randn(n, D, device="cuda")
 x = torch.empty_like(z); l = torch.empty(n, device="cuda")
 nT, T = f.spec.nT, f.spec.n_transforms
-prof = torch.zeros(T * nT, 8, dtype=torch.int64, device="cuda")
+prof = torch.zeros(T * nT + 16, 8, dtype=torch.int64, device="cuda")
 for _ in range(3):
     _lib.check(fn(C.byref(f._desc), _lib.ptr(z), _lib.ptr(x), _lib.ptr(l), n, _lib.ptr(prof), _lib.stream_handle()))
 torch.cuda.synchronize()
@@ -23,10 +23,15 @@ p = prof.cpu().numpy().astype(np.int64)
 t0 = p[0, 0]
 print(f"D={D} {name} n={n}: chain wave, cycles per tile: fragment loads issued | layer-0 burst + staging | wait B | staging reads | chain groups | wait A")
 tot = np.zeros(6)
+hw = p[T * nT:].reshape(-1)[:128].reshape(64, 2)
+print('HW_ID (simd = bits 5:4, cu = bits 11:8, se = 15:13) of the chain / burst wave of workgroups 0..11:')
+print([(f'cu{(int(a)>>8)&15}.se{(int(a)>>13)&7} simd {(int(a)>>4)&3}/{(int(b)>>4)&3}' + ('' if ((int(a)>>8)&0xff) == ((int(b)>>8)&0xff) else ' (other CU?)')) for a, b in hw[:12]])
+print('same SIMD for both waves:', int(sum(((int(a)>>4)&3) == ((int(b)>>4)&3) for a, b in hw)), 'of 64')
+p = p[:T * nT]
 for i in range(T * nT):
     if p[i, 0] == 0:
         continue
     d = np.diff(p[i, :7])
     tot += d
-    print(f"{i:3d} start {p[i,0]-t0:7d} | " + " ".join(f"{v:6d}" for v in d))
+    print(f"{i:3d} start {p[i,0]-t0:7d} | " + " ".join(f"{v:6d}" for v in d) + f"   (first group {p[i,7]-p[i,4]:5d})")
 print("sum:", " ".join(f"{int(v):7d}" for v in tot), " total", int(p[:, 6].max() - t0))
