@@ -30,8 +30,10 @@ struct ChainRot {
     int g[4];
 };
 
-// ABL (timing experiments only, results are wrong when != 0): 1 = skip the right-looking output updates,
-// 2 = skip the non-critical hidden updates of later quads, 64 = skip the x update's transcendental
+// ABL: 1 = no right-looking output updates -- the caller supplies the output partials of the previous tiles itself (the
+// two-wave sweep: its burst wave multiplies them left-looking against the h2 tiles this function then stores in H2);
+// timing experiments only (results are wrong): 2 = skip the non-critical hidden updates of later quads, 64 = skip the
+// x update's transcendental
 //
 // Groups I .. END-1 of the tile, one after the other, as STRAIGHT-LINE code: a conditional update of an
 // accumulator array costs a register copy per element on every path (SSA phi), so padding groups
@@ -40,7 +42,7 @@ struct ChainRot {
 // fragments of output tiles whose ranks are all below g are exact zeros).
 template <int PAT, int I, int END, int MAXO, int ABL = 0>
 __device__ __forceinline__ void chain_group_rot(ChainRot<MAXO>& s, float* H0, float* H1, float* X,
-                                                int Tt, int D, int nOT, int q, int p, float& ladj) {
+                                                int Tt, int D, int nOT, int q, int p, float& ladj, float* H2 = nullptr) {
     constexpr int NG = pat_ngroups(PAT);
     if constexpr (I < NG && I < END) {
         constexpr int c0 = pat_start(PAT, I), c1 = pat_end(PAT, I);
@@ -61,7 +63,10 @@ __device__ __forceinline__ void chain_group_rot(ChainRot<MAXO>& s, float* H0, fl
 #pragma unroll
             for (int c = c0; c <= c1; ++c) s.a2[jt] = MFMA(comp(s.wd2[jt], c), h1[c], s.a2[jt]);
 #pragma unroll
-        for (int c = c0; c <= c1; ++c) h2[c] = fmaxf((s.a2[c][0] + s.p2[c]) + h1[c], 0.0f);   // (used from registers only)
+        for (int c = c0; c <= c1; ++c) {
+            h2[c] = fmaxf((s.a2[c][0] + s.p2[c]) + h1[c], 0.0f);
+            if (ABL & 1) H2[hw + c] = h2[c];             // (the lone-wave sweep uses h2 from registers only)
+        }
         constexpr int slot = I >> 1;
 #pragma unroll
         for (int c = c0; c <= c1; ++c) s.outR[slot] = MFMA(comp(s.wo[slot], c), h2[c], s.outR[slot]);
@@ -83,7 +88,7 @@ __device__ __forceinline__ void chain_group_rot(ChainRot<MAXO>& s, float* H0, fl
 #pragma unroll
                 for (int c = c0; c <= c1; ++c) s.oN[O] = MFMA(comp(s.f3n[O], c), h2[c], s.oN[O]);
         }
-        chain_group_rot<PAT, I + 1, END, MAXO, ABL>(s, H0, H1, X, Tt, D, nOT, q, p, ladj);
+        chain_group_rot<PAT, I + 1, END, MAXO, ABL>(s, H0, H1, X, Tt, D, nOT, q, p, ladj, H2);
     }
 }
 

@@ -475,7 +475,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, p = lane & 15;
     const int D = m.D, Dp = m.Dp, Hp = m.Hp, T = m.T, nT = m.nT, nXT = m.nXT, nOT = m.nOT;
-    const int set_floats = 2 * Dp * 16 + 2 * Hp * 16 + 3 * 256 + MAXO * 256;   // LDS of one walker set
+    const int set_floats = 2 * Dp * 16 + 3 * Hp * 16 + 3 * 256 + MAXO * 256;   // LDS of one walker set
     const int cs = wv < TRI5_NC ? wv : 0;                                        // this chain wave's set in the workgroup
     const int64_t set = (int64_t)blockIdx.x * TRI5_NC + cs;
     const int64_t row0 = set * 16;
@@ -483,7 +483,8 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     float* X = Y + Dp * 16;
     float* H0 = X + Dp * 16;
     float* H1 = H0 + Hp * 16;
-    float* S = H1 + Hp * 16;                   // staging: [3 layers][16 p][16 rows] then [MAXO][16 p][16 rows]
+    float* H2 = H1 + Hp * 16;                  // h2 of the finished tiles: the burst wave's output partials read it
+    float* S = H2 + Hp * 16;                   // staging: [3 layers][16 p][16 rows] then [MAXO][16 p][16 rows]
     float* SO = S + 3 * 256;
     const int* feat_of_rank = m.meta + 8;
     const int* rank_of_feat = m.meta + 8 + T * D;
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     } else {
         for (int c = 0; c < TRI5_NC; ++c) {    // padding slots of the activations are read by the bursts: zero once
             float4* z4 = reinterpret_cast<float4*>(smem + (size_t)c * set_floats + 2 * Dp * 16);
-            const int n4 = (2 * Hp * 16) >> 2;
+            const int n4 = (3 * Hp * 16) >> 2;
             for (int e = lane; e < n4; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
@@ -548,6 +549,12 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
             float4 lA1, lA2, lB1, lB2, bA1, bA2, bB1, bB2;
             int4 dA, dB;
             bool natural_end = true;
+            f32x4 oN[MAXO];                                // output-layer partials of the walker set (right-looking)
+#pragma unroll
+            for (int O = 0; O < MAXO; ++O) {
+                const float4 bb = (O < nOT) ? bload4(rs, vo_q, oB3 + 64 * O) : make_float4(0.f, 0.f, 0.f, 0.f);
+                oN[O][0] = bb.x; oN[O][1] = bb.y; oN[O][2] = bb.z; oN[O][3] = bb.w;
+            }
 #define SW_PREFETCH(TT, P1, P2)                                                                                  \
             switch ((TT) < PK4 ? (TT) : PK4) {                                                                    \
                 case 1: prefetch_tile<1>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
@@ -614,10 +621,18 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                         }                                                                                        \
                     }                                                                                            \
                 }                                                                                                \
-                if (Tt > 0) lds_bar();                                    /* A(Tt-1): tile Tt-1 is final now */   \
+                /* the output layer's right-looking updates (what the lone wave does after every group) happen HERE,   */ \
+                /* once per tile: oN[O] += F3[O][Tt-1] . h2[Tt-1] for every output tile as soon as tile Tt-1 is final --   */ \
+                /* the same additions in the same order (bias, tile after tile, four k chunks); fragments requested now   */ \
                 int4 dg = DGW;                                                                                   \
                 dg.x &= 0xffff; dg.y &= 0xffff; dg.z &= 0xffff; dg.w &= 0xffff;                                  \
-                if (dg.x >= D && dg.y >= D && dg.z >= D && dg.w >= D) { natural_end = false; break; }           \
+                const bool pad_ = dg.x >= D && dg.y >= D && dg.z >= D && dg.w >= D;                              \
+                float4 f3p[MAXO];                                                                                \
+                _Pragma("unroll") for (int O = 0; O < MAXO; ++O)                                                 \
+                    f3p[O] = (Tt > 0 && O < nOT) ? bload4(rs, vo_lane, oF3 + (O * nT + Tt - 1) * 1024)           \
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);                              \
+                if (Tt > 0) lds_bar();                                    /* A(Tt-1): tile Tt-1 is final now */   \
+                if (pad_) { natural_end = false; break; }                                                       \
                 _Pragma("unroll") for (int c = 0; c < TRI5_NC; ++c) {                                            \
                     float* base_ = smem + (size_t)c * set_floats;                                                \
                     if (Tt > 0) {                                                                                \
@@ -639,9 +654,18 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                             a1[c] = MFMA(L1.w, b1.w, a1[c]); a2[c] = MFMA(L2.w, b2.w, a2[c]);                    \
                         }                                                                                        \
                     }                                                                                            \
-                    float* sp = base_ + 2 * Dp * 16 + 2 * Hp * 16 + (p << 4) + (q << 2);                         \
+                    float* sp = base_ + 2 * Dp * 16 + 3 * Hp * 16 + (p << 4) + (q << 2);                         \
                     *reinterpret_cast<float4*>(sp + 256) = make_float4(a1[c][0], a1[c][1], a1[c][2], a1[c][3]);  \
                     *reinterpret_cast<float4*>(sp + 512) = make_float4(a2[c][0], a2[c][1], a2[c][2], a2[c][3]);  \
+                    if (Tt > 0) {                                                                                \
+                        const float4 b = *reinterpret_cast<const float4*>(base_ + 2 * Dp * 16 + 2 * Hp * 16 + ((Tt - 1) << 8) + (lane << 2)); \
+                        _Pragma("unroll") for (int O = 0; O < MAXO; ++O) oN[O] = MFMA(f3p[O].x, b.x, oN[O]);      \
+                        _Pragma("unroll") for (int O = 0; O < MAXO; ++O) oN[O] = MFMA(f3p[O].y, b.y, oN[O]);      \
+                        _Pragma("unroll") for (int O = 0; O < MAXO; ++O) oN[O] = MFMA(f3p[O].z, b.z, oN[O]);      \
+                        _Pragma("unroll") for (int O = 0; O < MAXO; ++O) oN[O] = MFMA(f3p[O].w, b.w, oN[O]);      \
+                    }                                                                                            \
+                    _Pragma("unroll") for (int O = 0; O < MAXO; ++O)                                             \
+                        *reinterpret_cast<float4*>(sp + 768 + O * 256) = make_float4(oN[O][0], oN[O][1], oN[O][2], oN[O][3]); \
                 }                                                                                                \
                 lds_bar();                                                /* B(Tt) */                            \
             }
@@ -661,11 +685,6 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
         } else {
             // ------------------------------------------------------------------ CHAIN waves
             ChainRot<MAXO> s;
-#pragma unroll
-            for (int O = 0; O < MAXO; ++O) {
-                const float4 bb = (O < nOT) ? bload4(rs, vo_q, oB3 + 64 * O) : make_float4(0.f, 0.f, 0.f, 0.f);
-                s.oN[O][0] = bb.x; s.oN[O][1] = bb.y; s.oN[O][2] = bb.z; s.oN[O][3] = bb.w;
-            }
             {
                 const float* b3 = blk + (oB3 >> 2);
                 const float shift = b3[0], ls = fast_ls(b3[1]);
@@ -716,9 +735,6 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                     s.wo[sl] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
-                for (int O = 0; O < MAXO; ++O)
-                    s.f3n[O] = (O < nOT) ? bload4(rs, vo_lane, oF3 + (O * nT + Tt) * 1024) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const int gg = s.g[i] < D ? s.g[i] : 0;
 #pragma unroll
@@ -750,10 +766,6 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                 {
                     float* sp = S + (p << 4) + (q << 2);
                     *reinterpret_cast<float4*>(sp) = make_float4(a0[0], a0[1], a0[2], a0[3]);
-                    float* so = SO + (p << 4) + (q << 2);
-#pragma unroll
-                    for (int O = 0; O < MAXO; ++O)
-                        *reinterpret_cast<float4*>(so + O * 256) = make_float4(s.oN[O][0], s.oN[O][1], s.oN[O][2], s.oN[O][3]);
                 }
                 if (pf && lane == 0) pf[2] = clock64();
                 lds_bar();                                            // B(Tt): layers 1/2 of this tile are staged
@@ -775,7 +787,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                 }
                 if (pf && lane == 0) pf[4] = clock64();
                 switch (pat) {
-#define CASE(P) case P: chain_group_rot<P, 0, 1, MAXO, TRI5_ABL>(s, H0, H1, X, Tt, D, nOT, q, p, ladj); break;
+#define CASE(P) case P: chain_group_rot<P, 0, 1, MAXO, TRI5_ABL | 1>(s, H0, H1, X, Tt, D, nOT, q, p, ladj, H2); break;
                     CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
 #undef CASE
                 }
@@ -785,7 +797,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                     dg_next = *reinterpret_cast<const int4*>(DGT + 4 * (Tt + 1));
                 }
                 switch (pat) {
-#define CASE(P) case P: chain_group_rot<P, 1, 4, MAXO, TRI5_ABL>(s, H0, H1, X, Tt, D, nOT, q, p, ladj); break;
+#define CASE(P) case P: chain_group_rot<P, 1, 4, MAXO, TRI5_ABL | 1>(s, H0, H1, X, Tt, D, nOT, q, p, ladj, H2); break;
                     CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
 #undef CASE
                     default: break;
@@ -822,11 +834,12 @@ static bool tri5_wanted(const pmc_maf_t* m, int64_t n) {
     if (mode >= 0) return mode != 0;
     const int maxo = m->nOT <= 4 ? 4 : 8;
     const size_t lds1 = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256 + DG_WORDS(m)) * sizeof(float);   // one walker set
-    if (lds1 * TRI5_NC > 160 * 1024) return false;
+    const size_t lds5 = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256 + DG_WORDS(m)) * sizeof(float);   // (two-wave sweep)
+    if (lds5 * TRI5_NC > 160 * 1024) return false;
     // rounds a launch needs: workgroups resident per CU are bounded by the LDS (both kernels keep one set's tiles
     // per chain wave) and by the SIMDs (one 256-register wave each: 4 lone waves or 4 / (TRI5_NC + 1) groups).
     // The two-wave kernel takes ~0.75 of the lone wave's time per round.
-    const int64_t by_lds4 = (int64_t)((160 * 1024) / lds1), by_lds5 = (int64_t)((160 * 1024) / (lds1 * TRI5_NC));
+    const int64_t by_lds4 = (int64_t)((160 * 1024) / lds1), by_lds5 = (int64_t)((160 * 1024) / (lds5 * TRI5_NC));
     const int64_t res4 = 256 * (by_lds4 < 4 ? by_lds4 : 4);
     const int64_t wg5 = by_lds5 < 4 / (TRI5_NC + 1) ? by_lds5 : 4 / (TRI5_NC + 1);
     const int64_t res5 = 256 * TRI5_NC * wg5;
@@ -848,7 +861,7 @@ static int launch_tri5(const ProposeArgs* pa, const pmc_maf_t* m, const float* z
     if (m->n_out != 2 || !m->tri_ok || m->nOT > 8 || m->D > 64) return -1;
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
     const int maxo = m->nOT <= 4 ? 4 : 8;
-    const size_t lds = ((size_t)TRI5_NC * (2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256) + DG_WORDS(m)) * sizeof(float);
+    const size_t lds = ((size_t)TRI5_NC * (2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256) + DG_WORDS(m)) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     const ProposeArgs none{};
     const int64_t nsets = (n + 15) / 16;
