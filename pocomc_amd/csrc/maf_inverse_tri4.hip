@@ -15,6 +15,8 @@
 #include "maf_chain_rot.h"
 
 #define DG_WORDS(m) ((m)->nT * 4 + 4)      // LDS words of the tiles' degree table (4 per tile, padded)
+// + the two-wave sweep's permutation / rank-0 tables and its second x array (with alignment slack)
+#define TRI5_TABLE_WORDS(m) (((DG_WORDS(m) + (m)->T * (m)->Dp + 2 * (m)->T + 3) & ~3) + (m)->Dp * 16)
 #include "propose_body.h"
 
 #define PX4 2
@@ -480,8 +482,8 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     const int64_t set = (int64_t)blockIdx.x * TRI5_NC + cs;
     const int64_t row0 = set * 16;
     float* Y = smem + (size_t)cs * set_floats;
-    float* X = Y + Dp * 16;
-    float* H0 = X + Dp * 16;
+    float* XA = Y + Dp * 16;
+    float* H0 = XA + Dp * 16;
     float* H1 = H0 + Hp * 16;
     float* H2 = H1 + Hp * 16;                  // h2 of the finished tiles: the burst wave's output partials read it
     float* S = H2 + Hp * 16;                   // staging: [3 layers][16 p][16 rows] then [MAXO][16 p][16 rows]
@@ -530,18 +532,43 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     int* DGT = reinterpret_cast<int*>(smem + (size_t)TRI5_NC * set_floats);
     if (wv == TRI5_NC)
         for (int e = lane; e < nT * 4; e += 64) DGT[e] = quad_meta[e];
+    // between two transforms the chain wave re-ranks its x and starts the next sweep with rank 0: the indices and the two
+    // constants it needs come from LDS tables filled once (global loads there are dependent round trips on the
+    // critical path) -- PRM[t][r]: where rank r of transform t goes (rank of transform t - 1, or the feature for t = 0),
+    // B3T[t]: (shift, raw log-scale) of rank 0.  x alternates between two arrays; the burst wave zeroes the idle one.
+    int* PRM = DGT + DG_WORDS(&m);
+    float* B3T = reinterpret_cast<float*>(PRM + T * Dp);
+    float* XB = reinterpret_cast<float*>(DGT + ((DG_WORDS(&m) + T * Dp + 2 * T + 3) & ~3));      // (16-byte aligned)
+    for (int e = threadIdx.x; e < T * D; e += 64 * (TRI5_NC + 1)) {
+        const int tt = e / D, r = e - tt * D;
+        const int feat = feat_of_rank[tt * D + r];
+        PRM[tt * Dp + r] = tt > 0 ? rank_of_feat[(tt - 1) * D + feat] : feat;
+    }
+    for (int tt = threadIdx.x; tt < T; tt += 64 * (TRI5_NC + 1)) {
+        const float* b3 = m.packed + (size_t)tt * m.pk_per_transform + (oB3 >> 2);
+        B3T[2 * tt] = b3[0];
+        B3T[2 * tt + 1] = b3[1];
+    }
+    for (int e = threadIdx.x; e < (Dp * 16) >> 2; e += 64 * (TRI5_NC + 1)) {      // both x arrays start zeroed
+        reinterpret_cast<float4*>(XA)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(XB)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float ladj = 0.0f;
+    int xsel = 0;
+    __syncthreads();
 
     for (int t = T - 1; t >= 0; --t) {
         const float* blk = m.packed + (size_t)t * m.pk_per_transform;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)blk, 0, blk_bytes, 0x00020000);
-        if (wv < TRI5_NC) {
-            float4* z4 = reinterpret_cast<float4*>(X);
-            for (int e = lane; e < (Dp * 16) >> 2; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        __syncthreads();
+        float* X = xsel ? XB : XA;                     // zero on entry
+        float* Xidle = xsel ? XA : XB;                 // the previous transform's x: re-ranked already, zeroed below
+        xsel ^= 1;
 
         if (wv == TRI5_NC) {
+            if (t != T - 1) {
+                float4* z4 = reinterpret_cast<float4*>(Xidle);
+                for (int e = lane; e < (Dp * 16) >> 2; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             // ------------------------------------------------------------------ BURST wave
             // Two fragment sets, used alternately: while tile Tt is being prepared from one set, the fragments
             // of tile Tt+1 are already on their way into the other (nothing else hides their L2 latency here).
@@ -686,8 +713,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
             // ------------------------------------------------------------------ CHAIN waves
             ChainRot<MAXO> s;
             {
-                const float* b3 = blk + (oB3 >> 2);
-                const float shift = b3[0], ls = fast_ls(b3[1]);
+                const float shift = B3T[2 * t], ls = fast_ls(B3T[2 * t + 1]);
                 const float xv = (Y[lidx(0, p)] - shift) * fast_exp_neg(ls);
                 ladj -= ls;
                 if (q == 0) X[lidx(0, p)] = xv;
@@ -808,13 +834,23 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
             }
 #undef PREFETCH5
         }
-        __syncthreads();
         const bool last = (t == 0);
-        if (wv < TRI5_NC)
-            rerank_or_store(X, Y, out, row0, n, D, Dp, feat_of_rank + t * D,
-                            last ? nullptr : rank_of_feat + (t - 1) * D, lane);
+        if (wv < TRI5_NC) {
+            const int* prm = PRM + t * Dp;
+            for (int e = lane; e < D * 16; e += 64) {
+                const int r = e >> 4, pp = e & 15;
+                const float v = X[lidx(r, pp)];
+                const int tgt = prm[r];
+                if (!last) Y[lidx(tgt, pp)] = v;
+                else if (row0 + pp < n) out[(row0 + pp) * D + tgt] = v;
+            }
+            if (!last)
+                for (int e = lane; e < (Dp - D) * 16; e += 64) Y[lidx(D + (e >> 4), e & 15)] = 0.0f;
+        }
         __syncthreads();
+        if (last) xsel ^= 1;                           // (xsel names the array of the LAST transform again: the epilogue reads it)
     }
+    float* X = xsel ? XB : XA;
     if (wv < TRI5_NC && ladj_out && lane < 16 && row0 + p < n) ladj_out[row0 + p] = ladj;
     if constexpr (FM > 0 && TRI5_NC == 1) {
         if (pa.epi.on)                                 // both wavefronts: 16 walkers x D elements over 128 threads
@@ -834,7 +870,7 @@ static bool tri5_wanted(const pmc_maf_t* m, int64_t n) {
     if (mode >= 0) return mode != 0;
     const int maxo = m->nOT <= 4 ? 4 : 8;
     const size_t lds1 = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256 + DG_WORDS(m)) * sizeof(float);   // one walker set
-    const size_t lds5 = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256 + DG_WORDS(m)) * sizeof(float);   // (two-wave sweep)
+    const size_t lds5 = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256 + TRI5_TABLE_WORDS(m)) * sizeof(float);   // (two-wave sweep)
     if (lds5 * TRI5_NC > 160 * 1024) return false;
     // rounds a launch needs: workgroups resident per CU are bounded by the LDS (both kernels keep one set's tiles
     // per chain wave) and by the SIMDs (one 256-register wave each: 4 lone waves or 4 / (TRI5_NC + 1) groups).
@@ -861,7 +897,7 @@ static int launch_tri5(const ProposeArgs* pa, const pmc_maf_t* m, const float* z
     if (m->n_out != 2 || !m->tri_ok || m->nOT > 8 || m->D > 64) return -1;
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
     const int maxo = m->nOT <= 4 ? 4 : 8;
-    const size_t lds = ((size_t)TRI5_NC * (2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256) + DG_WORDS(m)) * sizeof(float);
+    const size_t lds = ((size_t)TRI5_NC * (2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256) + TRI5_TABLE_WORDS(m)) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     const ProposeArgs none{};
     const int64_t nsets = (n + 15) / 16;
