@@ -208,3 +208,34 @@ def test_nsf_inverse_matches_oracle(D, T, n):
     z2, l2 = f.forward(x)
     close(z2.numpy(), z, 5e-5)
     close(l2.numpy(), -l.numpy(), 1e-4)
+
+
+def test_sweeps_on_random_flow_shapes():
+    """Random (D <= 64, T, hidden, n): the lone-wave and the two-wave sweep agree bit for bit and follow the D-pass
+    inverse on the device (``scripts/fuzz_inverse.py`` is the long version)."""
+    from pocomc_amd import Flow
+    rng = np.random.default_rng(7)
+    done = 0
+    for case in range(40):
+        D = int(rng.integers(2, 65))
+        T = int(rng.integers(1, 8))
+        H = max(int(rng.choice([max(D - 1, 4), D + 3, 2 * D, 3 * D + 1, 128, 4 * (D - 1) + 5])), D - 1)
+        n = int(rng.choice([1, 15, 16, 17, 100, 1000, 5000]))
+        spec = MAFSpec(D, T, hidden=H)
+        if not spec.tri_ok:
+            continue
+        f = Flow(D, spec, seed=case)
+        f.set_params(cases.flow_params(spec, case))
+        z = torch.randn(n, D, generator=torch.Generator().manual_seed(case)) * 1.1
+        out = {}
+        for algo in (2, 6, 7):
+            f.inverse_algo = algo
+            out[algo] = [t.numpy() for t in f.inverse(z)]
+        np.testing.assert_array_equal(out[6][0], out[7][0])
+        np.testing.assert_array_equal(out[6][1], out[7][1])
+        fin = np.isfinite(out[2][0]).all(axis=1) & np.isfinite(out[7][0]).all(axis=1)
+        if fin.any():
+            sc = np.maximum(1.0, np.abs(out[2][0][fin]).max(axis=1, keepdims=True))
+            assert (np.abs(out[7][0][fin] - out[2][0][fin]) / sc).max() < 5e-5, (D, T, H, n)
+        done += 1
+    assert done >= 25
