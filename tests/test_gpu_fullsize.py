@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+import cases
+
 pytestmark = pytest.mark.gpu
 
 N_FULL = 10000
@@ -51,7 +53,7 @@ def test_triangular_sweep_equals_the_reference_algorithm_at_full_size(D, name):
     assert (la - lb).abs().max().item() < 2e-3
 
 
-def _engine(N, D, seed=77, offset=0, flow=None):
+def _engine(N, D, seed=77, offset=0, flow=None, like=None):
     from scipy.stats import uniform
     import pocomc_amd as pc
     from pocomc_amd.geometry import Geometry
@@ -63,7 +65,7 @@ def _engine(N, D, seed=77, offset=0, flow=None):
     x = rng.uniform(-9, 9, size=(N_FULL, D))
     u = scaler.forward(x)
     flow = flow or _flow(D, "maf3")
-    like = lambda xx: (-0.5 * np.sum((xx / 3.0) ** 2, axis=1), None)
+    like = like or (lambda xx: (-0.5 * np.sum((xx / 3.0) ** 2, axis=1), None))
     geo = Geometry()
     geo.fit(flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64))
     sl = slice(offset, offset + N)
@@ -75,12 +77,17 @@ def _engine(N, D, seed=77, offset=0, flow=None):
     return eng, prior, like, geo
 
 
-def test_metropolis_step_conserves_and_checksums_at_full_size():
-    """One tpCN step on 1e4 x 32 (config 4's per-GPU shard): every walker is afterwards either exactly its old self
-    or exactly its proposal, consistently across all state arrays; the sums the kernel reduces (what the
-    adaptation consumes, mcmc.py:152-177) equal the sums of the downloaded state."""
-    D = 32
-    eng, prior, like, geo = _engine(N_FULL, D)
+@pytest.mark.parametrize("D,name,target", [(32, "maf3", "gauss"), (50, "maf6", "bimodal")])
+def test_metropolis_step_conserves_and_checksums_at_full_size(D, name, target):
+    """One tpCN step on 1e4 x 32 (config 4's per-GPU shard) and on 1e4 x 50 with maf6 and the bimodal mixture of
+    BASELINE configs[2]: every walker is afterwards either exactly its old self or exactly its proposal, consistently
+    across all state arrays; the sums the kernel reduces (what the adaptation consumes, mcmc.py:152-177) equal the sums
+    of the downloaded state."""
+    like = None
+    if target == "bimodal":
+        bm = cases.make_bimodal(D)
+        like = lambda xx: (bm(xx), None)
+    eng, prior, like, geo = _engine(N_FULL, D, flow=_flow(D, name), like=like)
     before = eng.download()
     theta_before = eng.theta32.cpu().numpy().copy()
     eng.propose(0.35, float(geo.t_nu))
