@@ -2,7 +2,8 @@
 the middle of the timed region with its start (us, relative), duration, queue, and the idle gap of the device before it.
 
     rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o kt -- python bench.py --steps 100 --no-cpu-baseline --no-flow-bench
-    python scripts/step_timeline.py /tmp/kt [n_rows]
+    python scripts/step_timeline.py /tmp/kt [n_rows] [where]     (where: fraction of the accept launches at which the window
+                                                                  starts, default 0.2 = inside bench.py's timed region)
 """
 import csv
 import glob
@@ -14,9 +15,10 @@ path = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(path)))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:44], r.get("Queue_Id", "?"))
              for r in rows))
-# the steady state: the last third of the accept kernels
+# a window of the steady state
 acc = [i for i, e in enumerate(ev) if e[2].startswith("accept_kernel")]
-i0 = acc[len(acc) * 2 // 3]
+where = float(sys.argv[3]) if len(sys.argv) > 3 else 0.2
+i0 = acc[int(len(acc) * where)]
 t0 = ev[i0][0]
 busy_until = ev[i0][0]
 print(f"{'start_us':>9} {'dur_us':>7} {'gap_us':>7}  queue  kernel")
@@ -25,7 +27,7 @@ for s, e, name, q in ev[i0:i0 + rows_out]:
     print(f"{(s - t0) / 1e3:9.1f} {(e - s) / 1e3:7.1f} {gap if gap > 0 else 0:7.1f}  {q:>5}  {name}")
     busy_until = max(busy_until, e)
 # whole steady-state window: device busy fraction
-w = ev[i0:]
+w = ev[i0:i0 + 40 * rows_out]
 span = w[-1][1] - w[0][0]
 busy, cur_s, cur_e = 0, w[0][0], w[0][1]
 for s, e, _, _ in w[1:]:
