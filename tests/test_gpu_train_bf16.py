@@ -29,7 +29,7 @@ def make(D, T, H, seed=2, gain=1.0):
     return f, spec, flat
 
 
-@pytest.mark.parametrize("D,T,H,n,weighted", [(16, 2, 64, 100, True), (5, 3, 32, 33, False), (50, 6, 256, 300, False),
+@pytest.mark.parametrize("D,T,H,n,weighted", [(16, 2, 64, 100, True), (16, 2, 64, 1, False), (16, 2, 64, 31, True), (5, 3, 32, 33, False), (50, 6, 256, 300, False),
                                                (128, 8, 512, 512, False), (128, 8, 512, 700, True)])
 def test_bf16_loss_and_gradient_match_autograd(D, T, H, n, weighted):
     from pocomc_amd.train import loss_and_grad, _train_state
