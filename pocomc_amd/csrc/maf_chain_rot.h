@@ -31,7 +31,7 @@ struct ChainRot {
 };
 
 // ABL: 1 = no right-looking output updates -- the caller supplies the output partials of the previous tiles itself (the
-// two-wave sweep: its burst wave multiplies them left-looking against the h2 tiles this function then stores in H2);
+// two-wave sweep: its burst wave adds them once per tile from the h2 tile this function then stores in H2[tile parity]);
 // timing experiments only (results are wrong): 2 = skip the non-critical hidden updates of later quads, 64 = skip the
 // x update's transcendental
 //
@@ -65,7 +65,7 @@ __device__ __forceinline__ void chain_group_rot(ChainRot<MAXO>& s, float* H0, fl
 #pragma unroll
         for (int c = c0; c <= c1; ++c) {
             h2[c] = fmaxf((s.a2[c][0] + s.p2[c]) + h1[c], 0.0f);
-            if (ABL & 1) H2[hw + c] = h2[c];             // (the lone-wave sweep uses h2 from registers only)
+            if (ABL & 1) H2[((Tt & 1) << 8) + (q << 6) + (p << 2) + c] = h2[c];   // (two tiles deep; the lone-wave sweep uses h2 from registers only)
         }
         constexpr int slot = I >> 1;
 #pragma unroll

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, p = lane & 15;
     const int D = m.D, Dp = m.Dp, Hp = m.Hp, T = m.T, nT = m.nT, nXT = m.nXT, nOT = m.nOT;
-    const int set_floats = 2 * Dp * 16 + 3 * Hp * 16 + 3 * 256 + MAXO * 256;   // LDS of one walker set
+    const int set_floats = 2 * Dp * 16 + 2 * Hp * 16 + 2 * 256 + 3 * 256 + MAXO * 256;   // LDS of one walker set
     const int cs = wv < TRI5_NC ? wv : 0;                                        // this chain wave's set in the workgroup
     const int64_t set = (int64_t)blockIdx.x * TRI5_NC + cs;
     const int64_t row0 = set * 16;
@@ -485,8 +485,8 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     float* XA = Y + Dp * 16;
     float* H0 = XA + Dp * 16;
     float* H1 = H0 + Hp * 16;
-    float* H2 = H1 + Hp * 16;                  // h2 of the finished tiles: the burst wave's output partials read it
-    float* S = H2 + Hp * 16;                   // staging: [3 layers][16 p][16 rows] then [MAXO][16 p][16 rows]
+    float* H2 = H1 + Hp * 16;                  // h2 of the last two tiles [tile parity][256]: the burst wave's output updates read it
+    float* S = H2 + 2 * 256;                   // staging: [3 layers][16 p][16 rows] then [MAXO][16 p][16 rows]
     float* SO = S + 3 * 256;
     const int* feat_of_rank = m.meta + 8;
     const int* rank_of_feat = m.meta + 8 + T * D;
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     } else {
         for (int c = 0; c < TRI5_NC; ++c) {    // padding slots of the activations are read by the bursts: zero once
             float4* z4 = reinterpret_cast<float4*>(smem + (size_t)c * set_floats + 2 * Dp * 16);
-            const int n4 = (3 * Hp * 16) >> 2;
+            const int n4 = (2 * Hp * 16 + 2 * 256) >> 2;
             for (int e = lane; e < n4; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
@@ -681,11 +681,11 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                             a1[c] = MFMA(L1.w, b1.w, a1[c]); a2[c] = MFMA(L2.w, b2.w, a2[c]);                    \
                         }                                                                                        \
                     }                                                                                            \
-                    float* sp = base_ + 2 * Dp * 16 + 3 * Hp * 16 + (p << 4) + (q << 2);                         \
+                    float* sp = base_ + 2 * Dp * 16 + 2 * Hp * 16 + 2 * 256 + (p << 4) + (q << 2);                         \
                     *reinterpret_cast<float4*>(sp + 256) = make_float4(a1[c][0], a1[c][1], a1[c][2], a1[c][3]);  \
                     *reinterpret_cast<float4*>(sp + 512) = make_float4(a2[c][0], a2[c][1], a2[c][2], a2[c][3]);  \
                     if (Tt > 0) {                                                                                \
-                        const float4 b = *reinterpret_cast<const float4*>(base_ + 2 * Dp * 16 + 2 * Hp * 16 + ((Tt - 1) << 8) + (lane << 2)); \
+                        const float4 b = *reinterpret_cast<const float4*>(base_ + 2 * Dp * 16 + 2 * Hp * 16 + (((Tt - 1) & 1) << 8) + (lane << 2)); \
                         _Pragma("unroll") for (int O = 0; O < MAXO; ++O) oN[O] = MFMA(f3p[O].x, b.x, oN[O]);      \
                         _Pragma("unroll") for (int O = 0; O < MAXO; ++O) oN[O] = MFMA(f3p[O].y, b.y, oN[O]);      \
                         _Pragma("unroll") for (int O = 0; O < MAXO; ++O) oN[O] = MFMA(f3p[O].z, b.z, oN[O]);      \
@@ -870,7 +870,7 @@ static bool tri5_wanted(const pmc_maf_t* m, int64_t n) {
     if (mode >= 0) return mode != 0;
     const int maxo = m->nOT <= 4 ? 4 : 8;
     const size_t lds1 = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256 + DG_WORDS(m)) * sizeof(float);   // one walker set
-    const size_t lds5 = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256 + TRI5_TABLE_WORDS(m)) * sizeof(float);   // (two-wave sweep)
+    const size_t lds5 = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 5 * 256 + maxo * 256 + TRI5_TABLE_WORDS(m)) * sizeof(float);   // (two-wave sweep)
     if (lds5 * TRI5_NC > 160 * 1024) return false;
     // rounds a launch needs: workgroups resident per CU are bounded by the LDS (both kernels keep one set's tiles
     // per chain wave) and by the SIMDs (one 256-register wave each: 4 lone waves or 4 / (TRI5_NC + 1) groups).
@@ -897,7 +897,7 @@ static int launch_tri5(const ProposeArgs* pa, const pmc_maf_t* m, const float* z
     if (m->n_out != 2 || !m->tri_ok || m->nOT > 8 || m->D > 64) return -1;
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
     const int maxo = m->nOT <= 4 ? 4 : 8;
-    const size_t lds = ((size_t)TRI5_NC * (2 * m->Dp * 16 + 3 * m->Hp * 16 + 3 * 256 + maxo * 256) + TRI5_TABLE_WORDS(m)) * sizeof(float);
+    const size_t lds = ((size_t)TRI5_NC * (2 * m->Dp * 16 + 2 * m->Hp * 16 + 5 * 256 + maxo * 256) + TRI5_TABLE_WORDS(m)) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     const ProposeArgs none{};
     const int64_t nsets = (n + 15) / 16;
