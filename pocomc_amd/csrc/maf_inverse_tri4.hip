@@ -636,15 +636,30 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                     SW_BURST(Tt - 1, P1, P2, a1[c], a2[c], c1[c], c2[c], h0_, h1_)                               \
                     if (Tt - 1 >= PK4) {                                                                         \
                         for (int r = 0; r < 4; ++r) { a1[c][r] += c1[c][r]; a2[c][r] += c2[c][r]; }              \
-                        for (int K = PK4; K < Tt - 1; ++K) {                                                     \
-                            const float4 w1 = bload4(rs, vo_lane, oF1 + (Tt * nT + K) * 1024);                    \
-                            const float4 w2 = bload4(rs, vo_lane, oF2 + (Tt * nT + K) * 1024);                    \
-                            const float4 b1 = *reinterpret_cast<const float4*>(h0_ + (K << 8) + (lane << 2));    \
-                            const float4 b2 = *reinterpret_cast<const float4*>(h1_ + (K << 8) + (lane << 2));    \
-                            a1[c] = MFMA(w1.x, b1.x, a1[c]); a2[c] = MFMA(w2.x, b2.x, a2[c]);                    \
-                            a1[c] = MFMA(w1.y, b1.y, a1[c]); a2[c] = MFMA(w2.y, b2.y, a2[c]);                    \
-                            a1[c] = MFMA(w1.z, b1.z, a1[c]); a2[c] = MFMA(w2.z, b2.z, a2[c]);                    \
-                            a1[c] = MFMA(w1.w, b1.w, a1[c]); a2[c] = MFMA(w2.w, b2.w, a2[c]);                    \
+                        /* (flows wider than PK4 + 1 tiles: four K tiles' fragments in flight -- a load at a time  */ \
+                        /*  made the burst wave of a 25-tile flow wait an L2 round trip per K tile)                 */ \
+                        float4 w1r[4], w2r[4];                                                                   \
+                        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                       \
+                            const int Kl = min(PK4 + j_, nT - 1);                                                \
+                            w1r[j_] = bload4(rs, vo_lane, oF1 + (Tt * nT + Kl) * 1024);                           \
+                            w2r[j_] = bload4(rs, vo_lane, oF2 + (Tt * nT + Kl) * 1024);                           \
+                        }                                                                                        \
+                        for (int K0 = PK4; K0 < Tt - 1; K0 += 4) {                                               \
+                            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                   \
+                                const int K = K0 + j_;                                                           \
+                                const float4 w1 = w1r[j_], w2 = w2r[j_];                                         \
+                                const int Kn = min(K + 4, nT - 1);                                               \
+                                w1r[j_] = bload4(rs, vo_lane, oF1 + (Tt * nT + Kn) * 1024);                       \
+                                w2r[j_] = bload4(rs, vo_lane, oF2 + (Tt * nT + Kn) * 1024);                       \
+                                if (K < Tt - 1) {                                                                \
+                                    const float4 b1 = *reinterpret_cast<const float4*>(h0_ + (K << 8) + (lane << 2)); \
+                                    const float4 b2 = *reinterpret_cast<const float4*>(h1_ + (K << 8) + (lane << 2)); \
+                                    a1[c] = MFMA(w1.x, b1.x, a1[c]); a2[c] = MFMA(w2.x, b2.x, a2[c]);            \
+                                    a1[c] = MFMA(w1.y, b1.y, a1[c]); a2[c] = MFMA(w2.y, b2.y, a2[c]);            \
+                                    a1[c] = MFMA(w1.z, b1.z, a1[c]); a2[c] = MFMA(w2.z, b2.z, a2[c]);            \
+                                    a1[c] = MFMA(w1.w, b1.w, a1[c]); a2[c] = MFMA(w2.w, b2.w, a2[c]);            \
+                                }                                                                                \
+                            }                                                                                    \
                         }                                                                                        \
                     }                                                                                            \
                 }                                                                                                \
