@@ -277,15 +277,32 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
                 case 8: burst_tile<8>(a1, a2, pf1, pf2, H0, H1, lane); break;
                 default: break;
             }
-            for (int K = PK4; K < Tt; ++K) {
-                const float4 w1 = bload4(rs, vo_lane, oF1 + (Tt * nT + K) * 1024);
-                const float4 w2 = bload4(rs, vo_lane, oF2 + (Tt * nT + K) * 1024);
-                const float4 b1 = *reinterpret_cast<const float4*>(H0 + (K << 8) + (lane << 2));
-                const float4 b2 = *reinterpret_cast<const float4*>(H1 + (K << 8) + (lane << 2));
-                a1 = MFMA(w1.x, b1.x, a1); a2 = MFMA(w2.x, b2.x, a2);
-                a1 = MFMA(w1.y, b1.y, a1); a2 = MFMA(w2.y, b2.y, a2);
-                a1 = MFMA(w1.z, b1.z, a1); a2 = MFMA(w2.z, b2.z, a2);
-                a1 = MFMA(w1.w, b1.w, a1); a2 = MFMA(w2.w, b2.w, a2);
+            if (Tt > PK4) {                                 // flows wider than PK4 tiles: four K tiles' fragments in flight
+                float4 w1r[4], w2r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int Kl = min(PK4 + j, nT - 1);
+                    w1r[j] = bload4(rs, vo_lane, oF1 + (Tt * nT + Kl) * 1024);
+                    w2r[j] = bload4(rs, vo_lane, oF2 + (Tt * nT + Kl) * 1024);
+                }
+                for (int K0 = PK4; K0 < Tt; K0 += 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int K = K0 + j;
+                        const float4 w1 = w1r[j], w2 = w2r[j];
+                        const int Kn = min(K + 4, nT - 1);
+                        w1r[j] = bload4(rs, vo_lane, oF1 + (Tt * nT + Kn) * 1024);
+                        w2r[j] = bload4(rs, vo_lane, oF2 + (Tt * nT + Kn) * 1024);
+                        if (K < Tt) {
+                            const float4 b1 = *reinterpret_cast<const float4*>(H0 + (K << 8) + (lane << 2));
+                            const float4 b2 = *reinterpret_cast<const float4*>(H1 + (K << 8) + (lane << 2));
+                            a1 = MFMA(w1.x, b1.x, a1); a2 = MFMA(w2.x, b2.x, a2);
+                            a1 = MFMA(w1.y, b1.y, a1); a2 = MFMA(w2.y, b2.y, a2);
+                            a1 = MFMA(w1.z, b1.z, a1); a2 = MFMA(w2.z, b2.z, a2);
+                            a1 = MFMA(w1.w, b1.w, a1); a2 = MFMA(w2.w, b2.w, a2);
+                        }
+                    }
+                }
             }
             // ---- stage natural -> R layout ([p][row] so that a quad is one float4)
             {
@@ -890,7 +907,8 @@ static bool tri5_wanted(const pmc_maf_t* m, int64_t n) {
     // rounds a launch needs: workgroups resident per CU are bounded by the LDS (both kernels keep one set's tiles
     // per chain wave) and by the SIMDs (one 256-register wave each: 4 lone waves or 4 / (TRI5_NC + 1) groups).
     // The two-wave kernel takes ~0.75 of the lone wave's time per round.
-    const int64_t by_lds4 = (int64_t)((160 * 1024) / lds1), by_lds5 = (int64_t)((160 * 1024) / (lds5 * TRI5_NC));
+    // (512 bytes of slack per workgroup: three workgroups of 54 560 bytes do not share a CU's 163 840 in practice)
+    const int64_t by_lds4 = (int64_t)((160 * 1024) / (lds1 + 512)), by_lds5 = (int64_t)((160 * 1024) / (lds5 * TRI5_NC + 512));
     const int64_t res4 = 256 * (by_lds4 < 4 ? by_lds4 : 4);
     const int64_t wg5 = by_lds5 < 4 / (TRI5_NC + 1) ? by_lds5 : 4 / (TRI5_NC + 1);
     const int64_t res5 = 256 * TRI5_NC * wg5;
