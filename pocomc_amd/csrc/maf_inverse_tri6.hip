@@ -53,13 +53,21 @@ __device__ __forceinline__ void sfor(F&& f) {
 // ---- LDS words ----------------------------------------------------------------------------------------------------
 enum { F_H0 = 0, F_H1, F_H2, F_X, F_P0, F_P1, F_P2, F_P3, F_COUNT = 8 };
 
+// The words are addressed as LDS (address space 3) explicitly: through a generic pointer they become FLAT accesses,
+// which count on vmcnt as well -- every poll then waits for the weight fragments its wave has in flight (measured:
+// 1300 cycles per tile on the chain wavefront, a full L2 miss per row on the helpers).
+typedef __attribute__((address_space(3))) int lds_int;
+__device__ __forceinline__ volatile lds_int* lds_word(const int* flags, int which) {
+    return reinterpret_cast<volatile lds_int*>(static_cast<unsigned>(reinterpret_cast<uintptr_t>(flags + which)));   // (aperture: low 32 bits)
+}
+// (every lane reads the same word: said explicitly, the polls and the branches on them are scalar)
+__device__ __forceinline__ int peek(const int* flags, int which) { return __builtin_amdgcn_readfirstlane(*lds_word(flags, which)); }
 __device__ __forceinline__ void publish(int* flags, int which, int value) {
     asm volatile("" ::: "memory");                       // data stores stay before the word's store (DS ops are in order)
-    *reinterpret_cast<volatile int*>(flags + which) = value;
+    *lds_word(flags, which) = value;
 }
 __device__ __forceinline__ void wait_for(const int* flags, int which, int value) {
-    const volatile int* f = reinterpret_cast<const volatile int*>(flags + which);
-    while (*f < value) {}                                 // (an LDS round trip per poll is pause enough)
+    while (peek(flags, which) < value) {}                 // (an LDS round trip per poll is pause enough)
     asm volatile("" ::: "memory");
 }
 
@@ -78,13 +86,84 @@ struct ChainState {
 // `value` are the staged ones); only if the word is behind does the wave poll and read again.
 template <class LOAD>
 __device__ __forceinline__ void take(const int* flags, int which, int value, LOAD&& load) {
-    const int seen = *reinterpret_cast<const volatile int*>(flags + which);
+    const int seen = peek(flags, which);
     load();
     asm volatile("" ::: "memory");
     if (seen < value) {
         wait_for(flags, which, value);
         load();
     }
+}
+
+// acc/acd[sb] += sum_{K < Kn} frag[K] . Hin[sb][K] for a helper wavefront, every tile K < Kn final when `ready` returns
+// (it is called between the first fragment loads and the first activation reads).
+//
+// What bounds a helper (profile of workgroup 0 at D = 128, 33 hidden tiles; builds without the weight loads, without
+// the LDS reads and without the MFMAs all ran within 10 % of each other): a lone wavefront on its SIMD issues one
+// instruction per ~4 cycles, so a tile's four 32-cycle MFMAs hide about 28 other instructions.  The first version of
+// this loop spent 45 per tile (per-tile bounds tests, selects, address arithmetic): 180-250 cycles per tile.  Now the
+// loop body is one fragment load, one LDS read per subset and the MFMAs: chunks of C tiles, addressed by immediate
+// offsets from one base per chunk, three register sets in rotation (a copy of a set would wait for its loads) so that
+// the fragments (L2) and activations (LDS) of chunks i + 1 and i + 2 are in flight while chunk i multiplies; only whole
+// rotations of FULL chunks run in the loop (no bounds test inside; an exit between the stages would also make the wait
+// counts of the merged paths conservative), the last tiles (fewer than three chunks, two of them already loaded)
+// follow it behind one uniform branch each.  The empty asm and the scheduling barriers keep the compiler from moving a
+// set's loads down to the stage that multiplies them.
+template <int NS, int C, class READY>
+__device__ __forceinline__ void left_products(f32x4 (&acc)[NS], f32x4 (&acd)[NS], __amdgpu_buffer_rsrc_t rs, int vo_lane,
+                                              int base, const float* Hin, int szH, int Kn, int lane, READY&& ready) {
+    if (Kn <= 0) return;
+    float4 w0[C], w1[C], w2[C], b0[C][NS], b1[C][NS], b2[C][NS];
+    const float* hl = Hin + (lane << 2);
+    // chunk at tile Kc (a chunk that starts beyond the row is not used: tile 0 instead, always inside the arrays)
+    auto loadw = [&](float4 (&w)[C], int Kc) __attribute__((always_inline)) {
+        const int so = base + ((Kc < Kn ? Kc : 0) << 10);
+#pragma unroll
+        for (int j = 0; j < C; ++j) w[j] = bload4(rs, vo_lane + j * 1024, so);
+    };
+    auto loadb = [&](float4 (&b)[C][NS], int Kc) __attribute__((always_inline)) {
+        const float* hk = hl + ((Kc < Kn ? Kc : 0) << 8);
+#pragma unroll
+        for (int j = 0; j < C; ++j)
+#pragma unroll
+            for (int sb = 0; sb < NS; ++sb) b[j][sb] = *reinterpret_cast<const float4*>(hk + sb * szH + j * 256);
+    };
+    auto mma1 = [&](const float4& w, const float4 (&b)[NS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int sb = 0; sb < NS; ++sb) {
+            acc[sb] = MFMA(w.x, b[sb].x, acc[sb]); acd[sb] = MFMA(w.y, b[sb].y, acd[sb]);
+            acc[sb] = MFMA(w.z, b[sb].z, acc[sb]); acd[sb] = MFMA(w.w, b[sb].w, acd[sb]);
+        }
+    };
+#define STAGE(LW, LB, MW, MB)                                                                                       \
+        loadw(LW, K0 + 2 * C); loadb(LB, K0 + 2 * C);                                                               \
+        asm volatile("" ::: "memory");                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        _Pragma("unroll") for (int j = 0; j < C; ++j) mma1(MW[j], MB[j]);                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        K0 += C;
+    loadw(w0, 0); loadw(w1, C);
+    asm volatile("" ::: "memory");
+    ready();                                              // (the wait for the tiles' word, behind the first fragments' loads)
+    loadb(b0, 0); loadb(b1, C);
+    asm volatile("" ::: "memory");
+    int K0 = 0;
+    for (int it = (Kn / C) / 3; it > 0; --it) {
+        STAGE(w2, b2, w0, b0)
+        STAGE(w0, b0, w1, b1)
+        STAGE(w1, b1, w2, b2)
+    }
+#undef STAGE
+    if (K0 + 2 * C < Kn) {                                // the third chunk of the rest
+        loadw(w2, K0 + 2 * C); loadb(b2, K0 + 2 * C);
+        asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int j = 0; j < C; ++j) if (K0 + j < Kn) mma1(w0[j], b0[j]);
+#pragma unroll
+    for (int j = 0; j < C; ++j) if (K0 + C + j < Kn) mma1(w1[j], b1[j]);
+#pragma unroll
+    for (int j = 0; j < C; ++j) if (K0 + 2 * C + j < Kn) mma1(w2[j], b2[j]);
 }
 
 // One degree group of the tile (quads c0..c1), then the next (compile-time recursion over the quad pattern).
@@ -317,7 +396,10 @@ __global__ __launch_bounds__(256) void maf_inverse_tri6_kernel(pmc_maf_t m, cons
             });
             for (int T = 0; T < nT; ++T) {
                 int4 dg = dg_next;
-                dg.x &= 0xffff; dg.y &= 0xffff; dg.z &= 0xffff; dg.w &= 0xffff;
+                // (the same words in every lane; said explicitly, the compiler keeps what follows from them in scalar registers --
+                // otherwise every buffer load whose offset depends on a rank is wrapped in a waterfall loop)
+                dg.x = __builtin_amdgcn_readfirstlane(dg.x & 0xffff); dg.y = __builtin_amdgcn_readfirstlane(dg.y & 0xffff);
+                dg.z = __builtin_amdgcn_readfirstlane(dg.z & 0xffff); dg.w = __builtin_amdgcn_readfirstlane(dg.w & 0xffff);
                 if (dg.x >= D && dg.y >= D && dg.z >= D && dg.w >= D) break;       // padding tiles
                 const int pat = 1 | ((dg.y != dg.x) << 1) | ((dg.z != dg.y) << 2) | ((dg.w != dg.z) << 3);
                 {
@@ -328,7 +410,7 @@ __global__ __launch_bounds__(256) void maf_inverse_tri6_kernel(pmc_maf_t m, cons
                     s.g[3] = (ny && nz && nw) ? dg.w : D;
                 }
                 long long* pf = (pa.prof && blockIdx.x == 0) ? pa.prof + ((size_t)((Tn - 1 - t) * nT + T) * 4 + 0) * 4 : nullptr;
-                if (pf && lane == 0) pf[0] = clock64();
+                if (pf && lane == 0) { pf[0] = clock64(); if (T == 0) pf[3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4); }
                 s.w1 = w1n; s.w2 = w2n; s.w0 = w0nn; s.w3 = w3n;
                 if (T + 1 < nT) {
                     w1n = bload4(rs, vo_lane, oCW1 + (T + 1) * 1024);
@@ -375,34 +457,35 @@ __global__ __launch_bounds__(256) void maf_inverse_tri6_kernel(pmc_maf_t m, cons
             const int f_out = wv == 1 ? F_P1 : F_P2;
             int known = gen;                              // tiles < known - gen of the input layer are final
             auto need = [&](int K) {                       // tile K of the input layer must be final
-                if (known < gen + K + 1) { wait_for(flags, f_in, gen + K + 1); known = *reinterpret_cast<volatile int*>(flags + f_in); }
+                if (known < gen + K + 1) { wait_for(flags, f_in, gen + K + 1); known = peek(flags, f_in); }
             };
-            // acc/acd[sb] += sum_{K < T} frag[K] . Hin[sb][K]: four weight fragments in flight (a helper has nothing else to
-            // hide an L2 round trip with), tile K of the input layer awaited right before its use
-#define KLOOP(BASE)                                                                                                 \
-            {                                                                                                       \
-                const int base_ = (BASE);                                                                           \
-                float4 fr[4];                                                                                       \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
-                    fr[j] = j < T ? bload4(rs, vo_lane, base_ + j * 1024) : make_float4(0.f, 0.f, 0.f, 0.f);        \
-                for (int K0 = 0; K0 < T; K0 += 4) {                                                                 \
-                    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
-                        const int K = K0 + j;                                                                       \
-                        if (K < T) {                                                                                \
-                            const float4 w = fr[j];                                                                 \
-                            if (K + 4 < T) fr[j] = bload4(rs, vo_lane, base_ + (K + 4) * 1024);                     \
-                            if (pf && lane == 0 && K == T - 1) pf[1] = clock64();                                   \
-                            need(K);                                                                                \
-                            if (pf && lane == 0 && K == T - 1) pf[2] = clock64();                                   \
-                            _Pragma("unroll") for (int sb = 0; sb < NS; ++sb) {                                     \
-                                const float4 b = *reinterpret_cast<const float4*>(Hin + sb * szH + (K << 8) + (lane << 2)); \
-                                acc[sb] = MFMA(w.x, b.x, acc[sb]); acd[sb] = MFMA(w.y, b.y, acd[sb]);               \
-                                acc[sb] = MFMA(w.z, b.z, acc[sb]); acd[sb] = MFMA(w.w, b.w, acd[sb]);               \
-                            }                                                                                       \
-                        }                                                                                           \
-                    }                                                                                               \
+            // acc/acd[sb] += sum_{K < T} frag[K] . Hin[sb][K]: the tiles before the last are final as soon as the one before
+            // the last is (pipelined: left_products), the last tile of the input layer is awaited right before its use with
+            // its fragment already in registers
+            constexpr int CH = NS <= 2 ? 4 : 2;
+#define KLOOP(BASE, KBEG)                                                                                           \
+            if (T > (KBEG)) {                                                                                       \
+                const int base_ = (BASE), kb_ = (KBEG);                                                             \
+                const float4 w = bload4(rs, vo_lane, base_ + (T - 1) * 1024);                                       \
+                if (T - 1 > kb_)                                                                                    \
+                    left_products<NS, CH>(acc, acd, rs, vo_lane, base_ + kb_ * 1024, Hin + (kb_ << 8), szH, T - 1 - kb_, lane, \
+                                          [&]() __attribute__((always_inline)) { need(T - 2); });                   \
+                if (pf && lane == 0) pf[1] = clock64();                                                             \
+                need(T - 1);                                                                                        \
+                if (pf && lane == 0) pf[2] = clock64();                                                             \
+                _Pragma("unroll") for (int sb = 0; sb < NS; ++sb) {                                                 \
+                    const float4 b = *reinterpret_cast<const float4*>(Hin + sb * szH + ((T - 1) << 8) + (lane << 2)); \
+                    acc[sb] = MFMA(w.x, b.x, acc[sb]); acd[sb] = MFMA(w.y, b.y, acd[sb]);                           \
+                    acc[sb] = MFMA(w.z, b.z, acc[sb]); acd[sb] = MFMA(w.w, b.w, acd[sb]);                           \
                 }                                                                                                   \
             }
+            // wave 3 keeps the sums of two output tiles (slot = tile & 1) across the hidden tiles: consecutive hidden tiles
+            // share their output tiles (8 ranks each), so a hidden tile adds only the h2 tiles that became final since the
+            // slot was last staged instead of summing from tile 0 again (same order of additions, same bits); a new output
+            // tile costs one full row, once.
+            f32x4 oacc0[NS], oacd0[NS], oacc1[NS], oacd1[NS];
+            int slotO0 = -1, slotO1 = -1, slotK0 = 0, slotK1 = 0;
+            float4 obias0 = make_float4(0.f, 0.f, 0.f, 0.f), obias1 = obias0;
             if (wv == 3) {
                 // layer-0 partial of tile 0: bias only (cut = 0)
                 const float4 b0 = bload4(rs, vo_q, oB0);
@@ -412,20 +495,26 @@ __global__ __launch_bounds__(256) void maf_inverse_tri6_kernel(pmc_maf_t m, cons
             }
             for (int T = 0; T < nT; ++T) {
                 int4 dg = *reinterpret_cast<const int4*>(quad_meta + 4 * T);
-                dg.x &= 0xffff; dg.y &= 0xffff; dg.z &= 0xffff; dg.w &= 0xffff;
+                // (the same words in every lane; said explicitly, the compiler keeps what follows from them in scalar registers --
+                // otherwise every buffer load whose offset depends on a rank is wrapped in a waterfall loop)
+                dg.x = __builtin_amdgcn_readfirstlane(dg.x & 0xffff); dg.y = __builtin_amdgcn_readfirstlane(dg.y & 0xffff);
+                dg.z = __builtin_amdgcn_readfirstlane(dg.z & 0xffff); dg.w = __builtin_amdgcn_readfirstlane(dg.w & 0xffff);
                 if (dg.x >= D && dg.y >= D && dg.z >= D && dg.w >= D) break;
                 long long* pf = (pa.prof && blockIdx.x == 0) ? pa.prof + ((size_t)((Tn - 1 - t) * nT + T) * 4 + wv) * 4 : nullptr;
-                if (pf && lane == 0) pf[0] = clock64();
+                if (pf && lane == 0) { pf[0] = clock64(); if (T == 0) pf[2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4); }
                 if (wv != 3) {
                     const float4 bb = bload4(rs, vo_q, oB + 64 * T);
                     f32x4 acc[NS], acd[NS];
-                    for (int sb = 0; sb < NS; ++sb) { acc[sb] = f32x4{bb.x, bb.y, bb.z, bb.w}; acd[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                    KLOOP(oF + (T * nT) * 1024)
+                    // (the bias joins the sum when it is staged: as the accumulator's first value its load would have to land
+                    // before the first fragment is even requested)
+                    for (int sb = 0; sb < NS; ++sb) { acc[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; acd[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                    KLOOP(oF + (T * nT) * 1024, 0)
                     float* sp = SP + (T & 1) * (NS * 16 * SPAD);
 #pragma unroll
                     for (int sb = 0; sb < NS; ++sb)
                         *reinterpret_cast<float4*>(sp + (sb * 16 + p) * SPAD + 4 * q) =
-                            make_float4(acc[sb][0] + acd[sb][0], acc[sb][1] + acd[sb][1], acc[sb][2] + acd[sb][2], acc[sb][3] + acd[sb][3]);
+                            make_float4((acc[sb][0] + acd[sb][0]) + bb.x, (acc[sb][1] + acd[sb][1]) + bb.y,
+                                        (acc[sb][2] + acd[sb][2]) + bb.z, (acc[sb][3] + acd[sb][3]) + bb.w);
                     publish(flags, f_out, gen + T + 1);
                     if (pf && lane == 0) pf[3] = clock64();
                 } else {
@@ -436,54 +525,94 @@ __global__ __launch_bounds__(256) void maf_inverse_tri6_kernel(pmc_maf_t m, cons
                     if (dg.w < D) glast = dg.w;
                     const int O0 = gfirst >> 3, O1 = glast >> 3;
                     float* sp3 = SP3 + (T & 1) * (2 * 64 * SPAD);
-                    for (int so = 0; so <= (O1 != O0 ? 1 : 0); ++so) {
-                        const int O = O0 + so;
-                        const float4 bb = bload4(rs, vo_q, oB3 + 64 * O);
-                        f32x4 acc[NS], acd[NS];
-                        for (int sb = 0; sb < NS; ++sb) { acc[sb] = f32x4{bb.x, bb.y, bb.z, bb.w}; acd[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                        KLOOP(oF3 + (O * nT) * 1024)
+                    // first everything that does not wait for the chain's current tile (a new output tile's row up to
+                    // tile T - 2), then the last tile of both
+                    const int nso = O1 != O0 ? 2 : 1;
+                    float4 wl[2];
+                    auto pre = [&](f32x4 (&acc)[NS], f32x4 (&acd)[NS], int& sO, int& sK, float4& ob, int O, float4& w) __attribute__((always_inline)) {
+                        sO = __builtin_amdgcn_readfirstlane(sO); sK = __builtin_amdgcn_readfirstlane(sK);
+                        if (sO != O) {
+                            ob = bload4(rs, vo_q, oB3 + 64 * O);
+                            for (int sb = 0; sb < NS; ++sb) { acc[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; acd[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                            sO = O; sK = 0;
+                        }
+                        const int base_ = oF3 + (O * nT) * 1024;
+                        if (T > sK) w = bload4(rs, vo_lane, base_ + (T - 1) * 1024);
+                        if (T - 1 > sK)
+                            left_products<NS, CH>(acc, acd, rs, vo_lane, base_ + sK * 1024, Hin + (sK << 8), szH, T - 1 - sK, lane,
+                                                  [&]() __attribute__((always_inline)) { need(T - 2); });
+                    };
+                    auto fin = [&](f32x4 (&acc)[NS], f32x4 (&acd)[NS], int& sK, const float4& ob, int so, const float4& w) __attribute__((always_inline)) {
+                        if (T > sK) {
+#pragma unroll
+                            for (int sb = 0; sb < NS; ++sb) {
+                                const float4 b = *reinterpret_cast<const float4*>(Hin + sb * szH + ((T - 1) << 8) + (lane << 2));
+                                acc[sb] = MFMA(w.x, b.x, acc[sb]); acd[sb] = MFMA(w.y, b.y, acd[sb]);
+                                acc[sb] = MFMA(w.z, b.z, acc[sb]); acd[sb] = MFMA(w.w, b.w, acd[sb]);
+                            }
+                            sK = T;
+                        }
 #pragma unroll
                         for (int sb = 0; sb < NS; ++sb)
                             *reinterpret_cast<float4*>(sp3 + so * (64 * SPAD) + (sb * 16 + p) * SPAD + 4 * q) =
-                                make_float4(acc[sb][0] + acd[sb][0], acc[sb][1] + acd[sb][1], acc[sb][2] + acd[sb][2], acc[sb][3] + acd[sb][3]);
+                                make_float4((acc[sb][0] + acd[sb][0]) + ob.x, (acc[sb][1] + acd[sb][1]) + ob.y,
+                                            (acc[sb][2] + acd[sb][2]) + ob.z, (acc[sb][3] + acd[sb][3]) + ob.w);
+                    };
+                    for (int so = 0; so < nso; ++so) {
+                        const int O = O0 + so;
+                        if (O & 1) pre(oacc1, oacd1, slotO1, slotK1, obias1, O, wl[1]); else pre(oacc0, oacd0, slotO0, slotK0, obias0, O, wl[0]);
+                    }
+                    if (pf && lane == 0 && T > 0) pf[2] = clock64();
+                    if (T > 0) need(T - 1);
+                    for (int so = 0; so < nso; ++so) {
+                        const int O = O0 + so;
+                        if (O & 1) fin(oacc1, oacd1, slotK1, obias1, so, wl[1]); else fin(oacc0, oacd0, slotK0, obias0, so, wl[0]);
                     }
                     publish(flags, F_P3, gen + T + 1);
                     if (pf && lane == 0) pf[1] = clock64();
                     // ---- layer-0 partial of the NEXT tile: ranks before this tile's own (f0c), final once tile T-1 is
                     if (T + 1 < nT) {
-                        wait_for(flags, F_X, gen + T);                    // tile T-1 complete (T = 0: rank 0 is there)
                         const float4 b0 = bload4(rs, vo_q, oB0 + 64 * (T + 1));
-                        f32x4 acc[NS];
-                        for (int sb = 0; sb < NS; ++sb) acc[sb] = f32x4{b0.x, b0.y, b0.z, b0.w};
-                        {
-                            const int base_ = oF0C + ((T + 1) * nXT) * 1024;
-                            float4 fr[4];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                fr[j] = j < nXT ? bload4(rs, vo_lane, base_ + j * 1024) : make_float4(0.f, 0.f, 0.f, 0.f);
-                            for (int X0 = 0; X0 < nXT; X0 += 4) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    const int Xt = X0 + j;
-                                    if (Xt < nXT) {
-                                        const float4 w = fr[j];
-                                        if (Xt + 4 < nXT) fr[j] = bload4(rs, vo_lane, base_ + (Xt + 4) * 1024);
-#pragma unroll
-                                        for (int sb = 0; sb < NS; ++sb) {
-                                            const float4 b = *reinterpret_cast<const float4*>(Xb + sb * szY + (Xt << 8) + (lane << 2));
-                                            acc[sb] = MFMA(w.x, b.x, acc[sb]); acc[sb] = MFMA(w.y, b.y, acc[sb]);
-                                            acc[sb] = MFMA(w.z, b.z, acc[sb]); acc[sb] = MFMA(w.w, b.w, acc[sb]);
-                                        }
-                                    }
-                                }
-                            }
-                        }
+                        f32x4 acc[NS], acd[NS];
+                        for (int sb = 0; sb < NS; ++sb) { acc[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; acd[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                        // (the fragments right of the cut are zeros: only the tiles that hold ranks before this tile's own;
+                        // the wait for tile T-1 to be complete -- T = 0: rank 0 is there -- behind the first fragments' loads)
+                        const int nXn = (gfirst + 15) >> 4;
+                        if (nXn > 0)
+                            left_products<NS, CH>(acc, acd, rs, vo_lane, oF0C + ((T + 1) * nXT) * 1024, Xb, szY, nXn < nXT ? nXn : nXT, lane,
+                                                  [&]() __attribute__((always_inline)) { wait_for(flags, F_X, gen + T); });
                         float* sp0 = SP0 + ((T + 1) & 1) * (NS * 16 * SPAD);
 #pragma unroll
                         for (int sb = 0; sb < NS; ++sb)
-                            *reinterpret_cast<float4*>(sp0 + (sb * 16 + p) * SPAD + 4 * q) = make_float4(acc[sb][0], acc[sb][1], acc[sb][2], acc[sb][3]);
+                            *reinterpret_cast<float4*>(sp0 + (sb * 16 + p) * SPAD + 4 * q) =
+                                make_float4((acc[sb][0] + acd[sb][0]) + b0.x, (acc[sb][1] + acd[sb][1]) + b0.y,
+                                            (acc[sb][2] + acd[sb][2]) + b0.z, (acc[sb][3] + acd[sb][3]) + b0.w);
                         publish(flags, F_P0, gen + T + 2);
                         if (pf && lane == 0) pf[3] = clock64();
+                        // ---- ahead of the chain: a NEW output tile of the next hidden tile starts its row now, over the
+                        // h2 tiles that are final (all before this one), while the chain works through this tile -- the
+                        // next tile then only adds one h2 tile to each of its sums
+                        int4 dn = *reinterpret_cast<const int4*>(quad_meta + 4 * (T + 1));
+                        dn.x = __builtin_amdgcn_readfirstlane(dn.x & 0xffff); dn.y = __builtin_amdgcn_readfirstlane(dn.y & 0xffff);
+                        dn.z = __builtin_amdgcn_readfirstlane(dn.z & 0xffff); dn.w = __builtin_amdgcn_readfirstlane(dn.w & 0xffff);
+                        if (dn.x < D) {
+                            int nlast = dn.x;
+                            if (dn.y < D) nlast = dn.y;
+                            if (dn.z < D) nlast = dn.z;
+                            if (dn.w < D) nlast = dn.w;
+                            auto ahead = [&](f32x4 (&acc)[NS], f32x4 (&acd)[NS], int& sO, int& sK, float4& ob, int O) __attribute__((always_inline)) {
+                                sO = __builtin_amdgcn_readfirstlane(sO); sK = __builtin_amdgcn_readfirstlane(sK);
+                                if (sO == O) return;
+                                ob = bload4(rs, vo_q, oB3 + 64 * O);
+                                for (int sb = 0; sb < NS; ++sb) { acc[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; acd[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                                sO = O;
+                                left_products<NS, CH>(acc, acd, rs, vo_lane, oF3 + (O * nT) * 1024, Hin, szH, T, lane, []() {});
+                                sK = T;
+                            };
+                            for (int O = dn.x >> 3; O <= (nlast >> 3); ++O) {
+                                if (O & 1) ahead(oacc1, oacd1, slotO1, slotK1, obias1, O); else ahead(oacc0, oacd0, slotO0, slotK0, obias0, O);
+                            }
+                        }
                     }
                 }
             }

@@ -47,6 +47,16 @@ __global__ void lat_kernel(float* out, long long* cyc, int n) {
             c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c1, 4, 1, 0);
             c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c0, 4, 2, 0);
             c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c1, 4, 3, 0);
+        } else if (MODE == 6) {     // 16x16x4, 2 interleaved dependent chains
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c1, 0, 0, 0);
+        } else if (MODE == 7) {     // 16x16x4, 4 independent accumulators
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c3, 0, 0, 0);
         } else if (MODE == 5) {     // VALU fma chain with 4 independent accumulators (16 fma)
             for (int r = 0; r < 4; ++r) { c0[r] = fmaf(a, b, c0[r]); c1[r] = fmaf(a, b, c1[r]); c2[r] = fmaf(a, b, c2[r]); c3[r] = fmaf(a, b, c3[r]); }
         }
@@ -74,10 +84,11 @@ int main() {
     const int n = 20000;
     long long hc;
     const char* names[] = {"4x4x1 dependent (same acc), per MFMA", "4x4x1 4 independent accs, per MFMA", "16x16x4 dependent, per MFMA",
-                           "hop: 4 dep 4x4x1 + 4x(mul-add,max) + feed-back, per hop", "4x4x1 2 interleaved dep chains, per MFMA", "16 v_fma (4 indep x 4), per fma"};
-    float div[] = {4, 4, 4, 1, 4, 16};
+                           "hop: 4 dep 4x4x1 + 4x(mul-add,max) + feed-back, per hop", "4x4x1 2 interleaved dep chains, per MFMA", "16 v_fma (4 indep x 4), per fma",
+                           "16x16x4 2 interleaved dep chains, per MFMA", "16x16x4 4 independent accs, per MFMA"};
+    float div[] = {4, 4, 4, 1, 4, 16, 4, 4};
 #define RUN(M) lat_kernel<M><<<1, 64>>>(d0, cyc, n); hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost); printf("%-62s %.1f ticks (clock64; s_memtime 100 MHz?)\n", names[M], (double)hc / n / div[M]);
-    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5)
+    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7)
     // calibrate clock64 tick vs wall: run long kernel
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0); lat_kernel<1><<<1, 64>>>(d0, cyc, 2000000); hipEventRecord(e1); hipEventSynchronize(e1);
