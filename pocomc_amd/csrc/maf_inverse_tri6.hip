@@ -294,14 +294,14 @@ __device__ __forceinline__ void chain_group6(ChainState& s, float* H0, float* H1
 }  // namespace tri6
 
 // NS: 16-walker subsets per workgroup (1, 2 or 4); FM: 0 = plain inverse of `in`, 4 / 8 / 16 = fused proposal, D <= 4 FM.
-template <int NS, int FM>
-__global__ __launch_bounds__(256) void maf_inverse_tri6_kernel(pmc_maf_t m, const float* __restrict__ in,
+template <int NS, int FM, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, const float* __restrict__ in,
                                                                float* __restrict__ out, float* __restrict__ ladj_out,
                                                                int64_t n, ProposeArgs pa) {
     using namespace tri6;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, p = lane & 15;
     const int D = m.D, Dp = m.Dp, Hp = m.Hp, Tn = m.T, nT = m.nT, nXT = m.nXT, nOT = m.nOT;
     // ---- LDS map
@@ -340,6 +340,23 @@ __global__ __launch_bounds__(256) void maf_inverse_tri6_kernel(pmc_maf_t m, cons
 
     const int64_t set0 = (int64_t)blockIdx.x * NS;       // first 16-walker set of this workgroup
     if (threadIdx.x < F_COUNT) flags[threadIdx.x] = 0;
+    if constexpr (NW == 5) {
+        // Five wavefronts on four SIMDs: two of them share one.  Roles go by what a shared SIMD costs: the chain (role 0)
+        // and the output rows (3) to the wavefronts that have a SIMD to themselves, then the hidden layers (1, 2), the
+        // layer-0 partials (4: the lightest) last.
+        int* simd_of = flags + F_COUNT;
+        if (lane == 0) simd_of[wv] = (int)((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3);   // HW_ID.SIMD_ID
+        __syncthreads();
+        int sd[5], sharers[5];
+        for (int w = 0; w < 5; ++w) sd[w] = __builtin_amdgcn_readfirstlane(simd_of[w]);
+        for (int w = 0; w < 5; ++w) { sharers[w] = 0; for (int v = 0; v < 5; ++v) sharers[w] += sd[v] == sd[w]; }
+        int before = 0;                                  // wavefronts that choose before this one: fewer sharers, then lower index
+        for (int v = 0; v < 5; ++v) before += sharers[v] < sharers[wv] || (sharers[v] == sharers[wv] && v < wv);
+        const int order[5] = {0, 3, 1, 2, 4};
+        int role = 4;
+        for (int i = 0; i < 5; ++i) if (before == i) role = order[i];
+        wv = role;
+    }
     // ---- input: proposals (fused) or rows of `in`, one subset per wavefront
     for (int sb = wv; sb < NS; sb += 4) {
         float* Y = Yb + sb * szY;
@@ -486,7 +503,8 @@ __global__ __launch_bounds__(256) void maf_inverse_tri6_kernel(pmc_maf_t m, cons
             f32x4 oacc0[NS], oacd0[NS], oacc1[NS], oacd1[NS];
             int slotO0 = -1, slotO1 = -1, slotK0 = 0, slotK1 = 0;
             float4 obias0 = make_float4(0.f, 0.f, 0.f, 0.f), obias1 = obias0;
-            if (wv == 3) {
+            constexpr int P0W = NW == 5 ? 4 : 3;         // the wavefront that forms the layer-0 partials
+            if (wv == P0W) {
                 // layer-0 partial of tile 0: bias only (cut = 0)
                 const float4 b0 = bload4(rs, vo_q, oB0);
                 for (int sb = 0; sb < NS; ++sb)
@@ -500,9 +518,13 @@ __global__ __launch_bounds__(256) void maf_inverse_tri6_kernel(pmc_maf_t m, cons
                 dg.x = __builtin_amdgcn_readfirstlane(dg.x & 0xffff); dg.y = __builtin_amdgcn_readfirstlane(dg.y & 0xffff);
                 dg.z = __builtin_amdgcn_readfirstlane(dg.z & 0xffff); dg.w = __builtin_amdgcn_readfirstlane(dg.w & 0xffff);
                 if (dg.x >= D && dg.y >= D && dg.z >= D && dg.w >= D) break;
-                long long* pf = (pa.prof && blockIdx.x == 0) ? pa.prof + ((size_t)((Tn - 1 - t) * nT + T) * 4 + wv) * 4 : nullptr;
+                long long* pf = (pa.prof && blockIdx.x == 0 && wv < 4) ? pa.prof + ((size_t)((Tn - 1 - t) * nT + T) * 4 + wv) * 4 : nullptr;
                 if (pf && lane == 0) { pf[0] = clock64(); if (T == 0) pf[2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4); }
-                if (wv != 3) {
+                int gfirst = dg.x, glast = dg.x;
+                if (dg.y < D) glast = dg.y;
+                if (dg.z < D) glast = dg.z;
+                if (dg.w < D) glast = dg.w;
+                if (wv == 1 || wv == 2) {
                     const float4 bb = bload4(rs, vo_q, oB + 64 * T);
                     f32x4 acc[NS], acd[NS];
                     // (the bias joins the sum when it is staged: as the accumulator's first value its load would have to land
@@ -517,12 +539,9 @@ __global__ __launch_bounds__(256) void maf_inverse_tri6_kernel(pmc_maf_t m, cons
                                         (acc[sb][2] + acd[sb][2]) + bb.z, (acc[sb][3] + acd[sb][3]) + bb.w);
                     publish(flags, f_out, gen + T + 1);
                     if (pf && lane == 0) pf[3] = clock64();
-                } else {
+                }
+                if (wv == 3) {
                     // ---- output partials of this tile's ranks: output tile(s) O = rank >> 3 against h2 of tiles < T
-                    int gfirst = dg.x, glast = dg.x;
-                    if (dg.y < D) glast = dg.y;
-                    if (dg.z < D) glast = dg.z;
-                    if (dg.w < D) glast = dg.w;
                     const int O0 = gfirst >> 3, O1 = glast >> 3;
                     float* sp3 = SP3 + (T & 1) * (2 * 64 * SPAD);
                     // first everything that does not wait for the chain's current tile (a new output tile's row up to
@@ -570,6 +589,8 @@ __global__ __launch_bounds__(256) void maf_inverse_tri6_kernel(pmc_maf_t m, cons
                     }
                     publish(flags, F_P3, gen + T + 1);
                     if (pf && lane == 0) pf[1] = clock64();
+                }
+                if (wv == P0W) {
                     // ---- layer-0 partial of the NEXT tile: ranks before this tile's own (f0c), final once tile T-1 is
                     if (T + 1 < nT) {
                         const float4 b0 = bload4(rs, vo_q, oB0 + 64 * (T + 1));
@@ -588,7 +609,11 @@ __global__ __launch_bounds__(256) void maf_inverse_tri6_kernel(pmc_maf_t m, cons
                                 make_float4((acc[sb][0] + acd[sb][0]) + b0.x, (acc[sb][1] + acd[sb][1]) + b0.y,
                                             (acc[sb][2] + acd[sb][2]) + b0.z, (acc[sb][3] + acd[sb][3]) + b0.w);
                         publish(flags, F_P0, gen + T + 2);
-                        if (pf && lane == 0) pf[3] = clock64();
+                        if (pf && lane == 0 && wv == 3) pf[3] = clock64();
+                    }
+                }
+                if (wv == 3) {
+                    if (T + 1 < nT) {
                         // ---- ahead of the chain: a NEW output tile of the next hidden tile starts its row now, over the
                         // h2 tiles that are final (all before this one), while the chain works through this tile -- the
                         // next tile then only adds one h2 tile to each of its sums
@@ -619,10 +644,43 @@ __global__ __launch_bounds__(256) void maf_inverse_tri6_kernel(pmc_maf_t m, cons
         }
 #undef KLOOP
         __syncthreads();
-        const bool lastT = (t == 0);
-        for (int sb = wv; sb < NS; sb += 4)
-            rerank_or_store(Xb + sb * szY, Yb + sb * szY, out, (set0 + sb) * 16, n, D, Dp, feat_of_rank + t * D,
-                            lastT ? nullptr : rank_of_feat + (t - 1) * D, lane);
+        // re-rank for the next transform (or write out) with every thread of the workgroup: the target rank of a rank is two
+        // dependent global loads, so eight elements' worth are requested together (one wavefront walking the subset's
+        // 2048 elements one load pair at a time took 20 k cycles per transform at D = 128)
+        {
+            const bool lastT = (t == 0);
+            const int* for_cur = feat_of_rank + t * D;
+            const int* rank_next = lastT ? nullptr : rank_of_feat + (t - 1) * D;
+            const int per = Dp * 16, total = NS * per;
+            for (int e0 = threadIdx.x; e0 < total; e0 += 8 * 64 * NW) {
+                int dst[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = e0 + j * 64 * NW;
+                    const int r = (e % per) >> 4;
+                    dst[j] = -1;
+                    if (e < total && r < D) dst[j] = for_cur[r];
+                }
+                if (rank_next) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (dst[j] >= 0) dst[j] = rank_next[dst[j]];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = e0 + j * 64 * NW;
+                    if (e >= total) continue;
+                    const int sb = e / per, r = (e % per) >> 4, pp = e & 15;
+                    if (r < D) {
+                        const float v = Xb[sb * szY + lidx(r, pp)];
+                        const int64_t row = (set0 + sb) * 16 + pp;
+                        if (rank_next) Yb[sb * szY + lidx(dst[j], pp)] = v;
+                        else if (row < n) out[row * D + dst[j]] = v;
+                    } else if (rank_next) {
+                        Yb[sb * szY + lidx(r, pp)] = 0.0f;        // padding ranks
+                    }
+                }
+            }
+        }
         __syncthreads();
     }
     if (wv == 0 && ladj_out && writer) {
@@ -633,7 +691,7 @@ __global__ __launch_bounds__(256) void maf_inverse_tri6_kernel(pmc_maf_t m, cons
 
 static size_t tri6_lds_bytes(const pmc_maf_t* m, int ns) {
     return (size_t)(ns * (2 * m->Dp * 16 + 3 * m->Hp * 16) + 3 * 2 * ns * 16 * tri6::SPAD + 2 * 2 * 64 * tri6::SPAD) * sizeof(float)
-           + tri6::F_COUNT * sizeof(int);
+           + (tri6::F_COUNT + 8) * sizeof(int);          // (+ 8: the wavefronts' SIMD ids of the five-wave variant)
 }
 
 // walker subsets per workgroup: as few as keep the launch in one round (a chain wavefront takes the same time for 16
@@ -664,19 +722,23 @@ int pmc_launch_tri6(const ProposeArgs* pa, const pmc_maf_t* m, const float* z, f
     const size_t lds = tri6_lds_bytes(m, ns);
     const ProposeArgs none{};
     const unsigned grid = (unsigned)((n + 16 * ns - 1) / (16 * ns));
-#define LAUNCH6(NSV, FMV)                                                                                          \
+    // wide flows (helpers saturated: their work grows with the hidden tiles, the chain's does not) get a fifth wavefront for
+    // the layer-0 partials; it needs the kernel in 256 registers (two wavefronts on one SIMD): plain inverse, one subset
+    const bool five = !pa && ns == 1 && m->nT >= 20 && !getenv("PMC_TRI6_FOUR");
+#define LAUNCH6(NSV, FMV, NWV)                                                                                     \
     {                                                                                                              \
         if (lds > 48 * 1024) {                                                                                     \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri6_kernel<NSV, FMV>),   \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri6_kernel<NSV, FMV, NWV>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
             if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_inverse_tri6_kernel)");           \
         }                                                                                                          \
-        hipLaunchKernelGGL((maf_inverse_tri6_kernel<NSV, FMV>), dim3(grid), dim3(256), lds, stream, *m, z, x, ladj, \
-                           n, pa ? *pa : none);                                                                    \
+        hipLaunchKernelGGL((maf_inverse_tri6_kernel<NSV, FMV, NWV>), dim3(grid), dim3(64 * NWV), lds, stream, *m, z, x, \
+                           ladj, n, pa ? *pa : none);                                                              \
     }
 #define LAUNCH6F(FMV)                                                                                              \
-    { if (ns == 1) LAUNCH6(1, FMV) else if (ns == 2) LAUNCH6(2, FMV) else LAUNCH6(4, FMV) }
-    if (!pa) LAUNCH6F(0)
+    { if (ns == 1) LAUNCH6(1, FMV, 4) else if (ns == 2) LAUNCH6(2, FMV, 4) else LAUNCH6(4, FMV, 4) }
+    if (five) LAUNCH6(1, 0, 5)
+    else if (!pa) LAUNCH6F(0)
     else if (m->D <= 16) LAUNCH6F(4)
     else if (m->D <= 32) LAUNCH6F(8)
     else LAUNCH6F(16)
@@ -695,14 +757,15 @@ extern "C" int pmc_debug_tri6_profile(const pmc_maf_t* m, const float* z, float*
     if (ns == 0 || m->n_out != 2 || !m->tri_ok) return pmc_fail("pmc_debug_tri6_profile: flow not covered");
     const size_t lds = tri6_lds_bytes(m, ns);
     const unsigned grid = (unsigned)((n + 16 * ns - 1) / (16 * ns));
-#define LP(NSV)                                                                                                    \
+    const bool five = ns == 1 && m->nT >= 20 && !getenv("PMC_TRI6_FOUR");
+#define LP(NSV, NWV)                                                                                               \
     {                                                                                                              \
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri6_kernel<NSV, 0>), \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri6_kernel<NSV, 0, NWV>), \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-        hipLaunchKernelGGL((maf_inverse_tri6_kernel<NSV, 0>), dim3(grid), dim3(256), lds, (hipStream_t)stream, *m, z, x, \
-                           ladj, n, pa);                                                                           \
+        hipLaunchKernelGGL((maf_inverse_tri6_kernel<NSV, 0, NWV>), dim3(grid), dim3(64 * NWV), lds, (hipStream_t)stream, *m, z, \
+                           x, ladj, n, pa);                                                                        \
     }
-    if (ns == 1) LP(1) else if (ns == 2) LP(2) else LP(4)
+    if (five) LP(1, 5) else if (ns == 1) LP(1, 4) else if (ns == 2) LP(2, 4) else LP(4, 4)
 #undef LP
     return pmc_check_launch("maf_inverse_tri6_kernel<profile>");
 }
