@@ -689,6 +689,24 @@ def main():
                 tf = 5000 * 2 * sp5.macs_masked() / us5 / 1e6
                 flow_cfg5[prec] = {"us_per_call": us5, "rows_per_s": 5000 / us5 * 1e6, "achieved_tflops": tf, "peak_tflops": peak,
                                    "frac": tf / peak, "dense_equivalent_tflops": 5000 * sp5.flops_forward_dense() / us5 / 1e6}
+                if prec == "f32":
+                    # the sweep every MCMC step of this config runs (flow.py:116-132; float32 whatever the flow's precision,
+                    # csrc/maf_inverse_tri6.hip): 5000 walkers are two rounds of 256 workgroups x 16 walkers, 4096 are one
+                    z5 = torch.randn(5000, 128, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+                    inv = {}
+                    for rows in (4096, 5000):
+                        for _ in range(2):
+                            f5.inverse(z5[:rows])
+                        e0.record()
+                        for _ in range(5):
+                            f5.inverse(z5[:rows])
+                        e1.record()
+                        torch.cuda.synchronize()
+                        us_inv = e0.elapsed_time(e1) / 5 * 1e3
+                        tf_inv = rows * 2 * sp5.macs_masked() / us_inv / 1e6
+                        inv[str(rows)] = {"us_per_call": us_inv, "rows_per_s": rows / us_inv * 1e6, "achieved_tflops": tf_inv,
+                                          "peak_tflops": PEAK_F32_MFMA_TFLOPS, "frac": tf_inv / PEAK_F32_MFMA_TFLOPS}
+                    flow_cfg5["inverse_f32"] = inv
                 # Flow.fit's optimizer step at the reference's batch size (sampler.py:289: 512 rows): loss + gradient,
                 # clip, AdamW, image refresh -- the float32 slab kernels against the bf16 per-layer products
                 from pocomc_amd.train import AdamW

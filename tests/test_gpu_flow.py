@@ -87,6 +87,28 @@ def test_one_and_two_wave_sweeps_agree_bit_for_bit(D, T, n):
         assert duo == (1 if n <= 8192 else 0)
 
 
+@pytest.mark.parametrize("n", [1, 33, 700])
+def test_wide_sweep_with_four_and_five_wavefronts_agrees_bit_for_bit(n, monkeypatch):
+    """The lane-per-walker sweep of a wide flow (>= 20 hidden tiles: (D, T, H) = (128, 2, 512)) gives the layer-0
+    partials to a fifth wavefront and assigns the roles by SIMD; PMC_TRI6_FOUR keeps them on the output wavefront.  Same
+    additions in the same order: identical results, and both within 1e-5 of the oracle."""
+    from pocomc_amd.maf_spec import MAFSpec
+    import pocomc_amd as pc
+    spec = MAFSpec(128, 2)
+    f = pc.Flow(128, spec, seed=5)
+    z = torch.randn(n, 128, generator=torch.Generator().manual_seed(n))
+    f.inverse_algo = 0
+    x5, l5 = [t.cpu().numpy() for t in f.inverse(z.cuda())]
+    monkeypatch.setenv("PMC_TRI6_FOUR", "1")
+    x4, l4 = [t.cpu().numpy() for t in f.inverse(z.cuda())]
+    np.testing.assert_array_equal(x5, x4)
+    np.testing.assert_array_equal(l5, l4)
+    f.inverse_algo = 2                                     # D-pass cross-check kernel (no triangular structure used)
+    xd, ld = [t.cpu().numpy() for t in f.inverse(z.cuda())]
+    close(x5, xd, 1e-5)
+    close(l5, ld, 1e-5)
+
+
 def test_triangular_equals_naive_on_device():
     f, _ = make(32, 3)
     z = torch.randn(4096, 32, generator=torch.Generator().manual_seed(0))
