@@ -12,10 +12,29 @@
 //   * three HELPER wavefronts (one per layer: hidden 1, hidden 2, layer 0 + output) multiply everything LEFT of the
 //     diagonal tile with dense v_mfma_f32_16x16x4_f32 against tiles that are already final, for all the walker
 //     subsets of the workgroup from one set of weight fragments, and stage the partial pre-activations in LDS;
-//   * the four wavefronts are coupled by monotonic LDS words ("tiles < v of layer l are final", "partials of tile v-1
+//   * the wavefronts are coupled by monotonic LDS words ("tiles < v of layer l are final", "partials of tile v-1
 //     are staged") instead of workgroup barriers: a wave's DS operations execute in order, so a data store followed
 //     by the word's store needs no wait, and each helper starts on a tile as soon as ITS input layer is final --
 //     h0 of a tile's last group is known three dependent hops before the tile ends.
+//
+// Wide flows (BASELINE configs[4]: D = 128, 8 transforms, H = 512 -> 33 hidden tiles, 16 output tiles; one workgroup of
+// 16 walkers per CU, its three activation arrays take 101 KB of LDS).  In-kernel cycle stamps of workgroup 0
+// (scripts/profile_tri6_config5.py) took this shape from 2.04 ms to 0.69 ms per sweep of <= 4096 walkers:
+//   * a lone wavefront on its SIMD issues one instruction per ~4 cycles, so the helpers were bound by their instruction
+//     count (45 per 16 x 16 block against four 32-cycle MFMAs), not by L2 or the matrix pipe: left_products() below;
+//   * the hand-over words are addressed as LDS explicitly and read through readfirstlane -- as FLAT accesses every
+//     poll waited for the weight fragments its wave had in flight, and a rank word read with a vector load made the
+//     compiler wrap every buffer load that depends on it in a waterfall loop;
+//   * the output wavefront keeps the sums of two output tiles across hidden tiles (a hidden tile adds one h2 tile
+//     instead of a whole row) and starts a new output tile's row one hidden tile ahead of the chain; biases join the
+//     sums when they are staged (as first value of an accumulator the bias load delays the first fragment request);
+//   * flows of >= 20 hidden tiles run FIVE wavefronts: the layer-0 partials move to the fifth, and because two of five
+//     share a SIMD the roles are assigned by SIMD id at run time (chain and output rows get a SIMD to themselves);
+//   * the re-rank between transforms is done by the whole workgroup with the index loads batched (it was one wavefront
+//     with two dependent global loads per element: 20 k cycles per transform).
+// What bounds it now: below ~25 hidden tiles the chain wavefront (~4.2 k cycles per tile), above it the hidden-layer
+// helpers, whose row of T blocks (128 cycles each at the matrix pipe's float32 rate) can only start one tile before
+// it is needed.
 //
 // Same arithmetic as the other sweeps up to the order of additions (float32; parity vs oracle 1e-5 relative).
 #include <stdlib.h>
