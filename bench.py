@@ -557,11 +557,13 @@ def main():
     actual_flops = n_launch * 2 * spec.macs_masked()              # what the triangular sweep needs
     us["maf_inverse_timed_region"] = inv_us_live            # HIP events inside the timed region
     t_inv = inv_us_live * 1e-6
-    fused = eng.pre and spec.univariate == "affine" and spec.tri_ok and spec.nOT <= 8 and args.inverse in ("auto", "triangular")
+    lane_auto = args.inverse in ("auto", "triangular") and bool(lib.pmc_debug_inverse_uses_lane(ctypes.byref(flow._desc)))
+    fused = (eng.pre and spec.univariate == "affine" and spec.tri_ok and spec.nOT <= 8 and not lane_auto
+             and args.inverse in ("auto", "triangular"))
     duo = bool(lib.pmc_debug_inverse_uses_duo(ctypes.byref(flow._desc), n_launch))
     roof_kernel = ("maf_dense_kernel<1>" if (args.inverse == "naive" or not spec.tri_ok) else
                    "maf_inverse_tri_nsf_kernel" if spec.univariate == "rqs" else
-                   "maf_inverse_tri6_kernel" if (args.inverse == "lane" or spec.nOT > 8 or os.environ.get("PMC_INVERSE_LANE", "0") != "0") else
+                   "maf_inverse_tri6_kernel" if (args.inverse == "lane" or lane_auto or os.environ.get("PMC_INVERSE_LANE", "0") != "0") else
                    "maf_inverse_tri4_kernel" if args.inverse == "solo" else
                    "maf_inverse_tri5_kernel" if (args.inverse == "duo" or duo) else "maf_inverse_tri4_kernel")
     # HBM bytes per launch of the dominant kernel: PMC passes cannot run inside this process; the value is the

@@ -376,10 +376,9 @@ static int launch_tri5(const ProposeArgs* pa, const pmc_maf_t* m, const float* z
                        hipStream_t stream);
 
 // PMC_INVERSE_LANE=1: AUTO takes the lane-per-walker sweep (maf_inverse_tri6.hip) wherever it covers the flow (A/B
-// runs).  Default: the register-chain sweeps of this file where they apply (output tiles <= 8, i.e. D <= 64: measured
-// 68-72 us against 84-96 us for up to 8192 rows of maf3 @ D = 32, 768 against 1461 us at D = 50 / maf6), the
-// lane-per-walker sweep for the wider flows (D = 128, 8 transforms: 2.0 ms against 3.4 ms of the LDS-hop sweep it
-// replaced).
+// runs).  Default: the register-chain sweeps of this file for flows of < 16 hidden tiles (maf3 @ D = 32: 61-64 us
+// against 66-83 us for up to 8192 rows), the lane-per-walker sweep for the wider ones (pmc_tri6_preferred: D = 50 / maf6
+// 314 against 650 us, D = 128 / 8 transforms 0.69 ms per round) and for everything with more than 8 output tiles.
 static bool lane_sweep_enabled() {
     static const bool on = getenv("PMC_INVERSE_LANE") && atoi(getenv("PMC_INVERSE_LANE")) != 0;
     return on;
@@ -387,7 +386,7 @@ static bool lane_sweep_enabled() {
 
 int pmc_launch_inverse_tri4(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream,
                             int variant) {
-    if (variant < 0 && lane_sweep_enabled()) {
+    if (variant < 0 && (lane_sweep_enabled() || pmc_tri6_preferred(m))) {
         const int rc = pmc_launch_tri6(nullptr, m, z, x, ladj, n, stream);
         if (rc >= 0) return rc;
     }

@@ -715,18 +715,39 @@ static size_t tri6_lds_bytes(const pmc_maf_t* m, int ns) {
 
 // walker subsets per workgroup: as few as keep the launch in one round (a chain wavefront takes the same time for 16
 // and for 64 walkers; the helpers' share grows with the subsets), as many as the LDS admits otherwise
-static int tri6_subsets(const pmc_maf_t* m, int64_t n) {
+static int tri6_five_min() {
+    static const int v = getenv("PMC_TRI6_FIVE_MIN") ? atoi(getenv("PMC_TRI6_FIVE_MIN")) : 16;   // (A/B runs)
+    return v;
+}
+// the five-wavefront variant: plain inverse of a flow with >= 16 hidden tiles, one or two subsets (the kernel must stay
+// within 256 registers: two wavefronts share a SIMD, and only one such workgroup fits a CU)
+static bool tri6_five(const pmc_maf_t* m, bool fused) {
+    return !fused && m->nT >= tri6_five_min() && !getenv("PMC_TRI6_FOUR");
+}
+static int tri6_subsets(const pmc_maf_t* m, int64_t n, bool fused) {
     static const int forced = getenv("PMC_TRI6_SUBSETS") ? atoi(getenv("PMC_TRI6_SUBSETS")) : 0;
+    const bool five = tri6_five(m, fused);
     int best = 0;
-    for (int ns = 1; ns <= 4; ns *= 2) {
+    for (int ns = 1; ns <= (five ? 2 : 4); ns *= 2) {
         const size_t lds = tri6_lds_bytes(m, ns);
         if (lds > 160 * 1024) break;
         if (forced == ns) return ns;
         best = ns;
-        const int64_t per_cu = (int64_t)((160 * 1024) / lds) < 2 ? (int64_t)((160 * 1024) / lds) : 2;   // 4 waves each, one chain per SIMD pair
-        if ((n + 16 * ns - 1) / (16 * ns) <= 256 * per_cu) break;
+        int64_t per_cu = (int64_t)((160 * 1024) / lds) < 2 ? (int64_t)((160 * 1024) / lds) : 2;   // 4 waves each, one chain per SIMD pair
+        if (five) per_cu = 1;
+        if (!forced && (n + 16 * ns - 1) / (16 * ns) <= 256 * per_cu) break;
     }
     return best;
+}
+
+// AUTO's choice between this sweep and the register-chain sweeps of maf_inverse_tri4.hip for the flows both cover
+// (D <= 64): with >= 16 hidden tiles the five-wavefront variant is faster -- D = 50 / maf6 (25 tiles): 314 us per round
+// of <= 4096 walkers against 645-650 us of the two-wave sweep for <= 8192; D = 64 / maf3 (17 tiles): 120 against 160 us --
+// below that the two-wave sweep is (D = 32 / maf3, 9 tiles: 61-64 against 66-83 us).  The step then launches the
+// proposal and the scaler on their own (the fused instances of this kernel need more than 256 registers).
+bool pmc_tri6_preferred(const pmc_maf_t* m) {
+    if (m->n_out != 2 || !m->tri_ok || m->pk_per_transform * 4 > 0x7fffffffLL) return false;
+    return tri6_five(m, false) && tri6_lds_bytes(m, 1) <= 160 * 1024;
 }
 
 // same contract as pmc_launch_inverse_tri4 / pmc_launch_propose_inverse_tri4 (pa == nullptr: plain inverse of z);
@@ -736,14 +757,14 @@ int pmc_launch_tri6(const ProposeArgs* pa, const pmc_maf_t* m, const float* z, f
     if (m->n_out != 2 || !m->tri_ok) return -1;
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
     if (pa && m->D > 64) return -1;
-    const int ns = tri6_subsets(m, n);
+    const int ns = tri6_subsets(m, n, pa != nullptr);
     if (ns == 0) return -1;
     const size_t lds = tri6_lds_bytes(m, ns);
     const ProposeArgs none{};
     const unsigned grid = (unsigned)((n + 16 * ns - 1) / (16 * ns));
     // wide flows (helpers saturated: their work grows with the hidden tiles, the chain's does not) get a fifth wavefront for
     // the layer-0 partials; it needs the kernel in 256 registers (two wavefronts on one SIMD): plain inverse, one subset
-    const bool five = !pa && ns == 1 && m->nT >= 20 && !getenv("PMC_TRI6_FOUR");
+    const bool five = tri6_five(m, pa != nullptr) && ns <= 2;
 #define LAUNCH6(NSV, FMV, NWV)                                                                                     \
     {                                                                                                              \
         if (lds > 48 * 1024) {                                                                                     \
@@ -756,7 +777,7 @@ int pmc_launch_tri6(const ProposeArgs* pa, const pmc_maf_t* m, const float* z, f
     }
 #define LAUNCH6F(FMV)                                                                                              \
     { if (ns == 1) LAUNCH6(1, FMV, 4) else if (ns == 2) LAUNCH6(2, FMV, 4) else LAUNCH6(4, FMV, 4) }
-    if (five) LAUNCH6(1, 0, 5)
+    if (five) { if (ns == 1) LAUNCH6(1, 0, 5) else LAUNCH6(2, 0, 5) }
     else if (!pa) LAUNCH6F(0)
     else if (m->D <= 16) LAUNCH6F(4)
     else if (m->D <= 32) LAUNCH6F(8)
@@ -766,17 +787,23 @@ int pmc_launch_tri6(const ProposeArgs* pa, const pmc_maf_t* m, const float* z, f
     return pmc_check_launch("maf_inverse_tri6_kernel");
 }
 
+// whether PMC_INVERSE_AUTO (and with it the MCMC step) takes this sweep for the flow (bench.py names the kernel it times)
+extern "C" int pmc_debug_inverse_uses_lane(const pmc_maf_t* m) {
+    if (!m || m->n_out != 2 || !m->tri_ok) return 0;
+    return (m->nOT > 8 || pmc_tri6_preferred(m)) ? 1 : 0;
+}
+
 // measurement only (scripts/profile_tri6.py): cycle stamps of workgroup 0 -- prof[transform * nT + tile][wave 0..3][4]
 extern "C" int pmc_debug_tri6_profile(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, long long* prof,
                                       void* stream) {
     ProposeArgs pa{};
     pa.prof = prof;
     // (FM = 0 instances read nothing else of pa)
-    const int ns = tri6_subsets(m, n);
+    const int ns = tri6_subsets(m, n, false);
     if (ns == 0 || m->n_out != 2 || !m->tri_ok) return pmc_fail("pmc_debug_tri6_profile: flow not covered");
     const size_t lds = tri6_lds_bytes(m, ns);
     const unsigned grid = (unsigned)((n + 16 * ns - 1) / (16 * ns));
-    const bool five = ns == 1 && m->nT >= 20 && !getenv("PMC_TRI6_FOUR");
+    const bool five = tri6_five(m, false) && ns <= 2;
 #define LP(NSV, NWV)                                                                                               \
     {                                                                                                              \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri6_kernel<NSV, 0, NWV>), \
@@ -784,7 +811,7 @@ extern "C" int pmc_debug_tri6_profile(const pmc_maf_t* m, const float* z, float*
         hipLaunchKernelGGL((maf_inverse_tri6_kernel<NSV, 0, NWV>), dim3(grid), dim3(64 * NWV), lds, (hipStream_t)stream, *m, z, \
                            x, ladj, n, pa);                                                                        \
     }
-    if (five) LP(1, 5) else if (ns == 1) LP(1, 4) else if (ns == 2) LP(2, 4) else LP(4, 4)
+    if (five) { if (ns == 1) LP(1, 5) else LP(2, 5) } else if (ns == 1) LP(1, 4) else if (ns == 2) LP(2, 4) else LP(4, 4)
 #undef LP
     return pmc_check_launch("maf_inverse_tri6_kernel<profile>");
 }

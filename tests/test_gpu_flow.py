@@ -77,9 +77,14 @@ def test_one_and_two_wave_sweeps_agree_bit_for_bit(D, T, n):
         f.inverse_algo = algo
         out[algo] = [t.numpy() for t in f.inverse(z)]
     f.inverse_algo = 0
-    for a in (7, 0):
-        np.testing.assert_array_equal(out[a][0], out[6][0])
-        np.testing.assert_array_equal(out[a][1], out[6][1])
+    np.testing.assert_array_equal(out[7][0], out[6][0])
+    np.testing.assert_array_equal(out[7][1], out[6][1])
+    if f.spec.nT < 16:             # (from 16 hidden tiles on AUTO is the lane-per-walker sweep: another order of additions)
+        np.testing.assert_array_equal(out[0][0], out[6][0])
+        np.testing.assert_array_equal(out[0][1], out[6][1])
+    else:
+        close(out[0][0], out[6][0])
+        close(out[0][1], out[6][1])
     import ctypes as C
     from pocomc_amd import _lib
     duo = _lib.load().pmc_debug_inverse_uses_duo(C.byref(f._desc), n)

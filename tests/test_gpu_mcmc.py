@@ -308,7 +308,8 @@ def test_fused_proposal_and_inverse_equal_the_two_launches(D, N, kind):
                                float((1 - 0.4 ** 2) ** 0.5), C.byref(r), _lib.ptr(t64), _lib.ptr(t32), _lib.ptr(qa),
                                _lib.ptr(qb), N, D, st))
     u_a, l_a = mk(N, D, dt=torch.float32), mk(N, dt=torch.float32)
-    _lib.check(lib.pmc_maf_inverse(C.byref(flow._desc), _lib.ptr(t32), _lib.ptr(u_a), _lib.ptr(l_a), N, 0, st))
+    # (the sweep the fused launch contains: two waves per 16 rows -- AUTO would take the lane-per-walker sweep at D = 50)
+    _lib.check(lib.pmc_maf_inverse(C.byref(flow._desc), _lib.ptr(t32), _lib.ptr(u_a), _lib.ptr(l_a), N, 7, st))
     # one launch
     t64f, qaf, qbf = mk(N, D), mk(N), mk(N)
     u_b, l_b = mk(N, D, dt=torch.float32), mk(N, dt=torch.float32)
