@@ -530,13 +530,19 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                     *reinterpret_cast<float4*>(SP0 + (sb * 16 + p) * SPAD + 4 * q) = b0;
                 publish(flags, F_P0, gen + 1);
             }
-            for (int T = 0; T < nT; ++T) {
-                int4 dg = *reinterpret_cast<const int4*>(quad_meta + 4 * T);
-                // (the same words in every lane; said explicitly, the compiler keeps what follows from them in scalar registers --
-                // otherwise every buffer load whose offset depends on a rank is wrapped in a waterfall loop)
-                dg.x = __builtin_amdgcn_readfirstlane(dg.x & 0xffff); dg.y = __builtin_amdgcn_readfirstlane(dg.y & 0xffff);
-                dg.z = __builtin_amdgcn_readfirstlane(dg.z & 0xffff); dg.w = __builtin_amdgcn_readfirstlane(dg.w & 0xffff);
-                if (dg.x >= D && dg.y >= D && dg.z >= D && dg.w >= D) break;
+            // the tiles' rank words: lane T loads tile T's once per transform, a tile reads them with v_readlane (a global
+            // load + readfirstlane per tile put an L2 round trip at the head of every helper tile); live tiles are a prefix
+            int4 dgl = make_int4(D, D, D, D);
+            if (lane < nT) dgl = *reinterpret_cast<const int4*>(quad_meta + 4 * lane);
+            dgl.x &= 0xffff; dgl.y &= 0xffff; dgl.z &= 0xffff; dgl.w &= 0xffff;
+            const int nTr = __builtin_amdgcn_readfirstlane(
+                __builtin_popcountll(__builtin_amdgcn_ballot_w64(dgl.x < D || dgl.y < D || dgl.z < D || dgl.w < D)));
+            for (int T = 0; T < nTr; ++T) {
+                // (uniform, and said so: what follows from the rank words stays in scalar registers -- otherwise every buffer
+                // load whose offset depends on a rank is wrapped in a waterfall loop)
+                int4 dg;
+                dg.x = __builtin_amdgcn_readlane(dgl.x, T); dg.y = __builtin_amdgcn_readlane(dgl.y, T);
+                dg.z = __builtin_amdgcn_readlane(dgl.z, T); dg.w = __builtin_amdgcn_readlane(dgl.w, T);
                 long long* pf = (pa.prof && blockIdx.x == 0 && wv < 4) ? pa.prof + ((size_t)((Tn - 1 - t) * nT + T) * 4 + wv) * 4 : nullptr;
                 if (pf && lane == 0) { pf[0] = clock64(); if (T == 0) pf[2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4); }
                 int gfirst = dg.x, glast = dg.x;
@@ -636,10 +642,10 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                         // ---- ahead of the chain: a NEW output tile of the next hidden tile starts its row now, over the
                         // h2 tiles that are final (all before this one), while the chain works through this tile -- the
                         // next tile then only adds one h2 tile to each of its sums
-                        int4 dn = *reinterpret_cast<const int4*>(quad_meta + 4 * (T + 1));
-                        dn.x = __builtin_amdgcn_readfirstlane(dn.x & 0xffff); dn.y = __builtin_amdgcn_readfirstlane(dn.y & 0xffff);
-                        dn.z = __builtin_amdgcn_readfirstlane(dn.z & 0xffff); dn.w = __builtin_amdgcn_readfirstlane(dn.w & 0xffff);
-                        if (dn.x < D) {
+                        int4 dn;
+                        dn.x = __builtin_amdgcn_readlane(dgl.x, T + 1); dn.y = __builtin_amdgcn_readlane(dgl.y, T + 1);
+                        dn.z = __builtin_amdgcn_readlane(dgl.z, T + 1); dn.w = __builtin_amdgcn_readlane(dgl.w, T + 1);
+                        if (T + 1 < nTr && dn.x < D) {
                             int nlast = dn.x;
                             if (dn.y < D) nlast = dn.y;
                             if (dn.z < D) nlast = dn.z;
@@ -733,9 +739,8 @@ static int tri6_subsets(const pmc_maf_t* m, int64_t n, bool fused) {
         if (lds > 160 * 1024) break;
         if (forced == ns) return ns;
         best = ns;
-        int64_t per_cu = (int64_t)((160 * 1024) / lds) < 2 ? (int64_t)((160 * 1024) / lds) : 2;   // 4 waves each, one chain per SIMD pair
-        if (five) per_cu = 1;
-        if (!forced && (n + 16 * ns - 1) / (16 * ns) <= 256 * per_cu) break;
+        // one workgroup per CU: the five-wave variant by construction, the four-wave instances by their registers (264-416)
+        if (!forced && (n + 16 * ns - 1) / (16 * ns) <= 256) break;
     }
     return best;
 }
@@ -757,6 +762,7 @@ int pmc_launch_tri6(const ProposeArgs* pa, const pmc_maf_t* m, const float* z, f
     if (m->n_out != 2 || !m->tri_ok) return -1;
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
     if (pa && m->D > 64) return -1;
+    if (m->nT > 64) return -1;                           // (a lane per hidden tile holds its rank words)
     const int ns = tri6_subsets(m, n, pa != nullptr);
     if (ns == 0) return -1;
     const size_t lds = tri6_lds_bytes(m, ns);
