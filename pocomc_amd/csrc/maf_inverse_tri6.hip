@@ -128,11 +128,23 @@ __device__ __forceinline__ void take(const int* flags, int which, int value, LOA
 // counts of the merged paths conservative), the last tiles (fewer than three chunks, two of them already loaded)
 // follow it behind one uniform branch each.  The empty asm and the scheduling barriers keep the compiler from moving a
 // set's loads down to the stage that multiplies them.
-template <int NS, int C, class READY>
-__device__ __forceinline__ void left_products(f32x4 (&acc)[NS], f32x4 (&acd)[NS], __amdgpu_buffer_rsrc_t rs, int vo_lane,
-                                              int base, const float* Hin, int szH, int Kn, int lane, READY&& ready) {
+// PRE: the caller requested the row's first two chunks into w0 / w1 already (first_chunks() below: the hidden-layer helpers
+// do it for their NEXT row while they wait for the last input tile of the current one).
+template <int C>
+__device__ __forceinline__ void first_chunks(float4 (&w0)[C], float4 (&w1)[C], __amdgpu_buffer_rsrc_t rs, int vo_lane, int base,
+                                             int Kn) {
+#pragma unroll
+    for (int j = 0; j < C; ++j) w0[j] = bload4(rs, vo_lane + j * 1024, base);
+    const int so = base + ((C < Kn ? C : 0) << 10);
+#pragma unroll
+    for (int j = 0; j < C; ++j) w1[j] = bload4(rs, vo_lane + j * 1024, so);
+}
+template <int NS, int C, bool PRE, class READY>
+__device__ __forceinline__ void left_products_w(f32x4 (&acc)[NS], f32x4 (&acd)[NS], __amdgpu_buffer_rsrc_t rs, int vo_lane,
+                                                int base, const float* Hin, int szH, int Kn, int lane, float4 (&w0)[C],
+                                                float4 (&w1)[C], READY&& ready) {
     if (Kn <= 0) return;
-    float4 w0[C], w1[C], w2[C], b0[C][NS], b1[C][NS], b2[C][NS];
+    float4 w2[C], b0[C][NS], b1[C][NS], b2[C][NS];
     const float* hl = Hin + (lane << 2);
     // chunk at tile Kc (a chunk that starts beyond the row is not used: tile 0 instead, always inside the arrays)
     auto loadw = [&](float4 (&w)[C], int Kc) __attribute__((always_inline)) {
@@ -161,7 +173,7 @@ __device__ __forceinline__ void left_products(f32x4 (&acc)[NS], f32x4 (&acd)[NS]
         _Pragma("unroll") for (int j = 0; j < C; ++j) mma1(MW[j], MB[j]);                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
         K0 += C;
-    loadw(w0, 0); loadw(w1, C);
+    if constexpr (!PRE) { loadw(w0, 0); loadw(w1, C); }
     asm volatile("" ::: "memory");
     ready();                                              // (the wait for the tiles' word, behind the first fragments' loads)
     loadb(b0, 0); loadb(b1, C);
@@ -183,6 +195,13 @@ __device__ __forceinline__ void left_products(f32x4 (&acc)[NS], f32x4 (&acd)[NS]
     for (int j = 0; j < C; ++j) if (K0 + C + j < Kn) mma1(w1[j], b1[j]);
 #pragma unroll
     for (int j = 0; j < C; ++j) if (K0 + 2 * C + j < Kn) mma1(w2[j], b2[j]);
+}
+
+template <int NS, int C, class READY>
+__device__ __forceinline__ void left_products(f32x4 (&acc)[NS], f32x4 (&acd)[NS], __amdgpu_buffer_rsrc_t rs, int vo_lane,
+                                              int base, const float* Hin, int szH, int Kn, int lane, READY&& ready) {
+    float4 w0[C], w1[C];
+    left_products_w<NS, C, false>(acc, acd, rs, vo_lane, base, Hin, szH, Kn, lane, w0, w1, ready);
 }
 
 // One degree group of the tile (quads c0..c1), then the next (compile-time recursion over the quad pattern).
@@ -495,26 +514,7 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
             auto need = [&](int K) {                       // tile K of the input layer must be final
                 if (known < gen + K + 1) { wait_for(flags, f_in, gen + K + 1); known = peek(flags, f_in); }
             };
-            // acc/acd[sb] += sum_{K < T} frag[K] . Hin[sb][K]: the tiles before the last are final as soon as the one before
-            // the last is (pipelined: left_products), the last tile of the input layer is awaited right before its use with
-            // its fragment already in registers
             constexpr int CH = NS <= 2 ? 4 : 2;
-#define KLOOP(BASE, KBEG)                                                                                           \
-            if (T > (KBEG)) {                                                                                       \
-                const int base_ = (BASE), kb_ = (KBEG);                                                             \
-                const float4 w = bload4(rs, vo_lane, base_ + (T - 1) * 1024);                                       \
-                if (T - 1 > kb_)                                                                                    \
-                    left_products<NS, CH>(acc, acd, rs, vo_lane, base_ + kb_ * 1024, Hin + (kb_ << 8), szH, T - 1 - kb_, lane, \
-                                          [&]() __attribute__((always_inline)) { need(T - 2); });                   \
-                if (pf && lane == 0) pf[1] = clock64();                                                             \
-                need(T - 1);                                                                                        \
-                if (pf && lane == 0) pf[2] = clock64();                                                             \
-                _Pragma("unroll") for (int sb = 0; sb < NS; ++sb) {                                                 \
-                    const float4 b = *reinterpret_cast<const float4*>(Hin + sb * szH + ((T - 1) << 8) + (lane << 2)); \
-                    acc[sb] = MFMA(w.x, b.x, acc[sb]); acd[sb] = MFMA(w.y, b.y, acd[sb]);                           \
-                    acc[sb] = MFMA(w.z, b.z, acc[sb]); acd[sb] = MFMA(w.w, b.w, acd[sb]);                           \
-                }                                                                                                   \
-            }
             // wave 3 keeps the sums of two output tiles (slot = tile & 1) across the hidden tiles: consecutive hidden tiles
             // share their output tiles (8 ranks each), so a hidden tile adds only the h2 tiles that became final since the
             // slot was last staged instead of summing from tile 0 again (same order of additions, same bits); a new output
@@ -537,6 +537,10 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
             dgl.x &= 0xffff; dgl.y &= 0xffff; dgl.z &= 0xffff; dgl.w &= 0xffff;
             const int nTr = __builtin_amdgcn_readfirstlane(
                 __builtin_popcountll(__builtin_amdgcn_ballot_w64(dgl.x < D || dgl.y < D || dgl.z < D || dgl.w < D)));
+            if (wv == 1 || wv == 2) {
+            // hidden-layer helpers: what the current row needs first -- requested a tile ahead (row 0: its bias only)
+            float4 hw0[CH], hw1[CH], hwl = make_float4(0.f, 0.f, 0.f, 0.f), hbb = hwl;
+            if (wv == 1 || wv == 2) hbb = bload4(rs, vo_q, oB);
             for (int T = 0; T < nTr; ++T) {
                 // (uniform, and said so: what follows from the rank words stays in scalar registers -- otherwise every buffer
                 // load whose offset depends on a rank is wrapped in a waterfall loop)
@@ -550,21 +554,61 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                 if (dg.z < D) glast = dg.z;
                 if (dg.w < D) glast = dg.w;
                 if (wv == 1 || wv == 2) {
-                    const float4 bb = bload4(rs, vo_q, oB + 64 * T);
                     f32x4 acc[NS], acd[NS];
                     // (the bias joins the sum when it is staged: as the accumulator's first value its load would have to land
                     // before the first fragment is even requested)
                     for (int sb = 0; sb < NS; ++sb) { acc[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; acd[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                    KLOOP(oF + (T * nT) * 1024, 0)
+                    const int base_ = oF + (T * nT) * 1024;
+                    // acc/acd[sb] += sum_{K < T} frag[K] . Hin[sb][K]: the tiles before the last are final as soon as the one
+                    // before the last is (pipelined: left_products), the last tile of the input layer is awaited right before
+                    // its use; this row's first fragments, its last one and its bias were requested a tile ago (hw0, hw1, hwl,
+                    // hbb), the NEXT row's are requested before the wait
+                    if (T > 1)
+                        left_products_w<NS, CH, true>(acc, acd, rs, vo_lane, base_, Hin, szH, T - 1, lane, hw0, hw1,
+                                                      [&]() __attribute__((always_inline)) { need(T - 2); });
+                    float4 nbb = hbb, nwl = hwl;
+                    if (T + 1 < nTr) {
+                        const int basen = base_ + nT * 1024;
+                        nbb = bload4(rs, vo_q, oB + 64 * (T + 1));
+                        nwl = bload4(rs, vo_lane, basen + T * 1024);
+                        if (T > 0) first_chunks<CH>(hw0, hw1, rs, vo_lane, basen, T);
+                        asm volatile("" ::: "memory");
+                    }
+                    if (T > 0) {
+                        if (pf && lane == 0) pf[1] = clock64();
+                        need(T - 1);
+                        if (pf && lane == 0) pf[2] = clock64();
+#pragma unroll
+                        for (int sb = 0; sb < NS; ++sb) {
+                            const float4 b = *reinterpret_cast<const float4*>(Hin + sb * szH + ((T - 1) << 8) + (lane << 2));
+                            acc[sb] = MFMA(hwl.x, b.x, acc[sb]); acd[sb] = MFMA(hwl.y, b.y, acd[sb]);
+                            acc[sb] = MFMA(hwl.z, b.z, acc[sb]); acd[sb] = MFMA(hwl.w, b.w, acd[sb]);
+                        }
+                    }
                     float* sp = SP + (T & 1) * (NS * 16 * SPAD);
 #pragma unroll
                     for (int sb = 0; sb < NS; ++sb)
                         *reinterpret_cast<float4*>(sp + (sb * 16 + p) * SPAD + 4 * q) =
-                            make_float4((acc[sb][0] + acd[sb][0]) + bb.x, (acc[sb][1] + acd[sb][1]) + bb.y,
-                                        (acc[sb][2] + acd[sb][2]) + bb.z, (acc[sb][3] + acd[sb][3]) + bb.w);
+                            make_float4((acc[sb][0] + acd[sb][0]) + hbb.x, (acc[sb][1] + acd[sb][1]) + hbb.y,
+                                        (acc[sb][2] + acd[sb][2]) + hbb.z, (acc[sb][3] + acd[sb][3]) + hbb.w);
                     publish(flags, f_out, gen + T + 1);
                     if (pf && lane == 0) pf[3] = clock64();
+                    hbb = nbb; hwl = nwl;
                 }
+            }
+            } else {
+            for (int T = 0; T < nTr; ++T) {
+                // (uniform, and said so: what follows from the rank words stays in scalar registers -- otherwise every buffer
+                // load whose offset depends on a rank is wrapped in a waterfall loop)
+                int4 dg;
+                dg.x = __builtin_amdgcn_readlane(dgl.x, T); dg.y = __builtin_amdgcn_readlane(dgl.y, T);
+                dg.z = __builtin_amdgcn_readlane(dgl.z, T); dg.w = __builtin_amdgcn_readlane(dgl.w, T);
+                long long* pf = (pa.prof && blockIdx.x == 0 && wv < 4) ? pa.prof + ((size_t)((Tn - 1 - t) * nT + T) * 4 + wv) * 4 : nullptr;
+                if (pf && lane == 0) { pf[0] = clock64(); if (T == 0) pf[2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4); }
+                int gfirst = dg.x, glast = dg.x;
+                if (dg.y < D) glast = dg.y;
+                if (dg.z < D) glast = dg.z;
+                if (dg.w < D) glast = dg.w;
                 if (wv == 3) {
                     // ---- output partials of this tile's ranks: output tile(s) O = rank >> 3 against h2 of tiles < T
                     const int O0 = gfirst >> 3, O1 = glast >> 3;
@@ -666,8 +710,8 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                     }
                 }
             }
+            }
         }
-#undef KLOOP
         __syncthreads();
         // re-rank for the next transform (or write out) with every thread of the workgroup: the target rank of a rank is two
         // dependent global loads, so eight elements' worth are requested together (one wavefront walking the subset's
