@@ -236,7 +236,7 @@ def main():
                     help="fraction of the walkers in the first of two lanes (0.5 = equal).  The sweeps of the two lanes run one "
                          "after the other and cost the same whatever their size; a larger first lane puts more of the host "
                          "likelihood behind the second sweep: measured 2605 (0.5) / 2767 (0.65) / 2844 (0.7) / 2843 (0.8) steps/s")
-    ap.add_argument("--flow", default="maf3", help="maf3 | maf6 | maf12 | nsf3 | nsf6 | nsf12 (BASELINE configs use maf3)")
+    ap.add_argument("--flow", default="maf3", help="maf3 | maf6 | maf12 | nsf3 | nsf6 | nsf12 | customN = N-transform MAF (BASELINE configs use maf3; configs[4] is custom8 at --dim 128 --particles 5000)")
     ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "solo", "duo", "lane"], default="auto")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -296,7 +296,11 @@ def main():
     logdetj = scaler.inverse(u)[1]
     target = make_target(args.target, D)
     logl, logp = target(x), prior.logpdf(x)
-    flow = Flow(D, args.flow, seed=0)                       # replicated weights
+    if args.flow.startswith("custom"):                      # customN: N-transform MAF with the default hidden width (configs[4]: custom8 @ 128-D)
+        from pocomc_amd.maf_spec import MAFSpec
+        flow = Flow(D, MAFSpec(D, int(args.flow[6:])), seed=0)
+    else:
+        flow = Flow(D, args.flow, seed=0)                   # replicated weights
     flow.inverse_algo = {"auto": 0, "triangular": 1, "naive": 2, "solo": 6, "duo": 7, "lane": 8}[args.inverse]
     torch.manual_seed(0)                                    # same shuffles / batches on every rank
     u_fit = torch.from_numpy(scaler.forward(x_fit[:n])).float().cuda()
