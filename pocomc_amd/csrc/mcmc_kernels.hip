@@ -331,21 +331,33 @@ __global__ __launch_bounds__(256) void accept_kernel(
         const int j = j0 + tx;
         double csum = 0.0;
         if (j < D) {
+            // all eight rows' operands are requested before the first is used (one row at a time each load pair waited for
+            // the previous row's: eight L2 round trips in a row); the sums keep their order
+            double pu[ACC_ROWS / 8], px[ACC_ROWS / 8], cu[ACC_ROWS / 8];
+            float thn[ACC_ROWS / 8], tho[ACC_ROWS / 8];
+#pragma unroll
+            for (int i = 0; i < ACC_ROWS / 8; ++i) {
+                const int r = ty + 8 * i;
+                pu[i] = px[i] = cu[i] = 0.0; thn[i] = tho[i] = 0.0f;
+                if (r < rows) {
+                    const int64_t g = (row0 + r) * D + j;
+                    pu[i] = prop.u[g]; px[i] = prop.x[g];
+                    if (preconditioned) { thn[i] = (float)prop.theta64[g]; tho[i] = cur.theta32[g]; }   // theta is a float32 array (tools.py:339)
+                    else cu[i] = cur.u[g];
+                }
+            }
 #pragma unroll
             for (int i = 0; i < ACC_ROWS / 8; ++i) {
                 const int r = ty + 8 * i;
                 if (r < rows) {
                     const int64_t g = (row0 + r) * D + j;
                     const int a = flag[r];
-                    const double pu = prop.u[g], px = prop.x[g];
-                    if (a) { cur.u[g] = pu; cur.x[g] = px; }
+                    if (a) { cur.u[g] = pu[i]; cur.x[g] = px[i]; }
                     if (preconditioned) {
-                        const float th_new = (float)prop.theta64[g];            // theta is a float32 array (tools.py:339)
-                        const float th_old = cur.theta32[g];
-                        if (a) cur.theta32[g] = th_new;
-                        csum += (double)(a ? th_new : th_old);
+                        if (a) cur.theta32[g] = thn[i];
+                        csum += (double)(a ? thn[i] : tho[i]);
                     } else {
-                        csum += a ? pu : cur.u[g];
+                        csum += a ? pu[i] : cu[i];
                     }
                 }
             }
@@ -380,8 +392,20 @@ __global__ __launch_bounds__(256) void accept_kernel(
         const int S = max(1, 256 / Wc);
         const int c = tid % Wc, sidx = tid / Wc;
         double t = 0.0;
-        if (sidx < S)
-            for (int b2 = sidx; b2 < nb; b2 += S) t += partials[(size_t)b2 * W + c0 + c];
+        if (sidx < S) {
+            // (the partials of 16 blocks requested at once, added in the same order as one by one)
+            for (int b0 = sidx; b0 < nb; b0 += 16 * S) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int b2 = b0 + u * S;
+                    v[u] = b2 < nb ? partials[(size_t)b2 * W + c0 + c] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (b0 + u * S < nb) t += v[u];
+            }
+        }
         fold[tid] = (sidx < S) ? t : 0.0;
         __syncthreads();
         if (tid < Wc) {
