@@ -42,14 +42,17 @@ __device__ __forceinline__ void matvec16(const double* __restrict__ mat, int D, 
         if (16 * it < D) {
             f64x4 acc = {0.0, 0.0, 0.0, 0.0};
             const int i = 16 * it + i_l;
+            // (the row tile's operands are all requested before the first product: one at a time, a wide proposal --
+            // D = 128: 640 products per wavefront -- paid an L2 round trip per product; same products, same order)
+            double a[M];
 #pragma unroll
             for (int k = 0; k < M; ++k) {
-                if (4 * k < D && (!LOWER || 4 * k <= 16 * it + 15)) {
-                    const int j = 4 * k + q;
-                    const double a = (i < D && j < D) ? mat[(size_t)i * D + j] : 0.0;
-                    acc = DMFMA(a, vec[k], acc);
-                }
+                const int j = 4 * k + q;
+                a[k] = (4 * k < D && (!LOWER || 4 * k <= 16 * it + 15) && i < D && j < D) ? mat[(size_t)i * D + j] : 0.0;
             }
+#pragma unroll
+            for (int k = 0; k < M; ++k)
+                if (4 * k < D && (!LOWER || 4 * k <= 16 * it + 15)) acc = DMFMA(a[k], vec[k], acc);
             res[4 * it + 0] = acc[0]; res[4 * it + 1] = acc[1]; res[4 * it + 2] = acc[2]; res[4 * it + 3] = acc[3];
         }
     }
