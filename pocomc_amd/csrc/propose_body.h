@@ -33,6 +33,34 @@ __device__ __forceinline__ double quad_sum_d(double v) {
 
 // acc[it][r] = sum_j MAT[16*it + q + 4r][j] * vec[j]   for the lane's walker
 // LOWER: MAT is lower-triangular, K steps above the diagonal tile are skipped.
+// The lane's A operands of a whole matrix (frag[it][k] = MAT[16 it + (lane & 15)][4 k + q]) requested ahead of the
+// products: small proposals (M <= 8) keep both matrices in registers from the start of the kernel -- the loads are in
+// flight while the variates are generated, and the second quadratic form reuses S.  Same products in the same order.
+template <int M, bool LOWER>
+__device__ __forceinline__ void matfrag16(const double* __restrict__ mat, int D, double (&frag)[M / 4][M], int q, int p_lane) {
+#pragma unroll
+    for (int it = 0; it < M / 4; ++it) {
+        const int i = 16 * it + p_lane;
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+            const int j = 4 * k + q;
+            frag[it][k] = (16 * it < D && 4 * k < D && (!LOWER || 4 * k <= 16 * it + 15) && i < D && j < D) ? mat[(size_t)i * D + j] : 0.0;
+        }
+    }
+}
+template <int M, bool LOWER>
+__device__ __forceinline__ void matvec16_frag(const double (&frag)[M / 4][M], int D, const double (&vec)[M], double (&res)[M]) {
+#pragma unroll
+    for (int it = 0; it < M / 4; ++it) {
+        if (16 * it < D) {
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < M; ++k)
+                if (4 * k < D && (!LOWER || 4 * k <= 16 * it + 15)) acc = DMFMA(frag[it][k], vec[k], acc);
+            res[4 * it + 0] = acc[0]; res[4 * it + 1] = acc[1]; res[4 * it + 2] = acc[2]; res[4 * it + 3] = acc[3];
+        }
+    }
+}
 template <int M, bool LOWER>
 __device__ __forceinline__ void matvec16(const double* __restrict__ mat, int D, const double (&vec)[M],
                                          double (&res)[M], int q, int p_lane) {
@@ -76,6 +104,12 @@ __device__ __forceinline__ void propose_body(
     const bool tpcn = (kind == PMC_KIND_TPCN);
 
     // coordinates j = q + 4m of the walker: current position (minus mu for tpCN), noise
+    constexpr bool FRAG = M <= 8;                         // both matrices in registers (2 x M^2 / 4 doubles per lane)
+    double fS[FRAG ? M / 4 : 1][FRAG ? M : 1], fL[FRAG ? M / 4 : 1][FRAG ? M : 1];
+    if constexpr (FRAG) {
+        if (tpcn) matfrag16<M, false>(inv_cov, D, fS, q, p);
+        matfrag16<M, true>(chol, D, fL, q, p);
+    }
     double dif[M], zz[M], muv[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
@@ -86,24 +120,40 @@ __device__ __forceinline__ void propose_body(
             if (live) {
                 v = cur32 ? (double)cur32[k_w * D + j] : cur64[k_w * D + j];
                 if (rng.normal) z = rng.normal[k_w * D + j];
-                else {
-                    Philox ph(rng.seed, rng.step, gidx, 1);
-                    ph.ctr[0] = (uint32_t)(j >> 1);              // pair index: same stream as a sequential walk
-                    double a, b;
-                    ph.normal2(a, b);
-                    z = (j & 1) ? b : a;
-                }
             }
         }
         muv[m] = mj;
         dif[m] = tpcn ? v - mj : v;
         zz[m] = z;
     }
+    if (!rng.normal) {
+        // Box-Muller pair (j >> 1) serves coordinates j and j ^ 1, which lanes q and q ^ 1 of the walker hold at the same
+        // m.  Of every two m the lane generates ONE pair -- m = 2 i + (q & 1) -- keeps its half and hands the partner the
+        // other (one double over the 16-lane distance); the partner does the same for the other m: half the Philox rounds
+        // and transcendentals, every lane busy in every round, same values.
+        static_assert(M % 2 == 0, "coordinates come in pairs of m");
+        const int odd = q & 1;
+#pragma unroll
+        for (int i = 0; i < M / 2; ++i) {
+            const int j = q + 4 * (2 * i + odd);
+            double a = 0.0, b = 0.0;
+            if ((j & ~1) < D && live) {                       // (the pair's even member exists)
+                Philox ph(rng.seed, rng.step, gidx, 1);
+                ph.ctr[0] = (uint32_t)(j >> 1);              // pair index: same stream as a sequential walk
+                ph.normal2(a, b);
+            }
+            const double own = odd ? b : a, got = __shfl_xor(odd ? a : b, 16);
+            const double z0 = odd ? got : own, z1 = odd ? own : got;     // m = 2 i and m = 2 i + 1
+            if (q + 4 * (2 * i) < D && live) zz[2 * i] = z0;
+            if (q + 4 * (2 * i + 1) < D && live) zz[2 * i + 1] = z1;
+        }
+    }
 
     double scale_z = sigma, q_cur = 0.0;
     double tmp[M];
     if (tpcn) {
-        matvec16<M, false>(inv_cov, D, dif, tmp, q, p);         // rows q+4m of S.diff
+        if constexpr (FRAG) matvec16_frag<M, false>(fS, D, dif, tmp);
+        else matvec16<M, false>(inv_cov, D, dif, tmp, q, p);         // rows q+4m of S.diff
         double part = 0.0;
 #pragma unroll
         for (int m = 0; m < M; ++m) part += dif[m] * tmp[m];
@@ -114,7 +164,8 @@ __device__ __forceinline__ void propose_body(
         const double s = 1.0 / ((2.0 / (nu + q_cur)) * g);       // 1/np.random.gamma(shape, scale), mcmc.py:80
         scale_z = sigma * sqrt(s);
     }
-    matvec16<M, true>(chol, D, zz, tmp, q, p);                  // rows q+4m of L.z
+    if constexpr (FRAG) matvec16_frag<M, true>(fL, D, zz, tmp);
+    else matvec16<M, true>(chol, D, zz, tmp, q, p);                  // rows q+4m of L.z
     double prop[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
@@ -125,7 +176,8 @@ __device__ __forceinline__ void propose_body(
         double dp[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) dp[m] = (q + 4 * m < D) ? prop[m] - muv[m] : 0.0;
-        matvec16<M, false>(inv_cov, D, dp, tmp, q, p);
+        if constexpr (FRAG) matvec16_frag<M, false>(fS, D, dp, tmp);
+        else matvec16<M, false>(inv_cov, D, dp, tmp, q, p);
         double part = 0.0;
 #pragma unroll
         for (int m = 0; m < M; ++m) part += dp[m] * tmp[m];
