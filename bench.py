@@ -472,6 +472,7 @@ def main():
     #      stream the kernel is launched on)
     lib = eng.lib
     ev_pairs = [(lib.pmc_event_create(), lib.pmc_event_create()) for _ in range(args.steps)]
+    step_times = [] if os.environ.get("PMC_BENCH_STEP_TIMES") else None      # (debugging aid: distribution of the step times)
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -480,8 +481,14 @@ def main():
         else:
             roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = None, None
         timed_step()
+        if step_times is not None:
+            step_times.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
+    if step_times is not None and rank == 0:
+        st_ = np.diff(np.array([t0] + step_times)) * 1e6
+        print(f"[step times us] median {np.median(st_):.1f} p90 {np.percentile(st_, 90):.1f} p99 {np.percentile(st_, 99):.1f} max {st_.max():.1f} "
+              f"first5 {np.round(st_[:5], 1).tolist()} slow(>1.5x median) {int((st_ > 1.5 * np.median(st_)).sum())}", file=sys.stderr)
     roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = None, None
     seg_timed = {k: v / args.steps * 1e6 for k, v in (t_lseg if leng is not None else t_seg).items()}
     laned_host = None
