@@ -1,94 +1,171 @@
-// Register-resident chain of the triangular MAF inverse, ROTATED R layout (used by tri4).
+// Register-resident chain of the triangular MAF inverse (used by tri4 / tri5): a tile's 16 hidden units are 4 quads
+// (K = 4 of the MFMA); a degree group is one quad (or two), and the groups of a tile are run one after the other:
+//   h0 = relu(a0) -> layer-1 block -> h1 -> layer-2 block -> h2 -> output rows (shift, raw) -> x -> rank-1 update of a0.
 //
-// R layout: the A operand of a chain MFMA carries the 4 rows of one quad replicated
-// over the 16 tile rows, so every lane holds all 4 values of the quad for its walker.  A lane,
-// however, only ever USES one of them: lane (q, p) supplies row k = q of the B operand of the next
-// hop and adds the residual of that same row.  Rotating the replication -- tile row i = 4*qi + r
-// carries quad row (qi + r) & 3 -- puts "its own" row into accumulator register 0 of every lane:
-//   * no register select per hop, 1 add + 1 max instead of 8 + 3 cndmask;
-//   * the chain state per quad and layer is one float (layer 0) or reg 0 of one accumulator;
-//   * the rank-1 update of layer 0 is one FMA per later quad.
-// The output layer is not rotated (its rows are (shift, raw) pairs every lane reads by fixed index).
+// TRANSPOSED ACCUMULATOR LAYOUT (round 3).  Lane (q, p) supplies row k = q of the B operand of every hop and adds the
+// residual of that same row, so of a quad's four pre-activations it only ever needs "its own" row q -- but it needs that
+// row for EVERY quad of the tile.  The A operand of a chain MFMA therefore carries the tile's 16 rows transposed:
+// tile row i = 4*qi + r is row qi of quad r, so that accumulator register r of lane (qi, p) is row qi of quad r.  ONE
+// MFMA per layer and quad (K chunk c = quad c's four activations) then adds quad c's contribution to all four quads of
+// the tile at once -- the diagonal block the next hop waits for (register c) and the blocks that feed the later quads
+// (registers > c; earlier quads' registers receive exact zeros: the masked weights) -- where the first register-chain
+// sweeps (a quad's rows replicated 4x and rotated) needed one MFMA per (quad, later quad) pair: 12 instead of 24 chain
+// MFMAs per hidden tile, 2 instead of 8 fragment loads, and no MFMA off the dependent path left on the chain wave except
+// the second output accumulator.  Same products, same order of additions per pre-activation: bit-identical results.
+// The output layer is not transposed (its rows are (shift, raw) pairs every lane reads by fixed index).
+//
+// HAND-PLACED INSTRUCTION ORDER.  The chain wave is alone on its SIMD and issues in order; scripts/micro/chain_tile.hip
+// on the GPU: a hop (MFMA -> read -> add, add, max) 71 cycles, the univariate map 55, a dependent VALU operation 6, an
+// LDS round trip 73 -- and every MFMA that is NOT on the dependent path still costs the wave ~36 cycles wherever it
+// stands (the matrix pipe serialises them and the compiler pads result reads by instruction count).  So the groups are
+// written in the order they are to be issued, with scheduling fences between the lines, side effects (stores of h, the
+// previous group's x store and log-det term, work of the caller) in the shadow of the MFMA they follow, and the store
+// of x unconditional (lanes that do not own the word write a scratch word: no exec-masked branch between two groups).
 #ifndef PMC_MAF_CHAIN_ROT_H
 #define PMC_MAF_CHAIN_ROT_H
 
+#include <type_traits>
 #include "maf_chain.h"
+
+#define CHAIN_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 template <int MAXO>
 struct ChainRot {
     float a0[4];                   // layer-0 pre-activation of row q of each quad
     float p1[4], p2[4];            // layer-1/2 partial pre-activations of row q (previous tiles), added as scalars
-    f32x4 a1[4], a2[4];            // layer-1/2 accumulators of this tile's own contributions; [0] = row q
+    f32x4 acc1, acc2;              // layer-1/2 accumulators of this tile's own contributions; [r] = row q of quad r
     f32x4 outR[2];
     f32x4 oN[MAXO];
-    float4 wd1[4], wd2[4];         // rotated R-layout diagonal fragments
+    float4 wt1, wt2;               // the diagonal tile's fragments, rows transposed (chain_vo_T); component c = K chunk c
     float4 wo[2];
     float4 f3n[MAXO];
     float w0r[4][4];               // W0[rank of group i][slot 4*jt + q]
     float2 po[4];
     float yv[4];
     int g[4];
+    float h0s[4], h1s[4], h2s[4];  // activations of the tile's quads (row q): stored as one 16-byte word per layer by the last group
+    float* xa[4];                  // where group i's x goes: X[lidx(g, p)] for lane quad 0 of a live group, a scratch word otherwise
+    float pend_x, pend_ls;         // the previous group's x and log-scale, stored / subtracted in the next hop's shadow
+    float* pend_a;
 };
 
-// ABL: 1 = no right-looking output updates -- the caller supplies the output partials of the previous tiles itself (the
-// two-wave sweep: its burst wave adds them once per tile from the h2 tile this function then stores in H2[tile parity]);
-// timing experiments only (results are wrong): 2 = skip the non-critical hidden updates of later quads, 64 = skip the
-// x update's transcendental
+// lane offset (bytes) of the transposed gather inside a natural fragment record ([16 k-lanes][16 rows] x 16 B):
+// tile row i = lane & 15 carries row (i >> 2) of quad (i & 3)
+__device__ __forceinline__ int chain_vo_T(int lane) {
+    const int i = lane & 15;
+    return (((lane >> 4) << 4) + 4 * (i & 3) + (i >> 2)) << 4;
+}
+
+// the previous group's side effects: x into LDS (every lane stores: the ones that do not own the word write a scratch
+// word of their own), log-det term
+template <int MAXO>
+__device__ __forceinline__ void chain_flush(ChainRot<MAXO>& s, float& ladj) {
+    *s.pend_a = s.pend_x;
+    ladj -= s.pend_ls;
+}
+
+struct ChainNoExtra {
+    template <int I, int HOP> __device__ __forceinline__ void operator()(std::integral_constant<int, I>, std::integral_constant<int, HOP>) const {}
+};
+
+// per tile, before the first group: where the groups' x go (scratch: 64 words no one reads while the groups run), no
+// pending side effect
+template <int MAXO>
+__device__ __forceinline__ void chain_tile_begin(ChainRot<MAXO>& s, float* X, float* scratch, int D, int q, int p, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.xa[i] = (q == 0 && s.g[i] < D) ? X + lidx(s.g[i] < D ? s.g[i] : 0, p) : scratch + lane;
+    s.pend_a = scratch + lane;
+    s.pend_x = 0.0f;
+    s.pend_ls = 0.0f;
+}
+
+// (ABL: timing-only switches of scripts/abl_tri5.sh above 0xff -- results are wrong with them)
+// ABL & 1: no right-looking output updates -- the caller supplies the output partials of the previous tiles itself (the
+// two-wave sweep: its burst wave adds them once per tile from the h2 tile this function then stores in H2[tile parity]).
 //
 // Groups I .. END-1 of the tile, one after the other, as STRAIGHT-LINE code: a conditional update of an
 // accumulator array costs a register copy per element on every path (SSA phi), so padding groups
 // (degree >= D: zero weights, zero activations) run through the same instructions and only their
 // X / ladj side effects are masked; the right-looking output updates are unconditional too (the
 // fragments of output tiles whose ranks are all below g are exact zeros).
-template <int PAT, int I, int END, int MAXO, int ABL = 0>
-__device__ __forceinline__ void chain_group_rot(ChainRot<MAXO>& s, float* H0, float* H1, float* X,
-                                                int Tt, int D, int nOT, int q, int p, float& ladj, float* H2 = nullptr) {
+// `extra(group, hop)`: caller's work for the shadow of hop 0..2 of a group (e.g. the next tile's fragment requests).
+// The last group's side effects stay pending: chain_flush() after the last call of a tile.
+template <int PAT, int I, int END, int MAXO, int ABL = 0, class EX = ChainNoExtra>
+__device__ __forceinline__ void chain_group_rot(ChainRot<MAXO>& s, float* H0, float* H1, float* X, int Tt, int D, int nOT,
+                                                int q, int p, float& ladj, float* H2 = nullptr, const EX& extra = EX{}) {
     constexpr int NG = pat_ngroups(PAT);
     if constexpr (I < NG && I < END) {
         constexpr int c0 = pat_start(PAT, I), c1 = pat_end(PAT, I);
-        const int g = s.g[I];
-        const bool live = g < D;
+        const bool live = s.g[I] < D;
         const int hw = (Tt << 8) + (q << 6) + (p << 2);
+        std::integral_constant<int, I> gi;
         float h0[4], h1[4], h2[4];
+        // ---------------------------------------------------------------- hop 1
 #pragma unroll
-        for (int c = c0; c <= c1; ++c) { h0[c] = fmaxf(s.a0[c], 0.0f); H0[hw + c] = h0[c]; }
+        for (int c = c0; c <= c1; ++c) { h0[c] = fmaxf(s.a0[c], 0.0f); s.h0s[c] = h0[c]; }
+        CHAIN_FENCE();
 #pragma unroll
-        for (int jt = c0; jt < ((ABL & 2) ? c1 + 1 : 4); ++jt)
-#pragma unroll
-            for (int c = c0; c <= c1; ++c) s.a1[jt] = MFMA(comp(s.wd1[jt], c), h0[c], s.a1[jt]);
-#pragma unroll
-        for (int c = c0; c <= c1; ++c) { h1[c] = fmaxf((s.a1[c][0] + s.p1[c]) + h0[c], 0.0f); H1[hw + c] = h1[c]; }
-#pragma unroll
-        for (int jt = c0; jt < ((ABL & 2) ? c1 + 1 : 4); ++jt)
-#pragma unroll
-            for (int c = c0; c <= c1; ++c) s.a2[jt] = MFMA(comp(s.wd2[jt], c), h1[c], s.a2[jt]);
-#pragma unroll
-        for (int c = c0; c <= c1; ++c) {
-            h2[c] = fmaxf((s.a2[c][0] + s.p2[c]) + h1[c], 0.0f);
-            if (ABL & 1) H2[((Tt & 1) << 8) + (q << 6) + (p << 2) + c] = h2[c];   // (two tiles deep; the lone-wave sweep uses h2 from registers only)
+        for (int c = c0; c <= c1; ++c) s.acc1 = MFMA(comp(s.wt1, c), h0[c], s.acc1);
+        CHAIN_FENCE();
+        chain_flush(s, ladj);
+        if constexpr (I == NG - 1) {                   // (the tile's quads are 16 consecutive bytes per lane)
+            if (!(ABL & 0x400)) *reinterpret_cast<float4*>(H0 + hw) = make_float4(s.h0s[0], s.h0s[1], s.h0s[2], s.h0s[3]);
         }
+        extra(gi, std::integral_constant<int, 0>{});
+        CHAIN_FENCE();
+#pragma unroll
+        for (int c = c0; c <= c1; ++c) { h1[c] = fmaxf((s.acc1[c] + s.p1[c]) + h0[c], 0.0f); s.h1s[c] = h1[c]; }
+        CHAIN_FENCE();
+        // ---------------------------------------------------------------- hop 2
+#pragma unroll
+        for (int c = c0; c <= c1; ++c) s.acc2 = MFMA(comp(s.wt2, c), h1[c], s.acc2);
+        CHAIN_FENCE();
+        if constexpr (I == NG - 1) {
+            if (!(ABL & 0x400)) *reinterpret_cast<float4*>(H1 + hw) = make_float4(s.h1s[0], s.h1s[1], s.h1s[2], s.h1s[3]);
+        }
+        extra(gi, std::integral_constant<int, 1>{});
+        CHAIN_FENCE();
+#pragma unroll
+        for (int c = c0; c <= c1; ++c) { h2[c] = fmaxf((s.acc2[c] + s.p2[c]) + h1[c], 0.0f); s.h2s[c] = h2[c]; }
+        CHAIN_FENCE();
+        // ---------------------------------------------------------------- hop 3: output rows of this group
         constexpr int slot = I >> 1;
 #pragma unroll
         for (int c = c0; c <= c1; ++c) s.outR[slot] = MFMA(comp(s.wo[slot], c), h2[c], s.outR[slot]);
-        if constexpr (slot == 0 && NG > 2) {
-#pragma unroll
-            for (int c = c0; c <= c1; ++c) s.outR[1] = MFMA(comp(s.wo[1], c), h2[c], s.outR[1]);
+        CHAIN_FENCE();
+        if constexpr (I == NG - 1) {                   // (two tiles deep; the lone-wave sweep uses h2 from registers only)
+            if ((ABL & 1) && !(ABL & 0x400))
+                *reinterpret_cast<float4*>(H2 + ((Tt & 1) << 8) + (q << 6) + (p << 2)) = make_float4(s.h2s[0], s.h2s[1], s.h2s[2], s.h2s[3]);
         }
+        extra(gi, std::integral_constant<int, 2>{});
+        CHAIN_FENCE();
+        // ---------------------------------------------------------------- univariate map (zuko's affine inverse)
+        const float raw = s.outR[slot][2 * (I & 1) + 1] + s.po[I].y;
         const float shift = s.outR[slot][2 * (I & 1)] + s.po[I].x;
-        const float ls = fast_ls(s.outR[slot][2 * (I & 1) + 1] + s.po[I].y);
-        float xg = (ABL & 64) ? (s.yv[I] - shift) * ls : (s.yv[I] - shift) * fast_exp_neg(ls);
+        const float ls = fast_ls(raw);
+        const float ydiff = s.yv[I] - shift;
+        float xg = ydiff * fast_exp_neg(ls);
         xg = live ? xg : 0.0f;
-        ladj -= live ? ls : 0.0f;
-        if (q == 0 && live) X[lidx(g, p)] = xg;
 #pragma unroll
         for (int jt = c1 + 1; jt < 4; ++jt) s.a0[jt] = fmaf(s.w0r[I][jt], xg, s.a0[jt]);
+        s.pend_x = xg;
+        s.pend_ls = live ? ls : 0.0f;
+        s.pend_a = s.xa[I];
+        CHAIN_FENCE();
+        // ---------------------------------------------------------------- off the dependent path
+        if constexpr (slot == 0 && NG > 2) {           // groups 2, 3 read their rows from the second output accumulator
+#pragma unroll
+            for (int c = c0; c <= c1; ++c) s.outR[1] = MFMA(comp(s.wo[1], c), h2[c], s.outR[1]);
+            CHAIN_FENCE();
+        }
         if (!(ABL & 1)) {
 #pragma unroll
             for (int O = 0; O < MAXO; ++O)
 #pragma unroll
                 for (int c = c0; c <= c1; ++c) s.oN[O] = MFMA(comp(s.f3n[O], c), h2[c], s.oN[O]);
+            CHAIN_FENCE();
         }
-        chain_group_rot<PAT, I + 1, END, MAXO, ABL>(s, H0, H1, X, Tt, D, nOT, q, p, ladj, H2);
+        chain_group_rot<PAT, I + 1, END, MAXO, ABL, EX>(s, H0, H1, X, Tt, D, nOT, q, p, ladj, H2, extra);
     }
 }
 

@@ -123,8 +123,7 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
 
     // wave-constant lane offsets (bytes)
     const int vo_lane = lane << 4;                              // natural fragment record: lane * 16 B
-    // rotated R-layout gather inside a record (+ 64*jt): tile row i = lane&15 carries quad row ((i>>2) + (i&3)) & 3
-    const int vo_R = ((q << 4) + ((((lane & 15) >> 2) + (lane & 3)) & 3)) << 4;
+    const int vo_T = chain_vo_T(lane);                          // transposed gather inside a record (maf_chain_rot.h)
     const int vo_q = q << 4;                                    // 4 consecutive floats of quad q
 
     if constexpr (FM > 0) {
@@ -216,11 +215,8 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
             }
             const int soD1 = oF1 + (Tt * nT + Tt) * 1024, soD2 = oF2 + (Tt * nT + Tt) * 1024;
             if (!(ABL & 32)) {
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                s.wd1[jt] = bload4(rs, vo_R + 64 * jt, soD1);
-                s.wd2[jt] = bload4(rs, vo_R + 64 * jt, soD2);
-            }
+            s.wt1 = bload4(rs, vo_T, soD1);
+            s.wt2 = bload4(rs, vo_T, soD2);
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl) {
                 // rows (lane&3): 0,1 -> (shift, raw) of group 2*sl; 2,3 -> group 2*sl+1
@@ -322,9 +318,9 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
                 s.a0[jt] = S[(p << 4) + (jt << 2) + q];
                 s.p1[jt] = S[256 + (p << 4) + (jt << 2) + q];
                 s.p2[jt] = S[512 + (p << 4) + (jt << 2) + q];
-                s.a1[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                s.a2[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
+            s.acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            s.acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
             s.outR[0] = f32x4{0.f, 0.f, 0.f, 0.f};
             s.outR[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -335,6 +331,7 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
 
             // first group, then the next tile's burst fragments (loads return in order: issued any earlier
             // they would sit between the chain and its own fragments), then the remaining groups
+            chain_tile_begin(s, X, S, D, q, p, lane);
             if (!(ABL & 8))
             switch (pat) {
 #define CASE(P) case P: chain_group_rot<P, 0, 1, MAXO, ABL>(s, H0, H1, X, Tt, D, nOT, q, p, ladj); break;
@@ -352,6 +349,7 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
 #undef CASE
                 default: break;
             }
+            chain_flush(s, ladj);
             WAVE_LDS_FENCE();
         }
 #undef PREFETCH4
@@ -519,7 +517,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     const int oB3 = oB2 + Hp * 4;
     const int blk_bytes = (int)(m.pk_per_transform * 4);
     const int vo_lane = lane << 4;
-    const int vo_R = ((q << 4) + ((((lane & 15) >> 2) + (lane & 3)) & 3)) << 4;
+    const int vo_T = chain_vo_T(lane);
     const int vo_q = q << 4;
 
     auto lds_bar = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -776,11 +774,8 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                 if (pf && lane == 0) pf[0] = clock64();
                 if (!(TRI5_ABL & 16) || Tt == 0) {     // (ablation 16: the chain fragments of the transform's first tile for all)
                 const int soD1 = oF1 + (Tt * nT + Tt) * 1024, soD2 = oF2 + (Tt * nT + Tt) * 1024;
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
-                    s.wd1[jt] = bload4(rs, vo_R + 64 * jt, soD1);
-                    s.wd2[jt] = bload4(rs, vo_R + 64 * jt, soD2);
-                }
+                s.wt1 = bload4(rs, vo_T, soD1);
+                s.wt2 = bload4(rs, vo_T, soD2);
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
                     const int g_even = s.g[2 * sl], g_odd = s.g[2 * sl + 1];
@@ -800,13 +795,16 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                             rs, q << 2, oW0 + (gg * Hp + 16 * Tt + 4 * jt) * 4, 0));
                 }
                 }
+                if (!(TRI5_ABL & 0x2000) || Tt == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) s.yv[i] = Y[lidx(s.g[i] < D ? s.g[i] : 0, p)];
+                }
                 if (pf && lane == 0) pf[1] = clock64();
 
                 // layer 0 against x (final up to the previous tile's ranks)
                 f32x4 a0;
                 a0[0] = pb0.x; a0[1] = pb0.y; a0[2] = pb0.z; a0[3] = pb0.w;
+                if (!(TRI5_ABL & 0x1000) || Tt == 0) {
 #pragma unroll
                 for (int i = 0; i < PX4; ++i) {
                     if (i < nXT) {
@@ -814,6 +812,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                         a0 = MFMA(pf0[i].x, b.x, a0); a0 = MFMA(pf0[i].y, b.y, a0);
                         a0 = MFMA(pf0[i].z, b.z, a0); a0 = MFMA(pf0[i].w, b.w, a0);
                     }
+                }
                 }
                 for (int Xt = PX4; Xt < nXT; ++Xt) {
                     const float4 a = bload4(rs, vo_lane, oF0 + (Tt * nXT + Xt) * 1024);
@@ -827,38 +826,50 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                 if (pf && lane == 0) pf[2] = clock64();
                 lds_bar();                                            // B(Tt): layers 1/2 of this tile are staged
                 if (pf && lane == 0) pf[3] = clock64();
+                if (!(TRI5_ABL & 0x800) || Tt == 0) {
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
                     s.a0[jt] = S[(p << 4) + (jt << 2) + q];
                     s.p1[jt] = S[256 + (p << 4) + (jt << 2) + q];
                     s.p2[jt] = S[512 + (p << 4) + (jt << 2) + q];
-                    s.a1[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    s.a2[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                s.outR[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                s.outR[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int gg = s.g[i] < D ? s.g[i] : 0;
                     s.po[i] = *reinterpret_cast<const float2*>(SO + (gg >> 3) * 256 + (p << 4) + 2 * (gg & 7));
                 }
+                }
+                s.acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                s.acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                s.outR[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                s.outR[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                chain_tile_begin(s, X, S, D, q, p, lane);
                 if (pf && lane == 0) pf[4] = clock64();
+                // the next tile's layer-0 operands and degree words are requested in the shadows of the first group's hops
+                const bool more = Tt + 1 < nT;
+                auto ahead = [&](auto gi_, auto hop_) {
+                    constexpr int G = decltype(gi_)::value, HP = decltype(hop_)::value;
+                    if constexpr (G == 0) {
+                        if (more && !(TRI5_ABL & 0x100)) {
+                            if constexpr (HP < PX4) { if (HP < nXT) pf0[HP] = bload4(rs, vo_lane, oF0 + ((Tt + 1) * nXT + HP) * 1024); }
+                            if constexpr (HP == 2) {
+                                pb0 = bload4(rs, vo_q, oB0 + 64 * (Tt + 1));
+                                dg_next = *reinterpret_cast<const int4*>(DGT + 4 * (Tt + 1));
+                            }
+                        }
+                    }
+                };
+                static_assert(PX4 <= 3, "one layer-0 fragment per hop of the first group");
+                if (pat == 15 || (TRI5_ABL & 0x200)) {             // four single-quad groups: the common tile
+                    chain_group_rot<15, 0, 4, MAXO, TRI5_ABL | 1>(s, H0, H1, X, Tt, D, nOT, q, p, ladj, H2, ahead);
+                } else
                 switch (pat) {
-#define CASE(P) case P: chain_group_rot<P, 0, 1, MAXO, TRI5_ABL | 1>(s, H0, H1, X, Tt, D, nOT, q, p, ladj, H2); break;
-                    CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
-#undef CASE
-                }
-                if (pf && lane == 0) pf[7] = clock64();
-                if (Tt + 1 < nT) {
-                    PREFETCH5(Tt + 1);
-                    dg_next = *reinterpret_cast<const int4*>(DGT + 4 * (Tt + 1));
-                }
-                switch (pat) {
-#define CASE(P) case P: chain_group_rot<P, 1, 4, MAXO, TRI5_ABL | 1>(s, H0, H1, X, Tt, D, nOT, q, p, ladj, H2); break;
-                    CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
+#define CASE(P) case P: chain_group_rot<P, 0, 4, MAXO, TRI5_ABL | 1>(s, H0, H1, X, Tt, D, nOT, q, p, ladj, H2, ahead); break;
+                    CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13)
 #undef CASE
                     default: break;
                 }
+                chain_flush(s, ladj);
                 if (pf && lane == 0) pf[5] = clock64();
                 lds_bar();                                            // A(Tt): this tile is final
                 if (pf && lane == 0) pf[6] = clock64();
