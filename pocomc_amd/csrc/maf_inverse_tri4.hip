@@ -14,9 +14,11 @@
 #include <stdlib.h>
 #include "maf_chain_rot.h"
 
-#define DG_WORDS(m) ((m)->nT * 4 + 4)      // LDS words of the tiles' degree table (4 per tile, padded)
+#define DG_WORDS(m) ((m)->nT * 4 + 8)      // LDS words of the tiles' degree table (4 per tile, padded)
 // + the two-wave sweep's permutation / rank-0 tables and its second x array (with alignment slack)
-#define TRI5_TABLE_WORDS(m) (((DG_WORDS(m) + (m)->T * (m)->Dp + 2 * (m)->T + 3) & ~3) + (m)->Dp * 16)
+#define TRI5_TT_WORDS(m) (((m)->nT + 2) * 16)  // the two-wave sweep's per-tile table (16 words per hidden tile, two rows of "no groups" behind)
+#define TRI5_TABLE_WORDS(m) (((TRI5_TT_WORDS(m) + (m)->T * (m)->Dp + 2 * (m)->T + 3) & ~3) + (m)->Dp * 16)
+#define TRI5_LDS_FLOATS(m, maxo) (2 * (m)->Dp * 16 + 2 * (m)->Hp * 16 + 2 * 256 + 2 * (3 + (maxo)) * 256 + TRI5_TABLE_WORDS(m))
 #include "propose_body.h"
 
 #define PX4 2
@@ -74,6 +76,28 @@ __device__ __forceinline__ void burst_tile(f32x4& a1, f32x4& a2, const float4 (&
             c1 = MFMA(pf1[i].w, b1[i].w, c1); c2 = MFMA(pf2[i].w, b2[i].w, c2);
         }
         for (int r = 0; r < 4; ++r) { a1[r] += c1[r]; a2[r] += c2[r]; }
+    }
+}
+
+// the two-wave sweep's form: one accumulator per layer, the two layers alternating (a dependent MFMA is two issue slots
+// behind its predecessor)
+template <int TT>
+__device__ __forceinline__ void burst_tile_chain(f32x4& a1, f32x4& a2, const float4 (&pf1)[PK4], const float4 (&pf2)[PK4],
+                                                 const float* H0, const float* H1, int lane) {
+    if constexpr (TT > 0) {
+        float4 b1[TT], b2[TT];
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            b1[i] = *reinterpret_cast<const float4*>(H0 + (i << 8) + (lane << 2));
+            b2[i] = *reinterpret_cast<const float4*>(H1 + (i << 8) + (lane << 2));
+        }
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            a1 = MFMA(pf1[i].x, b1[i].x, a1); a2 = MFMA(pf2[i].x, b2[i].x, a2);
+            a1 = MFMA(pf1[i].y, b1[i].y, a1); a2 = MFMA(pf2[i].y, b2[i].y, a2);
+            a1 = MFMA(pf1[i].z, b1[i].z, a1); a2 = MFMA(pf2[i].z, b2[i].z, a2);
+            a1 = MFMA(pf1[i].w, b1[i].w, a1); a2 = MFMA(pf2[i].w, b2[i].w, a2);
+        }
     }
 }
 
@@ -156,6 +180,7 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
         __syncthreads();
 
         ChainRot<MAXO> s;
+        ChainFrags<MAXO> f;
 #pragma unroll
         for (int O = 0; O < MAXO; ++O) {
             const float4 bb = (O < nOT) ? bload4(rs, vo_q, oB3 + 64 * O) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -208,40 +233,42 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
             // ---- the chain's own fragments: issued first, they land while the bursts run
             {
                 const bool ny = dg.y != dg.x, nz = dg.z != dg.y, nw = dg.w != dg.z;
-                s.g[0] = dg.x;
-                s.g[1] = ny ? dg.y : (nz ? dg.z : (nw ? dg.w : D));
-                s.g[2] = ny ? (nz ? dg.z : (nw ? dg.w : D)) : ((nz && nw) ? dg.w : D);
-                s.g[3] = (ny && nz && nw) ? dg.w : D;
+                f.g[0] = dg.x;
+                f.g[1] = ny ? dg.y : (nz ? dg.z : (nw ? dg.w : D));
+                f.g[2] = ny ? (nz ? dg.z : (nw ? dg.w : D)) : ((nz && nw) ? dg.w : D);
+                f.g[3] = (ny && nz && nw) ? dg.w : D;
             }
             const int soD1 = oF1 + (Tt * nT + Tt) * 1024, soD2 = oF2 + (Tt * nT + Tt) * 1024;
             if (!(ABL & 32)) {
-            s.wt1 = bload4(rs, vo_T, soD1);
-            s.wt2 = bload4(rs, vo_T, soD2);
+            f.wt1 = bload4(rs, vo_T, soD1);
+            f.wt2 = bload4(rs, vo_T, soD2);
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl) {
                 // rows (lane&3): 0,1 -> (shift, raw) of group 2*sl; 2,3 -> group 2*sl+1
-                const int g_even = s.g[2 * sl], g_odd = s.g[2 * sl + 1];
+                const int g_even = f.g[2 * sl], g_odd = f.g[2 * sl + 1];
                 const int gsel = (lane & 2) ? g_odd : g_even;
                 const bool ok = gsel < D;
                 const int gg = ok ? gsel : 0;
                 const int vo = ((((gg >> 3) * nT) << 6) + (q << 4) + 2 * (gg & 7) + (lane & 1)) << 4;
                 const float4 v = bload4(rs, vo, oF3 + Tt * 1024);
-                s.wo[sl] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                f.wo[sl] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int O = 0; O < MAXO; ++O)
-                s.f3n[O] = (O < nOT) ? bload4(rs, vo_lane, oF3 + (O * nT + Tt) * 1024) : make_float4(0.f, 0.f, 0.f, 0.f);
+                f.f3n[O] = (O < nOT) ? bload4(rs, vo_lane, oF3 + (O * nT + Tt) * 1024) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int gg = s.g[i] < D ? s.g[i] : 0;
+                const int gg = f.g[i] < D ? f.g[i] : 0;
+                float w[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int jt = i + 1; jt < 4; ++jt)
-                    s.w0r[i][jt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                    w[jt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
                         rs, q << 2, oW0 + (gg * Hp + 16 * Tt + 4 * jt) * 4, 0));
+                f.w0o[i] = make_float4(w[0], w[1], w[2], w[3]);
             }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s.yv[i] = Y[lidx(s.g[i] < D ? s.g[i] : 0, p)];
+            for (int i = 0; i < 4; ++i) s.yv[i] = Y[lidx(f.g[i] < D ? f.g[i] : 0, p)];
 
             // ---- natural-layout bursts against everything that is already final
             f32x4 a0, a1, a2;
@@ -325,16 +352,16 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
             s.outR[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int gg = s.g[i] < D ? s.g[i] : 0;
+                const int gg = f.g[i] < D ? f.g[i] : 0;
                 s.po[i] = *reinterpret_cast<const float2*>(SO + (gg >> 3) * 256 + (p << 4) + 2 * (gg & 7));
             }
 
             // first group, then the next tile's burst fragments (loads return in order: issued any earlier
             // they would sit between the chain and its own fragments), then the remaining groups
-            chain_tile_begin(s, X, S, D, q, p, lane);
+            chain_tile_begin(s, f, X, S, D, q, p, lane);
             if (!(ABL & 8))
             switch (pat) {
-#define CASE(P) case P: chain_group_rot<P, 0, 1, MAXO, ABL>(s, H0, H1, X, Tt, D, nOT, q, p, ladj); break;
+#define CASE(P) case P: chain_group_rot<P, 0, 1, MAXO, ABL>(s, f, H0, H1, X, Tt, D, nOT, q, p, ladj); break;
                 CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
 #undef CASE
             }
@@ -344,7 +371,7 @@ __global__ __launch_bounds__(64) void maf_inverse_tri4_kernel(pmc_maf_t m, const
             }
             if (!(ABL & 8))
             switch (pat) {
-#define CASE(P) case P: chain_group_rot<P, 1, 4, MAXO, ABL>(s, H0, H1, X, Tt, D, nOT, q, p, ladj); break;
+#define CASE(P) case P: chain_group_rot<P, 1, 4, MAXO, ABL>(s, f, H0, H1, X, Tt, D, nOT, q, p, ladj); break;
                 CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
 #undef CASE
                 default: break;
@@ -459,27 +486,37 @@ int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* 
 }
 
 // ============================================================================================================
-// tri5: the same sweep with a BURST wave next to the chain waves.
+// tri5: the same sweep as TWO wavefronts per 16 walkers -- a CHAIN wave and a BURST wave -- right-looking (round 3).
 //
-// Ablations of tri4 (scripts/ablate_inverse.py): of its 100 us, 29 us are the left-looking bursts of the hidden
-// layers and 14 us the issue of their fragment prefetches -- work that does not depend on the chain of the tile
-// that is running.  Here a workgroup is three wavefronts: waves 0 and 1 (CHAIN waves) own 16 walkers each and keep
-// the dependent work -- the layer-0 burst against x, the per-group chain, the right-looking output updates -- and
-// wave 2 (the BURST wave) prepares, one tile ahead and for both walker sets from ONE set of weight fragments, the
-// layer-1/2 pre-activations of the next tile: everything against the tiles that are already final while the
-// chains run, the last K tile right after them.  Two LDS-only barriers per tile: A(t) "the chains of tile t
-// finished" and B(t) "the pre-activations of tile t are in the staging areas".
-// Where it pays: a workgroup lives on one CU (4 SIMDs, one such 256-VGPR wave each), so TRI5_NC = 1 runs at most
-// 512 walker sets at a time and TRI5_NC = 2 (one burst wave for two sets: 3 waves) 256 workgroups = 512 sets too.
-// Up to 8192 walkers the sweep takes ~68 us instead of tri4's ~90 us; 1e4 walkers (625 sets) need a second round
-// (140 us) where tri4's 625 single waves are all resident (100 us).  The launcher therefore picks this kernel for
-// n <= 16 * (sets resident at once) -- pocoMC's own default, n_active = 256, is deep inside that range -- and tri4
-// above it.  PMC_INVERSE_DUO=0 / 1 forces never / always (tests run both).
+// What bounds the sweep is the latency of one wavefront's in-order instruction stream (maf_chain_rot.h), so the work is
+// cut by WHEN its inputs exist, not by flops:
+//   * everything a hidden tile Tt needs from tiles <= Tt-2 (and from the ranks they produced) is a dense left-looking
+//     product that can be formed a whole tile time ahead: the BURST wave's -- layer 0 against x (the fragment image f0c:
+//     W0 with the columns of the ranks of tiles >= Tt-1 zeroed), layers 1 / 2 against h0 / h1, the output rows against h2
+//     (once per tile, right-looking, all output tiles that are not identically zero) -- into transposed accumulators
+//     (lane (q, p) holds row q of the tile's four quads: exactly what the chain's lane (q, p) adds) and from there into
+//     one of two staging buffers in LDS;
+//   * what tile Tt needs from tile Tt-1 exists only when that tile's groups have run, i.e. on the CHAIN wave: every group
+//     adds, next to its own tile's blocks, its share of the NEXT tile's pre-activations (ChainRot::accN1 / accN2 / outN /
+//     a0N: one MFMA per layer, two for the output rows, four FMAs) -- so that at a tile boundary the chain only adds
+//     two register sets (staged partial + own share) and goes on; no wave ever waits for work that could not have
+//     been started earlier.  The first version of this kernel (round 2) had the burst wave add tile Tt-1's blocks
+//     between two barriers while the chain waited, and the chain form the layer-0 product itself: 5.3 k cycles per
+//     tile against 2.3 k for the chain's own stream (scripts/micro/chain_tile.hip).
+// One LDS-only barrier per tile: E(Tt) = "tile Tt is final, the staging of tile Tt+1 is complete".
+// The chain's fragments of tile Tt+1 (16 loads) are requested in the shadows of tile Tt's hops into the other of two
+// register sets (the tile body exists twice), across transform boundaries too.
+// Residency: a workgroup lives on one CU (4 SIMDs, one such wave each): 512 walker sets at a time; the launcher
+// splits larger calls into rounds of this kernel (two rounds still beat the lone wave's one: DESIGN.md section 4).
 // ============================================================================================================
-#define TRI5_NC 1                  // chain waves (16-walker sets) per workgroup; see the note on occupancy above
+#define TRI5_NC 1                  // chain waves (16-walker sets) per workgroup
 #ifndef TRI5_ABL
-#define TRI5_ABL 0                 // timing experiments only (maf_chain_rot.h): results are wrong when != 0
+#define TRI5_ABL 0                 // timing experiments only (scripts/abl_tri5.sh): results are wrong when != 0
 #endif
+#define PXB 4                      // x tiles of the layer-0 product held in registers (D <= 64)
+#define TRI5_STAGE_FLOATS(MO) ((3 + (MO)) * 256)                 // one staging buffer: S0 | S1 | S2 (transposed, [lane][4]) | SO[MO] (natural)
+#define TRI5_SET_FLOATS(Dp, Hp, MO) (2 * (Dp) * 16 + 2 * (Hp) * 16 + 2 * 256 + 2 * TRI5_STAGE_FLOATS(MO))
+#define OOB_VOFF 0x40000000        // a lane offset beyond every image: the bounds-checked load returns zeros
 
 template <int MAXO, int FM>
 __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pmc_maf_t m, const float* __restrict__ in,
@@ -491,38 +528,125 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, p = lane & 15;
     const int D = m.D, Dp = m.Dp, Hp = m.Hp, T = m.T, nT = m.nT, nXT = m.nXT, nOT = m.nOT;
-    const int set_floats = 2 * Dp * 16 + 2 * Hp * 16 + 2 * 256 + 3 * 256 + MAXO * 256;   // LDS of one walker set
-    const int cs = wv < TRI5_NC ? wv : 0;                                        // this chain wave's set in the workgroup
-    const int64_t set = (int64_t)blockIdx.x * TRI5_NC + cs;
+    const int nTl = __builtin_amdgcn_readfirstlane(m.meta[7]);                                                   // live hidden tiles (the padding tiles trail)
+    const int64_t set = (int64_t)blockIdx.x;
     const int64_t row0 = set * 16;
-    float* Y = smem + (size_t)cs * set_floats;
+    float* Y = smem;
     float* XA = Y + Dp * 16;
     float* H0 = XA + Dp * 16;
     float* H1 = H0 + Hp * 16;
     float* H2 = H1 + Hp * 16;                  // h2 of the last two tiles [tile parity][256]: the burst wave's output updates read it
-    float* S = H2 + 2 * 256;                   // staging: [3 layers][16 p][16 rows] then [MAXO][16 p][16 rows]
-    float* SO = S + 3 * 256;
+    float* STG = H2 + 2 * 256;                 // two staging buffers (tile parity)
     const int* feat_of_rank = m.meta + 8;
     const int* rank_of_feat = m.meta + 8 + T * D;
     const int* quad_meta = m.meta + 8 + 2 * T * D;
 
-    const int oF0 = 0;
-    const int oF1 = oF0 + nT * nXT * 1024;
+    // byte offsets of the packed arrays inside one transform's block (maf_spec.py: pk_offsets)
+    const int oF1 = nT * nXT * 1024;
     const int oF2 = oF1 + nT * nT * 1024;
     const int oF3 = oF2 + nT * nT * 1024;
     const int oW0 = oF3 + nOT * nT * 1024;
     const int oB0 = oW0 + Dp * Hp * 4;
-    const int oB1 = oB0 + Hp * 4;
-    const int oB2 = oB1 + Hp * 4;
-    const int oB3 = oB2 + Hp * 4;
+    const int oB3 = oB0 + 3 * Hp * 4;
+    const int oCW0 = oB3 + nOT * 64 + 2 * nT * 1024;
+    const int oF0C = oCW0 + nT * 1024 + nT * 512;
+    const int oB0T = oF0C + nT * nXT * 1024;
+    const int oB1T = oB0T + Hp * 4;
+    const int oB2T = oB1T + Hp * 4;
     const int blk_bytes = (int)(m.pk_per_transform * 4);
+    // ONE bounds-checked resource over the whole image: a transform is an SGPR offset, a lane that must read zeros an
+    // offset beyond the image
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)m.packed, 0, blk_bytes * T, 0x00020000);
     const int vo_lane = lane << 4;
     const int vo_T = chain_vo_T(lane);
     const int vo_q = q << 4;
 
     auto lds_bar = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
+    // the tiles' degree words in LDS (a global load in the middle of a tile costs the chain an L2 round trip); two
+    // words of padding behind them: "no groups" for the tile after the last
+    // Per hidden tile, 16 words (filled once; two rows of "no groups" behind the last tile): the ranks its groups produce
+    // (word 0 also carries the quad pattern << 16), and what depends on a rank alone of the addresses the chain needs --
+    // byte offset of the rank's x / y word, of its (shift, raw) pair in a staged output tile, of its two rows in an
+    // output fragment record (out of range for a padding group: the bounds-checked load returns zeros).
+    int* DGT = reinterpret_cast<int*>(smem + TRI5_SET_FLOATS(Dp, Hp, MAXO));
+    // between two transforms the chain wave re-ranks its x and starts the next sweep with rank 0: the indices and the two
+    // constants it needs come from LDS tables filled once -- PRM[t][r]: where rank r of transform t goes (rank of
+    // transform t - 1, or the feature for t = 0), B3T[t]: (shift, raw log-scale) of rank 0.  x alternates between two
+    // arrays; the burst wave zeroes the idle one.
+    int* PRM = DGT + TRI5_TT_WORDS(&m);
+    float* B3T = reinterpret_cast<float*>(PRM + T * Dp);
+    float* XB = reinterpret_cast<float*>(DGT + ((TRI5_TT_WORDS(&m) + T * Dp + 2 * T + 3) & ~3));      // (16-byte aligned)
+    auto fill_table = [&]() {
+        for (int e = lane; e < (nT + 2) * 16; e += 64) {
+            const int tile = e >> 4, k = e & 15, i = k & 3;
+            int g = D, pat = 1;
+            if (tile < nT) {
+                int4 dg = *reinterpret_cast<const int4*>(quad_meta + 4 * tile);
+                dg.x &= 0xffff; dg.y &= 0xffff; dg.z &= 0xffff; dg.w &= 0xffff;
+                const bool ny = dg.y != dg.x, nz = dg.z != dg.y, nw = dg.w != dg.z;
+                pat = 1 | (ny << 1) | (nz << 2) | (nw << 3);
+                const int g1 = ny ? dg.y : (nz ? dg.z : (nw ? dg.w : D));
+                const int g2 = ny ? (nz ? dg.z : (nw ? dg.w : D)) : ((nz && nw) ? dg.w : D);
+                const int g3 = (ny && nz && nw) ? dg.w : D;
+                g = i == 0 ? dg.x : (i == 1 ? g1 : (i == 2 ? g2 : g3));
+            }
+            const bool live = g < D;
+            const int gg = live ? g : 0;
+            int v;
+            if (k < 4) v = g | (i == 0 ? pat << 16 : 0);
+            else if (k < 8) v = 4 * (((gg >> 4) << 8) + ((gg & 3) << 6) + ((gg >> 2) & 3));
+            else if (k < 12) v = 4 * ((gg >> 3) * 256 + 2 * (gg & 7));
+            else v = live ? ((((gg >> 3) * nT) << 6) + 2 * (gg & 7)) << 4 : OOB_VOFF;
+            DGT[e] = v;
+        }
+    };
+
+    // the chain's operands of tile U of transform tt, request number K of 16 (maf_chain_rot.h: ChainFrags); gU / gV: the
+    // ranks of tile U's / tile U+1's groups
+    // the chain's operands of tile U of transform tt, request number K of 16 (maf_chain_rot.h: ChainFrags); wvU / wvV: the
+    // fragment-row offsets of tile U's / tile U+1's groups (table words 12..15)
+    auto request = [&](ChainFrags<MAXO>& F, auto k_, const int tt, const int U, const int4 wvU, const int4 wvV) {
+        constexpr int K = decltype(k_)::value;
+        const int base = tt * blk_bytes;
+        const int Un = U + 1 < nT ? U + 1 : U;
+        const int voN = U + 1 < nT ? vo_T : OOB_VOFF;
+        auto rows = [&](const int w_even, const int w_odd) {    // rows (lane & 3): 0, 1 -> (shift, raw) of the even group; 2, 3 -> the odd one
+            return bload4(rs, ((lane & 2) ? w_odd : w_even) + (q << 8) + ((lane & 1) << 4), base + oF3 + U * 1024);
+        };
+        if constexpr (K == 0) F.wt1 = bload4(rs, vo_T, base + oF1 + (U * nT + U) * 1024);
+        else if constexpr (K == 1) F.wt2 = bload4(rs, vo_T, base + oF2 + (U * nT + U) * 1024);
+        else if constexpr (K == 2) F.wn1 = bload4(rs, voN, base + oF1 + (Un * nT + U) * 1024);
+        else if constexpr (K == 3) F.wn2 = bload4(rs, voN, base + oF2 + (Un * nT + U) * 1024);
+        else if constexpr (K == 4) F.wo[0] = rows(wvU.x, wvU.y);
+        else if constexpr (K == 5) F.wo[1] = rows(wvU.z, wvU.w);
+        else if constexpr (K == 6) F.woN[0] = rows(wvV.x, wvV.y);
+        else if constexpr (K == 7) F.woN[1] = rows(wvV.z, wvV.w);
+        else if constexpr (K < 11) F.w0o[K - 8] = bload4(rs, ((4 + K - 8) << 6) + vo_q, base + oCW0 + U * 1024);
+        else if constexpr (K == 11) F.w0o[3] = make_float4(0.f, 0.f, 0.f, 0.f);      // (the fourth group has no later quad)
+        else F.w0N[K - 12] = bload4(rs, U + 1 < nT ? ((K - 12) << 6) + vo_q : OOB_VOFF, base + oCW0 + Un * 1024);
+    };
+    // a tile's table words into its operand set
+    auto take_table = [&](ChainFrags<MAXO>& F, const int U) {
+        const int4 tg = *reinterpret_cast<const int4*>(DGT + 16 * U);
+        const int4 txy = *reinterpret_cast<const int4*>(DGT + 16 * U + 4);
+        const int4 tso = *reinterpret_cast<const int4*>(DGT + 16 * U + 8);
+        F.g[0] = tg.x & 0xffff; F.g[1] = tg.y; F.g[2] = tg.z; F.g[3] = tg.w;
+        F.pat = tg.x >> 16;
+        F.xy[0] = txy.x; F.xy[1] = txy.y; F.xy[2] = txy.z; F.xy[3] = txy.w;
+        F.so[0] = tso.x; F.so[1] = tso.y; F.so[2] = tso.z; F.so[3] = tso.w;
+    };
+
+    ChainFrags<MAXO> fA, fB;
     if (wv < TRI5_NC) {
+        // the first tile's operands are on their way while the walkers are proposed / loaded
+        fill_table();
+        WAVE_LDS_FENCE();
+        {
+            const int4 w0 = *reinterpret_cast<const int4*>(DGT + 12), w1 = *reinterpret_cast<const int4*>(DGT + 16 + 12);
+            take_table(fA, 0);
+            static_for<16>([&](auto k_) { request(fA, k_, T - 1, 0, w0, w1); });
+        }
         if constexpr (FM > 0) {
             for (int e = lane; e < (Dp - D) * 16; e += 64) Y[lidx(D + (e >> 4), e & 15)] = 0.0f;
             const double sg = pa.adapt ? pa.adapt[0] : pa.sigma, ca = pa.adapt ? pa.adapt[1] : pa.cn_a;
@@ -533,26 +657,13 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
             load_rows(Y, in, row0, n, D, Dp, feat_of_rank + (T - 1) * D, lane);
         }
     } else {
-        for (int c = 0; c < TRI5_NC; ++c) {    // padding slots of the activations are read by the bursts: zero once
-            float4* z4 = reinterpret_cast<float4*>(smem + (size_t)c * set_floats + 2 * Dp * 16);
-            const int n4 = (2 * Hp * 16 + 2 * 256) >> 2;
-            for (int e = lane; e < n4; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        // padding slots of the activations are read by the bursts (times zero weights): zero once
+        float4* z4 = reinterpret_cast<float4*>(H0);
+        const int n4 = (2 * Hp * 16 + 2 * 256 + 2 * TRI5_STAGE_FLOATS(MAXO)) >> 2;
+        for (int e = lane; e < n4; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (pa.prof && lane == 0 && blockIdx.x < 64)         // (measurement only: which SIMD / CU every wavefront landed on)
         pa.prof[(size_t)T * nT * 8 + blockIdx.x * 2 + wv] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-    // the tiles' degree words in LDS (see maf_inverse_tri4_kernel); filled by the burst wave, visible after the first
-    // __syncthreads() of the transform loop
-    int* DGT = reinterpret_cast<int*>(smem + (size_t)TRI5_NC * set_floats);
-    if (wv == TRI5_NC)
-        for (int e = lane; e < nT * 4; e += 64) DGT[e] = quad_meta[e];
-    // between two transforms the chain wave re-ranks its x and starts the next sweep with rank 0: the indices and the two
-    // constants it needs come from LDS tables filled once (global loads there are dependent round trips on the
-    // critical path) -- PRM[t][r]: where rank r of transform t goes (rank of transform t - 1, or the feature for t = 0),
-    // B3T[t]: (shift, raw log-scale) of rank 0.  x alternates between two arrays; the burst wave zeroes the idle one.
-    int* PRM = DGT + DG_WORDS(&m);
-    float* B3T = reinterpret_cast<float*>(PRM + T * Dp);
-    float* XB = reinterpret_cast<float*>(DGT + ((DG_WORDS(&m) + T * Dp + 2 * T + 3) & ~3));      // (16-byte aligned)
     for (int e = threadIdx.x; e < T * D; e += 64 * (TRI5_NC + 1)) {
         const int tt = e / D, r = e - tt * D;
         const int feat = feat_of_rank[tt * D + r];
@@ -571,313 +682,237 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     int xsel = 0;
     __syncthreads();
 
-    for (int t = T - 1; t >= 0; --t) {
-        const float* blk = m.packed + (size_t)t * m.pk_per_transform;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)blk, 0, blk_bytes, 0x00020000);
-        float* X = xsel ? XB : XA;                     // zero on entry
-        float* Xidle = xsel ? XA : XB;                 // the previous transform's x: re-ranked already, zeroed below
-        xsel ^= 1;
-
-        if (wv == TRI5_NC) {
+    // everything the preparation of tile TT needs from global memory: the hidden layers' fragments against tiles
+    // 0 .. TT-2 (transposed rows), the masked layer-0 fragments, the transposed biases, the output fragments
+            // against tile TT-2
+#define BURST_FETCH(TB, TT, P1, P2, XF, OF, Bz0, Bz1, Bz2)                                                        \
+            {   /* unconditional: a request under a branch makes the register set a conditional assignment -- copies */ \
+                /* behind a wait for the loads just issued; what a tile does not need is requested out of range (zeros) */ \
+                const int TT_ = (TT) < nT ? (TT) : nT - 1;                                                        \
+                const int so1_ = (TB) + oF1 + TT_ * nT * 1024, so2_ = (TB) + oF2 + TT_ * nT * 1024;               \
+                _Pragma("unroll") for (int i_ = 0; i_ < PK4; ++i_) {                                              \
+                    const int vo_ = i_ < TT_ - 1 ? vo_T : OOB_VOFF;                                               \
+                    P1[i_] = bload4(rs, vo_, so1_ + i_ * 1024);                                                   \
+                    P2[i_] = bload4(rs, vo_, so2_ + i_ * 1024);                                                   \
+                }                                                                                                 \
+                _Pragma("unroll") for (int i_ = 0; i_ < PXB; ++i_)                                                \
+                    XF[i_] = bload4(rs, i_ < nXT ? vo_T : OOB_VOFF, (TB) + oF0C + (TT_ * nXT + i_) * 1024);        \
+                Bz0 = bload4(rs, vo_q, (TB) + oB0T + 64 * TT_);                                                   \
+                Bz1 = bload4(rs, vo_q, (TB) + oB1T + 64 * TT_);                                                   \
+                Bz2 = bload4(rs, vo_q, (TB) + oB2T + 64 * TT_);                                                   \
+                _Pragma("unroll") for (int O = 0; O < MAXO; ++O)                                                  \
+                    OF[O] = bload4(rs, (TT_ >= 2 && O < nOT) ? vo_lane : OOB_VOFF, (TB) + oF3 + (O * nT + (TT_ >= 2 ? TT_ - 2 : 0)) * 1024); \
+            }
+    // The two wavefronts run loops of their own (their operand sets would otherwise be live across each other's code);
+    // they meet at the barriers: nTl + 1 LDS-only ones and one full one per transform.
+    if (wv == TRI5_NC) {
+        // Two operand sets, used alternately: while tile T1 is being prepared from one, the operands of tile T1 + 1
+        // are already on their way into the other (nothing else hides their L2 latency here).
+        float4 pA1[PK4], pA2[PK4], pB1[PK4], pB2[PK4], xA[PXB], xB[PXB], oA[MAXO], oB[MAXO], ob[MAXO];
+        float4 bA0, bA1, bA2, bB0, bB1, bB2;
+        {
+            const int tb0 = (T - 1) * blk_bytes;
+            BURST_FETCH(tb0, 0, pA1, pA2, xA, oA, bA0, bA1, bA2)
+#pragma unroll
+            for (int O = 0; O < MAXO; ++O) ob[O] = bload4(rs, O < nOT ? vo_q : OOB_VOFF, tb0 + oB3 + 64 * O);
+        }
+        for (int t = T - 1; t >= 0; --t) {
+            const int tb = t * blk_bytes;
+            float* X = xsel ? XB : XA;                     // zero on entry
+            float* Xidle = xsel ? XA : XB;                 // the previous transform's x: re-ranked already, zeroed below
+            xsel ^= 1;
+            // ------------------------------------------------------------------ BURST wave
             if (t != T - 1) {
                 float4* z4 = reinterpret_cast<float4*>(Xidle);
                 for (int e = lane; e < (Dp * 16) >> 2; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            // ------------------------------------------------------------------ BURST wave
-            // Two fragment sets, used alternately: while tile Tt is being prepared from one set, the fragments
-            // of tile Tt+1 are already on their way into the other (nothing else hides their L2 latency here).
-            float4 pfA1[PK4], pfA2[PK4], pfB1[PK4], pfB2[PK4];
-            float4 lA1, lA2, lB1, lB2, bA1, bA2, bB1, bB2;
-            int4 dA, dB;
-            bool natural_end = true;
-            f32x4 oN[MAXO];                                // output-layer partials of the walker set (right-looking)
+            f32x4 oN[MAXO];                                // output-layer partials of the walker set (right-looking, natural layout)
 #pragma unroll
-            for (int O = 0; O < MAXO; ++O) {
-                const float4 bb = (O < nOT) ? bload4(rs, vo_q, oB3 + 64 * O) : make_float4(0.f, 0.f, 0.f, 0.f);
-                oN[O][0] = bb.x; oN[O][1] = bb.y; oN[O][2] = bb.z; oN[O][3] = bb.w;
-            }
-#define SW_PREFETCH(TT, P1, P2)                                                                                  \
-            switch ((TT) < PK4 ? (TT) : PK4) {                                                                    \
-                case 1: prefetch_tile<1>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
-                case 2: prefetch_tile<2>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
-                case 3: prefetch_tile<3>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
-                case 4: prefetch_tile<4>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
-                case 5: prefetch_tile<5>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
-                case 6: prefetch_tile<6>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
-                case 7: prefetch_tile<7>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
-                case 8: prefetch_tile<8>(P1, P2, rs, vo_lane, oF1 + (TT) * nT * 1024, oF2 + (TT) * nT * 1024); break; \
-                default: break;                                                                                  \
-            }
-#define SW_BURST(NK, P1, P2, AA1, AA2, CC1, CC2, HH0, HH1)                                                       \
+            for (int O = 0; O < MAXO; ++O) { oN[O][0] = ob[O].x; oN[O][1] = ob[O].y; oN[O][2] = ob[O].z; oN[O][3] = ob[O].w; }
+#define BURST_K(NK, P1, P2, AA1, AA2)                                                                             \
             switch ((NK) < PK4 ? (NK) : PK4) {                                                                    \
-                case 1: burst_tile_open<1>(AA1, AA2, CC1, CC2, P1, P2, HH0, HH1, lane); break;                   \
-                case 2: burst_tile_open<2>(AA1, AA2, CC1, CC2, P1, P2, HH0, HH1, lane); break;                   \
-                case 3: burst_tile_open<3>(AA1, AA2, CC1, CC2, P1, P2, HH0, HH1, lane); break;                   \
-                case 4: burst_tile_open<4>(AA1, AA2, CC1, CC2, P1, P2, HH0, HH1, lane); break;                   \
-                case 5: burst_tile_open<5>(AA1, AA2, CC1, CC2, P1, P2, HH0, HH1, lane); break;                   \
-                case 6: burst_tile_open<6>(AA1, AA2, CC1, CC2, P1, P2, HH0, HH1, lane); break;                   \
-                case 7: burst_tile_open<7>(AA1, AA2, CC1, CC2, P1, P2, HH0, HH1, lane); break;                   \
-                case 8: burst_tile_open<8>(AA1, AA2, CC1, CC2, P1, P2, HH0, HH1, lane); break;                   \
-                default: break;                                                                                  \
+                case 1: burst_tile_chain<1>(AA1, AA2, P1, P2, H0, H1, lane); break;                               \
+                case 2: burst_tile_chain<2>(AA1, AA2, P1, P2, H0, H1, lane); break;                               \
+                case 3: burst_tile_chain<3>(AA1, AA2, P1, P2, H0, H1, lane); break;                               \
+                case 4: burst_tile_chain<4>(AA1, AA2, P1, P2, H0, H1, lane); break;                               \
+                case 5: burst_tile_chain<5>(AA1, AA2, P1, P2, H0, H1, lane); break;                               \
+                case 6: burst_tile_chain<6>(AA1, AA2, P1, P2, H0, H1, lane); break;                               \
+                case 7: burst_tile_chain<7>(AA1, AA2, P1, P2, H0, H1, lane); break;                               \
+                case 8: burst_tile_chain<8>(AA1, AA2, P1, P2, H0, H1, lane); break;                               \
+                default: break;                                                                                   \
             }
-            // everything tile TT needs from global memory: fragments against tiles 0..TT-1 (the last one, K = TT-1,
-            // once more in registers of its own: a run-time index into the set would go through scratch), biases,
-            // degree words
-#define FETCH_TILE(TT, P1, P2, L1, L2, Bb1, Bb2, DGW)                                                            \
-            if ((TT) < nT) {                                                                                     \
-                SW_PREFETCH(TT, P1, P2)                                                                          \
-                if ((TT) > 0) { L1 = bload4(rs, vo_lane, oF1 + ((TT) * nT + (TT) - 1) * 1024);                    \
-                                L2 = bload4(rs, vo_lane, oF2 + ((TT) * nT + (TT) - 1) * 1024); }                  \
-                Bb1 = bload4(rs, vo_q, oB1 + 64 * (TT)); Bb2 = bload4(rs, vo_q, oB2 + 64 * (TT));                \
-                DGW = *reinterpret_cast<const int4*>(DGT + 4 * (TT));                                            \
+            // prepare tile TT from set (P1 ...) while the chain runs tile TT-1; request tile TT+1 into set (N1 ...)
+#define BURST_TILE(TT, P1, P2, XF, OF, Bz0, Bz1, Bz2, N1, N2, NXF, NOF, Nz0, Nz1, Nz2)                             \
+            {                                                                                                     \
+                const int T1 = (TT);                                                                              \
+                BURST_FETCH(tb, T1 + 1, N1, N2, NXF, NOF, Nz0, Nz1, Nz2)                                          \
+                f32x4 a0, a1, a2;                                                                                 \
+                a0[0] = Bz0.x; a0[1] = Bz0.y; a0[2] = Bz0.z; a0[3] = Bz0.w;                                       \
+                a1[0] = Bz1.x; a1[1] = Bz1.y; a1[2] = Bz1.z; a1[3] = Bz1.w;                                       \
+                a2[0] = Bz2.x; a2[1] = Bz2.y; a2[2] = Bz2.z; a2[3] = Bz2.w;                                       \
+                const int nK = T1 - 1;                          /* hidden tiles 0 .. T1-2 are final */            \
+                BURST_K(nK, P1, P2, a1, a2)                                                                       \
+                if (nK > PK4) {                                 /* flows wider than PK4 + 2 tiles: four K tiles' fragments in flight */ \
+                    float4 w1r[4], w2r[4];                                                                        \
+                    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                            \
+                        const int Kl = min(PK4 + j_, nT - 1);                                                     \
+                        w1r[j_] = bload4(rs, vo_T, tb + oF1 + (T1 * nT + Kl) * 1024);                             \
+                        w2r[j_] = bload4(rs, vo_T, tb + oF2 + (T1 * nT + Kl) * 1024);                             \
+                    }                                                                                             \
+                    for (int K0 = PK4; K0 < nK; K0 += 4) {                                                        \
+                        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                        \
+                            const int K = K0 + j_;                                                                \
+                            const float4 w1 = w1r[j_], w2 = w2r[j_];                                              \
+                            const int Kn = min(K + 4, nT - 1);                                                    \
+                            w1r[j_] = bload4(rs, vo_T, tb + oF1 + (T1 * nT + Kn) * 1024);                         \
+                            w2r[j_] = bload4(rs, vo_T, tb + oF2 + (T1 * nT + Kn) * 1024);                         \
+                            if (K < nK) {                                                                         \
+                                const float4 b1 = *reinterpret_cast<const float4*>(H0 + (K << 8) + (lane << 2));  \
+                                const float4 b2 = *reinterpret_cast<const float4*>(H1 + (K << 8) + (lane << 2));  \
+                                a1 = MFMA(w1.x, b1.x, a1); a2 = MFMA(w2.x, b2.x, a2);                             \
+                                a1 = MFMA(w1.y, b1.y, a1); a2 = MFMA(w2.y, b2.y, a2);                             \
+                                a1 = MFMA(w1.z, b1.z, a1); a2 = MFMA(w2.z, b2.z, a2);                             \
+                                a1 = MFMA(w1.w, b1.w, a1); a2 = MFMA(w2.w, b2.w, a2);                             \
+                            }                                                                                     \
+                        }                                                                                         \
+                    }                                                                                             \
+                }                                                                                                 \
+                /* layer 0 against the ranks of tiles <= T1-2 (the chain adds the ranks of tile T1-1 itself) */   \
+                _Pragma("unroll") for (int i_ = 0; i_ < PXB; ++i_) {                                              \
+                    if (i_ < nXT) {                                                                               \
+                        const float4 b = *reinterpret_cast<const float4*>(X + (i_ << 8) + (lane << 2));           \
+                        a0 = MFMA(XF[i_].x, b.x, a0); a0 = MFMA(XF[i_].y, b.y, a0);                               \
+                        a0 = MFMA(XF[i_].z, b.z, a0); a0 = MFMA(XF[i_].w, b.w, a0);                               \
+                    }                                                                                             \
+                }                                                                                                 \
+                /* output rows: tile T1-2's h2 into every output tile that has a rank above its degrees */        \
+                if (T1 >= 2) {                                                                                    \
+                    const int O0 = (__builtin_amdgcn_readfirstlane(DGT[16 * (T1 - 2)]) & 0xffff) >> 3;                                             \
+                    const float4 b = *reinterpret_cast<const float4*>(H2 + (((T1 - 2) & 1) << 8) + (lane << 2));  \
+                    _Pragma("unroll") for (int O = 0; O < MAXO; ++O) {                                            \
+                        if (O >= O0 && O < nOT) {                                                                 \
+                            oN[O] = MFMA(OF[O].x, b.x, oN[O]); oN[O] = MFMA(OF[O].y, b.y, oN[O]);                 \
+                            oN[O] = MFMA(OF[O].z, b.z, oN[O]); oN[O] = MFMA(OF[O].w, b.w, oN[O]);                 \
+                        }                                                                                         \
+                    }                                                                                             \
+                }                                                                                                 \
+                float* st_ = STG + (T1 & 1) * TRI5_STAGE_FLOATS(MAXO);                                            \
+                *reinterpret_cast<float4*>(st_ + (lane << 2)) = make_float4(a0[0], a0[1], a0[2], a0[3]);          \
+                *reinterpret_cast<float4*>(st_ + 256 + (lane << 2)) = make_float4(a1[0], a1[1], a1[2], a1[3]);    \
+                *reinterpret_cast<float4*>(st_ + 512 + (lane << 2)) = make_float4(a2[0], a2[1], a2[2], a2[3]);    \
+                _Pragma("unroll") for (int O = 0; O < MAXO; ++O)                                                  \
+                    *reinterpret_cast<float4*>(st_ + 768 + O * 256 + (p << 4) + (q << 2)) = make_float4(oN[O][0], oN[O][1], oN[O][2], oN[O][3]); \
+                lds_bar();                                                /* E(T1 - 1) */                         \
             }
-#define HELPER_TILE(TT, P1, P2, L1, L2, Bb1, Bb2, DGW, NP1, NP2, NL1, NL2, NB1, NB2, NDG)                         \
-            {                                                                                                    \
-                const int Tt = (TT);                                                                             \
-                FETCH_TILE(Tt + 1, NP1, NP2, NL1, NL2, NB1, NB2, NDG)                                            \
-                /* same order of additions as tri4: partial sums (a: x,z terms; c: y,w terms) over the first      */ \
-                /* min(Tt, PK4) K tiles, folded, then the K tiles beyond PK4 one after the other                  */ \
-                f32x4 a1[TRI5_NC], a2[TRI5_NC], c1[TRI5_NC], c2[TRI5_NC];                                        \
-                _Pragma("unroll") for (int c = 0; c < TRI5_NC; ++c) {                                            \
-                    a1[c][0] = Bb1.x; a1[c][1] = Bb1.y; a1[c][2] = Bb1.z; a1[c][3] = Bb1.w;                      \
-                    a2[c][0] = Bb2.x; a2[c][1] = Bb2.y; a2[c][2] = Bb2.z; a2[c][3] = Bb2.w;                      \
-                    c1[c] = f32x4{0.f, 0.f, 0.f, 0.f}; c2[c] = f32x4{0.f, 0.f, 0.f, 0.f};                        \
-                }                                                                                                \
-                /* everything that is final while the chains of tile Tt-1 still run: K <= Tt-2 */                \
-                _Pragma("unroll") for (int c = 0; c < TRI5_NC; ++c) {                                            \
-                    const float* h0_ = smem + (size_t)c * set_floats + 2 * Dp * 16;                              \
-                    const float* h1_ = h0_ + Hp * 16;                                                            \
-                    SW_BURST(Tt - 1, P1, P2, a1[c], a2[c], c1[c], c2[c], h0_, h1_)                               \
-                    if (Tt - 1 >= PK4) {                                                                         \
-                        for (int r = 0; r < 4; ++r) { a1[c][r] += c1[c][r]; a2[c][r] += c2[c][r]; }              \
-                        /* (flows wider than PK4 + 1 tiles: four K tiles' fragments in flight -- a load at a time  */ \
-                        /*  made the burst wave of a 25-tile flow wait an L2 round trip per K tile)                 */ \
-                        float4 w1r[4], w2r[4];                                                                   \
-                        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                       \
-                            const int Kl = min(PK4 + j_, nT - 1);                                                \
-                            w1r[j_] = bload4(rs, vo_lane, oF1 + (Tt * nT + Kl) * 1024);                           \
-                            w2r[j_] = bload4(rs, vo_lane, oF2 + (Tt * nT + Kl) * 1024);                           \
-                        }                                                                                        \
-                        for (int K0 = PK4; K0 < Tt - 1; K0 += 4) {                                               \
-                            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                   \
-                                const int K = K0 + j_;                                                           \
-                                const float4 w1 = w1r[j_], w2 = w2r[j_];                                         \
-                                const int Kn = min(K + 4, nT - 1);                                               \
-                                w1r[j_] = bload4(rs, vo_lane, oF1 + (Tt * nT + Kn) * 1024);                       \
-                                w2r[j_] = bload4(rs, vo_lane, oF2 + (Tt * nT + Kn) * 1024);                       \
-                                if (K < Tt - 1) {                                                                \
-                                    const float4 b1 = *reinterpret_cast<const float4*>(h0_ + (K << 8) + (lane << 2)); \
-                                    const float4 b2 = *reinterpret_cast<const float4*>(h1_ + (K << 8) + (lane << 2)); \
-                                    a1[c] = MFMA(w1.x, b1.x, a1[c]); a2[c] = MFMA(w2.x, b2.x, a2[c]);            \
-                                    a1[c] = MFMA(w1.y, b1.y, a1[c]); a2[c] = MFMA(w2.y, b2.y, a2[c]);            \
-                                    a1[c] = MFMA(w1.z, b1.z, a1[c]); a2[c] = MFMA(w2.z, b2.z, a2[c]);            \
-                                    a1[c] = MFMA(w1.w, b1.w, a1[c]); a2[c] = MFMA(w2.w, b2.w, a2[c]);            \
-                                }                                                                                \
-                            }                                                                                    \
-                        }                                                                                        \
-                    }                                                                                            \
-                }                                                                                                \
-                /* the output layer's right-looking updates (what the lone wave does after every group) happen HERE,   */ \
-                /* once per tile: oN[O] += F3[O][Tt-1] . h2[Tt-1] for every output tile as soon as tile Tt-1 is final --   */ \
-                /* the same additions in the same order (bias, tile after tile, four k chunks); fragments requested now   */ \
-                int4 dg = DGW;                                                                                   \
-                dg.x &= 0xffff; dg.y &= 0xffff; dg.z &= 0xffff; dg.w &= 0xffff;                                  \
-                const bool pad_ = dg.x >= D && dg.y >= D && dg.z >= D && dg.w >= D;                              \
-                float4 f3p[MAXO];                                                                                \
-                _Pragma("unroll") for (int O = 0; O < MAXO; ++O)                                                 \
-                    f3p[O] = (Tt > 0 && O < nOT) ? bload4(rs, vo_lane, oF3 + (O * nT + Tt - 1) * 1024)           \
-                                                 : make_float4(0.f, 0.f, 0.f, 0.f);                              \
-                if (Tt > 0) lds_bar();                                    /* A(Tt-1): tile Tt-1 is final now */   \
-                if (pad_) { natural_end = false; break; }                                                       \
-                _Pragma("unroll") for (int c = 0; c < TRI5_NC; ++c) {                                            \
-                    float* base_ = smem + (size_t)c * set_floats;                                                \
-                    if (Tt > 0) {                                                                                \
-                        const int K = Tt - 1;                                                                    \
-                        const float* h0_ = base_ + 2 * Dp * 16;                                                  \
-                        const float* h1_ = h0_ + Hp * 16;                                                        \
-                        const float4 b1 = *reinterpret_cast<const float4*>(h0_ + (K << 8) + (lane << 2));        \
-                        const float4 b2 = *reinterpret_cast<const float4*>(h1_ + (K << 8) + (lane << 2));        \
-                        if (K < PK4) {                                                                           \
-                            a1[c] = MFMA(L1.x, b1.x, a1[c]); a2[c] = MFMA(L2.x, b2.x, a2[c]);                    \
-                            c1[c] = MFMA(L1.y, b1.y, c1[c]); c2[c] = MFMA(L2.y, b2.y, c2[c]);                    \
-                            a1[c] = MFMA(L1.z, b1.z, a1[c]); a2[c] = MFMA(L2.z, b2.z, a2[c]);                    \
-                            c1[c] = MFMA(L1.w, b1.w, c1[c]); c2[c] = MFMA(L2.w, b2.w, c2[c]);                    \
-                            for (int r = 0; r < 4; ++r) { a1[c][r] += c1[c][r]; a2[c][r] += c2[c][r]; }          \
-                        } else {                                                                                 \
-                            a1[c] = MFMA(L1.x, b1.x, a1[c]); a2[c] = MFMA(L2.x, b2.x, a2[c]);                    \
-                            a1[c] = MFMA(L1.y, b1.y, a1[c]); a2[c] = MFMA(L2.y, b2.y, a2[c]);                    \
-                            a1[c] = MFMA(L1.z, b1.z, a1[c]); a2[c] = MFMA(L2.z, b2.z, a2[c]);                    \
-                            a1[c] = MFMA(L1.w, b1.w, a1[c]); a2[c] = MFMA(L2.w, b2.w, a2[c]);                    \
-                        }                                                                                        \
-                    }                                                                                            \
-                    float* sp = base_ + 2 * Dp * 16 + 2 * Hp * 16 + 2 * 256 + (p << 4) + (q << 2);                         \
-                    *reinterpret_cast<float4*>(sp + 256) = make_float4(a1[c][0], a1[c][1], a1[c][2], a1[c][3]);  \
-                    *reinterpret_cast<float4*>(sp + 512) = make_float4(a2[c][0], a2[c][1], a2[c][2], a2[c][3]);  \
-                    if (Tt > 0) {                                                                                \
-                        const float4 b = *reinterpret_cast<const float4*>(base_ + 2 * Dp * 16 + 2 * Hp * 16 + (((Tt - 1) & 1) << 8) + (lane << 2)); \
-                        _Pragma("unroll") for (int O = 0; O < MAXO; ++O) oN[O] = MFMA(f3p[O].x, b.x, oN[O]);      \
-                        _Pragma("unroll") for (int O = 0; O < MAXO; ++O) oN[O] = MFMA(f3p[O].y, b.y, oN[O]);      \
-                        _Pragma("unroll") for (int O = 0; O < MAXO; ++O) oN[O] = MFMA(f3p[O].z, b.z, oN[O]);      \
-                        _Pragma("unroll") for (int O = 0; O < MAXO; ++O) oN[O] = MFMA(f3p[O].w, b.w, oN[O]);      \
-                    }                                                                                            \
-                    _Pragma("unroll") for (int O = 0; O < MAXO; ++O)                                             \
-                        *reinterpret_cast<float4*>(sp + 768 + O * 256) = make_float4(oN[O][0], oN[O][1], oN[O][2], oN[O][3]); \
-                }                                                                                                \
-                lds_bar();                                                /* B(Tt) */                            \
+            for (int T2 = 0; T2 < nTl; T2 += 2) {
+                BURST_TILE(T2, pA1, pA2, xA, oA, bA0, bA1, bA2, pB1, pB2, xB, oB, bB0, bB1, bB2)
+                if (T2 + 1 >= nTl) break;
+                BURST_TILE(T2 + 1, pB1, pB2, xB, oB, bB0, bB1, bB2, pA1, pA2, xA, oA, bA0, bA1, bA2)
             }
-            lA1 = lA2 = lB1 = lB2 = bA1 = bA2 = bB1 = bB2 = make_float4(0.f, 0.f, 0.f, 0.f);
-            dA = dB = make_int4(0, 0, 0, 0);
-            FETCH_TILE(0, pfA1, pfA2, lA1, lA2, bA1, bA2, dA)
-            for (int T2 = 0; T2 < nT; T2 += 2) {
-                HELPER_TILE(T2, pfA1, pfA2, lA1, lA2, bA1, bA2, dA, pfB1, pfB2, lB1, lB2, bB1, bB2, dB)
-                if (T2 + 1 >= nT) break;
-                HELPER_TILE(T2 + 1, pfB1, pfB2, lB1, lB2, bB1, bB2, dB, pfA1, pfA2, lA1, lA2, bA1, bA2, dA)
+            {   // the next transform's first operands and output biases: on their way before this one ends
+                const int tbn = (t > 0 ? t - 1 : 0) * blk_bytes;
+                BURST_FETCH(tbn, 0, pA1, pA2, xA, oA, bA0, bA1, bA2)
+#pragma unroll
+                for (int O = 0; O < MAXO; ++O) ob[O] = bload4(rs, O < nOT ? vo_q : OOB_VOFF, tbn + oB3 + 64 * O);
             }
-#undef HELPER_TILE
-#undef FETCH_TILE
-#undef SW_BURST
-#undef SW_PREFETCH
-            if (natural_end) lds_bar();                               // A(nT-1)
-        } else {
-            // ------------------------------------------------------------------ CHAIN waves
+#undef BURST_TILE
+#undef BURST_K
+#undef BURST_FETCH
+            lds_bar();                                                    // E(nTl - 1)
+            __syncthreads();                                              // (the chain re-ranked x)
+            if (t == 0) xsel ^= 1;
+        }
+    } else {
+        float4 w00 = bload4(rs, vo_q, (T - 1) * blk_bytes + oCW0);      // layer 0, first tile: the column of rank 0
+        for (int t = T - 1; t >= 0; --t) {
+            float* X = xsel ? XB : XA;                     // zero on entry
+            xsel ^= 1;
+            // ------------------------------------------------------------------ CHAIN wave
             ChainRot<MAXO> s;
-            {
+            {   // rank 0 reads nothing: bias only; its share of the first tile's layer 0 (the window's first slot)
                 const float shift = B3T[2 * t], ls = fast_ls(B3T[2 * t + 1]);
                 const float xv = (Y[lidx(0, p)] - shift) * fast_exp_neg(ls);
                 ladj -= ls;
                 if (q == 0) X[lidx(0, p)] = xv;
+                s.a0N[0] = w00.x * xv; s.a0N[1] = w00.y * xv; s.a0N[2] = w00.z * xv; s.a0N[3] = w00.w * xv;
             }
-            WAVE_LDS_FENCE();
-            float4 pf0[PX4], pb0;
-#define PREFETCH5(TT)                                                                                          \
-            {                                                                                                  \
-                const int TT_ = (TT);                                                                          \
-                _Pragma("unroll") for (int i_ = 0; i_ < PX4; ++i_)                                             \
-                    if (i_ < nXT) pf0[i_] = bload4(rs, vo_lane, oF0 + (TT_ * nXT + i_) * 1024);                 \
-                pb0 = bload4(rs, vo_q, oB0 + 64 * TT_);                                                        \
-            }
-            PREFETCH5(0);
-            int4 dg_next = *reinterpret_cast<const int4*>(DGT);
-            for (int Tt = 0; Tt < nT; ++Tt) {
-                int4 dg = dg_next;
-                dg.x &= 0xffff; dg.y &= 0xffff; dg.z &= 0xffff; dg.w &= 0xffff;
-                if (dg.x >= D && dg.y >= D && dg.z >= D && dg.w >= D) break;       // padding tiles
-                const int pat = 1 | ((dg.y != dg.x) << 1) | ((dg.z != dg.y) << 2) | ((dg.w != dg.z) << 3);
-                {
-                    const bool ny = dg.y != dg.x, nz = dg.z != dg.y, nw = dg.w != dg.z;
-                    s.g[0] = dg.x;
-                    s.g[1] = ny ? dg.y : (nz ? dg.z : (nw ? dg.w : D));
-                    s.g[2] = ny ? (nz ? dg.z : (nw ? dg.w : D)) : ((nz && nw) ? dg.w : D);
-                    s.g[3] = (ny && nz && nw) ? dg.w : D;
-                }
+            s.accN1 = s.accN2 = s.outN[0] = s.outN[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            lds_bar();                                                    // E(-1): the first tile's staging is complete
+
+            // one tile from the operands in `cur`, the next tile's requested into `nxt`
+            auto tile = [&](ChainFrags<MAXO>& cur, ChainFrags<MAXO>& nxt, const int Tt_) {
+                const int Tt = __builtin_amdgcn_readfirstlane(Tt_);
                 long long* pf = (pa.prof && blockIdx.x == 0) ? pa.prof + ((size_t)(T - 1 - t) * nT + Tt) * 8 : nullptr;
                 if (pf && lane == 0) pf[0] = clock64();
-                if (!(TRI5_ABL & 16) || Tt == 0) {     // (ablation 16: the chain fragments of the transform's first tile for all)
-                const int soD1 = oF1 + (Tt * nT + Tt) * 1024, soD2 = oF2 + (Tt * nT + Tt) * 1024;
-                s.wt1 = bload4(rs, vo_T, soD1);
-                s.wt2 = bload4(rs, vo_T, soD2);
-#pragma unroll
-                for (int sl = 0; sl < 2; ++sl) {
-                    const int g_even = s.g[2 * sl], g_odd = s.g[2 * sl + 1];
-                    const int gsel = (lane & 2) ? g_odd : g_even;
-                    const bool ok = gsel < D;
-                    const int gg = ok ? gsel : 0;
-                    const int vo = ((((gg >> 3) * nT) << 6) + (q << 4) + 2 * (gg & 7) + (lane & 1)) << 4;
-                    const float4 v = bload4(rs, vo, oF3 + Tt * 1024);
-                    s.wo[sl] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const int gg = s.g[i] < D ? s.g[i] : 0;
-#pragma unroll
-                    for (int jt = i + 1; jt < 4; ++jt)
-                        s.w0r[i][jt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                            rs, q << 2, oW0 + (gg * Hp + 16 * Tt + 4 * jt) * 4, 0));
-                }
-                }
-                if (!(TRI5_ABL & 0x2000) || Tt == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) s.yv[i] = Y[lidx(s.g[i] < D ? s.g[i] : 0, p)];
-                }
-                if (pf && lane == 0) pf[1] = clock64();
-
-                // layer 0 against x (final up to the previous tile's ranks)
-                f32x4 a0;
-                a0[0] = pb0.x; a0[1] = pb0.y; a0[2] = pb0.z; a0[3] = pb0.w;
-                if (!(TRI5_ABL & 0x1000) || Tt == 0) {
-#pragma unroll
-                for (int i = 0; i < PX4; ++i) {
-                    if (i < nXT) {
-                        const float4 b = *reinterpret_cast<const float4*>(X + (i << 8) + (lane << 2));
-                        a0 = MFMA(pf0[i].x, b.x, a0); a0 = MFMA(pf0[i].y, b.y, a0);
-                        a0 = MFMA(pf0[i].z, b.z, a0); a0 = MFMA(pf0[i].w, b.w, a0);
-                    }
-                }
-                }
-                for (int Xt = PX4; Xt < nXT; ++Xt) {
-                    const float4 a = bload4(rs, vo_lane, oF0 + (Tt * nXT + Xt) * 1024);
-                    const float4 b = *reinterpret_cast<const float4*>(X + (Xt << 8) + (lane << 2));
-                    a0 = MFMA(a.x, b.x, a0); a0 = MFMA(a.y, b.y, a0); a0 = MFMA(a.z, b.z, a0); a0 = MFMA(a.w, b.w, a0);
-                }
-                {
-                    float* sp = S + (p << 4) + (q << 2);
-                    *reinterpret_cast<float4*>(sp) = make_float4(a0[0], a0[1], a0[2], a0[3]);
-                }
-                if (pf && lane == 0) pf[2] = clock64();
-                lds_bar();                                            // B(Tt): layers 1/2 of this tile are staged
-                if (pf && lane == 0) pf[3] = clock64();
-                if (!(TRI5_ABL & 0x800) || Tt == 0) {
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
-                    s.a0[jt] = S[(p << 4) + (jt << 2) + q];
-                    s.p1[jt] = S[256 + (p << 4) + (jt << 2) + q];
-                    s.p2[jt] = S[512 + (p << 4) + (jt << 2) + q];
-                }
+                float* st = STG + (Tt & 1) * TRI5_STAGE_FLOATS(MAXO);
+                const float4 s0 = *reinterpret_cast<const float4*>(st + (lane << 2));
+                const float4 s1 = *reinterpret_cast<const float4*>(st + 256 + (lane << 2));
+                const float4 s2 = *reinterpret_cast<const float4*>(st + 512 + (lane << 2));
+                const int pat = __builtin_amdgcn_readfirstlane(cur.pat);
+                const char* stb = reinterpret_cast<const char*>(st) + 3072 + (p << 6);      // the walker's row of the staged output tiles
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int gg = s.g[i] < D ? s.g[i] : 0;
-                    s.po[i] = *reinterpret_cast<const float2*>(SO + (gg >> 3) * 256 + (p << 4) + 2 * (gg & 7));
+                    const float2 so = *reinterpret_cast<const float2*>(stb + cur.so[i]);
+                    s.po[i] = make_float2(so.x + s.outN[i >> 1][2 * (i & 1)], so.y + s.outN[i >> 1][2 * (i & 1) + 1]);
+                    s.yv[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Y) + (p << 4) + cur.xy[i]);
                 }
+                s.a0[0] = s0.x + s.a0N[0]; s.a0[1] = s0.y + s.a0N[1]; s.a0[2] = s0.z + s.a0N[2]; s.a0[3] = s0.w + s.a0N[3];
+                s.p1[0] = s1.x + s.accN1[0]; s.p1[1] = s1.y + s.accN1[1]; s.p1[2] = s1.z + s.accN1[2]; s.p1[3] = s1.w + s.accN1[3];
+                s.p2[0] = s2.x + s.accN2[0]; s.p2[1] = s2.y + s.accN2[1]; s.p2[2] = s2.z + s.accN2[2]; s.p2[3] = s2.w + s.accN2[3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s.a0N[j] = 0.0f;
+                s.accN1 = s.accN2 = s.outN[0] = s.outN[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                s.acc1 = s.acc2 = s.outR[0] = s.outR[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                {   // where the groups' x go (the lanes that do not own the word: a scratch word of their own, the staging buffer just read)
+                    float* scratch = st + lane;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        s.xa[i] = (q == 0 && cur.g[i] < D) ? reinterpret_cast<float*>(reinterpret_cast<char*>(X) + (p << 4) + cur.xy[i]) : scratch;
+                    s.pend_a = scratch; s.pend_x = 0.0f; s.pend_ls = 0.0f;
                 }
-                s.acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-                s.acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
-                s.outR[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                s.outR[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                chain_tile_begin(s, X, S, D, q, p, lane);
-                if (pf && lane == 0) pf[4] = clock64();
-                // the next tile's layer-0 operands and degree words are requested in the shadows of the first group's hops
-                const bool more = Tt + 1 < nT;
-                auto ahead = [&](auto gi_, auto hop_) {
-                    constexpr int G = decltype(gi_)::value, HP = decltype(hop_)::value;
-                    if constexpr (G == 0) {
-                        if (more && !(TRI5_ABL & 0x100)) {
-                            if constexpr (HP < PX4) { if (HP < nXT) pf0[HP] = bload4(rs, vo_lane, oF0 + ((Tt + 1) * nXT + HP) * 1024); }
-                            if constexpr (HP == 2) {
-                                pb0 = bload4(rs, vo_q, oB0 + 64 * (Tt + 1));
-                                dg_next = *reinterpret_cast<const int4*>(DGT + 4 * (Tt + 1));
-                            }
-                        }
+                // the next tile's operands (the first tile of the next transform behind the last): requested in the
+                // shadows of this tile's hops, 16 requests over 3 x (groups) shadows
+                // (every tile requests: behind the last tile of the last transform the loads are harmless and unused --
+                //  a conditional request would make the register set a conditional assignment, i.e. copies)
+                const bool more = Tt + 1 < nTl;
+                const int ntt = more ? t : (t > 0 ? t - 1 : 0), nU = more ? Tt + 1 : 0;
+                take_table(nxt, nU);
+                const int4 gU = *reinterpret_cast<const int4*>(DGT + 16 * nU + 12);
+                const int4 gV = *reinterpret_cast<const int4*>(DGT + 16 * (nU + 1) + 12);
+                auto ahead = [&](auto gi_, auto hop_, auto ng_) {
+                    constexpr int G = decltype(gi_)::value, HP = decltype(hop_)::value, NSH = 3 * decltype(ng_)::value;
+                    constexpr int LPS = (16 + NSH - 1) / NSH, k0 = (G * 3 + HP) * LPS;
+                    if constexpr (!(TRI5_ABL & 0x100)) {
+                        static_for<LPS>([&](auto j_) {
+                            constexpr int K = k0 + decltype(j_)::value;
+                            if constexpr (K < 16) request(nxt, std::integral_constant<int, K>{}, ntt, nU, gU, gV);
+                        });
                     }
                 };
-                static_assert(PX4 <= 3, "one layer-0 fragment per hop of the first group");
+                if (pf && lane == 0) pf[1] = clock64();
                 if (pat == 15 || (TRI5_ABL & 0x200)) {             // four single-quad groups: the common tile
-                    chain_group_rot<15, 0, 4, MAXO, TRI5_ABL | 1>(s, H0, H1, X, Tt, D, nOT, q, p, ladj, H2, ahead);
+                    chain_group_rot<15, 0, 4, MAXO, TRI5_ABL | 3>(s, cur, H0, H1, X, Tt, D, nOT, q, p, ladj, H2, ahead);
                 } else
                 switch (pat) {
-#define CASE(P) case P: chain_group_rot<P, 0, 4, MAXO, TRI5_ABL | 1>(s, H0, H1, X, Tt, D, nOT, q, p, ladj, H2, ahead); break;
+#define CASE(P) case P: chain_group_rot<P, 0, 4, MAXO, TRI5_ABL | 3>(s, cur, H0, H1, X, Tt, D, nOT, q, p, ladj, H2, ahead); break;
                     CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13)
 #undef CASE
                     default: break;
                 }
                 chain_flush(s, ladj);
-                if (pf && lane == 0) pf[5] = clock64();
-                lds_bar();                                            // A(Tt): this tile is final
-                if (pf && lane == 0) pf[6] = clock64();
+                if (pf && lane == 0) pf[2] = clock64();
+                lds_bar();                                            // E(Tt): this tile is final
+                if (pf && lane == 0) pf[3] = clock64();
+            };
+            // (two copies of the tile body, the operand sets swapping roles; a transform with an odd number of tiles leaves
+            //  the next transform's first operands in the second set: moved over once)
+            for (int T2 = 0; T2 < nTl; T2 += 2) {
+                tile(fA, fB, T2);
+                if (T2 + 1 >= nTl) { fA = fB; break; }
+                tile(fB, fA, T2 + 1);
             }
-#undef PREFETCH5
-        }
-        const bool last = (t == 0);
-        if (wv < TRI5_NC) {
+            w00 = bload4(rs, vo_q, (t > 0 ? t - 1 : 0) * blk_bytes + oCW0);
+            const bool last = (t == 0);
             const int* prm = PRM + t * Dp;
             for (int e = lane; e < D * 16; e += 64) {
                 const int r = e >> 4, pp = e & 15;
@@ -888,9 +923,9 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
             }
             if (!last)
                 for (int e = lane; e < (Dp - D) * 16; e += 64) Y[lidx(D + (e >> 4), e & 15)] = 0.0f;
+            __syncthreads();
+            if (last) xsel ^= 1;                           // (xsel names the array of the LAST transform again: the epilogue reads it)
         }
-        __syncthreads();
-        if (last) xsel ^= 1;                           // (xsel names the array of the LAST transform again: the epilogue reads it)
     }
     float* X = xsel ? XB : XA;
     if (wv < TRI5_NC && ladj_out && lane < 16 && row0 + p < n) ladj_out[row0 + p] = ladj;
@@ -910,22 +945,11 @@ static int tri5_mode() {
 static bool tri5_wanted(const pmc_maf_t* m, int64_t n) {
     const int mode = tri5_mode();
     if (mode >= 0) return mode != 0;
+    // The right-looking two-wave sweep takes ~0.55 of the lone wave's time per round, and a launch beyond the 512
+    // resident walker sets simply runs its surplus workgroups as they find a CU: it is taken whenever its LDS fits.
+    (void)n;
     const int maxo = m->nOT <= 4 ? 4 : 8;
-    const size_t lds1 = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256 + DG_WORDS(m)) * sizeof(float);   // one walker set
-    const size_t lds5 = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 5 * 256 + maxo * 256 + TRI5_TABLE_WORDS(m)) * sizeof(float);   // (two-wave sweep)
-    if (lds5 * TRI5_NC > 160 * 1024) return false;
-    // rounds a launch needs: workgroups resident per CU are bounded by the LDS (both kernels keep one set's tiles
-    // per chain wave) and by the SIMDs (one 256-register wave each: 4 lone waves or 4 / (TRI5_NC + 1) groups).
-    // The two-wave kernel takes ~0.75 of the lone wave's time per round.
-    // (512 bytes of slack per workgroup: three workgroups of 54 560 bytes do not share a CU's 163 840 in practice)
-    const int64_t by_lds4 = (int64_t)((160 * 1024) / (lds1 + 512)), by_lds5 = (int64_t)((160 * 1024) / (lds5 * TRI5_NC + 512));
-    const int64_t res4 = 256 * (by_lds4 < 4 ? by_lds4 : 4);
-    const int64_t wg5 = by_lds5 < 4 / (TRI5_NC + 1) ? by_lds5 : 4 / (TRI5_NC + 1);
-    const int64_t res5 = 256 * TRI5_NC * wg5;
-    if (res4 < 1 || res5 < 1) return false;
-    const int64_t sets = (n + 15) / 16;
-    const int64_t r4 = (sets + res4 - 1) / res4, r5 = (sets + res5 - 1) / res5;
-    return 3 * r5 < 4 * r4;
+    return (size_t)TRI5_LDS_FLOATS(m, maxo) * sizeof(float) <= 160 * 1024;
 }
 
 // which of the two D <= 64 sweeps PMC_INVERSE_AUTO launches for n rows (bench.py names the kernel it times with it)
@@ -938,9 +962,9 @@ extern "C" int pmc_debug_inverse_uses_duo(const pmc_maf_t* m, int64_t n) {
 static int launch_tri5(const ProposeArgs* pa, const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
                        hipStream_t stream) {
     if (m->n_out != 2 || !m->tri_ok || m->nOT > 8 || m->D > 64) return -1;
-    if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
+    if (m->pk_per_transform * 4 * m->T >= (int64_t)OOB_VOFF) return -1;       // one buffer resource over the whole image
     const int maxo = m->nOT <= 4 ? 4 : 8;
-    const size_t lds = ((size_t)TRI5_NC * (2 * m->Dp * 16 + 2 * m->Hp * 16 + 5 * 256 + maxo * 256) + TRI5_TABLE_WORDS(m)) * sizeof(float);
+    const size_t lds = (size_t)TRI5_LDS_FLOATS(m, maxo) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     const ProposeArgs none{};
     const int64_t nsets = (n + 15) / 16;

@@ -233,6 +233,10 @@ class MAFSpec:
             # the helper wavefront multiplies while the chain adds the newest ranks from registers)
             parts += [("cw1", nT * 256), ("cw2", nT * 256), ("cw0", nT * 256), ("cw3", nT * 128),
                       ("f0c", self.sz_f0)]
+            # the hidden layers' biases with the rows of every tile transposed (slot 16 T + 4 q + r holds the bias of unit
+            # 16 T + 4 r + q): what a lane of the two-wave sweep's transposed accumulators (csrc/maf_chain_rot.h) starts
+            # from, one 16-byte load per tile
+            parts += [("b0t", Hp), ("b1t", Hp), ("b2t", Hp)]
         off = 0
         self.pk_offsets = {}
         for name, sz in parts:
@@ -355,6 +359,9 @@ class MAFSpec:
                             r_in = 16 * X + 4 * c + lk
                             f0c[T, X, :, c] = np.where(r_in < cut, f0[T, X, :, c], -1)
                 put("cw1", cw1); put("cw2", cw2); put("cw0", cw0); put("cw3", cw3); put("f0c", f0c)
+                tr = (np.arange(Hp) & ~15) + 4 * (np.arange(Hp) & 3) + ((np.arange(Hp) >> 2) & 3)
+                for name in ("b0", "b1", "b2"):
+                    put(name + "t", bidx(name)[tr])
             if self.univariate == "rqs":
                 NO = self.n_out
                 f3i = np.full((D, 2, nT, 64, 4), -1, dtype=np.int64)
@@ -387,14 +394,15 @@ class MAFSpec:
     def device_meta(self) -> np.ndarray:
         """int32 metadata consumed by the kernels.
 
-        ``[0:8]``  header: D, H, T, Hp, Dp, nT, pk_per_transform, reserved
+        ``[0:8]``  header: D, H, T, Hp, Dp, nT, pk_per_transform, live hidden tiles
         ``[8:8+T*D]``        feature index of every rank, per transform
         ``[8+T*D:8+2*T*D]``  rank of every feature, per transform
         ``[8+2*T*D: +nQ]``   quad meta words (degree | last<<16), shared by all transforms
         """
         D, T = self.n_dim, self.n_transforms
+        live = int(np.sum((self.quad_deg.reshape(-1, 4) < D).any(axis=1)))      # hidden tiles with a degree group (the padding tiles trail)
         hdr = np.array([D, self.hidden, T, self.Hp, self.Dp, self.nT,
-                        self.pk_per_transform, 0], dtype=np.int32)
+                        self.pk_per_transform, live], dtype=np.int32)
         f_o_r = np.concatenate([np.argsort(o) for o in self.orders]).astype(np.int32)
         r_o_f = np.concatenate(self.orders).astype(np.int32)
         return np.concatenate([hdr, f_o_r, r_o_f, self.quad_meta]).astype(np.int32)

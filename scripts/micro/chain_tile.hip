@@ -7,13 +7,16 @@
 //   4: 16 dependent v_add_f32
 //   5: hop with the partial sum as the MFMA's accumulator input (one add less)
 //   6: 16 dependent LDS round trips (ds_write_b32 -> ds_read_b32 of the same word)
+//   7: the tile of the right-looking sweep (mode 0 + every group's share of the next tile + the tile-start reads)
+//   8: mode 7 + the next tile's 16 fragment loads issued in the shadows of the hops
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../pocomc_amd/csrc -I../../include chain_tile.hip -o chain_tile
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include "maf_chain_rot.h"
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
-template <int MODE>
-__global__ __launch_bounds__(64) void k(float* out, long long* cyc, int n, float seed) {
+template <int MODE, int CABL = 1>
+__global__ __launch_bounds__(64) void k(float* out, long long* cyc, int n, float seed, const float* wbuf) {
     __shared__ __attribute__((aligned(16))) float smem[4096];
     const int lane = threadIdx.x, q = lane >> 4, p = lane & 15;
     float* H0 = smem; float* H1 = smem + 1024; float* H2 = smem + 2048; float* X = smem + 2560; float* S = smem + 3584;
@@ -21,7 +24,7 @@ __global__ __launch_bounds__(64) void k(float* out, long long* cyc, int n, float
     __syncthreads();
     float acc = 0.0f;
     long long t0 = 0, t1 = 0;
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 0 || MODE == 7 || MODE == 8) {
         ChainRot<4> s;
         for (int j = 0; j < 4; ++j) {
             s.p1[j] = 0.1f * j; s.p2[j] = -0.05f * j; s.a0[j] = 0.3f + 0.01f * lane;
@@ -31,19 +34,55 @@ __global__ __launch_bounds__(64) void k(float* out, long long* cyc, int n, float
         s.wt1 = make_float4(0.01f * lane * seed, -0.02f * seed, 0.015f, 0.005f);
         s.wt2 = make_float4(-0.01f * lane * seed, 0.02f, -0.015f * seed, 0.004f);
         s.wo[0] = make_float4(0.01f, 0.02f * seed, 0.03f, 0.04f); s.wo[1] = make_float4(-0.01f, 0.02f, -0.03f * seed, 0.04f);
+        s.wn1 = s.wt2; s.wn2 = s.wt1; s.woN[0] = s.wo[1]; s.woN[1] = s.wo[0];
+        for (int j = 0; j < 4; ++j) { s.w0N[j] = make_float4(0.01f * j, 0.02f * seed, 0.03f, 0.01f * lane); s.a0N[j] = 0.0f; }
+        s.accN1 = s.accN2 = s.outN[0] = s.outN[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)wbuf, 0, 1 << 20, 0x00020000);
+        float4 ld[16];
+        int it_ = 0;
+        for (int j = 0; j < 16; ++j) ld[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto hook = [&](auto gi_, auto hop_) {
+            constexpr int G = decltype(gi_)::value, HP = decltype(hop_)::value;
+            if constexpr (MODE == 8) {
+                constexpr int k = G * 3 + HP;           // 12 shadows, 16 loads: the first four shadows take two
+                constexpr int a = k < 4 ? 2 * k : k + 4, b = k < 4 ? 2 * k + 2 : k + 5;
+#pragma unroll
+                for (int j = a; j < b; ++j) {
+                    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, lane << 4, (it_ * 16 + j) * 1024, 0);
+                    ld[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                }
+            }
+        };
         float ladj = 0.0f;
         t0 = clock64();
         for (int it = 0; it < n; ++it) {
+            it_ = it & 31;
+            if constexpr (MODE == 8) {                 // the fragments requested during the previous tile are this tile's
+                s.wt1 = ld[0]; s.wt2 = ld[1]; s.wn1 = ld[2]; s.wn2 = ld[3]; s.wo[0] = ld[4]; s.wo[1] = ld[5]; s.woN[0] = ld[6]; s.woN[1] = ld[7];
+                for (int j = 0; j < 4; ++j) { s.w0N[j] = ld[8 + j]; s.w0r[j][0] = ld[12 + j].x; s.w0r[j][1] = ld[12 + j].y; s.w0r[j][2] = ld[12 + j].z; s.w0r[j][3] = ld[12 + j].w; }
+            }
+            if constexpr (MODE >= 7) {                 // tile start of the right-looking sweep: staged partial + own share
+                const float4 s0 = *reinterpret_cast<const float4*>(S + (lane << 2)), s1 = *reinterpret_cast<const float4*>(S + 256 + (lane << 2)), s2 = *reinterpret_cast<const float4*>(S + 512 + (lane << 2));
+                s.a0[0] += s0.x + s.a0N[0]; s.a0[1] = s0.y + s.a0N[1]; s.a0[2] = s0.z + s.a0N[2]; s.a0[3] = s0.w + s.a0N[3];
+                s.p1[0] = s1.x + s.accN1[0]; s.p1[1] = s1.y + s.accN1[1]; s.p1[2] = s1.z + s.accN1[2]; s.p1[3] = s1.w + s.accN1[3];
+                s.p2[0] = s2.x + s.accN2[0]; s.p2[1] = s2.y + s.accN2[1]; s.p2[2] = s2.z + s.accN2[2]; s.p2[3] = s2.w + s.accN2[3];
+                for (int j = 0; j < 4; ++j) {
+                    const float2 so = *reinterpret_cast<const float2*>(S + 768 + (p << 4) + 2 * j);
+                    s.po[j] = make_float2(so.x + s.outN[j >> 1][2 * (j & 1)], so.y + s.outN[j >> 1][2 * (j & 1) + 1]);
+                    s.a0N[j] = 0.0f;
+                }
+                s.accN1 = s.accN2 = s.outN[0] = s.outN[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             s.acc1 = f32x4{0.f, 0.f, 0.f, 0.f}; s.acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
             s.outR[0] = f32x4{0.f, 0.f, 0.f, 0.f}; s.outR[1] = f32x4{0.f, 0.f, 0.f, 0.f};
             chain_tile_begin(s, X, S, 32, q, p, lane);
-            chain_group_rot<15, 0, 4, 4, 1>(s, H0, H1, X, it & 3, 32, 4, q, p, ladj, H2);
+            chain_group_rot<15, 0, 4, 4, CABL>(s, H0, H1, X, it & 3, 32, 4, q, p, ladj, H2, hook);
             chain_flush(s, ladj);
             s.a0[0] = s.a0[3] * 0.5f + s.pend_x;          // the next tile's first quad waits for this tile's last x
             s.a0[1] = 0.2f; s.a0[2] = 0.1f; s.a0[3] = 0.05f;
         }
         t1 = clock64();
-        acc = ladj + s.a0[0];
+        acc = ladj + s.a0[0] + ld[3].x;
     } else if constexpr (MODE == 1 || MODE == 2 || MODE == 5) {
         float w = 0.01f * seed + lane * 1e-4f, w2 = 0.02f * seed, h = 1.0f + lane * 1e-3f, pp = 0.1f * seed;
         f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
@@ -111,10 +150,13 @@ int main() {
     const char* names[] = {"pattern-15 tile, 4 groups (chain_group_rot): cycles per tile", "hop (MFMA, read, add, add, max) x8: cycles per hop",
                            "hop + one independent MFMA x8: cycles per hop", "univariate map + fma + max x8: cycles each",
                            "16 dependent v_add_f32: cycles each", "hop with the partial as the accumulator input x8: cycles per hop",
-                           "16 LDS write -> read round trips: cycles each"};
-    const double div[] = {1, 8, 8, 8, 16, 8, 16};
-#define RUN(M) for (int rep = 0; rep < 2; ++rep) { k<M><<<1, 64>>>(o, c, n, 1.0f); hipMemcpy(&hc, c, 8, hipMemcpyDeviceToHost); } \
+                           "16 LDS write -> read round trips: cycles each",
+                           "right-looking tile (own groups + share of the next tile, staged partials read): cycles per tile",
+                           "the same with the next tile's 16 fragments requested in the hops' shadows: cycles per tile"};
+    const double div[] = {1, 8, 8, 8, 16, 8, 16, 1, 1};
+    float* wbuf; hipMalloc(&wbuf, 1 << 20); hipMemset(wbuf, 0, 1 << 20);
+#define RUN(M) for (int rep = 0; rep < 2; ++rep) { k<M, (M >= 7 ? 3 : 1)><<<1, 64>>>(o, c, n, 1.0f, wbuf); hipMemcpy(&hc, c, 8, hipMemcpyDeviceToHost); } \
     printf("%-70s %.1f\n", names[M], (double)hc / n / div[M]);
-    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6)
+    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8)
     return 0;
 }

@@ -21,17 +21,19 @@ for _ in range(3):
 torch.cuda.synchronize()
 p = prof.cpu().numpy().astype(np.int64)
 t0 = p[0, 0]
-print(f"D={D} {name} n={n}: chain wave, cycles per tile: fragment loads issued | layer-0 burst + staging | wait B | staging reads | chain groups | wait A")
-tot = np.zeros(6)
+print(f"D={D} {name} n={n}: chain wave, cycles per tile: tile start (staging reads, sums) | groups | wait E")
 hw = p[T * nT:].reshape(-1)[:128].reshape(64, 2)
 print('HW_ID (simd = bits 5:4, cu = bits 11:8, se = 15:13) of the chain / burst wave of workgroups 0..11:')
 print([(f'cu{(int(a)>>8)&15}.se{(int(a)>>13)&7} simd {(int(a)>>4)&3}/{(int(b)>>4)&3}' + ('' if ((int(a)>>8)&0xff) == ((int(b)>>8)&0xff) else ' (other CU?)')) for a, b in hw[:12]])
-print('same SIMD for both waves:', int(sum(((int(a)>>4)&3) == ((int(b)>>4)&3) for a, b in hw)), 'of 64')
 p = p[:T * nT]
+tot = np.zeros(3)
+prev_end = None
 for i in range(T * nT):
     if p[i, 0] == 0:
         continue
-    d = np.diff(p[i, :7])
+    d = np.diff(p[i, :4])
     tot += d
-    print(f"{i:3d} start {p[i,0]-t0:7d} | " + " ".join(f"{v:6d}" for v in d) + f"   (first group {p[i,7]-p[i,4]:5d})")
-print("sum:", " ".join(f"{int(v):7d}" for v in tot), " total", int(p[:, 6].max() - t0))
+    gap = "" if prev_end is None else f"  (since the previous tile's end: {p[i,0]-prev_end})"
+    prev_end = p[i, 3]
+    print(f"{i:3d} start {p[i,0]-t0:7d} | " + " ".join(f"{v:6d}" for v in d) + gap)
+print("sum:", " ".join(f"{int(v):7d}" for v in tot), " total", int(p[:, 3].max() - t0))

@@ -12,6 +12,7 @@ import torch
 
 import cases
 from oracle.maf import OracleMAF
+from parity import close_rel
 from pocomc_amd.maf_spec import MAFSpec
 
 pytestmark = pytest.mark.gpu
@@ -66,30 +67,39 @@ def test_inverse_matches_oracle(D, T, n):
 
 @pytest.mark.parametrize("n", [1, 17, 4096, 10000])
 @pytest.mark.parametrize("D,T", [(32, 3), (10, 6), (64, 3), (64, 6)])
-def test_one_and_two_wave_sweeps_agree_bit_for_bit(D, T, n):
-    """PMC_INVERSE_TRIANGULAR_SOLO (one wavefront per 16 rows) and _DUO (chain + burst wavefront) add the same
-    terms in the same order: identical x and log-determinant, so what AUTO picks by size (and with it the
-    sharding of the walkers over GPUs or lanes) does not show in the results."""
+def test_the_two_wave_sweep_does_not_depend_on_the_launch_and_agrees_with_the_lone_wave(D, T, n):
+    """PMC_INVERSE_TRIANGULAR_DUO (chain + burst wavefront, right-looking: the round-3 sweep) is what AUTO takes for
+    every call size of the flows with fewer than 16 hidden tiles, so the size and the sharding of a walker set
+    (lanes, ranks) cannot show in the results: a row's x and log-determinant are bit-identical whether it is swept
+    alone, in a set of 16 or in the whole call.  PMC_INVERSE_TRIANGULAR_SOLO (one wavefront per 16 rows) forms the same
+    sums in another order (left-looking): it agrees to float32 rounding, measured walker by walker."""
     f, _ = make(D, T)
     z = torch.randn(n, D, generator=torch.Generator().manual_seed(n))
     out = {}
     for algo in (6, 7, 0):
         f.inverse_algo = algo
         out[algo] = [t.numpy() for t in f.inverse(z)]
+    f.inverse_algo = 7
+    for lo, hi in ((0, 1), (n // 2, n // 2 + 16), (max(n - 19, 0), n)):
+        hi = min(hi, n)
+        part = [t.numpy() for t in f.inverse(z[lo:hi])]
+        np.testing.assert_array_equal(part[0], out[7][0][lo:hi])
+        np.testing.assert_array_equal(part[1], out[7][1][lo:hi])
     f.inverse_algo = 0
-    np.testing.assert_array_equal(out[7][0], out[6][0])
-    np.testing.assert_array_equal(out[7][1], out[6][1])
+    fin = np.isfinite(out[6][0]).all(axis=1) & np.isfinite(out[6][1])
+    assert (fin == (np.isfinite(out[7][0]).all(axis=1) & np.isfinite(out[7][1]))).all()
+    assert fin.mean() > 0.99
+    close_rel(out[7][0][fin], out[6][0][fin], 2e-6, "two-wave vs lone-wave sweep, x")
     if f.spec.nT < 16:             # (from 16 hidden tiles on AUTO is the lane-per-walker sweep: another order of additions)
-        np.testing.assert_array_equal(out[0][0], out[6][0])
-        np.testing.assert_array_equal(out[0][1], out[6][1])
+        np.testing.assert_array_equal(out[0][0], out[7][0])
+        np.testing.assert_array_equal(out[0][1], out[7][1])
     else:
         close(out[0][0], out[6][0])
         close(out[0][1], out[6][1])
     import ctypes as C
     from pocomc_amd import _lib
-    duo = _lib.load().pmc_debug_inverse_uses_duo(C.byref(f._desc), n)
-    if (D, T) == (32, 3):          # 41 KB of LDS per walker set: 512 two-wave groups or 768 lone waves at a time
-        assert duo == (1 if n <= 8192 else 0)
+    if f.spec.nT < 16:
+        assert _lib.load().pmc_debug_inverse_uses_duo(C.byref(f._desc), n) == 1
 
 
 @pytest.mark.parametrize("n", [1, 33, 700])
@@ -238,8 +248,8 @@ def test_nsf_inverse_matches_oracle(D, T, n):
 
 
 def test_sweeps_on_random_flow_shapes():
-    """Random (D <= 64, T, hidden, n): the lone-wave and the two-wave sweep agree bit for bit and follow the D-pass
-    inverse on the device (``scripts/fuzz_inverse.py`` is the long version)."""
+    """Random (D <= 64, T, hidden, n): the lone-wave (left-looking) and the two-wave (right-looking) sweep agree to
+    float32 rounding and follow the D-pass inverse on the device (``scripts/fuzz_inverse.py`` is the long version)."""
     from pocomc_amd import Flow
     rng = np.random.default_rng(7)
     done = 0
@@ -258,11 +268,11 @@ def test_sweeps_on_random_flow_shapes():
         for algo in (2, 6, 7):
             f.inverse_algo = algo
             out[algo] = [t.numpy() for t in f.inverse(z)]
-        np.testing.assert_array_equal(out[6][0], out[7][0])
-        np.testing.assert_array_equal(out[6][1], out[7][1])
-        fin = np.isfinite(out[2][0]).all(axis=1) & np.isfinite(out[7][0]).all(axis=1)
+        fin = np.isfinite(out[2][0]).all(axis=1) & np.isfinite(out[7][0]).all(axis=1) & np.isfinite(out[6][0]).all(axis=1)
         if fin.any():
             sc = np.maximum(1.0, np.abs(out[2][0][fin]).max(axis=1, keepdims=True))
+            assert (np.abs(out[7][0][fin] - out[6][0][fin]) / sc).max() < 1e-4, (D, T, H, n)
+            assert np.abs(out[7][1][fin] - out[6][1][fin]).max() < 1e-3 * max(1.0, float(np.abs(out[6][1][fin]).max())), (D, T, H, n)
             # (two float32 algorithms with different summation orders; up to seven transforms amplify the rounding of a
             #  stretched row: measured <= 6e-5 over these shapes)
             assert (np.abs(out[7][0][fin] - out[2][0][fin]) / sc).max() < 5e-4, (D, T, H, n)
