@@ -505,7 +505,7 @@ int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* 
 //     tile against 2.3 k for the chain's own stream (scripts/micro/chain_tile.hip).
 // One LDS-only barrier per tile: E(Tt) = "tile Tt is final, the staging of tile Tt+1 is complete".
 // The chain's fragments of tile Tt+1 (16 loads) are requested in the shadows of tile Tt's hops into the other of two
-// register sets (the tile body exists twice), across transform boundaries too.
+// register set (copied over at the tile boundary), across transform boundaries too.
 // Residency: a workgroup lives on one CU (4 SIMDs, one such wave each): 512 walker sets at a time; the launcher
 // splits larger calls into rounds of this kernel (two rounds still beat the lone wave's one: DESIGN.md section 4).
 // ============================================================================================================
@@ -513,6 +513,9 @@ int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* 
 #ifndef TRI5_ABL
 #define TRI5_ABL 0                 // timing experiments only (scripts/abl_tri5.sh): results are wrong when != 0
 #endif
+#ifndef TRI5_ONE_BODY
+#define TRI5_ONE_BODY 1            // one tile body + a register copy of the operand set per tile (55.9 us at 7008 walkers) instead of two
+#endif                             // bodies with the sets swapping roles (58.5 us: twice the code, and the second copy allocates worse)
 #define PXB 4                      // x tiles of the layer-0 product held in registers (D <= 64)
 #define TRI5_STAGE_FLOATS(MO) ((3 + (MO)) * 256)                 // one staging buffer: S0 | S1 | S2 (transposed, [lane][4]) | SO[MO] (natural)
 #define TRI5_SET_FLOATS(Dp, Hp, MO) (2 * (Dp) * 16 + 2 * (Hp) * 16 + 2 * 256 + 2 * TRI5_STAGE_FLOATS(MO))
@@ -906,11 +909,18 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
             };
             // (two copies of the tile body, the operand sets swapping roles; a transform with an odd number of tiles leaves
             //  the next transform's first operands in the second set: moved over once)
+#if TRI5_ONE_BODY
+            for (int Tt = 0; Tt < nTl; ++Tt) {
+                tile(fA, fB, Tt);
+                fA = fB;
+            }
+#else
             for (int T2 = 0; T2 < nTl; T2 += 2) {
                 tile(fA, fB, T2);
                 if (T2 + 1 >= nTl) { fA = fB; break; }
                 tile(fB, fA, T2 + 1);
             }
+#endif
             w00 = bload4(rs, vo_q, (t > 0 ? t - 1 : 0) * blk_bytes + oCW0);
             const bool last = (t == 0);
             const int* prm = PRM + t * Dp;
