@@ -497,11 +497,24 @@ def main():
         for k in t_lseg:
             t_lseg[k] = 0.0
         n_lt = max(20, min(args.steps, 100))
+        leng.pipeline_stats(reset=True)
         for _ in range(n_lt):
             step_laned()
         torch.cuda.synchronize()
         laned_host = {**{k: v / n_lt * 1e6 for k, v in leng.host_timers.items()},
                       **{k: v / n_lt * 1e6 for k, v in t_lseg.items()}}
+        ps = leng.pipeline_stats(reset=True)
+        if ps is not None:
+            # the lane pipeline behind the C ABI keeps its own clocks: waits (completion words of x' and of the sums) and
+            # the time it spends enqueuing; what is left of a step call is the interpreter
+            laned_host["wait_device"] = (ps["wait_x"] + ps["wait_sums"]) / n_lt * 1e6
+            laned_host["enqueue_accept"] = ps["enqueue_accept"] / n_lt * 1e6
+            laned_host["enqueue_next_pre"] = ps["enqueue_next_pre"] / n_lt * 1e6
+            laned_host["pipeline"] = "pmc_pipeline_next (C ABI)"
+        laned_host["python_overhead"] = (laned_host["step_call"] - laned_host["likelihood"] - laned_host["prior"]
+                                         - laned_host["wait_device"] - laned_host.get("enqueue_accept", 0.0)
+                                         - laned_host.get("enqueue_next_pre", 0.0) - laned_host.get("enqueue_adapt", 0.0)
+                                         - laned_host.get("wait_sums", 0.0))
         leng.host_timers = None
         if pipelined:
             leng.finish_pipeline()

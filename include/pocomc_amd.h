@@ -487,6 +487,30 @@ int pmc_adapt_update(const double* const* parts, int32_t n_parts, int32_t D, dou
                      double* adapt_state, int32_t adapt_mode, double c_sigma, double c_mu, double cap, double n_total,
                      const pmc_done_t* done, void* stream);
 int pmc_stream_synchronize(void* stream);
+
+/* The pipelined step of a walker set stepped as row ranges ("lanes": the device works on the proposals of lane k+1 and
+ * the accept of lane k-1 while the host evaluates the likelihood of lane k), as one object: everything of a loop iteration
+ * of pocomc/mcmc.py:74-156 that is not a black box is enqueued by these calls; the host language keeps the prior /
+ * likelihood callbacks and the stop rule (mcmc.py:159-180, from the sums in the last lane's h_sums).
+ *   lanes[k]: the lanes' pmc_step_t (kept alive and unchanged by the caller; host_direct, h_done, done_ticket, rng_* set;
+ *   ONE adapt_state shared by all lanes, initialised by the caller with {sigma, (1 - sigma^2)^0.5, mu}); offsets[k]: the
+ *   lane's first global walker index (Philox key).
+ * pmc_pipeline_start enqueues the pre-steps (pmc_step_pre) of step `first_step` for every lane.  Then, per step:
+ *   pmc_pipeline_next(p, -1, ...)   returns when lane 0's x', finite mask and logp' are in host memory;
+ *   pmc_pipeline_next(p, k, ...)    the host has written lane k's logl' (and a host prior's logp'): enqueues its accept
+ *                                   (pmc_step_post); k < last: returns when lane k+1's x' is there; k == last: that accept
+ *                                   adds the lanes' sums and applies the adaptation (adapt_mode, c_sigma, c_mu, cap, n_total
+ *                                   as in pmc_step_t.adapt_*), the pre-steps of step + 1 follow (more != 0), and the call
+ *                                   returns when the sums are in the last lane's h_sums.
+ * Same launches in the same order as one pmc_step_pre / pmc_step_post per lane from the host language. */
+void* pmc_pipeline_create(const pmc_step_t* const* lanes, int32_t n_lanes, uint64_t seed, const uint64_t* offsets,
+                          void* prefetcher, double wait_timeout_s, void* stream);
+void pmc_pipeline_destroy(void* pipeline);
+int pmc_pipeline_start(void* pipeline, double nu, int64_t first_step);
+int pmc_pipeline_next(void* pipeline, int32_t lane_done, double beta, double nu, int32_t adapt_mode, double c_sigma,
+                      double c_mu, double cap, double n_total, int32_t more);
+/* out f64 [6] <- { seconds spent waiting for x', waiting for the sums, enqueuing accepts, enqueuing pre-steps, steps, 0 } */
+int pmc_pipeline_stats(void* pipeline, double* out, int32_t reset);
 /* hipEvent helpers for the host language (live kernel timing inside bench.py). */
 void* pmc_event_create(void);
 int pmc_event_record(void* ev, void* stream);

@@ -147,6 +147,11 @@ SIGNATURES = {
     "pmc_step_pre": (C.c_int, [P(pmc_step_t), P(pmc_rng_t), f64, f64, f64, c_p]),
     "pmc_step_post": (C.c_int, [P(pmc_step_t), P(pmc_rng_t), f64, f64, C.c_int, C.c_int, c_p]),
     "pmc_stream_synchronize": (C.c_int, [c_p]),
+    "pmc_pipeline_create": (C.c_void_p, [C.POINTER(C.c_void_p), i32, C.c_uint64, C.POINTER(C.c_uint64), c_p, f64, c_p]),
+    "pmc_pipeline_destroy": (None, [c_p]),
+    "pmc_pipeline_start": (C.c_int, [c_p, f64, i64]),
+    "pmc_pipeline_next": (C.c_int, [c_p, i32, f64, f64, i32, f64, f64, f64, f64, i32]),
+    "pmc_pipeline_stats": (C.c_int, [c_p, C.POINTER(C.c_double), i32]),
     "pmc_event_create": (c_p, []),
     "pmc_event_record": (C.c_int, [c_p, c_p]),
     "pmc_event_elapsed_ms": (C.c_float, [c_p, c_p]),

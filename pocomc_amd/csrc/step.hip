@@ -252,3 +252,132 @@ extern "C" float pmc_event_elapsed_ms(void* a, void* b) {
     return ms;
 }
 extern "C" void pmc_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// The pipelined step of a walker set stepped as K row ranges (lanes), as ONE object behind the C ABI: the host language
+// is left with the black boxes.  Per step (pocomc/mcmc.py:74-156) the driver thread does
+//     pmc_pipeline_next(p, -1, ...)            wait for lane 0's x'
+//     for k in lanes:  likelihood(lane k);  pmc_pipeline_next(p, k, ...)
+// and every call of pmc_pipeline_next enqueues what the device can do next and returns when the host has something to
+// do: the accept of lane k behind its logl', then either the wait for lane k+1's x', or -- behind the last lane -- the
+// closing accept (total sums, sigma / mu update on the device, sums + completion word to the host), the pre-steps of
+// step + 1 for all lanes, and the wait for the sums.  The same launches in the same order as mcmc.LanedEngine's
+// step_pipelined (Python, round 2): results are bit-identical; the ~60 us of interpreter time per step are not.
+struct pmc_pipeline {
+    int n_lanes;
+    const pmc_step_t* lanes[8];
+    pmc_rng_t rng[8];
+    int64_t step;                 // the step whose pre-steps are in flight
+    void* stream;
+    void* prefetcher;
+    double timeout;
+    double t_wait_x, t_wait_sums, t_enq_accept, t_enq_pre;
+    int64_t n_steps;
+};
+
+static double now_s() {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
+extern "C" void* pmc_pipeline_create(const pmc_step_t* const* lanes, int32_t n_lanes, uint64_t seed,
+                                     const uint64_t* offsets, void* prefetcher, double wait_timeout_s, void* stream) {
+    if (!lanes || n_lanes < 1 || n_lanes > 8 || !offsets) { pmc_fail("pmc_pipeline_create: 1..8 lanes"); return nullptr; }
+    for (int k = 0; k < n_lanes; ++k) {
+        const pmc_step_t* s = lanes[k];
+        if (!s || !s->host_direct || !s->h_done || !s->done_ticket || !s->adapt_state || s->p_xT) {
+            pmc_fail("pmc_pipeline_create: every lane needs host_direct buffers, completion words and adapt_state");
+            return nullptr;
+        }
+        if (s->adapt_state != lanes[0]->adapt_state) { pmc_fail("pmc_pipeline_create: one adapt_state for all lanes"); return nullptr; }
+    }
+    pmc_pipeline* p = new pmc_pipeline();
+    p->n_lanes = n_lanes;
+    for (int k = 0; k < n_lanes; ++k) {
+        p->lanes[k] = lanes[k];
+        p->rng[k] = pmc_rng_t{nullptr, nullptr, nullptr, seed, 0, offsets[k]};
+    }
+    p->step = 0;
+    p->stream = stream;
+    p->prefetcher = prefetcher;
+    p->timeout = wait_timeout_s;
+    p->t_wait_x = p->t_wait_sums = p->t_enq_accept = p->t_enq_pre = 0.0;
+    p->n_steps = 0;
+    return p;
+}
+
+extern "C" void pmc_pipeline_destroy(void* pp) { delete (pmc_pipeline*)pp; }
+
+static int pipeline_enqueue_pre(pmc_pipeline* p, int64_t step, double nu) {
+    for (int k = 0; k < p->n_lanes; ++k) {
+        pmc_step_t s = *p->lanes[k];
+        s.adapt_mode = 1;                                   // (pre: any non-zero mode = read sigma, cn_a, mu from adapt_state)
+        p->rng[k].step = (uint64_t)step;
+        const int rc = pmc_step_pre(&s, &p->rng[k], nu, 0.0, 0.0, p->stream);
+        if (rc) return rc;
+        if (p->prefetcher)                                  // helper threads read x' once as soon as its completion word shows up
+            (void)pmc_prefetcher_submit(p->prefetcher, s.h_done, step + 1, s.h_x, (int64_t)s.n * s.D * 8, p->timeout > 0 ? p->timeout : 1.0);
+    }
+    return 0;
+}
+
+extern "C" int pmc_pipeline_start(void* pp, double nu, int64_t first_step) {
+    pmc_pipeline* p = (pmc_pipeline*)pp;
+    if (!p) return pmc_fail("pmc_pipeline_start: null pipeline");
+    p->step = first_step;
+    return pipeline_enqueue_pre(p, first_step, nu);
+}
+
+extern "C" int pmc_pipeline_next(void* pp, int32_t lane_done, double beta, double nu, int32_t adapt_mode, double c_sigma,
+                                 double c_mu, double cap, double n_total, int32_t more) {
+    pmc_pipeline* p = (pmc_pipeline*)pp;
+    if (!p || lane_done < -1 || lane_done >= p->n_lanes) return pmc_fail("pmc_pipeline_next: bad argument");
+    const int last = p->n_lanes - 1;
+    double t0 = now_s();
+    if (lane_done >= 0) {
+        pmc_step_t s = *p->lanes[lane_done];
+        s.adapt_n_other = 0;
+        s.adapt_mode = 0;
+        if (lane_done == last) {
+            // the last range's accept closes the set: total sums, sigma / mu update, sums + completion word to the host
+            s.adapt_mode = adapt_mode; s.adapt_c_sigma = c_sigma; s.adapt_c_mu = c_mu; s.adapt_cap = cap;
+            s.adapt_n_total = n_total;
+            for (int k = 0; k < last; ++k) s.adapt_other[k] = p->lanes[k]->sums;
+            s.adapt_n_other = last;
+        }
+        const int rc = pmc_step_post(&s, &p->rng[lane_done], beta, nu, 0, lane_done == last ? 1 : 0, p->stream);
+        if (rc) return rc;
+        const double t1 = now_s();
+        p->t_enq_accept += t1 - t0;
+        t0 = t1;
+    }
+    if (lane_done < last) {
+        const int rc = pmc_wait_flag(p->lanes[lane_done + 1]->h_done, p->step + 1, p->timeout);
+        p->t_wait_x += now_s() - t0;
+        return rc;
+    }
+    if (more) {
+        const int rc = pipeline_enqueue_pre(p, p->step + 1, nu);
+        if (rc) return rc;
+        const double t1 = now_s();
+        p->t_enq_pre += t1 - t0;
+        t0 = t1;
+    }
+    const int rc = pmc_wait_flag(p->lanes[last]->h_done + 1, p->step + 1, p->timeout);
+    p->t_wait_sums += now_s() - t0;
+    p->step += 1;
+    p->n_steps += 1;
+    return rc;
+}
+
+// out[0..5] <- { seconds waiting for x', for the sums, enqueuing accepts, enqueuing pre-steps, steps, 0 } since the last reset
+extern "C" int pmc_pipeline_stats(void* pp, double* out, int32_t reset) {
+    pmc_pipeline* p = (pmc_pipeline*)pp;
+    if (!p || !out) return pmc_fail("pmc_pipeline_stats: null argument");
+    out[0] = p->t_wait_x; out[1] = p->t_wait_sums; out[2] = p->t_enq_accept; out[3] = p->t_enq_pre;
+    out[4] = (double)p->n_steps; out[5] = 0.0;
+    if (reset) { p->t_wait_x = p->t_wait_sums = p->t_enq_accept = p->t_enq_pre = 0.0; p->n_steps = 0; }
+    return 0;
+}

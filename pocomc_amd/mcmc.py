@@ -108,11 +108,18 @@ class Adaptation:
         return i >= self.n_max
 
 
-# How long the driver thread spins on a completion word before it gives up (seconds; <= 0: for ever).  In the sharded
-# pipelined step the word sits behind the all-reduce, i.e. behind the slowest rank's host likelihood: a run with an
-# expensive or imbalanced likelihood sets this through option_dict["wait_timeout"] / PMC_WAIT_TIMEOUT.
-import os as _os
-WAIT_TIMEOUT_S = float(_os.environ.get("PMC_WAIT_TIMEOUT", "600"))
+# How long the driver thread spins on a completion word before it gives up (seconds).  In the sharded pipelined step the
+# word sits behind the all-reduce, i.e. behind the slowest rank's host likelihood: a run with an expensive or imbalanced
+# likelihood raises it through option_dict["wait_timeout"] / PMC_WAIT_TIMEOUT.  It is a property of the engine
+# (``StepEngine.wait_timeout``), never of the process; values <= 0 or above the cap mean the cap (a dead peer or a hung
+# device must surface as an error, not as a silent spin).
+WAIT_TIMEOUT_DEFAULT_S = float(os.environ.get("PMC_WAIT_TIMEOUT", "600"))
+WAIT_TIMEOUT_CAP_S = 7 * 24 * 3600.0
+
+
+def _wait_timeout(value):
+    v = WAIT_TIMEOUT_DEFAULT_S if value is None else float(value)
+    return WAIT_TIMEOUT_CAP_S if (v <= 0.0 or v > WAIT_TIMEOUT_CAP_S) else v
 
 _POOLS = {}
 _PINNED_FREE = {}
@@ -299,6 +306,7 @@ class StepEngine:
         self.stream = None       # torch.cuda.Stream of the composite path (LanedEngine); None: the current one
         self.events = None       # bench.py: list of per-step HIP event tuples when not None
         self.host_timers = None  # bench.py: dict of accumulated host seconds when not None
+        self.wait_timeout = _wait_timeout(None)      # seconds the driver thread spins on a completion word before it raises
 
     def __del__(self):
         if getattr(self, "_recycle", False):       # (only after the owner synchronised with the device: mcmc._run)
@@ -404,20 +412,7 @@ class StepEngine:
                 self._rng_fast.step = self.step_idx if step is None else int(step)
                 self._rng_cur = self._rng_fast
             self._step.adapt_mode = 1 if self.device_adapt else 0         # (pre: any non-zero mode = read the state)
-            # the rest of the struct depends on the engine's switches only: written when one of them changed
-            cfg = (self.flow.inverse_algo if self.pre else 0, self.rng_prefill, self.host_direct, self.spin_wait)
-            if cfg != self._pre_cfg:
-                self._pre_cfg = cfg
-                if self.pre:
-                    self._step.inverse_algo = self.flow.inverse_algo
-                self._step.rng_ready = C.cast(C.pointer(self._rng_ready), C.c_void_p) if self.rng_prefill else None
-                direct = bool(self.host_direct and self.x_order == "F")
-                self._step.host_direct = int(direct)
-                self._step.p_xT = None if (direct or self.p_xT is None) else self.p_xT.data_ptr()
-                self._direct_now = direct and self.spin_wait
-                self._step.h_done = self.h_done.data_ptr() if self._direct_now else None
-                self._step.done_ticket = self._done_ticket.data_ptr() if self._direct_now else None
-                self._step.ev_pre_done = None if self._direct_now else self._ev_pre     # (the completion word replaces it)
+            self._configure_step()
             if self.device_adapt:
                 sigma, cn_a = 0.0, 0.0                      # the kernels read adapt_state instead
             else:
@@ -428,7 +423,7 @@ class StepEngine:
             if self.prefetcher is not None and self._direct_now:
                 # helper threads read x' once as soon as the completion word of this pre-step shows up
                 lib.pmc_prefetcher_submit(self.prefetcher, self.h_done.data_ptr(), int(self._rng_cur.step) + 1,
-                                          self.h_x.data_ptr(), n * D * 8, 1.0)
+                                          self.h_x.data_ptr(), n * D * 8, self.wait_timeout)
             self._post_uploads = True
             return
         self._post_uploads = False
@@ -471,16 +466,35 @@ class StepEngine:
         if timed:
             self._cur_ev = [e0, e1, e2, e3, self._ev()]
 
-    def evaluate(self, log_prior, log_like, have_blobs=False, blobs=None):
+    def _configure_step(self):
+        """The fields of the composite entry points' struct that depend on the engine's switches only: written when
+        one of them changed."""
+        cfg = (self.flow.inverse_algo if self.pre else 0, self.rng_prefill, self.host_direct, self.spin_wait)
+        if cfg != self._pre_cfg:
+            self._pre_cfg = cfg
+            if self.pre:
+                self._step.inverse_algo = self.flow.inverse_algo
+            self._step.rng_ready = C.cast(C.pointer(self._rng_ready), C.c_void_p) if self.rng_prefill else None
+            direct = bool(self.host_direct and self.x_order == "F")
+            self._step.host_direct = int(direct)
+            self._step.p_xT = None if (direct or self.p_xT is None) else self.p_xT.data_ptr()
+            self._direct_now = direct and self.spin_wait
+            self._step.h_done = self.h_done.data_ptr() if self._direct_now else None
+            self._step.done_ticket = self._done_ticket.data_ptr() if self._direct_now else None
+            self._step.ev_pre_done = None if self._direct_now else self._ev_pre     # (the completion word replaces it)
+
+    def evaluate(self, log_prior, log_like, have_blobs=False, blobs=None, waited=False):
         """Host black boxes on the compacted rows, ``mcmc.py:100-121``.  Returns
         ``(n_calls, blobs_prime)``."""
         tm = self.host_timers
         t0 = time.perf_counter() if tm is not None else 0.0
-        if self._post_uploads:
+        if waited:
+            pass                                      # (pmc_pipeline_next returned behind this lane's completion word)
+        elif self._post_uploads:
             # x', finite, logp' are complete at this event / completion word; the next step's variates are
             # generated behind it
             if self._direct_now:
-                _lib.check(self.lib.pmc_wait_flag(self.h_done.data_ptr(), self.step_idx + 1, WAIT_TIMEOUT_S), "pmc_wait_flag")
+                _lib.check(self.lib.pmc_wait_flag(self.h_done.data_ptr(), self.step_idx + 1, self.wait_timeout), "pmc_wait_flag")
             else:
                 _lib.check(self.lib.pmc_event_synchronize(self._ev_pre), "pmc_event_synchronize")
         else:
@@ -589,7 +603,7 @@ class StepEngine:
     def accept_wait(self):
         """Wait for what accept_enqueue started; returns this engine's host sums (valid with host_sums=True)."""
         if self._direct_now and self._host_sums and not self._want_mask:   # (the mask copy is a stream operation)
-            _lib.check(self.lib.pmc_wait_flag(self.h_done.data_ptr() + 8, self.step_idx + 1, WAIT_TIMEOUT_S), "pmc_wait_flag")
+            _lib.check(self.lib.pmc_wait_flag(self.h_done.data_ptr() + 8, self.step_idx + 1, self.wait_timeout), "pmc_wait_flag")
         else:
             _lib.check(self.lib.pmc_stream_synchronize(self._stream), "pmc_stream_synchronize")
         self.step_idx += 1
@@ -682,6 +696,22 @@ class LanedEngine:
         self._flag_value = 0
         self._parts = (C.c_void_p * len(self.lanes))(*[e.sums.data_ptr() for e in self.lanes])
         self._tot_part = (C.c_void_p * 1)(self._tot.data_ptr())
+        # the lane pipeline behind the C ABI (pmc_pipeline_*): default whenever the ranks do not have to all-reduce between
+        # the last accept and the adaptation (that exchange is torch.distributed's); PMC_C_PIPELINE=0: the same launches
+        # enqueued from Python (round 2; kept as the cross-check of the test suite)
+        self.c_pipeline = os.environ.get("PMC_C_PIPELINE", "1") != "0"
+        self._pipe = None
+
+    def __del__(self):
+        self._drop_pipe()
+
+    def _drop_pipe(self):
+        if getattr(self, "_pipe", None):
+            try:
+                self.lib.pmc_pipeline_destroy(self._pipe)
+            except Exception:
+                pass
+            self._pipe = None
 
     def _each(self, fn):
         out = []
@@ -716,14 +746,59 @@ class LanedEngine:
         for e in self.lanes[1:]:
             e._step.adapt_state = first.adapt_state.data_ptr()       # one state for all lanes
             e.device_adapt = True
+        import torch.distributed as dist
+        sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        self._drop_pipe()
+        if self.c_pipeline and not sharded and len(self.lanes) <= 8:
+            K = len(self.lanes)
+            for e in self.lanes:
+                e._configure_step()
+                e._post_uploads = True
+            assert all(e._direct_now for e in self.lanes)
+            self._lane_structs = (C.c_void_p * K)(*[C.addressof(e._step) for e in self.lanes])
+            offs = (C.c_uint64 * K)(*[e.offset for e in self.lanes])
+            stream = first.stream.cuda_stream if first.stream is not None else _lib.stream_handle()
+            first._stream = stream
+            self._pipe = self.lib.pmc_pipeline_create(self._lane_structs, K, first.seed, offs, first.prefetcher,
+                                                      float(first.wait_timeout), stream)
+            if not self._pipe:
+                _lib.check(1, "pmc_pipeline_create")
+            _lib.check(self.lib.pmc_pipeline_start(self._pipe, float(nu), int(first.step_idx)), "pmc_pipeline_start")
+            return
         for e in self.lanes:
             e.host_timers = self.host_timers
             e.propose(None, nu)
+
+    def pipeline_stats(self, reset=True):
+        """Host seconds the C pipeline spent {waiting for x', waiting for the sums, enqueuing accepts, enqueuing
+        pre-steps} and the steps they cover, since the last reset (None without a C pipeline)."""
+        if not self._pipe:
+            return None
+        out = (C.c_double * 6)()
+        _lib.check(self.lib.pmc_pipeline_stats(self._pipe, out, int(reset)), "pmc_pipeline_stats")
+        return dict(wait_x=out[0], wait_sums=out[1], enqueue_accept=out[2], enqueue_next_pre=out[3], steps=int(out[4]))
 
     def step_pipelined(self, beta, nu, coefficients, n_total, log_prior, log_like, more=True):
         """One step: per lane  wait x' -> likelihood -> enqueue accept;  then one launch adds the lane sums (and,
         between two of them, the ranks all-reduce), adapts sigma / mu on the device and hands the sums to the host;
         the pre-steps of the next step are enqueued behind it before the host waits for those sums."""
+        if self._pipe:
+            # pmc_pipeline_next: accept of the lane just evaluated, then the wait for the next lane's x' -- or, behind the
+            # last lane, the closing accept, the next pre-steps and the wait for the sums
+            nxt, P = self.lib.pmc_pipeline_next, self._pipe
+            mode, c_sigma, c_mu, cap = coefficients
+            tm = self.host_timers
+            if nxt(P, -1, beta, nu, mode, c_sigma, c_mu, cap, n_total, 0):
+                _lib.check(1, "pmc_pipeline_next")
+            calls = 0
+            for k, e in enumerate(self.lanes):
+                e.host_timers = tm
+                calls += e.evaluate(log_prior, log_like, waited=True)[0]
+                if nxt(P, k, beta, nu, mode, c_sigma, c_mu, cap, n_total, int(more)):
+                    _lib.check(1, "pmc_pipeline_next")
+            for e in self.lanes:
+                e.step_idx += 1
+            return calls, self.lanes[-1]._np_sums
         import torch.distributed as dist
         sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         lib, D, K = self.lib, self.D, len(self.lanes)
@@ -766,7 +841,7 @@ class LanedEngine:
                 e.propose(None, nu, step=e.step_idx + 1)
         t2 = clock() if tm is not None else 0.0
         if sharded:
-            _lib.check(lib.pmc_wait_flag(self._h_flag.data_ptr(), self._flag_value, WAIT_TIMEOUT_S), "pmc_wait_flag")
+            _lib.check(lib.pmc_wait_flag(self._h_flag.data_ptr(), self._flag_value, self.lanes[0].wait_timeout), "pmc_wait_flag")
             sums = self._h_tot.numpy()
         else:
             sums = last.accept_wait()                       # (increments the last lane's step counter)
@@ -902,7 +977,7 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
     # (needs the kernels to read / write the pinned host buffers themselves: x_order 'F')
     want_pipe = (option_dict.get("pipeline", True) and x_order == "F" and not have_blobs and trace is None
                  and replay is None and all(option_dict.get(k, True) for k in ("host_direct", "spin_wait")))
-    if lanes > 1 or (sharded and want_pipe):
+    if lanes > 1 or want_pipe:                      # (the pipelined step lives behind pmc_pipeline_*: one lane is a pipeline too)
         eng = LanedEngine(kind, n_walkers, n_dim, flow, scaler, lanes=lanes, group=group,
                           first_fraction=option_dict.get("first_lane"),
                           shard_offset=option_dict.get("shard_offset", 0), seed=seed, x_order=x_order,
@@ -914,8 +989,7 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
         tune = lambda **kw: [setattr(eng, k, v) for k, v in kw.items()]
     laned = isinstance(eng, LanedEngine)
     if option_dict.get("wait_timeout") is not None:
-        global WAIT_TIMEOUT_S
-        WAIT_TIMEOUT_S = float(option_dict["wait_timeout"])
+        tune(wait_timeout=_wait_timeout(option_dict["wait_timeout"]))
     for key in ("host_direct", "rng_prefill", "spin_wait"):
         if key in option_dict:
             tune(**{key: bool(option_dict[key])})

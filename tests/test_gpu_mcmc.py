@@ -641,6 +641,59 @@ def test_laned_kernel_call_equals_the_whole_set_call(kind, N, lanes, x_order):
         np.testing.assert_allclose(a[k][same], b[k][same], rtol=1e-8, atol=1e-10, err_msg=k)
 
 
+@pytest.mark.parametrize("kind", ["preconditioned_pcn", "preconditioned_rwm", "pcn", "rwm"])
+@pytest.mark.parametrize("N,lanes", [(1000, 1), (1000, 2), (4100, 3)])
+def test_the_pipeline_behind_the_c_abi_equals_the_python_pipeline_bit_for_bit(kind, N, lanes, monkeypatch):
+    """``pmc_pipeline_next`` (one C call per lane and step: accept of the lane just evaluated, next pre-steps, waits)
+    enqueues exactly the launches ``LanedEngine.step_pipelined`` enqueued from Python in round 2 (``PMC_C_PIPELINE=0``
+    keeps that path): identical walkers, sums, scale, counts -- every kernel of ``mcmc.py:74-156``'s four variants,
+    with a likelihood that rejects part of the space and a plateau stop in the middle of the call."""
+    from scipy.stats import uniform
+    import pocomc_amd as pc
+    from pocomc_amd import mcmc as pmcmc
+    from pocomc_amd.geometry import Geometry
+    import torch
+    D = 6
+    prior = pc.Prior([uniform(-5, 10)] * D)
+    rng = np.random.default_rng(N + lanes)
+    scaler = pc.Reparameterize(D, bounds=prior.bounds)
+    scaler.fit(prior.rvs(2000))
+    x = rng.uniform(-4, 4, size=(N, D))
+    u = scaler.forward(x)
+
+    def like(xx):
+        l = -0.5 * np.sum(xx ** 2, axis=1)
+        l[xx[:, 0] > 3.5] = -np.inf
+        return l, None
+    flow = pc.Flow(D, "maf3", seed=0)
+    geo = Geometry()
+    geo.fit(flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64))
+    geo.normal_cov = np.cov(u.T)
+    res, used = [], []
+    for c_pipe in ("1", "0"):
+        monkeypatch.setenv("PMC_C_PIPELINE", c_pipe)
+        made = []
+        real = pmcmc.LanedEngine.start_pipeline
+
+        def spy(self, *a, _real=real, _made=made, **k):
+            _real(self, *a, **k)
+            _made.append(bool(self._pipe))
+        monkeypatch.setattr(pmcmc.LanedEngine, "start_pipeline", spy)
+        state = dict(u=u.copy(), x=x.copy(), logdetj=scaler.inverse(u)[1], logl=like(x)[0], logp=prior.logpdf(x),
+                     beta=0.5, blobs=None)
+        funcs = dict(loglike=like, logprior=prior.logpdf, scaler=scaler, flow=flow, theta_geometry=geo, u_geometry=geo)
+        opts = dict(n_max=40, n_steps=2, progress_bar=None, proposal_scale=2.38 / D ** 0.5, seed=5, lanes=lanes, x_order="F")
+        res.append(getattr(pmcmc, kind)(state, funcs, opts))
+        monkeypatch.setattr(pmcmc.LanedEngine, "start_pipeline", real)
+        used.append(made)
+    assert used == [[True], [False]], used                  # the first call went through pmc_pipeline_*, the second did not
+    a, b = res
+    assert 2 <= a["steps"] == b["steps"] and a["calls"] == b["calls"]
+    for k in ("u", "x", "logl", "logp", "logdetj"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert a["proposal_scale"] == b["proposal_scale"] and a["accept"] == b["accept"] and a["efficiency"] == b["efficiency"]
+
+
 @pytest.mark.parametrize("name", ["tpcn_n256_d10_normal", "tpcn_n128_d6_mixed_bc"])
 def test_likelihoods_with_holes_match_the_oracle(name):
     """Edge cases of mcmc.py:100-134: a likelihood that is -inf on part of the space and NaN on another part
