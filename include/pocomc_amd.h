@@ -582,6 +582,10 @@ int pmc_affine_rows(const double* M, const double* mu, const double* in, double*
  * stats f64 [>= 1] on the device: stats[0] = max(logw) (pmc_logw_stats). */
 int pmc_bootstrap_logz(const double* logw, int64_t n, const double* stats, int64_t B, uint64_t seed, double* out,
                        void* stream);
+/* The same with the draws given: draws i64 [B][n] on the device, values in [0, n) -- np.random.choice(n, n) of
+ * sampler.py:908 as the reference drew it (parity tests replay the recorded stream). */
+int pmc_bootstrap_logz_replay(const double* logw, int64_t n, const double* stats, int64_t B, const int64_t* draws,
+                              double* out, void* stream);
 
 /* Sampler._resample gather, sampler.py:707-713: dst[i] = src[idx[i]] for the five arrays. */
 int pmc_gather(const int64_t* idx, int64_t n_out, int32_t D, const double* u, const double* x,

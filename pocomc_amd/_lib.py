@@ -169,6 +169,7 @@ SIGNATURES = {
     "pmc_column_medians_workspace_bytes": (C.c_int64, [i64, i32, i32]),
     "pmc_column_medians": (C.c_int, [c_p, c_p, c_p, i64, i32, c_p, c_p, c_p, i64, c_p]),
     "pmc_bootstrap_logz": (C.c_int, [c_p, i64, c_p, i64, C.c_uint64, c_p, c_p]),
+    "pmc_bootstrap_logz_replay": (C.c_int, [c_p, i64, c_p, i64, c_p, c_p, c_p]),
     "pmc_rng_fill": (C.c_int, [P(pmc_rng_t), f64, c_p, c_p, c_p, i64, i32, c_p]),
     "pmc_event_destroy": (None, [c_p]),
     "pmc_logw": (C.c_int, [c_p, c_p, c_p, f64, c_p, i32, i64, c_p]),

@@ -4,7 +4,8 @@
 // pool that stays in HBM.  Reductions are ordered (block partials summed by one block in index order): a run is
 // reproducible bit for bit.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <string.h>
+#include <rocprim/rocprim.hpp>
 #include <stdint.h>
 #include "philox.h"
 #include "pmc_internal.h"
@@ -90,9 +91,9 @@ extern "C" int pmc_sum_f64(const double* a, int64_t n, double* out, void* stream
 
 extern "C" int64_t pmc_trim_select_workspace_bytes(int64_t P) {
     size_t tmp = 0;
-    hipcub::CountingInputIterator<int64_t> it(0);
+    rocprim::counting_iterator<int64_t> it(0);
     KeepAbove op{nullptr, nullptr};
-    (void)hipcub::DeviceSelect::If(nullptr, tmp, it, (int64_t*)nullptr, (int64_t*)nullptr, (int)P, op);
+    (void)rocprim::select(nullptr, tmp, it, (int64_t*)nullptr, (int64_t*)nullptr, (size_t)P, op);
     return (int64_t)(tmp + 256);
 }
 
@@ -102,13 +103,13 @@ extern "C" int pmc_trim_select(const double* w, int64_t P, const double* thresho
     if (!w || !threshold || !idx_out || !w_out || !count || !workspace || P < 1) return pmc_fail("pmc_trim_select: bad argument");
     hipStream_t st = (hipStream_t)stream;
     size_t need = 0;
-    hipcub::CountingInputIterator<int64_t> it(0);
+    rocprim::counting_iterator<int64_t> it(0);
     KeepAbove op{w, threshold};
-    (void)hipcub::DeviceSelect::If(nullptr, need, it, idx_out, count, (int)P, op);
+    (void)rocprim::select(nullptr, need, it, idx_out, count, (size_t)P, op);
     if ((int64_t)need + 16 > workspace_bytes) return pmc_fail("pmc_trim_select: workspace too small");
     double* total = (double*)workspace;
     void* tmp = (void*)((char*)workspace + 16);
-    if (hipcub::DeviceSelect::If(tmp, need, it, idx_out, count, (int)P, op, st) != hipSuccess)
+    if (rocprim::select(tmp, need, it, idx_out, count, (size_t)P, op, st) != hipSuccess)
         return pmc_fail("pmc_trim_select: select failed");
     int64_t grid = (P + 255) / 256; if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(take_kernel, dim3((unsigned)grid), dim3(256), 0, st, w, (const int64_t*)idx_out, (const int64_t*)count, w_out);
@@ -263,8 +264,8 @@ __global__ void pick_median_kernel(const T* __restrict__ sorted, int64_t n, int 
 template <typename T>
 static int64_t medians_bytes(int64_t n, int32_t D) {
     size_t tmp = 0;
-    (void)hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, tmp, (const T*)nullptr, (T*)nullptr, (int)(n * D), (int)D,
-                                                     (const int*)nullptr, (const int*)nullptr);
+    (void)rocprim::segmented_radix_sort_keys(nullptr, tmp, (const T*)nullptr, (T*)nullptr, (unsigned)(n * D), (unsigned)D,
+                                             (const int*)nullptr, (const int*)nullptr);
     return (int64_t)(2 * sizeof(T) * (size_t)n * D + sizeof(int) * (size_t)(D + 1) + tmp + 512);
 }
 
@@ -280,13 +281,13 @@ static int medians_run(const T* x, const int64_t* idx, int64_t n, int32_t D, T* 
     int* off = (int*)(srt + (size_t)n * D);
     void* tmp = (void*)(((uintptr_t)(off + D + 1) + 255) & ~(uintptr_t)255);
     size_t need = 0;
-    (void)hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, need, (const T*)xt, srt, (int)(n * D), (int)D, off, off + 1);
+    (void)rocprim::segmented_radix_sort_keys(nullptr, need, (const T*)xt, srt, (unsigned)(n * D), (unsigned)D, (const int*)off, (const int*)(off + 1));
     if ((char*)tmp + need > (char*)workspace + bytes) return pmc_fail("pmc_column_medians: workspace too small");
     int64_t grid = (n * D + 255) / 256; if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(transpose_rows_kernel<T>, dim3((unsigned)grid), dim3(256), 0, st, x, idx, n, (int)D, xt);
     hipLaunchKernelGGL(segment_offsets_kernel, dim3(1), dim3(256), 0, st, n, (int)D, off);
-    if (hipcub::DeviceSegmentedRadixSort::SortKeys(tmp, need, (const T*)xt, srt, (int)(n * D), (int)D, off, off + 1, 0,
-                                                   (int)sizeof(T) * 8, st) != hipSuccess)
+    if (rocprim::segmented_radix_sort_keys(tmp, need, (const T*)xt, srt, (unsigned)(n * D), (unsigned)D, (const int*)off,
+                                           (const int*)(off + 1), 0u, (unsigned)sizeof(T) * 8, st) != hipSuccess)
         return pmc_fail("pmc_column_medians: sort failed");
     hipLaunchKernelGGL(pick_median_kernel<T>, dim3(1), dim3(256), 0, st, (const T*)srt, n, (int)D, med);
     return pmc_check_launch("pmc_column_medians");
@@ -308,21 +309,26 @@ extern "C" int pmc_column_medians(const double* x, const float* x32, const int64
 // bootstrap of the evidence estimate, sampler.py:905-911: out[b] = logsumexp(logw[choice(n, n)]) - log(n) for B
 // replicates; one workgroup per replicate, indices from Philox keyed by (seed, replicate, draw)
 // ---------------------------------------------------------------------------------------------------------------
+// replay != NULL: i64 [B][n] the draws of every replicate (np.random.choice(n, n) of sampler.py:908, recorded) instead of Philox
 __global__ __launch_bounds__(256) void bootstrap_lse_kernel(const double* __restrict__ logw, int64_t n, const double* __restrict__ stats,
-                                                            uint64_t seed, double* __restrict__ out) {
+                                                            uint64_t seed, const int64_t* __restrict__ replay, double* __restrict__ out) {
     __shared__ double part[256];
     const double mx = stats[0];
     double s = 0.0;
     for (int64_t e = (int64_t)threadIdx.x * 2; e < n; e += 512) {
-        Philox ph(seed, (uint64_t)blockIdx.x, (uint64_t)(e >> 1), 3);
-        double u0, u1;
-        ph.uniform2(u0, u1);
-        int64_t i0 = (int64_t)(u0 * (double)n); if (i0 >= n) i0 = n - 1;
-        s += exp(logw[i0] - mx);
-        if (e + 1 < n) {
-            int64_t i1 = (int64_t)(u1 * (double)n); if (i1 >= n) i1 = n - 1;
-            s += exp(logw[i1] - mx);
+        int64_t i0, i1;
+        if (replay) {
+            i0 = replay[(size_t)blockIdx.x * n + e];
+            i1 = e + 1 < n ? replay[(size_t)blockIdx.x * n + e + 1] : 0;
+        } else {
+            Philox ph(seed, (uint64_t)blockIdx.x, (uint64_t)(e >> 1), 3);
+            double u0, u1;
+            ph.uniform2(u0, u1);
+            i0 = (int64_t)(u0 * (double)n); if (i0 >= n) i0 = n - 1;
+            i1 = (int64_t)(u1 * (double)n); if (i1 >= n) i1 = n - 1;
         }
+        s += exp(logw[i0] - mx);
+        if (e + 1 < n) s += exp(logw[i1] - mx);
     }
     part[threadIdx.x] = s;
     __syncthreads();
@@ -337,7 +343,17 @@ __global__ __launch_bounds__(256) void bootstrap_lse_kernel(const double* __rest
 extern "C" int pmc_bootstrap_logz(const double* logw, int64_t n, const double* stats, int64_t B, uint64_t seed, double* out,
                                   void* stream) {
     if (!logw || !stats || !out || n < 1 || B < 1) return pmc_fail("pmc_bootstrap_logz: bad argument");
-    hipLaunchKernelGGL(bootstrap_lse_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, logw, n, stats, seed, out);
+    hipLaunchKernelGGL(bootstrap_lse_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, logw, n, stats, seed,
+                       (const int64_t*)nullptr, out);
+    return pmc_check_launch("bootstrap_lse_kernel");
+}
+
+// the same with the draws given (parity tests: the reference's recorded np.random.choice draws, sampler.py:908)
+extern "C" int pmc_bootstrap_logz_replay(const double* logw, int64_t n, const double* stats, int64_t B, const int64_t* draws,
+                                         double* out, void* stream) {
+    if (!logw || !stats || !out || !draws || n < 1 || B < 1) return pmc_fail("pmc_bootstrap_logz_replay: bad argument");
+    hipLaunchKernelGGL(bootstrap_lse_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, logw, n, stats, (uint64_t)0,
+                       draws, out);
     return pmc_check_launch("bootstrap_lse_kernel");
 }
 

@@ -7,7 +7,8 @@
 // reference's downward scan would accept.
 
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <string.h>
+#include <rocprim/rocprim.hpp>
 #include <stdint.h>
 #include "pmc_internal.h"
 
@@ -63,8 +64,8 @@ __global__ __launch_bounds__(1024) void trim_search_kernel(const double* __restr
 
 extern "C" int64_t pmc_trim_workspace_bytes(int64_t P) {
     size_t tmp_sort = 0, tmp_scan = 0;
-    hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_sort, (const double*)nullptr, (double*)nullptr, (int)P);
-    hipcub::DeviceScan::InclusiveSum(nullptr, tmp_scan, (const double*)nullptr, (double*)nullptr, (int)P);
+    (void)rocprim::radix_sort_keys(nullptr, tmp_sort, (const double*)nullptr, (double*)nullptr, (size_t)P);
+    (void)rocprim::inclusive_scan(nullptr, tmp_scan, (const double*)nullptr, (double*)nullptr, (size_t)P, rocprim::plus<double>());
     const size_t tmp = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
     return (int64_t)(4 * (size_t)P * sizeof(double) + tmp + 256);
 }
@@ -81,16 +82,16 @@ extern "C" int pmc_trim_threshold(const double* w, int64_t P, double ess, int32_
     void* tmp = (void*)(c2 + P);
     size_t tmp_bytes = (size_t)workspace_bytes - 4 * (size_t)P * sizeof(double);
     size_t need = 0;
-    hipcub::DeviceRadixSort::SortKeys(nullptr, need, w, sorted, (int)P);
-    if (hipcub::DeviceRadixSort::SortKeys(tmp, need, w, sorted, (int)P, 0, 64, st) != hipSuccess)
+    (void)rocprim::radix_sort_keys(nullptr, need, w, sorted, (size_t)P);
+    if (rocprim::radix_sort_keys(tmp, need, w, sorted, (size_t)P, 0u, 64u, st) != hipSuccess)
         return pmc_fail("pmc_trim_threshold: radix sort failed");
     int64_t grid = (P + 255) / 256; if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(square_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const double*)sorted, sq, P);
-    hipcub::DeviceScan::InclusiveSum(nullptr, need, (const double*)sorted, c1, (int)P);
+    (void)rocprim::inclusive_scan(nullptr, need, (const double*)sorted, c1, (size_t)P, rocprim::plus<double>());
     if (need > tmp_bytes) return pmc_fail("pmc_trim_threshold: workspace too small (scan)");
-    if (hipcub::DeviceScan::InclusiveSum(tmp, need, (const double*)sorted, c1, (int)P, st) != hipSuccess)
+    if (rocprim::inclusive_scan(tmp, need, (const double*)sorted, c1, (size_t)P, rocprim::plus<double>(), st) != hipSuccess)
         return pmc_fail("pmc_trim_threshold: scan failed");
-    if (hipcub::DeviceScan::InclusiveSum(tmp, need, (const double*)sq, c2, (int)P, st) != hipSuccess)
+    if (rocprim::inclusive_scan(tmp, need, (const double*)sq, c2, (size_t)P, rocprim::plus<double>(), st) != hipSuccess)
         return pmc_fail("pmc_trim_threshold: scan failed");
     hipLaunchKernelGGL(trim_search_kernel, dim3(1), dim3(1024), 0, st, (const double*)sorted, (const double*)c1,
                        (const double*)c2, P, ess, (int)bins, result);

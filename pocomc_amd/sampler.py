@@ -485,11 +485,16 @@ class Sampler:
     def evidence(self):
         return self.logz, self.logz_err
 
-    def _compute_evidence(self, n=5_000):
+    def _compute_evidence(self, n=5_000, replay=None):
         """Importance sampling with the flow as proposal (``sampler.py:869-920``): ``x_q`` goes to the host for the
         likelihood (the black box lives there); the error is the spread of ``max(n, 1000)`` bootstrap replicates of
-        the estimate, drawn and reduced on the device."""
-        theta_q, logq = self.flow.sample(n)
+        the estimate, drawn and reduced on the device.  ``replay`` (parity tests): ``dict(z=(n, D) base draw of the
+        flow, draws=(B, m) bootstrap indices)`` instead of the generators."""
+        if replay is not None:
+            theta_q, logq = self.flow.sample(len(replay["z"]), z=torch.as_tensor(replay["z"], dtype=torch.float32))
+            n = len(replay["z"])
+        else:
+            theta_q, logq = self.flow.sample(n)
         x_q, logdetj = self.scaler.inverse(theta_q.cpu().numpy().astype(np.float64))
         logq = logq.cpu().numpy().astype(np.float64)
         logp = self.log_prior(x_q)
@@ -504,11 +509,22 @@ class Sampler:
         ws = torch.empty(int(lib.pmc_reduce_workspace_bytes(m)), dtype=torch.uint8, device=dev)
         B = int(np.maximum(n, 1000))
         reps = torch.empty(B, dtype=torch.float64, device=dev)
-        seed = int(np.random.randint(0, 2 ** 31 - 1)) * 2 ** 31 + int(np.random.randint(0, 2 ** 31 - 1))
+        draws = None
+        if replay is not None:
+            draws = torch.from_numpy(np.ascontiguousarray(replay["draws"], dtype=np.int64)).to(dev)
+            assert draws.ndim == 2 and draws.shape[1] == m
+            B = draws.shape[0]
+            reps = torch.empty(B, dtype=torch.float64, device=dev)
+        else:
+            seed = int(np.random.randint(0, 2 ** 31 - 1)) * 2 ** 31 + int(np.random.randint(0, 2 ** 31 - 1))
         with torch.cuda.device(dev):
             st = _lib.stream_handle()
             _lib.check(lib.pmc_logw_stats(_lib.ptr(lw), m, 0, _lib.ptr(stats), _lib.ptr(ws), st), "pmc_logw_stats")
-            _lib.check(lib.pmc_bootstrap_logz(_lib.ptr(lw), m, _lib.ptr(stats), B, seed, _lib.ptr(reps), st), "pmc_bootstrap_logz")
+            if draws is not None:
+                _lib.check(lib.pmc_bootstrap_logz_replay(_lib.ptr(lw), m, _lib.ptr(stats), B, _lib.ptr(draws), _lib.ptr(reps), st),
+                           "pmc_bootstrap_logz_replay")
+            else:
+                _lib.check(lib.pmc_bootstrap_logz(_lib.ptr(lw), m, _lib.ptr(stats), B, seed, _lib.ptr(reps), st), "pmc_bootstrap_logz")
         s = stats.cpu().numpy()
         logz = s[0] + np.log(s[1]) - np.log(m)
         dlogz = float(np.std(reps.cpu().numpy()))

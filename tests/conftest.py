@@ -21,3 +21,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Largest relative errors the parity helper saw, per quantity (tests/parity.py: MEASURED)."""
+    try:
+        import parity
+    except ImportError:
+        return
+    if parity.MEASURED:
+        terminalreporter.write_line("parity: largest relative error per quantity (close_rel) -- "
+                                    + ", ".join(f"{k}: {v:.2e}" for k, v in sorted(parity.MEASURED.items())))

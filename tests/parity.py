@@ -2,6 +2,7 @@
 import numpy as np
 
 TOL = 1e-5
+MEASURED = {}            # what -> largest relative error seen in this process (printed by scripts / -s runs)
 
 
 def close(a, b, tol=TOL, what=""):
@@ -41,5 +42,7 @@ def close_rel(a, b, tol=TOL, what="", cancel=None):
         cancel = np.broadcast_to(np.asarray(cancel, np.float64), b.shape)
         cancel = np.where(np.isfinite(cancel), cancel, 0.0)
         r = r * np.where(fin, np.abs(b), 0.0) / np.maximum(np.maximum(np.where(fin, np.abs(b), 0.0), cancel), np.finfo(np.float64).tiny)
-    assert r.max() <= tol, f"{what}: max relative error {r.max():.3e} > {tol:g} ({int((r > tol).sum())} of {r.size} walkers)"
-    return float(r.max())
+    worst = float(r.max()) if r.size else 0.0
+    assert worst <= tol, f"{what}: max relative error {worst:.3e} > {tol:g} ({int((r > tol).sum())} of {r.size} walkers)"
+    MEASURED[what.split(",")[0]] = max(MEASURED.get(what.split(",")[0], 0.0), worst)
+    return worst

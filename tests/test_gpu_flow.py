@@ -1,9 +1,18 @@
 """Parity of the HIP flow kernels (through the C ABI) against the oracle, plus the
 reference's own property tests (``tests/test_flow.py``) on the product ``Flow``.
 
-Tolerance: the north star asks for 1e-5 relative in fp32; the oracle computes the same
-fp32 arithmetic in a different summation order, so values are compared with
-``rtol=1e-5`` and an ``atol`` of 1e-5 times the array's scale."""
+Tolerance (``tests/parity.py``): the north star asks for 1e-5 relative in fp32.  The affine flows (MAF) are held to
+exactly that, walker by walker and pure relative (``close_rel``: a walker's coordinates are one vector; a log-determinant
+or log-density -- a sum of terms of either sign -- is measured against the size of its terms, ``cancel=``, stated per
+call).  Measured maxima over the shapes below (printed at the end of a run, ``conftest.py``): z 2.5e-6, x 2.3e-6,
+log-determinant 1.2e-6, log_prob 4.1e-6.  The spline flows (NSF) are held to 2e-5 (z) / 5e-5 (x) / 1e-4 (log-determinant),
+same measure: a rational-quadratic bin amplifies an input's rounding by up to (bin height / bin width) x (derivative
+ratio) -- the knots come out of a softmax whose smallest bin is 1e-3 of the box -- and its log-derivative is a difference of
+logarithms of O(1) quantities, so two valid float32 evaluations of the same spline (numpy's IEEE division / exp / log in
+the oracle, v_rcp / v_exp / v_log at 1 ulp in the kernels) differ by a few ulp x that factor: measured 1.1e-5 (z),
+1.8e-5 (x), 2.4e-5 / 7.2e-5 (log-determinant forward / inverse), while the device's own forward and inverse agree with
+each other to 8e-6 (round trip) / 5e-6 (antisymmetry).  ``close`` (absolute slack scaled by the array) is used only where
+both sides are device results of different algorithms."""
 import warnings
 
 import numpy as np
@@ -12,7 +21,7 @@ import torch
 
 import cases
 from oracle.maf import OracleMAF
-from parity import close_rel
+from parity import close_rel, TOL
 from pocomc_amd.maf_spec import MAFSpec
 
 pytestmark = pytest.mark.gpu
@@ -42,9 +51,11 @@ def test_forward_logprob_matches_oracle(D, T, n):
     x = (np.random.default_rng(n).normal(size=(n, D)) * 1.5).astype(np.float32)
     z, ladj = f.forward(torch.from_numpy(x))
     zo, lo = o.forward(x)
-    close(z.numpy(), zo)
-    close(ladj.numpy(), lo)
-    close(f.log_prob(torch.from_numpy(x)).numpy(), o.log_prob(x))
+    terms = o.ladj_abs_terms(x)                                            # size of the log-determinant's terms, per walker
+    close_rel(z.numpy(), zo, TOL, "z")
+    close_rel(ladj.numpy(), lo, TOL, "ladj", cancel=terms)
+    base = 0.5 * (zo.astype(np.float64) ** 2).sum(axis=1) + 0.5 * D * np.log(2 * np.pi)
+    close_rel(f.log_prob(torch.from_numpy(x)).numpy(), o.log_prob(x), TOL, "log_prob", cancel=terms + base)
 
 
 @pytest.mark.parametrize("D,T", SHAPES)
@@ -55,14 +66,16 @@ def test_inverse_matches_oracle(D, T, n):
     xo, lo = o.inverse(z)                       # the reference's D-pass algorithm
     small = f.spec.nOT <= 8 and 2 * f.spec.Dp + 3 * f.spec.Hp + 176 <= 2560       # D <= 64, tiles fit the LDS (pmc_maf_inverse checks the 3-layer budget)
     # triangular (AUTO's pick), D-pass on the device, lane-per-walker sweep, one- / two-wave register-chain sweeps
+    terms = o.ladj_abs_terms(xo)
     for algo in ([1, 2, 8] + ([6, 7] if small else []) if f.spec.tri_ok else [2]):
         f.inverse_algo = algo
         x, l = f.inverse(torch.from_numpy(z))
-        close(x.numpy(), xo)
-        close(l.numpy(), lo)
+        close_rel(x.numpy(), xo, TOL, f"x, algorithm {algo}")
+        close_rel(l.numpy(), lo, TOL, f"ladj, algorithm {algo}", cancel=terms)
     f.inverse_algo = 0
     x, l = f.inverse(torch.from_numpy(z))
-    close(x.numpy(), xo)
+    close_rel(x.numpy(), xo, TOL, "x, AUTO")
+    close_rel(l.numpy(), lo, TOL, "ladj, AUTO", cancel=terms)
 
 
 @pytest.mark.parametrize("n", [1, 17, 4096, 10000])
@@ -148,8 +161,9 @@ def test_sample_matches_oracle():
     z = np.random.default_rng(5).normal(size=(257, 10)).astype(np.float32)
     x, lq = f.sample(257, z=torch.from_numpy(z))
     xo, lqo = o.sample_from(z)
-    close(x.numpy(), xo)
-    close(lq.numpy(), lqo)
+    close_rel(x.numpy(), xo, TOL, "x")
+    base = 0.5 * (z.astype(np.float64) ** 2).sum(axis=1) + 5.0 * np.log(2 * np.pi)
+    close_rel(lq.numpy(), lqo, TOL, "log q", cancel=o.ladj_abs_terms(xo) + base)
 
 
 # ----------------------------------------------- the reference's tests/test_flow.py
@@ -202,6 +216,7 @@ def test_flow_names():
 
 # ----------------------------------------------------------------- neural spline flows
 NSF_SHAPES = [(2, 3), (4, 3), (10, 3), (17, 2), (32, 3), (50, 6)]
+NSF_FWD, NSF_INV, NSF_LADJ = 2e-5, 5e-5, 1e-4        # per walker, pure relative (the header says why not 1e-5)
 
 
 def make_nsf(D, T, seed=3, gain=1.0):
@@ -221,9 +236,11 @@ def test_nsf_forward_logprob_matches_oracle(D, T, n):
     x = (np.random.default_rng(n).normal(size=(n, D)) * 2.5).astype(np.float32)
     z, ladj = f.forward(torch.from_numpy(x))
     zo, lo = o.forward(x)
-    close(z.numpy(), zo, 2e-5)
-    close(ladj.numpy(), lo, 2e-5)
-    close(f.log_prob(torch.from_numpy(x)).numpy(), o.log_prob(x), 2e-5)
+    terms = o.ladj_abs_terms(x)
+    close_rel(z.numpy(), zo, NSF_FWD, "nsf z")
+    close_rel(ladj.numpy(), lo, NSF_LADJ, "nsf ladj", cancel=terms)
+    base = 0.5 * (zo.astype(np.float64) ** 2).sum(axis=1) + 0.5 * D * np.log(2 * np.pi)
+    close_rel(f.log_prob(torch.from_numpy(x)).numpy(), o.log_prob(x), NSF_LADJ, "nsf log_prob", cancel=terms + base)
 
 
 @pytest.mark.parametrize("D,T", NSF_SHAPES)
@@ -232,19 +249,20 @@ def test_nsf_inverse_matches_oracle(D, T, n):
     f, o = make_nsf(D, T)
     z = (np.random.default_rng(7 + n).normal(size=(n, D)) * 1.5).astype(np.float32)
     xo, lo = o.inverse(z)                       # the reference's D-pass algorithm
+    terms = o.ladj_abs_terms(xo)
     for algo in ([1, 2] if f.spec.tri_ok else [2]):     # triangular sweep, D-pass on the device
         f.inverse_algo = algo
         x, l = f.inverse(torch.from_numpy(z))
-        close(x.numpy(), xo, 5e-5)
-        close(l.numpy(), lo, 5e-5)
+        close_rel(x.numpy(), xo, NSF_INV, f"nsf x, algorithm {algo}")
+        close_rel(l.numpy(), lo, NSF_LADJ, f"nsf ladj inverse, algorithm {algo}", cancel=terms)
     f.inverse_algo = 0
     x, l = f.inverse(torch.from_numpy(z))
-    close(x.numpy(), xo, 5e-5)
-    close(l.numpy(), lo, 5e-5)
+    close_rel(x.numpy(), xo, NSF_INV, "nsf x, AUTO")
+    close_rel(l.numpy(), lo, NSF_LADJ, "nsf ladj inverse, AUTO", cancel=terms)
     # tests/test_flow.py:88 and :164 on the product: round trip and ladj antisymmetry
     z2, l2 = f.forward(x)
-    close(z2.numpy(), z, 5e-5)
-    close(l2.numpy(), -l.numpy(), 1e-4)
+    close_rel(z2.numpy(), z, NSF_INV, "nsf round trip")
+    close_rel(l2.numpy(), -l.numpy(), NSF_LADJ, "nsf antisymmetry", cancel=terms)
 
 
 def test_sweeps_on_random_flow_shapes():

@@ -56,11 +56,13 @@ class VerifiedInverse(TorchFlowAdapter):
     """For sizes where zuko's D-pass inverse (``oracle.maf.OracleMAF.inverse``: (D+1) dense passes per transform) does
     not finish in seconds: the inverse comes from the device and is VERIFIED by the oracle before the oracle's step
     uses it -- a bijection's inverse is right iff the oracle's forward map takes it back to the input
-    (``tests/test_flow.py:88``) and the log-determinants are opposite (``:164``)."""
+    (``tests/test_flow.py:88``) and the log-determinants are opposite (``:164``): every row, at 10 x TOL (the forward map
+    amplifies); and 256 evenly spaced rows go through the oracle's D-pass inverse itself and are compared at TOL."""
 
     def __init__(self, maf, product_flow, tol=TOL):
         super().__init__(maf)
         self.product_flow, self.tol, self.worst = product_flow, tol, 0.0
+        self.subsample, self.worst_direct, self.n_direct = 256, 0.0, 0
 
     def inverse(self, theta):
         x, l = self.product_flow.inverse(theta)
@@ -74,6 +76,17 @@ class VerifiedInverse(TorchFlowAdapter):
         # the forward map amplifies an error of x by the flow's Jacobian; measured per walker against |theta|
         self.worst = max(self.worst, close_rel(back, theta.numpy()[ok], 10 * self.tol, "oracle.forward(device inverse)"))
         close_rel(-lf, l.numpy()[ok], 10 * self.tol, "ladj antisymmetry", cancel=self.maf.ladj_abs_terms(xn[ok]))
+        # ... and next to the round trip (a bijection argument, 10 x TOL) a direct comparison at TOL: 256 of the rows, evenly
+        # spaced, through the oracle's own D-pass inverse (zuko's algorithm; seconds at this size)
+        sub = np.flatnonzero(ok)[:: max(1, int(ok.sum()) // self.subsample)][: self.subsample]
+        xo, lo = self.maf.inverse(theta.numpy()[sub])
+        fin = np.isfinite(xo).all(axis=1) & np.isfinite(lo)
+        assert fin.mean() > 0.99
+        self.worst_direct = max(self.worst_direct,
+                                close_rel(xn[sub][fin], xo[fin], self.tol, "device inverse vs oracle D-pass inverse (subsample)"))
+        close_rel(l.numpy()[sub][fin], lo[fin], self.tol, "ladj of the inverse vs oracle (subsample)",
+                  cancel=self.maf.ladj_abs_terms(xo[fin]))
+        self.n_direct += int(fin.sum())
         return x, l
 
 

@@ -141,3 +141,41 @@ def test_a_run_is_reproducible_from_its_random_state(flow_kind):
                         hashlib.sha1(s.flow.params.cpu().numpy().tobytes()).hexdigest(), s.evidence()[0]))
         assert abs(s.evidence()[0] - (D * np.log(0.5 * np.sqrt(2 * np.pi)) - D * np.log(10.0))) < 0.3
     assert digests[0] == digests[1]
+
+
+@pytest.mark.parametrize("flow_name,n", [("maf3", 700), ("maf6", 1500)])
+def test_compute_evidence_replayed_against_the_oracle(flow_name, n):
+    """``Sampler._compute_evidence`` (``sampler.py:869-920``: flow.sample -> scaler.inverse -> prior -> likelihood ->
+    importance-sampling logZ -> bootstrap spread) against ``oracle/evidence.py`` on the SAME base draw of the flow and
+    the SAME bootstrap indices (the reference's ``np.random.choice`` calls under ``np.random.seed``, replayed through
+    ``pmc_bootstrap_logz_replay``).  Half-bounded prior: part of the draws falls outside its support and is dropped
+    (``:898-901``).  logZ to 1e-5 relative on its terms; the bootstrap's standard deviation -- a difference of
+    replicates that agree to 1e-6 -- to 1e-3 relative."""
+    import pocomc_amd as pc
+    from oracle.evidence import compute_evidence
+    from oracle.maf import OracleMAF
+    from oracle.scaler import Reparameterize as OracleScaler
+    from scipy.stats import halfnorm
+    D = 5
+    prior = pc.Prior([uniform(-4, 8)] * (D - 1) + [halfnorm(0, 2)])
+
+    def loglike(x):
+        return np.sum(-0.5 * ((x - 0.3) / 0.8) ** 2, axis=1) - 0.1 * x[:, 0] ** 4
+    s = pc.Sampler(prior=prior, likelihood=loglike, vectorize=True, flow=flow_name, random_state=3, n_effective=256,
+                   n_active=128, train_config={"epochs": 30})
+    s.run(progress=False, n_total=512, n_evidence=0)
+    rng = np.random.default_rng(n)
+    z = rng.normal(size=(n, D)).astype(np.float32)
+    osc = OracleScaler(D, bounds=prior.bounds)
+    osc.mu, osc.sigma = np.array(s.scaler.mu, dtype=np.float64), np.array(s.scaler.sigma, dtype=np.float64)
+    if hasattr(osc, "_refresh"):
+        osc._refresh()
+    maf = OracleMAF(s.flow.spec, s.flow.params.cpu().numpy())
+    logz_o, dlogz_o, draws, logw_o = compute_evidence(maf, osc, prior.logpdf, loglike, z, seed=17, n_boot=300)
+    assert 0.5 * n < len(logw_o) <= n
+    calls0 = s.calls
+    logz, dlogz = s._compute_evidence(replay=dict(z=z, draws=draws))
+    assert s.calls - calls0 == len(logw_o)                     # the same rows survived the prior
+    terms = np.abs(logw_o).max()
+    assert abs(logz - logz_o) <= 1e-5 * max(abs(logz_o), terms), (logz, logz_o)
+    assert abs(dlogz - dlogz_o) <= 1e-3 * dlogz_o, (dlogz, dlogz_o)
