@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # same table: dense bf16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
+TARGET_NAMES = {'rosenbrock': 'Rosenbrock', 'gaussian': 'correlated Gaussian (0.95)', 'bimodal': 'bimodal Gaussian mixture (means +-3)', 'funnel': "Neal's funnel"}
 
 
 def kernel_source_hash(root=ROOT):
@@ -80,6 +81,20 @@ def make_target(name, D):
     (correlated Gaussian, 0.95 off the diagonal: docs/source/likelihood.ipynb cell 4)."""
     if name == "rosenbrock":
         return rosenbrock
+    if name == "bimodal":
+        # BASELINE configs[2] (SURVEY 8(d) cfg 3): equal-weight two-component Gaussian mixture, means +-3, unit covariance
+        def bimodal(x):
+            a = np.einsum("ij,ij->i", x - 3.0, x - 3.0)
+            b = np.einsum("ij,ij->i", x + 3.0, x + 3.0)
+            return np.logaddexp(-0.5 * a, -0.5 * b) - np.log(2.0)
+        return bimodal
+    if name == "funnel":
+        # BASELINE configs[4] (SURVEY 8(d) cfg 5): Neal's funnel as a likelihood, x0 ~ N(0, 3^2), x_i ~ N(0, e^{x0})
+        def funnel(x):
+            x0 = x[:, 0]
+            r = x[:, 1:]
+            return -x0 * x0 / 18.0 - 0.5 * np.einsum("ij,ij->i", r, r) * np.exp(-x0) - 0.5 * (D - 1) * x0
+        return funnel
     cov = 0.95 * np.ones((D, D)) + 0.05 * np.eye(D)
     icov = np.linalg.inv(cov)
     norm = -0.5 * (D * np.log(2.0 * np.pi) + np.linalg.slogdet(cov)[1])
@@ -103,14 +118,15 @@ class UniformBox:
         return np.where(inside.all(axis=1), self.const, -np.inf)
 
 
-def cpu_baseline(D, n, beta, flat, spec, x0, u0_unused, geo, sigma0, seed, max_seconds=30.0, target=rosenbrock):
+def cpu_baseline(D, n, beta, flat, spec, x0, u0_unused, geo, sigma0, seed, max_seconds=30.0, target=rosenbrock,
+                 bounds=(-10.0, 10.0)):
     """The oracle (CPU restatement of the reference's algorithm: per-step numpy float64 +
     the float32 D-pass MAF inverse) timed on the host cores, on a bounded sample."""
     from threadpoolctl import threadpool_info
     from oracle import mcmc as omcmc
     from oracle.maf import OracleMAF, TorchFlowAdapter
     from oracle.scaler import Reparameterize as OracleScaler
-    prior = UniformBox(-10.0, 10.0, D)
+    prior = UniformBox(bounds[0], bounds[1], D)
     sc = OracleScaler(D, bounds=prior.bounds)
     sc.fit(x0)
     # bounded sample: shrink the population until one step is affordable, then scale linearly
@@ -218,9 +234,10 @@ def main():
     ap.add_argument("--event-every", type=int, default=10,
                     help="record the HIP event pair around the flow-inverse launch on every k-th timed step (an event "
                          "pair per step costs ~5 %% of the step rate: it splits the pre-phase's back-to-back launches)")
-    ap.add_argument("--target", choices=["rosenbrock", "gaussian"], default="rosenbrock",
-                    help="host likelihood: Rosenbrock (north_star / BASELINE configs[3], default) or the 0.95-correlated "
-                         "Gaussian of configs[1]")
+    ap.add_argument("--target", choices=["rosenbrock", "gaussian", "bimodal", "funnel"], default="rosenbrock",
+                    help="host likelihood: Rosenbrock (north_star / BASELINE configs[3], default), the 0.95-correlated "
+                         "Gaussian of configs[1], the bimodal mixture of configs[2] (--dim 50 --flow maf6) or Neal's funnel of "
+                         "configs[4] (--dim 128 --particles 5000 --flow custom8; prior U(-30, 30))")
     ap.add_argument("--no-pin", action="store_true",
                     help="do not pin the driver thread to the core it starts on (the host likelihood is single-threaded "
                          "numpy; migrations between cores cost ~8 %% and most of the run-to-run noise)")
@@ -284,14 +301,15 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     D, n, beta = args.dim, args.particles, 0.5
-    prior = UniformBox(-10.0, 10.0, D)
+    p_lo, p_hi = (-30.0, 30.0) if args.target == "funnel" else (-10.0, 10.0)      # config 5's prior is U(-30, 30)
+    prior = UniformBox(p_lo, p_hi, D)
     rng = np.random.default_rng(1000 + rank)
     # ---- synthetic setup (untimed): x ~ prior, scaler fitted on prior draws, flow, geometry
     fit_rng = np.random.default_rng(7)                      # identical on every rank
-    x_fit = fit_rng.uniform(-10.0, 10.0, size=(2 * n, D))
+    x_fit = fit_rng.uniform(p_lo, p_hi, size=(2 * n, D))
     scaler = Reparameterize(D, bounds=prior.bounds)
     scaler.fit(x_fit)
-    x = rng.uniform(-10.0, 10.0, size=(n, D))
+    x = rng.uniform(p_lo, p_hi, size=(n, D))
     u = scaler.forward(x)
     logdetj = scaler.inverse(u)[1]
     target = make_target(args.target, D)
@@ -347,7 +365,7 @@ def main():
     host_cores = None
     from scipy.stats import uniform as sp_uniform
     from pocomc_amd import Prior
-    pc_prior = Prior([sp_uniform(-10.0, 20.0)] * D)                   # pocoMC's own prior object
+    pc_prior = Prior([sp_uniform(p_lo, p_hi - p_lo)] * D)                   # pocoMC's own prior object
     device_prior = (not args.host_prior) and eng.set_device_prior(pc_prior)
     eng.load_state(u, x, logdetj, logl, logp)
     eng.set_geometry(mu=geo.t_mean, cov=geo.t_cov)
@@ -602,7 +620,7 @@ def main():
             if (pm.get("kernel_source_hash") == src_hash and n == 10000 and D == 32 and args.inverse == "auto"
                     and args.flow == "maf3" and pm.get("kernel", "").startswith(roof_kernel)
                     and pm.get("walkers_per_launch") == n_launch):
-                traffic = {"hbm_bytes_per_launch": pm["hbm_bytes_per_launch"], "unit": "B", "source": pm["source"],
+                traffic = {"hbm_bytes_per_launch": pm["hbm_bytes_per_launch"], "unit": "B", "source": pm["source"], "file": "profiles/" + cand,
                            "correction": pm["correction"], "algorithmic_bytes": pm.get("algorithmic_bytes", {}).get("total"),
                            "kernel_source_hash": src_hash, "note": pm.get("note")}
                 break
@@ -615,6 +633,10 @@ def main():
     roofline = {"bound": "mfma", "kernel": roof_kernel, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                 "traffic": None if traffic is None else traffic["hbm_bytes_per_launch"],     # HBM bytes per launch (PMC)
+                # PMC passes cannot run inside this process: `traffic` is the committed rocprofv3 measurement of this very
+                # command, used only when the kernel sources it was taken on are the ones this run was built from
+                "traffic_from": None if traffic is None else {"file": traffic["file"], "kernel_source_hash": traffic["kernel_source_hash"],
+                                                              "pmc_passes_in_this_invocation": False},
                 "traffic_detail": traffic,
                 "avg_launch_us": inv_us_live, "launches_timed": len(ev_pairs[::args.event_every]),
                 "walkers_per_launch": n_launch,
@@ -764,7 +786,7 @@ def main():
            "unit": "steps/s per 1e4 walkers", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32 flow (MFMA) + f64 step", "data": "synthetic",
-           "config": {"workload": f"{D}-D {'Rosenbrock' if args.target == 'rosenbrock' else 'correlated Gaussian (0.95)'}, U(-10,10)^{D} prior, {n} walkers/GPU x {world} GPU, {args.flow} "
+           "config": {"workload": f"{D}-D {TARGET_NAMES[args.target]}, U({p_lo:g},{p_hi:g})^{D} prior, {n} walkers/GPU x {world} GPU, {args.flow} "
                                   f"(H={spec.hidden}), beta={beta}, tpCN kernel, host numpy likelihood in the loop",
                       "walkers_per_gpu": n, "global_walkers": n * world, "n_dim": D, "flow": args.flow,
                       "flow_trained_50_epochs": flow_trained, "parallelism": f"walker-sharded x{world}",
@@ -774,6 +796,7 @@ def main():
                       "inverse_algo": args.inverse, "host_threads": args.host_threads, "host_prefetch_threads": args.host_prefetch, "host_x_order": args.x_order, "prior_on_device": bool(device_prior),
                       "accept_rate": float((ad_l if leng is not None else ad).mean_alpha),
                       "backend": (dist.get_backend() if world > 1 else None),
+                      "collectives": (None if world == 1 else ("RCCL (torch.distributed nccl backend on ROCm)" if dist.get_backend() == "nccl" else "gloo (functional check on a shared GPU)")),
                       "ranks_reported_by_backend": (dist.get_world_size() if world > 1 else 1),
                       "shared_gpu": bool(os.environ.get("PMC_BENCH_SHARE_GPU"))},
            "roofline": roofline,
@@ -794,7 +817,7 @@ def main():
     out["config"]["driver_pinned_to_core"] = pinned_core
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(D, n, beta, flow.params.cpu().numpy(), spec, x, u, geo, sigma0, seed=0,
-                                           target=target)
+                                           target=target, bounds=(p_lo, p_hi))
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -195,6 +195,10 @@ int pmc_weight_penalty(const float* params, const uint8_t* is_weight, float* gra
 /* Noise augmentation, flow.py:305 / :334: out f32 [n][D] = x + scale * N(0, 1), Philox keyed by (seed, pass, row). */
 int pmc_add_noise_f32(const float* x, int64_t n, int32_t D, float scale, uint64_t seed, uint64_t pass, float* out,
                       void* stream);
+/* The same for rows row0 .. row0 + n of a larger set (a rank's shard of a data-parallel fit): row r draws what row
+ * row0 + r of the whole set draws. */
+int pmc_add_noise_rows_f32(const float* x, int64_t n, int32_t D, float scale, uint64_t seed, uint64_t pass, uint64_t row0,
+                           float* out, void* stream);
 /* out f32 [1] = mean_j ||x[row] - x[j]||: what flow.py:241-245 scales the noise with (its `torch.mean(min_dist)` is
  * the mean of the LAST row's distance vector, not of the nearest-neighbour distances computed above it). */
 int pmc_mean_distance_f32(const float* x, int64_t n, int32_t D, int64_t row, float* out, void* stream);

@@ -158,6 +158,7 @@ SIGNATURES = {
     "pmc_event_synchronize": (C.c_int, [c_p]),
     "pmc_weight_penalty": (C.c_int, [c_p, c_p, c_p, i64, f64, f64, C.c_float, c_p, c_p, c_p]),
     "pmc_add_noise_f32": (C.c_int, [c_p, i64, i32, C.c_float, C.c_uint64, C.c_uint64, c_p, c_p]),
+    "pmc_add_noise_rows_f32": (C.c_int, [c_p, i64, i32, C.c_float, C.c_uint64, C.c_uint64, C.c_uint64, c_p, c_p]),
     "pmc_mean_distance_f32": (C.c_int, [c_p, i64, i32, i64, c_p, c_p]),
     "pmc_affine_rows": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, i32, c_p]),
     "pmc_sum_f64": (C.c_int, [c_p, i64, c_p, c_p]),

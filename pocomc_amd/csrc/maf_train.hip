@@ -889,11 +889,11 @@ extern "C" int pmc_weight_penalty(const float* params, const uint8_t* is_weight,
 
 // out = x + scale * N(0, 1): torch.randn_like noise of flow.py:305 / :334, Philox keyed by (seed, pass, row, pair)
 __global__ __launch_bounds__(256) void add_noise_kernel(const float* __restrict__ x, int64_t n, int D, float scale,
-                                                        uint64_t seed, uint64_t pass, float* __restrict__ out) {
+                                                        uint64_t seed, uint64_t pass, uint64_t row0, float* __restrict__ out) {
     const int half = (D + 1) / 2;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n * half; e += (int64_t)gridDim.x * 256) {
         const int64_t r = e / half; const int j = (int)(e % half) * 2;
-        Philox ph(seed, pass, (uint64_t)r, 4);
+        Philox ph(seed, pass, row0 + (uint64_t)r, 4);      // keyed by the GLOBAL row: a rank's shard draws what the whole set would
         ph.ctr[0] = (uint32_t)(j >> 1);
         double a, b;
         ph.normal2(a, b);
@@ -902,12 +902,18 @@ __global__ __launch_bounds__(256) void add_noise_kernel(const float* __restrict_
     }
 }
 
-extern "C" int pmc_add_noise_f32(const float* x, int64_t n, int32_t D, float scale, uint64_t seed, uint64_t pass,
-                                 float* out, void* stream) {
+extern "C" int pmc_add_noise_rows_f32(const float* x, int64_t n, int32_t D, float scale, uint64_t seed, uint64_t pass,
+                                      uint64_t row0, float* out, void* stream) {
     if (!x || !out || n < 1 || D < 1) return pmc_fail("pmc_add_noise_f32: bad argument");
     int64_t grid = (n * ((D + 1) / 2) + 255) / 256; if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, n, (int)D, scale, seed, pass, out);
+    hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, n, (int)D, scale, seed, pass,
+                       row0, out);
     return pmc_check_launch("add_noise_kernel");
+}
+
+extern "C" int pmc_add_noise_f32(const float* x, int64_t n, int32_t D, float scale, uint64_t seed, uint64_t pass,
+                                 float* out, void* stream) {
+    return pmc_add_noise_rows_f32(x, n, D, scale, seed, pass, 0, out, stream);
 }
 
 // out[0] = mean_j || x[row] - x[j] ||_2   (flow.py:241-245: the quantity the reference's noise scale is built from)

@@ -39,10 +39,13 @@ def torch_double_to_float(x: torch.Tensor, warn: bool = True) -> torch.Tensor:
 class Flow:
     """Masked autoregressive flow resident on one MI355X."""
 
-    def __init__(self, n_dim, flow="nsf3", device=None, seed=None, precision="f32"):   # default flow as pocomc/flow.py:46
+    def __init__(self, n_dim, flow="nsf3", device=None, seed=None, precision="f32", train_engine=None):   # default flow as pocomc/flow.py:46
         """``precision="bf16"`` (affine flows): ``forward`` / ``log_prob`` run on the bf16 matrix cores with fp32
-        accumulation (``csrc/maf_forward_bf16.hip``; BASELINE config 5 names this precision); parameters, training,
-        the inverse and the univariate maps stay float32.  Default: float32 everywhere, like the reference."""
+        accumulation (``csrc/maf_forward_bf16.hip``; BASELINE config 5 names this precision), and ``fit`` takes the bf16
+        gradient engine (``csrc/maf_train_bf16.hip``: bf16 weights / activations, fp32 master parameters, accumulation and
+        optimizer) when the hidden layers are wide (>= ``train.WIDE_MIN_HIDDEN`` units: the config-5 flow);
+        ``train_engine="f32" | "bf16"`` fixes the engine instead of the width rule (kept by ``save_state``).  The
+        parameters, the inverse and the univariate maps stay float32.  Default: float32 everywhere, like the reference."""
         self.n_dim = int(n_dim)
         if isinstance(flow, MAFSpec):
             spec = flow
@@ -75,6 +78,9 @@ class Flow:
         if precision == "bf16" and spec.univariate != "affine":
             raise NotImplementedError("the bf16 kernels are built for the affine flows")
         self.precision = precision
+        if train_engine not in (None, "f32", "bf16"):
+            raise ValueError("train_engine must be None, 'f32' or 'bf16'")
+        self.train_engine = train_engine
         self._bf16 = None              # (gather map, image, elements per transform), built on first use
         self.repack()
 
@@ -85,11 +91,11 @@ class Flow:
         return {"n_dim": self.n_dim,
                 "spec": (self.spec.n_dim, self.spec.n_transforms, self.spec.hidden, self.spec.univariate, self.spec.bins),
                 "params": self.params.detach().cpu().numpy(), "inverse_algo": self.inverse_algo,
-                "precision": self.precision}
+                "precision": self.precision, "train_engine": self.train_engine}
 
     def __setstate__(self, st):
         spec = MAFSpec(*st["spec"])
-        self.__init__(st["n_dim"], spec, precision=st.get("precision", "f32"))
+        self.__init__(st["n_dim"], spec, precision=st.get("precision", "f32"), train_engine=st.get("train_engine"))
         self.set_params(st["params"])
         self.inverse_algo = st.get("inverse_algo", 0)
 

@@ -115,7 +115,7 @@ class Geometry:
             self.normal_cov = S / (v1 - v2 / v1)                           # np.cov(theta.T, aweights=weights): ddof = 1
             idx = systematic_resample(n, weights=w, device_indices=True)   # geometry.py:52 (one np.random.random())
         # ---- fit_mvstud(sample): its start values are its result (module docstring)
-        _, Ss, _, _ = moments(th, idx)
+        Ss = S if idx is None else moments(th, idx)[1]                     # (unweighted: the scatter matrix just formed)
         med = column_medians(th, idx)                                      # student.py:45
         var = np.diag(Ss) / n
         if th.dtype == torch.float32:
@@ -126,6 +126,15 @@ class Geometry:
         else:
             raise RuntimeError("Failed to converge after 100 iterations (scipy.optimize.bisect(func0, 1e-300, 1e300), "
                                "pocomc/student.py:42)")
+        # The reference fails loudly on such input (NaN / inf rows: scipy's bisect raises on a NaN bracket; a singular
+        # scatter matrix: linalg.solve in the EM step raises LinAlgError) -- the shortcut above must not turn that into a
+        # silent NaN geometry that surfaces later, or never
+        if not (np.isfinite(med).all() and np.isfinite(sigma).all()):
+            raise ValueError("Geometry.fit: non-finite values in theta (median / scatter matrix are not finite)")
+        try:
+            np.linalg.cholesky(sigma)
+        except np.linalg.LinAlgError:
+            raise np.linalg.LinAlgError("Geometry.fit: the scatter matrix of theta is singular (student.py:70 solves with it)")
         self.t_mean, self.t_cov, self.t_nu = med, sigma, nu
         if not np.isfinite(self.t_nu):
             self.t_nu = 1e6                                                # geometry.py:58-59

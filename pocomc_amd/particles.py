@@ -94,7 +94,12 @@ class Particles:
                 return self.blobs[index]
             return np.concatenate(self.blobs) if flat else np.asarray(self.blobs)
         if key == "logw":
-            raise KeyError("logw is computed on demand: compute_logw_and_logz")
+            # (the reference keeps an empty list under this key and fills ``results["logw"]`` from
+            #  compute_logw_and_logz(1.0), particles.py:297-299: the computed log-weights are what a caller can want)
+            lw = self.compute_logw_and_logz(1.0)[0]
+            if index is not None:
+                return lw.reshape(self.T, N)[index]
+            return lw if flat else lw.reshape(self.T, N)
         a = self.rows(key).cpu().numpy()
         if index is not None:
             return a.reshape((self.T, N) + a.shape[1:])[index]
@@ -175,6 +180,10 @@ class Particles:
         """``particles.py:233-302``."""
         if self.results_dict is None:
             self.results_dict = {k: self.get(k) for k in ROW_KEYS + SCALAR_KEYS}
+            # every key of the reference's dict (particles.py:285-302): blobs too -- the stored blocks when a likelihood
+            # returned any, None otherwise
+            has_blobs = any(b is not None for b in self.blobs)
+            self.results_dict["blobs"] = self.get("blobs") if has_blobs else None
             self.results_dict["logw"], _ = self.compute_logw_and_logz(1.0)
         return self.results_dict
 

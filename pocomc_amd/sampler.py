@@ -445,32 +445,37 @@ class Sampler:
 
     # --------------------------------------------------------------------------------------------- likelihood
     def _log_like(self, x):
-        """``sampler.py:807-861``: vectorised call, or a map over the rows whose extra returns become blobs."""
+        """``sampler.py:807-861``.  Vectorised likelihood: one call on the whole block, no blobs.  Otherwise the
+        likelihood is mapped over the rows (``distribute``: ``map`` or a pool's); a row's return value is either the
+        log-likelihood alone or a sequence ``(logl, blob, blob, ...)`` whose tail is kept as that walker's blob."""
         if self.vectorize:
             return self.log_likelihood(x), None
-        results = list(self.distribute(self.log_likelihood, x))
-        try:
-            blob = [r[1:] for r in results if len(r) > 1]
-            if not blob:
-                raise IndexError
-            logl = np.array([float(r[0]) for r in results])
-            self.have_blobs = True
-        except (IndexError, TypeError):
-            return np.array([float(r) for r in results]), None
-        if self.blobs_dtype is not None:
-            dt = self.blobs_dtype
-        else:
+        per_row = list(self.distribute(self.log_likelihood, x))
+
+        def tail(r):
             try:
-                dt = np.atleast_1d(blob[0]).dtype
+                return r[1:] if len(r) > 1 else None
+            except TypeError:                                   # a bare number has no len()
+                return None
+        tails = [tail(r) for r in per_row]
+        if not any(t is not None for t in tails):
+            return np.array([float(r) for r in per_row]), None
+        self.have_blobs = True
+        logl = np.array([float(r[0]) for r in per_row])
+        kept = [t for t in tails if t is not None]
+        # element type of the stored blobs: the user's ``blobs_dtype``, else what numpy sees in the first one -- text and
+        # ragged returns are kept as Python objects
+        dtype = self.blobs_dtype
+        if dtype is None:
+            try:
+                dtype = np.atleast_1d(kept[0]).dtype
             except ValueError:
-                dt = np.dtype("object")
-            if dt.kind in "US":
-                dt = np.dtype("object")
-        blob = np.array(blob, dtype=dt)
-        axes = [a + 1 for a, s in enumerate(blob.shape[1:]) if s == 1]
-        if axes:
-            blob = np.squeeze(blob, tuple(axes))
-        return logl, blob
+                dtype = np.dtype(object)
+            if dtype.kind in ("U", "S"):
+                dtype = np.dtype(object)
+        blobs = np.array(kept, dtype=dtype)
+        unit_axes = tuple(ax for ax in range(1, blobs.ndim) if blobs.shape[ax] == 1)
+        return logl, (np.squeeze(blobs, unit_axes) if unit_axes else blobs)
 
     def _log_like_all(self, x):
         """The likelihood of all rows of ``x`` (identical on every rank), each rank evaluating its share."""

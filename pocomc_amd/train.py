@@ -429,11 +429,29 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
         if n_samples < 2:
             raise RuntimeError("min(): Expected reduction dim to be specified for input.numel() == 0.")
         md = torch.zeros(1, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            _lib.check(flow.lib.pmc_mean_distance_f32(_lib.ptr(x), n_samples, n_dim, n_samples - 1, _lib.ptr(md),
-                                                      _lib.stream_handle()), "pmc_mean_distance_f32")
+        if sharded:
+            # one scale for all ranks, the single-process value: the mean distance of the LAST row of the whole set (the
+            # last rank's last row) to every row of every shard
+            rank = dist.get_rank(group)
+            last = x[-1:].clone()
+            dist.broadcast(last, src=dist.get_global_rank(group, world - 1) if group is not None else world - 1, group=group)
+            xc = torch.cat([x, last]).contiguous()
+            with torch.cuda.device(dev):
+                _lib.check(flow.lib.pmc_mean_distance_f32(_lib.ptr(xc), n_samples + 1, n_dim, n_samples, _lib.ptr(md),
+                                                          _lib.stream_handle()), "pmc_mean_distance_f32")
+            tot = md.double() * (n_samples + 1)            # (the appended row adds a zero distance)
+            dist.all_reduce(tot, group=group)
+            md = (tot / (n_samples * world)).float()
+        else:
+            with torch.cuda.device(dev):
+                _lib.check(flow.lib.pmc_mean_distance_f32(_lib.ptr(x), n_samples, n_dim, n_samples - 1, _lib.ptr(md),
+                                                          _lib.stream_handle()), "pmc_mean_distance_f32")
         noise_scale = float(noise) * float(md.item())
         noise_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) * 2 ** 31 + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        if sharded:
+            sd = torch.tensor([noise_seed], dtype=torch.int64, device=dev)
+            dist.broadcast(sd, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            noise_seed = int(sd.item())
     opt = AdamW(flow, learning_rate, weight_decay)
     sched = ReduceLROnPlateau(opt, patience) if annealing else None
     _train_state(flow).repack(flow)
@@ -484,8 +502,11 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
             return src
         dst = noisy[which][sl]
         with torch.cuda.device(dev):
-            _lib.check(flow.lib.pmc_add_noise_f32(_lib.ptr(src), src.shape[0], n_dim, noise_scale, noise_seed,
-                                                  2 * epoch + which, _lib.ptr(dst), _lib.stream_handle()), "pmc_add_noise_f32")
+            # (a rank's shard draws the noise of ITS rows of the whole set: keyed by the global row)
+            row0 = (dist.get_rank(group) if sharded else 0) * src.shape[0]
+            _lib.check(flow.lib.pmc_add_noise_rows_f32(_lib.ptr(src), src.shape[0], n_dim, noise_scale, noise_seed,
+                                                       2 * epoch + which, row0, _lib.ptr(dst), _lib.stream_handle()),
+                       "pmc_add_noise_rows_f32")
         return dst
 
     def add_penalty(grad, loss, mult=1.0):

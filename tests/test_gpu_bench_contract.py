@@ -36,3 +36,25 @@ def test_bench_line_follows_the_contract(extra):
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1
+
+
+def test_two_ranks_on_a_shared_gpu_report_a_two_rank_line():
+    """``python bench.py --gpus 2`` on a one-GPU box: the bench launches its own two ranks (``torch.distributed.run``;
+    with fewer GPUs than ranks they share device 0 over gloo -- the multi-rank code path, flagged ``shared_gpu``): rc 0,
+    one JSON line from rank 0, ``n_gpus == 2``, 2 x 10000 walkers, a backend that reports two ranks, no CPU baseline at
+    N > 1, roofline present -- so that the first run on a real 8-GPU node cannot die on plumbing."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-flow-bench"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak"
+    c = d["config"]
+    assert c["global_walkers"] == 20000 and c["walkers_per_gpu"] == 10000
+    assert c["ranks_reported_by_backend"] == 2 and c["backend"] in ("nccl", "gloo") and c["collectives"]
+    import torch
+    assert c["shared_gpu"] == (torch.cuda.device_count() < 2)
+    assert d["value"] > 0 and abs(d["ms_per_step"] - 20000 / 1e4 / d["value"] * 1e3) < 1e-6 * d["ms_per_step"] + 1e-9
+    assert d["cpu_baseline"] is None and d["roofline"]["frac"] > 0
