@@ -146,40 +146,41 @@ static inline size_t scaler_epilogue_lds_bytes(int D) {
     return (size_t)(2 * 16 * D + D * 17) * sizeof(double) + 16 * sizeof(int);
 }
 
-template <class LIDX>
-__device__ __forceinline__ void scaler_epilogue(const ScalerEpi& e, const float* X, const int* __restrict__ rof,
-                                                double* scr, int64_t row0, int64_t n, int D, int tid, int nthr,
-                                                LIDX lidx_of) {
+// one element (walker r of the workgroup's 16, feature j) of the epilogue: the bijector, its Jacobian term, the boundary
+// conditions, the prior factor; u / x to the device arrays, x to the host's column-major array when asked (direct_cm),
+// the row tables Jt / Pt / rowfin (and Xt unless direct_cm) in LDS
+__device__ __forceinline__ void scaler_epilogue_element(const ScalerEpi& e, double* Jt, double* Pt, double* Xt, int* rowfin,
+                                                        float u32, int r, int j, int64_t row0, int64_t n, int D, bool direct_cm) {
     const pmc_scaler_t& s = e.s;
-    double* Jt = scr;                               // [16][D]
-    double* Pt = Jt + 16 * D;                       // [16][D] prior terms
-    double* Xt = Pt + 16 * D;                       // [D][17]
-    int* rowfin = reinterpret_cast<int*>(Xt + D * 17);
-    const int rows = (int)min((int64_t)16, n - row0);
-    if (tid < 16) rowfin[tid] = 1;
-    __syncthreads();
-    for (int el = tid; el < rows * D; el += nthr) {
-        const int r = el / D, j = el - r * D;
-        const int64_t g = (row0 + r) * D + j;
-        double u = (double)X[lidx_of(rof[j], r)];
-        double t, x, J;
+    const int64_t g = (row0 + r) * D + j;
+    double u = (double)u32;
+    double t, x, J;
+    t = s.scale ? s.mu[j] + s.sigma[j] * u : u;
+    bound_inverse(s, j, t, x, J);
+    if (s.bc) {
+        // mcmc.py:94-97: wrap x, re-derive u from it, invert again
+        x = apply_bc(s, j, x);
+        u = bound_forward(s, j, x);
         t = s.scale ? s.mu[j] + s.sigma[j] * u : u;
         bound_inverse(s, j, t, x, J);
-        if (s.bc) {
-            // mcmc.py:94-97: wrap x, re-derive u from it, invert again
-            x = apply_bc(s, j, x);
-            u = bound_forward(s, j, x);
-            t = s.scale ? s.mu[j] + s.sigma[j] * u : u;
-            bound_inverse(s, j, t, x, J);
-        }
-        e.u_out[g] = u;
-        e.x_out[g] = x;
-        Xt[j * 17 + r] = x;
-        Jt[r * D + j] = J;
-        if (e.have_prior) Pt[r * D + j] = prior_term(e.pr, j, x);
-        if (!isfinite(x)) rowfin[r] = 0;
     }
-    __syncthreads();
+    e.u_out[g] = u;
+    e.x_out[g] = x;
+    if (direct_cm) { if (e.x_colmajor) e.x_colmajor[(size_t)j * n + row0 + r] = x; }
+    else Xt[j * 17 + r] = x;
+    Jt[r * D + j] = J;
+    if (e.have_prior) Pt[r * D + j] = prior_term(e.pr, j, x);
+    if (!isfinite(x)) rowfin[r] = 0;
+}
+
+// the rows' part: log-determinant (numpy's pairwise sum of the Jacobian terms), finite mask, Prior.logpdf; then the
+// column-major store of x (unless the elements stored it already: cm_done) and the completion word.  Every thread of
+// the workgroup calls it behind a barrier that follows the last element.
+__device__ __forceinline__ void scaler_epilogue_rows(const ScalerEpi& e, const double* Jt, const double* Pt, const double* Xt,
+                                                     const int* rowfin, int64_t row0, int64_t n, int D, int tid, int nthr,
+                                                     bool cm_done) {
+    const pmc_scaler_t& s = e.s;
+    const int rows = (int)min((int64_t)16, n - row0);
     if (tid < rows) {
         double l = np_pairwise_sum(Jt + (size_t)tid * D, D);
         if (s.scale) l = s.sum_log_sigma + l;
@@ -198,7 +199,7 @@ __device__ __forceinline__ void scaler_epilogue(const ScalerEpi& e, const float*
             if (e.logp_copy) e.logp_copy[row0 + tid] = lp;
         }
     }
-    if (e.x_colmajor) {
+    if (e.x_colmajor && !cm_done) {
         for (int el = tid; el < rows * D; el += nthr) {
             const int j = el / rows, r = el - j * rows;
             e.x_colmajor[(size_t)j * n + row0 + r] = Xt[j * 17 + r];
@@ -217,5 +218,27 @@ __device__ __forceinline__ void scaler_epilogue(const ScalerEpi& e, const float*
         }
     }
 }
+
+template <class LIDX>
+__device__ __forceinline__ void scaler_epilogue(const ScalerEpi& e, const float* X, const int* __restrict__ rof,
+                                                double* scr, int64_t row0, int64_t n, int D, int tid, int nthr,
+                                                LIDX lidx_of) {
+    double* Jt = scr;                               // [16][D]
+    double* Pt = Jt + 16 * D;                       // [16][D] prior terms
+    double* Xt = Pt + 16 * D;                       // [D][17]
+    int* rowfin = reinterpret_cast<int*>(Xt + D * 17);
+    const int rows = (int)min((int64_t)16, n - row0);
+    if (tid < 16) rowfin[tid] = 1;
+    __syncthreads();
+    for (int el = tid; el < rows * D; el += nthr) {
+        const int r = el / D, j = el - r * D;
+        scaler_epilogue_element(e, Jt, Pt, Xt, rowfin, X[lidx_of(rof[j], r)], r, j, row0, n, D, false);
+    }
+    __syncthreads();
+    scaler_epilogue_rows(e, Jt, Pt, Xt, rowfin, row0, n, D, tid, nthr, false);
+}
+
+// the progressive form's tables only (no Xt): [16][D] Jacobian terms, [16][D] prior terms, 16 row flags
+static inline size_t scaler_progressive_lds_bytes(int D) { return (size_t)(2 * 16 * D) * sizeof(double) + 16 * sizeof(int); }
 
 #endif
