@@ -249,7 +249,7 @@ def main():
                          "lane while the host evaluates the likelihood of another); 1 = the whole set at once; 0 (default) = "
                          "2 for the affine flows (a lane's proposal + sweep launch is shorter than the whole set's), 1 for "
                          "the spline flows (their sweep takes the same time for 5e3 and 1e4 walkers)")
-    ap.add_argument("--first-lane", type=float, default=0.7,
+    ap.add_argument("--first-lane", type=float, default=0.65,
                     help="fraction of the walkers in the first of two lanes (0.5 = equal).  The sweeps of the two lanes run one "
                          "after the other and cost the same whatever their size; a larger first lane puts more of the host "
                          "likelihood behind the second sweep: measured 2605 (0.5) / 2767 (0.65) / 2844 (0.7) / 2843 (0.8) steps/s")
