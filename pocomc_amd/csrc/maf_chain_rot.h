@@ -166,7 +166,11 @@ __device__ __forceinline__ void chain_group_rot(ChainRot<MAXO>& s, const ChainFr
         for (int c = c0; c <= c1; ++c) { h2[c] = fmaxf((s.acc2[c] + s.p2[c]) + h1[c], 0.0f); s.h2s[c] = h2[c]; }
         CHAIN_FENCE();
         // ---------------------------------------------------------------- hop 3: output rows of this group
-        constexpr int slot = I >> 1;
+        // (ABL & 8, "half" mode of the two-wave sweep: ONE output accumulator whose rows differ between the two halves of
+        //  the wavefront -- lanes q < 2 receive the (shift, raw) pairs of groups 0, 1, lanes q >= 2 those of groups 2, 3 --
+        //  so a group costs one output MFMA instead of two, and its x crosses to the other half with v_permlane32_swap)
+        constexpr bool HALF = (ABL & 8) != 0;
+        constexpr int slot = HALF ? 0 : (I >> 1);
 #pragma unroll
         for (int c = c0; c <= c1; ++c) s.outR[slot] = MFMA(comp(f.wo[slot], c), h2[c], s.outR[slot]);
         CHAIN_FENCE();
@@ -177,11 +181,19 @@ __device__ __forceinline__ void chain_group_rot(ChainRot<MAXO>& s, const ChainFr
         extra(gi, std::integral_constant<int, 2>{}, ng);
         CHAIN_FENCE();
         // ---------------------------------------------------------------- univariate map (zuko's affine inverse)
-        const float raw = s.outR[slot][2 * (I & 1) + 1] + s.po[I].y;
-        const float shift = s.outR[slot][2 * (I & 1)] + s.po[I].x;
-        const float ls = fast_ls(raw);
-        const float ydiff = s.yv[I] - shift;
+        constexpr int pi = HALF ? (I & 1) : I;                      // half mode: po / yv hold the lane's own pair of groups
+        const float raw = s.outR[slot][2 * (I & 1) + 1] + s.po[pi].y;
+        const float shift = s.outR[slot][2 * (I & 1)] + s.po[pi].x;
+        float ls = fast_ls(raw);
+        const float ydiff = s.yv[pi] - shift;
         float xg = ydiff * fast_exp_neg(ls);
+        if constexpr (HALF) {
+            // the half that holds this group's rows computed x and the log-scale; the other half takes them over
+            const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(xg), __float_as_uint(xg), false, false);
+            const auto sl = __builtin_amdgcn_permlane32_swap(__float_as_uint(ls), __float_as_uint(ls), false, false);
+            xg = __uint_as_float(sx[I >> 1]);
+            ls = __uint_as_float(sl[I >> 1]);
+        }
         xg = live ? xg : 0.0f;
 #pragma unroll
         for (int jt = c1 + 1; jt < 4; ++jt) s.a0[jt] = fmaf(comp(f.w0o[I], jt), xg, s.a0[jt]);
@@ -194,12 +206,14 @@ __device__ __forceinline__ void chain_group_rot(ChainRot<MAXO>& s, const ChainFr
             s.a0N[2] = fmaf(f.w0N[I].z, xg, s.a0N[2]); s.a0N[3] = fmaf(f.w0N[I].w, xg, s.a0N[3]);
 #pragma unroll
             for (int c = c0; c <= c1; ++c) s.outN[0] = MFMA(comp(f.woN[0], c), h2[c], s.outN[0]);
+            if constexpr (!HALF) {
 #pragma unroll
-            for (int c = c0; c <= c1; ++c) s.outN[1] = MFMA(comp(f.woN[1], c), h2[c], s.outN[1]);
+                for (int c = c0; c <= c1; ++c) s.outN[1] = MFMA(comp(f.woN[1], c), h2[c], s.outN[1]);
+            }
             CHAIN_FENCE();
         }
         // ---------------------------------------------------------------- off the dependent path
-        if constexpr (slot == 0 && NG > 2) {           // groups 2, 3 read their rows from the second output accumulator
+        if constexpr (!HALF && slot == 0 && NG > 2) {  // groups 2, 3 read their rows from the second output accumulator
 #pragma unroll
             for (int c = c0; c <= c1; ++c) s.outR[1] = MFMA(comp(f.wo[1], c), h2[c], s.outR[1]);
             CHAIN_FENCE();

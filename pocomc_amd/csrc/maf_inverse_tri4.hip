@@ -614,17 +614,21 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
         const int base = tt * blk_bytes;
         const int Un = U + 1 < nT ? U + 1 : U;
         const int voN = U + 1 < nT ? vo_T : OOB_VOFF;
-        auto rows = [&](const int w_even, const int w_odd) {    // rows (lane & 3): 0, 1 -> (shift, raw) of the even group; 2, 3 -> the odd one
+        // the A operand of the output MFMA: tile row i = lane & 15 carries, for i < 8, (shift, raw) of the tile's groups 0 and
+        // 1 (i & 3 = 0, 1 / 2, 3), for i >= 8 those of groups 2 and 3 -- the wavefront's lower half receives the first pair
+        // of groups, its upper half the second (maf_chain_rot.h: half mode)
+        auto rows = [&](const int4 wv) {
+            const int w_even = (lane & 8) ? wv.z : wv.x, w_odd = (lane & 8) ? wv.w : wv.y;
             return bload4(rs, ((lane & 2) ? w_odd : w_even) + (q << 8) + ((lane & 1) << 4), base + oF3 + U * 1024);
         };
         if constexpr (K == 0) F.wt1 = bload4(rs, vo_T, base + oF1 + (U * nT + U) * 1024);
         else if constexpr (K == 1) F.wt2 = bload4(rs, vo_T, base + oF2 + (U * nT + U) * 1024);
         else if constexpr (K == 2) F.wn1 = bload4(rs, voN, base + oF1 + (Un * nT + U) * 1024);
         else if constexpr (K == 3) F.wn2 = bload4(rs, voN, base + oF2 + (Un * nT + U) * 1024);
-        else if constexpr (K == 4) F.wo[0] = rows(wvU.x, wvU.y);
-        else if constexpr (K == 5) F.wo[1] = rows(wvU.z, wvU.w);
-        else if constexpr (K == 6) F.woN[0] = rows(wvV.x, wvV.y);
-        else if constexpr (K == 7) F.woN[1] = rows(wvV.z, wvV.w);
+        else if constexpr (K == 4) F.wo[0] = rows(wvU);
+        else if constexpr (K == 5) { }
+        else if constexpr (K == 6) F.woN[0] = rows(wvV);
+        else if constexpr (K == 7) { }
         else if constexpr (K < 11) F.w0o[K - 8] = bload4(rs, ((4 + K - 8) << 6) + vo_q, base + oCW0 + U * 1024);
         else if constexpr (K == 11) F.w0o[3] = make_float4(0.f, 0.f, 0.f, 0.f);      // (the fourth group has no later quad)
         else F.w0N[K - 12] = bload4(rs, U + 1 < nT ? ((K - 12) << 6) + vo_q : OOB_VOFF, base + oCW0 + Un * 1024);
@@ -853,11 +857,13 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                 const float4 s2 = *reinterpret_cast<const float4*>(st + 512 + (lane << 2));
                 const int pat = __builtin_amdgcn_readfirstlane(cur.pat);
                 const char* stb = reinterpret_cast<const char*>(st) + 3072 + (p << 6);      // the walker's row of the staged output tiles
+                // (half mode: a lane keeps the output partials and the y of ITS pair of groups -- 0, 1 for q < 2; 2, 3 above)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float2 so = *reinterpret_cast<const float2*>(stb + cur.so[i]);
-                    s.po[i] = make_float2(so.x + s.outN[i >> 1][2 * (i & 1)], so.y + s.outN[i >> 1][2 * (i & 1) + 1]);
-                    s.yv[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Y) + (p << 4) + cur.xy[i]);
+                for (int k = 0; k < 2; ++k) {
+                    const int so_k = q < 2 ? cur.so[k] : cur.so[2 + k], xy_k = q < 2 ? cur.xy[k] : cur.xy[2 + k];
+                    const float2 so = *reinterpret_cast<const float2*>(stb + so_k);
+                    s.po[k] = make_float2(so.x + s.outN[0][2 * k], so.y + s.outN[0][2 * k + 1]);
+                    s.yv[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Y) + (p << 4) + xy_k);
                 }
                 s.a0[0] = s0.x + s.a0N[0]; s.a0[1] = s0.y + s.a0N[1]; s.a0[2] = s0.z + s.a0N[2]; s.a0[3] = s0.w + s.a0N[3];
                 s.p1[0] = s1.x + s.accN1[0]; s.p1[1] = s1.y + s.accN1[1]; s.p1[2] = s1.z + s.accN1[2]; s.p1[3] = s1.w + s.accN1[3];
@@ -894,10 +900,10 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                 };
                 if (pf && lane == 0) pf[1] = clock64();
                 if (pat == 15 || (TRI5_ABL & 0x200)) {             // four single-quad groups: the common tile
-                    chain_group_rot<15, 0, 4, MAXO, TRI5_ABL | 3>(s, cur, H0, H1, X, Tt, D, nOT, q, p, ladj, H2, ahead);
+                    chain_group_rot<15, 0, 4, MAXO, TRI5_ABL | 11>(s, cur, H0, H1, X, Tt, D, nOT, q, p, ladj, H2, ahead);
                 } else
                 switch (pat) {
-#define CASE(P) case P: chain_group_rot<P, 0, 4, MAXO, TRI5_ABL | 3>(s, cur, H0, H1, X, Tt, D, nOT, q, p, ladj, H2, ahead); break;
+#define CASE(P) case P: chain_group_rot<P, 0, 4, MAXO, TRI5_ABL | 11>(s, cur, H0, H1, X, Tt, D, nOT, q, p, ladj, H2, ahead); break;
                     CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13)
 #undef CASE
                     default: break;
