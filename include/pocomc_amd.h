@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PMC_ABI_VERSION 3
+#define PMC_ABI_VERSION 4
 
 const char* pmc_last_error(void);
 int pmc_abi_version(void);
@@ -455,6 +455,12 @@ typedef struct pmc_step {
                                * one on the stream): added to this step's sums before the update and before the host copy */
     int32_t adapt_n_other;
     int32_t adapt_pad2;
+    /* "every row is clean": with h_clean non-NULL pmc_step_pre leaves there, before the completion word h_done[0], the
+     * number of rows whose x' is not finite or whose device-evaluated logp' is not finite (mcmc.py:100-109's two masks) --
+     * 0 lets the host skip both mask scans and hand the whole block to the likelihood.  -1: the launch that ran does not
+     * count (only the fused proposal + sweep + scaler launch does); the host then scans h_fin / logp' as before. */
+    int64_t* h_clean;         /* pinned host int64 [1] or NULL */
+    uint32_t* clean_count;    /* device uint32 [1], zeroed once by the caller */
 } pmc_step_t;
 
 #define PMC_ADAPT_TPCN 1      /* sigma <- |min(sigma + c (mean alpha - 0.234), cap)|      (mcmc.py:152, :476) */

@@ -95,7 +95,7 @@ class pmc_step_t(C.Structure):
                 ("adapt_state", C.c_void_p), ("adapt_mode", C.c_int32), ("adapt_pad", C.c_int32),
                 ("adapt_c_sigma", C.c_double), ("adapt_c_mu", C.c_double), ("adapt_cap", C.c_double),
                 ("adapt_n_total", C.c_double), ("adapt_other", C.c_void_p * 7), ("adapt_n_other", C.c_int32),
-                ("adapt_pad2", C.c_int32)]
+                ("adapt_pad2", C.c_int32), ("h_clean", c_p), ("clean_count", c_p)]
 
 
 # name -> (restype, argtypes); every symbol include/pocomc_amd.h declares
@@ -212,7 +212,7 @@ def load():
         fn = getattr(lib, name)            # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.pmc_abi_version() != 3:
+    if lib.pmc_abi_version() != 4:
         raise PocomcAmdError("libpocomc_amd.so: ABI version mismatch")
     _lib = lib
     return lib

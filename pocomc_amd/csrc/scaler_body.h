@@ -140,6 +140,7 @@ struct ScalerEpi {
     double* u_out; double* x_out; double* x_colmajor; double* ldj_out; int32_t* finite_out;
     double* logp_out; int32_t* finite_copy; double* logp_copy;
     unsigned* done_ticket; long long* done_flag; long long done_value;
+    unsigned* bad_count; long long* bad_flag;       // optional: rows that are not clean (pmc_step_t.h_clean)
 };
 
 static inline size_t scaler_epilogue_lds_bytes(int D) {
@@ -188,6 +189,7 @@ __device__ __forceinline__ void scaler_epilogue_rows(const ScalerEpi& e, const d
         const int fin = (rowfin[tid] && isfinite(l)) ? 1 : 0;
         e.finite_out[row0 + tid] = fin;
         if (e.finite_copy) e.finite_copy[row0 + tid] = fin;
+        bool clean = fin != 0;
         if (e.have_prior) {
             // Prior.logpdf of the finite rows (mcmc.py:105-107): the terms dimension after dimension
             double lp = -INFINITY;
@@ -197,7 +199,9 @@ __device__ __forceinline__ void scaler_epilogue_rows(const ScalerEpi& e, const d
             }
             e.logp_out[row0 + tid] = lp;
             if (e.logp_copy) e.logp_copy[row0 + tid] = lp;
+            clean = clean && isfinite(lp);
         }
+        if (e.bad_count && !clean) atomicAdd(e.bad_count, 1u);            // (rows that the host's masks would drop: rare)
     }
     if (e.x_colmajor && !cm_done) {
         for (int el = tid; el < rows * D; el += nthr) {
@@ -212,6 +216,10 @@ __device__ __forceinline__ void scaler_epilogue_rows(const ScalerEpi& e, const d
             const unsigned t = __hip_atomic_fetch_add(e.done_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             if (t == gridDim.x - 1) {
                 *e.done_ticket = 0u;
+                if (e.bad_count && e.bad_flag) {          // (every block's count is in: its ticket came behind its atomicAdd)
+                    const unsigned bad = __hip_atomic_exchange(e.bad_count, 0u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    *e.bad_flag = (long long)bad;
+                }
                 __threadfence_system();
                 __hip_atomic_store(e.done_flag, e.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }

@@ -88,6 +88,8 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
             epi.done_ticket = done ? done->ticket : nullptr;
             epi.done_flag = done ? (long long*)done->flag : nullptr;
             epi.done_value = done ? (long long)done->value : 0LL;
+            epi.bad_count = (done && s->h_clean) ? s->clean_count : nullptr;
+            epi.bad_flag = (done && s->h_clean && s->clean_count) ? (long long*)s->h_clean : nullptr;
         }
         if (s->ev_inv0) (void)hipEventRecord((hipEvent_t)s->ev_inv0, st);
         rc = pmc_launch_propose_inverse_tri4(s->kind, s->cur.theta32, mu, s->inv_cov, s->chol, nu, sigma, cn_a, rng,
@@ -105,6 +107,7 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
                                tpcn ? s->p_quad : nullptr, n, D, stream, adapt);
         if (rc) return rc;
     }
+    if (s->h_clean && !(scaled && done && s->clean_count)) *s->h_clean = -1;     // (this launch sequence does not count)
     if (scaled) {
         rc = 0;
     } else if (s->preconditioned) {

@@ -65,7 +65,7 @@ class Adaptation:
         the device-side copy of this update (``pmc_step_t.adapt_*``).  Same expressions as in :meth:`update`, so
         host and device hold the same sigma and mu bit for bit."""
         i = self.i + 1
-        cap = float(np.minimum(2.38 / self.D ** 0.5, 0.99))
+        cap = min(2.38 / self.D ** 0.5, 0.99)
         if self.tpcn:
             mode, c = PMC_ADAPT_TPCN, 1 / (i + 1) ** 0.75
         elif self.kind == "preconditioned_rwm":
@@ -81,28 +81,31 @@ class Adaptation:
         Returns True when the loop must stop."""
         self.i += 1
         i, D, N = self.i, self.D, self.N
-        mean_alpha = sums[0] / N
+        # (Python floats: the same IEEE double operations as the reference's numpy scalars, without their dispatch cost --
+        #  this runs once per step on the driver thread)
+        mean_alpha = float(sums[0]) / N
         self.mean_alpha = mean_alpha
-        cap = np.minimum(2.38 / D ** 0.5, 0.99)
+        cap = min(2.38 / D ** 0.5, 0.99)
+        sigma = float(self.sigma)
         if self.tpcn:
-            self.sigma = np.abs(np.minimum(self.sigma + 1 / (i + 1) ** 0.75 * (mean_alpha - 0.234), cap))
+            self.sigma = abs(min(sigma + 1 / (i + 1) ** 0.75 * (mean_alpha - 0.234), cap))
         elif self.kind == "preconditioned_rwm":
-            self.sigma = self.sigma + 1 / (i + 1) * (mean_alpha - 0.234)
+            self.sigma = sigma + 1 / (i + 1) * (mean_alpha - 0.234)
         else:
-            self.sigma = np.abs(self.sigma + 1 / (i + 1) * (mean_alpha - 0.234))
+            self.sigma = abs(sigma + 1 / (i + 1) * (mean_alpha - 0.234))
         if self.kind == "preconditioned_pcn":
             # np.mean of the float32 theta array is a float32 (mcmc.py:156)
             mean_theta = (np.asarray(sums[4:4 + D]) / N).astype(np.float32)
             self.mu = self.mu + 1.0 / (i + 1.0) * (mean_theta - self.mu)
-        new = (sums[1] if self.tpcn else sums[2]) / N
+        new = float(sums[1] if self.tpcn else sums[2]) / N
         if new > self.logp2_val:
             self.cnt = 0
             self.logp2_val = new
         else:
             self.cnt += 1
-            ratio = (2.38 / D ** 0.5) / self.sigma
+            ratio = (2.38 / D ** 0.5) / self.sigma if self.sigma != 0.0 else float("inf")       # (numpy: division by zero -> inf)
             if self.kind == "preconditioned_rwm":
-                ratio = np.minimum(1.0, ratio)
+                ratio = min(1.0, ratio)
             if self.cnt >= self.n_steps * ratio ** 2.0:
                 return True
         return i >= self.n_max
@@ -286,6 +289,11 @@ class StepEngine:
         self.h_done = pin(2, dt=torch.int64)
         self.h_done.zero_()
         self._done_ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        # "every row is clean" word of the fused pre-step (pmc_step_t.h_clean): rows with a non-finite x' or logp'
+        self.h_clean = pin(1, dt=torch.int64)
+        self.h_clean.fill_(-1)
+        self._np_clean = self.h_clean.numpy()
+        self._clean_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self._direct_now = False
         self._pre_cfg = None     # switches the composite pre-step's struct fields were last written for
         # adaptation on the device (pmc_step_t.adapt_state): {sigma, cn_a, mu[D]}; see run_pipelined
@@ -481,6 +489,8 @@ class StepEngine:
             self._direct_now = direct and self.spin_wait
             self._step.h_done = self.h_done.data_ptr() if self._direct_now else None
             self._step.done_ticket = self._done_ticket.data_ptr() if self._direct_now else None
+            self._step.h_clean = self.h_clean.data_ptr() if self._direct_now else None
+            self._step.clean_count = self._clean_count.data_ptr() if self._direct_now else None
             self._step.ev_pre_done = None if self._direct_now else self._ev_pre     # (the completion word replaces it)
 
     def evaluate(self, log_prior, log_like, have_blobs=False, blobs=None, waited=False):
@@ -512,6 +522,11 @@ class StepEngine:
                 return r
         if self.prior_desc is not None:
             log_prior = None                          # logp' came back from the device with x'
+            if self._direct_now and self._np_clean[0] == 0 and self.host_threads <= 1 and not have_blobs:
+                # the fused pre-step counted no row with a non-finite x' or logp' (pmc_step_t.h_clean): both masks of
+                # mcmc.py:100-109 are all-true, x'[mask] is x' itself
+                self._np_logl[:] = log_like(self._np_x)[0]
+                return self.n, None
         n = self.n
         x_prime = self._np_x
         logp_prime = self._np_logp
