@@ -889,12 +889,27 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                 const int4 gU = *reinterpret_cast<const int4*>(DGT + 16 * nU + 12);
                 const int4 gV = *reinterpret_cast<const int4*>(DGT + 16 * (nU + 1) + 12);
                 auto ahead = [&](auto gi_, auto hop_, auto ng_) {
-                    constexpr int G = decltype(gi_)::value, HP = decltype(hop_)::value, NSH = 3 * decltype(ng_)::value;
+                    constexpr int G = decltype(gi_)::value, HP = decltype(hop_)::value, NG_ = decltype(ng_)::value, NSH = 3 * NG_;
                     constexpr int LPS = (16 + NSH - 1) / NSH, k0 = (G * 3 + HP) * LPS;
-                    if constexpr (!(TRI5_ABL & 0x100)) {
+                    auto into = [&](ChainFrags<MAXO>& F, auto k_) { request(F, k_, ntt, nU, gU, gV); };
+                    using std::integral_constant;
+                    if constexpr ((TRI5_ABL & 0x100) != 0) {
+                    } else if constexpr (NG_ == 4 && TRI5_ONE_BODY) {
+                        // the common tile: the layer-0 window columns of a group die with the group, so the next tile's go
+                        // straight into the CURRENT set once it has run; only what lives to the tile's end is buffered
+                        // (and copied over at the boundary: 7 of 13 operands)
+                        constexpr int sh = 3 * G + HP;
+                        if constexpr (sh == 0) { into(nxt, integral_constant<int, 0>{}); into(nxt, integral_constant<int, 1>{}); }
+                        else if constexpr (sh == 1) { into(nxt, integral_constant<int, 2>{}); into(nxt, integral_constant<int, 3>{}); }
+                        else if constexpr (sh == 2) { into(nxt, integral_constant<int, 4>{}); into(nxt, integral_constant<int, 6>{}); }
+                        else if constexpr (sh == 3) { into(cur, integral_constant<int, 8>{}); into(cur, integral_constant<int, 12>{}); }
+                        else if constexpr (sh == 4) { into(nxt, integral_constant<int, 15>{}); }
+                        else if constexpr (sh == 6) { into(cur, integral_constant<int, 9>{}); into(cur, integral_constant<int, 13>{}); }
+                        else if constexpr (sh == 9) { into(cur, integral_constant<int, 10>{}); into(cur, integral_constant<int, 14>{}); }
+                    } else {
                         static_for<LPS>([&](auto j_) {
                             constexpr int K = k0 + decltype(j_)::value;
-                            if constexpr (K < 16) request(nxt, std::integral_constant<int, K>{}, ntt, nU, gU, gV);
+                            if constexpr (K < 16) into(nxt, integral_constant<int, K>{});
                         });
                     }
                 };
@@ -917,8 +932,17 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
             //  the next transform's first operands in the second set: moved over once)
 #if TRI5_ONE_BODY
             for (int Tt = 0; Tt < nTl; ++Tt) {
+                const bool common = (__builtin_amdgcn_readfirstlane(fA.pat) == 15) && !(TRI5_ABL & 0x100);
                 tile(fA, fB, Tt);
-                fA = fB;
+                if (common) {                              // (the window columns were requested in place)
+                    fA.wt1 = fB.wt1; fA.wt2 = fB.wt2; fA.wn1 = fB.wn1; fA.wn2 = fB.wn2;
+                    fA.wo[0] = fB.wo[0]; fA.woN[0] = fB.woN[0]; fA.w0N[3] = fB.w0N[3];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { fA.g[i] = fB.g[i]; fA.xy[i] = fB.xy[i]; fA.so[i] = fB.so[i]; }
+                    fA.pat = fB.pat;
+                } else {
+                    fA = fB;
+                }
             }
 #else
             for (int T2 = 0; T2 < nTl; T2 += 2) {

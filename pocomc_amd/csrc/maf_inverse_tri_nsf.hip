@@ -27,6 +27,9 @@
 #define NPX 2     // x tiles prefetched per hidden tile
 #define NPK 8     // K tiles prefetched per hidden tile and layer
 #define NPO 10    // K tiles of the rank's two output tiles prefetched per group
+#ifndef NSF_ABL
+#define NSF_ABL 0 // timing-only builds (scripts/abl_nsf.sh)
+#endif
 
 // ABL (timing experiments only, wrong results): 1 = no spline solve, 2 = no output product, 4 = no hidden chain,
 // 8 = no per-rank output fragment loads
@@ -230,12 +233,12 @@ int pmc_launch_inverse_tri_nsf(const pmc_maf_t* m, const float* z, float* x, flo
     if (lds > 160 * 1024) return pmc_fail("pmc_maf_inverse: flow too wide for one wave's LDS budget (160 KiB)");
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri_nsf_kernel<0>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri_nsf_kernel<NSF_ABL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_inverse_tri_nsf_kernel)");
         lds_set = lds;
     }
-    hipLaunchKernelGGL(maf_inverse_tri_nsf_kernel<0>, dim3((unsigned)((n + 15) / 16)), dim3(64), lds, stream, *m, z, x,
+    hipLaunchKernelGGL(maf_inverse_tri_nsf_kernel<NSF_ABL>, dim3((unsigned)((n + 15) / 16)), dim3(64), lds, stream, *m, z, x,
                        ladj, n);
     return pmc_check_launch("maf_inverse_tri_nsf_kernel");
 }

@@ -8,7 +8,7 @@ import sys, torch
 sys.path.insert(0, {root!r})
 import pocomc_amd as pc
 f = pc.Flow({D}, {flow!r}, seed=0)
-f.inverse_algo = 7
+f.inverse_algo = int(__import__("os").environ.get("ABL_ALGO", "7"))
 z = torch.randn({n}, {D}, device='cuda')
 for _ in range(5): f.inverse(z)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
