@@ -216,12 +216,18 @@ extern "C" int pmc_maf_inverse(const pmc_maf_t* m, const float* z, float* x, flo
         // spline flows: triangular sweep, or the D-pass algorithm of the reference (zuko) as cross-check
         // and for layouts whose degree groups exceed a tile
         if (algo == PMC_INVERSE_AUTO) algo = m->tri_ok ? PMC_INVERSE_TRIANGULAR : PMC_INVERSE_NAIVE;
-        if (algo == PMC_INVERSE_TRIANGULAR) {
+        if (algo == PMC_INVERSE_TRIANGULAR || algo == PMC_INVERSE_TRIANGULAR_SOLO || algo == PMC_INVERSE_TRIANGULAR_DUO) {
             if (!m->tri_ok) return pmc_fail("pmc_maf_inverse: triangular sweep needs degree groups <= one tile");
+            // two wavefronts per 16 rows (D <= 64), else / on request the lone-wave sweep
+            if (algo != PMC_INVERSE_TRIANGULAR_SOLO) {
+                const int rc = pmc_launch_inverse_nsf2(m, z, x, ladj, n, (hipStream_t)stream);
+                if (rc >= 0) return rc;
+                if (algo == PMC_INVERSE_TRIANGULAR_DUO) return pmc_fail("pmc_maf_inverse: the two-wave spline sweep needs D <= 64 and its tiles in 160 KiB of LDS");
+            }
             return pmc_launch_inverse_tri_nsf(m, z, x, ladj, n, (hipStream_t)stream);
         }
         if (algo == PMC_INVERSE_NAIVE) return pmc_launch_inverse_dpass_wg(m, z, x, ladj, n, (hipStream_t)stream);
-        return pmc_fail("pmc_maf_inverse: spline flows know PMC_INVERSE_TRIANGULAR and PMC_INVERSE_NAIVE");
+        return pmc_fail("pmc_maf_inverse: spline flows know PMC_INVERSE_TRIANGULAR (_SOLO, _DUO) and PMC_INVERSE_NAIVE");
     }
     const int asked = algo;
     if (algo == PMC_INVERSE_AUTO) algo = m->tri_ok ? PMC_INVERSE_TRIANGULAR : PMC_INVERSE_NAIVE;

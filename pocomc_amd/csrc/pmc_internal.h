@@ -13,6 +13,7 @@ int pmc_launch_forward_wg(const pmc_maf_t* m, const float* x, float* z, float* l
                           hipStream_t stream, const int64_t* idx = nullptr);
 int pmc_launch_inverse_dpass_wg(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream);
 int pmc_launch_inverse_tri_nsf(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream);
+int pmc_launch_inverse_nsf2(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream);   // -1: not covered
 int pmc_launch_inverse_tri4(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream, int variant = -1);   // variant: -1 by size, 0 solo, 1 duo
 bool pmc_tri6_preferred(const pmc_maf_t* m);     // AUTO takes the lane-per-walker sweep for this flow (maf_inverse_tri6.hip)
 int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* mu, const double* inv_cov,

@@ -172,6 +172,52 @@ __device__ __forceinline__ void rqs_inverse_coop(const float* par, float* tab, i
     ladj = inside ? rqs_log(jac) : 0.0f;
 }
 
+// Inverse for the two-wave sweep (maf_inverse_nsf2.hip), where lane (q, p) of the chain wave holds rows 4q .. 4q+3 of the
+// rank's two output tiles for walker p (o0: widths 0-3 | widths 4-7 | heights 0-3 | heights 4-7 by q; o1: derivatives
+// 0-3 | 4-6 | - | -): every lane soft-clips and exponentiates ITS four widths / heights before the exchange (the soft clip
+// bounds them by |log slope| / 2 = 3.45, so the softmax needs no maximum), the panel row carries the sixteen unnormalised
+// weights and the raw derivatives, and behind the ONE exchange every lane finds the bin on unnormalised cumulative sums
+// (knot_j < y  <=>  cum_j < (y + B) / 2B * sum) and normalises only the four knots of that bin.  par: 32 floats of LDS.
+__device__ __forceinline__ void rqs_inverse_split(const f32x4& o0, const f32x4& o1, float* par, int q, float y, float& x, float& ladj) {
+    {
+        float4 e;
+        e.x = rqs_exp(rqs_clip2(o0[0])); e.y = rqs_exp(rqs_clip2(o0[1])); e.z = rqs_exp(rqs_clip2(o0[2])); e.w = rqs_exp(rqs_clip2(o0[3]));
+        *reinterpret_cast<float4*>(par + 4 * q) = e;
+        *reinterpret_cast<float4*>(par + 16 + 4 * q) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+    }
+    WAVE_LDS_FENCE();
+    const float4 w0 = *reinterpret_cast<const float4*>(par), w1 = *reinterpret_cast<const float4*>(par + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(par + 8), h1 = *reinterpret_cast<const float4*>(par + 12);
+    const float ch1 = h0.x, ch2 = ch1 + h0.y, ch3 = ch2 + h0.z, ch4 = ch3 + h0.w, ch5 = ch4 + h1.x, ch6 = ch5 + h1.y, ch7 = ch6 + h1.z, hs = ch7 + h1.w;
+    const float cw1 = w0.x, cw2 = cw1 + w0.y, cw3 = cw2 + w0.z, cw4 = cw3 + w0.w, cw5 = cw4 + w1.x, cw6 = cw5 + w1.y, cw7 = cw6 + w1.z, ws = cw7 + w1.w;
+    const bool inside = (y > -RQS_BOUND) && (y <= RQS_BOUND);
+    const float t = (y + RQS_BOUND) * (0.5f / RQS_BOUND) * hs;
+    int k = 0;
+    float a0 = 0.0f, a1 = ch1, b0 = 0.0f, b1 = cw1;
+#define RQS_STEP(J, CA, CB, WA, WB) if (CA < t) { k = J; a0 = CA; a1 = CB; b0 = WA; b1 = WB; }
+    RQS_STEP(1, ch1, ch2, cw1, cw2) RQS_STEP(2, ch2, ch3, cw2, cw3) RQS_STEP(3, ch3, ch4, cw3, cw4) RQS_STEP(4, ch4, ch5, cw4, cw5)
+    RQS_STEP(5, ch5, ch6, cw5, cw6) RQS_STEP(6, ch6, ch7, cw6, cw7) RQS_STEP(7, ch7, hs, cw7, ws)
+#undef RQS_STEP
+    const float q0 = par[2 * RQS_K + (k >= 1 ? k - 1 : 0)], q1 = par[2 * RQS_K + (k + 1 < RQS_K ? k : 0)];
+    const float rh = rqs_rcp(hs) * (2.0f * RQS_BOUND), rw = rqs_rcp(ws) * (2.0f * RQS_BOUND);
+    const float y0 = a0 * rh - RQS_BOUND, y1 = a1 * rh - RQS_BOUND, x0 = b0 * rw - RQS_BOUND, x1 = b1 * rw - RQS_BOUND;
+    const float r0 = (k >= 1) ? rqs_clip1(q0) : 0.0f, r1 = (k + 1 < RQS_K) ? rqs_clip1(q1) : 0.0f;
+    const float d0 = rqs_exp(r0), d1 = rqs_exp(r1);
+    const float dx = x1 - x0, dy = y1 - y0;
+    const float s = dy * rqs_rcp(dx);
+    const float yr = inside ? y - y0 : 0.0f;
+    const float e = d0 + d1 - 2.0f * s;
+    const float qa = dy * (s - d0) + yr * e;
+    const float qb = dy * d0 - yr * e;
+    const float qc = -s * yr;
+    const float z = 2.0f * qc * rqs_rcp(-qb - __builtin_amdgcn_sqrtf(qb * qb - 4.0f * qa * qc));
+    const float u = z * (1.0f - z);
+    const float rden = rqs_rcp(s + e * u);
+    const float jac = s * s * (2.0f * s * u + d0 * (1.0f - z) * (1.0f - z) + d1 * z * z) * (rden * rden);
+    x = inside ? x0 + z * dx : y;
+    ladj = inside ? rqs_log(jac) : 0.0f;
+}
+
 // Reverse mode of F = gy * y + gl * ladj:  dphi[23] and gx = dF/dx.
 __device__ __forceinline__ void rqs_backward(const float* phi, float x, float gy, float gl, float* dphi, float& gx) {
     RqsTables t;

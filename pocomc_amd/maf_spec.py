@@ -224,6 +224,9 @@ class MAFSpec:
             self.sz_f3i = D * 2 * nT * 256       # [rank][half][ktile][lane][4]
             self.sz_b3i = D * 32                 # [rank][32]
             parts += [("f3i", self.sz_f3i), ("b3i", self.sz_b3i)]
+            # the two-wave spline sweep (csrc/maf_inverse_nsf2.hip) shares the affine two-wave sweep's hidden part: the
+            # layer-0 window columns (cw0), the masked layer-0 fragments (f0c), the transposed biases -- see below
+            parts += [("cw0", nT * 256), ("f0c", self.sz_f0), ("b0t", Hp), ("b1t", Hp), ("b2t", Hp)]
         else:
             # chain image of the lane-per-walker inverse sweep (csrc/maf_inverse_tri6.hip): A operands of
             # v_mfma_f32_4x4x1_16b_f32 -- lane l holds W[out quad row l & 3][k slot l >> 2], one VGPR = a 4 x 16 block --
@@ -327,7 +330,8 @@ class MAFSpec:
             put("f0", f0); put("f1", f12["W1"]); put("f2", f12["W2"]); put("f3", f3)
             put("w0n", w0n); put("b0", bidx("b0")); put("b1", bidx("b1")); put("b2", bidx("b2"))
             put("b3", b3)
-            if self.univariate == "affine":
+            if True:                                         # (cw1 / cw2 / cw3: the affine image only)
+                affine = self.univariate == "affine"
                 ci, ck = lane & 3, lane >> 2                # 4x4x1 A operand: row within the out quad, k slot
                 tg = self.tile_groups()                      # per tile: degrees of its groups (in order)
                 cw1 = np.full((nT, 64, 4), -1, dtype=np.int64)
@@ -358,7 +362,9 @@ class MAFSpec:
                         for c in range(4):
                             r_in = 16 * X + 4 * c + lk
                             f0c[T, X, :, c] = np.where(r_in < cut, f0[T, X, :, c], -1)
-                put("cw1", cw1); put("cw2", cw2); put("cw0", cw0); put("cw3", cw3); put("f0c", f0c)
+                if affine:
+                    put("cw1", cw1); put("cw2", cw2); put("cw3", cw3)
+                put("cw0", cw0); put("f0c", f0c)
                 tr = (np.arange(Hp) & ~15) + 4 * (np.arange(Hp) & 3) + ((np.arange(Hp) >> 2) & 3)
                 for name in ("b0", "b1", "b2"):
                     put(name + "t", bidx(name)[tr])
