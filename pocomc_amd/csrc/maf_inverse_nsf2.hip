@@ -22,9 +22,11 @@
 #ifndef NSF2_ABL
 #define NSF2_ABL 0                 // timing experiments only (scripts/abl_nsf.sh): results are wrong when != 0
 #endif                             // 1 no spline solve, 2 no output MFMAs on the chain, 4 burst: no output partials, 8 nor their loads, 16 chain: no output fragment requests, 32 burst: no hidden products
-#define NSF2_PK 8                  // K tiles of the hidden bursts held in registers
+#define NSF2_PK 10                 // K tiles of the hidden bursts held in registers; the static burst tile covers flows of <= NSF2_PK + 1 live tiles
+#ifndef NSF2_SPREAD
+#define NSF2_SPREAD 1              // the chain's requests spread over the shadows of its MFMAs (1) or issued as a block at the group's start (0)
+#endif
 #define NSF2_PX 4                  // x tiles of the layer-0 product held in registers (D <= 64)
-#define NSF2_PO 8                  // K tiles of a rank's output partial held in registers
 #define NSF2_OOB 0x40000000        // a lane offset beyond every image: the bounds-checked load returns zeros
 #define NSF2_STAGE_FLOATS (3 * 256)                 // hidden staging S0 | S1 | S2 (transposed, [lane][4])
 #define NSF2_PART_FLOATS (4 * 2 * 256)              // output staging [group][half][lane][4]
@@ -69,27 +71,40 @@ __device__ __forceinline__ void nsf_for(F&& f) {
 //   else the caller wants in flight).
 template <int PAT, int I, class AH>
 __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (&ob)[2], const float* part, float* X, const float* Y,
-                                          float* PAR, float* TAB, int D, int q, int p, int lane, float& ladj, const AH& ahead) {
+                                          float* PAR, float* TAB, int D, int q, int p, int lane, float& ladj, const AH& ahead,
+                                          long long* pf = nullptr) {
+#define NSF_STAMP(K) if (pf) { const long long now_ = clock64(); pf[K] += now_ - pf[15]; pf[15] = now_; }
     constexpr int NG = pat_ngroups(PAT);
     if constexpr (I < NG) {
         constexpr int c0 = pat_start(PAT, I), c1 = pat_end(PAT, I);
         {
             const NsfOut& o = ob[I & 1];
-            ahead(std::integral_constant<int, I>{});
-            CHAIN_FENCE();
+            std::integral_constant<int, I> gi;
+            std::integral_constant<int, NG> ngc;
+            NSF_STAMP(7)
+            if constexpr (!NSF2_SPREAD) {
+                nsf_for<6>([&](auto sl_) { ahead(gi, sl_, ngc); });
+                CHAIN_FENCE();
+            }
+            NSF_STAMP(0)
             // ---- the rank's parameters, part that does not wait for this group's hops: staged partial (bias + h2 tiles
             // <= Tt-2, burst wave) + previous tile + the own tile's earlier quads
             f32x4 o0 = as_acc(*reinterpret_cast<const float4*>(part + (2 * I) * 256 + (lane << 2)));
             f32x4 o1 = as_acc(*reinterpret_cast<const float4*>(part + (2 * I + 1) * 256 + (lane << 2)));
             if (!(NSF2_ABL & 2)) {
                 o0 = MFMA(o.fp0.x, s.h2p[0], o0); o1 = MFMA(o.fp1.x, s.h2p[0], o1);
+                CHAIN_FENCE(); if constexpr (NSF2_SPREAD) ahead(gi, std::integral_constant<int, 0>{}, ngc); CHAIN_FENCE();
                 o0 = MFMA(o.fp0.y, s.h2p[1], o0); o1 = MFMA(o.fp1.y, s.h2p[1], o1);
+                CHAIN_FENCE(); if constexpr (NSF2_SPREAD) ahead(gi, std::integral_constant<int, 1>{}, ngc); CHAIN_FENCE();
                 o0 = MFMA(o.fp0.z, s.h2p[2], o0); o1 = MFMA(o.fp1.z, s.h2p[2], o1);
+                CHAIN_FENCE(); if constexpr (NSF2_SPREAD) ahead(gi, std::integral_constant<int, 2>{}, ngc); CHAIN_FENCE();
                 o0 = MFMA(o.fp0.w, s.h2p[3], o0); o1 = MFMA(o.fp1.w, s.h2p[3], o1);
+                CHAIN_FENCE(); if constexpr (NSF2_SPREAD) ahead(gi, std::integral_constant<int, 3>{}, ngc); CHAIN_FENCE();
 #pragma unroll
                 for (int c = 0; c < c0; ++c) { o0 = MFMA(comp(o.fc0, c), s.h2s[c], o0); o1 = MFMA(comp(o.fc1, c), s.h2s[c], o1); }
             }
             CHAIN_FENCE();
+            NSF_STAMP(1)
             float h0[4], h1[4], h2[4];
             // ---------------------------------------------------------------- hop 1
 #pragma unroll
@@ -101,6 +116,8 @@ __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (
 #pragma unroll
             for (int c = c0; c <= c1; ++c) s.accN1 = MFMA(comp(f.wn1, c), h0[c], s.accN1);
             CHAIN_FENCE();
+            if constexpr (NSF2_SPREAD) ahead(gi, std::integral_constant<int, 4>{}, ngc);
+            CHAIN_FENCE();
 #pragma unroll
             for (int c = c0; c <= c1; ++c) { h1[c] = fmaxf((s.acc1[c] + s.p1[c]) + h0[c], 0.0f); s.h1s[c] = h1[c]; }
             CHAIN_FENCE();
@@ -111,15 +128,19 @@ __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (
 #pragma unroll
             for (int c = c0; c <= c1; ++c) s.accN2 = MFMA(comp(f.wn2, c), h1[c], s.accN2);
             CHAIN_FENCE();
+            if constexpr (NSF2_SPREAD) ahead(gi, std::integral_constant<int, 5>{}, ngc);
+            CHAIN_FENCE();
 #pragma unroll
             for (int c = c0; c <= c1; ++c) { h2[c] = fmaxf((s.acc2[c] + s.p2[c]) + h1[c], 0.0f); s.h2s[c] = h2[c]; }
             CHAIN_FENCE();
+            NSF_STAMP(2)
             // ---------------------------------------------------------------- hop 3: the group's own quads
             if (!(NSF2_ABL & 2)) {
 #pragma unroll
                 for (int c = c0; c <= c1; ++c) { o0 = MFMA(comp(o.fc0, c), h2[c], o0); o1 = MFMA(comp(o.fc1, c), h2[c], o1); }
             }
             CHAIN_FENCE();
+            NSF_STAMP(3)
             // ---------------------------------------------------------------- every lane gets its row's 23 values; spline
             const float yv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Y) + (p << 4) + f.xy[I]);
             float xg, l;
@@ -135,94 +156,187 @@ __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (
             if (q == 0) *reinterpret_cast<float*>(reinterpret_cast<char*>(X) + (p << 4) + f.xy[I]) = xg;
             ladj -= l;
             WAVE_LDS_FENCE();
+            NSF_STAMP(4)
             // ---------------------------------------------------------------- rank-1 updates of layer 0: own tile, next tile
 #pragma unroll
             for (int jt = c1 + 1; jt < 4; ++jt) s.a0[jt] = fmaf(comp(f.w0o[I], jt), xg, s.a0[jt]);
             s.a0N[0] = fmaf(f.w0N[I].x, xg, s.a0N[0]); s.a0N[1] = fmaf(f.w0N[I].y, xg, s.a0N[1]);
             s.a0N[2] = fmaf(f.w0N[I].z, xg, s.a0N[2]); s.a0N[3] = fmaf(f.w0N[I].w, xg, s.a0N[3]);
             CHAIN_FENCE();
-            nsf_group<PAT, I + 1, AH>(s, f, ob, part, X, Y, PAR, TAB, D, q, p, lane, ladj, ahead);
+            NSF_STAMP(5)
+            nsf_group<PAT, I + 1, AH>(s, f, ob, part, X, Y, PAR, TAB, D, q, p, lane, ladj, ahead, pf);
         }
     }
 }
 
-// BURST wave: bias + the two output tiles against the final h2 tiles 0 .. NK-1 for the (up to four) ranks of a tile, into
-// the staged partials the chain's accumulators start from.  NK is a compile-time constant (dispatched once per tile): a
-// rank's 2 NK fragment loads are issued while the previous rank's MFMAs run, and nothing is requested that is not used
-// (an out-of-range request costs the vector memory pipe as much as a real one).
-template <int NK>
-__device__ __forceinline__ void nsf_out_partials(__amdgpu_buffer_rsrc_t rs, const int tb_f3i, const int tb_b3i, const int nT, const int D,
-                                                 const int g0, const int g1, const int g2, const int g3, const float* H2,
-                                                 float* dst, const int lane, const int vo_lane, const int vo_q) {
+// ---------------------------------------------------------------------------------------------------------------------
+// BURST wave, one tile (flows of up to NSF2_PK + 1 live hidden tiles: every count below is a compile-time constant, the
+// tile index is dispatched once per tile).  A lone wavefront issues in order: a block of loads costs ~60 cycles apiece and
+// a block of MFMAs 32 apiece, but loads issued BETWEEN MFMAs cost nothing (the matrix pipe is busy anyway), and nothing is
+// requested that is not used.  So the next tile's hidden operands are requested in the shadows of this tile's hidden
+// products, and rank r + 1's output fragments in the shadows of rank r's output products.
+struct NsfBurstSet { float4 p1[NSF2_PK], p2[NSF2_PK], xf[NSF2_PX], b0, b1, b2; };       // (the streamed path's operand sets)
+struct NsfBurstCarry { float4 f0[NSF2_PK], f1[NSF2_PK], b0, b1; };                        // the next tile's first rank: fragments, bias rows
+struct NsfBurstCtx {
+    __amdgpu_buffer_rsrc_t rs;
+    int tb, oF1, oF2, oF0C, oB0T, oB1T, oB2T, oF3I, oB3I, nT, nXT, D, lane, vo_lane, vo_T, vo_q;
+    const float *X, *H0, *H1, *H2;
+    float *stg, *part;
+    int g[4], gn;                  // the ranks of this tile's groups; of the next tile's first group
+};
+
+// Order inside the tile: the four ranks' output partials first (the first rank's fragments came with the previous tile,
+// rank r + 1's are requested in the shadows of rank r's products, the tile's hidden operands in the shadows of the last
+// rank's), then the hidden layers (the next tile's first-rank fragments in their shadows).  Only those cross a tile
+// boundary (in `carry`); everything else is local to the dispatched case.
+template <int T1>
+__device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCarry& carry) {
+    constexpr int NK = T1 > 0 ? T1 - 1 : 0;          // final hidden tiles: 0 .. T1-2
+    constexpr int NN = T1;                           // the next tile's: 0 .. T1-1
     constexpr int NF = NK > 0 ? NK : 1;
+    static_assert(NN <= NSF2_PK, "carry too small");
+    const int lane = c.lane;
     float4 fa0[NF], fa1[NF], fb0[NF], fb1[NF], ba0, ba1, bb0, bb1;
-    auto fetch = [&](const int g, float4 (&F0)[NF], float4 (&F1)[NF], float4& B0, float4& B1) {
-        const bool lv = g < D;
-        const int gg = lv ? g : 0;
-        const int so = tb_f3i + gg * 2 * nT * 1024;
-        const int vo = lv ? vo_lane : NSF2_OOB;
-        if (!(NSF2_ABL & 8))
-#pragma unroll
-        for (int i = 0; i < NK; ++i) { F0[i] = nbload4(rs, vo, so + i * 1024); F1[i] = nbload4(rs, vo, so + (nT + i) * 1024); }
-        B0 = nbload4(rs, lv ? vo_q : NSF2_OOB, tb_b3i + gg * 128);
-        B1 = nbload4(rs, lv ? vo_q : NSF2_OOB, tb_b3i + gg * 128 + 64);
+    float4 hp1[NF], hp2[NF], xf[NSF2_PX], hb0, hb1, hb2;
+    auto obase = [&](const int g) { return c.tb + c.oF3I + (g < c.D ? g : 0) * 2 * c.nT * 1024; };
+    auto ovo = [&](const int g) { return g < c.D ? c.vo_lane : NSF2_OOB; };
+    auto obias = [&](const int g, float4& B0, float4& B1) {
+        const int so = c.tb + c.oB3I + (g < c.D ? g : 0) * 128, vo = g < c.D ? c.vo_q : NSF2_OOB;
+        B0 = nbload4(c.rs, vo, so);
+        B1 = nbload4(c.rs, vo, so + 64);
     };
-    auto comp_store = [&](const float4 (&F0)[NF], const float4 (&F1)[NF], const float4& B0, const float4& B1, float* d) {
+    const int soH1 = c.tb + c.oF1 + T1 * c.nT * 1024, soH2 = c.tb + c.oF2 + T1 * c.nT * 1024;
+    // one rank: bias + the two output tiles against h2 tiles 0 .. NK-1; `side(i)`: the caller's loads for the shadow of K step i
+    auto rank = [&](const float4* F0, const float4* F1, const float4& B0, const float4& B1, float* d, auto&& side) {
         f32x4 o0 = as_acc(B0), o1 = as_acc(B1);
-        if (!(NSF2_ABL & 4)) {
 #pragma unroll
-            for (int i = 0; i < NK; ++i) {
-                const float4 b = *reinterpret_cast<const float4*>(H2 + (i << 8) + (lane << 2));
+        for (int i = 0; i < NK; ++i) {
+            const float4 b = *reinterpret_cast<const float4*>(c.H2 + (i << 8) + (lane << 2));
+            if (!(NSF2_ABL & 4)) {
                 o0 = MFMA(F0[i].x, b.x, o0); o1 = MFMA(F1[i].x, b.x, o1);
                 o0 = MFMA(F0[i].y, b.y, o0); o1 = MFMA(F1[i].y, b.y, o1);
                 o0 = MFMA(F0[i].z, b.z, o0); o1 = MFMA(F1[i].z, b.z, o1);
                 o0 = MFMA(F0[i].w, b.w, o0); o1 = MFMA(F1[i].w, b.w, o1);
             }
+            side(i);
+            CHAIN_FENCE();
         }
         *reinterpret_cast<float4*>(d + (lane << 2)) = make_float4(o0[0], o0[1], o0[2], o0[3]);
         *reinterpret_cast<float4*>(d + 256 + (lane << 2)) = make_float4(o1[0], o1[1], o1[2], o1[3]);
     };
-    fetch(g0, fa0, fa1, ba0, ba1);
-    fetch(g1, fb0, fb1, bb0, bb1);
-    comp_store(fa0, fa1, ba0, ba1, dst);
-    fetch(g2, fa0, fa1, ba0, ba1);
-    comp_store(fb0, fb1, bb0, bb1, dst + 512);
-    fetch(g3, fb0, fb1, bb0, bb1);
-    comp_store(fa0, fa1, ba0, ba1, dst + 1024);
-    comp_store(fb0, fb1, bb0, bb1, dst + 1536);
+    auto fetch_into = [&](const int g, float4* N0, float4* N1) {
+        const int so = obase(g), vo = ovo(g);
+        return [=, &c](const int i) {
+            if (!(NSF2_ABL & 8)) { N0[i] = nbload4(c.rs, vo, so + i * 1024); N1[i] = nbload4(c.rs, vo, so + (c.nT + i) * 1024); }
+        };
+    };
+    // ---- (1) output partials
+    obias(c.g[1], bb0, bb1);
+    rank(carry.f0, carry.f1, carry.b0, carry.b1, c.part, fetch_into(c.g[1], fb0, fb1));
+    obias(c.g[2], ba0, ba1);
+    rank(fb0, fb1, bb0, bb1, c.part + 512, fetch_into(c.g[2], fa0, fa1));
+    obias(c.g[3], bb0, bb1);
+#pragma unroll
+    for (int i = 0; i < NSF2_PX; ++i) xf[i] = nbload4(c.rs, i < c.nXT ? c.vo_T : NSF2_OOB, c.tb + c.oF0C + (T1 * c.nXT + i) * 1024);
+    rank(fa0, fa1, ba0, ba1, c.part + 1024, fetch_into(c.g[3], fb0, fb1));
+    hb0 = nbload4(c.rs, c.vo_q, c.tb + c.oB0T + 64 * T1);
+    hb1 = nbload4(c.rs, c.vo_q, c.tb + c.oB1T + 64 * T1);
+    hb2 = nbload4(c.rs, c.vo_q, c.tb + c.oB2T + 64 * T1);
+    rank(fb0, fb1, bb0, bb1, c.part + 1536, [&](const int i) {
+        hp1[i] = nbload4(c.rs, c.vo_T, soH1 + i * 1024);
+        hp2[i] = nbload4(c.rs, c.vo_T, soH2 + i * 1024);
+    });
+    // ---- (2) hidden layers against the final tiles; the next tile's first rank requested in the shadows
+    f32x4 a0 = as_acc(hb0), a1 = as_acc(hb1), a2 = as_acc(hb2);
+    const int soN = obase(c.gn), voN = ovo(c.gn);
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        const float4 b1 = *reinterpret_cast<const float4*>(c.H0 + (i << 8) + (lane << 2));
+        const float4 b2 = *reinterpret_cast<const float4*>(c.H1 + (i << 8) + (lane << 2));
+        if (!(NSF2_ABL & 32)) {
+            a1 = MFMA(hp1[i].x, b1.x, a1); a2 = MFMA(hp2[i].x, b2.x, a2);
+            a1 = MFMA(hp1[i].y, b1.y, a1); a2 = MFMA(hp2[i].y, b2.y, a2);
+            a1 = MFMA(hp1[i].z, b1.z, a1); a2 = MFMA(hp2[i].z, b2.z, a2);
+            a1 = MFMA(hp1[i].w, b1.w, a1); a2 = MFMA(hp2[i].w, b2.w, a2);
+        }
+        if (!(NSF2_ABL & 8)) { carry.f0[i] = nbload4(c.rs, voN, soN + i * 1024); carry.f1[i] = nbload4(c.rs, voN, soN + (c.nT + i) * 1024); }
+        CHAIN_FENCE();
+    }
+#pragma unroll
+    for (int i = NK; i < NN; ++i)
+        if (!(NSF2_ABL & 8)) { carry.f0[i] = nbload4(c.rs, voN, soN + i * 1024); carry.f1[i] = nbload4(c.rs, voN, soN + (c.nT + i) * 1024); }
+    obias(c.gn, carry.b0, carry.b1);
+    // layer 0 against the ranks of tiles <= T1-2 (the chain adds the ranks of tile T1-1 itself)
+#pragma unroll
+    for (int i = 0; i < NSF2_PX; ++i) {
+        if (i < c.nXT) {
+            const float4 b = *reinterpret_cast<const float4*>(c.X + (i << 8) + (lane << 2));
+            a0 = MFMA(xf[i].x, b.x, a0); a0 = MFMA(xf[i].y, b.y, a0);
+            a0 = MFMA(xf[i].z, b.z, a0); a0 = MFMA(xf[i].w, b.w, a0);
+        }
+    }
+    *reinterpret_cast<float4*>(c.stg + (lane << 2)) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+    *reinterpret_cast<float4*>(c.stg + 256 + (lane << 2)) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+    *reinterpret_cast<float4*>(c.stg + 512 + (lane << 2)) = make_float4(a2[0], a2[1], a2[2], a2[3]);
 }
 
-// the same for flows with more than NSF2_PO + 1 hidden tiles: fragments streamed K tile by K tile
+// Two accumulators over K tiles K0 .. nK-1 with the fragments of four K tiles in flight (the streamed path of the wide
+// flows): acc0 += W0[K] . act0[K], acc1 += W1[K] . act1[K]; fragment K of operand j at byte offset soj + K * 1024.
+__device__ __forceinline__ void nsf_stream2(f32x4& acc0, f32x4& acc1, __amdgpu_buffer_rsrc_t rs, const int vo, const int so0, const int so1,
+                                            const int K0, const int nK, const float* act0, const float* act1, const int lane) {
+    if (K0 >= nK) return;
+    float4 w0r[4], w1r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int v = K0 + j < nK ? vo : NSF2_OOB;
+        w0r[j] = nbload4(rs, v, so0 + (K0 + j) * 1024);
+        w1r[j] = nbload4(rs, v, so1 + (K0 + j) * 1024);
+    }
+    for (int Kb = K0; Kb < nK; Kb += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int K = Kb + j;
+            const float4 w0 = w0r[j], w1 = w1r[j];
+            const int v = K + 4 < nK ? vo : NSF2_OOB;
+            w0r[j] = nbload4(rs, v, so0 + (K + 4) * 1024);
+            w1r[j] = nbload4(rs, v, so1 + (K + 4) * 1024);
+            if (K < nK) {
+                const float4 b0 = *reinterpret_cast<const float4*>(act0 + (K << 8) + (lane << 2));
+                const float4 b1 = *reinterpret_cast<const float4*>(act1 + (K << 8) + (lane << 2));
+                acc0 = MFMA(w0.x, b0.x, acc0); acc1 = MFMA(w1.x, b1.x, acc1);
+                acc0 = MFMA(w0.y, b0.y, acc0); acc1 = MFMA(w1.y, b1.y, acc1);
+                acc0 = MFMA(w0.z, b0.z, acc0); acc1 = MFMA(w1.z, b1.z, acc1);
+                acc0 = MFMA(w0.w, b0.w, acc0); acc1 = MFMA(w1.w, b1.w, acc1);
+            }
+        }
+    }
+}
+
+// flows with more live hidden tiles than the static burst tile covers: a rank's output partial, fragments streamed
 __device__ __forceinline__ void nsf_out_partials_wide(__amdgpu_buffer_rsrc_t rs, const int tb_f3i, const int tb_b3i, const int nT, const int D,
                                                       const int nK, const int g, const float* H2, float* d, const int lane,
                                                       const int vo_lane, const int vo_q) {
     const bool lv = g < D;
     const int gg = lv ? g : 0;
     f32x4 o0 = as_acc(nbload4(rs, lv ? vo_q : NSF2_OOB, tb_b3i + gg * 128)), o1 = as_acc(nbload4(rs, lv ? vo_q : NSF2_OOB, tb_b3i + gg * 128 + 64));
-    if (lv) {
-        for (int K = 0; K < nK; ++K) {
-            const float4 w0 = nbload4(rs, vo_lane, tb_f3i + (gg * 2 * nT + K) * 1024);
-            const float4 w1 = nbload4(rs, vo_lane, tb_f3i + ((gg * 2 + 1) * nT + K) * 1024);
-            const float4 b = *reinterpret_cast<const float4*>(H2 + (K << 8) + (lane << 2));
-            o0 = MFMA(w0.x, b.x, o0); o1 = MFMA(w1.x, b.x, o1);
-            o0 = MFMA(w0.y, b.y, o0); o1 = MFMA(w1.y, b.y, o1);
-            o0 = MFMA(w0.z, b.z, o0); o1 = MFMA(w1.z, b.z, o1);
-            o0 = MFMA(w0.w, b.w, o0); o1 = MFMA(w1.w, b.w, o1);
-        }
-    }
+    if (lv) nsf_stream2(o0, o1, rs, vo_lane, tb_f3i + gg * 2 * nT * 1024, tb_f3i + (gg * 2 + 1) * nT * 1024, 0, nK, H2, H2, lane);
     *reinterpret_cast<float4*>(d + (lane << 2)) = make_float4(o0[0], o0[1], o0[2], o0[3]);
     *reinterpret_cast<float4*>(d + 256 + (lane << 2)) = make_float4(o1[0], o1[1], o1[2], o1[3]);
 }
 
 template <int FM>
 __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, const float* __restrict__ in, float* __restrict__ out,
-                                                               float* __restrict__ ladj_out, int64_t n) {
+                                                               float* __restrict__ ladj_out, int64_t n, long long* prof) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, p = lane & 15;
     const int D = m.D, Dp = m.Dp, Hp = m.Hp, T = m.T, nT = m.nT, nXT = m.nXT, nOT = m.nOT;
     const int nTl = __builtin_amdgcn_readfirstlane(m.meta[7]);
+    // (measurement only, FM == -1: cycles of the chain wave of workgroup 0 by section, summed over the sweep)
+    long long pfv[16];
+    long long* pf = (FM == -1 && prof && blockIdx.x == 0) ? pfv : nullptr;
+    if (FM == -1) for (int i = 0; i < 16; ++i) pfv[i] = 0;
     const int64_t row0 = (int64_t)blockIdx.x * 16;
     float* Y = smem;
     float* XA = Y + Dp * 16;
@@ -332,9 +446,20 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
             Bz1 = nbload4(rs, vo_q, (TB) + oB1T + 64 * TT_);                                                      \
             Bz2 = nbload4(rs, vo_q, (TB) + oB2T + 64 * TT_);                                                      \
         }
-        float4 pA1[NSF2_PK], pA2[NSF2_PK], pB1[NSF2_PK], pB2[NSF2_PK], xA[NSF2_PX], xB[NSF2_PX];
-        float4 bA0, bA1, bA2, bB0, bB1, bB2;
-        NB_FETCH((T - 1) * blk_bytes, 0, pA1, pA2, xA, bA0, bA1, bA2)
+        NsfBurstSet sA, sB;
+        const bool static_tiles = nTl <= NSF2_PK + 1;
+        NsfBurstCtx bc;
+        bc.rs = rs; bc.oF1 = oF1; bc.oF2 = oF2; bc.oF0C = oF0C; bc.oB0T = oB0T; bc.oB1T = oB1T; bc.oB2T = oB2T; bc.oF3I = oF3I; bc.oB3I = oB3I;
+        bc.nT = nT; bc.nXT = nXT; bc.D = D; bc.lane = lane; bc.vo_lane = vo_lane; bc.vo_T = vo_T; bc.vo_q = vo_q;
+        bc.H0 = H0; bc.H1 = H1; bc.H2 = H2;
+        NsfBurstCarry carry;
+        if (static_tiles) {
+            const int g0n = __builtin_amdgcn_readfirstlane(DGT[0]) & 0xffff;
+            carry.b0 = nbload4(rs, vo_q, (T - 1) * blk_bytes + oB3I + g0n * 128);
+            carry.b1 = nbload4(rs, vo_q, (T - 1) * blk_bytes + oB3I + g0n * 128 + 64);
+        } else {
+            NB_FETCH((T - 1) * blk_bytes, 0, sA.p1, sA.p2, sA.xf, sA.b0, sA.b1, sA.b2)
+        }
         for (int t = T - 1; t >= 0; --t) {
             const int tb = t * blk_bytes;
             float* X = xsel ? XB : XA;                     // zero on entry
@@ -366,16 +491,7 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                 NB_FETCH(tb, T1 + 1, N1, N2, NXF, Nz0, Nz1, Nz2)                                                  \
                 f32x4 a0 = as_acc(Bz0), a1 = as_acc(Bz1), a2 = as_acc(Bz2);                                       \
                 if (!(NSF2_ABL & 32)) NB_K(nK, P1, P2, a1, a2)                                                                          \
-                for (int K = NSF2_PK; K < nK; ++K) {            /* flows wider than NSF2_PK + 2 tiles */          \
-                    const float4 w1 = nbload4(rs, vo_T, tb + oF1 + (T1 * nT + K) * 1024);                         \
-                    const float4 w2 = nbload4(rs, vo_T, tb + oF2 + (T1 * nT + K) * 1024);                         \
-                    const float4 b1 = *reinterpret_cast<const float4*>(H0 + (K << 8) + (lane << 2));              \
-                    const float4 b2 = *reinterpret_cast<const float4*>(H1 + (K << 8) + (lane << 2));              \
-                    a1 = MFMA(w1.x, b1.x, a1); a2 = MFMA(w2.x, b2.x, a2);                                         \
-                    a1 = MFMA(w1.y, b1.y, a1); a2 = MFMA(w2.y, b2.y, a2);                                         \
-                    a1 = MFMA(w1.z, b1.z, a1); a2 = MFMA(w2.z, b2.z, a2);                                         \
-                    a1 = MFMA(w1.w, b1.w, a1); a2 = MFMA(w2.w, b2.w, a2);                                         \
-                }                                                                                                 \
+                nsf_stream2(a1, a2, rs, vo_T, tb + oF1 + T1 * nT * 1024, tb + oF2 + T1 * nT * 1024, NSF2_PK, nK, H0, H1, lane);  /* flows wider than NSF2_PK + 2 tiles */ \
                 _Pragma("unroll") for (int i_ = 0; i_ < NSF2_PX; ++i_) {                                          \
                     if (i_ < nXT) {                                                                               \
                         const float4 b = *reinterpret_cast<const float4*>(X + (i_ << 8) + (lane << 2));            \
@@ -389,33 +505,42 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                 *reinterpret_cast<float4*>(st_ + 512 + (lane << 2)) = make_float4(a2[0], a2[1], a2[2], a2[3]);    \
                 float* pt_ = PART + (T1 & 1) * NSF2_PART_FLOATS;                                                  \
                 const int f3_ = tb + oF3I, b3_ = tb + oB3I;                                                       \
-                switch (nK < 0 ? 0 : nK) {                                                                        \
-                    case 0: nsf_out_partials<0>(rs, f3_, b3_, nT, D, g0_, g1_, g2_, g3_, H2, pt_, lane, vo_lane, vo_q); break; \
-                    case 1: nsf_out_partials<1>(rs, f3_, b3_, nT, D, g0_, g1_, g2_, g3_, H2, pt_, lane, vo_lane, vo_q); break; \
-                    case 2: nsf_out_partials<2>(rs, f3_, b3_, nT, D, g0_, g1_, g2_, g3_, H2, pt_, lane, vo_lane, vo_q); break; \
-                    case 3: nsf_out_partials<3>(rs, f3_, b3_, nT, D, g0_, g1_, g2_, g3_, H2, pt_, lane, vo_lane, vo_q); break; \
-                    case 4: nsf_out_partials<4>(rs, f3_, b3_, nT, D, g0_, g1_, g2_, g3_, H2, pt_, lane, vo_lane, vo_q); break; \
-                    case 5: nsf_out_partials<5>(rs, f3_, b3_, nT, D, g0_, g1_, g2_, g3_, H2, pt_, lane, vo_lane, vo_q); break; \
-                    case 6: nsf_out_partials<6>(rs, f3_, b3_, nT, D, g0_, g1_, g2_, g3_, H2, pt_, lane, vo_lane, vo_q); break; \
-                    case 7: nsf_out_partials<7>(rs, f3_, b3_, nT, D, g0_, g1_, g2_, g3_, H2, pt_, lane, vo_lane, vo_q); break; \
-                    case 8: nsf_out_partials<8>(rs, f3_, b3_, nT, D, g0_, g1_, g2_, g3_, H2, pt_, lane, vo_lane, vo_q); break; \
-                    default:                                                                                      \
-                        nsf_out_partials_wide(rs, f3_, b3_, nT, D, nK, g0_, H2, pt_, lane, vo_lane, vo_q);        \
-                        nsf_out_partials_wide(rs, f3_, b3_, nT, D, nK, g1_, H2, pt_ + 512, lane, vo_lane, vo_q);  \
-                        nsf_out_partials_wide(rs, f3_, b3_, nT, D, nK, g2_, H2, pt_ + 1024, lane, vo_lane, vo_q); \
-                        nsf_out_partials_wide(rs, f3_, b3_, nT, D, nK, g3_, H2, pt_ + 1536, lane, vo_lane, vo_q); \
-                        break;                                                                                    \
-                }                                                                                                 \
+                nsf_out_partials_wide(rs, f3_, b3_, nT, D, nK, g0_, H2, pt_, lane, vo_lane, vo_q);                \
+                nsf_out_partials_wide(rs, f3_, b3_, nT, D, nK, g1_, H2, pt_ + 512, lane, vo_lane, vo_q);          \
+                nsf_out_partials_wide(rs, f3_, b3_, nT, D, nK, g2_, H2, pt_ + 1024, lane, vo_lane, vo_q);         \
+                nsf_out_partials_wide(rs, f3_, b3_, nT, D, nK, g3_, H2, pt_ + 1536, lane, vo_lane, vo_q);         \
                 lds_bar();                                                /* E(T1 - 1) */                         \
             }
-            for (int T2 = 0; T2 < nTl; T2 += 2) {
-                NB_TILE(T2, pA1, pA2, xA, bA0, bA1, bA2, pB1, pB2, xB, bB0, bB1, bB2)
-                if (T2 + 1 >= nTl) break;
-                NB_TILE(T2 + 1, pB1, pB2, xB, bB0, bB1, bB2, pA1, pA2, xA, bA0, bA1, bA2)
-            }
-            {   // the next transform's first operands: on their way before this one ends
-                const int tbn = (t > 0 ? t - 1 : 0) * blk_bytes;
-                NB_FETCH(tbn, 0, pA1, pA2, xA, bA0, bA1, bA2)
+            if (static_tiles) {
+                bc.tb = tb; bc.X = X;
+                for (int T1 = 0; T1 < nTl; ++T1) {
+                    const int4 tg = *reinterpret_cast<const int4*>(DGT + 8 * T1);
+                    bc.g[0] = __builtin_amdgcn_readfirstlane(tg.x & 0xffff); bc.g[1] = __builtin_amdgcn_readfirstlane(tg.y);
+                    bc.g[2] = __builtin_amdgcn_readfirstlane(tg.z); bc.g[3] = __builtin_amdgcn_readfirstlane(tg.w);
+                    bc.gn = T1 + 1 < nTl ? (__builtin_amdgcn_readfirstlane(DGT[8 * (T1 + 1)]) & 0xffff) : D;
+                    bc.stg = STG + (T1 & 1) * NSF2_STAGE_FLOATS;
+                    bc.part = PART + (T1 & 1) * NSF2_PART_FLOATS;
+                    switch (T1) {
+#define CASE(K) case K: nsf_burst_tile<K>(bc, carry); break;
+                        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+#undef CASE
+                        default: break;
+                    }
+                    lds_bar();                                            // E(T1 - 1)
+                }
+                {   // the next transform's first tile has no final tile behind it: the bias rows of its first rank
+                    const int tbn = (t > 0 ? t - 1 : 0) * blk_bytes, g0n = __builtin_amdgcn_readfirstlane(DGT[0]) & 0xffff;
+                    carry.b0 = nbload4(rs, vo_q, tbn + oB3I + g0n * 128);
+                    carry.b1 = nbload4(rs, vo_q, tbn + oB3I + g0n * 128 + 64);
+                }
+            } else {
+                for (int T2 = 0; T2 < nTl; T2 += 2) {
+                    NB_TILE(T2, sA.p1, sA.p2, sA.xf, sA.b0, sA.b1, sA.b2, sB.p1, sB.p2, sB.xf, sB.b0, sB.b1, sB.b2)
+                    if (T2 + 1 >= nTl) break;
+                    NB_TILE(T2 + 1, sB.p1, sB.p2, sB.xf, sB.b0, sB.b1, sB.b2, sA.p1, sA.p2, sA.xf, sA.b0, sA.b1, sA.b2)
+                }
+                const int tbn = (t > 0 ? t - 1 : 0) * blk_bytes;      // the next transform's first operands: on their way before this one ends
+                NB_FETCH(tbn, 0, sA.p1, sA.p2, sA.xf, sA.b0, sA.b1, sA.b2)
             }
             lds_bar();                                                    // E(nTl - 1)
             __syncthreads();                                              // (the chain re-ranked x)
@@ -428,35 +553,36 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
         NsfHid fA, fB;
         NsfOut ob[2];
         // the chain's hidden operands of tile U of transform tt
-        auto request_hid = [&](NsfHid& F, const int tt, const int U) {
+        // request number K of 11 of the chain's hidden operands of tile U of transform tt
+        auto request_hid = [&](NsfHid& F, auto k_, const int tt, const int U) {
+            constexpr int K = decltype(k_)::value;
             const int base = tt * blk_bytes;
             const int Un = U + 1 < nT ? U + 1 : U;
             const int voN = U + 1 < nT ? vo_T : NSF2_OOB;
-            F.wt1 = nbload4(rs, vo_T, base + oF1 + (U * nT + U) * 1024);
-            F.wt2 = nbload4(rs, vo_T, base + oF2 + (U * nT + U) * 1024);
-            F.wn1 = nbload4(rs, voN, base + oF1 + (Un * nT + U) * 1024);
-            F.wn2 = nbload4(rs, voN, base + oF2 + (Un * nT + U) * 1024);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) F.w0o[i] = nbload4(rs, ((4 + i) << 6) + vo_q, base + oCW0 + U * 1024);
-            F.w0o[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) F.w0N[i] = nbload4(rs, U + 1 < nT ? (i << 6) + vo_q : NSF2_OOB, base + oCW0 + Un * 1024);
+            if constexpr (K == 0) F.wt1 = nbload4(rs, vo_T, base + oF1 + (U * nT + U) * 1024);
+            else if constexpr (K == 1) F.wt2 = nbload4(rs, vo_T, base + oF2 + (U * nT + U) * 1024);
+            else if constexpr (K == 2) F.wn1 = nbload4(rs, voN, base + oF1 + (Un * nT + U) * 1024);
+            else if constexpr (K == 3) F.wn2 = nbload4(rs, voN, base + oF2 + (Un * nT + U) * 1024);
+            else if constexpr (K < 7) F.w0o[K - 4] = nbload4(rs, ((4 + K - 4) << 6) + vo_q, base + oCW0 + U * 1024);
+            else if constexpr (K < 11) F.w0N[K - 7] = nbload4(rs, U + 1 < nT ? ((K - 7) << 6) + vo_q : NSF2_OOB, base + oCW0 + Un * 1024);
         };
-        // rank g's two output tiles against hidden tiles Kp (previous; < 0: none) and Kc (own) of transform tt
-        auto request_out = [&](NsfOut& O, const int tt, const int g, const int Kp, const int Kc) {
+        // request number K of 4 of rank g's two output tiles against hidden tiles Kp (previous; < 0: none) and Kc (own) of transform tt
+        auto request_out = [&](NsfOut& O, auto k_, const int tt, const int g, const int Kp, const int Kc) {
+            constexpr int K = decltype(k_)::value;
             const bool lv = g < D;
             const int so = tt * blk_bytes + oF3I + (lv ? g : 0) * 2 * nT * 1024;
             const int vp = (lv && Kp >= 0) ? vo_lane : NSF2_OOB, vc = lv ? vo_lane : NSF2_OOB;
             const int kp = Kp >= 0 ? Kp : 0;
             if (NSF2_ABL & 16) return;
-            O.fp0 = nbload4(rs, vp, so + kp * 1024);
-            O.fp1 = nbload4(rs, vp, so + (nT + kp) * 1024);
-            O.fc0 = nbload4(rs, vc, so + Kc * 1024);
-            O.fc1 = nbload4(rs, vc, so + (nT + Kc) * 1024);
+            if constexpr (K == 0) O.fp0 = nbload4(rs, vp, so + kp * 1024);
+            else if constexpr (K == 1) O.fp1 = nbload4(rs, vp, so + (nT + kp) * 1024);
+            else if constexpr (K == 2) O.fc0 = nbload4(rs, vc, so + Kc * 1024);
+            else O.fc1 = nbload4(rs, vc, so + (nT + Kc) * 1024);
         };
         take_table(fA, 0);
-        request_hid(fA, T - 1, 0);
-        request_out(ob[0], T - 1, fA.g[0], -1, 0);
+        fA.w0o[3] = fB.w0o[3] = make_float4(0.f, 0.f, 0.f, 0.f);          // (the fourth group has no later quad)
+        nsf_for<11>([&](auto k_) { request_hid(fA, k_, T - 1, 0); });
+        nsf_for<4>([&](auto k_) { request_out(ob[0], k_, T - 1, fA.g[0], -1, 0); });
         float4 w00 = nbload4(rs, vo_q, (T - 1) * blk_bytes + oCW0);      // layer 0, first tile: the column of rank 0
         float4 r00 = nbload4(rs, vo_q, (T - 1) * blk_bytes + oB3I), r01 = nbload4(rs, vo_q, (T - 1) * blk_bytes + oB3I + 64);
         for (int t = T - 1; t >= 0; --t) {
@@ -478,6 +604,7 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
 
             for (int Tt_ = 0; Tt_ < nTl; ++Tt_) {
                 const int Tt = __builtin_amdgcn_readfirstlane(Tt_);
+                if (pf) pf[15] = clock64();
                 NsfHid& cur = fA;
                 NsfHid& nxt = fB;
                 const float* st = STG + (Tt & 1) * NSF2_STAGE_FLOATS;
@@ -497,20 +624,31 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                 const bool more = Tt + 1 < nTl;
                 const int ntt = more ? t : (t > 0 ? t - 1 : 0), nU = more ? Tt + 1 : 0;
                 take_table(nxt, nU);
-                auto ahead = [&](auto gi_) {
-                    constexpr int G = decltype(gi_)::value;
-                    if constexpr (G == 0) request_hid(nxt, ntt, nU);
-                    // the next group's output fragments: a later group of this tile, or the next tile's first
-                    const bool last = G + 1 >= ng;
-                    const int gn = last ? nxt.g[0] : cur.g[(G + 1) & 3];
-                    request_out(ob[(G + 1) & 1], last ? ntt : t, gn, last ? (more ? Tt : -1) : Tt - 1, last ? nU : Tt);
+                // the shadows of a group's MFMAs (slot 0..3: behind the pairs of previous-tile output products; 4, 5: behind the
+                // hidden hops): the next group's output fragments -- a later group of this tile, or the next tile's first -- and
+                // this group's share of the next tile's hidden operands
+                auto ahead = [&](auto gi_, auto slot_, auto ng_) {
+                    constexpr int G = decltype(gi_)::value, SL = decltype(slot_)::value, NG_ = decltype(ng_)::value;
+                    if constexpr (SL < 4) {
+                        const bool last = G + 1 >= NG_;
+                        const int gn = last ? nxt.g[0] : cur.g[(G + 1) & 3];
+                        request_out(ob[(G + 1) & 1], slot_, last ? ntt : t, gn, last ? (more ? Tt : -1) : Tt - 1, last ? nU : Tt);
+                    } else {
+                        constexpr int LPG = (11 + NG_ - 1) / NG_, H = (LPG + 1) / 2;       // loads per group; in the first hop's shadow
+                        constexpr int k0 = G * LPG + (SL == 4 ? 0 : H), k1 = G * LPG + (SL == 4 ? H : LPG);
+                        nsf_for<k1 - k0>([&](auto j_) {
+                            constexpr int K = k0 + decltype(j_)::value;
+                            if constexpr (K < 11) request_hid(nxt, std::integral_constant<int, K>{}, ntt, nU);
+                        });
+                    }
                 };
                 switch (pat) {
-#define CASE(P) case P: nsf_group<P, 0>(s, cur, ob, part, X, Y, PAR, TAB, D, q, p, lane, ladj, ahead); break;
+#define CASE(P) case P: nsf_group<P, 0>(s, cur, ob, part, X, Y, PAR, TAB, D, q, p, lane, ladj, ahead, pf); break;
                     CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
 #undef CASE
                     default: break;
                 }
+                NSF_STAMP(6)
                 {   // the tile's activations: one 16-byte word per layer and lane (row q of every quad)
                     const int hw = (Tt << 8) + (q << 6) + (p << 2);
                     *reinterpret_cast<float4*>(H0 + hw) = make_float4(s.h0s[0], s.h0s[1], s.h0s[2], s.h0s[3]);
@@ -518,8 +656,11 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                     *reinterpret_cast<float4*>(H2 + hw) = make_float4(s.h2s[0], s.h2s[1], s.h2s[2], s.h2s[3]);
                 }
                 if (ng & 1) ob[0] = ob[1];                   // (an odd number of groups leaves the next group's fragments in the second slot)
+                NSF_STAMP(8)
                 lds_bar();                                   // E(Tt): this tile is final
+                NSF_STAMP(9)
                 fA = fB;
+                NSF_STAMP(10)
             }
             w00 = nbload4(rs, vo_q, (t > 0 ? t - 1 : 0) * blk_bytes + oCW0);
             r00 = nbload4(rs, vo_q, (t > 0 ? t - 1 : 0) * blk_bytes + oB3I);
@@ -536,6 +677,7 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
             __syncthreads();
         }
         if (ladj_out && lane < 16 && row0 + p < n) ladj_out[row0 + p] = ladj;
+        if (pf && lane == 0) for (int i = 0; i < 16; ++i) prof[i] = pfv[i];
     }
 }
 
@@ -555,6 +697,19 @@ int pmc_launch_inverse_nsf2(const pmc_maf_t* m, const float* z, float* x, float*
         if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_inverse_nsf2_kernel)");
         lds_set = lds;
     }
-    hipLaunchKernelGGL(maf_inverse_nsf2_kernel<0>, dim3((unsigned)((n + 15) / 16)), dim3(128), lds, stream, *m, z, x, ladj, n);
+    hipLaunchKernelGGL(maf_inverse_nsf2_kernel<0>, dim3((unsigned)((n + 15) / 16)), dim3(128), lds, stream, *m, z, x, ladj, n,
+                       (long long*)nullptr);
     return pmc_check_launch("maf_inverse_nsf2_kernel");
+}
+
+// measurement only (scripts/profile_nsf2.py): cycles of the chain wave of workgroup 0 by section of a group, summed over the sweep
+extern "C" int pmc_debug_nsf2_profile(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, long long* prof, void* stream) {
+    if (pmc_launch_inverse_nsf2(m, z, x, ladj, 16, (hipStream_t)stream) < 0) return pmc_fail("pmc_debug_nsf2_profile: flow not covered");
+    const size_t lds = (size_t)NSF2_LDS_FLOATS(m) * sizeof(float);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_nsf2_kernel<-1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_inverse_nsf2_kernel<-1>)");
+    }
+    hipLaunchKernelGGL(maf_inverse_nsf2_kernel<-1>, dim3((unsigned)((n + 15) / 16)), dim3(128), lds, (hipStream_t)stream, *m, z, x, ladj, n, prof);
+    return pmc_check_launch("maf_inverse_nsf2_kernel<profile>");
 }

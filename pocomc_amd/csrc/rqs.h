@@ -13,6 +13,9 @@
 #include "maf_common.h"
 
 #define RQS_K 8
+#ifndef RQS_SELECT_REGS
+#define RQS_SELECT_REGS 0   // rqs_inverse_split: the bin's derivatives by register selects (1) or by an indexed LDS read (0)
+#endif
 #define RQS_NOUT 23
 #define RQS_BOUND 5.0f
 
@@ -192,17 +195,36 @@ __device__ __forceinline__ void rqs_inverse_split(const f32x4& o0, const f32x4& 
     const float cw1 = w0.x, cw2 = cw1 + w0.y, cw3 = cw2 + w0.z, cw4 = cw3 + w0.w, cw5 = cw4 + w1.x, cw6 = cw5 + w1.y, cw7 = cw6 + w1.z, ws = cw7 + w1.w;
     const bool inside = (y > -RQS_BOUND) && (y <= RQS_BOUND);
     const float t = (y + RQS_BOUND) * (0.5f / RQS_BOUND) * hs;
-    int k = 0;
-    float a0 = 0.0f, a1 = ch1, b0 = 0.0f, b1 = cw1;
-#define RQS_STEP(J, CA, CB, WA, WB) if (CA < t) { k = J; a0 = CA; a1 = CB; b0 = WA; b1 = WB; }
-    RQS_STEP(1, ch1, ch2, cw1, cw2) RQS_STEP(2, ch2, ch3, cw2, cw3) RQS_STEP(3, ch3, ch4, cw3, cw4) RQS_STEP(4, ch4, ch5, cw4, cw5)
-    RQS_STEP(5, ch5, ch6, cw5, cw6) RQS_STEP(6, ch6, ch7, cw6, cw7) RQS_STEP(7, ch7, hs, cw7, ws)
+    // the bin and what belongs to it, by compare-and-select over registers (an LDS read by run-time index would put a
+    // second round trip on the dependent path); the end knots' raw log-derivative is 0 (derivative 1)
+#if RQS_SELECT_REGS
+    const float4 d03 = *reinterpret_cast<const float4*>(par + 16), d46 = *reinterpret_cast<const float4*>(par + 20);
+    float a0 = 0.0f, a1 = ch1, b0 = 0.0f, b1 = cw1, q0 = 0.0f, q1 = d03.x;
+#define RQS_STEP(CA, CB, WA, WB, QA, QB) if (CA < t) { a0 = CA; a1 = CB; b0 = WA; b1 = WB; q0 = QA; q1 = QB; }
+    RQS_STEP(ch1, ch2, cw1, cw2, d03.x, d03.y) RQS_STEP(ch2, ch3, cw2, cw3, d03.y, d03.z) RQS_STEP(ch3, ch4, cw3, cw4, d03.z, d03.w)
+    RQS_STEP(ch4, ch5, cw4, cw5, d03.w, d46.x) RQS_STEP(ch5, ch6, cw5, cw6, d46.x, d46.y) RQS_STEP(ch6, ch7, cw6, cw7, d46.y, d46.z)
+    RQS_STEP(ch7, hs, cw7, ws, d46.z, 0.0f)
 #undef RQS_STEP
+    const float rh = rqs_rcp(hs) * (2.0f * RQS_BOUND), rw = rqs_rcp(ws) * (2.0f * RQS_BOUND);
+    const float y0 = a0 * rh - RQS_BOUND, y1 = a1 * rh - RQS_BOUND, x0 = b0 * rw - RQS_BOUND, x1 = b1 * rw - RQS_BOUND;
+    const float d0 = rqs_exp(rqs_clip1(q0)), d1 = rqs_exp(rqs_clip1(q1));
+#else
+    // bisection over the nine knots (three compares, 20 selects; the linear scan was 7 compares and 35 selects in a chain)
+    const bool c4 = ch4 < t;
+    const float e0 = c4 ? ch4 : 0.0f, e1 = c4 ? ch5 : ch1, e2 = c4 ? ch6 : ch2, e3 = c4 ? ch7 : ch3, e4 = c4 ? hs : ch4;
+    const float f0 = c4 ? cw4 : 0.0f, f1 = c4 ? cw5 : cw1, f2 = c4 ? cw6 : cw2, f3 = c4 ? cw7 : cw3, f4 = c4 ? ws : cw4;
+    const bool c2 = e2 < t;
+    const float g0 = c2 ? e2 : e0, g1 = c2 ? e3 : e1, g2 = c2 ? e4 : e2;
+    const float i0 = c2 ? f2 : f0, i1 = c2 ? f3 : f1, i2 = c2 ? f4 : f2;
+    const bool c1 = g1 < t;
+    const float a0 = c1 ? g1 : g0, a1 = c1 ? g2 : g1, b0 = c1 ? i1 : i0, b1 = c1 ? i2 : i1;
+    const int k = (c4 ? 4 : 0) + (c2 ? 2 : 0) + (c1 ? 1 : 0);
     const float q0 = par[2 * RQS_K + (k >= 1 ? k - 1 : 0)], q1 = par[2 * RQS_K + (k + 1 < RQS_K ? k : 0)];
     const float rh = rqs_rcp(hs) * (2.0f * RQS_BOUND), rw = rqs_rcp(ws) * (2.0f * RQS_BOUND);
     const float y0 = a0 * rh - RQS_BOUND, y1 = a1 * rh - RQS_BOUND, x0 = b0 * rw - RQS_BOUND, x1 = b1 * rw - RQS_BOUND;
     const float r0 = (k >= 1) ? rqs_clip1(q0) : 0.0f, r1 = (k + 1 < RQS_K) ? rqs_clip1(q1) : 0.0f;
     const float d0 = rqs_exp(r0), d1 = rqs_exp(r1);
+#endif
     const float dx = x1 - x0, dy = y1 - y0;
     const float s = dy * rqs_rcp(dx);
     const float yr = inside ? y - y0 : 0.0f;

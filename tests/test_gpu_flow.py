@@ -215,7 +215,7 @@ def test_flow_names():
 
 
 # ----------------------------------------------------------------- neural spline flows
-NSF_SHAPES = [(2, 3), (4, 3), (10, 3), (17, 2), (32, 3), (50, 6)]
+NSF_SHAPES = [(2, 3), (4, 3), (10, 3), (17, 2), (32, 3), (40, 2), (50, 6)]     # (40: the widest flow of the static burst tile; 50: the streamed path)
 NSF_FWD, NSF_INV, NSF_LADJ = 2e-5, 5e-5, 1e-4        # per walker, pure relative (the header says why not 1e-5)
 
 
@@ -250,7 +250,7 @@ def test_nsf_inverse_matches_oracle(D, T, n):
     z = (np.random.default_rng(7 + n).normal(size=(n, D)) * 1.5).astype(np.float32)
     xo, lo = o.inverse(z)                       # the reference's D-pass algorithm
     terms = o.ladj_abs_terms(xo)
-    for algo in ([1, 2] if f.spec.tri_ok else [2]):     # triangular sweep, D-pass on the device
+    for algo in ([1, 6, 7, 2] if f.spec.tri_ok else [2]):     # triangular sweeps (AUTO's choice, lone wave, two waves), D-pass on the device
         f.inverse_algo = algo
         x, l = f.inverse(torch.from_numpy(z))
         close_rel(x.numpy(), xo, NSF_INV, f"nsf x, algorithm {algo}")
@@ -263,6 +263,36 @@ def test_nsf_inverse_matches_oracle(D, T, n):
     z2, l2 = f.forward(x)
     close_rel(z2.numpy(), z, NSF_INV, "nsf round trip")
     close_rel(l2.numpy(), -l.numpy(), NSF_LADJ, "nsf antisymmetry", cancel=terms)
+
+
+def test_spline_sweeps_on_random_flow_shapes():
+    """Random spline flows (D <= 64, T, hidden, n): the lone-wave and the two-wave sweep (static burst tiles up to 11 live
+    hidden tiles, streamed above) agree to float32 rounding and follow the D-pass inverse on the device."""
+    from pocomc_amd import Flow
+    rng = np.random.default_rng(11)
+    done = 0
+    for case in range(24):
+        D = int(rng.integers(2, 65))
+        T = int(rng.integers(1, 5))
+        H = max(int(rng.choice([max(D - 1, 4), D + 3, 2 * D, 3 * D + 1, 128, 4 * (D - 1) + 5])), D - 1)
+        n = int(rng.choice([1, 15, 16, 17, 100, 1000]))
+        spec = MAFSpec(D, T, hidden=H, univariate="rqs")
+        if not spec.tri_ok:
+            continue
+        f = Flow(D, spec, seed=case)
+        f.set_params(cases.flow_params(spec, case))
+        z = torch.randn(n, D, generator=torch.Generator().manual_seed(case)) * 1.5
+        out = {}
+        for algo in (2, 6, 7):
+            f.inverse_algo = algo
+            out[algo] = [t.numpy() for t in f.inverse(z)]
+        sc = np.maximum(1.0, np.abs(out[2][0]).max(axis=1, keepdims=True))
+        assert np.isfinite(out[7][0]).all() and np.isfinite(out[6][0]).all(), (D, T, H, n)
+        assert (np.abs(out[7][0] - out[6][0]) / sc).max() < 2e-4, (D, T, H, n)
+        assert (np.abs(out[7][0] - out[2][0]) / sc).max() < 5e-4, (D, T, H, n)
+        assert np.abs(out[7][1] - out[6][1]).max() < 1e-3 * max(1.0, float(np.abs(out[6][1]).max())), (D, T, H, n)
+        done += 1
+    assert done >= 15
 
 
 def test_sweeps_on_random_flow_shapes():
