@@ -379,7 +379,9 @@ def main():
     # the timed region steps the same walkers as a pipeline of row ranges (what mcmc._run does from 4096 walkers
     # on); `eng` (the whole set at once) stays for the instrumented passes below
     if args.lanes <= 0:
-        args.lanes = 2 if (flow.spec.univariate == "affine" and flow.spec.tri_ok and flow.spec.nOT <= 8 and D <= 64) else 1
+        # (two row ranges wherever a two-wave sweep covers the flow: 512 walker sets are resident at a time, a launch of
+        #  all 10000 walkers would run in two rounds)
+        args.lanes = 2 if (flow.spec.tri_ok and D <= 64 and (flow.spec.univariate == "rqs" or flow.spec.nOT <= 8)) else 1
     leng = None
     pipelined = (not args.no_pipeline) and args.x_order == "F" and D <= 256
     bufsize0 = None
@@ -605,10 +607,12 @@ def main():
     us["maf_inverse_timed_region"] = inv_us_live            # HIP events inside the timed region
     t_inv = inv_us_live * 1e-6
     lane_auto = args.inverse in ("auto", "triangular") and bool(lib.pmc_debug_inverse_uses_lane(ctypes.byref(flow._desc)))
-    fused = (eng.pre and spec.univariate == "affine" and spec.tri_ok and spec.nOT <= 8 and not lane_auto
-             and args.inverse in ("auto", "triangular"))
+    nsf2 = spec.univariate == "rqs" and bool(lib.pmc_debug_inverse_uses_nsf2(ctypes.byref(flow._desc)))
+    fused = (eng.pre and spec.tri_ok and not lane_auto and args.inverse in ("auto", "triangular")
+             and ((spec.univariate == "affine" and spec.nOT <= 8) or nsf2))
     duo = bool(lib.pmc_debug_inverse_uses_duo(ctypes.byref(flow._desc), n_launch))
     roof_kernel = ("maf_dense_kernel<1>" if (args.inverse == "naive" or not spec.tri_ok) else
+                   "maf_inverse_nsf2_kernel" if (nsf2 and args.inverse in ("auto", "triangular", "duo")) else
                    "maf_inverse_tri_nsf_kernel" if spec.univariate == "rqs" else
                    "maf_inverse_tri6_kernel" if (args.inverse == "lane" or lane_auto or os.environ.get("PMC_INVERSE_LANE", "0") != "0") else
                    "maf_inverse_tri4_kernel" if args.inverse == "solo" else

@@ -108,6 +108,7 @@ SIGNATURES = {
     "pmc_maf_train_waves": (C.c_int, [C.POINTER(pmc_maf_t)]),
     "pmc_debug_inverse_uses_duo": (C.c_int, [C.POINTER(pmc_maf_t), C.c_int64]),
     "pmc_debug_inverse_uses_lane": (C.c_int, [C.POINTER(pmc_maf_t)]),
+    "pmc_debug_inverse_uses_nsf2": (C.c_int, [C.POINTER(pmc_maf_t)]),
     "pmc_abi_version": (C.c_int, []),
     "pmc_maf_pack": (C.c_int, [c_p, c_p, c_p, i64, c_p]),
     "pmc_maf_forward": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, c_p, i64, c_p]),

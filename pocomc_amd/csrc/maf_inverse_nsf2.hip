@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include "maf_chain_rot.h"
 #include "rqs.h"
+#include "propose_body.h"
 
 #ifndef NSF2_ABL
 #define NSF2_ABL 0                 // timing experiments only (scripts/abl_nsf.sh): results are wrong when != 0
@@ -324,9 +325,12 @@ __device__ __forceinline__ void nsf_out_partials_wide(__amdgpu_buffer_rsrc_t rs,
     *reinterpret_cast<float4*>(d + 256 + (lane << 2)) = make_float4(o1[0], o1[1], o1[2], o1[3]);
 }
 
+// FM: 0 = plain inverse of `in`; 4 / 8 / 16 = fused proposal (pocomc/mcmc.py:77-85) of the workgroup's 16 walkers as the
+// prologue (D <= 4 FM) and, when pa.epi.on, the scaler (+ prior) on them as the epilogue (scaler_body.h); -1: the plain
+// inverse with cycle stamps (measurement only)
 template <int FM>
 __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, const float* __restrict__ in, float* __restrict__ out,
-                                                               float* __restrict__ ladj_out, int64_t n, long long* prof) {
+                                                               float* __restrict__ ladj_out, int64_t n, long long* prof, ProposeArgs pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -413,7 +417,17 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
         const int n4 = (2 * Dp * 16 + 3 * Hp * 16 + 2 * NSF2_STAGE_FLOATS + 2 * NSF2_PART_FLOATS) >> 2;
         for (int e = threadIdx.x; e < n4; e += 128) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (wv == 0) load_rows(Y, in, row0, n, D, Dp, feat_of_rank + (T - 1) * D, lane);
+    if (wv == 0) {
+        if constexpr (FM > 0) {
+            for (int e = lane; e < (Dp - D) * 16; e += 64) Y[lidx(D + (e >> 4), e & 15)] = 0.0f;
+            const double sg = pa.adapt ? pa.adapt[0] : pa.sigma, ca = pa.adapt ? pa.adapt[1] : pa.cn_a;
+            propose_body<FM>(pa.kind, pa.cur32, nullptr, pa.adapt ? pa.adapt + 2 : pa.mu, pa.inv_cov, pa.chol, pa.nu, sg, ca,
+                             pa.rng, pa.prop64, nullptr, pa.quad, pa.quad_prop, n, D, Y, rank_of_feat + (T - 1) * D,
+                             (int64_t)blockIdx.x);
+        } else {
+            load_rows(Y, in, row0, n, D, Dp, feat_of_rank + (T - 1) * D, lane);
+        }
+    }
     float ladj = 0.0f;
     int xsel = 0;
     __syncthreads();
@@ -679,37 +693,74 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
         if (ladj_out && lane < 16 && row0 + p < n) ladj_out[row0 + p] = ladj;
         if (pf && lane == 0) for (int i = 0; i < 16; ++i) prof[i] = pfv[i];
     }
+    if constexpr (FM > 0) {
+        // the scaler (+ prior) on the 16 walkers while they are in LDS (x of the first transform, by its ranks); both
+        // wavefronts; the activation arrays are free now and serve as its scratch
+        if (pa.epi.on) {
+            const float* Xl = (xsel ^ 1) ? XB : XA;
+            scaler_epilogue(pa.epi, Xl, rank_of_feat, reinterpret_cast<double*>(H0), row0, n, D, (int)threadIdx.x, 128,
+                            [](int r, int pp) { return lidx(r, pp); });
+        }
+    }
 }
 
 // Covered: spline flows whose degree groups fit a hidden tile (tri_ok), D <= 64 (NSF2_PX x tiles), one buffer resource
-// over the whole image.  -1: not covered (the caller launches the lone-wave sweep).
-int pmc_launch_inverse_nsf2(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream) {
+// over the whole image.  -1: not covered (the caller launches the lone-wave sweep / the separate kernels).
+// pa == nullptr: plain inverse of z; else the fused proposal (+ scaler epilogue when pa->epi.on).
+static int launch_nsf2(const ProposeArgs* pa, const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream) {
     static const int mode = getenv("PMC_INVERSE_NSF_DUO") ? atoi(getenv("PMC_INVERSE_NSF_DUO")) : -1;
     if (mode == 0) return -1;
     if (m->n_out != 23 || !m->tri_ok || m->D > 64 || m->D < 2) return -1;
     if (m->pk_per_transform * 4 * m->T >= (int64_t)NSF2_OOB) return -1;
     const size_t lds = (size_t)NSF2_LDS_FLOATS(m) * sizeof(float);
     if (lds > 160 * 1024) return -1;
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_nsf2_kernel<0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_inverse_nsf2_kernel)");
-        lds_set = lds;
+    const ProposeArgs none{};
+#define LAUNCHN(FMV)                                                                                              \
+    {                                                                                                             \
+        if (lds > 48 * 1024) {                                                                                    \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_nsf2_kernel<FMV>),       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+            if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_inverse_nsf2_kernel)");          \
+        }                                                                                                         \
+        hipLaunchKernelGGL(maf_inverse_nsf2_kernel<FMV>, dim3((unsigned)((n + 15) / 16)), dim3(128), lds, stream, *m, z, x, \
+                           ladj, n, pa ? pa->prof : (long long*)nullptr, pa ? *pa : none);                        \
     }
-    hipLaunchKernelGGL(maf_inverse_nsf2_kernel<0>, dim3((unsigned)((n + 15) / 16)), dim3(128), lds, stream, *m, z, x, ladj, n,
-                       (long long*)nullptr);
+    if (pa && pa->prof) LAUNCHN(-1)
+    else if (!pa || !pa->cur32) LAUNCHN(0)
+    else if (m->D <= 16) LAUNCHN(4)
+    else if (m->D <= 32) LAUNCHN(8)
+    else LAUNCHN(16)
+#undef LAUNCHN
     return pmc_check_launch("maf_inverse_nsf2_kernel");
+}
+
+// whether PMC_INVERSE_AUTO launches this kernel for the flow (bench.py names the kernel it times with it)
+extern "C" int pmc_debug_inverse_uses_nsf2(const pmc_maf_t* m) {
+    static const int mode = getenv("PMC_INVERSE_NSF_DUO") ? atoi(getenv("PMC_INVERSE_NSF_DUO")) : -1;
+    if (!m || mode == 0 || m->n_out != 23 || !m->tri_ok || m->D > 64 || m->D < 2) return 0;
+    if (m->pk_per_transform * 4 * m->T >= (int64_t)NSF2_OOB) return 0;
+    return (size_t)NSF2_LDS_FLOATS(m) * sizeof(float) <= 160 * 1024 ? 1 : 0;
+}
+
+int pmc_launch_inverse_nsf2(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream) {
+    return launch_nsf2(nullptr, m, z, x, ladj, n, stream);
+}
+
+// the spline flows' instance of pmc_launch_propose_inverse_tri4 (same contract; called from there)
+int pmc_launch_propose_inverse_nsf2(ProposeArgs* pa, const ScalerEpi* epi, int* epi_done, const pmc_maf_t* m, float* x, float* ladj,
+                                    int64_t n, hipStream_t stream) {
+    if (epi_done) *epi_done = 0;
+    // the scaler as the sweep's epilogue: its scratch aliases the three activation arrays of the walker set
+    const bool epi_ok = epi && epi_done && epi->s.D == m->D && scaler_epilogue_lds_bytes(m->D) <= (size_t)3 * m->Hp * 16 * sizeof(float);
+    if (epi_ok) { pa->epi = *epi; pa->epi.on = 1; }
+    const int rc = launch_nsf2(pa, m, nullptr, x, ladj, n, stream);
+    if (rc == 0 && epi_ok) *epi_done = 1;
+    return rc;
 }
 
 // measurement only (scripts/profile_nsf2.py): cycles of the chain wave of workgroup 0 by section of a group, summed over the sweep
 extern "C" int pmc_debug_nsf2_profile(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, long long* prof, void* stream) {
-    if (pmc_launch_inverse_nsf2(m, z, x, ladj, 16, (hipStream_t)stream) < 0) return pmc_fail("pmc_debug_nsf2_profile: flow not covered");
-    const size_t lds = (size_t)NSF2_LDS_FLOATS(m) * sizeof(float);
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_nsf2_kernel<-1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_inverse_nsf2_kernel<-1>)");
-    }
-    hipLaunchKernelGGL(maf_inverse_nsf2_kernel<-1>, dim3((unsigned)((n + 15) / 16)), dim3(128), lds, (hipStream_t)stream, *m, z, x, ladj, n, prof);
-    return pmc_check_launch("maf_inverse_nsf2_kernel<profile>");
+    ProposeArgs pa{};
+    pa.prof = prof;
+    return launch_nsf2(&pa, m, z, x, ladj, n, (hipStream_t)stream) < 0 ? pmc_fail("pmc_debug_nsf2_profile: flow not covered") : 0;
 }

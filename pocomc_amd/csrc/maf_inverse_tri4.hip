@@ -450,6 +450,10 @@ int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* 
                                     float* ladj, int64_t n, hipStream_t stream, const double* adapt,
                                     const ScalerEpi* epi, int* epi_done) {
     if (epi_done) *epi_done = 0;
+    if (m->n_out == 23) {                                  // spline flows: the two-wave spline sweep has the fused instances
+        ProposeArgs pan{kind, cur32, mu, inv_cov, chol, nu, sigma, cn_a, *rng, prop64, quad, quad_prop, adapt};
+        return pmc_launch_propose_inverse_nsf2(&pan, epi, epi_done, m, x, ladj, n, stream);
+    }
     if (m->n_out != 2 || !m->tri_ok || m->nOT > 8 || m->D > 64) return -1;
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
     const int maxo = m->nOT <= 4 ? 4 : 8;

@@ -455,11 +455,14 @@ def test_device_side_adaptation_equals_host_side(kind, N, n_max, flow_name):
         np.testing.assert_allclose(a[k][same], b[k][same], rtol=1e-8, atol=1e-10, err_msg=k)
 
 
-@pytest.mark.parametrize("N,lanes,bounds", [(333, 1, "box"), (1000, 2, "box"), (77, 1, "mixed")])
-def test_scaler_epilogue_of_the_sweep_equals_the_scaler_launch(monkeypatch, N, lanes, bounds):
+@pytest.mark.parametrize("N,lanes,bounds,flow_name", [(333, 1, "box", "maf3"), (1000, 2, "box", "maf3"), (77, 1, "mixed", "maf3"),
+                                                      (333, 1, "box", "nsf3"), (1000, 2, "mixed", "nsf3")])
+def test_scaler_epilogue_of_the_sweep_equals_the_scaler_launch(monkeypatch, N, lanes, bounds, flow_name):
     """The fused proposal + inverse launch applies the scaler and the prior to its 16 walkers as an epilogue
     (``scaler_body.h``: the same element code as ``scaler_inverse_kernel``, float64 in numpy's order).  PMC_NO_FUSE=2 keeps
-    the scaler a launch of its own: the whole kernel call is the same bit for bit, boundary conditions included."""
+    the scaler a launch of its own: the whole kernel call is the same bit for bit, boundary conditions included.  The spline
+    flows' fused instances (``maf_inverse_nsf2.hip``) are also compared with no fusion at all (PMC_NO_FUSE=1: proposal
+    kernel, plain sweep, scaler kernel)."""
     from scipy.stats import uniform, norm
     import pocomc_amd as pc
     from pocomc_amd import mcmc as pmcmc
@@ -478,12 +481,12 @@ def test_scaler_epilogue_of_the_sweep_equals_the_scaler_launch(monkeypatch, N, l
     x = np.column_stack([rng.uniform(-4, 4, size=N) for _ in range(D)])
     u = scaler.forward(x)
     like = lambda xx: (-0.5 * np.sum(xx ** 2, axis=1), None)
-    flow = pc.Flow(D, "maf3", seed=0)
+    flow = pc.Flow(D, flow_name, seed=0)
     geo = Geometry()
     geo.fit(flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64))
     geo.normal_cov = np.cov(u.T)
     res = []
-    for no_fuse in ("0", "2"):
+    for no_fuse in (("0", "2", "1") if flow_name.startswith("nsf") else ("0", "2")):
         monkeypatch.setenv("PMC_NO_FUSE", no_fuse)
         state = dict(u=u.copy(), x=x.copy(), logdetj=scaler.inverse(u)[1], logl=like(x)[0], logp=prior.logpdf(x),
                      beta=0.5, blobs=None)
@@ -491,10 +494,11 @@ def test_scaler_epilogue_of_the_sweep_equals_the_scaler_launch(monkeypatch, N, l
         opts = dict(n_max=6, n_steps=10 ** 6, progress_bar=None, proposal_scale=2.38 / D ** 0.5, seed=11, x_order="F",
                     lanes=lanes)
         res.append(pmcmc.preconditioned_pcn(state, funcs, opts))
-    a, b = res
-    assert a["calls"] == b["calls"] and a["accept"] == b["accept"] and a["proposal_scale"] == b["proposal_scale"]
-    for k in ("u", "x", "logl", "logp", "logdetj"):
-        assert np.array_equal(a[k], b[k]), k
+    a = res[0]
+    for b in res[1:]:
+        assert a["calls"] == b["calls"] and a["accept"] == b["accept"] and a["proposal_scale"] == b["proposal_scale"]
+        for k in ("u", "x", "logl", "logp", "logdetj"):
+            assert np.array_equal(a[k], b[k]), k
 
 
 def test_cache_warmer_threads_do_not_touch_the_results():
