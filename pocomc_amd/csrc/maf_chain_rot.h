@@ -41,7 +41,8 @@ struct ChainFrags {
     float4 w0N[4];                 // [group].jt: W0[row q of quad jt of the next tile][the rank the group produces]
     float4 f3n[MAXO];              // lone-wave sweep: right-looking updates of all output tiles
     int g[4];                      // the ranks the tile's groups produce (>= D: padding group)
-    int xy[4], so[4];              // two-wave sweep: byte offsets of the groups' x / y word (walker 0) and of their staged output partials
+    int xy[4], so[4];              // two-wave sweep: byte offsets of the groups' x word (walker 0) and of their staged output partials
+    int yo[4];                     // two-wave sweep: byte offsets of the groups' y word in the PREVIOUS transform's x array (no re-ranking between transforms)
     int pat;                       // two-wave sweep: the tile's quad pattern
 };
 

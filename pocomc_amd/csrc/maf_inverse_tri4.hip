@@ -17,7 +17,8 @@
 #define DG_WORDS(m) ((m)->nT * 4 + 8)      // LDS words of the tiles' degree table (4 per tile, padded)
 // + the two-wave sweep's permutation / rank-0 tables and its second x array (with alignment slack)
 #define TRI5_TT_WORDS(m) (((m)->nT + 2) * 16)  // the two-wave sweep's per-tile table (16 words per hidden tile, two rows of "no groups" behind)
-#define TRI5_TABLE_WORDS(m) (((TRI5_TT_WORDS(m) + (m)->T * (m)->Dp + 2 * (m)->T + 3) & ~3) + (m)->Dp * 16)
+#define TRI5_YT_WORDS(m) ((m)->T * (((m)->nT + 2) * 4 + 1))   // per transform: the y offsets of every tile's groups, of rank 0
+#define TRI5_TABLE_WORDS(m) (((TRI5_TT_WORDS(m) + (m)->T * (m)->Dp + 2 * (m)->T + 3) & ~3) + (m)->Dp * 16 + ((TRI5_YT_WORDS(m) + 3) & ~3))
 #define TRI5_LDS_FLOATS(m, maxo) (2 * (m)->Dp * 16 + 2 * (m)->Hp * 16 + 2 * 256 + 2 * (3 + (maxo)) * 256 + TRI5_TABLE_WORDS(m))
 #include "propose_body.h"
 
@@ -584,6 +585,11 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     int* PRM = DGT + TRI5_TT_WORDS(&m);
     float* B3T = reinterpret_cast<float*>(PRM + T * Dp);
     float* XB = reinterpret_cast<float*>(DGT + ((TRI5_TT_WORDS(&m) + T * Dp + 2 * T + 3) & ~3));      // (16-byte aligned)
+    // No re-ranking between transforms: transform t reads its input y where the previous transform (t + 1) left it --
+    // YT[t][tile][group]: byte offset (walker 0) of the y word of the rank the group produces, in the x array of transform
+    // t + 1 (by ITS ranks), or in Y for the first transform; Y0T[t]: the same for rank 0.
+    int* YT = reinterpret_cast<int*>(XB + Dp * 16);
+    int* Y0T = YT + T * (nT + 2) * 4;
     auto fill_table = [&]() {
         for (int e = lane; e < (nT + 2) * 16; e += 64) {
             const int tile = e >> 4, k = e & 15, i = k & 3;
@@ -638,7 +644,9 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
         else F.w0N[K - 12] = bload4(rs, U + 1 < nT ? ((K - 12) << 6) + vo_q : OOB_VOFF, base + oCW0 + Un * 1024);
     };
     // a tile's table words into its operand set
-    auto take_table = [&](ChainFrags<MAXO>& F, const int U) {
+    auto take_table = [&](ChainFrags<MAXO>& F, const int tt, const int U) {
+        const int4 ty = *reinterpret_cast<const int4*>(YT + (tt * (nT + 2) + U) * 4);
+        F.yo[0] = ty.x; F.yo[1] = ty.y; F.yo[2] = ty.z; F.yo[3] = ty.w;
         const int4 tg = *reinterpret_cast<const int4*>(DGT + 16 * U);
         const int4 txy = *reinterpret_cast<const int4*>(DGT + 16 * U + 4);
         const int4 tso = *reinterpret_cast<const int4*>(DGT + 16 * U + 8);
@@ -654,8 +662,21 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
         fill_table();
         WAVE_LDS_FENCE();
         {
+            auto woff = [](const int r) { return 4 * (((r >> 4) << 8) + ((r & 3) << 6) + ((r >> 2) & 3)); };
+            auto src_rank = [&](const int tt, const int g) {       // where rank g of transform tt sits in its input array
+                if (g >= D) return 0;
+                return tt == T - 1 ? g : rank_of_feat[(tt + 1) * D + feat_of_rank[tt * D + g]];
+            };
+            for (int e = lane; e < T * (nT + 2) * 4; e += 64) {
+                const int tt = e / ((nT + 2) * 4), rem = e - tt * (nT + 2) * 4;
+                YT[e] = woff(src_rank(tt, DGT[16 * (rem >> 2) + (rem & 3)] & 0xffff));
+            }
+            for (int tt = lane; tt < T; tt += 64) Y0T[tt] = woff(src_rank(tt, 0));
+        }
+        WAVE_LDS_FENCE();
+        {
             const int4 w0 = *reinterpret_cast<const int4*>(DGT + 12), w1 = *reinterpret_cast<const int4*>(DGT + 16 + 12);
-            take_table(fA, 0);
+            take_table(fA, T - 1, 0);
             static_for<16>([&](auto k_) { request(fA, k_, T - 1, 0, w0, w1); });
         }
         if constexpr (FM > 0) {
@@ -721,25 +742,16 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
         // are already on their way into the other (nothing else hides their L2 latency here).
         float4 pA1[PK4], pA2[PK4], pB1[PK4], pB2[PK4], xA[PXB], xB[PXB], oA[MAXO], oB[MAXO], ob[MAXO];
         float4 bA0, bA1, bA2, bB0, bB1, bB2;
-        {
-            const int tb0 = (T - 1) * blk_bytes;
-            BURST_FETCH(tb0, 0, pA1, pA2, xA, oA, bA0, bA1, bA2)
-#pragma unroll
-            for (int O = 0; O < MAXO; ++O) ob[O] = bload4(rs, O < nOT ? vo_q : OOB_VOFF, tb0 + oB3 + 64 * O);
-        }
+        // The first tile of a transform needs nothing of the transform (biases only): it is staged while the chain still
+        // runs the LAST tile of the transform before (the staging buffers alternate across the boundary: `spar`), so that
+        // at a transform boundary the chain solves rank 0 and goes on.
+        int tb = (T - 1) * blk_bytes, spar = 0;
+        // (what the x array holds on entry -- zeros, or the x of two transforms ago -- meets zero weights only: the layer-0
+        //  fragments f0c carry the columns of the ranks that are final; the other array is the chain's y)
+        float* X = XA;
+        f32x4 oN[MAXO];                                    // output-layer partials of the walker set (right-looking, natural layout)
         for (int t = T - 1; t >= 0; --t) {
-            const int tb = t * blk_bytes;
-            float* X = xsel ? XB : XA;                     // zero on entry
-            float* Xidle = xsel ? XA : XB;                 // the previous transform's x: re-ranked already, zeroed below
-            xsel ^= 1;
             // ------------------------------------------------------------------ BURST wave
-            if (t != T - 1) {
-                float4* z4 = reinterpret_cast<float4*>(Xidle);
-                for (int e = lane; e < (Dp * 16) >> 2; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            f32x4 oN[MAXO];                                // output-layer partials of the walker set (right-looking, natural layout)
-#pragma unroll
-            for (int O = 0; O < MAXO; ++O) { oN[O][0] = ob[O].x; oN[O][1] = ob[O].y; oN[O][2] = ob[O].z; oN[O][3] = ob[O].w; }
 #define BURST_K(NK, P1, P2, AA1, AA2)                                                                             \
             switch ((NK) < PK4 ? (NK) : PK4) {                                                                    \
                 case 1: burst_tile_chain<1>(AA1, AA2, P1, P2, H0, H1, lane); break;                               \
@@ -762,7 +774,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                 a1[0] = Bz1.x; a1[1] = Bz1.y; a1[2] = Bz1.z; a1[3] = Bz1.w;                                       \
                 a2[0] = Bz2.x; a2[1] = Bz2.y; a2[2] = Bz2.z; a2[3] = Bz2.w;                                       \
                 const int nK = T1 - 1;                          /* hidden tiles 0 .. T1-2 are final */            \
-                BURST_K(nK, P1, P2, a1, a2)                                                                       \
+                BURST_K(nK, P1, P2, a1, a2)                                                             \
                 if (nK > PK4) {                                 /* flows wider than PK4 + 2 tiles: four K tiles' fragments in flight */ \
                     float4 w1r[4], w2r[4];                                                                        \
                     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                            \
@@ -807,42 +819,55 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                         }                                                                                         \
                     }                                                                                             \
                 }                                                                                                 \
-                float* st_ = STG + (T1 & 1) * TRI5_STAGE_FLOATS(MAXO);                                            \
+                float* st_ = STG + ((T1 + spar) & 1) * TRI5_STAGE_FLOATS(MAXO);                                   \
                 *reinterpret_cast<float4*>(st_ + (lane << 2)) = make_float4(a0[0], a0[1], a0[2], a0[3]);          \
                 *reinterpret_cast<float4*>(st_ + 256 + (lane << 2)) = make_float4(a1[0], a1[1], a1[2], a1[3]);    \
                 *reinterpret_cast<float4*>(st_ + 512 + (lane << 2)) = make_float4(a2[0], a2[1], a2[2], a2[3]);    \
                 _Pragma("unroll") for (int O = 0; O < MAXO; ++O)                                                  \
                     *reinterpret_cast<float4*>(st_ + 768 + O * 256 + (p << 4) + (q << 2)) = make_float4(oN[O][0], oN[O][1], oN[O][2], oN[O][3]); \
-                lds_bar();                                                /* E(T1 - 1) */                         \
+                if (T1 > 0) lds_bar();                                    /* E(T1 - 1) */                         \
             }
-            for (int T2 = 0; T2 < nTl; T2 += 2) {
-                BURST_TILE(T2, pA1, pA2, xA, oA, bA0, bA1, bA2, pB1, pB2, xB, oB, bB0, bB1, bB2)
+            // the first tile of transform tt (block offset tb, x array X, staging parity spar: set by the caller)
+#define BURST_FIRST()                                                                                             \
+            {                                                                                                     \
+                BURST_FETCH(tb, 0, pA1, pA2, xA, oA, bA0, bA1, bA2)                                               \
+                _Pragma("unroll") for (int O = 0; O < MAXO; ++O) ob[O] = bload4(rs, O < nOT ? vo_q : OOB_VOFF, tb + oB3 + 64 * O); \
+                _Pragma("unroll") for (int O = 0; O < MAXO; ++O) { oN[O][0] = ob[O].x; oN[O][1] = ob[O].y; oN[O][2] = ob[O].z; oN[O][3] = ob[O].w; } \
+                BURST_TILE(0, pA1, pA2, xA, oA, bA0, bA1, bA2, pB1, pB2, xB, oB, bB0, bB1, bB2)                    \
+            }
+            if (t == T - 1) BURST_FIRST()
+            lds_bar();                                                    // E(-1): the chain solved rank 0
+            for (int T2 = 1; T2 < nTl; T2 += 2) {
+                BURST_TILE(T2, pB1, pB2, xB, oB, bB0, bB1, bB2, pA1, pA2, xA, oA, bA0, bA1, bA2)
                 if (T2 + 1 >= nTl) break;
-                BURST_TILE(T2 + 1, pB1, pB2, xB, oB, bB0, bB1, bB2, pA1, pA2, xA, oA, bA0, bA1, bA2)
+                BURST_TILE(T2 + 1, pA1, pA2, xA, oA, bA0, bA1, bA2, pB1, pB2, xB, oB, bB0, bB1, bB2)
             }
-            {   // the next transform's first operands and output biases: on their way before this one ends
-                const int tbn = (t > 0 ? t - 1 : 0) * blk_bytes;
-                BURST_FETCH(tbn, 0, pA1, pA2, xA, oA, bA0, bA1, bA2)
-#pragma unroll
-                for (int O = 0; O < MAXO; ++O) ob[O] = bload4(rs, O < nOT ? vo_q : OOB_VOFF, tbn + oB3 + 64 * O);
+            if (t > 0) {                                                  // the next transform's first tile, while the chain runs this one's last
+                tb = (t - 1) * blk_bytes;
+                X = (X == XA) ? XB : XA;
+                spar = (spar + nTl) & 1;
+                BURST_FIRST()
             }
+#undef BURST_FIRST
 #undef BURST_TILE
 #undef BURST_K
 #undef BURST_FETCH
             lds_bar();                                                    // E(nTl - 1)
-            __syncthreads();                                              // (the chain re-ranked x)
-            if (t == 0) xsel ^= 1;
+            if (t == 0) { __syncthreads(); xsel = (X == XB); }            // (the chain stored the result; xsel names the last x array)
         }
     } else {
         float4 w00 = bload4(rs, vo_q, (T - 1) * blk_bytes + oCW0);      // layer 0, first tile: the column of rank 0
+        const float* Ysrc = Y;                             // the input of the transform: Y, then the previous transform's x array
+        int spar = 0;                                      // staging parity of the transform's first tile (the buffers alternate across transforms)
         for (int t = T - 1; t >= 0; --t) {
-            float* X = xsel ? XB : XA;                     // zero on entry
+            float* X = xsel ? XB : XA;
             xsel ^= 1;
             // ------------------------------------------------------------------ CHAIN wave
             ChainRot<MAXO> s;
             {   // rank 0 reads nothing: bias only; its share of the first tile's layer 0 (the window's first slot)
                 const float shift = B3T[2 * t], ls = fast_ls(B3T[2 * t + 1]);
-                const float xv = (Y[lidx(0, p)] - shift) * fast_exp_neg(ls);
+                const float y0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Ysrc) + (p << 4) + Y0T[t]);
+                const float xv = (y0 - shift) * fast_exp_neg(ls);
                 ladj -= ls;
                 if (q == 0) X[lidx(0, p)] = xv;
                 s.a0N[0] = w00.x * xv; s.a0N[1] = w00.y * xv; s.a0N[2] = w00.z * xv; s.a0N[3] = w00.w * xv;
@@ -851,11 +876,12 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
             lds_bar();                                                    // E(-1): the first tile's staging is complete
 
             // one tile from the operands in `cur`, the next tile's requested into `nxt`
-            auto tile = [&](ChainFrags<MAXO>& cur, ChainFrags<MAXO>& nxt, const int Tt_) {
+            auto tile = [&](ChainFrags<MAXO>& cur, ChainFrags<MAXO>& nxt, const int Tt_, auto fast_) {
+                constexpr bool FAST = decltype(fast_)::value;          // the caller knows the tile has four single-quad groups
                 const int Tt = __builtin_amdgcn_readfirstlane(Tt_);
                 long long* pf = (pa.prof && blockIdx.x == 0) ? pa.prof + ((size_t)(T - 1 - t) * nT + Tt) * 8 : nullptr;
                 if (pf && lane == 0) pf[0] = clock64();
-                float* st = STG + (Tt & 1) * TRI5_STAGE_FLOATS(MAXO);
+                float* st = STG + ((Tt + spar) & 1) * TRI5_STAGE_FLOATS(MAXO);
                 const float4 s0 = *reinterpret_cast<const float4*>(st + (lane << 2));
                 const float4 s1 = *reinterpret_cast<const float4*>(st + 256 + (lane << 2));
                 const float4 s2 = *reinterpret_cast<const float4*>(st + 512 + (lane << 2));
@@ -864,10 +890,10 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                 // (half mode: a lane keeps the output partials and the y of ITS pair of groups -- 0, 1 for q < 2; 2, 3 above)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const int so_k = q < 2 ? cur.so[k] : cur.so[2 + k], xy_k = q < 2 ? cur.xy[k] : cur.xy[2 + k];
+                    const int so_k = q < 2 ? cur.so[k] : cur.so[2 + k], yo_k = q < 2 ? cur.yo[k] : cur.yo[2 + k];
                     const float2 so = *reinterpret_cast<const float2*>(stb + so_k);
                     s.po[k] = make_float2(so.x + s.outN[0][2 * k], so.y + s.outN[0][2 * k + 1]);
-                    s.yv[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Y) + (p << 4) + xy_k);
+                    s.yv[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Ysrc) + (p << 4) + yo_k);
                 }
                 s.a0[0] = s0.x + s.a0N[0]; s.a0[1] = s0.y + s.a0N[1]; s.a0[2] = s0.z + s.a0N[2]; s.a0[3] = s0.w + s.a0N[3];
                 s.p1[0] = s1.x + s.accN1[0]; s.p1[1] = s1.y + s.accN1[1]; s.p1[2] = s1.z + s.accN1[2]; s.p1[3] = s1.w + s.accN1[3];
@@ -889,7 +915,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                 //  a conditional request would make the register set a conditional assignment, i.e. copies)
                 const bool more = Tt + 1 < nTl;
                 const int ntt = more ? t : (t > 0 ? t - 1 : 0), nU = more ? Tt + 1 : 0;
-                take_table(nxt, nU);
+                take_table(nxt, ntt, nU);
                 const int4 gU = *reinterpret_cast<const int4*>(DGT + 16 * nU + 12);
                 const int4 gV = *reinterpret_cast<const int4*>(DGT + 16 * (nU + 1) + 12);
                 auto ahead = [&](auto gi_, auto hop_, auto ng_) {
@@ -898,7 +924,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                     auto into = [&](ChainFrags<MAXO>& F, auto k_) { request(F, k_, ntt, nU, gU, gV); };
                     using std::integral_constant;
                     if constexpr ((TRI5_ABL & 0x100) != 0) {
-                    } else if constexpr (NG_ == 4 && TRI5_ONE_BODY) {
+                    } else if constexpr (FAST && NG_ == 4 && TRI5_ONE_BODY) {
                         // the common tile: the layer-0 window columns of a group die with the group, so the next tile's go
                         // straight into the CURRENT set once it has run; only what lives to the tile's end is buffered
                         // (and copied over at the boundary: 7 of 13 operands)
@@ -918,12 +944,12 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                     }
                 };
                 if (pf && lane == 0) pf[1] = clock64();
-                if (pat == 15 || (TRI5_ABL & 0x200)) {             // four single-quad groups: the common tile
+                if constexpr (FAST || (TRI5_ABL & 0x200) != 0) {   // four single-quad groups: the common tile
                     chain_group_rot<15, 0, 4, MAXO, TRI5_ABL | 11>(s, cur, H0, H1, X, Tt, D, nOT, q, p, ladj, H2, ahead);
                 } else
                 switch (pat) {
 #define CASE(P) case P: chain_group_rot<P, 0, 4, MAXO, TRI5_ABL | 11>(s, cur, H0, H1, X, Tt, D, nOT, q, p, ladj, H2, ahead); break;
-                    CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13)
+                    CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
 #undef CASE
                     default: break;
                 }
@@ -935,40 +961,43 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
             // (two copies of the tile body, the operand sets swapping roles; a transform with an odd number of tiles leaves
             //  the next transform's first operands in the second set: moved over once)
 #if TRI5_ONE_BODY
-            for (int Tt = 0; Tt < nTl; ++Tt) {
-                const bool common = (__builtin_amdgcn_readfirstlane(fA.pat) == 15) && !(TRI5_ABL & 0x100);
-                tile(fA, fB, Tt);
-                if (common) {                              // (the window columns were requested in place)
+            // Runs of common tiles are a loop of their own: a tile body that joins the other patterns' bodies pays for it
+            // with ~45 register copies per join (every register a body updates becomes a conditional assignment), per tile.
+            for (int Tt = 0; Tt < nTl;) {
+                while (Tt < nTl && __builtin_amdgcn_readfirstlane(fA.pat) == 15 && !(TRI5_ABL & 0x100)) {
+                    tile(fA, fB, Tt, std::true_type{});
+                    // (the window columns were requested in place)
                     fA.wt1 = fB.wt1; fA.wt2 = fB.wt2; fA.wn1 = fB.wn1; fA.wn2 = fB.wn2;
                     fA.wo[0] = fB.wo[0]; fA.woN[0] = fB.woN[0]; fA.w0N[3] = fB.w0N[3];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { fA.g[i] = fB.g[i]; fA.xy[i] = fB.xy[i]; fA.so[i] = fB.so[i]; }
+                    for (int i = 0; i < 4; ++i) { fA.g[i] = fB.g[i]; fA.xy[i] = fB.xy[i]; fA.so[i] = fB.so[i]; fA.yo[i] = fB.yo[i]; }
                     fA.pat = fB.pat;
-                } else {
-                    fA = fB;
+                    ++Tt;
                 }
+                if (Tt >= nTl) break;
+                tile(fA, fB, Tt, std::false_type{});
+                fA = fB;
+                ++Tt;
             }
 #else
             for (int T2 = 0; T2 < nTl; T2 += 2) {
-                tile(fA, fB, T2);
+                tile(fA, fB, T2, std::false_type{});
                 if (T2 + 1 >= nTl) { fA = fB; break; }
-                tile(fB, fA, T2 + 1);
+                tile(fB, fA, T2 + 1, std::false_type{});
             }
 #endif
             w00 = bload4(rs, vo_q, (t > 0 ? t - 1 : 0) * blk_bytes + oCW0);
-            const bool last = (t == 0);
-            const int* prm = PRM + t * Dp;
-            for (int e = lane; e < D * 16; e += 64) {
-                const int r = e >> 4, pp = e & 15;
-                const float v = X[lidx(r, pp)];
-                const int tgt = prm[r];
-                if (!last) Y[lidx(tgt, pp)] = v;
-                else if (row0 + pp < n) out[(row0 + pp) * D + tgt] = v;
+            Ysrc = X;                                      // the next transform reads its y from here, through its offset table
+            spar = (spar + nTl) & 1;
+            if (t == 0) {
+                const int* prm = PRM;                      // rank -> feature of the last transform inverted
+                for (int e = lane; e < D * 16; e += 64) {
+                    const int r = e >> 4, pp = e & 15;
+                    if (row0 + pp < n) out[(row0 + pp) * D + prm[r]] = X[lidx(r, pp)];
+                }
+                __syncthreads();
+                xsel ^= 1;                                 // (xsel names the array of the LAST transform again: the epilogue reads it)
             }
-            if (!last)
-                for (int e = lane; e < (Dp - D) * 16; e += 64) Y[lidx(D + (e >> 4), e & 15)] = 0.0f;
-            __syncthreads();
-            if (last) xsel ^= 1;                           // (xsel names the array of the LAST transform again: the epilogue reads it)
         }
     }
     float* X = xsel ? XB : XA;
