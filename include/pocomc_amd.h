@@ -52,9 +52,9 @@ typedef struct pmc_maf {
 #define PMC_INVERSE_AUTO 0
 #define PMC_INVERSE_TRIANGULAR 1   /* one sweep over the degree groups */
 #define PMC_INVERSE_NAIVE 2        /* the reference's D fixed-point passes (zuko) */
-#define PMC_INVERSE_TRIANGULAR_SOLO 6 /* the D <= 64 sweep, one wavefront per 16 rows (AUTO, flows of < 16 hidden tiles: above 8192 rows) */
+#define PMC_INVERSE_TRIANGULAR_SOLO 6 /* the D <= 64 sweep, one wavefront per 16 rows: the left-looking cross-check of the two-wave sweeps (affine and spline flows) */
 #define PMC_INVERSE_TRIANGULAR_LANE 8 /* lane-per-walker chain wavefront + three or four helper wavefronts per 16-64 rows (AUTO: affine flows with >= 16 hidden tiles or D > 64) */
-#define PMC_INVERSE_TRIANGULAR_DUO 7  /* the same sweep with a second, burst wavefront per 16 rows (AUTO, flows of < 16 hidden tiles: up to 8192 rows) */
+#define PMC_INVERSE_TRIANGULAR_DUO 7  /* the same sweep with a second, burst wavefront per 16 rows, right-looking (AUTO: affine flows of < 16 hidden tiles, spline flows with D <= 64) */
 
 /* packed[i] = idx[i] >= 0 ? flat[idx[i]] : 0   (canonical fp32 params -> kernel layout) */
 int pmc_maf_pack(const float* flat, const int32_t* pack_idx, float* packed, int64_t n_packed, void* stream);

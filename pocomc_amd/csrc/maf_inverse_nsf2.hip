@@ -32,8 +32,9 @@
 #define NSF2_STAGE_FLOATS (3 * 256)                 // hidden staging S0 | S1 | S2 (transposed, [lane][4])
 #define NSF2_PART_FLOATS (4 * 2 * 256)              // output staging [group][half][lane][4]
 #define NSF2_TT_WORDS(m) (((m)->nT + 2) * 8)        // per-tile table: ranks (word 0 also the pattern), x / y byte offsets
+#define NSF2_YT_WORDS(m) ((m)->T * (((m)->nT + 2) * 4 + 1))   // per transform: the y offsets of every tile's groups, of rank 0
 #define NSF2_LDS_FLOATS(m) (3 * (m)->Dp * 16 + 3 * (m)->Hp * 16 + 2 * NSF2_STAGE_FLOATS + 2 * NSF2_PART_FLOATS + 16 * 32 + 16 * 24 + \
-                            ((NSF2_TT_WORDS(m) + (m)->T * (m)->Dp + 3) & ~3))
+                            ((NSF2_TT_WORDS(m) + (m)->Dp + NSF2_YT_WORDS(m) + 3) & ~3))
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
@@ -49,7 +50,7 @@ struct NsfHid {
     float4 wn1, wn2;               // block (Tt + 1, Tt), transposed
     float4 w0o[4];                 // [group].jt: W0[row q of quad jt of this tile][the rank the group produces]
     float4 w0N[4];                 // the same against the next tile's quads
-    int g[4], xy[4], pat;
+    int g[4], xy[4], yo[4], pat;   // ranks of the groups, byte offsets of their x word and of their y word in the input array (walker 0), quad pattern
 };
 // a rank's two output tiles against the previous (fp) and the own (fc) hidden tile, natural fragments
 struct NsfOut { float4 fp0, fp1, fc0, fc1; };
@@ -143,7 +144,7 @@ __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (
             CHAIN_FENCE();
             NSF_STAMP(3)
             // ---------------------------------------------------------------- every lane gets its row's 23 values; spline
-            const float yv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Y) + (p << 4) + f.xy[I]);
+            const float yv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Y) + (p << 4) + f.yo[I]);
             float xg, l;
             if (NSF2_ABL & 1) {
                 float* pr = PAR + (p << 5) + (q << 2);
@@ -354,6 +355,8 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
     float* TAB = PAR + 16 * 32;                // [16 rows][24]: knot tables (rqs_inverse_coop)
     int* DGT = reinterpret_cast<int*>(TAB + 16 * 24);
     int* PRM = DGT + NSF2_TT_WORDS(&m);
+    int* YT = PRM + Dp;
+    int* Y0T = YT + T * (nT + 2) * 4;
     const int* feat_of_rank = m.meta + 8;
     const int* rank_of_feat = m.meta + 8 + T * D;
     const int* quad_meta = m.meta + 8 + 2 * T * D;
@@ -407,10 +410,32 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
         const int gg = g < D ? g : 0;
         DGT[e] = k < 4 ? (g | (i == 0 ? pat << 16 : 0)) : 4 * (((gg >> 4) << 8) + ((gg & 3) << 6) + ((gg >> 2) & 3));
     }
-    for (int e = threadIdx.x; e < T * D; e += 128) {
-        const int tt = e / D, r = e - tt * D;
-        const int feat = feat_of_rank[tt * D + r];
-        PRM[tt * Dp + r] = tt > 0 ? rank_of_feat[(tt - 1) * D + feat] : feat;
+    for (int r = threadIdx.x; r < D; r += 128) PRM[r] = feat_of_rank[r];     // (the last transform's x is stored by feature)
+    // No re-ranking between transforms: transform t reads its input y where the transform before it (t + 1) left it --
+    // YT[t][tile][group]: byte offset (walker 0) of the y word of the rank the group produces in the x array of transform
+    // t + 1 (by ITS ranks), or in Y for the first transform; Y0T[t]: the same for rank 0.
+    {
+        auto woff = [](const int r) { return 4 * (((r >> 4) << 8) + ((r & 3) << 6) + ((r >> 2) & 3)); };
+        auto src_rank = [&](const int tt, const int g) {
+            if (g >= D) return 0;
+            return tt == T - 1 ? g : rank_of_feat[(tt + 1) * D + feat_of_rank[tt * D + g]];
+        };
+        for (int e = threadIdx.x; e < T * (nT + 2) * 4; e += 128) {
+            const int tt = e / ((nT + 2) * 4), rem = e - tt * (nT + 2) * 4, tile = rem >> 2, i = rem & 3;
+            // (the group's rank, recomputed as the table above does: the table itself is being written by other threads)
+            int g = D;
+            if (tile < nT) {
+                int4 dg = *reinterpret_cast<const int4*>(quad_meta + 4 * tile);
+                dg.x &= 0xffff; dg.y &= 0xffff; dg.z &= 0xffff; dg.w &= 0xffff;
+                const bool ny = dg.y != dg.x, nz = dg.z != dg.y, nw = dg.w != dg.z;
+                const int g1 = ny ? dg.y : (nz ? dg.z : (nw ? dg.w : D));
+                const int g2 = ny ? (nz ? dg.z : (nw ? dg.w : D)) : ((nz && nw) ? dg.w : D);
+                const int g3 = (ny && nz && nw) ? dg.w : D;
+                g = i == 0 ? dg.x : (i == 1 ? g1 : (i == 2 ? g2 : g3));
+            }
+            YT[e] = woff(src_rank(tt, g));
+        }
+        for (int tt = threadIdx.x; tt < T; tt += 128) Y0T[tt] = woff(src_rank(tt, 0));
     }
     {   // x arrays, activations (their padding slots are read against zero weights) and staging start zeroed
         float4* z4 = reinterpret_cast<float4*>(XA);
@@ -432,7 +457,10 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
     int xsel = 0;
     __syncthreads();
 
-    auto take_table = [&](NsfHid& F, const int U) {
+    auto take_table = [&](NsfHid& F, const int tt, const int U) {
+        const int4 ty = *reinterpret_cast<const int4*>(YT + (tt * (nT + 2) + U) * 4);
+        F.yo[0] = __builtin_amdgcn_readfirstlane(ty.x); F.yo[1] = __builtin_amdgcn_readfirstlane(ty.y);
+        F.yo[2] = __builtin_amdgcn_readfirstlane(ty.z); F.yo[3] = __builtin_amdgcn_readfirstlane(ty.w);
         const int4 tg = *reinterpret_cast<const int4*>(DGT + 8 * U);
         const int4 txy = *reinterpret_cast<const int4*>(DGT + 8 * U + 4);
         F.g[0] = __builtin_amdgcn_readfirstlane(tg.x & 0xffff); F.g[1] = __builtin_amdgcn_readfirstlane(tg.y);
@@ -467,22 +495,32 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
         bc.nT = nT; bc.nXT = nXT; bc.D = D; bc.lane = lane; bc.vo_lane = vo_lane; bc.vo_T = vo_T; bc.vo_q = vo_q;
         bc.H0 = H0; bc.H1 = H1; bc.H2 = H2;
         NsfBurstCarry carry;
-        if (static_tiles) {
-            const int g0n = __builtin_amdgcn_readfirstlane(DGT[0]) & 0xffff;
-            carry.b0 = nbload4(rs, vo_q, (T - 1) * blk_bytes + oB3I + g0n * 128);
-            carry.b1 = nbload4(rs, vo_q, (T - 1) * blk_bytes + oB3I + g0n * 128 + 64);
-        } else {
+        if (!static_tiles) {
             NB_FETCH((T - 1) * blk_bytes, 0, sA.p1, sA.p2, sA.xf, sA.b0, sA.b1, sA.b2)
         }
+        // (what the x array holds on entry -- zeros, or the x of two transforms ago -- meets zero weights only: the layer-0
+        //  fragments f0c carry the columns of the ranks that are final; the other array is the chain's y)
+        int spar = 0;                                      // staging parity of the transform's first tile (the buffers alternate across transforms)
+        // the static path's first tile of transform tt (biases only): staged while the chain still runs the LAST tile of the
+        // transform before, so that at a transform boundary the chain solves rank 0 and goes on
+        auto first_tile = [&](const int tt, float* Xt, const int par) {
+            const int4 tg = *reinterpret_cast<const int4*>(DGT);
+            const int g0n = __builtin_amdgcn_readfirstlane(tg.x & 0xffff);
+            carry.b0 = nbload4(rs, vo_q, tt * blk_bytes + oB3I + g0n * 128);
+            carry.b1 = nbload4(rs, vo_q, tt * blk_bytes + oB3I + g0n * 128 + 64);
+            bc.tb = tt * blk_bytes; bc.X = Xt;
+            bc.g[0] = g0n; bc.g[1] = __builtin_amdgcn_readfirstlane(tg.y);
+            bc.g[2] = __builtin_amdgcn_readfirstlane(tg.z); bc.g[3] = __builtin_amdgcn_readfirstlane(tg.w);
+            bc.gn = 1 < nTl ? (__builtin_amdgcn_readfirstlane(DGT[8]) & 0xffff) : D;
+            bc.stg = STG + (par & 1) * NSF2_STAGE_FLOATS;
+            bc.part = PART + (par & 1) * NSF2_PART_FLOATS;
+            nsf_burst_tile<0>(bc, carry);
+        };
+        if (static_tiles) first_tile(T - 1, XA, 0);
         for (int t = T - 1; t >= 0; --t) {
             const int tb = t * blk_bytes;
-            float* X = xsel ? XB : XA;                     // zero on entry
-            float* Xidle = xsel ? XA : XB;
+            float* X = xsel ? XB : XA;
             xsel ^= 1;
-            if (t != T - 1) {
-                float4* z4 = reinterpret_cast<float4*>(Xidle);
-                for (int e = lane; e < (Dp * 16) >> 2; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
 #define NB_K(NK, P1, P2, AA1, AA2)                                                                                \
             _Pragma("unroll") for (int i_ = 0; i_ < NSF2_PK; ++i_) {                                              \
                 if (i_ < (NK)) {                                                                                  \
@@ -513,11 +551,11 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                         a0 = MFMA(XF[i_].z, b.z, a0); a0 = MFMA(XF[i_].w, b.w, a0);                               \
                     }                                                                                             \
                 }                                                                                                 \
-                float* st_ = STG + (T1 & 1) * NSF2_STAGE_FLOATS;                                                  \
+                float* st_ = STG + ((T1 + spar) & 1) * NSF2_STAGE_FLOATS;                                         \
                 *reinterpret_cast<float4*>(st_ + (lane << 2)) = make_float4(a0[0], a0[1], a0[2], a0[3]);          \
                 *reinterpret_cast<float4*>(st_ + 256 + (lane << 2)) = make_float4(a1[0], a1[1], a1[2], a1[3]);    \
                 *reinterpret_cast<float4*>(st_ + 512 + (lane << 2)) = make_float4(a2[0], a2[1], a2[2], a2[3]);    \
-                float* pt_ = PART + (T1 & 1) * NSF2_PART_FLOATS;                                                  \
+                float* pt_ = PART + ((T1 + spar) & 1) * NSF2_PART_FLOATS;                                         \
                 const int f3_ = tb + oF3I, b3_ = tb + oB3I;                                                       \
                 nsf_out_partials_wide(rs, f3_, b3_, nT, D, nK, g0_, H2, pt_, lane, vo_lane, vo_q);                \
                 nsf_out_partials_wide(rs, f3_, b3_, nT, D, nK, g1_, H2, pt_ + 512, lane, vo_lane, vo_q);          \
@@ -526,27 +564,24 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                 lds_bar();                                                /* E(T1 - 1) */                         \
             }
             if (static_tiles) {
+                lds_bar();                                                // E(-1): the chain solved rank 0
                 bc.tb = tb; bc.X = X;
-                for (int T1 = 0; T1 < nTl; ++T1) {
+                for (int T1 = 1; T1 < nTl; ++T1) {
                     const int4 tg = *reinterpret_cast<const int4*>(DGT + 8 * T1);
                     bc.g[0] = __builtin_amdgcn_readfirstlane(tg.x & 0xffff); bc.g[1] = __builtin_amdgcn_readfirstlane(tg.y);
                     bc.g[2] = __builtin_amdgcn_readfirstlane(tg.z); bc.g[3] = __builtin_amdgcn_readfirstlane(tg.w);
                     bc.gn = T1 + 1 < nTl ? (__builtin_amdgcn_readfirstlane(DGT[8 * (T1 + 1)]) & 0xffff) : D;
-                    bc.stg = STG + (T1 & 1) * NSF2_STAGE_FLOATS;
-                    bc.part = PART + (T1 & 1) * NSF2_PART_FLOATS;
+                    bc.stg = STG + ((T1 + spar) & 1) * NSF2_STAGE_FLOATS;
+                    bc.part = PART + ((T1 + spar) & 1) * NSF2_PART_FLOATS;
                     switch (T1) {
 #define CASE(K) case K: nsf_burst_tile<K>(bc, carry); break;
-                        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+                        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
 #undef CASE
                         default: break;
                     }
                     lds_bar();                                            // E(T1 - 1)
                 }
-                {   // the next transform's first tile has no final tile behind it: the bias rows of its first rank
-                    const int tbn = (t > 0 ? t - 1 : 0) * blk_bytes, g0n = __builtin_amdgcn_readfirstlane(DGT[0]) & 0xffff;
-                    carry.b0 = nbload4(rs, vo_q, tbn + oB3I + g0n * 128);
-                    carry.b1 = nbload4(rs, vo_q, tbn + oB3I + g0n * 128 + 64);
-                }
+                if (t > 0) first_tile(t - 1, xsel ? XB : XA, spar + nTl);     // (the next transform's x array and parity)
             } else {
                 for (int T2 = 0; T2 < nTl; T2 += 2) {
                     NB_TILE(T2, sA.p1, sA.p2, sA.xf, sA.b0, sA.b1, sA.b2, sB.p1, sB.p2, sB.xf, sB.b0, sB.b1, sB.b2)
@@ -557,7 +592,8 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                 NB_FETCH(tbn, 0, sA.p1, sA.p2, sA.xf, sA.b0, sA.b1, sA.b2)
             }
             lds_bar();                                                    // E(nTl - 1)
-            __syncthreads();                                              // (the chain re-ranked x)
+            spar = (spar + nTl) & 1;
+            if (t == 0) __syncthreads();                                  // (the chain stored the result)
         }
 #undef NB_TILE
 #undef NB_K
@@ -593,19 +629,22 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
             else if constexpr (K == 2) O.fc0 = nbload4(rs, vc, so + Kc * 1024);
             else O.fc1 = nbload4(rs, vc, so + (nT + Kc) * 1024);
         };
-        take_table(fA, 0);
+        take_table(fA, T - 1, 0);
         fA.w0o[3] = fB.w0o[3] = make_float4(0.f, 0.f, 0.f, 0.f);          // (the fourth group has no later quad)
         nsf_for<11>([&](auto k_) { request_hid(fA, k_, T - 1, 0); });
         nsf_for<4>([&](auto k_) { request_out(ob[0], k_, T - 1, fA.g[0], -1, 0); });
         float4 w00 = nbload4(rs, vo_q, (T - 1) * blk_bytes + oCW0);      // layer 0, first tile: the column of rank 0
         float4 r00 = nbload4(rs, vo_q, (T - 1) * blk_bytes + oB3I), r01 = nbload4(rs, vo_q, (T - 1) * blk_bytes + oB3I + 64);
+        const float* Ysrc = Y;                             // the input of the transform: Y, then the previous transform's x array
+        int spar = 0;
         for (int t = T - 1; t >= 0; --t) {
-            float* X = xsel ? XB : XA;                     // zero on entry
+            float* X = xsel ? XB : XA;
             xsel ^= 1;
             NsfChain s;
             {   // rank 0 reads nothing: bias only
                 float xv, l;
-                rqs_inverse_split(as_acc(r00), as_acc(r01), PAR + (p << 5), q, Y[lidx(0, p)], xv, l);
+                const float y0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Ysrc) + (p << 4) + Y0T[t]);
+                rqs_inverse_split(as_acc(r00), as_acc(r01), PAR + (p << 5), q, y0, xv, l);
                 if (q == 0) X[lidx(0, p)] = xv;
                 ladj -= l;
                 WAVE_LDS_FENCE();
@@ -621,8 +660,8 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                 if (pf) pf[15] = clock64();
                 NsfHid& cur = fA;
                 NsfHid& nxt = fB;
-                const float* st = STG + (Tt & 1) * NSF2_STAGE_FLOATS;
-                const float* part = PART + (Tt & 1) * NSF2_PART_FLOATS;
+                const float* st = STG + ((Tt + spar) & 1) * NSF2_STAGE_FLOATS;
+                const float* part = PART + ((Tt + spar) & 1) * NSF2_PART_FLOATS;
                 const float4 s0 = *reinterpret_cast<const float4*>(st + (lane << 2));
                 const float4 s1 = *reinterpret_cast<const float4*>(st + 256 + (lane << 2));
                 const float4 s2 = *reinterpret_cast<const float4*>(st + 512 + (lane << 2));
@@ -637,7 +676,7 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                 // what follows this tile: the next live tile, or the first tile of the next transform
                 const bool more = Tt + 1 < nTl;
                 const int ntt = more ? t : (t > 0 ? t - 1 : 0), nU = more ? Tt + 1 : 0;
-                take_table(nxt, nU);
+                take_table(nxt, ntt, nU);
                 // the shadows of a group's MFMAs (slot 0..3: behind the pairs of previous-tile output products; 4, 5: behind the
                 // hidden hops): the next group's output fragments -- a later group of this tile, or the next tile's first -- and
                 // this group's share of the next tile's hidden operands
@@ -657,7 +696,7 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                     }
                 };
                 switch (pat) {
-#define CASE(P) case P: nsf_group<P, 0>(s, cur, ob, part, X, Y, PAR, TAB, D, q, p, lane, ladj, ahead, pf); break;
+#define CASE(P) case P: nsf_group<P, 0>(s, cur, ob, part, X, Ysrc, PAR, TAB, D, q, p, lane, ladj, ahead, pf); break;
                     CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
 #undef CASE
                     default: break;
@@ -679,16 +718,15 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
             w00 = nbload4(rs, vo_q, (t > 0 ? t - 1 : 0) * blk_bytes + oCW0);
             r00 = nbload4(rs, vo_q, (t > 0 ? t - 1 : 0) * blk_bytes + oB3I);
             r01 = nbload4(rs, vo_q, (t > 0 ? t - 1 : 0) * blk_bytes + oB3I + 64);
-            const bool last = (t == 0);
-            const int* prm = PRM + t * Dp;
-            for (int e = lane; e < D * 16; e += 64) {
-                const int r = e >> 4, pp = e & 15;
-                const float v = X[lidx(r, pp)];
-                const int tgt = prm[r];
-                if (!last) Y[lidx(tgt, pp)] = v;
-                else if (row0 + pp < n) out[(row0 + pp) * D + tgt] = v;
+            Ysrc = X;                                      // the next transform reads its y from here, through its offset table
+            spar = (spar + nTl) & 1;
+            if (t == 0) {
+                for (int e = lane; e < D * 16; e += 64) {
+                    const int r = e >> 4, pp = e & 15;
+                    if (row0 + pp < n) out[(row0 + pp) * D + PRM[r]] = X[lidx(r, pp)];
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
         if (ladj_out && lane < 16 && row0 + p < n) ladj_out[row0 + p] = ladj;
         if (pf && lane == 0) for (int i = 0; i < 16; ++i) prof[i] = pfv[i];
