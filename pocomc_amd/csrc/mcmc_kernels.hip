@@ -176,9 +176,10 @@ __global__ __launch_bounds__(SCL_THREADS) void scaler_inverse_kernel(
         }
     }
     if (done_flag) {
-        // completion word in pinned host memory: every block makes its own stores visible system-wide, draws
-        // a ticket; the last one publishes done_value (the host spins on it instead of going through the runtime)
-        __threadfence_system();
+        // completion word in pinned host memory: every thread waits for the acknowledgement of its stores (agent-scope
+        // release; see scaler_body.h), the block draws a ticket, the last one publishes done_value with a system-scope
+        // release (the host spins on it instead of going through the runtime)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         if (tid == 0) {
             const unsigned t = __hip_atomic_fetch_add(done_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);

@@ -210,7 +210,13 @@ __device__ __forceinline__ void scaler_epilogue_rows(const ScalerEpi& e, const d
         }
     }
     if (e.done_flag) {
-        __threadfence_system();
+        // Every thread waits for the acknowledgement of its own stores (agent-scope release: pinned host memory is not
+        // cached on the device, so there is nothing to write back), the workgroup draws a ticket (agent-scope acq_rel), the
+        // last one publishes the word with a system-scope release.  A __threadfence_system() here made every one of the ~400
+        // workgroups write back and invalidate the whole L2: 12 us of the launch (timing-only builds of this file), 6 us in
+        // scripts/micro/pcie_store.hip, which also checks that the host never sees the word before the data (0 stale words
+        // in 8000 launches x 208 k words with either fence).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         if (tid == 0) {
             const unsigned t = __hip_atomic_fetch_add(e.done_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
