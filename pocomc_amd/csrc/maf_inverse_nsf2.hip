@@ -33,7 +33,7 @@
 #define NSF2_PART_FLOATS (4 * 2 * 256)              // output staging [group][half][lane][4]
 #define NSF2_TT_WORDS(m) (((m)->nT + 2) * 8)        // per-tile table: ranks (word 0 also the pattern), x / y byte offsets
 #define NSF2_YT_WORDS(m) ((m)->T * (((m)->nT + 2) * 4 + 1))   // per transform: the y offsets of every tile's groups, of rank 0
-#define NSF2_LDS_FLOATS(m) (3 * (m)->Dp * 16 + 3 * (m)->Hp * 16 + 2 * NSF2_STAGE_FLOATS + 2 * NSF2_PART_FLOATS + 16 * 32 + 16 * 24 + \
+#define NSF2_LDS_FLOATS(m) (3 * (m)->Dp * 16 + 3 * (m)->Hp * 16 + 2 * NSF2_STAGE_FLOATS + 2 * NSF2_PART_FLOATS + 16 * 32 + \
                             ((NSF2_TT_WORDS(m) + (m)->Dp + NSF2_YT_WORDS(m) + 3) & ~3))
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -73,7 +73,7 @@ __device__ __forceinline__ void nsf_for(F&& f) {
 //   else the caller wants in flight).
 template <int PAT, int I, class AH>
 __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (&ob)[2], const float* part, float* X, const float* Y,
-                                          float* PAR, float* TAB, int D, int q, int p, int lane, float& ladj, const AH& ahead,
+                                          float* PAR, int D, int q, int p, int lane, float& ladj, const AH& ahead,
                                           long long* pf = nullptr) {
 #define NSF_STAMP(K) if (pf) { const long long now_ = clock64(); pf[K] += now_ - pf[15]; pf[15] = now_; }
     constexpr int NG = pat_ngroups(PAT);
@@ -166,7 +166,7 @@ __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (
             s.a0N[2] = fmaf(f.w0N[I].z, xg, s.a0N[2]); s.a0N[3] = fmaf(f.w0N[I].w, xg, s.a0N[3]);
             CHAIN_FENCE();
             NSF_STAMP(5)
-            nsf_group<PAT, I + 1, AH>(s, f, ob, part, X, Y, PAR, TAB, D, q, p, lane, ladj, ahead, pf);
+            nsf_group<PAT, I + 1, AH>(s, f, ob, part, X, Y, PAR, D, q, p, lane, ladj, ahead, pf);
         }
     }
 }
@@ -351,9 +351,8 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
     float* H2 = H1 + Hp * 16;
     float* STG = H2 + Hp * 16;                 // two hidden staging buffers (tile parity)
     float* PART = STG + 2 * NSF2_STAGE_FLOATS; // two output staging buffers (tile parity)
-    float* PAR = PART + 2 * NSF2_PART_FLOATS;  // [16 rows][32]: the 23 spline parameters of the current rank
-    float* TAB = PAR + 16 * 32;                // [16 rows][24]: knot tables (rqs_inverse_coop)
-    int* DGT = reinterpret_cast<int*>(TAB + 16 * 24);
+    float* PAR = PART + 2 * NSF2_PART_FLOATS;  // [16 rows][32]: the exchange panel of the current rank (rqs_inverse_split)
+    int* DGT = reinterpret_cast<int*>(PAR + 16 * 32);
     int* PRM = DGT + NSF2_TT_WORDS(&m);
     int* YT = PRM + Dp;
     int* Y0T = YT + T * (nT + 2) * 4;
@@ -696,7 +695,7 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                     }
                 };
                 switch (pat) {
-#define CASE(P) case P: nsf_group<P, 0>(s, cur, ob, part, X, Ysrc, PAR, TAB, D, q, p, lane, ladj, ahead, pf); break;
+#define CASE(P) case P: nsf_group<P, 0>(s, cur, ob, part, X, Ysrc, PAR, D, q, p, lane, ladj, ahead, pf); break;
                     CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
 #undef CASE
                     default: break;

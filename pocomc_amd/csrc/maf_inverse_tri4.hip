@@ -18,7 +18,7 @@
 // + the two-wave sweep's permutation / rank-0 tables and its second x array (with alignment slack)
 #define TRI5_TT_WORDS(m) (((m)->nT + 2) * 16)  // the two-wave sweep's per-tile table (16 words per hidden tile, two rows of "no groups" behind)
 #define TRI5_YT_WORDS(m) ((m)->T * (((m)->nT + 2) * 4 + 1))   // per transform: the y offsets of every tile's groups, of rank 0
-#define TRI5_TABLE_WORDS(m) (((TRI5_TT_WORDS(m) + (m)->T * (m)->Dp + 2 * (m)->T + 3) & ~3) + (m)->Dp * 16 + ((TRI5_YT_WORDS(m) + 3) & ~3))
+#define TRI5_TABLE_WORDS(m) (((TRI5_TT_WORDS(m) + (m)->Dp + 2 * (m)->T + 3) & ~3) + (m)->Dp * 16 + ((TRI5_YT_WORDS(m) + 3) & ~3))
 #define TRI5_LDS_FLOATS(m, maxo) (2 * (m)->Dp * 16 + 2 * (m)->Hp * 16 + 2 * 256 + 2 * (3 + (maxo)) * 256 + TRI5_TABLE_WORDS(m))
 #include "propose_body.h"
 
@@ -511,6 +511,9 @@ int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* 
 // One LDS-only barrier per tile: E(Tt) = "tile Tt is final, the staging of tile Tt+1 is complete".
 // The chain's fragments of tile Tt+1 (16 loads) are requested in the shadows of tile Tt's hops into the other of two
 // register set (copied over at the tile boundary), across transform boundaries too.
+// Between transforms nothing is re-ranked: transform t reads its y through a per-transform offset table from the x array
+// of transform t + 1 (the two x arrays alternate), and the first tile of a transform -- biases only -- is staged while the
+// chain still runs the last tile of the transform before ("Transform boundaries").
 // Residency: a workgroup lives on one CU (4 SIMDs, one such wave each): 512 walker sets at a time; the launcher
 // splits larger calls into rounds of this kernel (two rounds still beat the lone wave's one: DESIGN.md section 4).
 // ============================================================================================================
@@ -518,9 +521,6 @@ int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* 
 #ifndef TRI5_ABL
 #define TRI5_ABL 0                 // timing experiments only (scripts/abl_tri5.sh): results are wrong when != 0
 #endif
-#ifndef TRI5_ONE_BODY
-#define TRI5_ONE_BODY 1            // one tile body + a register copy of the operand set per tile (55.9 us at 7008 walkers) instead of two
-#endif                             // bodies with the sets swapping roles (58.5 us: twice the code, and the second copy allocates worse)
 #define PXB 4                      // x tiles of the layer-0 product held in registers (D <= 64)
 #define TRI5_STAGE_FLOATS(MO) ((3 + (MO)) * 256)                 // one staging buffer: S0 | S1 | S2 (transposed, [lane][4]) | SO[MO] (natural)
 #define TRI5_SET_FLOATS(Dp, Hp, MO) (2 * (Dp) * 16 + 2 * (Hp) * 16 + 2 * 256 + 2 * TRI5_STAGE_FLOATS(MO))
@@ -578,13 +578,12 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     // byte offset of the rank's x / y word, of its (shift, raw) pair in a staged output tile, of its two rows in an
     // output fragment record (out of range for a padding group: the bounds-checked load returns zeros).
     int* DGT = reinterpret_cast<int*>(smem + TRI5_SET_FLOATS(Dp, Hp, MAXO));
-    // between two transforms the chain wave re-ranks its x and starts the next sweep with rank 0: the indices and the two
-    // constants it needs come from LDS tables filled once -- PRM[t][r]: where rank r of transform t goes (rank of
-    // transform t - 1, or the feature for t = 0), B3T[t]: (shift, raw log-scale) of rank 0.  x alternates between two
-    // arrays; the burst wave zeroes the idle one.
+    // between two transforms the chain wave starts the next sweep with rank 0; the constants it needs come from LDS tables
+    // filled once -- B3T[t]: (shift, raw log-scale) of rank 0; PRM[r]: the feature of rank r of the last transform (whose x
+    // is stored by feature).  x alternates between two arrays.
     int* PRM = DGT + TRI5_TT_WORDS(&m);
-    float* B3T = reinterpret_cast<float*>(PRM + T * Dp);
-    float* XB = reinterpret_cast<float*>(DGT + ((TRI5_TT_WORDS(&m) + T * Dp + 2 * T + 3) & ~3));      // (16-byte aligned)
+    float* B3T = reinterpret_cast<float*>(PRM + Dp);
+    float* XB = reinterpret_cast<float*>(DGT + ((TRI5_TT_WORDS(&m) + Dp + 2 * T + 3) & ~3));      // (16-byte aligned)
     // No re-ranking between transforms: transform t reads its input y where the previous transform (t + 1) left it --
     // YT[t][tile][group]: byte offset (walker 0) of the y word of the rank the group produces, in the x array of transform
     // t + 1 (by ITS ranks), or in Y for the first transform; Y0T[t]: the same for rank 0.
@@ -696,11 +695,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     }
     if (pa.prof && lane == 0 && blockIdx.x < 64)         // (measurement only: which SIMD / CU every wavefront landed on)
         pa.prof[(size_t)T * nT * 8 + blockIdx.x * 2 + wv] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-    for (int e = threadIdx.x; e < T * D; e += 64 * (TRI5_NC + 1)) {
-        const int tt = e / D, r = e - tt * D;
-        const int feat = feat_of_rank[tt * D + r];
-        PRM[tt * Dp + r] = tt > 0 ? rank_of_feat[(tt - 1) * D + feat] : feat;
-    }
+    for (int r = threadIdx.x; r < D; r += 64 * (TRI5_NC + 1)) PRM[r] = feat_of_rank[r];      // (the last transform's x is stored by feature)
     for (int tt = threadIdx.x; tt < T; tt += 64 * (TRI5_NC + 1)) {
         const float* b3 = m.packed + (size_t)tt * m.pk_per_transform + (oB3 >> 2);
         B3T[2 * tt] = b3[0];
@@ -924,7 +919,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                     auto into = [&](ChainFrags<MAXO>& F, auto k_) { request(F, k_, ntt, nU, gU, gV); };
                     using std::integral_constant;
                     if constexpr ((TRI5_ABL & 0x100) != 0) {
-                    } else if constexpr (FAST && NG_ == 4 && TRI5_ONE_BODY) {
+                    } else if constexpr (FAST && NG_ == 4) {
                         // the common tile: the layer-0 window columns of a group die with the group, so the next tile's go
                         // straight into the CURRENT set once it has run; only what lives to the tile's end is buffered
                         // (and copied over at the boundary: 7 of 13 operands)
@@ -958,9 +953,8 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                 lds_bar();                                            // E(Tt): this tile is final
                 if (pf && lane == 0) pf[3] = clock64();
             };
-            // (two copies of the tile body, the operand sets swapping roles; a transform with an odd number of tiles leaves
-            //  the next transform's first operands in the second set: moved over once)
-#if TRI5_ONE_BODY
+            // One tile body; the next tile's operands arrive in the second set and are moved over at the boundary (two bodies
+            // with the sets swapping roles were slower: twice the code, and the second copy allocated worse).
             // Runs of common tiles are a loop of their own: a tile body that joins the other patterns' bodies pays for it
             // with ~45 register copies per join (every register a body updates becomes a conditional assignment), per tile.
             for (int Tt = 0; Tt < nTl;) {
@@ -979,13 +973,6 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
                 fA = fB;
                 ++Tt;
             }
-#else
-            for (int T2 = 0; T2 < nTl; T2 += 2) {
-                tile(fA, fB, T2, std::false_type{});
-                if (T2 + 1 >= nTl) { fA = fB; break; }
-                tile(fB, fA, T2 + 1, std::false_type{});
-            }
-#endif
             w00 = bload4(rs, vo_q, (t > 0 ? t - 1 : 0) * blk_bytes + oCW0);
             Ysrc = X;                                      // the next transform reads its y from here, through its offset table
             spar = (spar + nTl) & 1;
