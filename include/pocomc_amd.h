@@ -275,7 +275,12 @@ int pmc_prior_logpdf(const pmc_prior_t* pr, const double* x, const int32_t* fini
 
 /* Completion word of a kernel in pinned host memory: the last workgroup to finish stores `value` to `*flag`
  * after every workgroup's results are visible system-wide; the host then spins on the word (pmc_wait_flag)
- * instead of waking up through the runtime's stream / event synchronisation (~10-20 us per wait). */
+ * instead of waking up through the runtime's stream / event synchronisation (~10-20 us per wait).
+ * Ordering: every workgroup waits for the acknowledgement of its own stores (agent-scope release), draws a
+ * ticket (agent-scope acq_rel); the last one stores the word with a system-scope release.  The results the
+ * host reads behind the word must therefore live in memory the device does not cache -- pinned (coherent,
+ * fine-grained) host memory, as hipHostMalloc returns it by default; the host reads the word with acquire
+ * semantics (pmc_wait_flag does). */
 typedef struct pmc_done {
     int64_t* flag;            /* pinned, device-accessible host memory */
     int64_t value;

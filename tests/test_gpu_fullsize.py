@@ -178,6 +178,43 @@ def test_pipelined_two_lane_steps_equal_whole_set_steps_at_full_size():
     assert 0.3 < moved.mean() < 1.0
 
 
+@pytest.mark.parametrize("name", ["maf3", "nsf3"])
+def test_the_host_never_reads_behind_the_completion_word_at_full_size(name):
+    """The pipelined kernel call hands x', the finite mask and logp' to the host through pinned memory behind completion
+    words (every workgroup waits for the acknowledgement of its stores -- agent scope --, the last one publishes the word
+    with a system-scope release: ``scaler_body.h``).  120 steps of 1e4 x 32 walkers as two row ranges against the same call
+    with ``host_direct=False`` (stream-ordered copies, runtime synchronisation): one stale word of x' read by the likelihood
+    changes a log-likelihood, then an accept decision, then everything after it -- the results are the same bit for bit."""
+    from scipy.stats import uniform
+    import pocomc_amd as pc
+    from pocomc_amd import mcmc as pmcmc
+    from pocomc_amd.geometry import Geometry
+    D, N = 32, N_FULL
+    prior = pc.Prior([uniform(-10, 20)] * D)
+    rng = np.random.default_rng(5)
+    scaler = pc.Reparameterize(D, bounds=prior.bounds)
+    scaler.fit(rng.uniform(-10, 10, size=(4000, D)))
+    x = rng.uniform(-9, 9, size=(N, D))
+    u = scaler.forward(x)
+    wts = np.linspace(0.5, 1.5, D)
+    like = lambda xx: (-0.5 * np.sum(wts * (xx / 3.0) ** 2, axis=1), None)     # (every coordinate of every walker counts)
+    flow = _flow(D, name)
+    geo = Geometry()
+    geo.fit(flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64))
+    res = []
+    for direct in (True, False):
+        state = dict(u=u.copy(), x=x.copy(), logdetj=scaler.inverse(u)[1], logl=like(x)[0], logp=prior.logpdf(x),
+                     beta=0.5, blobs=None)
+        funcs = dict(loglike=like, logprior=prior.logpdf, scaler=scaler, flow=flow, theta_geometry=geo)
+        opts = dict(n_max=120, n_steps=10 ** 6, progress_bar=None, proposal_scale=2.38 / D ** 0.5, seed=7,
+                    device_prior=True, x_order="F", host_direct=direct, lanes=2)
+        res.append(pmcmc.preconditioned_pcn(state, funcs, opts))
+    assert res[0]["steps"] == res[1]["steps"] == 120 and res[0]["accept"] == res[1]["accept"]
+    assert res[0]["calls"] == res[1]["calls"] == 120 * N
+    for k in ("u", "x", "logl", "logp", "logdetj"):
+        assert np.array_equal(res[0][k], res[1][k]), k
+
+
 def test_pool_statistics_trim_and_resample_at_full_size():
     """An 8e4-particle persistent pool (config 4, 8 iterations x 1e4): the mixture log-weights normalise, ESS agrees
     with its definition, trimming keeps >= 99 % of the ESS with weights that sum to one, systematic resampling
