@@ -431,7 +431,9 @@ __global__ __launch_bounds__(256) void accept_kernel(
         if (ad.state && ad.mode) adapt_apply(ad, total, tid, D);
     } else if (ad.state && ad.mode) adapt_apply(ad, sums, tid, D);   // pmc_step_t.adapt_state: the proposal of the next step
     if (done_flag) {
-        __threadfence_system();           // the sums (and every block's state updates) before the completion word
+        // the sums' host copy acknowledged before the completion word (agent-scope release: scaler_body.h says why that
+        // is enough); the state updates are device memory, ordered for the next kernel by the kernel boundary
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
     }
     if (tid == 0) {
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(256) void adapt_update_kernel(AdaptParts parts, int
     __syncthreads();
     if (ad.state && ad.mode) adapt_apply(ad, tot, tid, D);
     if (done_flag) {
-        __threadfence_system();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         if (tid == 0) __hip_atomic_store(done_flag, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

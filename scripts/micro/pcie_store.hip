@@ -11,8 +11,9 @@
 #include <chrono>
 
 // FENCE 0: __threadfence_system() in every workgroup (writes back L2: what the step did until round 3); 1: agent-scope
-// release in every workgroup (a wait for the stores' acknowledgements) -- the completion word itself is a system-scope
-// release store by the last workgroup either way
+// release in every workgroup (a wait for the stores' acknowledgements), the completion word a system-scope release store by
+// the last workgroup (which writes L2 back once); 2: as 1, the word a relaxed system-scope store behind an agent-scope
+// release (no write-back at all: everything the host reads behind the word is in memory the device does not cache)
 template <int FENCE>
 __global__ __launch_bounds__(128) void k(double* host, long long n, int D, int pattern, unsigned* ticket, long long* flag,
                                           long long value, int spin) {
@@ -36,7 +37,12 @@ __global__ __launch_bounds__(128) void k(double* host, long long n, int D, int p
         const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (t == gridDim.x - 1) {
             *ticket = 0;
-            __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (FENCE == 2) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
@@ -50,7 +56,7 @@ int main(int argc, char** argv) {
     *flag = 0;
     const int grid = (int)((n + 15) / 16);
     long long val = 0;
-    for (int fence : {0, 1})
+    for (int fence : {0, 1, 2})
     for (int spin : {0, 100000}) {
         double base = 0;
         for (int pattern : {-1, 0}) {
@@ -61,7 +67,8 @@ int main(int argc, char** argv) {
                 hipDeviceSynchronize();
                 auto t0 = std::chrono::steady_clock::now();
                 if (fence == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(128), 0, 0, host, n, D, pattern, ticket, flag, val, spin);
-                else hipLaunchKernelGGL(k<1>, dim3(grid), dim3(128), 0, 0, host, n, D, pattern, ticket, flag, val, spin);
+                else if (fence == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(128), 0, 0, host, n, D, pattern, ticket, flag, val, spin);
+                else hipLaunchKernelGGL(k<2>, dim3(grid), dim3(128), 0, 0, host, n, D, pattern, ticket, flag, val, spin);
                 while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != val) { }
                 auto t1 = std::chrono::steady_clock::now();
                 // the word is there: is every x' of THIS launch there?  (read at once, before the kernel has ended)
@@ -76,7 +83,7 @@ int main(int argc, char** argv) {
             }
             if (pattern < 0) base = sum / reps;
             printf("fence %s  spin %6d cycles  %-22s launch -> flag: mean %6.1f us  min %6.1f us   (minus the empty kernel: %5.1f us -> %5.1f GB/s)  stale words seen: %lld\n",
-                   fence ? "agent " : "system", spin, pattern < 0 ? "no stores" : "F: 128-byte chunks", sum / reps, best,
+                   fence == 0 ? "system       " : fence == 1 ? "agent        " : "agent,relaxed", spin, pattern < 0 ? "no stores" : "F: 128-byte chunks", sum / reps, best,
                    sum / reps - base, pattern < 0 ? 0.0 : n * D * 8 / (sum / reps - base) * 1e-3, bad);
         }
     }
