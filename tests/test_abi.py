@@ -294,6 +294,132 @@ def test_chain_image_of_the_lane_sweep_reproduces_the_inverse(D, T):
     np.testing.assert_allclose(l, lo, rtol=2e-5, atol=2e-5)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# The spline image of the two-wave spline sweep (MAFSpec.pack_index with univariate="rqs": f3i / b3i and -- new in round 3 --
+# cw0 / f0c / b0t / b1t / b2t), checked on the CPU by walking csrc/maf_inverse_nsf2.hip's decomposition in numpy:
+#   burst wave, a tile ahead:  transposed biases + f0c against the ranks before the previous tile's + f1 / f2 against the
+#                              hidden tiles <= T-2; per rank  b3i + f3i against the h2 tiles <= T-2
+#   chain wave:                the diagonal tile and the block (T+1, T) of f1 / f2 (right-looking share of the next tile),
+#                              the layer-0 window columns cw0, the rank's f3i fragments against the previous tile and the
+#                              own tile's quads so far; padding groups absorbed by the last live group; y read from the
+#                              previous transform's x through the rank permutation (no re-ranking)
+def _nsf2_emulate(spec, flat, z):
+    import numpy as np
+    from oracle.maf import rqs_inverse
+    D, nT, nXT, Hp, Dp, T_ = spec.n_dim, spec.nT, spec.nXT, spec.Hp, spec.Dp, spec.n_transforms
+    idx = spec.pack_index()
+    packed = np.where(idx >= 0, flat[np.maximum(idx, 0)], 0.0).astype(np.float64)
+    lane = np.arange(64)
+    li, lk = lane & 15, lane >> 4
+    ci, ck = lane & 3, lane >> 2
+    n = len(z)
+    tg = spec.tile_groups()
+    live_tiles = int(spec.device_meta()[7])
+    f_o_r = [np.argsort(o) for o in spec.orders]           # feature of rank, per transform
+    tr = (np.arange(Hp) & ~15) + 4 * (np.arange(Hp) & 3) + ((np.arange(Hp) >> 2) & 3)
+    ladj = np.zeros(n)
+    src = None                                              # the previous transform's x, by ITS ranks
+    for t in reversed(range(T_)):
+        P = packed[t * spec.pk_per_transform:(t + 1) * spec.pk_per_transform]
+        po = spec.pk_offsets
+        sec = lambda name, shape: P[po[name]:po[name] + int(np.prod(shape))].reshape(shape)
+
+        def frag_block(f):           # [lane][4] -> dense 16 x 16 block, rows = out slot, cols = in slot
+            B = np.zeros((16, 16))
+            for c in range(4):
+                B[li, 4 * c + lk] = f[:, c]
+            return B
+
+        def window(cw):              # [lane][4 out quads] -> dense 16 (out slot) x 16 (k slot)
+            B = np.zeros((16, 16))
+            for a in range(4):
+                B[4 * a + ci, ck] = cw[:, a]
+            return B
+        f1, f2 = sec("f1", (nT, nT, 64, 4)), sec("f2", (nT, nT, 64, 4))
+        f0c, cw0 = sec("f0c", (nT, nXT, 64, 4)), sec("cw0", (nT, 64, 4))
+        f3i, b3i = sec("f3i", (D, 2, nT, 64, 4)), sec("b3i", (D, 32))
+        bt = [sec(k, (Hp,)) for k in ("b0t", "b1t", "b2t")]
+        for k, name in enumerate(("b0", "b1", "b2")):                       # transposed biases: slot 16T + 4q + r <- unit 16T + 4r + q
+            assert np.array_equal(bt[k], sec(name, (Hp,))[tr])
+        b0, b1, b2 = (sec(k, (Hp,)) for k in ("b0", "b1", "b2"))
+
+        def y_of(g):                 # the input of rank g: Y for the first transform, else the previous x through the permutation
+            if t == T_ - 1:
+                return np.asarray(z, np.float64)[:, f_o_r[t][g]]
+            return src[:, spec.orders[t + 1][f_o_r[t][g]]]
+
+        def params(g, upto_tile, own_quads, H2):
+            """bias + the rank's two private output tiles against h2 tiles < upto_tile (burst), tile upto_tile - 1 ... :
+            here simply everything final plus the own tile's quads so far (the split is checked by the zero pattern below)"""
+            out = b3i[g].copy()[None, :].repeat(n, 0)
+            for half in range(2):
+                for K in range(upto_tile + 1):
+                    B = frag_block(f3i[g, half, K])
+                    cols = np.arange(16) if K < upto_tile else own_quads
+                    out[:, 16 * half:16 * half + 16] += H2[:, 16 * K + cols] @ B[:, cols].T
+                    if K == upto_tile:                                      # what the chain does not add must be exact zeros
+                        later = np.setdiff1d(np.arange(16), own_quads)
+                        assert not B[:, later].any()
+            return out[:, :23]
+
+        x = np.zeros((n, Dp))
+        H0, H1, H2 = (np.zeros((n, Hp)) for _ in range(3))
+        x0, l0 = rqs_inverse(y_of(0), b3i[0][None, :23].repeat(n, 0))
+        x[:, 0] = x0; ladj -= l0
+        a0n = np.outer(x[:, 0], window(cw0[0])[:, 0])                       # rank 0 = k slot 0 of tile 0's window
+        n1 = np.zeros((n, 16)); n2 = np.zeros((n, 16))                      # the previous tile's right-looking share
+        for T in range(live_tiles):
+            own = tg[T]
+            qd = spec.quad_deg[4 * T:4 * T + 4]
+            # burst wave: staging of tile T from what is final two tiles back
+            a0 = b0[16 * T:16 * T + 16] + sum(x[:, 16 * X:16 * X + 16] @ frag_block(f0c[T, X]).T for X in range(nXT)) + a0n
+            p1 = b1[16 * T:16 * T + 16] + sum(H0[:, 16 * K:16 * K + 16] @ frag_block(f1[T, K]).T for K in range(T - 1)) + n1
+            p2 = b2[16 * T:16 * T + 16] + sum(H1[:, 16 * K:16 * K + 16] @ frag_block(f2[T, K]).T for K in range(T - 1)) + n2
+            a0n = np.zeros((n, 16)); n1 = np.zeros((n, 16)); n2 = np.zeros((n, 16))
+            W1d, W2d = frag_block(f1[T, T]), frag_block(f2[T, T])
+            W1n = frag_block(f1[T + 1, T]) if T + 1 < nT else np.zeros((16, 16))
+            W2n = frag_block(f2[T + 1, T]) if T + 1 < nT else np.zeros((16, 16))
+            W0w = window(cw0[T])
+            W0n = window(cw0[T + 1]) if T + 1 < nT else np.zeros((16, 16))
+            done = np.zeros(0, dtype=int)
+            for I, d in enumerate(own):
+                quads = [j for j in range(4) if qd[j] == d]
+                if I == len(own) - 1:                                       # the last live group absorbs the padding quads
+                    quads += [j for j in range(4) if qd[j] >= D]
+                sl_ = np.concatenate([np.arange(4 * j, 4 * j + 4) for j in quads])
+                h0 = np.maximum(a0[:, sl_], 0.0); H0[:, 16 * T + sl_] = h0
+                p1 = p1 + h0 @ W1d[:, sl_].T; n1 = n1 + h0 @ W1n[:, sl_].T
+                h1 = np.maximum(p1[:, sl_] + h0, 0.0); H1[:, 16 * T + sl_] = h1
+                p2 = p2 + h1 @ W2d[:, sl_].T; n2 = n2 + h1 @ W2n[:, sl_].T
+                h2 = np.maximum(p2[:, sl_] + h1, 0.0); H2[:, 16 * T + sl_] = h2
+                done = np.concatenate([done, sl_])
+                phi = params(d, T, done, H2)
+                xg, lg = rqs_inverse(y_of(d), phi)
+                x[:, d] = xg; ladj -= lg
+                a0 = a0 + np.outer(xg, W0w[:, 4 + I])                       # the later quads of this tile
+                a0n = a0n + np.outer(xg, W0n[:, I])                         # the next tile
+        src = x
+    out = np.zeros((n, D))
+    out[:, f_o_r[0]] = src[:, :D]                                           # the last transform's x, by feature
+    return out, ladj
+
+
+@pytest.mark.parametrize("D,T", [(3, 2), (4, 3), (5, 3), (10, 3), (17, 2), (32, 3), (40, 2), (50, 2)])
+def test_spline_image_of_the_two_wave_sweep_reproduces_the_inverse(D, T):
+    import numpy as np
+    from oracle.maf import OracleMAF
+    from pocomc_amd.maf_spec import MAFSpec
+    spec = MAFSpec(D, T, univariate="rqs")
+    if not spec.tri_ok:
+        pytest.skip("degree groups wider than a tile")
+    flat = (spec.init_params(5) * np.float32(1.3)).astype(np.float32)
+    z = (np.random.default_rng(D).normal(size=(10, D)) * 1.5).astype(np.float32)
+    xo, lo = OracleMAF(spec, flat).inverse(z)
+    x, l = _nsf2_emulate(spec, flat, z)
+    np.testing.assert_allclose(x, xo, rtol=5e-5, atol=5e-5)
+    np.testing.assert_allclose(l, lo, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("D,T,H", [(16, 2, 64), (50, 3, 256), (128, 2, 512)])
 def test_bf16_training_image_covers_every_unmasked_parameter_once(D, T, H):
     """``MAFSpec.wide_index`` (gather map of the row-major bf16 image of ``csrc/maf_train_bf16.hip`` and scatter map of
