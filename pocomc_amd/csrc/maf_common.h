@@ -209,6 +209,14 @@ __device__ __forceinline__ void maf_hidden_pass(const pmc_maf_t& m, const MafVie
     }
 }
 
+// 16 bytes through a bounds-checked buffer resource: wave-constant VGPR byte offset + SGPR byte offset (a lane offset
+// beyond the resource's size returns zeros: how the sweeps "request nothing" without a branch)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 // Compiler-only fence between dependent LDS accesses of ONE wavefront: a wave's DS
 // instructions execute in issue order, so a ds_read after a ds_write needs no s_barrier
 // and no s_waitcnt -- only that the compiler keeps the program order.

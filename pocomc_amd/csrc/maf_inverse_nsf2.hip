@@ -36,12 +36,6 @@
 #define NSF2_LDS_FLOATS(m) (3 * (m)->Dp * 16 + 3 * (m)->Hp * 16 + 2 * NSF2_STAGE_FLOATS + 2 * NSF2_PART_FLOATS + 16 * 32 + \
                             ((NSF2_TT_WORDS(m) + (m)->Dp + NSF2_YT_WORDS(m) + 3) & ~3))
 
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float4 nbload4(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
 __device__ __forceinline__ f32x4 as_acc(const float4& v) { f32x4 r; r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; return r; }
 
 // the chain's hidden-layer operands of a tile (static data, requested a tile ahead) and its table words
@@ -63,11 +57,6 @@ struct NsfChain {
     float h2p[4];                  // the previous tile's h2 (B operands of the fp products)
 };
 
-template <int N, class F>
-__device__ __forceinline__ void nsf_for(F&& f) {
-    if constexpr (N > 0) { nsf_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
-}
-
 // Groups I .. of a tile with quad pattern PAT, one after the other, straight-line.
 //   ob[I & 1]: this group's output fragments; `ahead(I)` requests the next group's into ob[(I + 1) & 1] (and whatever
 //   else the caller wants in flight).
@@ -85,7 +74,7 @@ __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (
             std::integral_constant<int, NG> ngc;
             NSF_STAMP(7)
             if constexpr (!NSF2_SPREAD) {
-                nsf_for<6>([&](auto sl_) { ahead(gi, sl_, ngc); });
+                static_for<6>([&](auto sl_) { ahead(gi, sl_, ngc); });
                 CHAIN_FENCE();
             }
             NSF_STAMP(0)
@@ -204,8 +193,8 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
     auto ovo = [&](const int g) { return g < c.D ? c.vo_lane : NSF2_OOB; };
     auto obias = [&](const int g, float4& B0, float4& B1) {
         const int so = c.tb + c.oB3I + (g < c.D ? g : 0) * 128, vo = g < c.D ? c.vo_q : NSF2_OOB;
-        B0 = nbload4(c.rs, vo, so);
-        B1 = nbload4(c.rs, vo, so + 64);
+        B0 = bload4(c.rs, vo, so);
+        B1 = bload4(c.rs, vo, so + 64);
     };
     const int soH1 = c.tb + c.oF1 + T1 * c.nT * 1024, soH2 = c.tb + c.oF2 + T1 * c.nT * 1024;
     // one rank: bias + the two output tiles against h2 tiles 0 .. NK-1; `side(i)`: the caller's loads for the shadow of K step i
@@ -229,7 +218,7 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
     auto fetch_into = [&](const int g, float4* N0, float4* N1) {
         const int so = obase(g), vo = ovo(g);
         return [=, &c](const int i) {
-            if (!(NSF2_ABL & 8)) { N0[i] = nbload4(c.rs, vo, so + i * 1024); N1[i] = nbload4(c.rs, vo, so + (c.nT + i) * 1024); }
+            if (!(NSF2_ABL & 8)) { N0[i] = bload4(c.rs, vo, so + i * 1024); N1[i] = bload4(c.rs, vo, so + (c.nT + i) * 1024); }
         };
     };
     // ---- (1) output partials
@@ -239,14 +228,14 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
     rank(fb0, fb1, bb0, bb1, c.part + 512, fetch_into(c.g[2], fa0, fa1));
     obias(c.g[3], bb0, bb1);
 #pragma unroll
-    for (int i = 0; i < NSF2_PX; ++i) xf[i] = nbload4(c.rs, i < c.nXT ? c.vo_T : NSF2_OOB, c.tb + c.oF0C + (T1 * c.nXT + i) * 1024);
+    for (int i = 0; i < NSF2_PX; ++i) xf[i] = bload4(c.rs, i < c.nXT ? c.vo_T : NSF2_OOB, c.tb + c.oF0C + (T1 * c.nXT + i) * 1024);
     rank(fa0, fa1, ba0, ba1, c.part + 1024, fetch_into(c.g[3], fb0, fb1));
-    hb0 = nbload4(c.rs, c.vo_q, c.tb + c.oB0T + 64 * T1);
-    hb1 = nbload4(c.rs, c.vo_q, c.tb + c.oB1T + 64 * T1);
-    hb2 = nbload4(c.rs, c.vo_q, c.tb + c.oB2T + 64 * T1);
+    hb0 = bload4(c.rs, c.vo_q, c.tb + c.oB0T + 64 * T1);
+    hb1 = bload4(c.rs, c.vo_q, c.tb + c.oB1T + 64 * T1);
+    hb2 = bload4(c.rs, c.vo_q, c.tb + c.oB2T + 64 * T1);
     rank(fb0, fb1, bb0, bb1, c.part + 1536, [&](const int i) {
-        hp1[i] = nbload4(c.rs, c.vo_T, soH1 + i * 1024);
-        hp2[i] = nbload4(c.rs, c.vo_T, soH2 + i * 1024);
+        hp1[i] = bload4(c.rs, c.vo_T, soH1 + i * 1024);
+        hp2[i] = bload4(c.rs, c.vo_T, soH2 + i * 1024);
     });
     // ---- (2) hidden layers against the final tiles; the next tile's first rank requested in the shadows
     f32x4 a0 = as_acc(hb0), a1 = as_acc(hb1), a2 = as_acc(hb2);
@@ -261,12 +250,12 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
             a1 = MFMA(hp1[i].z, b1.z, a1); a2 = MFMA(hp2[i].z, b2.z, a2);
             a1 = MFMA(hp1[i].w, b1.w, a1); a2 = MFMA(hp2[i].w, b2.w, a2);
         }
-        if (!(NSF2_ABL & 8)) { carry.f0[i] = nbload4(c.rs, voN, soN + i * 1024); carry.f1[i] = nbload4(c.rs, voN, soN + (c.nT + i) * 1024); }
+        if (!(NSF2_ABL & 8)) { carry.f0[i] = bload4(c.rs, voN, soN + i * 1024); carry.f1[i] = bload4(c.rs, voN, soN + (c.nT + i) * 1024); }
         CHAIN_FENCE();
     }
 #pragma unroll
     for (int i = NK; i < NN; ++i)
-        if (!(NSF2_ABL & 8)) { carry.f0[i] = nbload4(c.rs, voN, soN + i * 1024); carry.f1[i] = nbload4(c.rs, voN, soN + (c.nT + i) * 1024); }
+        if (!(NSF2_ABL & 8)) { carry.f0[i] = bload4(c.rs, voN, soN + i * 1024); carry.f1[i] = bload4(c.rs, voN, soN + (c.nT + i) * 1024); }
     obias(c.gn, carry.b0, carry.b1);
     // layer 0 against the ranks of tiles <= T1-2 (the chain adds the ranks of tile T1-1 itself)
 #pragma unroll
@@ -291,8 +280,8 @@ __device__ __forceinline__ void nsf_stream2(f32x4& acc0, f32x4& acc1, __amdgpu_b
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int v = K0 + j < nK ? vo : NSF2_OOB;
-        w0r[j] = nbload4(rs, v, so0 + (K0 + j) * 1024);
-        w1r[j] = nbload4(rs, v, so1 + (K0 + j) * 1024);
+        w0r[j] = bload4(rs, v, so0 + (K0 + j) * 1024);
+        w1r[j] = bload4(rs, v, so1 + (K0 + j) * 1024);
     }
     for (int Kb = K0; Kb < nK; Kb += 4) {
 #pragma unroll
@@ -300,8 +289,8 @@ __device__ __forceinline__ void nsf_stream2(f32x4& acc0, f32x4& acc1, __amdgpu_b
             const int K = Kb + j;
             const float4 w0 = w0r[j], w1 = w1r[j];
             const int v = K + 4 < nK ? vo : NSF2_OOB;
-            w0r[j] = nbload4(rs, v, so0 + (K + 4) * 1024);
-            w1r[j] = nbload4(rs, v, so1 + (K + 4) * 1024);
+            w0r[j] = bload4(rs, v, so0 + (K + 4) * 1024);
+            w1r[j] = bload4(rs, v, so1 + (K + 4) * 1024);
             if (K < nK) {
                 const float4 b0 = *reinterpret_cast<const float4*>(act0 + (K << 8) + (lane << 2));
                 const float4 b1 = *reinterpret_cast<const float4*>(act1 + (K << 8) + (lane << 2));
@@ -320,7 +309,7 @@ __device__ __forceinline__ void nsf_out_partials_wide(__amdgpu_buffer_rsrc_t rs,
                                                       const int vo_lane, const int vo_q) {
     const bool lv = g < D;
     const int gg = lv ? g : 0;
-    f32x4 o0 = as_acc(nbload4(rs, lv ? vo_q : NSF2_OOB, tb_b3i + gg * 128)), o1 = as_acc(nbload4(rs, lv ? vo_q : NSF2_OOB, tb_b3i + gg * 128 + 64));
+    f32x4 o0 = as_acc(bload4(rs, lv ? vo_q : NSF2_OOB, tb_b3i + gg * 128)), o1 = as_acc(bload4(rs, lv ? vo_q : NSF2_OOB, tb_b3i + gg * 128 + 64));
     if (lv) nsf_stream2(o0, o1, rs, vo_lane, tb_f3i + gg * 2 * nT * 1024, tb_f3i + (gg * 2 + 1) * nT * 1024, 0, nK, H2, H2, lane);
     *reinterpret_cast<float4*>(d + (lane << 2)) = make_float4(o0[0], o0[1], o0[2], o0[3]);
     *reinterpret_cast<float4*>(d + 256 + (lane << 2)) = make_float4(o1[0], o1[1], o1[2], o1[3]);
@@ -478,14 +467,14 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
             const int so1_ = (TB) + oF1 + TT_ * nT * 1024, so2_ = (TB) + oF2 + TT_ * nT * 1024;                   \
             _Pragma("unroll") for (int i_ = 0; i_ < NSF2_PK; ++i_) {                                              \
                 const int vo_ = i_ < TT_ - 1 ? vo_T : NSF2_OOB;                                                   \
-                P1[i_] = nbload4(rs, vo_, so1_ + i_ * 1024);                                                      \
-                P2[i_] = nbload4(rs, vo_, so2_ + i_ * 1024);                                                      \
+                P1[i_] = bload4(rs, vo_, so1_ + i_ * 1024);                                                      \
+                P2[i_] = bload4(rs, vo_, so2_ + i_ * 1024);                                                      \
             }                                                                                                     \
             _Pragma("unroll") for (int i_ = 0; i_ < NSF2_PX; ++i_)                                                \
-                XF[i_] = nbload4(rs, i_ < nXT ? vo_T : NSF2_OOB, (TB) + oF0C + (TT_ * nXT + i_) * 1024);           \
-            Bz0 = nbload4(rs, vo_q, (TB) + oB0T + 64 * TT_);                                                      \
-            Bz1 = nbload4(rs, vo_q, (TB) + oB1T + 64 * TT_);                                                      \
-            Bz2 = nbload4(rs, vo_q, (TB) + oB2T + 64 * TT_);                                                      \
+                XF[i_] = bload4(rs, i_ < nXT ? vo_T : NSF2_OOB, (TB) + oF0C + (TT_ * nXT + i_) * 1024);           \
+            Bz0 = bload4(rs, vo_q, (TB) + oB0T + 64 * TT_);                                                      \
+            Bz1 = bload4(rs, vo_q, (TB) + oB1T + 64 * TT_);                                                      \
+            Bz2 = bload4(rs, vo_q, (TB) + oB2T + 64 * TT_);                                                      \
         }
         NsfBurstSet sA, sB;
         const bool static_tiles = nTl <= NSF2_PK + 1;
@@ -505,8 +494,8 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
         auto first_tile = [&](const int tt, float* Xt, const int par) {
             const int4 tg = *reinterpret_cast<const int4*>(DGT);
             const int g0n = __builtin_amdgcn_readfirstlane(tg.x & 0xffff);
-            carry.b0 = nbload4(rs, vo_q, tt * blk_bytes + oB3I + g0n * 128);
-            carry.b1 = nbload4(rs, vo_q, tt * blk_bytes + oB3I + g0n * 128 + 64);
+            carry.b0 = bload4(rs, vo_q, tt * blk_bytes + oB3I + g0n * 128);
+            carry.b1 = bload4(rs, vo_q, tt * blk_bytes + oB3I + g0n * 128 + 64);
             bc.tb = tt * blk_bytes; bc.X = Xt;
             bc.g[0] = g0n; bc.g[1] = __builtin_amdgcn_readfirstlane(tg.y);
             bc.g[2] = __builtin_amdgcn_readfirstlane(tg.z); bc.g[3] = __builtin_amdgcn_readfirstlane(tg.w);
@@ -608,12 +597,12 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
             const int base = tt * blk_bytes;
             const int Un = U + 1 < nT ? U + 1 : U;
             const int voN = U + 1 < nT ? vo_T : NSF2_OOB;
-            if constexpr (K == 0) F.wt1 = nbload4(rs, vo_T, base + oF1 + (U * nT + U) * 1024);
-            else if constexpr (K == 1) F.wt2 = nbload4(rs, vo_T, base + oF2 + (U * nT + U) * 1024);
-            else if constexpr (K == 2) F.wn1 = nbload4(rs, voN, base + oF1 + (Un * nT + U) * 1024);
-            else if constexpr (K == 3) F.wn2 = nbload4(rs, voN, base + oF2 + (Un * nT + U) * 1024);
-            else if constexpr (K < 7) F.w0o[K - 4] = nbload4(rs, ((4 + K - 4) << 6) + vo_q, base + oCW0 + U * 1024);
-            else if constexpr (K < 11) F.w0N[K - 7] = nbload4(rs, U + 1 < nT ? ((K - 7) << 6) + vo_q : NSF2_OOB, base + oCW0 + Un * 1024);
+            if constexpr (K == 0) F.wt1 = bload4(rs, vo_T, base + oF1 + (U * nT + U) * 1024);
+            else if constexpr (K == 1) F.wt2 = bload4(rs, vo_T, base + oF2 + (U * nT + U) * 1024);
+            else if constexpr (K == 2) F.wn1 = bload4(rs, voN, base + oF1 + (Un * nT + U) * 1024);
+            else if constexpr (K == 3) F.wn2 = bload4(rs, voN, base + oF2 + (Un * nT + U) * 1024);
+            else if constexpr (K < 7) F.w0o[K - 4] = bload4(rs, ((4 + K - 4) << 6) + vo_q, base + oCW0 + U * 1024);
+            else if constexpr (K < 11) F.w0N[K - 7] = bload4(rs, U + 1 < nT ? ((K - 7) << 6) + vo_q : NSF2_OOB, base + oCW0 + Un * 1024);
         };
         // request number K of 4 of rank g's two output tiles against hidden tiles Kp (previous; < 0: none) and Kc (own) of transform tt
         auto request_out = [&](NsfOut& O, auto k_, const int tt, const int g, const int Kp, const int Kc) {
@@ -623,17 +612,17 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
             const int vp = (lv && Kp >= 0) ? vo_lane : NSF2_OOB, vc = lv ? vo_lane : NSF2_OOB;
             const int kp = Kp >= 0 ? Kp : 0;
             if (NSF2_ABL & 16) return;
-            if constexpr (K == 0) O.fp0 = nbload4(rs, vp, so + kp * 1024);
-            else if constexpr (K == 1) O.fp1 = nbload4(rs, vp, so + (nT + kp) * 1024);
-            else if constexpr (K == 2) O.fc0 = nbload4(rs, vc, so + Kc * 1024);
-            else O.fc1 = nbload4(rs, vc, so + (nT + Kc) * 1024);
+            if constexpr (K == 0) O.fp0 = bload4(rs, vp, so + kp * 1024);
+            else if constexpr (K == 1) O.fp1 = bload4(rs, vp, so + (nT + kp) * 1024);
+            else if constexpr (K == 2) O.fc0 = bload4(rs, vc, so + Kc * 1024);
+            else O.fc1 = bload4(rs, vc, so + (nT + Kc) * 1024);
         };
         take_table(fA, T - 1, 0);
         fA.w0o[3] = fB.w0o[3] = make_float4(0.f, 0.f, 0.f, 0.f);          // (the fourth group has no later quad)
-        nsf_for<11>([&](auto k_) { request_hid(fA, k_, T - 1, 0); });
-        nsf_for<4>([&](auto k_) { request_out(ob[0], k_, T - 1, fA.g[0], -1, 0); });
-        float4 w00 = nbload4(rs, vo_q, (T - 1) * blk_bytes + oCW0);      // layer 0, first tile: the column of rank 0
-        float4 r00 = nbload4(rs, vo_q, (T - 1) * blk_bytes + oB3I), r01 = nbload4(rs, vo_q, (T - 1) * blk_bytes + oB3I + 64);
+        static_for<11>([&](auto k_) { request_hid(fA, k_, T - 1, 0); });
+        static_for<4>([&](auto k_) { request_out(ob[0], k_, T - 1, fA.g[0], -1, 0); });
+        float4 w00 = bload4(rs, vo_q, (T - 1) * blk_bytes + oCW0);      // layer 0, first tile: the column of rank 0
+        float4 r00 = bload4(rs, vo_q, (T - 1) * blk_bytes + oB3I), r01 = bload4(rs, vo_q, (T - 1) * blk_bytes + oB3I + 64);
         const float* Ysrc = Y;                             // the input of the transform: Y, then the previous transform's x array
         int spar = 0;
         for (int t = T - 1; t >= 0; --t) {
@@ -688,7 +677,7 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                     } else {
                         constexpr int LPG = (11 + NG_ - 1) / NG_, H = (LPG + 1) / 2;       // loads per group; in the first hop's shadow
                         constexpr int k0 = G * LPG + (SL == 4 ? 0 : H), k1 = G * LPG + (SL == 4 ? H : LPG);
-                        nsf_for<k1 - k0>([&](auto j_) {
+                        static_for<k1 - k0>([&](auto j_) {
                             constexpr int K = k0 + decltype(j_)::value;
                             if constexpr (K < 11) request_hid(nxt, std::integral_constant<int, K>{}, ntt, nU);
                         });
@@ -714,9 +703,9 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                 fA = fB;
                 NSF_STAMP(10)
             }
-            w00 = nbload4(rs, vo_q, (t > 0 ? t - 1 : 0) * blk_bytes + oCW0);
-            r00 = nbload4(rs, vo_q, (t > 0 ? t - 1 : 0) * blk_bytes + oB3I);
-            r01 = nbload4(rs, vo_q, (t > 0 ? t - 1 : 0) * blk_bytes + oB3I + 64);
+            w00 = bload4(rs, vo_q, (t > 0 ? t - 1 : 0) * blk_bytes + oCW0);
+            r00 = bload4(rs, vo_q, (t > 0 ? t - 1 : 0) * blk_bytes + oB3I);
+            r01 = bload4(rs, vo_q, (t > 0 ? t - 1 : 0) * blk_bytes + oB3I + 64);
             Ysrc = X;                                      // the next transform reads its y from here, through its offset table
             spar = (spar + nTl) & 1;
             if (t == 0) {

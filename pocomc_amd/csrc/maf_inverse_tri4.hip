@@ -25,13 +25,6 @@
 #define PX4 2
 #define PK4 8
 
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-
 
 // Straight-line burst of hidden tile TT against tiles 0..TT-1 (TT is a compile-time constant):
 // every LDS read is issued up front and two independent accumulators per layer keep the MFMAs

@@ -42,15 +42,11 @@
 #include "maf_chain.h"
 #include "propose_body.h"
 
-typedef unsigned int u32x4_t6 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2_t6 __attribute__((ext_vector_type(2)));
 
 namespace tri6 {
 
-__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    const u32x4_t6 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
+using ::bload4;                    // (maf_common.h)
 __device__ __forceinline__ float2 bload2(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
     const u32x2_t6 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
     return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
