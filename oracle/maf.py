@@ -25,14 +25,54 @@ import math
 
 import numpy as np
 
-from pocomc_amd.maf_spec import MAFSpec, LOG_SLOPE
+from pocomc_amd.maf_spec import MAFSpec      # the canonical PARAMETER LAYOUT only (offsets / shapes of the flat vector)
 
 F32 = np.float32
+LOG_SLOPE = math.log(1e-3)                   # zuko MonotonicAffineTransform / MonotonicRQSTransform: slope = 1e-3
+
+
+# --------------------------------------------------------------------------
+# Masks of zuko's MaskedMLP, built here from zuko's published recipe -- NOT taken from the product
+# (``tests/test_oracle_golden.py::test_oracle_masks_equal_the_product_masks`` asserts that the two constructions
+# agree).  zuko ``MaskedAutoregressiveTransform``: ``adjacency[o, i] = order[feature(o)] > order[i]`` with
+# ``feature(o) = o // total`` (``total`` hyper-network outputs per feature: 2 for the affine map, 3 bins - 1 for the
+# spline); zuko ``MaskedMLP(adjacency, hidden_features, residual=True)``:
+#     adjacency, inverse = unique(adjacency, dim=0)                 (rows sorted lexicographically)
+#     precedence[i, j]   = adjacency[j] is a subset of adjacency[i] (A A^T == row sums)
+#     layer 0:      mask = adjacency;              later layers: mask = precedence[:, indices]
+#     hidden layer: reachable = rows of mask with any entry; indices = reachable[arange(H) % len(reachable)];
+#                   mask = mask[indices]
+#     output layer: mask = mask[inverse]
+# --------------------------------------------------------------------------
+def zuko_masks(order, total, hidden, n_hidden=3):
+    """Boolean masks ``[M0 (H, D), M1 (H, H), ..., M_out (total * D, H)]`` for the feature ``order`` (rank per feature)."""
+    order = np.asarray(order)
+    D = len(order)
+    out_order = np.repeat(order, total)
+    adjacency = out_order[:, None] > order[None, :]
+    adjacency, inverse = np.unique(adjacency, axis=0, return_inverse=True)
+    inverse = np.asarray(inverse).reshape(-1)
+    a = adjacency.astype(np.int64)
+    precedence = (a @ a.T) == a.sum(axis=-1)[None, :]
+    masks, indices = [], None
+    for i in range(n_hidden + 1):
+        mask = adjacency if i == 0 else precedence[:, indices]
+        if not mask.any():
+            raise ValueError("The adjacency matrix leads to a null Jacobian.")
+        if i < n_hidden:
+            reachable = np.flatnonzero(mask.sum(axis=-1))
+            indices = reachable[np.arange(hidden) % len(reachable)]
+            mask = mask[indices]
+        else:
+            mask = mask[inverse]
+        masks.append(mask)
+    return masks
 
 
 def soft_log_scale(raw):
-    """zuko ``MonotonicAffineTransform``: ``scale / (1 + |scale / log(slope)|)``."""
-    return (raw / (F32(1.0) + np.abs(raw / F32(LOG_SLOPE)))).astype(F32)
+    """zuko ``MonotonicAffineTransform``: ``scale / (1 + |scale / log(slope)|)`` (in the dtype of ``raw``)."""
+    F = raw.dtype.type
+    return (raw / (F(1.0) + np.abs(raw / F(LOG_SLOPE)))).astype(F)
 
 
 # --------------------------------------------------------------------------
@@ -55,13 +95,15 @@ def _rqs_knots(phi, K, xp):
     h = h / (1 + abs(2 * h / ls))
     d = d / (1 + abs(d / ls))
     if xp is np:
+        F = phi.dtype.type                          # float32 like the reference; float64 for the yardstick evaluation
+
         def softmax(v):
             e = np.exp(v - v.max(axis=-1, keepdims=True))
-            return (e / e.sum(axis=-1, keepdims=True, dtype=F32)).astype(F32)
-        zero = np.zeros(phi.shape[:-1] + (1,), dtype=F32)
-        xk = (F32(RQS_BOUND) * (2 * np.cumsum(np.concatenate([zero, softmax(w)], -1), axis=-1, dtype=F32) - 1)).astype(F32)
-        yk = (F32(RQS_BOUND) * (2 * np.cumsum(np.concatenate([zero, softmax(h)], -1), axis=-1, dtype=F32) - 1)).astype(F32)
-        dk = np.exp(np.concatenate([zero, d, zero], -1)).astype(F32)
+            return (e / e.sum(axis=-1, keepdims=True, dtype=F)).astype(F)
+        zero = np.zeros(phi.shape[:-1] + (1,), dtype=F)
+        xk = (F(RQS_BOUND) * (2 * np.cumsum(np.concatenate([zero, softmax(w)], -1), axis=-1, dtype=F) - 1)).astype(F)
+        yk = (F(RQS_BOUND) * (2 * np.cumsum(np.concatenate([zero, softmax(h)], -1), axis=-1, dtype=F) - 1)).astype(F)
+        dk = np.exp(np.concatenate([zero, d, zero], -1)).astype(F)
         return xk, yk, dk
     import torch
     zero = torch.zeros(phi.shape[:-1] + (1,), dtype=phi.dtype)
@@ -121,27 +163,33 @@ def rqs_inverse(y, phi, K=8, xp=np):
 class OracleMAF:
     """float32 numpy MAF / NSF with the canonical parameter vector of ``MAFSpec``."""
 
-    def __init__(self, spec: MAFSpec, flat: np.ndarray):
+    def __init__(self, spec: MAFSpec, flat: np.ndarray, dtype=F32):
+        """``dtype=np.float64``: the SAME float32 parameters, every operation of the flow in float64 -- the yardstick
+        for two float32 evaluations (this file's, a kernel's) of an ill-conditioned map such as the spline."""
         self.spec = spec
+        self.F = F = np.dtype(dtype).type
         self.flat = np.asarray(flat, dtype=F32)
         assert self.flat.shape == (spec.n_params,)
         self._mats = []
+        D = spec.n_dim
         for t in range(spec.n_transforms):
-            M0, M1, M2, M3 = spec.masks(t)
+            # zuko MAF / NSF: the feature order alternates identity / reversed per transform
+            order = np.arange(D) if t % 2 == 0 else np.arange(D)[::-1]
+            M0, M1, M2, M3 = zuko_masks(order, spec.n_out, spec.hidden)
             v = lambda n: spec.view(self.flat, t, n)
             self._mats.append(dict(
-                W0=(v("W0") * M0).astype(F32), b0=v("b0"),
-                W1=(v("W1") * M1).astype(F32), b1=v("b1"),
-                W2=(v("W2") * M2).astype(F32), b2=v("b2"),
-                W3=(v("W3") * M3).astype(F32), b3=v("b3")))
+                W0=(v("W0") * M0).astype(F), b0=v("b0").astype(F),
+                W1=(v("W1") * M1).astype(F), b1=v("b1").astype(F),
+                W2=(v("W2") * M2).astype(F), b2=v("b2").astype(F),
+                W3=(v("W3") * M3).astype(F), b3=v("b3").astype(F)))
 
     # hyper-network of one transform: x (N,D) -> phi (N, D, n_out)
     def _phi(self, t: int, x: np.ndarray):
         m = self._mats[t]
-        h = np.maximum(x @ m["W0"].T + m["b0"], F32(0))
-        h = np.maximum(h + (h @ m["W1"].T + m["b1"]), F32(0))
-        h = np.maximum(h + (h @ m["W2"].T + m["b2"]), F32(0))
-        phi = (h @ m["W3"].T + m["b3"]).astype(F32)
+        h = np.maximum(x @ m["W0"].T + m["b0"], self.F(0))
+        h = np.maximum(h + (h @ m["W1"].T + m["b1"]), self.F(0))
+        h = np.maximum(h + (h @ m["W2"].T + m["b2"]), self.F(0))
+        phi = (h @ m["W3"].T + m["b3"]).astype(self.F)
         return phi.reshape(len(x), self.spec.n_dim, self.spec.n_out)
 
     def _hyper(self, t: int, x: np.ndarray):
@@ -154,26 +202,26 @@ class OracleMAF:
         phi = self._phi(t, x)
         if self.spec.univariate == "affine":
             ls = soft_log_scale(phi[..., 1])
-            return (x * np.exp(ls) + phi[..., 0]).astype(F32), ls
+            return (x * np.exp(ls) + phi[..., 0]).astype(self.F), ls
         y, l = rqs_forward(x, phi, self.spec.bins)
-        return y.astype(F32), l.astype(F32)
+        return y.astype(self.F), l.astype(self.F)
 
     def _inv(self, t, xcur, y):
         """one fixed-point pass: parameters from ``xcur``, inverse univariate applied to ``y``."""
         phi = self._phi(t, xcur)
         if self.spec.univariate == "affine":
             ls = soft_log_scale(phi[..., 1])
-            return ((y - phi[..., 0]) / np.exp(ls)).astype(F32), ls
+            return ((y - phi[..., 0]) / np.exp(ls)).astype(self.F), ls
         x, l = rqs_inverse(y, phi, self.spec.bins)
-        return x.astype(F32), l.astype(F32)
+        return x.astype(self.F), l.astype(self.F)
 
     def forward(self, x):
         """data -> latent, ``(z, ladj)``; ``pocomc/flow.py:99-114``."""
-        x = np.asarray(x, dtype=F32)
-        ladj = np.zeros(len(x), dtype=F32)
+        x = np.asarray(x, dtype=self.F)
+        ladj = np.zeros(len(x), dtype=self.F)
         for t in range(self.spec.n_transforms):
             x, l = self._fwd(t, x)
-            ladj = (ladj + l.sum(axis=1, dtype=F32)).astype(F32)
+            ladj = (ladj + l.sum(axis=1, dtype=self.F)).astype(self.F)
         return x, ladj
 
     def ladj_abs_terms(self, x):
@@ -181,7 +229,7 @@ class OracleMAF:
         the log-determinant sums.  The terms have either sign, so two valid float32 evaluations of the sum (zuko's, this
         file's, a kernel's) agree to ``eps * sum|terms|``, not to ``eps * |sum|``: parity tests measure a
         log-determinant's error against this figure (the condition of the sum), never against a global maximum."""
-        x = np.asarray(x, dtype=F32)
+        x = np.asarray(x, dtype=self.F)
         acc = np.zeros(len(x), dtype=np.float64)
         for t in range(self.spec.n_transforms):
             x, l = self._fwd(t, x)
@@ -191,15 +239,15 @@ class OracleMAF:
     def inverse(self, z):
         """latent -> data, ``(x, ladj)``; ``pocomc/flow.py:116-132``.  ``ladj`` is
         the log-determinant of the inverse map (= ``-ladj_forward(x)``)."""
-        y = np.asarray(z, dtype=F32)
+        y = np.asarray(z, dtype=self.F)
         D = self.spec.n_dim
-        ladj = np.zeros(len(y), dtype=F32)
+        ladj = np.zeros(len(y), dtype=self.F)
         for t in reversed(range(self.spec.n_transforms)):
             x = np.zeros_like(y)
             for _ in range(D):                      # zuko: passes = features
                 x, _l = self._inv(t, x, y)
             _x, l = self._inv(t, x, y)              # extra pass for the ladj
-            ladj = (ladj - l.sum(axis=1, dtype=F32)).astype(F32)
+            ladj = (ladj - l.sum(axis=1, dtype=self.F)).astype(self.F)
             y = x
         return y, ladj
 
@@ -207,18 +255,18 @@ class OracleMAF:
         """``pocomc/flow.py:134-147``: base ``N(0,I)`` log-density + ladj."""
         z, ladj = self.forward(x)
         D = self.spec.n_dim
-        base = (-0.5 * (z.astype(F32) ** 2).sum(axis=1, dtype=F32)
-                - F32(0.5 * D * math.log(2 * math.pi))).astype(F32)
-        return (base + ladj).astype(F32)
+        base = (-0.5 * (z.astype(self.F) ** 2).sum(axis=1, dtype=self.F)
+                - self.F(0.5 * D * math.log(2 * math.pi))).astype(self.F)
+        return (base + ladj).astype(self.F)
 
     def sample_from(self, z):
         """``pocomc/flow.py:149-163`` with the base draw ``z`` given (replay)."""
         x, ladj_inv = self.inverse(z)
         D = self.spec.n_dim
-        base = (-0.5 * (np.asarray(z, F32) ** 2).sum(axis=1, dtype=F32)
-                - F32(0.5 * D * math.log(2 * math.pi))).astype(F32)
+        base = (-0.5 * (np.asarray(z, self.F) ** 2).sum(axis=1, dtype=self.F)
+                - self.F(0.5 * D * math.log(2 * math.pi))).astype(self.F)
         # log q(x) = log N(z) + ladj_forward(x) = log N(z) - ladj_inverse(z)
-        return x, (base - ladj_inv).astype(F32)
+        return x, (base - ladj_inv).astype(self.F)
 
 
 class TorchFlowAdapter:

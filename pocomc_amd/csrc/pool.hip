@@ -320,6 +320,8 @@ __global__ __launch_bounds__(256) void bootstrap_lse_kernel(const double* __rest
         if (replay) {
             i0 = replay[(size_t)blockIdx.x * n + e];
             i1 = e + 1 < n ? replay[(size_t)blockIdx.x * n + e + 1] : 0;
+            // a recorded draw outside [0, n) is the caller's error: the replicate becomes NaN instead of a read out of bounds
+            if (i0 < 0 || i0 >= n || i1 < 0 || i1 >= n) { s = __builtin_nan(""); i0 = 0; i1 = 0; }
         } else {
             Philox ph(seed, (uint64_t)blockIdx.x, (uint64_t)(e >> 1), 3);
             double u0, u1;

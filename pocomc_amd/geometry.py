@@ -131,8 +131,10 @@ class Geometry:
         # silent NaN geometry that surfaces later, or never
         if not (np.isfinite(med).all() and np.isfinite(sigma).all()):
             raise ValueError("Geometry.fit: non-finite values in theta (median / scatter matrix are not finite)")
+        # (the reference's own failure condition: ``linalg.solve(cov, ...)`` of the EM step, student.py:70, raises on an
+        #  exactly singular matrix only -- near-singular or slightly indefinite scatter matrices pass there and pass here)
         try:
-            np.linalg.cholesky(sigma)
+            np.linalg.solve(sigma, np.eye(D))
         except np.linalg.LinAlgError:
             raise np.linalg.LinAlgError("Geometry.fit: the scatter matrix of theta is singular (student.py:70 solves with it)")
         self.t_mean, self.t_cov, self.t_nu = med, sigma, nu

@@ -435,6 +435,7 @@ class StepEngine:
             self._post_uploads = True
             return
         self._post_uploads = False
+        self._np_clean[0] = -1        # (the fine-grained launches count no rows: a word left by a composite pre-step is stale)
         self._rng_cur = self._rng(replay)
         st = _lib.stream_handle()
         kind = PMC_KIND_TPCN if self.tpcn else PMC_KIND_RWM
@@ -522,7 +523,8 @@ class StepEngine:
                 return r
         if self.prior_desc is not None:
             log_prior = None                          # logp' came back from the device with x'
-            if self._direct_now and self._np_clean[0] == 0 and self.host_threads <= 1 and not have_blobs:
+            if ((waited or self._post_uploads) and self._direct_now and self._np_clean[0] == 0
+                    and self.host_threads <= 1 and not have_blobs):
                 # the fused pre-step counted no row with a non-finite x' or logp' (pmc_step_t.h_clean): both masks of
                 # mcmc.py:100-109 are all-true, x'[mask] is x' itself
                 self._np_logl[:] = log_like(self._np_x)[0]

@@ -518,6 +518,8 @@ class Sampler:
         if replay is not None:
             draws = torch.from_numpy(np.ascontiguousarray(replay["draws"], dtype=np.int64)).to(dev)
             assert draws.ndim == 2 and draws.shape[1] == m
+            if m and (int(draws.min()) < 0 or int(draws.max()) >= m):
+                raise ValueError("replayed bootstrap draws must index the surviving rows: 0 <= draw < %d" % m)
             B = draws.shape[0]
             reps = torch.empty(B, dtype=torch.float64, device=dev)
         else:

@@ -93,6 +93,18 @@ class HalfBoundPrior:
         return x
 
 
+class CutPrior(HalfBoundPrior):
+    """HalfBoundPrior whose density vanishes for x_0 > cut INSIDE the scaler's bounds: ``logpdf`` returns -inf on rows
+    the bijector cannot exclude (the non-finite-prior branch of ``sampler.py:898-901`` / ``mcmc.py:104-109``)."""
+
+    def __init__(self, D, cut=0.9):
+        super().__init__(D)
+        self.cut = cut
+
+    def logpdf(self, x):
+        return np.where(x[:, 0] > self.cut, -np.inf, super().logpdf(x))
+
+
 class Geo:
     """Stand-in for ``pocomc.geometry.Geometry`` outputs (step inputs, G1)."""
 
@@ -127,6 +139,21 @@ MCMC_CASES = {
     "rwm_n320_d32_uniform":  dict(kind="rwm",                N=320, D=32, T=3, beta=0.5, nu=5.0, prior="uniform", target="corr",       seed=14, n_max=3),
     "rwm_n256_d10_mixed":    dict(kind="rwm",                N=256, D=10, T=3, beta=0.4, nu=5.0, prior="mixed",   target="gauss",      seed=15, n_max=4),
     "tpcn_n256_d50_bimodal": dict(kind="preconditioned_pcn", N=256, D=50, T=6, beta=0.5, nu=5.0, prior="uniform", target="bimodal",    seed=16, n_max=2),
+    # round 4: the spline flows (the reference's default is nsf6, sampler.py:169; Flow's own nsf3, flow.py:46) through the
+    # reference's kernels -- "flow": the univariate map of MAFSpec ("rqs" = zuko NSF, 8 bins)
+    "tpcn_n128_d8_nsf3":     dict(kind="preconditioned_pcn", N=128, D=8,  T=3, beta=0.6, nu=5.0, prior="uniform", target="rosenbrock", seed=17, n_max=4, flow="rqs"),
+    "tpcn_n256_d10_nsf6":    dict(kind="preconditioned_pcn", N=256, D=10, T=6, beta=1.0, nu=1e6, prior="normal",  target="gauss",      seed=18, n_max=3, flow="rqs"),
+    "prwm_n128_d8_nsf3":     dict(kind="preconditioned_rwm", N=128, D=8,  T=3, beta=0.6, nu=5.0, prior="mixed",   target="gauss",      seed=19, n_max=4, flow="rqs"),
+    "tpcn_n512_d32_nsf3":    dict(kind="preconditioned_pcn", N=512, D=32, T=3, beta=0.5, nu=5.0, prior="uniform", target="corr",       seed=20, n_max=2, flow="rqs"),
+}
+
+# BASELINE-size cases WITH golden vectors from the reference: a one-step call (n_max = 1: every walker's step depends on
+# its own row only, so a row subsample of the reference's output pins the call) -- the reference's per-walker Python
+# loops and the oracle's D-pass spline inverse take about a minute here, once, in make_golden.py.  ``rows``: every
+# ``stride``-th walker's output is stored.
+BIG_GOLDEN_CASES = {
+    "tpcn_n10000_d32_nsf3": dict(kind="preconditioned_pcn", N=10000, D=32, T=3, beta=0.5, nu=5.0, prior="uniform", target="rosenbrock", seed=24, n_max=1, flow="rqs", stride=16),
+    "tpcn_n10000_d32_maf3": dict(kind="preconditioned_pcn", N=10000, D=32, T=3, beta=0.5, nu=5.0, prior="uniform", target="rosenbrock", seed=25, n_max=1, stride=16),
 }
 
 
@@ -150,12 +177,45 @@ BIG_CASES = {
 }
 
 
+# ---------------------------------------------------- orchestrator cases (pocomc/sampler.py:680-805)
+def sampler_pool(seed, T=9, N=128, D=4):
+    """A persistent-sampling history: T iterations of N particles (seeded; ``u[:, 0]`` is the pool row index, so the
+    rows a method keeps can be read off its output)."""
+    rs = np.random.RandomState(seed)
+    betas = np.sort(rs.uniform(0, 0.6, T)); betas[0] = 0.0
+    logzs = np.cumsum(rs.randn(T)) * 0.5; logzs[0] = 0.0
+    rows = dict(u=rs.randn(T, N, D), x=rs.randn(T, N, D), logdetj=rs.randn(T, N), logp=rs.randn(T, N) - 3.0,
+                logl=rs.randn(T, N) * 6.0 - 8.0)
+    rows["u"][:, :, 0] = np.arange(T * N).reshape(T, N)
+    return betas, logzs, rows
+
+
+SAMPLER_CASES = {
+    # name: pool seed, metric, dynamic, n_effective, n_active  (the three branches of sampler.py:747-777)
+    "keep_beta_ess":   dict(seed=1, metric="ess", dynamic=False, n_effective=5000, n_active=128),
+    "posterior_ess":   dict(seed=2, metric="ess", dynamic=True,  n_effective=8,    n_active=4),
+    "bisect_ess":      dict(seed=3, metric="ess", dynamic=False, n_effective=256,  n_active=128),
+    "bisect_ess_dyn":  dict(seed=4, metric="ess", dynamic=True,  n_effective=200,  n_active=128),
+    "bisect_uss_dyn":  dict(seed=5, metric="uss", dynamic=True,  n_effective=300,  n_active=128),
+    "bisect_uss":      dict(seed=6, metric="uss", dynamic=False, n_effective=150,  n_active=64),
+    "bisect_ess_dyn2": dict(seed=7, metric="ess", dynamic=True,  n_effective=420,  n_active=128),
+    "bisect_ess_dyn3": dict(seed=8, metric="ess", dynamic=True,  n_effective=130,  n_active=128),
+}
+
+
+def find_case(name):
+    for table in (MCMC_CASES, BIG_CASES, BIG_GOLDEN_CASES):
+        if name in table:
+            return table[name]
+    raise KeyError(name)
+
+
 def build_case(name, scaler_cls):
     """Instantiate a case: returns ``(state_dict, function_dict, option_dict, aux)``.
 
     ``scaler_cls`` is the ``Reparameterize`` class to use (the reference's when
     generating goldens, the oracle's / the product's in tests)."""
-    c = MCMC_CASES[name] if name in MCMC_CASES else BIG_CASES[name]
+    c = find_case(name)
     N, D = c["N"], c["D"]
     rng = np.random.default_rng(1000 + c["seed"])
     prior = {"uniform": lambda: UniformPrior(-10.0, 10.0, D),
@@ -173,7 +233,7 @@ def build_case(name, scaler_cls):
     logdetj = scaler.inverse(u)[1]
     logp = prior.logpdf(x)
     logl = target(x)
-    spec = MAFSpec(D, c["T"])
+    spec = MAFSpec(D, c["T"], univariate=c.get("flow", "affine"))
     flat = flow_params(spec, c["seed"])
     # geometry (inputs of the step): a random SPD matrix around the particle scatter
     A = rng.normal(size=(D, D)) * 0.3

@@ -11,6 +11,13 @@ reference's duck-typed Flow contract (``pocomc/tools.py:336-349``), so these
 vectors pin everything *given* a flow; the flow itself stays parity-unpinned
 (SURVEY.md section 8(c)).
 
+Round 4: ``pocomc.sampler`` is imported too -- its only obstacle is the ``import zuko`` line of ``pocomc/flow.py:6``; an
+EMPTY module object under that name lets the import statement pass (nothing of zuko is executed, faked or restated by
+it: the reference's ``Flow`` class is never instantiated) -- and the orchestrator methods ``Sampler._reweight``
+(``sampler.py:717-805``), ``_resample`` (``:680-715``) and ``_compute_evidence`` (``:869-920``) are called unbound on a
+duck-typed ``self`` that carries the reference's own ``Particles`` / ``Reparameterize`` and the oracle flow behind the
+``.sample`` contract.  Like the MCMC vectors they pin the orchestrator arithmetic *given* a flow.
+
 Outputs (data only -- inputs and the reference's outputs): ``tests/golden/*.npz``.
 The GPU box never runs this script and never sees ``/root/reference``.
 """
@@ -38,7 +45,89 @@ def load_reference():
     mods = {}
     for m in ("tools", "student", "geometry", "scaler", "particles", "mcmc"):
         mods[m] = importlib.import_module(f"pocomc.{m}")
+    # pocomc/flow.py:6 ``import zuko``: an empty module satisfies the statement; pocomc.flow.Flow is never constructed
+    if "zuko" not in sys.modules:
+        sys.modules["zuko"] = types.ModuleType("zuko")
+    mods["sampler"] = importlib.import_module("pocomc.sampler")
     return mods
+
+
+class _Bar:
+    """Stand-in for the tqdm wrapper (``tools.py:189-224``): the orchestrator only reports to it."""
+
+    def update_iter(self):
+        pass
+
+    def update_stats(self, info):
+        pass
+
+
+def sampler_goldens(ref, out):
+    from oracle.maf import OracleMAF
+    from pocomc_amd.maf_spec import MAFSpec
+    import cases
+    S = ref["sampler"].Sampler
+    T = ref["tools"]
+    for name, c in cases.SAMPLER_CASES.items():
+        betas, logzs, rows = cases.sampler_pool(c["seed"])
+        nT, N, D = rows["u"].shape
+        P = ref["particles"].Particles(N, D)
+        for t in range(nT):
+            P.update(dict(u=rows["u"][t], x=rows["x"][t], logdetj=rows["logdetj"][t], logl=rows["logl"][t],
+                          logp=rows["logp"][t], beta=betas[t], logz=logzs[t]))
+        me = types.SimpleNamespace(t=nT, pbar=_Bar(), particles=P, metric=c["metric"], n_effective=c["n_effective"],
+                                   dynamic=c["dynamic"], n_active=c["n_active"], have_blobs=False,
+                                   dynamic_ratio=T.unique_sample_size(np.ones(c["n_effective"]), k=c["n_active"]) / c["n_active"])
+        cur = S._reweight(me, {})
+        tag = f"sampler/{name}"
+        out[f"{tag}/beta"] = np.asarray(cur["beta"])
+        out[f"{tag}/logz"] = np.asarray(cur["logz"])
+        out[f"{tag}/ess"] = np.asarray(cur["ess"])
+        out[f"{tag}/n_effective_after"] = np.asarray(me.n_effective)
+        out[f"{tag}/weights"] = cur["weights"]
+        out[f"{tag}/idx"] = cur["u"][:, 0].astype(np.int64)
+        for k in ("x", "logdetj", "logl", "logp"):
+            out[f"{tag}/kept_{k}"] = cur[k]
+        # _resample on that selection, both schemes (sampler.py:702-705), numpy's legacy stream seeded
+        for scheme in ("mult", "syst"):
+            me2 = types.SimpleNamespace(resample=scheme, n_active=c["n_active"], have_blobs=False)
+            np.random.seed(100 + c["seed"])
+            r = S._resample(me2, dict(cur))
+            out[f"{tag}/{scheme}/rows"] = r["u"][:, 0].astype(np.int64)
+            for k in ("x", "logdetj", "logl", "logp"):
+                out[f"{tag}/{scheme}/{k}"] = r[k]
+
+    # _compute_evidence (sampler.py:869-920): the oracle flow behind ``.sample``, the reference's scaler, a prior with a
+    # bounded support (part of the draws is dropped, :898-901), numpy's legacy stream for the bootstrap
+    import torch
+    for name, (Dn, Tn, uni, n, seed) in {"maf3_d5": (5, 3, "affine", 600, 17), "nsf3_d4": (4, 3, "rqs", 400, 18)}.items():
+        spec = MAFSpec(Dn, Tn, univariate=uni)
+        flat = cases.flow_params(spec, seed, gain=1.0)
+        maf = OracleMAF(spec, flat)
+        prior = cases.CutPrior(Dn)
+        rs = np.random.RandomState(seed)
+        x_fit = prior.rvs(512, np.random.default_rng(seed))
+        sc = ref["scaler"].Reparameterize(Dn, prior.bounds)
+        sc.fit(x_fit)
+        z = rs.randn(n, Dn).astype(np.float32)
+
+        class _F:
+            def sample(self, size):
+                assert size == n
+                x, lq = maf.sample_from(z)
+                return torch.from_numpy(x), torch.from_numpy(lq)
+        like = lambda x: -0.5 * np.sum(((x - 0.3) / 0.8) ** 2, axis=1) - 0.1 * x[:, 0] ** 4
+        me = types.SimpleNamespace(flow=_F(), scaler=sc, log_prior=prior.logpdf, calls=0, pbar=_Bar())
+        me._log_like = lambda x: (like(x), None)
+        np.random.seed(seed)
+        logz, dlogz = S._compute_evidence(me, n)
+        tag = f"evidence/{name}"
+        out[f"{tag}/x_fit"] = x_fit
+        out[f"{tag}/z"] = z
+        out[f"{tag}/logz"] = np.asarray(logz)
+        out[f"{tag}/dlogz"] = np.asarray(dlogz)
+        out[f"{tag}/calls"] = np.asarray(me.calls)
+        out[f"{tag}/spec"] = np.asarray([Dn, Tn, 1 if uni == "rqs" else 0, n, seed])
 
 
 def main():
@@ -70,6 +159,35 @@ def main():
         out[f"mcmc/{name}/in/scaler_sigma"] = funcs["scaler"].sigma
     np.savez_compressed(os.path.join(HERE, "mcmc_reference.npz"), **out)
     print("mcmc_reference.npz:", len(out), "arrays")
+
+    # --------------------------------------------- BASELINE-size one-step calls (row subsample of the reference's output)
+    out = {}
+    for name, c in cases.BIG_GOLDEN_CASES.items():
+        kernel = getattr(ref["mcmc"], c["kind"])
+        state, funcs, opts, aux = cases.build_case(name, ref["scaler"].Reparameterize)
+        funcs["flow"] = TorchFlowAdapter(OracleMAF(aux["spec"], aux["flat"]))
+        opts["n_max"] = 1
+        tag = f"mcmc_big/{name}"
+        sl = slice(None, None, c["stride"])
+        for k in ("u", "x", "logdetj", "logl", "logp"):
+            out[f"{tag}/in/{k}"] = state[k][sl]
+        out[f"{tag}/in/scaler_mu"] = funcs["scaler"].mu
+        out[f"{tag}/in/scaler_sigma"] = funcs["scaler"].sigma
+        np.random.seed(c["seed"])
+        res = kernel(state, funcs, opts)
+        for k in ("u", "x", "logdetj", "logl", "logp"):
+            out[f"{tag}/{k}"] = res[k][sl]
+        for k in ("efficiency", "accept", "steps", "calls", "proposal_scale"):
+            out[f"{tag}/{k}"] = np.asarray(res[k])
+        print(tag, "accept", res["accept"], "calls", res["calls"])
+    np.savez_compressed(os.path.join(HERE, "mcmc_big_reference.npz"), **out)
+    print("mcmc_big_reference.npz:", len(out), "arrays")
+
+    # ------------------------------------------------- orchestrator methods of pocomc/sampler.py
+    out = {}
+    sampler_goldens(ref, out)
+    np.savez_compressed(os.path.join(HERE, "sampler_reference.npz"), **out)
+    print("sampler_reference.npz:", len(out), "arrays")
 
     # ------------------------------------------------------------------ scaler
     # the four bound types of tests/test_scaler.py:9-54, 100x10 data, seed 0

@@ -265,6 +265,50 @@ def test_nsf_inverse_matches_oracle(D, T, n):
     close_rel(l2.numpy(), -l.numpy(), NSF_LADJ, "nsf antisymmetry", cancel=terms)
 
 
+@pytest.mark.parametrize("D,T", NSF_SHAPES)
+def test_nsf_float32_evaluations_against_the_float64_yardstick(D, T):
+    """Why the spline flows are not held to 1e-5 against the float32 oracle: the rational-quadratic spline differences
+    knots of size <= 5 that are cumulative sums of a softmax (bin widths ~0.1-1), so ANY float32 evaluation -- zuko's,
+    the oracle's, a kernel's -- sits eps * cond away from the exact map of the same float32 parameters, with cond ~ 10-100.
+    The yardstick is that exact map: ``OracleMAF(dtype=float64)``.  Asserted per batch: the kernels' distance to it is
+    within the north star's 1e-5 (measured on MI355X: <= 6.1e-6 over these shapes, forward and every inverse sweep; the
+    float32 oracle's own distance: <= 5.3e-6) AND not larger than YARD x the float32 oracle's own distance to it or 1e-5,
+    whichever is larger -- i.e. the device is as good a float32 evaluation of the reference's flow as float32 numpy is;
+    both distances are printed."""
+    f, o = make_nsf(D, T)
+    o64 = OracleMAF(o.spec, o.flat, dtype=np.float64)
+    from parity import rel_rows
+    YARD = 2.0
+    rng = np.random.default_rng(100 + D)
+    n = 300
+    x = (rng.normal(size=(n, D)) * 2.5).astype(np.float32)
+    z64, l64 = o64.forward(x)
+    z32, l32 = o.forward(x)
+    zk, lk = f.forward(torch.from_numpy(x))
+    terms = o.ladj_abs_terms(x)
+    e_o, e_k = rel_rows(z32, z64).max(), rel_rows(zk.numpy(), z64).max()
+    tiny = np.finfo(np.float64).tiny                 # (a row outside the spline box in every transform: ladj = 0 exactly)
+    el_o = (np.abs(l32 - l64) / np.maximum(np.maximum(np.abs(l64), terms), tiny)).max()
+    el_k = (np.abs(lk.numpy() - l64) / np.maximum(np.maximum(np.abs(l64), terms), tiny)).max()
+    print(f"nsf D={D} T={T} forward: z oracle32 {e_o:.2e} kernel {e_k:.2e}; ladj oracle32 {el_o:.2e} kernel {el_k:.2e}")
+    assert e_k <= max(YARD * e_o, 1e-5) and el_k <= max(YARD * el_o, 1e-5)
+    assert e_k <= TOL and el_k <= TOL
+    z = (rng.normal(size=(n, D)) * 1.5).astype(np.float32)
+    x64, li64 = o64.inverse(z)
+    x32, li32 = o.inverse(z)
+    terms = o.ladj_abs_terms(x32)
+    for algo in ([0, 6, 7] if f.spec.tri_ok else [2]):
+        f.inverse_algo = algo
+        xk, lik = f.inverse(torch.from_numpy(z))
+        e_o, e_k = rel_rows(x32, x64).max(), rel_rows(xk.numpy(), x64).max()
+        el_o = (np.abs(li32 - li64) / np.maximum(np.maximum(np.abs(li64), terms), tiny)).max()
+        el_k = (np.abs(lik.numpy() - li64) / np.maximum(np.maximum(np.abs(li64), terms), tiny)).max()
+        print(f"nsf D={D} T={T} inverse algorithm {algo}: x oracle32 {e_o:.2e} kernel {e_k:.2e}; ladj oracle32 {el_o:.2e} kernel {el_k:.2e}")
+        assert e_k <= max(YARD * e_o, 1e-5) and el_k <= max(YARD * el_o, 1e-5), (algo, e_k, e_o, el_k, el_o)
+        assert e_k <= TOL and el_k <= TOL, (algo, e_k, el_k)
+    f.inverse_algo = 0
+
+
 def test_spline_sweeps_on_random_flow_shapes():
     """Random spline flows (D <= 64, T, hidden, n): the lone-wave and the two-wave sweep (static burst tiles up to 11 live
     hidden tiles, streamed above) agree to float32 rounding and follow the D-pass inverse on the device."""

@@ -179,3 +179,89 @@ def test_compute_evidence_replayed_against_the_oracle(flow_name, n):
     terms = np.abs(logw_o).max()
     assert abs(logz - logz_o) <= 1e-5 * max(abs(logz_o), terms), (logz, logz_o)
     assert abs(dlogz - dlogz_o) <= 1e-3 * dlogz_o, (dlogz, dlogz_o)
+
+
+# ------------------------------------------------------------ orchestrator arithmetic vs the reference's own sampler.py
+def _sampler_on_pool(c, N, D):
+    import pocomc_amd as pc
+    from pocomc_amd.particles import Particles
+    from pocomc_amd.sampler import _Progress
+    prior = pc.Prior([norm(0, 1)] * D)
+    s = pc.Sampler(prior=prior, likelihood=log_likelihood_vectorized, vectorize=True, flow="maf3", random_state=0,
+                   n_effective=c["n_effective"], n_active=c["n_active"], metric=c["metric"], dynamic=c["dynamic"])
+    s.particles = Particles(N, D)
+    s.pbar, s.walkers = _Progress(False), {}
+    return s
+
+
+@pytest.mark.parametrize("name", list(__import__("cases").SAMPLER_CASES))
+def test_temper_and_draw_match_the_reference_sampler(name, golden_dir):
+    """``Sampler._temper`` / ``_draw`` on a resident pool against ``Sampler._reweight`` (``sampler.py:717-805``) and
+    ``_resample`` (``:680-715``) of the reference itself (called unbound by ``tests/golden/make_golden.py`` on the same
+    history): the three branches of the temperature ladder, ESS and USS metrics, the dynamic ESS adjustment in both
+    directions, trimming, both resampling schemes on numpy's legacy stream.  beta, the dynamic n_effective, the kept
+    rows and the resampled rows are exact; weights / logZ / ESS to 1e-12 (device reductions sum in another order)."""
+    import cases
+    g = np.load(f"{golden_dir}/sampler_reference.npz")
+    c = cases.SAMPLER_CASES[name]
+    betas, logzs, rows = cases.sampler_pool(c["seed"])
+    nT, N, D = rows["u"].shape
+    s = _sampler_on_pool(c, N, D)
+    for t in range(nT):
+        s.particles.update(dict(u=rows["u"][t], x=rows["x"][t], logdetj=rows["logdetj"][t], logp=rows["logp"][t],
+                                logl=rows["logl"][t], beta=betas[t], logz=logzs[t], iter=t, calls=0, steps=1,
+                                efficiency=1.0, ess=1.0, accept=1.0))
+    s.t = nT
+    idx, w = s._temper()
+    tag = f"sampler/{name}"
+    assert s.walkers["beta"] == float(g[f"{tag}/beta"])
+    np.testing.assert_allclose(s.walkers["logz"], g[f"{tag}/logz"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(s.walkers["ess"], g[f"{tag}/ess"], rtol=1e-11)
+    assert s.n_effective == int(g[f"{tag}/n_effective_after"])
+    np.testing.assert_array_equal(idx.cpu().numpy(), g[f"{tag}/idx"])
+    np.testing.assert_allclose(w.cpu().numpy(), g[f"{tag}/weights"], rtol=1e-12)
+    kept = s.particles.take(idx)
+    for k in ("x", "logdetj", "logl", "logp"):
+        np.testing.assert_array_equal(kept[k].cpu().numpy(), g[f"{tag}/kept_{k}"])
+    for scheme in ("mult", "syst"):
+        s.resample = scheme
+        np.random.seed(100 + c["seed"])
+        s._draw((idx, w))
+        np.testing.assert_array_equal(s.walkers["u"][:, 0].cpu().numpy().astype(np.int64), g[f"{tag}/{scheme}/rows"])
+        for k in ("x", "logdetj", "logl", "logp"):
+            np.testing.assert_array_equal(s.walkers[k].cpu().numpy(), g[f"{tag}/{scheme}/{k}"])
+
+
+@pytest.mark.parametrize("name", ["maf3_d5", "nsf3_d4"])
+def test_compute_evidence_matches_the_reference_sampler(name, golden_dir):
+    """``Sampler._compute_evidence`` against the reference's own method (``sampler.py:869-920`` called unbound by
+    ``make_golden.py`` with the oracle flow behind ``.sample``): same base draw, the bootstrap indices of the same
+    legacy-stream seed replayed through ``pmc_bootstrap_logz_replay``; a prior whose support cuts inside the scaler's
+    bounds (rows dropped, ``:898-901``).  logZ to the flow's tolerance on its terms, the bootstrap spread to 1e-3."""
+    import cases
+    import pocomc_amd as pc
+    from pocomc_amd.maf_spec import MAFSpec
+    from pocomc_amd.sampler import _Progress
+    g = np.load(f"{golden_dir}/sampler_reference.npz")
+    tag = f"evidence/{name}"
+    Dn, Tn, rqs, n, seed = (int(v) for v in g[f"{tag}/spec"])
+    spec = MAFSpec(Dn, Tn, univariate="rqs" if rqs else "affine")
+    flow = pc.Flow(Dn, spec)
+    flow.set_params(cases.flow_params(spec, seed, gain=1.0))
+    prior = cases.CutPrior(Dn)
+
+    class P:                                   # the Sampler's view of a prior (prior.py): logpdf, rvs, bounds, dim
+        logpdf, bounds, dim = staticmethod(prior.logpdf), prior.bounds, Dn
+        rvs = staticmethod(lambda m: prior.rvs(m, np.random.default_rng(0)))
+    like = lambda x: -0.5 * np.sum(((x - 0.3) / 0.8) ** 2, axis=1) - 0.1 * x[:, 0] ** 4
+    s = pc.Sampler(prior=P, likelihood=like, vectorize=True, flow=flow, random_state=0, n_effective=256, n_active=128)
+    s.scaler.fit(g[f"{tag}/x_fit"])
+    s.pbar = _Progress(False)
+    m = int(g[f"{tag}/calls"])
+    np.random.seed(seed)
+    draws = np.stack([np.random.choice(m, m) for _ in range(max(n, 1000))])
+    logz, dlogz = s._compute_evidence(replay=dict(z=g[f"{tag}/z"], draws=draws))
+    assert s.calls == m < n
+    tol = 5e-5 if rqs else 1e-5
+    assert abs(logz - float(g[f"{tag}/logz"])) <= tol * max(abs(float(g[f"{tag}/logz"])), 30.0), (logz, g[f"{tag}/logz"])
+    assert abs(dlogz - float(g[f"{tag}/dlogz"])) <= 1e-3 * float(g[f"{tag}/dlogz"]), (dlogz, g[f"{tag}/dlogz"])

@@ -17,7 +17,7 @@ from pocomc_amd.maf_spec import MAFSpec
 
 @pytest.fixture(scope="module")
 def gold(golden_dir):
-    return {k: np.load(os.path.join(golden_dir, f"{k}_reference.npz")) for k in ("mcmc", "scaler", "tools")}
+    return {k: np.load(os.path.join(golden_dir, f"{k}_reference.npz")) for k in ("mcmc", "scaler", "tools", "mcmc_big", "sampler")}
 
 
 # ----------------------------------------------------------------- MCMC kernels
@@ -43,6 +43,28 @@ def test_mcmc_kernels_match_reference(gold, name, exact):
             np.testing.assert_allclose(res[k], g[f"{tag}/{k}"], err_msg=f"{tag}/{k}", **tol)
         for k in ("efficiency", "accept", "proposal_scale"):
             np.testing.assert_allclose(res[k], g[f"{tag}/{k}"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", list(cases.BIG_GOLDEN_CASES))
+def test_one_step_calls_at_baseline_size_match_reference(gold, name):
+    """BASELINE's size (1e4 x 32), one step, affine and spline flow: the oracle's vectorised kernel against the row
+    subsample of the reference's output (every walker's step depends on its own row only)."""
+    g = gold["mcmc_big"]
+    c = cases.BIG_GOLDEN_CASES[name]
+    state, funcs, opts, aux = cases.build_case(name, Reparameterize)
+    sl = slice(None, None, c["stride"])
+    tag = f"mcmc_big/{name}"
+    for k in ("u", "x", "logdetj", "logl", "logp"):
+        np.testing.assert_allclose(state[k][sl], g[f"{tag}/in/{k}"], rtol=1e-13, atol=1e-13)
+    funcs["flow"] = TorchFlowAdapter(OracleMAF(aux["spec"], aux["flat"]))
+    opts["n_max"] = 1
+    np.random.seed(c["seed"])
+    res = omcmc.preconditioned_pcn(state, funcs, opts, exact=False)
+    assert res["steps"] == int(g[f"{tag}/steps"]) and res["calls"] == int(g[f"{tag}/calls"])
+    for k in ("u", "x", "logdetj", "logl", "logp"):
+        np.testing.assert_allclose(res[k][sl], g[f"{tag}/{k}"], rtol=1e-11, atol=1e-11, err_msg=k)
+    for k in ("efficiency", "accept", "proposal_scale"):
+        np.testing.assert_allclose(res[k], g[f"{tag}/{k}"], rtol=1e-12)
 
 
 def test_replay_reproduces_stream(gold):
@@ -150,6 +172,58 @@ def test_geometry_matches_reference(gold):
     np.testing.assert_allclose(G2.t_cov, g["geometry/w_t_cov"], rtol=1e-12)
     np.testing.assert_allclose(G2.t_nu, g["geometry/w_t_nu"], rtol=1e-12)
     np.testing.assert_allclose(G2.normal_cov, g["geometry/w_normal_cov"], rtol=1e-13)
+
+
+# ------------------------------------------------- orchestrator: Sampler._compute_evidence
+@pytest.mark.parametrize("name", ["maf3_d5", "nsf3_d4"])
+def test_evidence_oracle_matches_reference(gold, name):
+    """``oracle/evidence.py`` against ``Sampler._compute_evidence`` of the reference itself (``sampler.py:869-920`` called
+    unbound by ``make_golden.py``; same base draw, same legacy-stream seed for the bootstrap)."""
+    from oracle.evidence import compute_evidence
+    g = gold["sampler"]
+    tag = f"evidence/{name}"
+    Dn, Tn, rqs, n, seed = (int(v) for v in g[f"{tag}/spec"])
+    spec = MAFSpec(Dn, Tn, univariate="rqs" if rqs else "affine")
+    maf = OracleMAF(spec, cases.flow_params(spec, seed, gain=1.0))
+    prior = cases.CutPrior(Dn)
+    sc = Reparameterize(Dn, prior.bounds)
+    sc.fit(g[f"{tag}/x_fit"])
+    like = lambda x: -0.5 * np.sum(((x - 0.3) / 0.8) ** 2, axis=1) - 0.1 * x[:, 0] ** 4
+    logz, dlogz, draws, logw = compute_evidence(maf, sc, prior.logpdf, like, g[f"{tag}/z"], seed=seed)
+    assert len(logw) == int(g[f"{tag}/calls"]) < n                 # part of the draws fell outside the prior's support
+    np.testing.assert_allclose(logz, g[f"{tag}/logz"], rtol=1e-13)
+    np.testing.assert_allclose(dlogz, g[f"{tag}/dlogz"], rtol=1e-12)
+
+
+# ------------------------------------------------- flow: masks, the reference's properties
+@pytest.mark.parametrize("D,T,H,uni", [(2, 2, None, "affine"), (4, 3, None, "affine"), (10, 3, None, "rqs"), (32, 3, None, "affine"),
+                                       (50, 6, None, "affine"), (7, 2, 6, "rqs"), (9, 4, 19, "affine"), (128, 2, None, "affine")])
+def test_oracle_masks_equal_the_product_masks(D, T, H, uni):
+    """The oracle builds its masks from zuko's recipe (adjacency -> unique rows -> precedence, ``oracle.maf.zuko_masks``),
+    the product from the closed form ``degree(k) = 1 + k mod (D - 1)`` (``MAFSpec.masks``): two constructions, one result."""
+    from oracle.maf import zuko_masks
+    spec = MAFSpec(D, T, hidden=H, univariate=uni)
+    for t in range(T):
+        order = np.arange(D) if t % 2 == 0 else np.arange(D)[::-1]
+        assert np.array_equal(order, spec.orders[t])
+        for a, b in zip(zuko_masks(order, spec.n_out, spec.hidden), spec.masks(t)):
+            assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_float64_yardstick_of_the_oracle():
+    """``OracleMAF(dtype=float64)``: the same float32 parameters, float64 arithmetic -- float32 and float64 evaluations
+    agree to float32 rounding times the conditioning (affine: ~1e-6; spline: ~1e-5, the knot differences cancel)."""
+    for uni, tol in (("affine", 5e-6), ("rqs", 1e-4)):
+        spec = MAFSpec(6, 3, univariate=uni)
+        flat = cases.flow_params(spec, 2)
+        o32, o64 = OracleMAF(spec, flat), OracleMAF(spec, flat, dtype=np.float64)
+        x = (np.random.default_rng(0).normal(size=(64, 6)) * 2.0).astype(np.float32)
+        z32, l32 = o32.forward(x)
+        z64, l64 = o64.forward(x)
+        assert z32.dtype == np.float32 and z64.dtype == np.float64 and l64.dtype == np.float64
+        assert (np.abs(z32 - z64).max(axis=1) / np.abs(z64).max(axis=1)).max() < tol
+        xi64, li64 = o64.inverse(z64)
+        assert np.abs(xi64 - x).max() < 1e-9 and np.abs(li64 + l64).max() < 1e-9      # the float64 round trip is exact to 1e-9
 
 
 # ------------------------------------------------- flow: the reference's properties
