@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PMC_ABI_VERSION 4
+#define PMC_ABI_VERSION 5
 
 const char* pmc_last_error(void);
 int pmc_abi_version(void);
@@ -47,6 +47,11 @@ typedef struct pmc_maf {
     int64_t pk_per_transform;
     int32_t tri_ok;           /* every degree group fits one 16-slot tile */
     int32_t n_out;            /* hyper-network outputs per feature: 2 = affine (MAF), 23 = 8-bin spline (NSF) */
+    const uint16_t* lane16;   /* NULL, or the 16-bit image of the lane-per-walker sweep's helper fragments (pmc_maf_pack_lane16):
+                               * the inverse of the wide flows then multiplies everything left of the diagonal tile with 16-bit
+                               * operands and float32 accumulation -- an opt-in precision, see PMC_INVERSE_TRIANGULAR_LANE16 */
+    int32_t lane16_fmt;       /* 1 bfloat16, 2 float16 (0: no image) */
+    int32_t reserved;
 } pmc_maf_t;
 
 #define PMC_INVERSE_AUTO 0
@@ -54,6 +59,12 @@ typedef struct pmc_maf {
 #define PMC_INVERSE_NAIVE 2        /* the reference's D fixed-point passes (zuko) */
 #define PMC_INVERSE_TRIANGULAR_SOLO 6 /* the D <= 64 sweep, one wavefront per 16 rows: the left-looking cross-check of the two-wave sweeps (affine and spline flows) */
 #define PMC_INVERSE_TRIANGULAR_LANE 8 /* lane-per-walker chain wavefront + three or four helper wavefronts per 16-64 rows (AUTO: affine flows with >= 16 hidden tiles or D > 64) */
+#define PMC_INVERSE_TRIANGULAR_LANE16 9 /* the lane-per-walker sweep with 16-bit helper operands (pmc_maf_t.lane16 required): the chain --
+                                        * diagonal tiles, newest ranks, univariate map, log-determinant -- stays float32, the
+                                        * left-looking products of the three helper wavefronts run on v_mfma_f32_16x16x16_bf16 / _f16
+                                        * with float32 accumulation; two walker subsets share a workgroup at D = 128 (BASELINE config
+                                        * 5: 5000 walkers in one round).  AUTO takes it when the image is attached and the flow is
+                                        * one the lane sweep is preferred for; _LANE (8) always multiplies in float32 */
 #define PMC_INVERSE_TRIANGULAR_DUO 7  /* the same sweep with a second, burst wavefront per 16 rows, right-looking (AUTO: affine flows of < 16 hidden tiles, spline flows with D <= 64) */
 
 /* packed[i] = idx[i] >= 0 ? flat[idx[i]] : 0   (canonical fp32 params -> kernel layout) */
@@ -79,6 +90,12 @@ int pmc_maf_forward_bf16(const pmc_maf_t* m, const uint16_t* image, int64_t imag
  * inverse map.  z,x f32 [n][D]; ladj f32 [n] or NULL. */
 int pmc_maf_inverse(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
                     int algo, void* stream);
+
+/* 16-bit helper image of the lane-per-walker inverse sweep (Flow.inverse of the wide flows, flow.py:116-132, in the opt-in
+ * precision of BASELINE config 5): image u16 [pmc_maf_lane16_elems(m)], derived on the device from m->packed (call again
+ * after every pmc_maf_pack); fmt 1 = bfloat16, 2 = float16, round to nearest even.  Attach it as m->lane16 / lane16_fmt. */
+int64_t pmc_maf_lane16_elems(const pmc_maf_t* m);
+int pmc_maf_pack_lane16(const pmc_maf_t* m, int fmt, uint16_t* image, void* stream);
 
 /* Training-side device image (host side: MAFSpec.train_index()).  The loss/gradient kernel
  * gives every workgroup a private gradient slab in tile order and a scratch copy of each

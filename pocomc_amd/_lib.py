@@ -21,7 +21,8 @@ class pmc_maf_t(C.Structure):
                 ("Hp", C.c_int32), ("Dp", C.c_int32),
                 ("nT", C.c_int32), ("nXT", C.c_int32), ("nOT", C.c_int32),
                 ("pk_per_transform", C.c_int64),
-                ("tri_ok", C.c_int32), ("n_out", C.c_int32)]
+                ("tri_ok", C.c_int32), ("n_out", C.c_int32),
+                ("lane16", c_p), ("lane16_fmt", C.c_int32), ("reserved", C.c_int32)]
 
 
 class pmc_maf_train_t(C.Structure):
@@ -115,6 +116,8 @@ SIGNATURES = {
     "pmc_maf_pack_bf16": (C.c_int, [c_p, c_p, c_p, i64, c_p]),
     "pmc_maf_forward_bf16": (C.c_int, [P(pmc_maf_t), c_p, i64, c_p, c_p, c_p, c_p, i64, c_p, c_p]),
     "pmc_maf_inverse": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, i64, C.c_int, c_p]),
+    "pmc_maf_lane16_elems": (C.c_int64, [P(pmc_maf_t)]),
+    "pmc_maf_pack_lane16": (C.c_int, [P(pmc_maf_t), C.c_int, c_p, c_p]),
     "pmc_maf_loss_grad": (C.c_int, [P(pmc_maf_t), P(pmc_maf_train_t), c_p, c_p, c_p, C.c_float, c_p, c_p, i64, c_p]),
     "pmc_maf_train_epoch": (C.c_int, [P(pmc_maf_t), P(pmc_maf_train_t), P(pmc_adamw_t), c_p, c_p, c_p, i64, i64, c_p,
                                       c_p]),
@@ -213,7 +216,7 @@ def load():
         fn = getattr(lib, name)            # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.pmc_abi_version() != 4:
+    if lib.pmc_abi_version() != 5:
         raise PocomcAmdError("libpocomc_amd.so: ABI version mismatch")
     _lib = lib
     return lib

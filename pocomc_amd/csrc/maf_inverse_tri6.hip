@@ -65,6 +65,103 @@ __device__ __forceinline__ void sfor(F&& f) {
     }
 }
 
+// ---- operand types of the helper wavefronts' left-looking products ---------------------------------------------------
+// HB = 0: float32 (v_mfma_f32_16x16x4_f32 x 4 per 16 x 16 block; fragments [lane][4] floats, activations float32 in LDS).
+// HB = 1 / 2: bfloat16 / float16 operands, float32 accumulation (v_mfma_f32_16x16x16_bf16 / _f16, ONE per 16 x 16 block:
+// ~16 cycles of matrix pipe against 128): the 16-bit image pmc_maf_pack_lane16 derives from the float32 fragments
+// (pmc_maf_t.lane16: lane l = row l & 15, k = 4 (l >> 4) .. + 3, 8 bytes per lane and block) and activations the chain
+// wavefront stores as 16-bit quads (lane (c, p) of a tile = units 4 c .. 4 c + 3 of walker p: half the LDS, which is what
+// lets a second walker subset share the workgroup at D = 128).  The CHAIN stays float32 whatever HB: the diagonal tile of
+// the hidden layers, the layer-0 columns of the newest ranks, the own output rows, the univariate map, the log-determinant;
+// so do the layer-0 partials (x is float32).  Opt-in precision (Flow(precision="bf16")), stated tolerance in the tests.
+typedef short s16x4_t6 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x4_t6 __attribute__((ext_vector_type(4)));
+typedef __bf16 b16x2_t6 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x2_t6 __attribute__((ext_vector_type(2)));
+typedef float f32x2_t6 __attribute__((ext_vector_type(2)));
+typedef __bf16 b16x8_t6 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x8_t6 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint2 bload2u(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    const u32x2_t6 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    return make_uint2(v.x, v.y);
+}
+
+__device__ __forceinline__ uint4 bload4u(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// Fragment rows: a row of k tiles is k blocks of 1 KiB (float32), or ceil(k / 2) PAIRS of 1 KiB with 16-bit operands -- lane
+// (c, i) of a pair holds W[i][4 c .. 4 c + 3] of tile 2 b in its first 8 bytes and of tile 2 b + 1 in the next 8, so that ONE
+// 16-byte load per lane feeds two tiles' MFMAs.  (scripts/micro/load_latency.hip: with two or more wavefronts of a CU
+// loading, a wavefront gets one buffer load back per ~90-110 cycles WHATEVER its width, 8 or 16 bytes per lane -- the
+// helpers' 16-bit products are paced by the NUMBER of load instructions, not by bytes or by the matrix pipe.)
+template <int HB> struct Ops;
+template <> struct Ops<0> {
+    using W = float4;
+    static constexpr int BLK = 1024;                      // bytes of one 16 x 16 fragment block
+    static constexpr int TF = 256;                        // floats of one tile of an activation array (per subset)
+    static __device__ __forceinline__ int row_bytes(int tiles) { return tiles << 10; }
+    static __device__ __forceinline__ int act_floats(int tiles) { return tiles << 8; }
+    static __device__ __forceinline__ W zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ W loadw(__amdgpu_buffer_rsrc_t rs, int lane, int soff) { return bload4(rs, lane << 4, soff); }
+    static __device__ __forceinline__ W loadw_tile(__amdgpu_buffer_rsrc_t rs, int lane, int rowbase, int t) { return bload4(rs, lane << 4, rowbase + (t << 10)); }
+    static __device__ __forceinline__ W loadb(const float* H, int K, int lane) {
+        return *reinterpret_cast<const float4*>(H + (K << 8) + (lane << 2));
+    }
+    static __device__ __forceinline__ void mma(f32x4& acc, f32x4& acd, const W& w, const W& b, int) {
+        acc = MFMA(w.x, b.x, acc); acd = MFMA(w.y, b.y, acd);
+        acc = MFMA(w.z, b.z, acc); acd = MFMA(w.w, b.w, acd);
+    }
+};
+template <int HB> struct Ops {
+    using W = uint2;                                      // a single tile's fragment / B operand (half of a pair's 16 bytes)
+    static constexpr int TF = 128;                        // floats per tile of an activation array: pairs of tiles are 256
+    static __device__ __forceinline__ int row_bytes(int tiles) { return ((tiles + 1) >> 1) << 10; }
+    static __device__ __forceinline__ int act_floats(int tiles) { return ((tiles + 1) >> 1) << 8; }
+    static __device__ __forceinline__ W zero() { return make_uint2(0u, 0u); }
+    static __device__ __forceinline__ W loadw_tile(__amdgpu_buffer_rsrc_t rs, int lane, int rowbase, int t) {
+        return bload2u(rs, (lane << 4) + ((t & 1) << 3), rowbase + ((t >> 1) << 10));
+    }
+    // activations: [pair of tiles][lane (c, p)][tile 2 b: units 4 c .. 4 c + 3 | tile 2 b + 1: the same] -- 16 bytes per lane
+    static __device__ __forceinline__ W loadb(const float* H, int t, int lane) {
+        return *reinterpret_cast<const uint2*>(H + ((t >> 1) << 8) + (lane << 2) + ((t & 1) << 1));
+    }
+    static __device__ __forceinline__ uint4 loadb_pair(const float* H, int pair, int lane) {
+        return *reinterpret_cast<const uint4*>(H + (pair << 8) + (lane << 2));
+    }
+    static __device__ __forceinline__ f32x4 mfma16(const W& w, const W& b, f32x4 c) {
+        if constexpr (HB == 1)
+            return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<const s16x4_t6*>(&w), *reinterpret_cast<const s16x4_t6*>(&b), c, 0, 0, 0);
+        else
+            return __builtin_amdgcn_mfma_f32_16x16x16f16(*reinterpret_cast<const h16x4_t6*>(&w), *reinterpret_cast<const h16x4_t6*>(&b), c, 0, 0, 0);
+    }
+    // a pair of tiles in one instruction: k = 8 c + j  <->  tile 2 b + (j >> 2), unit 4 c + (j & 3), the same in A and B
+    static __device__ __forceinline__ f32x4 mfma32(const uint4& w, const uint4& b, f32x4 c) {
+        if constexpr (HB == 1)
+            return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const b16x8_t6*>(&w), *reinterpret_cast<const b16x8_t6*>(&b), c, 0, 0, 0);
+        else
+            return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const h16x8_t6*>(&w), *reinterpret_cast<const h16x8_t6*>(&b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma(f32x4& acc, f32x4& acd, const W& w, const W& b, int j) {
+        if (j & 1) acd = mfma16(w, b, acd); else acc = mfma16(w, b, acc);
+    }
+};
+// the chain's store of one quad (units 4 c .. 4 c + 3 of its walker) of a hidden tile as 16-bit values: 8 bytes
+template <int HB>
+__device__ __forceinline__ void store_quad16(float* H, int T, int c, int p, const f32x4& v) {
+    uint2 w;
+    if constexpr (HB == 1) {
+        const b16x2_t6 a = __builtin_convertvector(f32x2_t6{v[0], v[1]}, b16x2_t6), b = __builtin_convertvector(f32x2_t6{v[2], v[3]}, b16x2_t6);
+        w.x = *reinterpret_cast<const unsigned*>(&a); w.y = *reinterpret_cast<const unsigned*>(&b);
+    } else {
+        const h16x2_t6 a = __builtin_convertvector(f32x2_t6{v[0], v[1]}, h16x2_t6), b = __builtin_convertvector(f32x2_t6{v[2], v[3]}, h16x2_t6);
+        w.x = *reinterpret_cast<const unsigned*>(&a); w.y = *reinterpret_cast<const unsigned*>(&b);
+    }
+    *reinterpret_cast<uint2*>(H + ((T >> 1) << 8) + (((c << 4) + p) << 2) + ((T & 1) << 1)) = w;
+}
+
 // ---- LDS words ----------------------------------------------------------------------------------------------------
 enum { F_H0 = 0, F_H1, F_H2, F_X, F_P0, F_P1, F_P2, F_P3, F_COUNT = 8 };
 
@@ -81,8 +178,12 @@ __device__ __forceinline__ void publish(int* flags, int which, int value) {
     asm volatile("" ::: "memory");                       // data stores stay before the word's store (DS ops are in order)
     *lds_word(flags, which) = value;
 }
+// NAP: the helper wavefronts' polls sleep between two looks (s_sleep 1 = 64 cycles).  With 16-bit operands a helper is done
+// with its row thousands of cycles before the chain publishes the next tile; three wavefronts polling back to back put an
+// LDS instruction in front of every DS operation of the chain (measured: chain tile 4.3 k -> 5.3 k cycles)
+template <bool NAP = false>
 __device__ __forceinline__ void wait_for(const int* flags, int which, int value) {
-    while (peek(flags, which) < value) {}                 // (an LDS round trip per poll is pause enough)
+    while (peek(flags, which) < value) { if constexpr (NAP) __builtin_amdgcn_s_sleep(1); }
     asm volatile("" ::: "memory");
 }
 
@@ -95,6 +196,29 @@ struct ChainState {
     float yv[4];
     int g[4];
 };
+
+// the chain's store of x_g: float32 over y_g IN PLACE (the array holds the transform's input by rank; a rank's y is read
+// before its x is written, and what the layer-0 helper multiplies of the ranks not solved yet meets zero weights only: f0c),
+// and, with 16-bit helpers, one element of the 16x16x16 B layout the layer-0 helper reads (lane ((g & 15) >> 2, p) of tile
+// g >> 4, element g & 3)
+template <int HB>
+__device__ __forceinline__ void store_x(float* A, float* X16, int g, int p, float v) {
+    A[lidx(g, p)] = v;
+    if constexpr (HB != 0) {
+        unsigned short h;
+        if constexpr (HB == 1) { const __bf16 b = (__bf16)v; h = *reinterpret_cast<const unsigned short*>(&b); }
+        else { const _Float16 b = (_Float16)v; h = *reinterpret_cast<const unsigned short*>(&b); }
+        reinterpret_cast<unsigned short*>(X16)[((((g >> 5) << 6) + (((g & 15) >> 2) << 4) + p) << 3) + (((g >> 4) & 1) << 2) + (g & 3)] = h;
+    }
+}
+// groups of a tile from its four quad degrees (rank words): s.g[i] = rank of group i, D = no such group
+__device__ __forceinline__ void tile_groups(const int4& dg, int D, int (&g)[4]) {
+    const bool ny = dg.y != dg.x, nz = dg.z != dg.y, nw = dg.w != dg.z;
+    g[0] = dg.x;
+    g[1] = ny ? dg.y : (nz ? dg.z : (nw ? dg.w : D));
+    g[2] = ny ? (nz ? dg.z : (nw ? dg.w : D)) : ((nz && nw) ? dg.w : D);
+    g[3] = (ny && nz && nw) ? dg.w : D;
+}
 
 // Speculative hand-over read: the word and the staged data are read in ONE LDS round trip (DS operations of a wave
 // execute in order and the writer stored the data before the word, so data read after a word that already shows
@@ -126,47 +250,43 @@ __device__ __forceinline__ void take(const int* flags, int which, int value, LOA
 // set's loads down to the stage that multiplies them.
 // PRE: the caller requested the row's first two chunks into w0 / w1 already (first_chunks() below: the hidden-layer helpers
 // do it for their NEXT row while they wait for the last input tile of the current one).
+// ---- float32 fragments: chunks of C tiles, three register sets in rotation (see the comment above)
 template <int C>
-__device__ __forceinline__ void first_chunks(float4 (&w0)[C], float4 (&w1)[C], __amdgpu_buffer_rsrc_t rs, int vo_lane, int base,
-                                             int Kn) {
+__device__ __forceinline__ void first_chunks32(float4 (&w0)[C], float4 (&w1)[C], __amdgpu_buffer_rsrc_t rs, int lane, int base, int Kn) {
 #pragma unroll
-    for (int j = 0; j < C; ++j) w0[j] = bload4(rs, vo_lane + j * 1024, base);
+    for (int j = 0; j < C; ++j) w0[j] = bload4(rs, lane << 4, base + j * 1024);
     const int so = base + ((C < Kn ? C : 0) << 10);
 #pragma unroll
-    for (int j = 0; j < C; ++j) w1[j] = bload4(rs, vo_lane + j * 1024, so);
+    for (int j = 0; j < C; ++j) w1[j] = bload4(rs, lane << 4, so + j * 1024);
 }
 template <int NS, int C, bool PRE, class READY>
-__device__ __forceinline__ void left_products_w(f32x4 (&acc)[NS], f32x4 (&acd)[NS], __amdgpu_buffer_rsrc_t rs, int vo_lane,
-                                                int base, const float* Hin, int szH, int Kn, int lane, float4 (&w0)[C],
-                                                float4 (&w1)[C], READY&& ready) {
+__device__ __forceinline__ void left32_w(f32x4 (&acc)[NS], f32x4 (&acd)[NS], __amdgpu_buffer_rsrc_t rs, int base,
+                                         const float* Hin, int szH, int Kn, int lane, float4 (&w0)[C], float4 (&w1)[C], READY&& ready) {
     if (Kn <= 0) return;
+    using O = Ops<0>;
     float4 w2[C], b0[C][NS], b1[C][NS], b2[C][NS];
-    const float* hl = Hin + (lane << 2);
     // chunk at tile Kc (a chunk that starts beyond the row is not used: tile 0 instead, always inside the arrays)
     auto loadw = [&](float4 (&w)[C], int Kc) __attribute__((always_inline)) {
         const int so = base + ((Kc < Kn ? Kc : 0) << 10);
 #pragma unroll
-        for (int j = 0; j < C; ++j) w[j] = bload4(rs, vo_lane + j * 1024, so);
+        for (int j = 0; j < C; ++j) w[j] = bload4(rs, lane << 4, so + j * 1024);
     };
     auto loadb = [&](float4 (&b)[C][NS], int Kc) __attribute__((always_inline)) {
-        const float* hk = hl + ((Kc < Kn ? Kc : 0) << 8);
+        const int K0 = Kc < Kn ? Kc : 0;
 #pragma unroll
         for (int j = 0; j < C; ++j)
 #pragma unroll
-            for (int sb = 0; sb < NS; ++sb) b[j][sb] = *reinterpret_cast<const float4*>(hk + sb * szH + j * 256);
+            for (int sb = 0; sb < NS; ++sb) b[j][sb] = O::loadb(Hin + sb * szH, K0 + j, lane);
     };
-    auto mma1 = [&](const float4& w, const float4 (&b)[NS]) __attribute__((always_inline)) {
+    auto mma1 = [&](const float4& w, const float4 (&b)[NS], int j) __attribute__((always_inline)) {
 #pragma unroll
-        for (int sb = 0; sb < NS; ++sb) {
-            acc[sb] = MFMA(w.x, b[sb].x, acc[sb]); acd[sb] = MFMA(w.y, b[sb].y, acd[sb]);
-            acc[sb] = MFMA(w.z, b[sb].z, acc[sb]); acd[sb] = MFMA(w.w, b[sb].w, acd[sb]);
-        }
+        for (int sb = 0; sb < NS; ++sb) O::mma(acc[sb], acd[sb], w, b[sb], j);
     };
 #define STAGE(LW, LB, MW, MB)                                                                                       \
         loadw(LW, K0 + 2 * C); loadb(LB, K0 + 2 * C);                                                               \
         asm volatile("" ::: "memory");                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
-        _Pragma("unroll") for (int j = 0; j < C; ++j) mma1(MW[j], MB[j]);                                           \
+        _Pragma("unroll") for (int j = 0; j < C; ++j) mma1(MW[j], MB[j], j);                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
         K0 += C;
     if constexpr (!PRE) { loadw(w0, 0); loadw(w1, C); }
@@ -186,18 +306,114 @@ __device__ __forceinline__ void left_products_w(f32x4 (&acc)[NS], f32x4 (&acd)[N
         asm volatile("" ::: "memory");
     }
 #pragma unroll
-    for (int j = 0; j < C; ++j) if (K0 + j < Kn) mma1(w0[j], b0[j]);
+    for (int j = 0; j < C; ++j) if (K0 + j < Kn) mma1(w0[j], b0[j], j);
 #pragma unroll
-    for (int j = 0; j < C; ++j) if (K0 + C + j < Kn) mma1(w1[j], b1[j]);
+    for (int j = 0; j < C; ++j) if (K0 + C + j < Kn) mma1(w1[j], b1[j], j);
 #pragma unroll
-    for (int j = 0; j < C; ++j) if (K0 + 2 * C + j < Kn) mma1(w2[j], b2[j]);
+    for (int j = 0; j < C; ++j) if (K0 + 2 * C + j < Kn) mma1(w2[j], b2[j], j);
 }
 
-template <int NS, int C, class READY>
-__device__ __forceinline__ void left_products(f32x4 (&acc)[NS], f32x4 (&acd)[NS], __amdgpu_buffer_rsrc_t rs, int vo_lane,
-                                              int base, const float* Hin, int szH, int Kn, int lane, READY&& ready) {
-    float4 w0[C], w1[C];
-    left_products_w<NS, C, false>(acc, acd, rs, vo_lane, base, Hin, szH, Kn, lane, w0, w1, ready);
+// ---- 16-bit fragments: the same rotation over chunks of C PAIRS of tiles; tiles [K0, K1) of the row at `rowbase`
+template <int C>
+__device__ __forceinline__ void first_chunks16(uint4 (&w0)[C], uint4 (&w1)[C], __amdgpu_buffer_rsrc_t rs, int lane, int rowbase, int K1) {
+    const int p1 = K1 >> 1;                               // (full pairs of the range [0, K1))
+#pragma unroll
+    for (int j = 0; j < C; ++j) w0[j] = bload4u(rs, lane << 4, rowbase + j * 1024);
+    const int so = rowbase + ((C < p1 ? C : 0) << 10);
+#pragma unroll
+    for (int j = 0; j < C; ++j) w1[j] = bload4u(rs, lane << 4, so + j * 1024);
+}
+template <int HB, int NS, int C, bool PRE, class READY>
+__device__ __forceinline__ void left16_w(f32x4 (&acc)[NS], f32x4 (&acd)[NS], __amdgpu_buffer_rsrc_t rs, int rowbase,
+                                         const float* Hin, int szH, int K0, int K1, int lane, uint4 (&w0)[C], uint4 (&w1)[C],
+                                         READY&& ready) {
+    if (K1 <= K0) return;
+    using O = Ops<HB>;
+    // the range as  [a leading single tile]  full pairs [pf0, pf1)  [a trailing single tile]: a full pair is ONE 16-byte
+    // fragment load, one 16-byte LDS read per subset and one v_mfma_f32_16x16x32 per subset -- no per-tile scalar work (a lone
+    // wavefront issues an instruction per ~5 cycles and a 16-bit MFMA no longer hides any: the loop's instruction count is
+    // its time)
+    const bool lead = (K0 & 1) != 0;                      // tile K0 = second half of pair K0 >> 1
+    const int pf0 = (K0 + 1) >> 1, pf1 = K1 >> 1;
+    const bool trail = (K1 & 1) != 0 && !(lead && K1 - 1 == K0);      // tile K1 - 1 = first half of pair pf1
+    uint2 wl = make_uint2(0u, 0u), wt = make_uint2(0u, 0u);
+    if (lead) wl = O::loadw_tile(rs, lane, rowbase, K0);
+    if (trail) wt = O::loadw_tile(rs, lane, rowbase, K1 - 1);
+    const int np = pf1 > pf0 ? pf1 - pf0 : 0;
+    uint4 w2[C], b0[C][NS], b1[C][NS], b2[C][NS];
+    // chunk at pair pc (a chunk that starts beyond the range is not used: pair 0 of the row instead, always inside the image;
+    // pairs of a chunk beyond pf1 are loaded and never multiplied)
+    auto loadw = [&](uint4 (&w)[C], int pc) __attribute__((always_inline)) {
+        const int so = rowbase + ((pc < pf1 ? pc : 0) << 10);
+#pragma unroll
+        for (int j = 0; j < C; ++j) w[j] = bload4u(rs, lane << 4, so + j * 1024);
+    };
+    auto loadb = [&](uint4 (&b)[C][NS], int pc) __attribute__((always_inline)) {
+        const float* hk = Hin + ((pc < pf1 ? pc : 0) << 8);
+#pragma unroll
+        for (int j = 0; j < C; ++j)
+#pragma unroll
+            for (int sb = 0; sb < NS; ++sb) b[j][sb] = O::loadb_pair(hk + sb * szH, j, lane);
+    };
+    auto mma1 = [&](const uint4& w, const uint4 (&b)[NS], int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int sb = 0; sb < NS; ++sb) {
+            if (j & 1) acd[sb] = O::mfma32(w, b[sb], acd[sb]); else acc[sb] = O::mfma32(w, b[sb], acc[sb]);
+        }
+    };
+#define STAGE(LW, LB, MW, MB)                                                                                       \
+        loadw(LW, P + 2 * C); loadb(LB, P + 2 * C);                                                                 \
+        asm volatile("" ::: "memory");                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        _Pragma("unroll") for (int j = 0; j < C; ++j) mma1(MW[j], MB[j], j);                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        P += C;
+    if constexpr (!PRE) { if (np > 0) { loadw(w0, pf0); loadw(w1, pf0 + C); } }
+    asm volatile("" ::: "memory");
+    ready();                                              // (the wait for the tiles' word, behind the first fragments' loads)
+    if (np > 0) {
+        loadb(b0, pf0); loadb(b1, pf0 + C);
+        asm volatile("" ::: "memory");
+        int P = pf0;
+        for (int it = (np / C) / 3; it > 0; --it) {
+            STAGE(w2, b2, w0, b0)
+            STAGE(w0, b0, w1, b1)
+            STAGE(w1, b1, w2, b2)
+        }
+        if (P + 2 * C < pf1) {                            // the third chunk of the rest
+            loadw(w2, P + 2 * C); loadb(b2, P + 2 * C);
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < C; ++j) if (P + j < pf1) mma1(w0[j], b0[j], j);
+#pragma unroll
+        for (int j = 0; j < C; ++j) if (P + C + j < pf1) mma1(w1[j], b1[j], j);
+#pragma unroll
+        for (int j = 0; j < C; ++j) if (P + 2 * C + j < pf1) mma1(w2[j], b2[j], j);
+    }
+#undef STAGE
+    if (lead) {
+#pragma unroll
+        for (int sb = 0; sb < NS; ++sb) acc[sb] = O::mfma16(wl, O::loadb(Hin + sb * szH, K0, lane), acc[sb]);
+    }
+    if (trail) {
+#pragma unroll
+        for (int sb = 0; sb < NS; ++sb) acd[sb] = O::mfma16(wt, O::loadb(Hin + sb * szH, K1 - 1, lane), acd[sb]);
+    }
+}
+
+// acc/acd[sb] += sum_{K in [K0, K1)} frag[row][K] . H[sb][K]   (rowbase: byte offset of the row's first block / pair; Hin: tile 0
+// of subset 0; every tile of the range final when `ready` returns).  C: tiles (float32) / pairs (16-bit) per chunk.
+template <int HB, int NS, int C, class READY>
+__device__ __forceinline__ void left_products(f32x4 (&acc)[NS], f32x4 (&acd)[NS], __amdgpu_buffer_rsrc_t rs, int rowbase,
+                                              const float* Hin, int szH, int K0, int K1, int lane, READY&& ready) {
+    if constexpr (HB == 0) {
+        float4 w0[C], w1[C];
+        left32_w<NS, C, false>(acc, acd, rs, rowbase + (K0 << 10), Hin + (K0 << 8), szH, K1 - K0, lane, w0, w1, ready);
+    } else {
+        uint4 w0[C], w1[C];
+        left16_w<HB, NS, C, false>(acc, acd, rs, rowbase, Hin, szH, K0, K1, lane, w0, w1, ready);
+    }
 }
 
 // One degree group of the tile (quads c0..c1), then the next (compile-time recursion over the quad pattern).
@@ -205,10 +421,10 @@ __device__ __forceinline__ void left_products(f32x4 (&acc)[NS], f32x4 (&acd)[NS]
 // and the group's critical path is  h0 -> [own block of layer 1] -> h1 -> [own block of layer 2] -> h2 -> [own output
 // rows] -> x -> [layer-0 column of the next quad].  The blocks that feed LATER quads are issued in the gaps the VALU
 // epilogues of that path leave (about four MFMAs each); what does not fit follows at the end of the group.
-template <int PAT, int I>
-__device__ __forceinline__ void chain_group6(ChainState& s, float* H0, float* H1, float* H2, float* X, int* flags,
+template <int PAT, int I, int HB>
+__device__ __forceinline__ void chain_group6(ChainState& s, float* H0, float* H1, float* H2, float* X, float* X16, int* flags,
                                              const float* SP1, const float* SP2, const float* SP3, int T, int D,
-                                             int gen, int sub_off_sp, int p, bool writer, float& ladj) {
+                                             int gen, int sub_off_sp, int sp3_rows, int p, bool writer, float& ladj) {
     constexpr int NG = pat_ngroups(PAT);
     if constexpr (I < NG) {
         constexpr int c0 = pat_start(PAT, I), c1 = pat_end(PAT, I);
@@ -234,7 +450,10 @@ __device__ __forceinline__ void chain_group6(ChainState& s, float* H0, float* H1
         sfor<c0, c1 + 1>([&](auto cc) __attribute__((always_inline)) {
             constexpr int c = decltype(cc)::value;
             for (int r = 0; r < 4; ++r) h0[c][r] = fmaxf(s.a0[c][r], 0.0f);
-            if (writer) for (int r = 0; r < 4; ++r) H0[hw + (r << 6) + c] = h0[c][r];
+            if (writer) {
+                if constexpr (HB == 0) { for (int r = 0; r < 4; ++r) H0[hw + (r << 6) + c] = h0[c][r]; }
+                else store_quad16<HB>(H0, T, c, p, h0[c]);
+            }
         });
         if constexpr (last) publish(flags, F_H0, gen + T + 1);
         if constexpr (I == 0) {                           // partial pre-activations of layer 1 (tiles left of this one)
@@ -250,7 +469,10 @@ __device__ __forceinline__ void chain_group6(ChainState& s, float* H0, float* H1
         sfor<c0, c1 + 1>([&](auto cc) __attribute__((always_inline)) {
             constexpr int c = decltype(cc)::value;
             for (int r = 0; r < 4; ++r) h1[c][r] = fmaxf(s.acc1[c][r] + h0[c][r], 0.0f);
-            if (writer) for (int r = 0; r < 4; ++r) H1[hw + (r << 6) + c] = h1[c][r];
+            if (writer) {
+                if constexpr (HB == 0) { for (int r = 0; r < 4; ++r) H1[hw + (r << 6) + c] = h1[c][r]; }
+                else store_quad16<HB>(H1, T, c, p, h1[c]);
+            }
         });
         if constexpr (last) publish(flags, F_H1, gen + T + 1);
         if constexpr (I == 0) {
@@ -266,7 +488,10 @@ __device__ __forceinline__ void chain_group6(ChainState& s, float* H0, float* H1
         sfor<c0, c1 + 1>([&](auto cc) __attribute__((always_inline)) {
             constexpr int c = decltype(cc)::value;
             for (int r = 0; r < 4; ++r) h2[c][r] = fmaxf(s.acc2[c][r] + h1[c][r], 0.0f);
-            if (writer) for (int r = 0; r < 4; ++r) H2[hw + (r << 6) + c] = h2[c][r];
+            if (writer) {
+                if constexpr (HB == 0) { for (int r = 0; r < 4; ++r) H2[hw + (r << 6) + c] = h2[c][r]; }
+                else store_quad16<HB>(H2, T, c, p, h2[c]);
+            }
         });
         if constexpr (last) publish(flags, F_H2, gen + T + 1);
         // ---- output rows of this tile's ranks: (shift, raw) of groups (0,1) in o[0], (2,3) in o[1]
@@ -277,7 +502,7 @@ __device__ __forceinline__ void chain_group6(ChainState& s, float* H0, float* H1
                 for (int i = 0; i < 4; ++i) {
                     const int gg = s.g[i] < D ? s.g[i] : 0;
                     const int slot = ((gg >> 3) != O0) ? 1 : 0;
-                    po[i] = *reinterpret_cast<const float2*>(SP3 + slot * (64 * SPAD) + sub_off_sp + 2 * (gg & 7));
+                    po[i] = *reinterpret_cast<const float2*>(SP3 + slot * (sp3_rows * SPAD) + sub_off_sp + 2 * (gg & 7));
                 }
             });
             s.o[0] = f32x4{po[0].x, po[0].y, po[1].x, po[1].y};
@@ -305,7 +530,7 @@ __device__ __forceinline__ void chain_group6(ChainState& s, float* H0, float* H1
         float xg = (s.yv[I] - shift) * fast_exp_neg(ls);
         xg = live ? xg : 0.0f;
         ladj -= live ? ls : 0.0f;
-        if (writer && live) X[lidx(g, p)] = xg;
+        if (writer && live) store_x<HB>(X, X16, g, p, xg);
         if constexpr (last) publish(flags, F_X, gen + T + 1);
         // ---- layer-0 column of the new rank: the next quad first (k slot 4 + I of this tile's window, or, after the
         // tile's last group, k slot I of the next tile's), then everything that feeds later quads
@@ -321,14 +546,15 @@ __device__ __forceinline__ void chain_group6(ChainState& s, float* H0, float* H1
             s.a0n[a] = M4<I>(comp(s.w0n, a), xg, s.a0n[a]);
         });
 #undef BLOCKS
-        chain_group6<PAT, I + 1>(s, H0, H1, H2, X, flags, SP1, SP2, SP3, T, D, gen, sub_off_sp, p, writer, ladj);
+        chain_group6<PAT, I + 1, HB>(s, H0, H1, H2, X, X16, flags, SP1, SP2, SP3, T, D, gen, sub_off_sp, sp3_rows, p, writer, ladj);
     }
 }
 
 }  // namespace tri6
 
-// NS: 16-walker subsets per workgroup (1, 2 or 4); FM: 0 = plain inverse of `in`, 4 / 8 / 16 = fused proposal, D <= 4 FM.
-template <int NS, int FM, int NW = 4>
+// NS: 16-walker subsets per workgroup (1, 2 or 4); FM: 0 = plain inverse of `in`, 4 / 8 / 16 / 32 = fused proposal, D <= 4 FM;
+// HB: operand type of the helpers' left-looking products (0 float32, 1 bfloat16, 2 float16; Ops above).
+template <int NS, int FM, int NW = 4, int HB = 0>
 __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, const float* __restrict__ in,
                                                                float* __restrict__ out, float* __restrict__ ladj_out,
                                                                int64_t n, ProposeArgs pa) {
@@ -339,17 +565,24 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
     const int q = lane >> 4, p = lane & 15;
     const int D = m.D, Dp = m.Dp, Hp = m.Hp, Tn = m.T, nT = m.nT, nXT = m.nXT, nOT = m.nOT;
     // ---- LDS map
-    const int szY = Dp * 16, szH = Hp * 16;
+    using HO = Ops<HB>;
+    constexpr int SP3R = 16 * NS;                         // walker rows of one staged output tile
+    // Yb: the transform's input by rank; Xb: its solution by rank (zeros where not solved yet: the layer-0 helper multiplies
+    // whole tiles).  With 16-bit helpers the helper reads X16b instead (x once more, as B operand of the 16x16x16 MFMA) and
+    // Xb IS Yb: x_g overwrites y_g in place (a rank's y is read before its x is written) -- the 8 KB per subset that let a
+    // second subset share the workgroup at D = 128.
+    const int szY = Dp * 16, szX16 = HB ? HO::act_floats(nXT) : 0, szH = HO::act_floats(nT);      // floats per subset
     float* Yb = smem;                                    // [NS][szY]
-    float* Xb = Yb + NS * szY;                           // [NS][szY]
-    float* H0b = Xb + NS * szY;                          // [NS][szH]
+    float* Xb = HB ? Yb : Yb + NS * szY;                 // [NS][szY]
+    float* X16b = Xb + NS * szY;                         // [NS][szX16]
+    float* H0b = X16b + NS * szX16;                      // [NS][szH]
     float* H1b = H0b + NS * szH;
     float* H2b = H1b + NS * szH;
     float* SP0 = H2b + NS * szH;                         // [2 parities][NS][16][SPAD]
     float* SP1 = SP0 + 2 * NS * 16 * SPAD;
     float* SP2 = SP1 + 2 * NS * 16 * SPAD;
-    float* SP3 = SP2 + 2 * NS * 16 * SPAD;               // [2 parities][2 output tiles][64 (4 subsets max)][SPAD]
-    int* flags = reinterpret_cast<int*>(SP3 + 2 * 2 * 64 * SPAD);
+    float* SP3 = SP2 + 2 * NS * 16 * SPAD;               // [2 parities][2 output tiles][16 NS][SPAD]
+    int* flags = reinterpret_cast<int*>(SP3 + 2 * 2 * SP3R * SPAD);
     const int* feat_of_rank = m.meta + 8;
     const int* rank_of_feat = m.meta + 8 + Tn * D;
     const int* quad_meta = m.meta + 8 + 2 * Tn * D;
@@ -371,6 +604,11 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
     const int blk_bytes = (int)(m.pk_per_transform * 4);
     const int vo_lane = lane << 4, vo_q = q << 4;
     (void)oF0; (void)oW0;
+    // sections of the helpers' fragment image: the float32 image itself, or the 16-bit one (f1 | f2 | f3, 512-byte blocks)
+    const int rbH = HO::row_bytes(nT), rbX = HO::row_bytes(nXT);      // bytes of a fragment row over the hidden / the rank tiles
+    const int hF1 = HB ? 0 : oF1, hF2 = HB ? nT * rbH : oF2, hF3 = HB ? 2 * nT * rbH : oF3;
+    const int hF0C = HB ? (2 * nT + nOT) * rbH : oF0C;
+    const int h16_bytes = (2 * nT + nOT) * rbH + nT * rbX;
 
     const int64_t set0 = (int64_t)blockIdx.x * NS;       // first 16-walker set of this workgroup
     if (threadIdx.x < F_COUNT) flags[threadIdx.x] = 0;
@@ -409,14 +647,20 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
     const int csub = (lane >> 4) % NS;
     const bool writer = lane < 16 * NS;
     const int sub_sp = (csub * 16 + p) * SPAD;            // this lane's row inside a staging tile
+    // the tiles' rank words, once: lane T holds tile T's (v_readlane per tile; nT <= 64)
+    int4 dgl = make_int4(D, D, D, D);
+    if (lane < nT) dgl = *reinterpret_cast<const int4*>(quad_meta + 4 * lane);
+    dgl.x &= 0xffff; dgl.y &= 0xffff; dgl.z &= 0xffff; dgl.w &= 0xffff;
 
     int gen = 1;                                         // (words start at 0: nothing is published)
     for (int t = Tn - 1; t >= 0; --t, gen += 256) {
         const float* blk = m.packed + (size_t)t * m.pk_per_transform;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)blk, 0, blk_bytes, 0x00020000);
-        {   // unknown ranks are zeros (the helpers multiply whole tiles)
-            float4* z4 = reinterpret_cast<float4*>(Xb);
-            for (int e = threadIdx.x; e < (NS * szY) >> 2; e += 256) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const __amdgpu_buffer_rsrc_t rsw = HB ? __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(reinterpret_cast<const unsigned char*>(m.lane16) + (size_t)t * h16_bytes), 0, h16_bytes, 0x00020000) : rs;
+        {   // ranks not solved yet are zeros where the layer-0 helper reads x (it multiplies whole tiles)
+            float4* z4 = reinterpret_cast<float4*>(HB ? X16b : Xb);
+            for (int e = threadIdx.x; e < (NS * (HB ? szX16 : szY)) >> 2; e += 64 * NW) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
 
@@ -425,7 +669,14 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
             ChainState s;
             float* H0 = H0b + csub * szH; float* H1 = H1b + csub * szH; float* H2 = H2b + csub * szH;
             float* X = Xb + csub * szY;
+            float* X16 = X16b + csub * szX16;
             const float* Y = Yb + csub * szY;
+            auto tile_words = [&](int T) __attribute__((always_inline)) {
+                int4 dg;
+                dg.x = __builtin_amdgcn_readlane(dgl.x, T); dg.y = __builtin_amdgcn_readlane(dgl.y, T);
+                dg.z = __builtin_amdgcn_readlane(dgl.z, T); dg.w = __builtin_amdgcn_readlane(dgl.w, T);
+                return dg;
+            };
             // rank 0 reads nothing: bias only
             float x0;
             {
@@ -433,12 +684,11 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                 const float shift = b3[0], ls = fast_ls(b3[1]);
                 x0 = (Y[lidx(0, p)] - shift) * fast_exp_neg(ls);
                 ladj -= ls;
-                if (writer) X[lidx(0, p)] = x0;
+                if (writer) store_x<HB>(X, X16, 0, p, x0);
             }
             publish(flags, F_X, gen + 0);
             float4 w1n = bload4(rs, vo_lane, oCW1), w2n = bload4(rs, vo_lane, oCW2), w0nn = bload4(rs, vo_lane, oCW0);
             float2 w3n = bload2(rs, lane << 3, oCW3);
-            int4 dg_next = *reinterpret_cast<const int4*>(quad_meta);
             for (int a = 0; a < 4; ++a) s.a0n[a] = f32x4{0.f, 0.f, 0.f, 0.f};
             // rank 0 is "group 0 of the tile before tile 0": k slot 0 of tile 0's window
             sfor<0, 4>([&](auto aa) __attribute__((always_inline)) {
@@ -446,20 +696,12 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                 s.a0n[a] = M4<0>(comp(w0nn, a), x0, s.a0n[a]);
             });
             for (int T = 0; T < nT; ++T) {
-                int4 dg = dg_next;
-                // (the same words in every lane; said explicitly, the compiler keeps what follows from them in scalar registers --
-                // otherwise every buffer load whose offset depends on a rank is wrapped in a waterfall loop)
-                dg.x = __builtin_amdgcn_readfirstlane(dg.x & 0xffff); dg.y = __builtin_amdgcn_readfirstlane(dg.y & 0xffff);
-                dg.z = __builtin_amdgcn_readfirstlane(dg.z & 0xffff); dg.w = __builtin_amdgcn_readfirstlane(dg.w & 0xffff);
+                // (the tile's rank words are the same in every lane and come through v_readlane: what follows from them stays in
+                // scalar registers -- otherwise every buffer load whose offset depends on a rank is wrapped in a waterfall loop)
+                const int4 dg = tile_words(T);
                 if (dg.x >= D && dg.y >= D && dg.z >= D && dg.w >= D) break;       // padding tiles
                 const int pat = 1 | ((dg.y != dg.x) << 1) | ((dg.z != dg.y) << 2) | ((dg.w != dg.z) << 3);
-                {
-                    const bool ny = dg.y != dg.x, nz = dg.z != dg.y, nw = dg.w != dg.z;
-                    s.g[0] = dg.x;
-                    s.g[1] = ny ? dg.y : (nz ? dg.z : (nw ? dg.w : D));
-                    s.g[2] = ny ? (nz ? dg.z : (nw ? dg.w : D)) : ((nz && nw) ? dg.w : D);
-                    s.g[3] = (ny && nz && nw) ? dg.w : D;
-                }
+                tile_groups(dg, D, s.g);
                 long long* pf = (pa.prof && blockIdx.x == 0) ? pa.prof + ((size_t)((Tn - 1 - t) * nT + T) * 4 + 0) * 4 : nullptr;
                 if (pf && lane == 0) { pf[0] = clock64(); if (T == 0) pf[3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4); }
                 s.w1 = w1n; s.w2 = w2n; s.w0 = w0nn; s.w3 = w3n;
@@ -468,7 +710,6 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                     w2n = bload4(rs, vo_lane, oCW2 + (T + 1) * 1024);
                     w0nn = bload4(rs, vo_lane, oCW0 + (T + 1) * 1024);
                     w3n = bload2(rs, lane << 3, oCW3 + (T + 1) * 512);
-                    dg_next = *reinterpret_cast<const int4*>(quad_meta + 4 * (T + 1));
                 } else {
                     w0nn = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
@@ -490,9 +731,9 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                 if (pf && lane == 0) pf[1] = clock64();
                 const float* sp1 = SP1 + (T & 1) * (NS * 16 * SPAD);
                 const float* sp2 = SP2 + (T & 1) * (NS * 16 * SPAD);
-                const float* sp3 = SP3 + (T & 1) * (2 * 64 * SPAD);
+                const float* sp3 = SP3 + (T & 1) * (2 * SP3R * SPAD);
                 switch (pat) {
-#define CASE(P) case P: chain_group6<P, 0>(s, H0, H1, H2, X, flags, sp1, sp2, sp3, T, D, gen, sub_sp, p, writer, ladj); break;
+#define CASE(P) case P: chain_group6<P, 0, HB>(s, H0, H1, H2, X, X16, flags, sp1, sp2, sp3, T, D, gen, sub_sp, SP3R, p, writer, ladj); break;
                     CASE(1) CASE(3) CASE(5) CASE(7) CASE(9) CASE(11) CASE(13) CASE(15)
 #undef CASE
                 }
@@ -502,14 +743,16 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
             // ================================================================== HELPERS
             // wv 1: hidden layer 1 (reads H0), wv 2: hidden layer 2 (reads H1), wv 3: layer 0 (cut) + output rows (reads X, H2)
             const float* Hin = wv == 1 ? H0b : (wv == 2 ? H1b : H2b);
-            const int oF = wv == 1 ? oF1 : oF2, oB = wv == 1 ? oB1 : oB2;
+            const int oF = wv == 1 ? hF1 : hF2, oB = wv == 1 ? oB1 : oB2;
             float* SP = wv == 1 ? SP1 : SP2;
             const int f_in = wv == 1 ? F_H0 : (wv == 2 ? F_H1 : F_H2);
             const int f_out = wv == 1 ? F_P1 : F_P2;
             int known = gen;                              // tiles < known - gen of the input layer are final
             auto need = [&](int K) {                       // tile K of the input layer must be final
-                if (known < gen + K + 1) { wait_for(flags, f_in, gen + K + 1); known = peek(flags, f_in); }
+                if (known < gen + K + 1) { wait_for<HB != 0>(flags, f_in, gen + K + 1); known = peek(flags, f_in); }
             };
+            // tiles per chunk of the pipelined left-looking products (two chunks' fragments in flight): 16-bit fragments are a
+            // quarter of the matrix-pipe time per tile, so the L2 latency needs twice the tiles in flight to stay hidden
             constexpr int CH = NS <= 2 ? 4 : 2;
             // wave 3 keeps the sums of two output tiles (slot = tile & 1) across the hidden tiles: consecutive hidden tiles
             // share their output tiles (8 ranks each), so a hidden tile adds only the h2 tiles that became final since the
@@ -528,14 +771,14 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
             }
             // the tiles' rank words: lane T loads tile T's once per transform, a tile reads them with v_readlane (a global
             // load + readfirstlane per tile put an L2 round trip at the head of every helper tile); live tiles are a prefix
-            int4 dgl = make_int4(D, D, D, D);
-            if (lane < nT) dgl = *reinterpret_cast<const int4*>(quad_meta + 4 * lane);
-            dgl.x &= 0xffff; dgl.y &= 0xffff; dgl.z &= 0xffff; dgl.w &= 0xffff;
             const int nTr = __builtin_amdgcn_readfirstlane(
                 __builtin_popcountll(__builtin_amdgcn_ballot_w64(dgl.x < D || dgl.y < D || dgl.z < D || dgl.w < D)));
             if (wv == 1 || wv == 2) {
             // hidden-layer helpers: what the current row needs first -- requested a tile ahead (row 0: its bias only)
-            float4 hw0[CH], hw1[CH], hwl = make_float4(0.f, 0.f, 0.f, 0.f), hbb = hwl;
+            using WC = std::conditional_t<HB == 0, float4, uint4>;         // a chunk element: a tile's block / a pair of tiles
+            WC hw0[CH], hw1[CH];
+            typename HO::W hwl = HO::zero();
+            float4 hbb = make_float4(0.f, 0.f, 0.f, 0.f);
             if (wv == 1 || wv == 2) hbb = bload4(rs, vo_q, oB);
             for (int T = 0; T < nTr; ++T) {
                 // (uniform, and said so: what follows from the rank words stays in scalar registers -- otherwise every buffer
@@ -554,20 +797,29 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                     // (the bias joins the sum when it is staged: as the accumulator's first value its load would have to land
                     // before the first fragment is even requested)
                     for (int sb = 0; sb < NS; ++sb) { acc[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; acd[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                    const int base_ = oF + (T * nT) * 1024;
+                    const int base_ = oF + T * rbH;
                     // acc/acd[sb] += sum_{K < T} frag[K] . Hin[sb][K]: the tiles before the last are final as soon as the one
                     // before the last is (pipelined: left_products), the last tile of the input layer is awaited right before
                     // its use; this row's first fragments, its last one and its bias were requested a tile ago (hw0, hw1, hwl,
                     // hbb), the NEXT row's are requested before the wait
-                    if (T > 1)
-                        left_products_w<NS, CH, true>(acc, acd, rs, vo_lane, base_, Hin, szH, T - 1, lane, hw0, hw1,
-                                                      [&]() __attribute__((always_inline)) { need(T - 2); });
-                    float4 nbb = hbb, nwl = hwl;
+                    if (T > 1) {
+                        if constexpr (HB == 0)
+                            left32_w<NS, CH, true>(acc, acd, rsw, base_, Hin, szH, T - 1, lane, hw0, hw1,
+                                                   [&]() __attribute__((always_inline)) { need(T - 2); });
+                        else
+                            left16_w<HB, NS, CH, true>(acc, acd, rsw, base_, Hin, szH, 0, T - 1, lane, hw0, hw1,
+                                                       [&]() __attribute__((always_inline)) { need(T - 2); });
+                    }
+                    float4 nbb = hbb;
+                    typename HO::W nwl = hwl;
                     if (T + 1 < nTr) {
-                        const int basen = base_ + nT * 1024;
+                        const int basen = base_ + rbH;
                         nbb = bload4(rs, vo_q, oB + 64 * (T + 1));
-                        nwl = bload4(rs, vo_lane, basen + T * 1024);
-                        if (T > 0) first_chunks<CH>(hw0, hw1, rs, vo_lane, basen, T);
+                        nwl = HO::loadw_tile(rsw, lane, basen, T);
+                        if (T > 0) {
+                            if constexpr (HB == 0) first_chunks32<CH>(hw0, hw1, rsw, lane, basen, T);
+                            else first_chunks16<CH>(hw0, hw1, rsw, lane, basen, T);
+                        }
                         asm volatile("" ::: "memory");
                     }
                     if (T > 0) {
@@ -575,11 +827,8 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                         need(T - 1);
                         if (pf && lane == 0) pf[2] = clock64();
 #pragma unroll
-                        for (int sb = 0; sb < NS; ++sb) {
-                            const float4 b = *reinterpret_cast<const float4*>(Hin + sb * szH + ((T - 1) << 8) + (lane << 2));
-                            acc[sb] = MFMA(hwl.x, b.x, acc[sb]); acd[sb] = MFMA(hwl.y, b.y, acd[sb]);
-                            acc[sb] = MFMA(hwl.z, b.z, acc[sb]); acd[sb] = MFMA(hwl.w, b.w, acd[sb]);
-                        }
+                        for (int sb = 0; sb < NS; ++sb)
+                            HO::mma(acc[sb], acd[sb], hwl, HO::loadb(Hin + sb * szH, T - 1, lane), 1);
                     }
                     float* sp = SP + (T & 1) * (NS * 16 * SPAD);
 #pragma unroll
@@ -601,6 +850,7 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                 dg.z = __builtin_amdgcn_readlane(dgl.z, T); dg.w = __builtin_amdgcn_readlane(dgl.w, T);
                 long long* pf = (pa.prof && blockIdx.x == 0 && wv < 4) ? pa.prof + ((size_t)((Tn - 1 - t) * nT + T) * 4 + wv) * 4 : nullptr;
                 if (pf && lane == 0) { pf[0] = clock64(); if (T == 0) pf[2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4); }
+                long long* pe = (pf && wv == 3) ? pa.prof + (size_t)Tn * nT * 16 + (size_t)((Tn - 1 - t) * nT + T) * 8 : nullptr;
                 int gfirst = dg.x, glast = dg.x;
                 if (dg.y < D) glast = dg.y;
                 if (dg.z < D) glast = dg.z;
@@ -608,37 +858,34 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                 if (wv == 3) {
                     // ---- output partials of this tile's ranks: output tile(s) O = rank >> 3 against h2 of tiles < T
                     const int O0 = gfirst >> 3, O1 = glast >> 3;
-                    float* sp3 = SP3 + (T & 1) * (2 * 64 * SPAD);
+                    float* sp3 = SP3 + (T & 1) * (2 * SP3R * SPAD);
                     // first everything that does not wait for the chain's current tile (a new output tile's row up to
                     // tile T - 2), then the last tile of both
                     const int nso = O1 != O0 ? 2 : 1;
-                    float4 wl[2];
-                    auto pre = [&](f32x4 (&acc)[NS], f32x4 (&acd)[NS], int& sO, int& sK, float4& ob, int O, float4& w) __attribute__((always_inline)) {
+                    typename HO::W wl[2];
+                    auto pre = [&](f32x4 (&acc)[NS], f32x4 (&acd)[NS], int& sO, int& sK, float4& ob, int O, typename HO::W& w) __attribute__((always_inline)) {
                         sO = __builtin_amdgcn_readfirstlane(sO); sK = __builtin_amdgcn_readfirstlane(sK);
                         if (sO != O) {
                             ob = bload4(rs, vo_q, oB3 + 64 * O);
                             for (int sb = 0; sb < NS; ++sb) { acc[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; acd[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                             sO = O; sK = 0;
                         }
-                        const int base_ = oF3 + (O * nT) * 1024;
-                        if (T > sK) w = bload4(rs, vo_lane, base_ + (T - 1) * 1024);
+                        const int base_ = hF3 + O * rbH;
+                        if (T > sK) w = HO::loadw_tile(rsw, lane, base_, T - 1);
                         if (T - 1 > sK)
-                            left_products<NS, CH>(acc, acd, rs, vo_lane, base_ + sK * 1024, Hin + (sK << 8), szH, T - 1 - sK, lane,
-                                                  [&]() __attribute__((always_inline)) { need(T - 2); });
+                            left_products<HB, NS, CH>(acc, acd, rsw, base_, Hin, szH, sK, T - 1, lane,
+                                                      [&]() __attribute__((always_inline)) { need(T - 2); });
                     };
-                    auto fin = [&](f32x4 (&acc)[NS], f32x4 (&acd)[NS], int& sK, const float4& ob, int so, const float4& w) __attribute__((always_inline)) {
+                    auto fin = [&](f32x4 (&acc)[NS], f32x4 (&acd)[NS], int& sK, const float4& ob, int so, const typename HO::W& w) __attribute__((always_inline)) {
                         if (T > sK) {
 #pragma unroll
-                            for (int sb = 0; sb < NS; ++sb) {
-                                const float4 b = *reinterpret_cast<const float4*>(Hin + sb * szH + ((T - 1) << 8) + (lane << 2));
-                                acc[sb] = MFMA(w.x, b.x, acc[sb]); acd[sb] = MFMA(w.y, b.y, acd[sb]);
-                                acc[sb] = MFMA(w.z, b.z, acc[sb]); acd[sb] = MFMA(w.w, b.w, acd[sb]);
-                            }
+                            for (int sb = 0; sb < NS; ++sb)
+                                HO::mma(acc[sb], acd[sb], w, HO::loadb(Hin + sb * szH, T - 1, lane), 1);
                             sK = T;
                         }
 #pragma unroll
                         for (int sb = 0; sb < NS; ++sb)
-                            *reinterpret_cast<float4*>(sp3 + so * (64 * SPAD) + (sb * 16 + p) * SPAD + 4 * q) =
+                            *reinterpret_cast<float4*>(sp3 + so * (SP3R * SPAD) + (sb * 16 + p) * SPAD + 4 * q) =
                                 make_float4((acc[sb][0] + acd[sb][0]) + ob.x, (acc[sb][1] + acd[sb][1]) + ob.y,
                                             (acc[sb][2] + acd[sb][2]) + ob.z, (acc[sb][3] + acd[sb][3]) + ob.w);
                     };
@@ -648,6 +895,7 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                     }
                     if (pf && lane == 0 && T > 0) pf[2] = clock64();
                     if (T > 0) need(T - 1);
+                    if (pe && lane == 0) pe[0] = clock64();
                     for (int so = 0; so < nso; ++so) {
                         const int O = O0 + so;
                         if (O & 1) fin(oacc1, oacd1, slotK1, obias1, so, wl[1]); else fin(oacc0, oacd0, slotK0, obias0, so, wl[0]);
@@ -665,8 +913,9 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                         // the wait for tile T-1 to be complete -- T = 0: rank 0 is there -- behind the first fragments' loads)
                         const int nXn = (gfirst + 15) >> 4;
                         if (nXn > 0)
-                            left_products<NS, CH>(acc, acd, rs, vo_lane, oF0C + ((T + 1) * nXT) * 1024, Xb, szY, nXn < nXT ? nXn : nXT, lane,
-                                                  [&]() __attribute__((always_inline)) { wait_for(flags, F_X, gen + T); });
+                            left_products<HB, NS, CH>(acc, acd, rsw, hF0C + (T + 1) * rbX, HB ? X16b : Xb, HB ? szX16 : szY, 0, nXn < nXT ? nXn : nXT, lane,
+                                                      [&]() __attribute__((always_inline)) { if (pe && lane == 0) pe[4] = clock64(); wait_for<HB != 0>(flags, F_X, gen + T); if (pe && lane == 0) pe[5] = clock64(); });
+                        if (pe && lane == 0) pe[1] = clock64();
                         float* sp0 = SP0 + ((T + 1) & 1) * (NS * 16 * SPAD);
 #pragma unroll
                         for (int sb = 0; sb < NS; ++sb)
@@ -696,27 +945,38 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                                 ob = bload4(rs, vo_q, oB3 + 64 * O);
                                 for (int sb = 0; sb < NS; ++sb) { acc[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; acd[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                                 sO = O;
-                                left_products<NS, CH>(acc, acd, rs, vo_lane, oF3 + (O * nT) * 1024, Hin, szH, T, lane, []() {});
+                                left_products<HB, NS, CH>(acc, acd, rsw, hF3 + O * rbH, Hin, szH, 0, T, lane, []() {});
                                 sK = T;
                             };
                             for (int O = dn.x >> 3; O <= (nlast >> 3); ++O) {
                                 if (O & 1) ahead(oacc1, oacd1, slotO1, slotK1, obias1, O); else ahead(oacc0, oacd0, slotO0, slotK0, obias0, O);
                             }
+                            if (pe && lane == 0) pe[3] = clock64();
                         }
                     }
                 }
             }
             }
         }
-        __syncthreads();
+        __syncthreads();                                  // (the helpers are done with this transform's x and activations)
         // re-rank for the next transform (or write out) with every thread of the workgroup: the target rank of a rank is two
         // dependent global loads, so eight elements' worth are requested together (one wavefront walking the subset's
-        // 2048 elements one load pair at a time took 20 k cycles per transform at D = 128)
+        // 2048 elements one load pair at a time took 20 k cycles per transform at D = 128).  16-bit helpers: x sits where y
+        // did, so it first moves to the (now idle) activation arrays and is re-ranked from there.
         {
             const bool lastT = (t == 0);
             const int* for_cur = feat_of_rank + t * D;
             const int* rank_next = lastT ? nullptr : rank_of_feat + (t - 1) * D;
             const int per = Dp * 16, total = NS * per;
+            const float* Xs = Xb;
+            if constexpr (HB != 0) {
+                if (rank_next) {
+                    for (int e = threadIdx.x; e < (NS * szY) >> 2; e += 64 * NW)
+                        reinterpret_cast<float4*>(H0b)[e] = reinterpret_cast<const float4*>(Xb)[e];
+                    Xs = H0b;
+                    __syncthreads();
+                }
+            }
             for (int e0 = threadIdx.x; e0 < total; e0 += 8 * 64 * NW) {
                 int dst[8];
 #pragma unroll
@@ -736,7 +996,7 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                     if (e >= total) continue;
                     const int sb = e / per, r = (e % per) >> 4, pp = e & 15;
                     if (r < D) {
-                        const float v = Xb[sb * szY + lidx(r, pp)];
+                        const float v = Xs[sb * szY + lidx(r, pp)];
                         const int64_t row = (set0 + sb) * 16 + pp;
                         if (rank_next) Yb[sb * szY + lidx(dst[j], pp)] = v;
                         else if (row < n) out[row * D + dst[j]] = v;
@@ -754,8 +1014,12 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
     }
 }
 
-static size_t tri6_lds_bytes(const pmc_maf_t* m, int ns) {
-    return (size_t)(ns * (2 * m->Dp * 16 + 3 * m->Hp * 16) + 3 * 2 * ns * 16 * tri6::SPAD + 2 * 2 * 64 * tri6::SPAD) * sizeof(float)
+static int tri6_hb(const pmc_maf_t* m) { return (m->lane16 && (m->lane16_fmt == 1 || m->lane16_fmt == 2)) ? m->lane16_fmt : 0; }
+
+static size_t tri6_lds_bytes(const pmc_maf_t* m, int ns, int hb = 0) {
+    const int h_floats = hb ? ((m->nT + 1) >> 1) * 256 : m->nT * 256;       // (Ops<HB>::act_floats: one activation array of a subset)
+    const int x_floats = hb ? m->Dp * 16 + ((m->nXT + 1) >> 1) * 256 : 2 * m->Dp * 16;   // y, x by rank (16-bit helpers: x over y in place + the helper's copy)
+    return (size_t)(ns * (x_floats + 3 * h_floats) + 3 * 2 * ns * 16 * tri6::SPAD + 2 * 2 * 16 * ns * tri6::SPAD) * sizeof(float)
            + (tri6::F_COUNT + 8) * sizeof(int);          // (+ 8: the wavefronts' SIMD ids of the five-wave variant)
 }
 
@@ -765,17 +1029,18 @@ static int tri6_five_min() {
     static const int v = getenv("PMC_TRI6_FIVE_MIN") ? atoi(getenv("PMC_TRI6_FIVE_MIN")) : 16;   // (A/B runs)
     return v;
 }
-// the five-wavefront variant: plain inverse of a flow with >= 16 hidden tiles, one or two subsets (the kernel must stay
-// within 256 registers: two wavefronts share a SIMD, and only one such workgroup fits a CU)
-static bool tri6_five(const pmc_maf_t* m, bool fused) {
-    return !fused && m->nT >= tri6_five_min() && !getenv("PMC_TRI6_FOUR");
+// the five-wavefront variant: plain float32 inverse of a flow with >= 16 hidden tiles, one or two subsets (the kernel must
+// stay within 256 registers: two wavefronts share a SIMD, and only one such workgroup fits a CU).  With 16-bit helper
+// operands the helpers are an order of magnitude below the chain: four wavefronts, a SIMD each.
+static bool tri6_five(const pmc_maf_t* m, bool fused, int hb = 0) {
+    return !fused && !hb && m->nT >= tri6_five_min() && !getenv("PMC_TRI6_FOUR");
 }
-static int tri6_subsets(const pmc_maf_t* m, int64_t n, bool fused) {
+static int tri6_subsets(const pmc_maf_t* m, int64_t n, bool fused, int hb = 0) {
     static const int forced = getenv("PMC_TRI6_SUBSETS") ? atoi(getenv("PMC_TRI6_SUBSETS")) : 0;
-    const bool five = tri6_five(m, fused);
+    const bool five = tri6_five(m, fused, hb);
     int best = 0;
     for (int ns = 1; ns <= (five ? 2 : 4); ns *= 2) {
-        const size_t lds = tri6_lds_bytes(m, ns);
+        const size_t lds = tri6_lds_bytes(m, ns, hb);
         if (lds > 160 * 1024) break;
         if (forced == ns) return ns;
         best = ns;
@@ -792,45 +1057,107 @@ static int tri6_subsets(const pmc_maf_t* m, int64_t n, bool fused) {
 // proposal and the scaler on their own (the fused instances of this kernel need more than 256 registers).
 bool pmc_tri6_preferred(const pmc_maf_t* m) {
     if (m->n_out != 2 || !m->tri_ok || m->pk_per_transform * 4 > 0x7fffffffLL) return false;
+    const int hb = tri6_hb(m);
+    if (hb) return m->nT >= tri6_five_min() && tri6_lds_bytes(m, 1, hb) <= 160 * 1024;
     return tri6_five(m, false) && tri6_lds_bytes(m, 1) <= 160 * 1024;
 }
 
 // same contract as pmc_launch_inverse_tri4 / pmc_launch_propose_inverse_tri4 (pa == nullptr: plain inverse of z);
-// -1: this flow is not covered (spline flows, degree groups wider than a tile, tiles beyond the LDS)
+// -1: this flow is not covered (spline flows, degree groups wider than a tile, tiles beyond the LDS).
+// m->lane16 (pmc_maf_pack_lane16): the helpers multiply with 16-bit operands (Ops above).
 int pmc_launch_tri6(const ProposeArgs* pa, const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
                     hipStream_t stream) {
     if (m->n_out != 2 || !m->tri_ok) return -1;
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
     if (pa && m->D > 64) return -1;
     if (m->nT > 64) return -1;                           // (a lane per hidden tile holds its rank words)
-    const int ns = tri6_subsets(m, n, pa != nullptr);
+    const int hb = tri6_hb(m);
+    const int ns = tri6_subsets(m, n, pa != nullptr, hb);
     if (ns == 0) return -1;
-    const size_t lds = tri6_lds_bytes(m, ns);
+    if (hb && m->Dp * 16 > 3 * ((m->nT + 1) >> 1) * 256) return -1;   // (the in-place re-rank parks x in the activation arrays)
+    const size_t lds = tri6_lds_bytes(m, ns, hb);
     const ProposeArgs none{};
     const unsigned grid = (unsigned)((n + 16 * ns - 1) / (16 * ns));
     // wide flows (helpers saturated: their work grows with the hidden tiles, the chain's does not) get a fifth wavefront for
     // the layer-0 partials; it needs the kernel in 256 registers (two wavefronts on one SIMD): plain inverse, one subset
-    const bool five = tri6_five(m, pa != nullptr) && ns <= 2;
-#define LAUNCH6(NSV, FMV, NWV)                                                                                     \
+    const bool five = tri6_five(m, pa != nullptr, hb) && ns <= 2;
+#define LAUNCH6(NSV, FMV, NWV, HBV)                                                                                \
     {                                                                                                              \
         if (lds > 48 * 1024) {                                                                                     \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri6_kernel<NSV, FMV, NWV>), \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri6_kernel<NSV, FMV, NWV, HBV>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
             if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_inverse_tri6_kernel)");           \
         }                                                                                                          \
-        hipLaunchKernelGGL((maf_inverse_tri6_kernel<NSV, FMV, NWV>), dim3(grid), dim3(64 * NWV), lds, stream, *m, z, x, \
+        hipLaunchKernelGGL((maf_inverse_tri6_kernel<NSV, FMV, NWV, HBV>), dim3(grid), dim3(64 * NWV), lds, stream, *m, z, x, \
                            ladj, n, pa ? *pa : none);                                                              \
     }
 #define LAUNCH6F(FMV)                                                                                              \
-    { if (ns == 1) LAUNCH6(1, FMV, 4) else if (ns == 2) LAUNCH6(2, FMV, 4) else LAUNCH6(4, FMV, 4) }
-    if (five) { if (ns == 1) LAUNCH6(1, 0, 5) else LAUNCH6(2, 0, 5) }
+    { if (ns == 1) LAUNCH6(1, FMV, 4, 0) else if (ns == 2) LAUNCH6(2, FMV, 4, 0) else LAUNCH6(4, FMV, 4, 0) }
+#define LAUNCH6H(HBV)                                                                                              \
+    { if (ns == 1) LAUNCH6(1, 0, 4, HBV) else if (ns == 2) LAUNCH6(2, 0, 4, HBV) else LAUNCH6(4, 0, 4, HBV) }
+    if (hb && pa) return -1;                             // (no fused instance with 16-bit helpers yet)
+    if (hb == 1) LAUNCH6H(1)
+    else if (hb == 2) LAUNCH6H(2)
+    else if (five) { if (ns == 1) LAUNCH6(1, 0, 5, 0) else LAUNCH6(2, 0, 5, 0) }
     else if (!pa) LAUNCH6F(0)
     else if (m->D <= 16) LAUNCH6F(4)
     else if (m->D <= 32) LAUNCH6F(8)
     else LAUNCH6F(16)
+#undef LAUNCH6H
 #undef LAUNCH6F
 #undef LAUNCH6
     return pmc_check_launch("maf_inverse_tri6_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 16-bit image of the helpers' fragments (pmc_maf_t.lane16), derived on the device from the float32 image: per transform
+// the sections f1 | f2 | f3 | f0c (hidden layers 1, 2, output rows, layer 0 left of the chain's window), each [row tile][pair
+// of k tiles][lane][8] (Ops above: one 16-byte load per lane feeds two tiles), a block's 256 weights W[i][k]
+// re-laid from the 16x16x4 A layout (lane = (k & 3) * 16 + i, component k >> 2) to the 16x16x16 one (lane = (k >> 2) * 16
+// + i, element k & 3) and rounded to nearest even.  fmt: 1 bfloat16, 2 float16.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_lane16_kernel(pmc_maf_t m, int fmt, unsigned short* __restrict__ img) {
+    const int nT = m.nT, nOT = m.nOT, nXT = m.nXT;
+    const int nP = (nT + 1) >> 1, nPX = (nXT + 1) >> 1;                      // pairs of a row over the hidden / the rank tiles
+    const int64_t rows_h = 2 * (int64_t)nT + nOT;                           // rows of f1 | f2 | f3 (k tiles: hidden) ...
+    const int64_t pairs_per_t = rows_h * nP + (int64_t)nT * nPX;            // ... | f0c (k tiles: ranks)
+    // float offsets inside a transform's float32 image (MAFSpec._build_device_layout: f0 f1 f2 f3 w0n b0 b1 b2 b3 cw1 cw2 cw0 cw3 f0c)
+    const int64_t off_f1 = (int64_t)nT * nXT * 256;
+    const int64_t off_f0c = off_f1 + (2 * (int64_t)nT * nT + (int64_t)nOT * nT) * 256 + (int64_t)m.Dp * m.Hp + 3 * (int64_t)m.Hp +
+                            (int64_t)nOT * 16 + 3 * (int64_t)nT * 256 + (int64_t)nT * 128;
+    const int64_t total = pairs_per_t * m.T * 512;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t pr = e >> 9;                       // pair (512 elements: 64 lanes x 8)
+        const int t = (int)(pr / pairs_per_t);
+        int64_t b = pr - (int64_t)t * pairs_per_t;
+        int64_t row, src0; int pair, ntiles;
+        if (b < rows_h * nP) { row = b / nP; pair = (int)(b - row * nP); ntiles = nT; src0 = off_f1 + row * nT * 256; }
+        else { b -= rows_h * nP; row = b / nPX; pair = (int)(b - row * nPX); ntiles = nXT; src0 = off_f0c + row * nXT * 256; }
+        const int w = (int)(e & 511), lane = w >> 3, j8 = w & 7;
+        const int tile = 2 * pair + (j8 >> 2), j = j8 & 3;       // lane (c, i), element j of the tile's half: k = 4 c + j
+        const int c = lane >> 4, i = lane & 15;
+        float v = 0.0f;
+        if (tile < ntiles) v = m.packed[(size_t)t * m.pk_per_transform + (size_t)(src0 + (int64_t)tile * 256) + ((j * 16 + i) << 2) + c];
+        unsigned short h;
+        if (fmt == 1) { const __bf16 x = (__bf16)v; h = *reinterpret_cast<const unsigned short*>(&x); }
+        else { const _Float16 x = (_Float16)v; h = *reinterpret_cast<const unsigned short*>(&x); }
+        img[e] = h;
+    }
+}
+
+extern "C" int64_t pmc_maf_lane16_elems(const pmc_maf_t* m) {
+    if (!m) return 0;
+    const int64_t nP = (m->nT + 1) >> 1, nPX = (m->nXT + 1) >> 1;
+    return ((2 * (int64_t)m->nT + m->nOT) * nP + (int64_t)m->nT * nPX) * 512 * m->T;
+}
+
+extern "C" int pmc_maf_pack_lane16(const pmc_maf_t* m, int fmt, uint16_t* image, void* stream) {
+    if (!m || !m->packed || !image || (fmt != 1 && fmt != 2)) return pmc_fail("pmc_maf_pack_lane16: bad argument");
+    if (m->n_out != 2) return pmc_fail("pmc_maf_pack_lane16: affine flows only");
+    const int64_t total = pmc_maf_lane16_elems(m);
+    int64_t grid = (total + 255) / 256; if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(pack_lane16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *m, fmt, image);
+    return pmc_check_launch("pack_lane16_kernel");
 }
 
 // whether PMC_INVERSE_AUTO (and with it the MCMC step) takes this sweep for the flow (bench.py names the kernel it times)
@@ -845,19 +1172,22 @@ extern "C" int pmc_debug_tri6_profile(const pmc_maf_t* m, const float* z, float*
     ProposeArgs pa{};
     pa.prof = prof;
     // (FM = 0 instances read nothing else of pa)
-    const int ns = tri6_subsets(m, n, false);
+    const int hb = tri6_hb(m);
+    const int ns = tri6_subsets(m, n, false, hb);
     if (ns == 0 || m->n_out != 2 || !m->tri_ok) return pmc_fail("pmc_debug_tri6_profile: flow not covered");
-    const size_t lds = tri6_lds_bytes(m, ns);
+    const size_t lds = tri6_lds_bytes(m, ns, hb);
     const unsigned grid = (unsigned)((n + 16 * ns - 1) / (16 * ns));
-    const bool five = tri6_five(m, false) && ns <= 2;
-#define LP(NSV, NWV)                                                                                               \
+    const bool five = tri6_five(m, false, hb) && ns <= 2;
+#define LP(NSV, NWV, HBV)                                                                                          \
     {                                                                                                              \
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri6_kernel<NSV, 0, NWV>), \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri6_kernel<NSV, 0, NWV, HBV>), \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-        hipLaunchKernelGGL((maf_inverse_tri6_kernel<NSV, 0, NWV>), dim3(grid), dim3(64 * NWV), lds, (hipStream_t)stream, *m, z, \
+        hipLaunchKernelGGL((maf_inverse_tri6_kernel<NSV, 0, NWV, HBV>), dim3(grid), dim3(64 * NWV), lds, (hipStream_t)stream, *m, z, \
                            x, ladj, n, pa);                                                                        \
     }
-    if (five) { if (ns == 1) LP(1, 5) else LP(2, 5) } else if (ns == 1) LP(1, 4) else if (ns == 2) LP(2, 4) else LP(4, 4)
+    if (hb == 1) { if (ns == 1) LP(1, 4, 1) else if (ns == 2) LP(2, 4, 1) else LP(4, 4, 1) }
+    else if (hb == 2) { if (ns == 1) LP(1, 4, 2) else if (ns == 2) LP(2, 4, 2) else LP(4, 4, 2) }
+    else if (five) { if (ns == 1) LP(1, 5, 0) else LP(2, 5, 0) } else if (ns == 1) LP(1, 4, 0) else if (ns == 2) LP(2, 4, 0) else LP(4, 4, 0)
 #undef LP
     return pmc_check_launch("maf_inverse_tri6_kernel<profile>");
 }

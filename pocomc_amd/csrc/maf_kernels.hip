@@ -244,8 +244,12 @@ extern "C" int pmc_maf_inverse(const pmc_maf_t* m, const float* z, float* x, flo
         const int rc = pmc_launch_inverse_tri4(m, z, x, ladj, n, (hipStream_t)stream, algo == PMC_INVERSE_TRIANGULAR_DUO);
         if (rc >= 0) return rc;
         return pmc_fail("pmc_maf_inverse: this sweep needs D <= 64 and its tiles in 160 KiB of LDS");
-    } else if (algo == PMC_INVERSE_TRIANGULAR_LANE) {
-        const int rc = pmc_launch_tri6(nullptr, m, z, x, ladj, n, (hipStream_t)stream);
+    } else if (algo == PMC_INVERSE_TRIANGULAR_LANE || algo == PMC_INVERSE_TRIANGULAR_LANE16) {
+        pmc_maf_t mf = *m;
+        if (algo == PMC_INVERSE_TRIANGULAR_LANE) mf.lane16 = nullptr;       // (the float32 helpers, whatever is attached)
+        else if (!m->lane16 || (m->lane16_fmt != 1 && m->lane16_fmt != 2))
+            return pmc_fail("pmc_maf_inverse: PMC_INVERSE_TRIANGULAR_LANE16 needs pmc_maf_t.lane16 (pmc_maf_pack_lane16)");
+        const int rc = pmc_launch_tri6(nullptr, &mf, z, x, ladj, n, (hipStream_t)stream);
         if (rc >= 0) return rc;
         return pmc_fail("pmc_maf_inverse: the lane-per-walker sweep needs an affine flow whose degree groups fit a tile");
     }

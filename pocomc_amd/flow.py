@@ -39,13 +39,20 @@ def torch_double_to_float(x: torch.Tensor, warn: bool = True) -> torch.Tensor:
 class Flow:
     """Masked autoregressive flow resident on one MI355X."""
 
-    def __init__(self, n_dim, flow="nsf3", device=None, seed=None, precision="f32", train_engine=None):   # default flow as pocomc/flow.py:46
+    def __init__(self, n_dim, flow="nsf3", device=None, seed=None, precision="f32", train_engine=None,
+                 inverse_precision=None):                                                                 # default flow as pocomc/flow.py:46
         """``precision="bf16"`` (affine flows): ``forward`` / ``log_prob`` run on the bf16 matrix cores with fp32
         accumulation (``csrc/maf_forward_bf16.hip``; BASELINE config 5 names this precision), and ``fit`` takes the bf16
         gradient engine (``csrc/maf_train_bf16.hip``: bf16 weights / activations, fp32 master parameters, accumulation and
         optimizer) when the hidden layers are wide (>= ``train.WIDE_MIN_HIDDEN`` units: the config-5 flow);
         ``train_engine="f32" | "bf16"`` fixes the engine instead of the width rule (kept by ``save_state``).  The
-        parameters, the inverse and the univariate maps stay float32.  Default: float32 everywhere, like the reference."""
+        parameters, the chain of the inverse and the univariate maps stay float32.  ``inverse_precision`` ("f32" | "bf16" |
+        "f16"; default: "bf16" for ``precision="bf16"``, else "f32"): operand type of the LEFT-LOOKING products of the
+        inverse sweep of the wide flows (``csrc/maf_inverse_tri6.hip``: everything left of the diagonal tile, multiplied by
+        the helper wavefronts on ``v_mfma_f32_16x16x16_bf16 / _f16`` with float32 accumulation; the dependent chain stays
+        float32) -- it halves the activations' LDS footprint, so that BASELINE config 5's 5000 walkers per GPU take one round
+        of the sweep instead of two.  Narrow flows (fewer than 16 hidden tiles) keep the float32 sweeps whatever it says.
+        Default: float32 everywhere, like the reference."""
         self.n_dim = int(n_dim)
         if isinstance(flow, MAFSpec):
             spec = flow
@@ -81,6 +88,19 @@ class Flow:
         if train_engine not in (None, "f32", "bf16"):
             raise ValueError("train_engine must be None, 'f32' or 'bf16'")
         self.train_engine = train_engine
+        if inverse_precision is None:
+            inverse_precision = "bf16" if precision == "bf16" else "f32"
+        if inverse_precision not in ("f32", "bf16", "f16"):
+            raise ValueError("inverse_precision must be 'f32', 'bf16' or 'f16'")
+        if inverse_precision != "f32" and spec.univariate != "affine":
+            raise NotImplementedError("the 16-bit helper products are built for the affine flows")
+        self.inverse_precision = inverse_precision
+        self._lane16 = None            # 16-bit image of the lane sweep's helper fragments (pmc_maf_pack_lane16)
+        if inverse_precision != "f32":
+            self._lane16 = torch.zeros(int(self.lib.pmc_maf_lane16_elems(C.byref(self._desc))), dtype=torch.int16,
+                                       device=self.device)
+            self._desc.lane16 = self._lane16.data_ptr()
+            self._desc.lane16_fmt = 1 if inverse_precision == "bf16" else 2
         self._bf16 = None              # (gather map, image, elements per transform), built on first use
         self.repack()
 
@@ -91,11 +111,13 @@ class Flow:
         return {"n_dim": self.n_dim,
                 "spec": (self.spec.n_dim, self.spec.n_transforms, self.spec.hidden, self.spec.univariate, self.spec.bins),
                 "params": self.params.detach().cpu().numpy(), "inverse_algo": self.inverse_algo,
-                "precision": self.precision, "train_engine": self.train_engine}
+                "precision": self.precision, "train_engine": self.train_engine,
+                "inverse_precision": self.inverse_precision}
 
     def __setstate__(self, st):
         spec = MAFSpec(*st["spec"])
-        self.__init__(st["n_dim"], spec, precision=st.get("precision", "f32"), train_engine=st.get("train_engine"))
+        self.__init__(st["n_dim"], spec, precision=st.get("precision", "f32"), train_engine=st.get("train_engine"),
+                      inverse_precision=st.get("inverse_precision"))
         self.set_params(st["params"])
         self.inverse_algo = st.get("inverse_algo", 0)
 
@@ -106,6 +128,9 @@ class Flow:
             _lib.check(self.lib.pmc_maf_pack(_lib.ptr(self.params), _lib.ptr(self._pack_idx),
                                              _lib.ptr(self._packed), self._packed.numel(),
                                              _lib.stream_handle()), "pmc_maf_pack")
+            if getattr(self, "_lane16", None) is not None:
+                _lib.check(self.lib.pmc_maf_pack_lane16(C.byref(self._desc), int(self._desc.lane16_fmt),
+                                                        _lib.ptr(self._lane16), _lib.stream_handle()), "pmc_maf_pack_lane16")
             if getattr(self, "_bf16", None) is not None:
                 idx, img, _ = self._bf16
                 _lib.check(self.lib.pmc_maf_pack_bf16(_lib.ptr(self.params), _lib.ptr(idx), _lib.ptr(img), img.numel(),

@@ -24,12 +24,12 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), s
         assert s in _lib.SIGNATURES, f"{s} declared in the header but not bound"
-    assert lib.pmc_abi_version() == 4
+    assert lib.pmc_abi_version() == 5
 
 
 def test_struct_sizes():
     from pocomc_amd import _lib
-    assert ctypes.sizeof(_lib.pmc_maf_t) == 64
+    assert ctypes.sizeof(_lib.pmc_maf_t) == 80
     assert ctypes.sizeof(_lib.pmc_scaler_t) == 7 * 8 + 4 * 4 + 8
     assert ctypes.sizeof(_lib.pmc_rng_t) == 48
     assert ctypes.sizeof(_lib.pmc_state_t) == 56
