@@ -761,7 +761,11 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
             f32x4 oacc0[NS], oacd0[NS], oacc1[NS], oacd1[NS];
             int slotO0 = -1, slotO1 = -1, slotK0 = 0, slotK1 = 0;
             float4 obias0 = make_float4(0.f, 0.f, 0.f, 0.f), obias1 = obias0;
-            constexpr int P0W = NW == 5 ? 4 : 3;         // the wavefront that forms the layer-0 partials
+            // the wavefront that forms the layer-0 partials: the fifth; of four, the output wavefront -- or, with 16-bit operands,
+            // the hidden layer 2's: its row is staged when the chain starts the tile, and it idles from there until the tile's h1
+            // is final, while the output wavefront (a tile's output partials, then a new output tile's whole row) is the one the
+            // chain waits for (measured: 6.5-8.5 k cycles per iteration against the chain's 5.5 k)
+            constexpr int P0W = NW == 5 ? 4 : (HB ? 2 : 3);
             if (wv == P0W) {
                 // layer-0 partial of tile 0: bias only (cut = 0)
                 const float4 b0 = bload4(rs, vo_q, oB0);
@@ -773,6 +777,28 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
             // load + readfirstlane per tile put an L2 round trip at the head of every helper tile); live tiles are a prefix
             const int nTr = __builtin_amdgcn_readfirstlane(
                 __builtin_popcountll(__builtin_amdgcn_ballot_w64(dgl.x < D || dgl.y < D || dgl.z < D || dgl.w < D)));
+            // ---- layer-0 partial of the NEXT tile: ranks before this tile's own (f0c: the fragments right of the cut are zeros), final
+            // once tile T-1 is (T = 0: rank 0 is there; the wait sits behind the first fragments' loads).  Pasted where the wavefront that
+            // forms it (P0W) has its tile loop -- as a lambda it moved the five-wave variant past its 256 registers.
+#define LAYER0_STEP() \
+                    if (T + 1 < nT) { \
+                        const float4 b0 = bload4(rs, vo_q, oB0 + 64 * (T + 1)); \
+                        f32x4 acc[NS], acd[NS]; \
+                        for (int sb = 0; sb < NS; ++sb) { acc[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; acd[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; } \
+                        const int nXn = (gfirst + 15) >> 4; \
+                        if (nXn > 0) \
+                            left_products<HB, NS, CH>(acc, acd, rsw, hF0C + (T + 1) * rbX, HB ? X16b : Xb, HB ? szX16 : szY, 0, nXn < nXT ? nXn : nXT, lane, \
+                                                      [&]() __attribute__((always_inline)) { if (pe && lane == 0) pe[4] = clock64(); wait_for<HB != 0>(flags, F_X, gen + T); if (pe && lane == 0) pe[5] = clock64(); }); \
+                        if (pe && lane == 0) pe[1] = clock64(); \
+                        float* sp0 = SP0 + ((T + 1) & 1) * (NS * 16 * SPAD); \
+_Pragma("unroll") \
+                        for (int sb = 0; sb < NS; ++sb) \
+                            *reinterpret_cast<float4*>(sp0 + (sb * 16 + p) * SPAD + 4 * q) = \
+                                make_float4((acc[sb][0] + acd[sb][0]) + b0.x, (acc[sb][1] + acd[sb][1]) + b0.y, \
+                                            (acc[sb][2] + acd[sb][2]) + b0.z, (acc[sb][3] + acd[sb][3]) + b0.w); \
+                        publish(flags, F_P0, gen + T + 2); \
+                        if (pf && lane == 0 && wv == 3) pf[3] = clock64(); \
+                    }
             if (wv == 1 || wv == 2) {
             // hidden-layer helpers: what the current row needs first -- requested a tile ahead (row 0: its bias only)
             using WC = std::conditional_t<HB == 0, float4, uint4>;         // a chunk element: a tile's block / a pair of tiles
@@ -839,6 +865,7 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                     publish(flags, f_out, gen + T + 1);
                     if (pf && lane == 0) pf[3] = clock64();
                     hbb = nbb; hwl = nwl;
+                    if constexpr (P0W == 2) { if (wv == 2) { long long* pe = nullptr; LAYER0_STEP() } }
                 }
             }
             } else {
@@ -903,29 +930,7 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
                     publish(flags, F_P3, gen + T + 1);
                     if (pf && lane == 0) pf[1] = clock64();
                 }
-                if (wv == P0W) {
-                    // ---- layer-0 partial of the NEXT tile: ranks before this tile's own (f0c), final once tile T-1 is
-                    if (T + 1 < nT) {
-                        const float4 b0 = bload4(rs, vo_q, oB0 + 64 * (T + 1));
-                        f32x4 acc[NS], acd[NS];
-                        for (int sb = 0; sb < NS; ++sb) { acc[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; acd[sb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                        // (the fragments right of the cut are zeros: only the tiles that hold ranks before this tile's own;
-                        // the wait for tile T-1 to be complete -- T = 0: rank 0 is there -- behind the first fragments' loads)
-                        const int nXn = (gfirst + 15) >> 4;
-                        if (nXn > 0)
-                            left_products<HB, NS, CH>(acc, acd, rsw, hF0C + (T + 1) * rbX, HB ? X16b : Xb, HB ? szX16 : szY, 0, nXn < nXT ? nXn : nXT, lane,
-                                                      [&]() __attribute__((always_inline)) { if (pe && lane == 0) pe[4] = clock64(); wait_for<HB != 0>(flags, F_X, gen + T); if (pe && lane == 0) pe[5] = clock64(); });
-                        if (pe && lane == 0) pe[1] = clock64();
-                        float* sp0 = SP0 + ((T + 1) & 1) * (NS * 16 * SPAD);
-#pragma unroll
-                        for (int sb = 0; sb < NS; ++sb)
-                            *reinterpret_cast<float4*>(sp0 + (sb * 16 + p) * SPAD + 4 * q) =
-                                make_float4((acc[sb][0] + acd[sb][0]) + b0.x, (acc[sb][1] + acd[sb][1]) + b0.y,
-                                            (acc[sb][2] + acd[sb][2]) + b0.z, (acc[sb][3] + acd[sb][3]) + b0.w);
-                        publish(flags, F_P0, gen + T + 2);
-                        if (pf && lane == 0 && wv == 3) pf[3] = clock64();
-                    }
-                }
+                if (wv == P0W && P0W != 2) { LAYER0_STEP() }
                 if (wv == 3) {
                     if (T + 1 < nT) {
                         // ---- ahead of the chain: a NEW output tile of the next hidden tile starts its row now, over the
@@ -958,6 +963,7 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
             }
             }
         }
+#undef LAYER0_STEP
         __syncthreads();                                  // (the helpers are done with this transform's x and activations)
         // re-rank for the next transform (or write out) with every thread of the workgroup: the target rank of a rank is two
         // dependent global loads, so eight elements' worth are requested together (one wavefront walking the subset's
