@@ -260,6 +260,11 @@ def main():
                          "likelihood behind the second sweep: measured 2605 (0.5) / 2767 (0.65) / 2844 (0.7) / 2843 (0.8) steps/s")
     ap.add_argument("--flow", default="maf3", help="maf3 | maf6 | maf12 | nsf3 | nsf6 | nsf12 | customN = N-transform MAF (BASELINE configs use maf3; configs[4] is custom8 at --dim 128 --particles 5000)")
     ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "solo", "duo", "lane"], default="auto")
+    ap.add_argument("--precision", choices=["f32", "bf16", "f16"], default="f32",
+                    help="f32: float32 flow everywhere (default, the 1e-5 path).  bf16 (BASELINE configs[4] names it) / f16: the wide flows' "
+                         "inverse sweep multiplies everything left of the diagonal tile with 16-bit operands and float32 accumulation "
+                         "(Flow(inverse_precision=...); the dependent chain stays float32) -- opt-in precision, tolerance stated in "
+                         "tests/test_gpu_config.py")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
@@ -321,9 +326,9 @@ def main():
     logl, logp = target(x), prior.logpdf(x)
     if args.flow.startswith("custom"):                      # customN: N-transform MAF with the default hidden width (configs[4]: custom8 @ 128-D)
         from pocomc_amd.maf_spec import MAFSpec
-        flow = Flow(D, MAFSpec(D, int(args.flow[6:])), seed=0)
+        flow = Flow(D, MAFSpec(D, int(args.flow[6:])), seed=0, inverse_precision=args.precision)
     else:
-        flow = Flow(D, args.flow, seed=0)                   # replicated weights
+        flow = Flow(D, args.flow, seed=0, inverse_precision=args.precision if not args.flow.startswith("nsf") else "f32")   # replicated weights
     flow.inverse_algo = {"auto": 0, "triangular": 1, "naive": 2, "solo": 6, "duo": 7, "lane": 8}[args.inverse]
     torch.manual_seed(0)                                    # same shuffles / batches on every rank
     u_fit = torch.from_numpy(scaler.forward(x_fit[:n])).float().cuda()
@@ -643,14 +648,18 @@ def main():
     # SURVEY 8(d) naive-equivalent figure ((D+1) dense passes per transform, which this algorithm does not perform) is
     # kept as a side key
     achieved = actual_flops / t_inv / 1e12
-    roofline = {"bound": "mfma", "kernel": roof_kernel, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None if traffic is None else traffic["hbm_bytes_per_launch"],     # HBM bytes per launch (PMC)
-                # PMC passes cannot run inside this process: `traffic` is the committed rocprofv3 measurement of this very
-                # command, used only when the kernel sources it was taken on are the ones this run was built from
-                "traffic_from": None if traffic is None else {"file": traffic["file"], "kernel_source_hash": traffic["kernel_source_hash"],
-                                                              "pmc_passes_in_this_invocation": False},
-                "traffic_detail": traffic,
+    lane16 = args.precision != "f32" and roof_kernel == "maf_inverse_tri6_kernel" and bool(flow._desc.lane16)
+    peak = PEAK_BF16_MFMA_TFLOPS if lane16 else PEAK_F32_MFMA_TFLOPS
+    roofline = {"bound": "mfma", "kernel": roof_kernel, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak,
+                "peak_note": ("dense bf16 / f16 MFMA peak: the left-looking products (the bulk of the executed flops) run on "
+                              "v_mfma_f32_16x16x32_bf16 / _f16; the dependent chain (diagonal tiles) stays on v_mfma_f32_4x4x1_16b_f32"
+                              if lane16 else "float32 MFMA peak (= vector peak)"),
+                # HBM bytes per launch come from PMC counters, which cannot be collected inside this process: null here;
+                # the committed rocprofv3 PMC measurement of this very command (same kernel sources, by hash) is kept under
+                # `traffic_committed_profile` for reference
+                "traffic": None,
+                "traffic_committed_profile": traffic,
                 "avg_launch_us": inv_us_live, "launches_timed": len(ev_pairs[::args.event_every]),
                 "walkers_per_launch": n_launch,
                 "flops_per_launch": actual_flops,
@@ -795,10 +804,29 @@ def main():
             flow_cfg5 = {"error": repr(exc)}
     ms_per_step = dt / args.steps * 1e3
     value = (n * world * args.steps / dt) / 1e4
+    # 16-bit helper products: how far the sweep this run timed is from the float32 sweep ON THE TRAINED FLOW, at the current
+    # walkers' theta (the opt-in precision's cost in accuracy, measured where it is used)
+    lane16_check = None
+    if args.precision != "f32" and bool(flow._desc.lane16):
+        th = (leng.lanes[0].theta32 if leng is not None else eng.theta32)[:4096].clone()
+        keep = flow.inverse_algo
+        flow.inverse_algo = 0
+        x16, l16 = flow.inverse(th)
+        flow.inverse_algo = 8                               # PMC_INVERSE_TRIANGULAR_LANE: the float32 helpers
+        x32, l32 = flow.inverse(th)
+        flow.inverse_algo = keep
+        okr = torch.isfinite(x32).all(dim=1) & torch.isfinite(x16).all(dim=1)
+        ex = ((x16 - x32).abs().max(dim=1).values / x32.abs().max(dim=1).values.clamp_min(1e-30))[okr]
+        el = (l16 - l32).abs()[okr]
+        lane16_check = {"rows": int(okr.sum().item()), "x_rel_err_max": float(ex.max().item()), "x_rel_err_median": float(ex.median().item()),
+                        "ladj_abs_err_max": float(el.max().item()), "ladj_abs_err_median": float(el.median().item()),
+                        "note": f"{args.precision} left-looking products against the float32 sweep of the same (trained) flow, per walker"}
     out = {"metric": "preconditioned MCMC steps/sec (1e4 particles, 32-D)", "value": value,
            "unit": "steps/s per 1e4 walkers", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32 flow (MFMA) + f64 step", "data": "synthetic",
+           "dtype": ("f32 flow (MFMA) + f64 step" if args.precision == "f32" else
+                     f"{args.precision} left-looking products + f32 chain of the flow inverse (MFMA, f32 accumulation) + f64 step"),
+           "data": "synthetic",
            "config": {"workload": f"{D}-D {TARGET_NAMES[args.target]}, U({p_lo:g},{p_hi:g})^{D} prior, {n} walkers/GPU x {world} GPU, {args.flow} "
                                   f"(H={spec.hidden}), beta={beta}, tpCN kernel, host numpy likelihood in the loop",
                       "walkers_per_gpu": n, "global_walkers": n * world, "n_dim": D, "flow": args.flow,
@@ -806,7 +834,7 @@ def main():
                       "lanes": len(leng.lanes) if leng is not None else 1,
                       "lane_rows": [int(e_.n) for e_ in leng.lanes] if leng is not None else [n],
                       "pipelined_device_adaptation": bool(pipelined and leng is not None),
-                      "inverse_algo": args.inverse, "host_threads": args.host_threads, "host_prefetch_threads": args.host_prefetch, "host_x_order": args.x_order, "prior_on_device": bool(device_prior),
+                      "inverse_algo": args.inverse, "inverse_precision": args.precision, "host_threads": args.host_threads, "host_prefetch_threads": args.host_prefetch, "host_x_order": args.x_order, "prior_on_device": bool(device_prior),
                       "accept_rate": float((ad_l if leng is not None else ad).mean_alpha),
                       "backend": (dist.get_backend() if world > 1 else None),
                       "collectives": (None if world == 1 else ("RCCL (torch.distributed nccl backend on ROCm)" if dist.get_backend() == "nccl" else "gloo (functional check on a shared GPU)")),
@@ -815,6 +843,7 @@ def main():
            "roofline": roofline,
            "roofline_sweeps": sweeps,
            "flow_fit": flow_fit,
+           "inverse_16bit_vs_f32": lane16_check,
            "flow_config5": flow_cfg5,
            "device_only_steps_per_s": 1e6 / (us["propose"] + us["maf_inverse"] + us["scaler_inverse"]
                                              + us["accept_reduce"]),

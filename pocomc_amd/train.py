@@ -610,6 +610,6 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
     torch.cuda.current_stream().synchronize()
     for t in acc_h + h_perm[0] + h_perm[1]:
         _pinned_give(t)
-    if getattr(flow, "_bf16", None) is not None:
-        flow.repack()                              # the bf16 image follows the trained float32 parameters
+    if getattr(flow, "_bf16", None) is not None or getattr(flow, "_lane16", None) is not None:
+        flow.repack()                              # the 16-bit images follow the trained float32 parameters
     return history

@@ -128,3 +128,59 @@ def test_bf16_forward_and_logprob_against_the_fp32_oracle(D, T, n):
     assert (np.abs(z2.numpy() - o2.forward(x)[0]).max(axis=1) / np.abs(o2.forward(x)[0]).max(axis=1)).max() < 3e-2
     with pytest.raises(NotImplementedError):
         Flow(4, "nsf3", precision="bf16")
+
+
+# ------------------------------------------------------------------ 16-bit helper operands of the lane sweep (config 5)
+@pytest.mark.parametrize("D,T,n", [(128, 8, 33), (128, 8, 5000), (50, 6, 6496), (64, 3, 1000)])
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_lane_sweep_with_16bit_helpers_against_the_float32_sweep(D, T, n, prec):
+    """``Flow(inverse_precision="bf16" | "f16")``: the lane-per-walker sweep multiplies everything LEFT of the diagonal tile
+    (the helper wavefronts' products: weights and activations rounded to 16 bits, float32 accumulation) on
+    ``v_mfma_f32_16x16x32_bf16 / _f16``; the dependent chain stays float32.  Opt-in precision, stated tolerance (per walker,
+    against the float32 sweep of the same flow, itself held to 1e-5 against the oracle above; n = 33 also against the
+    oracle's D-pass inverse): bf16 -- x within 3e-2 of the row's scale, the log-determinant within 0.3 absolute (it sums
+    T D log-scales each good to ~2^-9 of its hyper-network's terms); f16 (three more mantissa bits) -- 4e-3 and 4e-2.
+    Measured on MI355X at (128, 8): bf16 1.1e-2 / 0.098, f16 1.4e-3 / 0.012.  These are flows of the default initialisation
+    x 1.2: a TRAINED flow can condition the sweep much worse (bench.py reports ``inverse_16bit_vs_f32`` on its trained flow)."""
+    from pocomc_amd import Flow
+    spec = MAFSpec(D, T)
+    flat = cases.flow_params(spec, 3)
+    f32 = Flow(D, spec)
+    f32.set_params(flat)
+    f16 = Flow(D, spec, inverse_precision=prec)
+    f16.set_params(flat)
+    assert f16.inverse_precision == prec and f16._desc.lane16
+    z = (np.random.default_rng(n).normal(size=(n, D)) * 1.2).astype(np.float32)
+    f32.inverse_algo = 8                                     # PMC_INVERSE_TRIANGULAR_LANE: float32 helpers
+    xr, lr = (t.numpy() for t in f32.inverse(torch.from_numpy(z)))
+    x, l = (t.numpy() for t in f16.inverse(torch.from_numpy(z)))            # AUTO: the 16-bit helpers
+    fin = np.isfinite(xr).all(axis=1)
+    assert fin.mean() > 0.995 and np.isfinite(x[fin]).all()
+    ex = np.abs(x - xr)[fin].max(axis=1) / np.abs(xr[fin]).max(axis=1)
+    el = np.abs(l - lr)[fin]
+    print(f"{prec} helpers D={D} T={T} n={n}: x max {ex.max():.2e} median {np.median(ex):.2e}; ladj max {el.max():.2e} median {np.median(el):.2e}")
+    tx, tl = (3e-2, 0.3) if prec == "bf16" else (4e-3, 4e-2)
+    assert ex.max() < tx and el.max() < tl
+    assert ex.max() > 1e-6                                   # (it IS the 16-bit path: the float32 sweeps agree to 1e-6)
+    # explicit algorithm ids: 9 = 16-bit helpers (needs the image), 8 = float32 helpers whatever is attached
+    f16.inverse_algo = 9
+    x9, _ = f16.inverse(torch.from_numpy(z[:64]))
+    np.testing.assert_array_equal(x9.numpy(), x[:64])
+    f16.inverse_algo = 8
+    x8, _ = f16.inverse(torch.from_numpy(z[:64]))
+    np.testing.assert_array_equal(x8.numpy(), xr[:64])
+    with pytest.raises(Exception):
+        f32.inverse_algo = 9
+        f32.inverse(torch.from_numpy(z[:16]))
+    if n <= 64:
+        xo, lo = OracleMAF(spec, flat).inverse(z)
+        eo = (np.abs(x - xo).max(axis=1) / np.abs(xo).max(axis=1)).max()
+        assert eo < tx
+    # the image follows the parameters (set_params / the end of fit)
+    f16.inverse_algo = 0
+    f16.set_params(flat * np.float32(0.5))
+    f32.set_params(flat * np.float32(0.5))
+    f32.inverse_algo = 8
+    xa, _ = f16.inverse(torch.from_numpy(z[:256]))
+    xb, _ = f32.inverse(torch.from_numpy(z[:256]))
+    assert (np.abs(xa.numpy() - xb.numpy()).max(axis=1) / np.abs(xb.numpy()).max(axis=1)).max() < tx
