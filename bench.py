@@ -822,7 +822,7 @@ def main():
                         "ladj_abs_err_max": float(el.max().item()), "ladj_abs_err_median": float(el.median().item()),
                         "note": f"{args.precision} left-looking products against the float32 sweep of the same (trained) flow, per walker"}
     out = {"metric": "preconditioned MCMC steps/sec (1e4 particles, 32-D)", "value": value,
-           "unit": "steps/s per 1e4 walkers", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "unit": ("steps/s per 1e4 walkers" if world == 1 else "steps/s × global_walkers/1e4 (weak)"), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": ("f32 flow (MFMA) + f64 step" if args.precision == "f32" else
                      f"{args.precision} left-looking products + f32 chain of the flow inverse (MFMA, f32 accumulation) + f64 step"),
@@ -837,7 +837,12 @@ def main():
                       "inverse_algo": args.inverse, "inverse_precision": args.precision, "host_threads": args.host_threads, "host_prefetch_threads": args.host_prefetch, "host_x_order": args.x_order, "prior_on_device": bool(device_prior),
                       "accept_rate": float((ad_l if leng is not None else ad).mean_alpha),
                       "backend": (dist.get_backend() if world > 1 else None),
-                      "collectives": (None if world == 1 else ("RCCL (torch.distributed nccl backend on ROCm)" if dist.get_backend() == "nccl" else "gloo (functional check on a shared GPU)")),
+                      "collectives": (None if world == 1 else
+                                      ("pmc_comm mailboxes inside the C pipeline (IPC device memory, one 2+2D-double sum per step; "
+                                       "the process group only exchanges the handles at start-up)"
+                                       if (laned_host or {}).get("pipeline") else
+                                       ("RCCL (torch.distributed nccl backend on ROCm)" if dist.get_backend() == "nccl"
+                                        else "gloo (functional check on a shared GPU)"))),
                       "ranks_reported_by_backend": (dist.get_world_size() if world > 1 else 1),
                       "shared_gpu": bool(os.environ.get("PMC_BENCH_SHARE_GPU"))},
            "roofline": roofline,

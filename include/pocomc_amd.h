@@ -520,6 +520,24 @@ int pmc_adapt_update(const double* const* parts, int32_t n_parts, int32_t D, dou
                      const pmc_done_t* done, void* stream);
 int pmc_stream_synchronize(void* stream);
 
+/* The all-reduce of a sharded step (one exchange of D + 4 doubles per step so that sigma, mu and the stop
+ * decision of mcmc.py:152-180 are global) inside this library: one process per GPU on one node, a mailbox per rank in its
+ * HBM shared through hipIpc handles (xGMI peer stores + sequence words), sums formed in RANK ORDER by every rank -- the same
+ * bits everywhere, whatever the arrival order.
+ *   comm = pmc_comm_create(rank, world <= 8, width >= D + 4);  pmc_comm_handle(comm, h64) -> 64 bytes the host language
+ *   exchanges between the ranks' processes (e.g. torch.distributed.all_gather_object);  pmc_comm_connect(comm, world x 64 B).
+ *   pmc_comm_adapt_update = pmc_adapt_update with the parts' total summed over the ranks first (every rank calls it in
+ *   the same order; timeout_s bounds the wait for a peer: on a timeout sums[0] is NaN and `done` is written all the same).
+ *   pmc_pipeline_set_comm(pipeline, comm): the pipelined step of a sharded walker set. */
+void* pmc_comm_create(int32_t rank, int32_t world, int32_t width);
+int pmc_comm_handle(void* comm, void* out64);
+int pmc_comm_connect(void* comm, const void* handles);
+void pmc_comm_destroy(void* comm);
+int pmc_comm_adapt_update(void* comm, const double* const* parts, int32_t n_parts, int32_t D, double* total_out, double* h_sums,
+                          double* adapt_state, int32_t adapt_mode, double c_sigma, double c_mu, double cap, double n_total,
+                          const pmc_done_t* done, double timeout_s, void* stream);
+int pmc_pipeline_set_comm(void* pipeline, void* comm);
+
 /* The pipelined step of a walker set stepped as row ranges ("lanes": the device works on the proposals of lane k+1 and
  * the accept of lane k-1 while the host evaluates the likelihood of lane k), as one object: everything of a loop iteration
  * of pocomc/mcmc.py:74-156 that is not a black box is enqueued by these calls; the host language keeps the prior /

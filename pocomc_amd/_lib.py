@@ -152,6 +152,13 @@ SIGNATURES = {
     "pmc_step_post": (C.c_int, [P(pmc_step_t), P(pmc_rng_t), f64, f64, C.c_int, C.c_int, c_p]),
     "pmc_stream_synchronize": (C.c_int, [c_p]),
     "pmc_pipeline_create": (C.c_void_p, [C.POINTER(C.c_void_p), i32, C.c_uint64, C.POINTER(C.c_uint64), c_p, f64, c_p]),
+    "pmc_pipeline_set_comm": (C.c_int, [c_p, c_p]),
+    "pmc_comm_create": (C.c_void_p, [i32, i32, i32]),
+    "pmc_comm_handle": (C.c_int, [c_p, c_p]),
+    "pmc_comm_connect": (C.c_int, [c_p, c_p]),
+    "pmc_comm_destroy": (None, [c_p]),
+    "pmc_comm_adapt_update": (C.c_int, [c_p, C.POINTER(C.c_void_p), i32, i32, c_p, c_p, c_p, i32, f64, f64, f64, f64, P(pmc_done_t), f64,
+                                        c_p]),
     "pmc_pipeline_destroy": (None, [c_p]),
     "pmc_pipeline_start": (C.c_int, [c_p, f64, i64]),
     "pmc_pipeline_next": (C.c_int, [c_p, i32, f64, f64, i32, f64, f64, f64, f64, i32]),

@@ -7,6 +7,7 @@
 // These are HBM/L2-streaming sweeps with wave-level reductions -- no MFMA here.
 
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <math.h>
 #include <stdint.h>
 #include "philox.h"
@@ -831,6 +832,159 @@ extern "C" int pmc_adapt_update(const double* const* parts, int32_t n_parts, int
     hipLaunchKernelGGL(adapt_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ap, (int)n_parts, (int)D, total_out,
                        h_sums, ad, done ? (long long*)done->flag : nullptr, done ? (long long)done->value : 0LL);
     return pmc_check_launch("adapt_update_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The one exchange between the ranks of a sharded step (mcmc.py:152-156 need the GLOBAL sums: SURVEY.md 8(e)): an
+// all-reduce of D + 4 doubles, as a launch of this library on the step's own stream -- so that the sharded step runs
+// behind pmc_pipeline_* like the single-rank one, without a host round trip or a torch.distributed call between the last
+// accept and the adaptation.  One GPU per rank, all on one node: every rank owns a MAILBOX in its HBM (uncached
+// allocation), shared with the others through hipIpcGetMemHandle / hipIpcOpenMemHandle (xGMI peer access), laid out
+//     [2 parities][world][width doubles | sequence word].
+// Call number `seq` (all ranks call in the same order): a rank adds its own parts, writes the total into slot
+// [seq & 1][rank] of EVERY mailbox (its own too) with system-scope stores, then the sequence word of that slot with a
+// system-scope release; it then waits until the `world` words of its own mailbox show `seq` and adds the slots IN RANK ORDER
+// -- every rank forms the same sum bit for bit, whatever the arrival order.  A slot is rewritten two calls later, by when
+// every reader of the old value has published its next call (which it does only after reading).  The adaptation and the
+// completion word follow in the same kernel (adapt_update_kernel's tail).  The wait is bounded: on a timeout the sums'
+// first entry is NaN and the completion word is written all the same -- the host raises.
+// ---------------------------------------------------------------------------------------------------------------------
+struct pmc_comm {
+    int rank, world, width, stride;        // stride: doubles per slot (width + 1, rounded to 8)
+    double* own;                           // [2][world][stride], uncached device memory
+    double* peer[8];                       // the ranks' mailboxes as mapped into this process (peer[rank] == own)
+    long long seq;
+    hipIpcMemHandle_t handle;
+    bool connected;
+};
+
+struct CommPeers { double* p[8]; };
+
+__global__ __launch_bounds__(256) void comm_adapt_kernel(AdaptParts parts, int n_parts, int D, CommPeers peers, double* own, int rank,
+                                                         int world, int stride, long long seq, long long timeout_ticks,
+                                                         double* total_out, double* h_sums, pmc_adapt_args ad, long long* done_flag,
+                                                         long long done_value) {
+    __shared__ double tot[260];
+    __shared__ int late;
+    const int tid = threadIdx.x, W = D + 4;
+    const int par = (int)(seq & 1);
+    if (tid == 0) late = 0;
+    for (int j = tid; j < W; j += 256) {
+        double t = parts.p[0][j];
+        for (int k = 1; k < n_parts; ++k) t += parts.p[k][j];
+        for (int r = 0; r < world; ++r)
+            __hip_atomic_store(peers.p[r] + ((size_t)par * world + rank) * stride + j, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid < world)
+        __hip_atomic_store(reinterpret_cast<long long*>(peers.p[tid] + ((size_t)par * world + rank) * stride + (stride - 1)), seq,
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid < world) {
+        const long long* word = reinterpret_cast<const long long*>(own + ((size_t)par * world + tid) * stride + (stride - 1));
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            __builtin_amdgcn_s_sleep(8);
+            if (timeout_ticks > 0 && wall_clock64() - t0 > timeout_ticks) { late = 1; break; }
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < W; j += 256) {
+        double t = 0.0;
+        for (int r = 0; r < world; ++r)
+            t += __hip_atomic_load(own + ((size_t)par * world + r) * stride + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (late && j == 0) t = __builtin_nan("");
+        tot[j] = t;
+        if (total_out) total_out[j] = t;
+        if (h_sums) h_sums[j] = t;
+    }
+    __syncthreads();
+    if (ad.state && ad.mode && !late) adapt_apply(ad, tot, tid, D);
+    if (done_flag) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done_flag, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+extern "C" void* pmc_comm_create(int32_t rank, int32_t world, int32_t width) {
+    if (world < 1 || world > 8 || rank < 0 || rank >= world || width < 1 || width > 260) { pmc_fail("pmc_comm_create: 1..8 ranks, width <= 260"); return nullptr; }
+    pmc_comm* c = new pmc_comm();
+    c->rank = rank; c->world = world; c->width = width; c->stride = (width + 1 + 7) & ~7;
+    c->seq = 0; c->connected = false;
+    const size_t bytes = (size_t)2 * world * c->stride * sizeof(double);
+    void* ptr = nullptr;
+    // uncached: a peer's stores over xGMI must be what this device's loads see, without a cache line of its own in between
+    hipError_t e = hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&ptr, bytes); }
+    if (e != hipSuccess) { pmc_fail_hip(e, "pmc_comm_create: allocation of the mailbox"); delete c; return nullptr; }
+    if (hipMemset(ptr, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { pmc_fail("pmc_comm_create: hipMemset"); (void)hipFree(ptr); delete c; return nullptr; }
+    c->own = (double*)ptr;
+    for (int r = 0; r < 8; ++r) c->peer[r] = nullptr;
+    c->peer[rank] = c->own;
+    if (world > 1) {
+        e = hipIpcGetMemHandle(&c->handle, ptr);
+        if (e != hipSuccess) { pmc_fail_hip(e, "pmc_comm_create: hipIpcGetMemHandle"); (void)hipFree(ptr); delete c; return nullptr; }
+    } else c->connected = true;
+    return c;
+}
+
+extern "C" int pmc_comm_handle(void* cc, void* out64) {
+    pmc_comm* c = (pmc_comm*)cc;
+    if (!c || !out64) return pmc_fail("pmc_comm_handle: null argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    memcpy(out64, &c->handle, 64);
+    return 0;
+}
+
+// handles: world x 64 bytes, rank r's at 64 r (as pmc_comm_handle returned them in the ranks' processes)
+extern "C" int pmc_comm_connect(void* cc, const void* handles) {
+    pmc_comm* c = (pmc_comm*)cc;
+    if (!c || !handles) return pmc_fail("pmc_comm_connect: null argument");
+    for (int r = 0; r < c->world; ++r) {
+        if (r == c->rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char*)handles + 64 * r, 64);
+        void* ptr = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return pmc_fail_hip(e, "pmc_comm_connect: hipIpcOpenMemHandle");
+        c->peer[r] = (double*)ptr;
+    }
+    c->connected = true;
+    return 0;
+}
+
+extern "C" void pmc_comm_destroy(void* cc) {
+    pmc_comm* c = (pmc_comm*)cc;
+    if (!c) return;
+    for (int r = 0; r < c->world; ++r)
+        if (r != c->rank && c->peer[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
+    if (c->own) (void)hipFree(c->own);
+    delete c;
+}
+
+// total over the parts of this rank AND over the ranks (rank order), then as pmc_adapt_update: total_out / h_sums / the
+// adaptation / done.  Every rank must make the same sequence of calls.  timeout_s <= 0: wait for ever.
+extern "C" int pmc_comm_adapt_update(void* cc, const double* const* parts, int32_t n_parts, int32_t D, double* total_out,
+                                     double* h_sums, double* adapt_state, int32_t adapt_mode, double c_sigma, double c_mu, double cap,
+                                     double n_total, const pmc_done_t* done, double timeout_s, void* stream) {
+    pmc_comm* c = (pmc_comm*)cc;
+    if (!c || !c->connected) return pmc_fail("pmc_comm_adapt_update: the communicator is not connected");
+    if (!parts || n_parts < 1 || n_parts > 8 || D < 1 || D + 4 > c->width) return pmc_fail("pmc_comm_adapt_update: bad argument");
+    AdaptParts ap{};
+    for (int k = 0; k < n_parts; ++k) {
+        if (!parts[k]) return pmc_fail("pmc_comm_adapt_update: null part");
+        ap.p[k] = parts[k];
+    }
+    CommPeers pe{};
+    for (int r = 0; r < c->world; ++r) pe.p[r] = c->peer[r];
+    pmc_adapt_args ad{adapt_state, adapt_state ? adapt_mode : 0, c_sigma, c_mu, cap, n_total, {}, 0};
+    c->seq += 1;
+    const long long ticks = timeout_s > 0.0 ? (long long)(timeout_s * 1.0e8) : 0LL;        // wall_clock64: 100 MHz
+    hipLaunchKernelGGL(comm_adapt_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ap, (int)n_parts, (int)D, pe, c->own, c->rank,
+                       c->world, c->stride, c->seq, ticks, total_out, h_sums, ad, done ? (long long*)done->flag : nullptr,
+                       done ? (long long)done->value : 0LL);
+    return pmc_check_launch("comm_adapt_kernel");
 }
 
 int pmc_accept_adapt(int kind, int preconditioned, pmc_state_t* cur, const pmc_proposal_t* prop, double beta, double nu,

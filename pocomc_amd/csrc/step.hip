@@ -274,6 +274,7 @@ struct pmc_pipeline {
     int64_t step;                 // the step whose pre-steps are in flight
     void* stream;
     void* prefetcher;
+    void* comm;                   // pmc_comm of a sharded walker set (the ranks' sums are exchanged behind the last accept), or NULL
     double timeout;
     double t_wait_x, t_wait_sums, t_enq_accept, t_enq_pre;
     int64_t n_steps;
@@ -305,6 +306,7 @@ extern "C" void* pmc_pipeline_create(const pmc_step_t* const* lanes, int32_t n_l
     p->step = 0;
     p->stream = stream;
     p->prefetcher = prefetcher;
+    p->comm = nullptr;
     p->timeout = wait_timeout_s;
     p->t_wait_x = p->t_wait_sums = p->t_enq_accept = p->t_enq_pre = 0.0;
     p->n_steps = 0;
@@ -312,6 +314,16 @@ extern "C" void* pmc_pipeline_create(const pmc_step_t* const* lanes, int32_t n_l
 }
 
 extern "C" void pmc_pipeline_destroy(void* pp) { delete (pmc_pipeline*)pp; }
+
+// a sharded walker set (one process per GPU): behind the last lane's accept the ranks' sums are added by the library's own
+// all-reduce (pmc_comm_adapt_update: IPC mailboxes, sums in rank order) before the adaptation -- the same pipeline as a
+// single rank's, one more dependent launch
+extern "C" int pmc_pipeline_set_comm(void* pp, void* comm) {
+    pmc_pipeline* p = (pmc_pipeline*)pp;
+    if (!p) return pmc_fail("pmc_pipeline_set_comm: null pipeline");
+    p->comm = comm;
+    return 0;
+}
 
 static int pipeline_enqueue_pre(pmc_pipeline* p, int64_t step, double nu) {
     for (int k = 0; k < p->n_lanes; ++k) {
@@ -343,15 +355,25 @@ extern "C" int pmc_pipeline_next(void* pp, int32_t lane_done, double beta, doubl
         pmc_step_t s = *p->lanes[lane_done];
         s.adapt_n_other = 0;
         s.adapt_mode = 0;
-        if (lane_done == last) {
+        if (lane_done == last && !p->comm) {
             // the last range's accept closes the set: total sums, sigma / mu update, sums + completion word to the host
             s.adapt_mode = adapt_mode; s.adapt_c_sigma = c_sigma; s.adapt_c_mu = c_mu; s.adapt_cap = cap;
             s.adapt_n_total = n_total;
             for (int k = 0; k < last; ++k) s.adapt_other[k] = p->lanes[k]->sums;
             s.adapt_n_other = last;
         }
-        const int rc = pmc_step_post(&s, &p->rng[lane_done], beta, nu, 0, lane_done == last ? 1 : 0, p->stream);
+        const int rc = pmc_step_post(&s, &p->rng[lane_done], beta, nu, 0, (lane_done == last && !p->comm) ? 1 : 0, p->stream);
         if (rc) return rc;
+        if (lane_done == last && p->comm) {
+            // sharded: this rank's lanes + the other ranks' totals (rank order), the adaptation, sums + completion word
+            const double* parts[8];
+            for (int k = 0; k <= last; ++k) parts[k] = p->lanes[k]->sums;
+            const pmc_step_t* sl = p->lanes[last];
+            pmc_done_t dn{sl->h_done + 1, (int64_t)p->step + 1, nullptr};
+            const int rc2 = pmc_comm_adapt_update(p->comm, parts, last + 1, sl->D, nullptr, sl->h_sums, sl->adapt_state, adapt_mode,
+                                                  c_sigma, c_mu, cap, n_total, &dn, p->timeout, p->stream);
+            if (rc2) return rc2;
+        }
         const double t1 = now_s();
         p->t_enq_accept += t1 - t0;
         t0 = t1;

@@ -174,6 +174,50 @@ def allreduce_sums(sums_dev, group=None):
     return sums_dev
 
 
+_COMMS = {}
+
+
+def small_comm(lib, group, width):
+    """The library's own all-reduce for the D + 4 sums of a sharded step (``pmc_comm_*``: a mailbox per rank in its HBM,
+    shared through hipIpc handles; sums in rank order, so every rank holds the same bits): one communicator per process
+    group and process, created on first use -- the 64-byte handles travel through ``torch.distributed.all_gather_object``
+    (any backend), everything after that is device to device.  One node, one process per GPU, <= 8 ranks; returns None
+    where that does not hold or ``PMC_C_ALLREDUCE=0`` (the step then exchanges through ``torch.distributed``)."""
+    import torch.distributed as dist
+    if os.environ.get("PMC_C_ALLREDUCE", "1") == "0":
+        return None
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world > 8:
+        return None
+    key = (id(group), world, rank)
+    c = _COMMS.get(key)
+    if c is not None and c[1] >= width:
+        return c[0]
+    w = max(int(width), 260)                          # (D <= 256: one communicator serves every engine of the group)
+    h = lib.pmc_comm_create(rank, world, w)
+    ok = bool(h)
+    buf = (C.c_ubyte * 64)()
+    if ok:
+        ok = lib.pmc_comm_handle(h, buf) == 0
+    mine = (bytes(buf), ok, os.uname().nodename)
+    allh = [None] * world
+    dist.all_gather_object(allh, mine, group=group)
+    if not all(a[1] for a in allh) or len({a[2] for a in allh}) != 1:
+        if h:
+            lib.pmc_comm_destroy(h)
+        _COMMS[key] = (None, 1 << 30)
+        return None
+    blob = b"".join(a[0] for a in allh)
+    good = lib.pmc_comm_connect(h, blob) == 0
+    flags = [None] * world
+    dist.all_gather_object(flags, good, group=group)
+    if not all(flags):
+        lib.pmc_comm_destroy(h)
+        h = None
+    _COMMS[key] = (h, w)
+    return h
+
+
 # --------------------------------------------------------------------------
 class StepEngine:
     """Device-resident state + buffers of one MCMC kernel call."""
@@ -766,7 +810,8 @@ class LanedEngine:
         import torch.distributed as dist
         sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         self._drop_pipe()
-        if self.c_pipeline and not sharded and len(self.lanes) <= 8:
+        comm = small_comm(self.lib, self.group, self.D + 4) if (sharded and self.c_pipeline) else None
+        if self.c_pipeline and (not sharded or comm) and len(self.lanes) <= 8:
             K = len(self.lanes)
             for e in self.lanes:
                 e._configure_step()
@@ -780,6 +825,10 @@ class LanedEngine:
                                                       float(first.wait_timeout), stream)
             if not self._pipe:
                 _lib.check(1, "pmc_pipeline_create")
+            if comm:
+                # sharded: the ranks' sums meet inside the library (pmc_comm_adapt_update) between the last accept and the
+                # adaptation -- the same C pipeline as a single rank's
+                _lib.check(self.lib.pmc_pipeline_set_comm(self._pipe, comm), "pmc_pipeline_set_comm")
             _lib.check(self.lib.pmc_pipeline_start(self._pipe, float(nu), int(first.step_idx)), "pmc_pipeline_start")
             return
         for e in self.lanes:
@@ -815,7 +864,10 @@ class LanedEngine:
                     _lib.check(1, "pmc_pipeline_next")
             for e in self.lanes:
                 e.step_idx += 1
-            return calls, self.lanes[-1]._np_sums
+            sums = self.lanes[-1]._np_sums
+            if sums[0] != sums[0]:                       # (NaN: a rank did not arrive within the timeout, pmc_comm_adapt_update)
+                raise _lib.PocomcAmdError("sharded step: a rank did not deliver its sums within wait_timeout")
+            return calls, sums
         import torch.distributed as dist
         sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         lib, D, K = self.lib, self.D, len(self.lanes)

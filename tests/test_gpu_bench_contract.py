@@ -58,3 +58,9 @@ def test_two_ranks_on_a_shared_gpu_report_a_two_rank_line():
     assert c["shared_gpu"] == (torch.cuda.device_count() < 2)
     assert d["value"] > 0 and abs(d["ms_per_step"] - 20000 / 1e4 / d["value"] * 1e3) < 1e-6 * d["ms_per_step"] + 1e-9
     assert d["cpu_baseline"] is None and d["roofline"]["frac"] > 0
+    # the sharded step runs behind the C ABI (pmc_pipeline_next + the pmc_comm mailboxes): no process-group call per step
+    assert "global_walkers/1e4 (weak)" in d["unit"]
+    h = d["laned_path_host_us_per_step"]
+    assert h["pipeline"] == "pmc_pipeline_next (C ABI)" and "pmc_comm" in c["collectives"]
+    print("two-rank python_overhead us/step:", h["python_overhead"])
+    assert h["python_overhead"] <= 12.0, h               # (measured 9.3 on a shared GPU, 20 timed steps; 2 us of margin)

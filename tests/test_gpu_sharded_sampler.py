@@ -192,3 +192,39 @@ def test_two_rank_pipelined_kernel_call_equals_one_rank(tmp_path, lanes):
     same = np.isclose(u2, whole["u"], rtol=1e-9, atol=1e-12).all(axis=1)
     assert same.mean() >= 0.995, same.mean()
     np.testing.assert_allclose(np.concatenate([r0["logl"], r1["logl"]])[same], whole["logl"][same], rtol=1e-8)
+
+
+def _comm_worker(rank, world, port, out, c_allreduce):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      PMC_C_ALLREDUCE=c_allreduce)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pocomc_amd import mcmc as pmcmc
+    lo, hi = rank * 320, (rank + 1) * 320
+    r = _kernel_call(lo, hi, 2, dict(group=None, shard_offset=lo))
+    used = any(v[0] for v in pmcmc._COMMS.values())
+    np.savez(out % rank, u=r["u"], x=r["x"], logl=r["logl"], sigma=r["proposal_scale"], accept=r["accept"], steps=r["steps"], used=used)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_the_sharded_step_behind_the_c_abi_equals_the_torch_distributed_path(tmp_path):
+    """Two ranks, walkers sharded: the step runs behind ``pmc_pipeline_*`` with the library's own all-reduce between the
+    last accept and the adaptation (``pmc_comm_adapt_update``: hipIpc-shared mailboxes, the ranks' sums added in rank
+    order) -- bit for bit what the round-2 Python pipeline produces with ``torch.distributed.all_reduce`` in that place
+    (``PMC_C_ALLREDUCE=0``): with two ranks a + b is the same double in either order."""
+    import torch.multiprocessing as mp
+    res = {}
+    for flag in ("1", "0"):
+        out = str(tmp_path / f"c{flag}_%d.npz")
+        mp.spawn(_comm_worker, args=(2, _free_port(), out, flag), nprocs=2, join=True)
+        res[flag] = [np.load(out % 0), np.load(out % 1)]
+    assert bool(res["1"][0]["used"]) and bool(res["1"][1]["used"])          # the communicator was created and connected
+    assert not bool(res["0"][0]["used"])
+    for rk in (0, 1):
+        a, b = res["1"][rk], res["0"][rk]
+        assert int(a["steps"]) == int(b["steps"]) == 6
+        assert float(a["sigma"]) == float(b["sigma"]) and float(a["accept"]) == float(b["accept"])
+        for k in ("u", "x", "logl"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert float(res["1"][0]["sigma"]) == float(res["1"][1]["sigma"])
