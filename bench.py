@@ -55,8 +55,8 @@ def rosenbrock(x):
     Fortran-ordered (n, D) input (the engine's x_order='F'): every coordinate is a contiguous vector of n walkers, so
     the work is three elementwise passes and two fused square-and-sum reductions (einsum) over (D/2, n) blocks, instead
     of seven elementwise passes and a reduction.  C-ordered input (the CPU baseline's arrays): the row-wise form."""
-    if x.flags.f_contiguous and not x.flags.c_contiguous:
-        xT = x.T                                           # (D, n), C-contiguous view
+    if x.strides[0] == x.itemsize and x.strides[1] > x.itemsize:     # (column-major, or a row range of a column-major array)
+        xT = x.T                                           # (D, n) view, every row a contiguous vector
         a, b = xT[::2], xT[1::2]
         t = np.multiply(a, a)
         t -= b
@@ -258,6 +258,12 @@ def main():
                     help="fraction of the walkers in the first of two lanes (0.5 = equal).  The sweeps of the two lanes run one "
                          "after the other and cost the same whatever their size; a larger first lane puts more of the host "
                          "likelihood behind the second sweep: measured 2605 (0.5) / 2767 (0.65) / 2844 (0.7) / 2843 (0.8) steps/s")
+    ap.add_argument("--head-rows", type=int, default=0,
+                    help="rows of the first lane whose x' crosses PCIe ahead of the others, with a completion word of their own: "
+                         "the host's likelihood starts on them while the rest arrives (pmc_step_t.head_rows); 0 (default) = off.  "
+                         "Measured at 1536 rows: the word arrives 25 us earlier (wait_device 111 -> 86-93 us), and the likelihood "
+                         "pays it back -- it reads the head while the other rows' 1.3 MB are being written to the same memory "
+                         "(22-32 ns/row instead of 15.5) and is called once more: 3340-3360 steps/s either way")
     ap.add_argument("--flow", default="maf3", help="maf3 | maf6 | maf12 | nsf3 | nsf6 | nsf12 | customN = N-transform MAF (BASELINE configs use maf3; configs[4] is custom8 at --dim 128 --particles 5000)")
     ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "solo", "duo", "lane"], default="auto")
     ap.add_argument("--precision", choices=["f32", "bf16", "f16"], default="f32",
@@ -399,7 +405,7 @@ def main():
     if args.lanes > 1 or pipelined:
         leng = LanedEngine("preconditioned_pcn", n, D, flow, scaler, lanes=args.lanes, group=None,
                            shard_offset=rank * n, seed=20240928, x_order=args.x_order, streams=not pipelined,
-                           first_fraction=args.first_lane)
+                           first_fraction=args.first_lane, head_rows=max(0, args.head_rows))
         if device_prior:
             leng.set_device_prior(pc_prior)
         leng.load_state(u, x, logdetj, logl, logp)
@@ -489,9 +495,18 @@ def main():
     blas_limit = threadpool_limits(limits=1)
     if leng is not None and pipelined:
         leng.start_pipeline(float(ad_l.sigma), ad_l.mu, nu)      # the pre-steps of the first step
+    # events, collector pass: before the warm-up, so that nothing but the barrier stands between the warm-up steps and the
+    # timed ones (a collector pass takes tens of ms in which the GPU idles and clocks down: the first timed step then took
+    # 420-480 us against 297)
+    lib = eng.lib
+    ev_pairs = [(lib.pmc_event_create(), lib.pmc_event_create()) for _ in range(args.steps)]
+    import gc
+    gc.collect()
+    gc.disable()          # (no collector pause inside the 6 ms the driver times at --steps 20; re-enabled behind the region)
     for _ in range(args.warmup):
         step()
-        if leng is not None:
+    if leng is not None:                                     # (the timed path last, back to back: W warm-up steps of it)
+        for _ in range(args.warmup):
             step_laned()
     for k in t_seg:
         t_seg[k] = 0.0
@@ -500,12 +515,7 @@ def main():
     # ---- timed region: K steps through the composite entry points; the only instrumentation is one
     #      HIP event pair per step around the flow-inverse launch (recorded inside pmc_step_pre, on the
     #      stream the kernel is launched on)
-    lib = eng.lib
-    ev_pairs = [(lib.pmc_event_create(), lib.pmc_event_create()) for _ in range(args.steps)]
     step_times = [] if os.environ.get("PMC_BENCH_STEP_TIMES") else None      # (debugging aid: distribution of the step times)
-    import gc
-    gc.collect()
-    gc.disable()          # (no collector pause inside the 6 ms the driver times at --steps 20; re-enabled behind the region)
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -519,8 +529,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
+    head_rows_used = int(leng.lanes[0].head_rows) if (leng is not None and leng.lanes[0]._np_head[2] == 1) else 0
     if step_times is not None and rank == 0:
         st_ = np.diff(np.array([t0] + step_times)) * 1e6
+        if len(st_) <= 40:
+            print("[step times us] all", np.round(st_, 0).tolist(), file=sys.stderr)
         print(f"[step times us] median {np.median(st_):.1f} p90 {np.percentile(st_, 90):.1f} p99 {np.percentile(st_, 99):.1f} max {st_.max():.1f} "
               f"first5 {np.round(st_[:5], 1).tolist()} slow(>1.5x median) {int((st_ > 1.5 * np.median(st_)).sum())}", file=sys.stderr)
     roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = None, None
@@ -550,6 +563,40 @@ def main():
                                          - laned_host.get("enqueue_next_pre", 0.0) - laned_host.get("enqueue_adapt", 0.0)
                                          - laned_host.get("wait_sums", 0.0))
         leng.host_timers = None
+        if os.environ.get("PMC_BENCH_EPI_STAMPS") and rank == 0:
+            # measurement only: where the fused launch of lane 0 spends its epilogue (100 MHz stamps per workgroup)
+            import ctypes
+            nb = (leng.lanes[0].n + 15) // 16
+            stamps = torch.zeros(nb, 8, dtype=torch.int64, device="cuda")
+            fn = lib.pmc_debug_set_epilogue_stamps
+            fn.restype, fn.argtypes = None, [ctypes.c_void_p, ctypes.c_int64]
+            fn(stamps.data_ptr(), leng.lanes[0].n)
+            for _ in range(3):
+                step_laned()
+            torch.cuda.synchronize()
+            fn(None, 0)
+            st = stamps.cpu().numpy()
+            t0_ = st[:, 6].min()
+            us_ = lambda a: (a - t0_) / 100.0
+            names = ["epilogue entry", "elements done", "rows entry", "before x' stores (behind the head wait)", "x' stores issued",
+                     "fence passed", "kernel entry"]
+            hb = int(leng.lanes[0].head_rows) // 16
+            for sel, nm in ((slice(0, hb), "head blocks"), (slice(hb, nb), "other blocks")):
+                if st[sel].shape[0] == 0:
+                    continue
+                for i in (6, 0, 1, 2, 3, 4, 5):
+                    v = us_(st[sel, i])
+                    print(f"[epilogue stamps] {nm:12s} {names[i]:42s} min {v.min():7.1f} median {np.median(v):7.1f} p90 {np.percentile(v, 90):7.1f} max {v.max():7.1f} us", file=sys.stderr)
+            cu = st[:, 7] & 0xffffffff
+            xcc = (st[:, 7] >> 32) & 0xf
+            key = (xcc << 16) | ((cu >> 8) & 0xff) | (((cu >> 13) & 7) << 8)       # (xcc, se, sh+cu)
+            uniq, cnt = np.unique(key, return_counts=True)
+            late = us_(st[:, 0])
+            per = {k: c for k, c in zip(uniq, cnt)}
+            solo = np.array([per[k] == 1 for k in key])
+            print(f"[epilogue stamps] CUs used {len(uniq)}, blocks {nb}; sweep end (epilogue entry) median: blocks alone on their CU "
+                  f"{np.median(late[solo]) if solo.any() else float('nan'):.1f} us, blocks sharing a CU {np.median(late[~solo]) if (~solo).any() else float('nan'):.1f} us",
+                  file=sys.stderr)
         if pipelined:
             leng.finish_pipeline()
     inv_us_live = float(np.mean([lib.pmc_event_elapsed_ms(a, b) for a, b in ev_pairs[::args.event_every]])) * 1e3
@@ -833,6 +880,7 @@ def main():
                       "flow_trained_50_epochs": flow_trained, "parallelism": f"walker-sharded x{world}",
                       "lanes": len(leng.lanes) if leng is not None else 1,
                       "lane_rows": [int(e_.n) for e_ in leng.lanes] if leng is not None else [n],
+                      "head_rows": head_rows_used,
                       "pipelined_device_adaptation": bool(pipelined and leng is not None),
                       "inverse_algo": args.inverse, "inverse_precision": args.precision, "host_threads": args.host_threads, "host_prefetch_threads": args.host_prefetch, "host_x_order": args.x_order, "prior_on_device": bool(device_prior),
                       "accept_rate": float((ad_l if leng is not None else ad).mean_alpha),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PMC_ABI_VERSION 5
+#define PMC_ABI_VERSION 6
 
 const char* pmc_last_error(void);
 int pmc_abi_version(void);
@@ -314,6 +314,10 @@ int pmc_wait_flag(const int64_t* flag, int64_t value, double timeout_s);
 void* pmc_prefetcher_create(int32_t n_threads, const int32_t* cpus);
 int pmc_prefetcher_submit(void* prefetcher, const void* flag, int64_t value, const void* buf, int64_t bytes,
                           double timeout_s);
+/* the same for `count` pieces of `bytes` bytes, `stride` bytes apart (the first rows of every column of a column-major x':
+ * pmc_step_t.head_rows) */
+int pmc_prefetcher_submit_strided(void* prefetcher, const void* flag, int64_t value, const void* buf, int64_t bytes,
+                                  int64_t stride, int64_t count, double timeout_s);
 void pmc_prefetcher_destroy(void* prefetcher);
 
 /* pmc_scaler_inverse and pmc_prior_logpdf in ONE launch (the step's pre-phase is a chain of small
@@ -483,6 +487,15 @@ typedef struct pmc_step {
      * count (only the fused proposal + sweep + scaler launch does); the host then scans h_fin / logp' as before. */
     int64_t* h_clean;         /* pinned host int64 [1] or NULL */
     uint32_t* clean_count;    /* device uint32 [1], zeroed once by the caller */
+    /* "Head first": the x' of a launch crosses PCIe at ~40 GB/s, ~40 us for 6.5e3 x 32 rows, and the host's likelihood
+     * cannot start before rows are there.  With head_rows > 0 (a multiple of 16, < n) the fused proposal + sweep + scaler
+     * launch sends the rows [0, head_rows) first and raises h_head[0] <- step + 1 when they have arrived (h_head[1] <- rows
+     * counted not clean up to then, as h_clean; -1: not counted); h_done[0] follows when all rows have.  pmc_step_pre
+     * writes h_head[2] <- 1 at enqueue time when the launch sequence it chose raises the word, 0 when it does not (the
+     * host then waits for h_done[0] as without a head). */
+    int64_t head_rows;
+    int64_t* h_head;          /* pinned host int64 [3] or NULL */
+    uint32_t* head_ticket;    /* device uint32 [2], zeroed once by the caller */
 } pmc_step_t;
 
 #define PMC_ADAPT_TPCN 1      /* sigma <- |min(sigma + c (mean alpha - 0.234), cap)|      (mcmc.py:152, :476) */
@@ -560,6 +573,9 @@ int pmc_pipeline_start(void* pipeline, double nu, int64_t first_step);
 int pmc_pipeline_next(void* pipeline, int32_t lane_done, double beta, double nu, int32_t adapt_mode, double c_sigma,
                       double c_mu, double cap, double n_total, int32_t more);
 /* out f64 [6] <- { seconds spent waiting for x', waiting for the sums, enqueuing accepts, enqueuing pre-steps, steps, 0 } */
+/* behind a lane whose launch sends a head first (pmc_step_t.head_rows): pmc_pipeline_next returned with the head's rows in
+ * host memory; this waits for the others */
+int pmc_pipeline_wait_lane(void* pipeline, int32_t lane);
 int pmc_pipeline_stats(void* pipeline, double* out, int32_t reset);
 /* hipEvent helpers for the host language (live kernel timing inside bench.py). */
 void* pmc_event_create(void);

@@ -527,6 +527,13 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (FM > 0) {
+        if (pa.epi.on && pa.epi.stamps && threadIdx.x == 0) {          // (measurement only: scaler_body.h, ScalerEpi::stamps)
+            pa.epi.stamps[blockIdx.x * 8 + 6] = wall_clock64();
+            pa.epi.stamps[blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                                ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        }
+    }
     const int q = lane >> 4, p = lane & 15;
     const int D = m.D, Dp = m.Dp, Hp = m.Hp, T = m.T, nT = m.nT, nXT = m.nXT, nOT = m.nOT;
     const int nTl = __builtin_amdgcn_readfirstlane(m.meta[7]);                                                   // live hidden tiles (the padding tiles trail)

@@ -1020,7 +1020,7 @@ extern "C" int pmc_logw_stats(const double* logw, int64_t P, int64_t k, double* 
     const int nb = (int)grid_for(P, 256, RED_BLOCKS);
     hipLaunchKernelGGL(max_partial_kernel, dim3(nb), dim3(256), 0, st, logw, P, ws);
     hipLaunchKernelGGL(max_final_kernel, dim3(1), dim3(256), 0, st, ws, nb);
-    hipMemcpyAsync(stats, ws + nb, sizeof(double), hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(stats, ws + nb, sizeof(double), hipMemcpyDeviceToDevice, st);
     hipLaunchKernelGGL(wsum_partial_kernel, dim3(nb), dim3(256), 0, st, logw, P, (const double*)stats,
                        (const double*)nullptr, (int64_t)0, 0, ws);
     hipLaunchKernelGGL(wsum_final_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nb, stats, 1, 2);

@@ -13,6 +13,9 @@
 #include "pmc_internal.h"
 #include "scaler_body.h"
 
+static long long* g_epilogue_stamps = nullptr;       // pmc_debug_set_epilogue_stamps
+static int64_t g_epilogue_stamps_n = 0;
+
 extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu, double sigma, double cn_a,
                             void* stream) {
     if (!s || !rng) return pmc_fail("pmc_step_pre: null argument");
@@ -90,6 +93,12 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
             epi.done_value = done ? (long long)done->value : 0LL;
             epi.bad_count = (done && s->h_clean) ? s->clean_count : nullptr;
             epi.bad_flag = (done && s->h_clean && s->clean_count) ? (long long*)s->h_clean : nullptr;
+            epi.stamps = (n == g_epilogue_stamps_n) ? g_epilogue_stamps : nullptr;
+            if (done && xT && s->head_rows > 0 && s->head_rows < n && (s->head_rows & 15) == 0 && s->h_head && s->head_ticket) {
+                epi.head_blocks = (unsigned)(s->head_rows >> 4);        // (16 walkers per workgroup in both fused sweeps)
+                epi.head_ticket = s->head_ticket;
+                epi.head_flag = (long long*)s->h_head;
+            }
         }
         if (s->ev_inv0) (void)hipEventRecord((hipEvent_t)s->ev_inv0, st);
         rc = pmc_launch_propose_inverse_tri4(s->kind, s->cur.theta32, mu, s->inv_cov, s->chol, nu, sigma, cn_a, rng,
@@ -108,6 +117,8 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
         if (rc) return rc;
     }
     if (s->h_clean && !(scaled && done && s->clean_count)) *s->h_clean = -1;     // (this launch sequence does not count)
+    if (s->h_head)                                   // does the sequence raise the head's word?  (the host reads this before it waits)
+        s->h_head[2] = (scaled && done && xT && s->head_rows > 0 && s->head_rows < n && (s->head_rows & 15) == 0 && s->head_ticket) ? 1 : 0;
     if (scaled) {
         rc = 0;
     } else if (s->preconditioned) {
@@ -208,6 +219,10 @@ extern "C" int pmc_step_post(const pmc_step_t* s, const pmc_rng_t* rng, double b
     return 0;
 }
 
+// measurement only (bench.py, PMC_BENCH_EPI_STAMPS): device int64 [blocks][8] that the epilogue of the fused launches over
+// n_rows rows stamps, or NULL
+extern "C" void pmc_debug_set_epilogue_stamps(long long* dev, int64_t n_rows) { g_epilogue_stamps = dev; g_epilogue_stamps_n = n_rows; }
+
 extern "C" int pmc_stream_synchronize(void* stream) {
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return pmc_fail_hip(e, "hipStreamSynchronize");
@@ -218,7 +233,8 @@ extern "C" int pmc_stream_synchronize(void* stream) {
 // launch of every timed step through pmc_step_t.ev_inv0 / ev_inv1).
 extern "C" void* pmc_event_create(void) {
     hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) { pmc_fail("hipEventCreate failed"); return nullptr; }
+    const char* fl = getenv("PMC_EVENT_FLAGS");
+    if (hipEventCreateWithFlags(&e, fl ? (unsigned)atoi(fl) : hipEventDefault) != hipSuccess) { pmc_fail("hipEventCreate failed"); return nullptr; }
     return (void*)e;
 }
 extern "C" int pmc_event_record(void* ev, void* stream) {
@@ -332,6 +348,10 @@ static int pipeline_enqueue_pre(pmc_pipeline* p, int64_t step, double nu) {
         p->rng[k].step = (uint64_t)step;
         const int rc = pmc_step_pre(&s, &p->rng[k], nu, 0.0, 0.0, p->stream);
         if (rc) return rc;
+        const bool head = s.head_rows > 0 && s.h_head && s.h_head[2] == 1;
+        if (p->prefetcher && head)                          // (the head of a column-major x': D runs of head_rows doubles)
+            (void)pmc_prefetcher_submit_strided(p->prefetcher, s.h_head, step + 1, s.h_x, s.head_rows * 8, (int64_t)s.n * 8, s.D,
+                                                p->timeout > 0 ? p->timeout : 1.0);
         if (p->prefetcher)                                  // helper threads read x' once as soon as its completion word shows up
             (void)pmc_prefetcher_submit(p->prefetcher, s.h_done, step + 1, s.h_x, (int64_t)s.n * s.D * 8, p->timeout > 0 ? p->timeout : 1.0);
     }
@@ -379,7 +399,11 @@ extern "C" int pmc_pipeline_next(void* pp, int32_t lane_done, double beta, doubl
         t0 = t1;
     }
     if (lane_done < last) {
-        const int rc = pmc_wait_flag(p->lanes[lane_done + 1]->h_done, p->step + 1, p->timeout);
+        // the next lane's x': its first rows when the launch sends a head first (the caller evaluates those, then
+        // pmc_pipeline_wait_lane for the rest), all of them otherwise
+        const pmc_step_t* nx = p->lanes[lane_done + 1];
+        const bool head = nx->head_rows > 0 && nx->h_head && nx->h_head[2] == 1;
+        const int rc = pmc_wait_flag(head ? nx->h_head : nx->h_done, p->step + 1, p->timeout);
         p->t_wait_x += now_s() - t0;
         return rc;
     }
@@ -394,6 +418,16 @@ extern "C" int pmc_pipeline_next(void* pp, int32_t lane_done, double beta, doubl
     p->t_wait_sums += now_s() - t0;
     p->step += 1;
     p->n_steps += 1;
+    return rc;
+}
+
+// all rows of lane `lane`'s x' of the step in flight (behind a head: pmc_step_t.head_rows)
+extern "C" int pmc_pipeline_wait_lane(void* pp, int32_t lane) {
+    pmc_pipeline* p = (pmc_pipeline*)pp;
+    if (!p || lane < 0 || lane >= p->n_lanes) return pmc_fail("pmc_pipeline_wait_lane: bad argument");
+    const double t0 = now_s();
+    const int rc = pmc_wait_flag(p->lanes[lane]->h_done, p->step + 1, p->timeout);
+    p->t_wait_x += now_s() - t0;
     return rc;
 }
 

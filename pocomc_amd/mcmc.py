@@ -211,6 +211,19 @@ def small_comm(lib, group, width):
     good = lib.pmc_comm_connect(h, blob) == 0
     flags = [None] * world
     dist.all_gather_object(flags, good, group=group)
+    if all(flags):
+        # one exchange with known values before any step depends on the mailboxes: rank r sends r + 1 in every word (a
+        # mapping that opened but whose stores do not arrive shows up here, as a timeout or a wrong sum, on every rank
+        # alike -- the step then exchanges through torch.distributed)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        part = torch.full((8,), float(rank + 1), dtype=torch.float64, device=dev)
+        tot = torch.zeros(8, dtype=torch.float64, device=dev)
+        parts = (C.c_void_p * 1)(part.data_ptr())
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.pmc_comm_adapt_update(h, parts, 1, 4, tot.data_ptr(), None, None, 0, 0.0, 0.0, 0.0, 1.0, None, 10.0, stream)
+        torch.cuda.synchronize(dev)
+        good = rc == 0 and bool((tot == world * (world + 1) / 2).all().item())
+        dist.all_gather_object(flags, good, group=group)
     if not all(flags):
         lib.pmc_comm_destroy(h)
         h = None
@@ -338,6 +351,14 @@ class StepEngine:
         self.h_clean.fill_(-1)
         self._np_clean = self.h_clean.numpy()
         self._clean_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        # "head first" (pmc_step_t.head_rows): the fused launch sends the first head_rows rows of x' over PCIe before the
+        # others and raises a word of their own, so that the likelihood can start on them; 0: off
+        self.head_rows = 0
+        self.h_head = pin(3, dt=torch.int64)
+        self.h_head.zero_()
+        self._np_head = self.h_head.numpy()
+        self._head_ticket = torch.zeros(2, dtype=torch.int32, device=dev)
+        self._head_views = None
         self._direct_now = False
         self._pre_cfg = None     # switches the composite pre-step's struct fields were last written for
         # adaptation on the device (pmc_step_t.adapt_state): {sigma, cn_a, mu[D]}; see run_pipelined
@@ -522,7 +543,7 @@ class StepEngine:
     def _configure_step(self):
         """The fields of the composite entry points' struct that depend on the engine's switches only: written when
         one of them changed."""
-        cfg = (self.flow.inverse_algo if self.pre else 0, self.rng_prefill, self.host_direct, self.spin_wait)
+        cfg = (self.flow.inverse_algo if self.pre else 0, self.rng_prefill, self.host_direct, self.spin_wait, int(self.head_rows))
         if cfg != self._pre_cfg:
             self._pre_cfg = cfg
             if self.pre:
@@ -537,10 +558,19 @@ class StepEngine:
             self._step.h_clean = self.h_clean.data_ptr() if self._direct_now else None
             self._step.clean_count = self._clean_count.data_ptr() if self._direct_now else None
             self._step.ev_pre_done = None if self._direct_now else self._ev_pre     # (the completion word replaces it)
+            h = int(self.head_rows)
+            if h % 16 or not 0 <= h < self.n:
+                raise ValueError("head_rows: a multiple of 16 below the number of rows")
+            self._step.head_rows = h if self._direct_now else 0
+            self._step.h_head = self.h_head.data_ptr() if self._direct_now else None
+            self._step.head_ticket = self._head_ticket.data_ptr() if self._direct_now else None
+            self._np_head[2] = 0
+            self._head_views = (self._np_x[:h], self._np_x[h:], self._np_logl[:h], self._np_logl[h:]) if h else None
 
-    def evaluate(self, log_prior, log_like, have_blobs=False, blobs=None, waited=False):
+    def evaluate(self, log_prior, log_like, have_blobs=False, blobs=None, waited=False, rest=None):
         """Host black boxes on the compacted rows, ``mcmc.py:100-121``.  Returns
-        ``(n_calls, blobs_prime)``."""
+        ``(n_calls, blobs_prime)``.  ``rest``: the caller waited for the head of x' only (``head_rows``); ``rest()`` waits
+        for the other rows."""
         tm = self.host_timers
         t0 = time.perf_counter() if tm is not None else 0.0
         if waited:
@@ -565,6 +595,26 @@ class StepEngine:
             def log_like(a, _f=_ll):
                 ta = time.perf_counter(); r = _f(a); tm["likelihood"] += time.perf_counter() - ta
                 return r
+        if rest is not None:
+            if (self.prior_desc is not None and self._head_views is not None and self._direct_now and self._np_head[1] == 0
+                    and self.host_threads <= 1 and not have_blobs):
+                # the rows of the head are in host memory and clean: their likelihood runs while the others cross the link
+                xh, xt, lh, lt = self._head_views
+                ta = time.perf_counter() if tm is not None else 0.0
+                lh[:] = log_like(xh)[0]
+                tb = time.perf_counter() if tm is not None else 0.0
+                rest()
+                tc = time.perf_counter() if tm is not None else 0.0
+                if self._np_clean[0] == 0:
+                    lt[:] = log_like(xt)[0]
+                    if tm is not None:
+                        tm["head_likelihood"] = tm.get("head_likelihood", 0.0) + tb - ta
+                        tm["head_rest_wait"] = tm.get("head_rest_wait", 0.0) + tc - tb
+                        tm["head_tail_likelihood"] = tm.get("head_tail_likelihood", 0.0) + time.perf_counter() - tc
+                    return self.n, None
+                # (a row behind the head is not clean: the masks below, on all rows -- rare)
+            else:
+                rest()
         if self.prior_desc is not None:
             log_prior = None                          # logp' came back from the device with x'
             if ((waited or self._post_uploads) and self._direct_now and self._np_clean[0] == 0
@@ -720,7 +770,7 @@ class LanedEngine:
     the order in which the D+4 sums are added (last bits of mean(alpha), mean(theta))."""
 
     def __init__(self, kind, n, n_dim, flow, scaler, lanes=2, group=None, shard_offset=0, seed=0, x_order="C",
-                 streams=True, first_fraction=None):
+                 streams=True, first_fraction=None, head_rows=0):
         """``streams=False``: all lanes on the current stream, one after the other (the pipelined mode:
         :meth:`start_pipeline` / :meth:`step_pipelined`)."""
         n = int(n)
@@ -747,6 +797,10 @@ class LanedEngine:
                 e = StepEngine(kind, hi - lo, n_dim, flow, scaler, group=group, shard_offset=int(shard_offset) + lo,
                                seed=seed, x_order=x_order)
             self.lanes.append(e)
+        # "head first": lane 0 is the one the host waits for with nothing else to do -- its launch sends its first rows over
+        # PCIe ahead of the others (pmc_step_t.head_rows; the pipelined mode evaluates them while the rest arrives)
+        h = (int(head_rows) // 16) * 16
+        self.lanes[0].head_rows = h if 0 < h < self.lanes[0].n else 0
         self.lib = self.lanes[0].lib
         self.tpcn, self.pre = self.lanes[0].tpcn, self.lanes[0].pre
         self._tot = torch.zeros(self.D + 4, dtype=torch.float64, device=self.device)
@@ -859,7 +913,12 @@ class LanedEngine:
             calls = 0
             for k, e in enumerate(self.lanes):
                 e.host_timers = tm
-                calls += e.evaluate(log_prior, log_like, waited=True)[0]
+                rest = None
+                if e._np_head[2] == 1:              # (pmc_pipeline_next returned behind the head of this lane's x' only)
+                    def rest(k=k):
+                        if self.lib.pmc_pipeline_wait_lane(P, k):
+                            _lib.check(1, "pmc_pipeline_wait_lane")
+                calls += e.evaluate(log_prior, log_like, waited=True, rest=rest)[0]
                 if nxt(P, k, beta, nu, mode, c_sigma, c_mu, cap, n_total, int(more)):
                     _lib.check(1, "pmc_pipeline_next")
             for e in self.lanes:
@@ -1048,7 +1107,7 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
                  and replay is None and all(option_dict.get(k, True) for k in ("host_direct", "spin_wait")))
     if lanes > 1 or want_pipe:                      # (the pipelined step lives behind pmc_pipeline_*: one lane is a pipeline too)
         eng = LanedEngine(kind, n_walkers, n_dim, flow, scaler, lanes=lanes, group=group,
-                          first_fraction=option_dict.get("first_lane"),
+                          first_fraction=option_dict.get("first_lane"), head_rows=int(option_dict.get("head_rows") or 0),
                           shard_offset=option_dict.get("shard_offset", 0), seed=seed, x_order=x_order,
                           streams=not want_pipe)
         tune = eng.configure
