@@ -516,6 +516,8 @@ def main():
     #      HIP event pair per step around the flow-inverse launch (recorded inside pmc_step_pre, on the
     #      stream the kernel is launched on)
     step_times = [] if os.environ.get("PMC_BENCH_STEP_TIMES") else None      # (debugging aid: distribution of the step times)
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_THREAD) if step_times is not None else None
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -532,6 +534,12 @@ def main():
     head_rows_used = int(leng.lanes[0].head_rows) if (leng is not None and leng.lanes[0]._np_head[2] == 1) else 0
     if step_times is not None and rank == 0:
         st_ = np.diff(np.array([t0] + step_times)) * 1e6
+        ru1 = resource.getrusage(resource.RUSAGE_THREAD)
+        # what the driver thread went through inside the timed region: a step of tens of ms with involuntary switches is a
+        # preemption of the pinned core, with page faults a first touch, with neither the device / runtime
+        print(f"[step times us] driver thread: involuntary switches {ru1.ru_nivcsw - ru0.ru_nivcsw}, voluntary {ru1.ru_nvcsw - ru0.ru_nvcsw}, "
+              f"minor faults {ru1.ru_minflt - ru0.ru_minflt}, major {ru1.ru_majflt - ru0.ru_majflt}; slowest step #{int(st_.argmax())} "
+              f"{st_.max():.0f} us", file=sys.stderr)
         if len(st_) <= 40:
             print("[step times us] all", np.round(st_, 0).tolist(), file=sys.stderr)
         print(f"[step times us] median {np.median(st_):.1f} p90 {np.percentile(st_, 90):.1f} p99 {np.percentile(st_, 99):.1f} max {st_.max():.1f} "

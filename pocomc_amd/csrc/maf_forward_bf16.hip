@@ -282,6 +282,11 @@ extern "C" int pmc_maf_forward_bf16(const pmc_maf_t* m, const uint16_t* image, i
     // 151 / 148.  The call is a chain of 4 T barrier-separated layers whose cost hardly depends on the rows (fragment
     // latency, two to five tiles per wave): sixteen waves shorten the chain, two row sets per workgroup halve the
     // fragment traffic per row once every CU has work.  PMC_FWD_BF16_RS / PMC_FWD_BF16_NW force a shape (A/B runs).
+    // Round 4: a wave's first PF fragments of the NEXT layer requested across the barrier (values returned from a helper and
+    // selected by pointer: 89 -> 103 VGPRs, no scratch -- round 3's attempt had them assigned under branches: 115 VGPRs and a
+    // scratch round trip): 157 / 124 us against 150 / 122 -- nothing: a layer does not start with an exposed round trip, its
+    // two tiles per wave stream ~270 KB through a CU that takes in ~41 B/clk (scripts/micro/load_latency.hip): 75 us of the
+    // 150 are that feed, the rest barrier skew between sixteen waves.  Removed again.
     static const int f_rs = getenv("PMC_FWD_BF16_RS") ? atoi(getenv("PMC_FWD_BF16_RS")) : 0;
     static const int f_nw = getenv("PMC_FWD_BF16_NW") ? atoi(getenv("PMC_FWD_BF16_NW")) : 0;
     int rs = f_rs ? f_rs : (n >= 4096 ? 2 : 1);

@@ -176,9 +176,9 @@ def teacher_forced(name, verified_inverse=False):
             u64, l64 = yard.inverse(tr["theta_prime"].astype(np.float32))
             fin = np.isfinite(u64).all(axis=1) & np.isfinite(tr["u_prime"]).all(axis=1)
             worst["u_prime_f64"] = max(worst.get("u_prime_f64", 0), close_rel(
-                eng.p_u.cpu().numpy()[fin], u64[fin], 1e-5, "u_prime vs the float64 evaluation"))
+                eng.p_u.cpu().numpy()[fin], u64[fin], NSF_X, "u_prime vs the float64 evaluation"))
             worst["ldjf_prime_f64"] = max(worst.get("ldjf_prime_f64", 0), close_rel(
-                eng.p_ldjf.cpu().numpy()[fin], l64[fin], 1e-5, "logdetj_flow_prime vs the float64 evaluation",
+                eng.p_ldjf.cpu().numpy()[fin], l64[fin], NSF_LADJ, "logdetj_flow_prime vs the float64 evaluation",
                 cancel=oflow.ladj_abs_terms(tr["u_prime"][fin])))
         # (the scaler's log-determinant is a float64 function of the float32 u': it inherits u's tolerance through
         #  d logdetj / d u_j ~ -t_j sigma_j, i.e. |d logdetj| <= 1e-5 (1 + sum_j u_j'^2) to first order)
