@@ -254,10 +254,12 @@ def main():
                          "lane while the host evaluates the likelihood of another); 1 = the whole set at once; 0 (default) = "
                          "2 for the affine flows (a lane's proposal + sweep launch is shorter than the whole set's), 1 for "
                          "the spline flows (their sweep takes the same time for 5e3 and 1e4 walkers)")
-    ap.add_argument("--first-lane", type=float, default=0.65,
+    ap.add_argument("--first-lane", type=float, default=None,
                     help="fraction of the walkers in the first of two lanes (0.5 = equal).  The sweeps of the two lanes run one "
                          "after the other and cost the same whatever their size; a larger first lane puts more of the host "
-                         "likelihood behind the second sweep: measured 2605 (0.5) / 2767 (0.65) / 2844 (0.7) / 2843 (0.8) steps/s")
+                         "likelihood behind the second sweep: measured 2605 (0.5) / 2767 (0.65) / 2844 (0.7) / 2843 (0.8) steps/s.  "
+                         "Default: 0.65; 0.75 for the flows that take the lane-per-walker sweep (config 3, f16 helpers: 762 (0.5) / "
+                         "811 (0.6) / 864 (0.75) steps/s -- a lane of <= 8192 walkers is one round of that sweep whatever its size)")
     ap.add_argument("--head-rows", type=int, default=0,
                     help="rows of the first lane whose x' crosses PCIe ahead of the others, with a completion word of their own: "
                          "the host's likelihood starts on them while the rest arrives (pmc_step_t.head_rows); 0 (default) = off.  "
@@ -402,6 +404,10 @@ def main():
         # fewer than 8192 rows (scripts/hosttest.py).  A lane of 5008 rows (a thread's chunk of 2500) stays on the
         # direct path with 1024.
         bufsize0 = np.setbufsize(1024)
+    if args.first_lane is None:
+        import ctypes as _ct
+        args.first_lane = 0.75 if (args.inverse in ("auto", "triangular", "lane")
+                                   and flow.lib.pmc_debug_inverse_uses_lane(_ct.byref(flow._desc))) else 0.65
     if args.lanes > 1 or pipelined:
         leng = LanedEngine("preconditioned_pcn", n, D, flow, scaler, lanes=args.lanes, group=None,
                            shard_offset=rank * n, seed=20240928, x_order=args.x_order, streams=not pipelined,

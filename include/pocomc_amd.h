@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PMC_ABI_VERSION 6
+#define PMC_ABI_VERSION 7
 
 const char* pmc_last_error(void);
 int pmc_abi_version(void);
@@ -483,8 +483,8 @@ typedef struct pmc_step {
     int32_t adapt_pad2;
     /* "every row is clean": with h_clean non-NULL pmc_step_pre leaves there, before the completion word h_done[0], the
      * number of rows whose x' is not finite or whose device-evaluated logp' is not finite (mcmc.py:100-109's two masks) --
-     * 0 lets the host skip both mask scans and hand the whole block to the likelihood.  -1: the launch that ran does not
-     * count (only the fused proposal + sweep + scaler launch does); the host then scans h_fin / logp' as before. */
+     * 0 lets the host skip both mask scans and hand the whole block to the likelihood.  -1: the launch sequence that ran
+     * does not count (no device prior, or x' not handed over by the kernels); the host then scans h_fin / logp' as before. */
     int64_t* h_clean;         /* pinned host int64 [1] or NULL */
     uint32_t* clean_count;    /* device uint32 [1], zeroed once by the caller */
     /* "Head first": the x' of a launch crosses PCIe at ~40 GB/s, ~40 us for 6.5e3 x 32 rows, and the host's likelihood
@@ -496,6 +496,13 @@ typedef struct pmc_step {
     int64_t head_rows;
     int64_t* h_head;          /* pinned host int64 [3] or NULL */
     uint32_t* head_ticket;    /* device uint32 [2], zeroed once by the caller */
+    /* 1: in the HOST copy of x' (h_x with host_direct) a row that does not reach the likelihood -- x' or the device-evaluated
+     * logp' not finite, the rows h_clean counts -- carries the walker's current x (cur.x) instead of x'.  The host can then
+     * hand the whole block to a row-wise likelihood and overwrite those rows' values with -inf (mcmc.py:118-121 does that to
+     * the rows it left out) instead of gathering the other rows first (x'[mask], mcmc.py:117: 280 us for 6.5e3 x 50 doubles).
+     * The device copy p_x keeps x'.  Needs h_clean / clean_count and a device prior. */
+    int32_t fill_rejected;
+    int32_t fill_pad;
 } pmc_step_t;
 
 #define PMC_ADAPT_TPCN 1      /* sigma <- |min(sigma + c (mean alpha - 0.234), cap)|      (mcmc.py:152, :476) */

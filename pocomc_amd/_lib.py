@@ -97,7 +97,8 @@ class pmc_step_t(C.Structure):
                 ("adapt_c_sigma", C.c_double), ("adapt_c_mu", C.c_double), ("adapt_cap", C.c_double),
                 ("adapt_n_total", C.c_double), ("adapt_other", C.c_void_p * 7), ("adapt_n_other", C.c_int32),
                 ("adapt_pad2", C.c_int32), ("h_clean", c_p), ("clean_count", c_p),
-                ("head_rows", C.c_int64), ("h_head", c_p), ("head_ticket", c_p)]
+                ("head_rows", C.c_int64), ("h_head", c_p), ("head_ticket", c_p),
+                ("fill_rejected", C.c_int32), ("fill_pad", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/pocomc_amd.h declares
@@ -226,7 +227,7 @@ def load():
         fn = getattr(lib, name)            # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.pmc_abi_version() != 6:
+    if lib.pmc_abi_version() != 7:
         raise PocomcAmdError("libpocomc_amd.so: ABI version mismatch")
     _lib = lib
     return lib

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(SCL_THREADS) void scaler_inverse_kernel(
     double* __restrict__ u_out, double* __restrict__ x_out, double* __restrict__ x_colmajor,
     double* __restrict__ ldj_out, int32_t* __restrict__ finite_out, int64_t n, pmc_prior_t pr,
     double* __restrict__ logp_out, int32_t* __restrict__ finite_copy, double* __restrict__ logp_copy,
-    unsigned* __restrict__ done_ticket, long long* __restrict__ done_flag, long long done_value) {
+    unsigned* __restrict__ done_ticket, long long* __restrict__ done_flag, long long done_value, pmc_scaler_extra ex) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int D = s.D;
     const bool keep_x = x_colmajor || logp_out;   // x' stays in LDS for the column-major copy / the fused prior
@@ -167,13 +167,20 @@ __global__ __launch_bounds__(SCL_THREADS) void scaler_inverse_kernel(
             }
             logp_out[row0 + tid] = lp;
             if (logp_copy) logp_copy[row0 + tid] = lp;
+            if (!isfinite(lp)) rowfin[tid] = 0;
         }
+        // rowfin: from here on "the row reaches the likelihood" (mcmc.py:100-109's two masks)
+        if (!fin) rowfin[tid] = 0;
+        if (ex.bad_count && !rowfin[tid]) atomicAdd(ex.bad_count, 1u);
     }
     if (x_colmajor) {
-        // host copy of x' in column-major order ((n, D) Fortran array on the host): coalesced along rows
+        if (ex.fill_x) __syncthreads();
+        // host copy of x' in column-major order ((n, D) Fortran array on the host): coalesced along rows.  A row that does
+        // not reach the likelihood carries the walker's CURRENT x there when asked (pmc_step_t.fill_rejected): the host can
+        // hand the whole block to the likelihood and drop those rows' values instead of gathering the others
         for (int e = tid; e < rows * D; e += SCL_THREADS) {
             const int j = e / rows, r = e - j * rows;
-            x_colmajor[(size_t)j * n + row0 + r] = Xt[j * (SCL_ROWS + 1) + r];
+            x_colmajor[(size_t)j * n + row0 + r] = (ex.fill_x && !rowfin[r]) ? ex.fill_x[(row0 + r) * D + j] : Xt[j * (SCL_ROWS + 1) + r];
         }
     }
     if (done_flag) {
@@ -186,6 +193,10 @@ __global__ __launch_bounds__(SCL_THREADS) void scaler_inverse_kernel(
             const unsigned t = __hip_atomic_fetch_add(done_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             if (t == gridDim.x - 1) {
                 *done_ticket = 0u;
+                if (ex.bad_count && ex.bad_flag) {        // (every block's count is in: its ticket came behind its atomicAdd)
+                    const unsigned bad = __hip_atomic_exchange(ex.bad_count, 0u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    *ex.bad_flag = (long long)bad;
+                }
                 __threadfence_system();
                 __hip_atomic_store(done_flag, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -713,6 +724,14 @@ extern "C" int pmc_scaler_inverse_prior(const pmc_scaler_t* s, const pmc_prior_t
                                         const double* u_in64, double* u_out, double* x, double* x_colmajor,
                                         double* logdetj, int32_t* finite, double* logp, int32_t* finite_copy,
                                         double* logp_copy, const pmc_done_t* done, int64_t n, void* stream) {
+    return pmc_scaler_inverse_prior_ex(s, prior, u_in, u_in64, u_out, x, x_colmajor, logdetj, finite, logp, finite_copy, logp_copy,
+                                       done, n, stream, nullptr);
+}
+
+int pmc_scaler_inverse_prior_ex(const pmc_scaler_t* s, const pmc_prior_t* prior, const float* u_in,
+                                const double* u_in64, double* u_out, double* x, double* x_colmajor,
+                                double* logdetj, int32_t* finite, double* logp, int32_t* finite_copy,
+                                double* logp_copy, const pmc_done_t* done, int64_t n, void* stream, const pmc_scaler_extra* extra) {
     if (int e = check_scaler(s)) return e;
     if (n == 0) return 0;
     if ((!u_in) == (!u_in64)) return pmc_fail("pmc_scaler_inverse: exactly one of u_in / u_in64 must be given");
@@ -723,6 +742,8 @@ extern "C" int pmc_scaler_inverse_prior(const pmc_scaler_t* s, const pmc_prior_t
         return pmc_fail("pmc_scaler_inverse_prior: bad prior descriptor");
     pmc_prior_t pr_val = {};
     if (prior) pr_val = *prior;
+    pmc_scaler_extra ex{};
+    if (extra && done && x_colmajor) ex = *extra;       // (the count travels with the completion word, the fill with the host copy)
     const size_t lds = (size_t)SCL_ROWS * s->D * sizeof(double) + SCL_ROWS * sizeof(int) +
                        ((x_colmajor || logp) ? (size_t)s->D * (SCL_ROWS + 1) * sizeof(double) : 0);
     if (lds > 160 * 1024 || s->D > 1024) return pmc_fail("pmc_scaler_inverse: n_dim too large");
@@ -734,7 +755,7 @@ extern "C" int pmc_scaler_inverse_prior(const pmc_scaler_t* s, const pmc_prior_t
     hipLaunchKernelGGL(scaler_inverse_kernel, dim3((unsigned)((n + SCL_ROWS - 1) / SCL_ROWS)), dim3(SCL_THREADS), lds,
                        (hipStream_t)stream, *s, u_in, u_in64, u_out, x, x_colmajor, logdetj, finite, n, pr_val, logp, finite_copy,
                        logp_copy, done ? done->ticket : nullptr, done ? (long long*)done->flag : nullptr,
-                       done ? (long long)done->value : 0LL);
+                       done ? (long long)done->value : 0LL, ex);
     return pmc_check_launch("scaler_inverse_kernel");
 }
 

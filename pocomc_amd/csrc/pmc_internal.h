@@ -28,6 +28,14 @@ int pmc_launch_propose_mfma(int kind, const float* cur32, const double* cur64, c
 int pmc_launch_clip_adamw(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
                           double beta1, double beta2, double eps, double wd, double max_norm, int64_t step,
                           float* sq_scratch, hipStream_t st);
+// pmc_scaler_inverse_prior with the step's extras: the number of rows that do not reach the likelihood (non-finite x' or
+// logp') into *bad_flag in front of the completion word (bad_count: device word, zero between launches), and the walkers'
+// current x (device f64 [n][D]) for those rows in the HOST copy of x' (pmc_step_t.fill_rejected)
+struct pmc_scaler_extra { unsigned* bad_count; long long* bad_flag; const double* fill_x; };
+int pmc_scaler_inverse_prior_ex(const pmc_scaler_t* s, const pmc_prior_t* prior, const float* u_in, const double* u_in64,
+                                double* u_out, double* x, double* x_colmajor, double* logdetj, int32_t* finite, double* logp,
+                                int32_t* finite_copy, double* logp_copy, const pmc_done_t* done, int64_t n, void* stream,
+                                const pmc_scaler_extra* extra);
 // pmc_propose with sigma / cn_a / mu taken from pmc_step_t.adapt_state (device) when adapt != NULL
 int pmc_propose_adapt(int kind, const float* cur32, const double* cur64, const double* mu, const double* inv_cov,
                       const double* chol, double nu, double sigma, double cn_a, const pmc_rng_t* rng, double* prop64,

@@ -144,6 +144,7 @@ struct ScalerEpi {
     // "head first" (pmc_step_t.head_rows): the first head_blocks workgroups send their x' over the link before the others
     // and raise head_flag[0] <- done_value (head_flag[1] <- rows counted not clean so far) when it has arrived
     unsigned head_blocks; unsigned* head_ticket; long long* head_flag;
+    const double* fill_x;                           // pmc_step_t.fill_rejected: the walkers' current x (device [n][D]) or NULL
     long long* stamps;                              // measurement only (pmc_debug_set_epilogue_stamps): [block][8] of the 100 MHz clock
 };
 
@@ -182,7 +183,7 @@ __device__ __forceinline__ void scaler_epilogue_element(const ScalerEpi& e, doub
 // column-major store of x (unless the elements stored it already: cm_done) and the completion word.  Every thread of
 // the workgroup calls it behind a barrier that follows the last element.
 __device__ __forceinline__ void scaler_epilogue_rows(const ScalerEpi& e, const double* Jt, const double* Pt, const double* Xt,
-                                                     const int* rowfin, int64_t row0, int64_t n, int D, int tid, int nthr,
+                                                     int* rowfin, int64_t row0, int64_t n, int D, int tid, int nthr,
                                                      bool cm_done) {
     const pmc_scaler_t& s = e.s;
     const int rows = (int)min((int64_t)16, n - row0);
@@ -206,7 +207,9 @@ __device__ __forceinline__ void scaler_epilogue_rows(const ScalerEpi& e, const d
             clean = clean && isfinite(lp);
         }
         if (e.bad_count && !clean) atomicAdd(e.bad_count, 1u);            // (rows that the host's masks would drop: rare)
+        if (e.fill_x) rowfin[tid] = clean ? 1 : 0;                              // (from here on: "the row reaches the likelihood")
     }
+    if (e.fill_x) __syncthreads();
     if (e.stamps && tid == 0) e.stamps[blockIdx.x * 8 + 2] = wall_clock64();
     const bool split = e.head_blocks > 0 && e.done_flag && e.head_ticket && e.head_flag;
     const bool in_head = split && blockIdx.x < e.head_blocks;
@@ -225,7 +228,8 @@ __device__ __forceinline__ void scaler_epilogue_rows(const ScalerEpi& e, const d
     if (e.x_colmajor && !cm_done) {
         for (int el = tid; el < rows * D; el += nthr) {
             const int j = el / rows, r = el - j * rows;
-            e.x_colmajor[(size_t)j * n + row0 + r] = Xt[j * 17 + r];
+            // (a row that does not reach the likelihood: the walker's current x in the host copy, see scaler_inverse_kernel)
+            e.x_colmajor[(size_t)j * n + row0 + r] = (e.fill_x && !rowfin[r]) ? e.fill_x[(row0 + r) * D + j] : Xt[j * 17 + r];
         }
     }
     if (e.stamps && tid == 0) e.stamps[blockIdx.x * 8 + 4] = wall_clock64();

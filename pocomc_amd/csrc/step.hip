@@ -94,6 +94,7 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
             epi.bad_count = (done && s->h_clean) ? s->clean_count : nullptr;
             epi.bad_flag = (done && s->h_clean && s->clean_count) ? (long long*)s->h_clean : nullptr;
             epi.stamps = (n == g_epilogue_stamps_n) ? g_epilogue_stamps : nullptr;
+            epi.fill_x = (s->fill_rejected && epi.bad_flag && xT) ? s->cur.x : nullptr;
             if (done && xT && s->head_rows > 0 && s->head_rows < n && (s->head_rows & 15) == 0 && s->h_head && s->head_ticket) {
                 epi.head_blocks = (unsigned)(s->head_rows >> 4);        // (16 walkers per workgroup in both fused sweeps)
                 epi.head_ticket = s->head_ticket;
@@ -116,7 +117,12 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
                                tpcn ? s->p_quad : nullptr, n, D, stream, adapt);
         if (rc) return rc;
     }
-    if (s->h_clean && !(scaled && done && s->clean_count)) *s->h_clean = -1;     // (this launch sequence does not count)
+    // the scaler launch of its own counts the rows that do not reach the likelihood like the fused epilogue does (and fills
+    // their host rows when asked) whenever it hands x' to the host itself and evaluates the prior
+    pmc_scaler_extra sx{};
+    const bool counted = done && s->h_clean && s->clean_count && xT && (scaled || pr);
+    if (!scaled && counted) { sx.bad_count = s->clean_count; sx.bad_flag = (long long*)s->h_clean; sx.fill_x = s->fill_rejected ? s->cur.x : nullptr; }
+    if (s->h_clean && !counted) *s->h_clean = -1;     // (this launch sequence does not count)
     if (s->h_head)                                   // does the sequence raise the head's word?  (the host reads this before it waits)
         s->h_head[2] = (scaled && done && xT && s->head_rows > 0 && s->head_rows < n && (s->head_rows & 15) == 0 && s->head_ticket) ? 1 : 0;
     if (scaled) {
@@ -128,11 +134,11 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
             if (s->ev_inv1) (void)hipEventRecord((hipEvent_t)s->ev_inv1, st);
             if (rc) return rc;
         }
-        rc = pmc_scaler_inverse_prior(s->scaler, pr, s->p_u32, nullptr, s->p_u, s->p_x, xT, s->p_logdetj, s->p_fin, lp,
-                                      fin2, lp2, done, n, stream);
+        rc = pmc_scaler_inverse_prior_ex(s->scaler, pr, s->p_u32, nullptr, s->p_u, s->p_x, xT, s->p_logdetj, s->p_fin, lp,
+                                         fin2, lp2, done, n, stream, &sx);
     } else {
-        rc = pmc_scaler_inverse_prior(s->scaler, pr, nullptr, s->p_theta64, s->p_u, s->p_x, xT, s->p_logdetj, s->p_fin,
-                                      lp, fin2, lp2, done, n, stream);
+        rc = pmc_scaler_inverse_prior_ex(s->scaler, pr, nullptr, s->p_theta64, s->p_u, s->p_x, xT, s->p_logdetj, s->p_fin,
+                                         lp, fin2, lp2, done, n, stream, &sx);
     }
     if (rc) return rc;
     if (direct) return finish();

@@ -359,6 +359,11 @@ class StepEngine:
         self._np_head = self.h_head.numpy()
         self._head_ticket = torch.zeros(2, dtype=torch.int32, device=dev)
         self._head_views = None
+        # rows that do not reach the likelihood (x' or logp' not finite): their HOST rows of x' carry the walker's current x
+        # (pmc_step_t.fill_rejected), so that up to fill_rejected_max * n such rows cost a few wasted evaluations instead of
+        # the gather x'[mask] of mcmc.py:117 (280 us for 6.5e3 x 50 doubles); their logl' is -inf either way (:118-121)
+        self.fill_rejected = True
+        self.fill_rejected_max = 0.05
         self._direct_now = False
         self._pre_cfg = None     # switches the composite pre-step's struct fields were last written for
         # adaptation on the device (pmc_step_t.adapt_state): {sigma, cn_a, mu[D]}; see run_pipelined
@@ -543,7 +548,8 @@ class StepEngine:
     def _configure_step(self):
         """The fields of the composite entry points' struct that depend on the engine's switches only: written when
         one of them changed."""
-        cfg = (self.flow.inverse_algo if self.pre else 0, self.rng_prefill, self.host_direct, self.spin_wait, int(self.head_rows))
+        cfg = (self.flow.inverse_algo if self.pre else 0, self.rng_prefill, self.host_direct, self.spin_wait, int(self.head_rows),
+               bool(self.fill_rejected))
         if cfg != self._pre_cfg:
             self._pre_cfg = cfg
             if self.pre:
@@ -558,6 +564,7 @@ class StepEngine:
             self._step.h_clean = self.h_clean.data_ptr() if self._direct_now else None
             self._step.clean_count = self._clean_count.data_ptr() if self._direct_now else None
             self._step.ev_pre_done = None if self._direct_now else self._ev_pre     # (the completion word replaces it)
+            self._step.fill_rejected = int(bool(self.fill_rejected) and self._direct_now)
             h = int(self.head_rows)
             if h % 16 or not 0 <= h < self.n:
                 raise ValueError("head_rows: a multiple of 16 below the number of rows")
@@ -623,6 +630,17 @@ class StepEngine:
                 # mcmc.py:100-109 are all-true, x'[mask] is x' itself
                 self._np_logl[:] = log_like(self._np_x)[0]
                 return self.n, None
+            bad = int(self._np_clean[0])
+            if ((waited or self._post_uploads) and self._direct_now and self._step.fill_rejected
+                    and 0 < bad <= self.fill_rejected_max * self.n and self.host_threads <= 1 and not have_blobs):
+                # a few rows do not reach the likelihood; their host rows hold the walkers' current x (fill_rejected): the
+                # whole block goes to the likelihood, those rows' values are dropped -- the calls counted are the rows of
+                # mcmc.py:117's x'[mask]
+                good = self._np_fin.astype(bool) & np.isfinite(self._np_logp)
+                ll = log_like(self._np_x)[0]
+                np.copyto(self._np_logl, ll)
+                self._np_logl[~good] = -np.inf
+                return int(good.sum()), None
         n = self.n
         x_prime = self._np_x
         logp_prime = self._np_logp
@@ -1118,7 +1136,7 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
     laned = isinstance(eng, LanedEngine)
     if option_dict.get("wait_timeout") is not None:
         tune(wait_timeout=_wait_timeout(option_dict["wait_timeout"]))
-    for key in ("host_direct", "rng_prefill", "spin_wait"):
+    for key in ("host_direct", "rng_prefill", "spin_wait", "fill_rejected"):
         if key in option_dict:
             tune(**{key: bool(option_dict[key])})
     if option_dict.get("host_threads", 1) > 1:

@@ -787,6 +787,65 @@ def test_the_pipeline_behind_the_c_abi_equals_the_python_pipeline_bit_for_bit(ki
     assert a["proposal_scale"] == b["proposal_scale"] and a["accept"] == b["accept"] and a["efficiency"] == b["efficiency"]
 
 
+@pytest.mark.parametrize("kind,flow_name,D", [("preconditioned_pcn", "maf3", 6), ("preconditioned_pcn", "maf6", 50),
+                                              ("preconditioned_rwm", "nsf3", 6), ("pcn", None, 6), ("rwm", None, 6)])
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_rows_that_do_not_reach_the_likelihood_are_filled_not_gathered(kind, flow_name, D, lanes):
+    """``pmc_step_t.fill_rejected``: a proposal outside the prior's support (or not finite) is rejected whatever its
+    likelihood (``mcmc.py:118-121``: logl' = -inf for the rows left out of ``x'[mask]``, ``:117``).  With a few such rows the
+    device puts the walker's CURRENT x into their host rows of x' and the host hands the whole block to the likelihood
+    instead of gathering the others: same walkers, sums and call counts as with the gather, bit for bit; the likelihood
+    never sees a point outside the support; it is called on whole blocks.  Fused launch (maf3), lane sweep + scaler launch
+    (maf6, D = 50), spline sweep, and the kernels without a flow."""
+    from scipy.stats import uniform
+    import pocomc_amd as pc
+    from pocomc_amd import mcmc as pmcmc
+    from pocomc_amd.geometry import Geometry
+    import torch
+    N = 2048
+    prior = pc.Prior([uniform(-3, 6)] * D)                  # narrower than the scaler's box: x' can leave the support
+    rng = np.random.default_rng(D + lanes)
+    scaler = pc.Reparameterize(D, bounds=np.array([[-10.0, 10.0]] * D))
+    x = rng.uniform(-2.0, 2.0, size=(N, D))
+    x *= 0.5                                                    # the bulk well inside ...
+    x[: N // 64] = rng.uniform(2.9, 2.99, size=(N // 64, D))    # ... and a few walkers right at the edge: < 5 % of the rows fall out
+    scaler.fit(x)
+    u = scaler.forward(x)
+    shapes = []
+
+    def like(xx):
+        assert np.isfinite(xx).all() and (np.abs(xx) <= 3.0).all()      # (mcmc.py:117 never passes anything else)
+        shapes.append(xx.shape[0])
+        acc = np.zeros(xx.shape[0])
+        for j in range(xx.shape[1]):                         # (column after column: the same bits whatever the layout of xx --
+            acc += xx[:, j] ** 2                             #  a gathered x'[mask] is a C-ordered copy, the block is F-ordered)
+        return -0.5 * acc, None
+    flow = pc.Flow(D, flow_name or "maf3", seed=0)
+    flow.set_params(0.25 * flow.params.cpu())               # (a tame map: the walkers' moves stay small at D = 50 too)
+    geo = Geometry()
+    geo.fit(flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64))
+    geo.normal_cov = np.cov(u.T)
+    res, seen = [], []
+    for fill in (True, False):
+        del shapes[:]
+        state = dict(u=u.copy(), x=x.copy(), logdetj=scaler.inverse(u)[1], logl=like(x)[0], logp=prior.logpdf(x),
+                     beta=0.5, blobs=None)
+        funcs = dict(loglike=like, logprior=prior.logpdf, scaler=scaler, flow=flow, theta_geometry=geo, u_geometry=geo)
+        opts = dict(n_max=8, n_steps=10 ** 6, progress_bar=None, proposal_scale=0.25 / D ** 0.5, seed=5, lanes=lanes, x_order="F",
+                    fill_rejected=fill)
+        res.append(getattr(pmcmc, kind)(state, funcs, opts))
+        seen.append(list(shapes[1:]))
+    a, b = res
+    assert a["steps"] == b["steps"] == 8 and a["calls"] == b["calls"] < 8 * N      # some rows never reached the likelihood
+    for k in ("u", "x", "logl", "logp", "logdetj"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert a["proposal_scale"] == b["proposal_scale"] and a["accept"] == b["accept"]
+    blocks = {N} if lanes == 1 else {N // 2}
+    whole = [c for c in seen[0] if c in blocks]
+    assert len(whole) >= len(seen[0]) // 2 and sum(seen[0]) > a["calls"], seen[0]   # filled: whole blocks (but for steps with > 5 % out)
+    assert sum(seen[1]) == b["calls"] < 8 * N                                      # gathered: exactly the rows of x'[mask]
+
+
 @pytest.mark.parametrize("holes", [False, True])
 @pytest.mark.parametrize("N,lanes,head", [(1000, 1, 256), (2000, 2, 512), (4100, 3, 16)])
 def test_head_first_rows_give_the_same_call(N, lanes, head, holes, monkeypatch):
