@@ -344,7 +344,14 @@ def main():
     _train_state(flow)                                      # one-time host-side index maps / buffers of the Flow
     torch.cuda.synchronize()
     tf0 = time.perf_counter()
-    hist = flow.fit(u_fit, epochs=50, batch_size=512, validation_split=0.5, patience=D, annealing=False, verbose=0)
+    # D <= 64: 50 epochs (a setup-time shortcut of the Sampler's fit, sampler.py:655-669: epochs = 5000, patience = D, the best
+    # validation state restored at the early stop, flow.py:364-374).  At config 5 (D = 128, 2500 training rows, 1.6e6
+    # parameters) the shortcut is not harmless: the validation loss is best at epoch ~5 and 1e15 at epoch 50 -- cut there
+    # WITHOUT the restore, the flow's inverse overflows float32 on 58 % of the walkers' own theta = forward(u), nothing is
+    # ever accepted and the likelihood is never called (scripts/config5_flow_health.py; every config-5 line up to
+    # profiles/r04_a_* was measured in that state).  The wide flows therefore run the Sampler's rule to its early stop.
+    fit_epochs = 50 if D <= 64 else 1000
+    hist = flow.fit(u_fit, epochs=fit_epochs, batch_size=512, validation_split=0.5, patience=D, annealing=False, verbose=0)
     torch.cuda.synchronize()
     fit_s = time.perf_counter() - tf0
     flow_trained = True
@@ -891,7 +898,8 @@ def main():
            "config": {"workload": f"{D}-D {TARGET_NAMES[args.target]}, U({p_lo:g},{p_hi:g})^{D} prior, {n} walkers/GPU x {world} GPU, {args.flow} "
                                   f"(H={spec.hidden}), beta={beta}, tpCN kernel, host numpy likelihood in the loop",
                       "walkers_per_gpu": n, "global_walkers": n * world, "n_dim": D, "flow": args.flow,
-                      "flow_trained_50_epochs": flow_trained, "parallelism": f"walker-sharded x{world}",
+                      "flow_trained_50_epochs": flow_trained, "flow_fit_epochs": (flow_fit or {}).get("epochs"),
+                      "flow_fit_rule": ("50 epochs" if D <= 64 else "the Sampler's: patience = D, best validation state restored at the early stop"), "parallelism": f"walker-sharded x{world}",
                       "lanes": len(leng.lanes) if leng is not None else 1,
                       "lane_rows": [int(e_.n) for e_ in leng.lanes] if leng is not None else [n],
                       "head_rows": head_rows_used,
