@@ -314,7 +314,7 @@ def test_spline_sweeps_on_random_flow_shapes():
     hidden tiles, streamed above) agree to float32 rounding and follow the D-pass inverse on the device."""
     from pocomc_amd import Flow
     rng = np.random.default_rng(11)
-    done = 0
+    done, worst64 = 0, 0.0
     for case in range(24):
         D = int(rng.integers(2, 65))
         T = int(rng.integers(1, 5))
@@ -335,7 +335,16 @@ def test_spline_sweeps_on_random_flow_shapes():
         assert (np.abs(out[7][0] - out[6][0]) / sc).max() < 2e-4, (D, T, H, n)
         assert (np.abs(out[7][0] - out[2][0]) / sc).max() < 5e-4, (D, T, H, n)
         assert np.abs(out[7][1] - out[6][1]).max() < 1e-3 * max(1.0, float(np.abs(out[6][1]).max())), (D, T, H, n)
+        # ... and, on up to 32 rows, the float64 evaluation of the same parameters by the oracle (zuko's D-pass algorithm in
+        # numpy): not a device-against-device statement
+        k = min(n, 32)
+        x64, l64 = OracleMAF(spec, cases.flow_params(spec, case), dtype=np.float64).inverse(z[:k].numpy())
+        ok = np.isfinite(x64).all(axis=1)
+        e64 = float((np.abs(out[7][0][:k][ok] - x64[ok]) / np.maximum(1.0, np.abs(x64[ok]).max(axis=1, keepdims=True))).max()) if ok.any() else 0.0
+        worst64 = max(worst64, e64)
+        assert e64 < 5e-5, (D, T, H, n, e64)                 # (the spline's stated bound; measured 8.3e-6)
         done += 1
+    print(f"spline sweeps on random shapes: two-wave sweep against the float64 oracle, worst row {worst64:.2e}")
     assert done >= 15
 
 
@@ -344,7 +353,7 @@ def test_sweeps_on_random_flow_shapes():
     float32 rounding and follow the D-pass inverse on the device (``scripts/fuzz_inverse.py`` is the long version)."""
     from pocomc_amd import Flow
     rng = np.random.default_rng(7)
-    done = 0
+    done, worst64 = 0, 0.0
     for case in range(40):
         D = int(rng.integers(2, 65))
         T = int(rng.integers(1, 8))
@@ -368,5 +377,14 @@ def test_sweeps_on_random_flow_shapes():
             # (two float32 algorithms with different summation orders; up to seven transforms amplify the rounding of a
             #  stretched row: measured <= 6e-5 over these shapes)
             assert (np.abs(out[7][0][fin] - out[2][0][fin]) / sc).max() < 5e-4, (D, T, H, n)
+        # ... and, on up to 32 rows, the float64 evaluation of the same parameters by the oracle: not device against device
+        k = min(n, 32)
+        x64, l64 = OracleMAF(spec, cases.flow_params(spec, case), dtype=np.float64).inverse(z[:k].numpy())
+        ok = np.isfinite(x64).all(axis=1) & fin[:k] & (np.abs(x64).max(axis=1) < 1e30)
+        if ok.any():
+            e64 = float((np.abs(out[7][0][:k][ok] - x64[ok]) / np.maximum(1.0, np.abs(x64[ok]).max(axis=1, keepdims=True))).max())
+            worst64 = max(worst64, e64)
+            assert e64 < 1e-5, (D, T, H, n, e64)             # (the north star's 1e-5; measured 1.2e-6)
         done += 1
+    print(f"sweeps on random shapes: two-wave sweep against the float64 oracle, worst row {worst64:.2e}")
     assert done >= 25
