@@ -814,10 +814,7 @@ _Pragma("unroll") \
                 dg.z = __builtin_amdgcn_readlane(dgl.z, T); dg.w = __builtin_amdgcn_readlane(dgl.w, T);
                 long long* pf = (pa.prof && blockIdx.x == 0 && wv < 4) ? pa.prof + ((size_t)((Tn - 1 - t) * nT + T) * 4 + wv) * 4 : nullptr;
                 if (pf && lane == 0) { pf[0] = clock64(); if (T == 0) pf[2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4); }
-                int gfirst = dg.x, glast = dg.x;
-                if (dg.y < D) glast = dg.y;
-                if (dg.z < D) glast = dg.z;
-                if (dg.w < D) glast = dg.w;
+                const int gfirst = dg.x;
                 if (wv == 1 || wv == 2) {
                     f32x4 acc[NS], acd[NS];
                     // (the bias joins the sum when it is staged: as the accumulator's first value its load would have to land
