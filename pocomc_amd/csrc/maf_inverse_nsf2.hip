@@ -24,9 +24,6 @@
 #define NSF2_ABL 0                 // timing experiments only (scripts/abl_nsf.sh): results are wrong when != 0
 #endif                             // 1 no spline solve, 2 no output MFMAs on the chain, 4 burst: no output partials, 8 nor their loads, 16 chain: no output fragment requests, 32 burst: no hidden products
 #define NSF2_PK 10                 // K tiles of the hidden bursts held in registers; the static burst tile covers flows of <= NSF2_PK + 1 live tiles
-#ifndef NSF2_SPREAD
-#define NSF2_SPREAD 1              // the chain's requests spread over the shadows of its MFMAs (1) or issued as a block at the group's start (0)
-#endif
 #define NSF2_PX 4                  // x tiles of the layer-0 product held in registers (D <= 64)
 #define NSF2_OOB 0x40000000        // a lane offset beyond every image: the bounds-checked load returns zeros
 #define NSF2_STAGE_FLOATS (3 * 256)                 // hidden staging S0 | S1 | S2 (transposed, [lane][4])
@@ -55,11 +52,47 @@ struct NsfChain {
     float a0N[4];
     float h0s[4], h1s[4], h2s[4];  // this tile's activations, row q of every quad
     float h2p[4];                  // the previous tile's h2 (B operands of the fp products)
+    f32x4 o0, o1;                  // the current group's 23 parameters so far: staged partial + previous tile + the tile's earlier quads,
+                                   // formed in the shadow of the PREVIOUS group's spline solve (round 4)
+    RqsPend pend;                  // the previous group's solve, log-derivative not evaluated yet
+    float pend_x;                  // its x: store and off-path rank-1 updates pending
 };
 
 // Groups I .. of a tile with quad pattern PAT, one after the other, straight-line.
-//   ob[I & 1]: this group's output fragments; `ahead(I)` requests the next group's into ob[(I + 1) & 1] (and whatever
-//   else the caller wants in flight).
+//
+// Round 4: ONLY WHAT WAITS FOR x STANDS BETWEEN TWO RANKS' x.  A rank's parameters are
+//   staged partial (burst wave) + previous tile's h2 (8 MFMAs) + the own tile's earlier quads (2 per quad) + the group's own
+//   quads (2 per quad, behind its hops),
+// and only the last term depends on the x the previous group has just solved.  The first three used to stand at the head
+// of the group -- ~10 MFMAs = 320 cycles of matrix pipe between x and the first hop that needs it -- while the spline solve
+// before it (~170 vector instructions, two LDS round trips, no MFMA) left the pipe idle; and the solve's log-derivative,
+// the x store and the rank-1 updates of the NEXT tile stood between x and the next hop although nothing there waits for them.
+//   * The following group's MFMAs are issued in the numbered slots of this group's solve (rqs_inverse_split_sh: one MFMA
+//     per slot, each behind >= 32 cycles of vector work or inside an LDS wait) into n0 / n1 -> s.o0 / s.o1:
+//       - groups 1 .. NG-1: exactly the products and the order of additions they had (bit-identical);
+//       - group 0 of the NEXT tile, in the last solve of this one: its previous tile is this tile, whose h2 is final by
+//         then; the staged partial of the next tile only exists behind the barrier, so the accumulators start from zero
+//         and the caller adds the partial at the head of the tile (a different order of additions for these ranks).
+//   * What a solve leaves behind (s.pend: log-derivative, x store, the next tile's and the later quads' rank-1 updates)
+//     runs in the next group's hops, between the MFMA the chain waits for and the right-looking one behind it -- 32 cycles
+//     in which the wavefront could issue nothing anyway -- and at the end of the tile for its last group (nsf_settle).
+// Fragments: group I reads ob[I & 1]; the requests keep their distance of one whole group: `ahead(G, slot)` with
+// G = I + 1 asks for what follows group I + 1 -- a later group of this tile or the next tile's first -- into
+// ob[(I + 2) & 1] = ob[I & 1], whose own-quad fragments the MFMAs just above were the last to read; G = NG (the next tile's
+// first group is being prepared) asks for the group after THAT into ob[1].  A tile of an odd number of groups leaves the
+// next tile's first group in ob[1]: its own-tile fragments (the previous-tile ones are used up here) move to ob[0].
+template <int PAT, int J>
+__device__ __forceinline__ void nsf_settle_a(NsfChain& s, const NsfHid& f, float* X, int q, int p, int keep_from) {
+    // group J's x store and rank-1 updates off the dependent path: the next tile's quads, this tile's quads from `keep_from`
+    constexpr int c1 = pat_end(PAT, J);
+    const float xg = s.pend_x;
+    if (q == 0) *reinterpret_cast<float*>(reinterpret_cast<char*>(X) + (p << 4) + f.xy[J]) = xg;
+#pragma unroll
+    for (int jt = c1 + 1; jt < 4; ++jt) if (jt >= keep_from) s.a0[jt] = fmaf(comp(f.w0o[J], jt), xg, s.a0[jt]);
+    s.a0N[0] = fmaf(f.w0N[J].x, xg, s.a0N[0]); s.a0N[1] = fmaf(f.w0N[J].y, xg, s.a0N[1]);
+    s.a0N[2] = fmaf(f.w0N[J].z, xg, s.a0N[2]); s.a0N[3] = fmaf(f.w0N[J].w, xg, s.a0N[3]);
+}
+
 template <int PAT, int I, class AH>
 __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (&ob)[2], const float* part, float* X, const float* Y,
                                           float* PAR, int D, int q, int p, int lane, float& ladj, const AH& ahead,
@@ -71,31 +104,9 @@ __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (
         {
             const NsfOut& o = ob[I & 1];
             std::integral_constant<int, I> gi;
+            std::integral_constant<int, I + 1> gn;
             std::integral_constant<int, NG> ngc;
             NSF_STAMP(7)
-            if constexpr (!NSF2_SPREAD) {
-                static_for<6>([&](auto sl_) { ahead(gi, sl_, ngc); });
-                CHAIN_FENCE();
-            }
-            NSF_STAMP(0)
-            // ---- the rank's parameters, part that does not wait for this group's hops: staged partial (bias + h2 tiles
-            // <= Tt-2, burst wave) + previous tile + the own tile's earlier quads
-            f32x4 o0 = as_acc(*reinterpret_cast<const float4*>(part + (2 * I) * 256 + (lane << 2)));
-            f32x4 o1 = as_acc(*reinterpret_cast<const float4*>(part + (2 * I + 1) * 256 + (lane << 2)));
-            if (!(NSF2_ABL & 2)) {
-                o0 = MFMA(o.fp0.x, s.h2p[0], o0); o1 = MFMA(o.fp1.x, s.h2p[0], o1);
-                CHAIN_FENCE(); if constexpr (NSF2_SPREAD) ahead(gi, std::integral_constant<int, 0>{}, ngc); CHAIN_FENCE();
-                o0 = MFMA(o.fp0.y, s.h2p[1], o0); o1 = MFMA(o.fp1.y, s.h2p[1], o1);
-                CHAIN_FENCE(); if constexpr (NSF2_SPREAD) ahead(gi, std::integral_constant<int, 1>{}, ngc); CHAIN_FENCE();
-                o0 = MFMA(o.fp0.z, s.h2p[2], o0); o1 = MFMA(o.fp1.z, s.h2p[2], o1);
-                CHAIN_FENCE(); if constexpr (NSF2_SPREAD) ahead(gi, std::integral_constant<int, 2>{}, ngc); CHAIN_FENCE();
-                o0 = MFMA(o.fp0.w, s.h2p[3], o0); o1 = MFMA(o.fp1.w, s.h2p[3], o1);
-                CHAIN_FENCE(); if constexpr (NSF2_SPREAD) ahead(gi, std::integral_constant<int, 3>{}, ngc); CHAIN_FENCE();
-#pragma unroll
-                for (int c = 0; c < c0; ++c) { o0 = MFMA(comp(o.fc0, c), s.h2s[c], o0); o1 = MFMA(comp(o.fc1, c), s.h2s[c], o1); }
-            }
-            CHAIN_FENCE();
-            NSF_STAMP(1)
             float h0[4], h1[4], h2[4];
             // ---------------------------------------------------------------- hop 1
 #pragma unroll
@@ -104,10 +115,12 @@ __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (
 #pragma unroll
             for (int c = c0; c <= c1; ++c) s.acc1 = MFMA(comp(f.wt1, c), h0[c], s.acc1);
             CHAIN_FENCE();
+            if constexpr (I > 0) nsf_settle_a<PAT, I - 1>(s, f, X, q, p, c1 + 1);      // (the previous group's side effects)
+            CHAIN_FENCE();
 #pragma unroll
             for (int c = c0; c <= c1; ++c) s.accN1 = MFMA(comp(f.wn1, c), h0[c], s.accN1);
             CHAIN_FENCE();
-            if constexpr (NSF2_SPREAD) ahead(gi, std::integral_constant<int, 4>{}, ngc);
+            ahead(gi, std::integral_constant<int, 4>{}, ngc);
             CHAIN_FENCE();
 #pragma unroll
             for (int c = c0; c <= c1; ++c) { h1[c] = fmaxf((s.acc1[c] + s.p1[c]) + h0[c], 0.0f); s.h1s[c] = h1[c]; }
@@ -116,10 +129,20 @@ __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (
 #pragma unroll
             for (int c = c0; c <= c1; ++c) s.acc2 = MFMA(comp(f.wt2, c), h1[c], s.acc2);
             CHAIN_FENCE();
+            if constexpr (I > 0) rqs_ladj_1(s.pend);
+            // (this group's y, and the staged partial the following group's parameters start from)
+            const float yv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Y) + (p << 4) + f.yo[I]);
+            constexpr bool LAST = I + 1 >= NG;
+            f32x4 n0 = f32x4{0.f, 0.f, 0.f, 0.f}, n1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (!LAST) {
+                n0 = as_acc(*reinterpret_cast<const float4*>(part + (2 * (I + 1)) * 256 + (lane << 2)));
+                n1 = as_acc(*reinterpret_cast<const float4*>(part + (2 * (I + 1) + 1) * 256 + (lane << 2)));
+            }
+            CHAIN_FENCE();
 #pragma unroll
             for (int c = c0; c <= c1; ++c) s.accN2 = MFMA(comp(f.wn2, c), h1[c], s.accN2);
             CHAIN_FENCE();
-            if constexpr (NSF2_SPREAD) ahead(gi, std::integral_constant<int, 5>{}, ngc);
+            ahead(gi, std::integral_constant<int, 5>{}, ngc);
             CHAIN_FENCE();
 #pragma unroll
             for (int c = c0; c <= c1; ++c) { h2[c] = fmaxf((s.acc2[c] + s.p2[c]) + h1[c], 0.0f); s.h2s[c] = h2[c]; }
@@ -128,35 +151,79 @@ __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (
             // ---------------------------------------------------------------- hop 3: the group's own quads
             if (!(NSF2_ABL & 2)) {
 #pragma unroll
-                for (int c = c0; c <= c1; ++c) { o0 = MFMA(comp(o.fc0, c), h2[c], o0); o1 = MFMA(comp(o.fc1, c), h2[c], o1); }
+                for (int c = c0; c <= c1; ++c) s.o0 = MFMA(comp(o.fc0, c), h2[c], s.o0);
+                CHAIN_FENCE();
+                if constexpr (I > 0) rqs_ladj_2(s.pend);
+                CHAIN_FENCE();
+#pragma unroll
+                for (int c = c0; c <= c1; ++c) s.o1 = MFMA(comp(o.fc1, c), h2[c], s.o1);
             }
             CHAIN_FENCE();
             NSF_STAMP(3)
-            // ---------------------------------------------------------------- every lane gets its row's 23 values; spline
-            const float yv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Y) + (p << 4) + f.yo[I]);
-            float xg, l;
+            // ---------------------------------------------------------------- this rank's spline solve; in its slots the
+            // following group's parameters as far as they do not wait for that group's hops
+            constexpr int d0 = LAST ? 0 : pat_start(PAT, I + 1);
+            constexpr int NM = 8 + 2 * d0;
+            static_assert(NM <= RQS_NSLOTS, "more shadow MFMAs than slots");
+            const NsfOut& on = ob[(I + 1) & 1];
+            const float* hB = LAST ? s.h2s : s.h2p;                       // the following group's previous tile
+            float xg;
+            RqsPend pn;
+            auto shadow = [&](auto k_) {
+                constexpr int K = decltype(k_)::value;
+                if constexpr (K < 8) {
+                    constexpr int j = K >> 1;
+                    if constexpr ((K & 1) == 0) { if (!(NSF2_ABL & 2)) n0 = MFMA(comp(on.fp0, j), hB[j], n0); }
+                    else {
+                        if (!(NSF2_ABL & 2)) n1 = MFMA(comp(on.fp1, j), hB[j], n1);
+                        if constexpr (!(LAST && (NG & 1))) ahead(gn, std::integral_constant<int, j>{}, ngc);
+                        else if constexpr (K == 7) {                        // (the requests' target is the buffer the MFMAs read)
+                            ob[0].fc0 = ob[1].fc0; ob[0].fc1 = ob[1].fc1;
+                            static_for<4>([&](auto sl_) { ahead(gn, sl_, ngc); });
+                        }
+                    }
+                } else if constexpr (K < NM) {
+                    constexpr int c = (K - 8) >> 1;
+                    if (!(NSF2_ABL & 2)) {
+                        if constexpr ((K & 1) == 0) n0 = MFMA(comp(on.fc0, c), s.h2s[c], n0);
+                        else n1 = MFMA(comp(on.fc1, c), s.h2s[c], n1);
+                    }
+                }
+                if constexpr (K == 5 && I > 0) ladj -= rqs_ladj_3(s.pend);          // (inside the exchange's LDS wait)
+            };
             if (NSF2_ABL & 1) {
                 float* pr = PAR + (p << 5) + (q << 2);
-                *reinterpret_cast<float4*>(pr) = make_float4(o0[0], o0[1], o0[2], o0[3]);
-                *reinterpret_cast<float4*>(pr + 16) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+                *reinterpret_cast<float4*>(pr) = make_float4(s.o0[0], s.o0[1], s.o0[2], s.o0[3]);
+                *reinterpret_cast<float4*>(pr + 16) = make_float4(s.o1[0], s.o1[1], s.o1[2], s.o1[3]);
                 WAVE_LDS_FENCE();
-                xg = yv + PAR[(p << 5)] + PAR[(p << 5) + 22]; l = PAR[(p << 5) + 8];
+                xg = yv + PAR[(p << 5)] + PAR[(p << 5) + 22];
+                pn.s = 1.0f; pn.e = 0.0f; pn.z = PAR[(p << 5) + 8]; pn.d0 = pn.d1 = 1.0f; pn.inside = true;
+                static_for<RQS_NSLOTS>(shadow);
             } else {
-                rqs_inverse_split(o0, o1, PAR + (p << 5), q, yv, xg, l);
+                rqs_inverse_split_sh(s.o0, s.o1, PAR + (p << 5), q, yv, xg, pn, shadow);
             }
-            if (q == 0) *reinterpret_cast<float*>(reinterpret_cast<char*>(X) + (p << 4) + f.xy[I]) = xg;
-            ladj -= l;
-            WAVE_LDS_FENCE();
+            CHAIN_FENCE();
             NSF_STAMP(4)
-            // ---------------------------------------------------------------- rank-1 updates of layer 0: own tile, next tile
+            // ---------------------------------------------------------------- what the next hop waits for: the rank-1 update of the
+            // following group's quads; everything else of this solve stays pending
+            if constexpr (!LAST) {
+                constexpr int e1 = pat_end(PAT, I + 1);
 #pragma unroll
-            for (int jt = c1 + 1; jt < 4; ++jt) s.a0[jt] = fmaf(comp(f.w0o[I], jt), xg, s.a0[jt]);
-            s.a0N[0] = fmaf(f.w0N[I].x, xg, s.a0N[0]); s.a0N[1] = fmaf(f.w0N[I].y, xg, s.a0N[1]);
-            s.a0N[2] = fmaf(f.w0N[I].z, xg, s.a0N[2]); s.a0N[3] = fmaf(f.w0N[I].w, xg, s.a0N[3]);
+                for (int jt = c1 + 1; jt <= e1; ++jt) s.a0[jt] = fmaf(comp(f.w0o[I], jt), xg, s.a0[jt]);
+            }
+            s.pend = pn;
+            s.pend_x = xg;
+            s.o0 = n0; s.o1 = n1;
             CHAIN_FENCE();
             NSF_STAMP(5)
             nsf_group<PAT, I + 1, AH>(s, f, ob, part, X, Y, PAR, D, q, p, lane, ladj, ahead, pf);
         }
+    } else {
+        // the last group's side effects
+        nsf_settle_a<PAT, NG - 1>(s, f, X, q, p, 4);
+        rqs_ladj_1(s.pend); rqs_ladj_2(s.pend);
+        ladj -= rqs_ladj_3(s.pend);
+        WAVE_LDS_FENCE();
     }
 }
 
@@ -200,9 +267,13 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
     // one rank: bias + the two output tiles against h2 tiles 0 .. NK-1; `side(i)`: the caller's loads for the shadow of K step i
     auto rank = [&](const float4* F0, const float4* F1, const float4& B0, const float4& B1, float* d, auto&& side) {
         f32x4 o0 = as_acc(B0), o1 = as_acc(B1);
+        // (the next K step's activations are requested before this step's MFMAs: issued behind them, an LDS read showed
+        //  ~50 cycles of its latency at every step -- 37 steps in the last tile of a nine-tile flow)
+        float4 bnx = *reinterpret_cast<const float4*>(c.H2 + (lane << 2));
 #pragma unroll
         for (int i = 0; i < NK; ++i) {
-            const float4 b = *reinterpret_cast<const float4*>(c.H2 + (i << 8) + (lane << 2));
+            const float4 b = bnx;
+            if (i + 1 < NK) bnx = *reinterpret_cast<const float4*>(c.H2 + ((i + 1) << 8) + (lane << 2));
             if (!(NSF2_ABL & 4)) {
                 o0 = MFMA(F0[i].x, b.x, o0); o1 = MFMA(F1[i].x, b.x, o1);
                 o0 = MFMA(F0[i].y, b.y, o0); o1 = MFMA(F1[i].y, b.y, o1);
@@ -240,10 +311,14 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
     // ---- (2) hidden layers against the final tiles; the next tile's first rank requested in the shadows
     f32x4 a0 = as_acc(hb0), a1 = as_acc(hb1), a2 = as_acc(hb2);
     const int soN = obase(c.gn), voN = ovo(c.gn);
+    float4 b1n = *reinterpret_cast<const float4*>(c.H0 + (lane << 2)), b2n = *reinterpret_cast<const float4*>(c.H1 + (lane << 2));
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
-        const float4 b1 = *reinterpret_cast<const float4*>(c.H0 + (i << 8) + (lane << 2));
-        const float4 b2 = *reinterpret_cast<const float4*>(c.H1 + (i << 8) + (lane << 2));
+        const float4 b1 = b1n, b2 = b2n;
+        if (i + 1 < NK) {
+            b1n = *reinterpret_cast<const float4*>(c.H0 + ((i + 1) << 8) + (lane << 2));
+            b2n = *reinterpret_cast<const float4*>(c.H1 + ((i + 1) << 8) + (lane << 2));
+        }
         if (!(NSF2_ABL & 32)) {
             a1 = MFMA(hp1[i].x, b1.x, a1); a2 = MFMA(hp2[i].x, b2.x, a2);
             a1 = MFMA(hp1[i].y, b1.y, a1); a2 = MFMA(hp2[i].y, b2.y, a2);
@@ -329,7 +404,11 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
     const int nTl = __builtin_amdgcn_readfirstlane(m.meta[7]);
     // (measurement only, FM == -1: cycles of the chain wave of workgroup 0 by section, summed over the sweep)
     long long pfv[16];
+#ifdef NSF2_TILE_STAMPS
+    long long* pf = nullptr;
+#else
     long long* pf = (FM == -1 && prof && blockIdx.x == 0) ? pfv : nullptr;
+#endif
     if (FM == -1) for (int i = 0; i < 16; ++i) pfv[i] = 0;
     const int64_t row0 = (int64_t)blockIdx.x * 16;
     float* Y = smem;
@@ -369,6 +448,20 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
     const int vo_T = chain_vo_T(lane);
     const int vo_q = q << 4;
     auto lds_bar = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // (measurement only, a library built with -DNSF2_TILE_STAMPS, FM == -1: when the two wavefronts of workgroup 0 reach and
+    //  leave every barrier -- prof[16 + 4 * barrier + {0, 1} chain, {2, 3} burst]; scripts/profile_nsf2_tiles.py)
+#ifdef NSF2_TILE_STAMPS
+    long long* ts = (FM == -1 && prof && blockIdx.x == 0) ? prof + 16 : nullptr;
+    int bar_no = 0;
+    auto lds_bar_t = [&]() {
+        if (ts && lane == 0) ts[4 * bar_no + 2 * wv] = clock64();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (ts && lane == 0) ts[4 * bar_no + 2 * wv + 1] = clock64();
+        ++bar_no;
+    };
+#else
+    auto lds_bar_t = lds_bar;
+#endif
 
     // per hidden tile 8 words (two rows of "no groups" behind the last tile): the ranks its groups produce (word 0 also
     // the quad pattern << 16), the byte offsets of those ranks' x / y word (walker 0)
@@ -552,7 +645,7 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                 lds_bar();                                                /* E(T1 - 1) */                         \
             }
             if (static_tiles) {
-                lds_bar();                                                // E(-1): the chain solved rank 0
+                lds_bar_t();                                              // E(-1): the chain solved rank 0
                 bc.tb = tb; bc.X = X;
                 for (int T1 = 1; T1 < nTl; ++T1) {
                     const int4 tg = *reinterpret_cast<const int4*>(DGT + 8 * T1);
@@ -567,7 +660,7 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
 #undef CASE
                         default: break;
                     }
-                    lds_bar();                                            // E(T1 - 1)
+                    lds_bar_t();                                          // E(T1 - 1)
                 }
                 if (t > 0) first_tile(t - 1, xsel ? XB : XA, spar + nTl);     // (the next transform's x array and parity)
             } else {
@@ -579,7 +672,7 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                 const int tbn = (t > 0 ? t - 1 : 0) * blk_bytes;      // the next transform's first operands: on their way before this one ends
                 NB_FETCH(tbn, 0, sA.p1, sA.p2, sA.xf, sA.b0, sA.b1, sA.b2)
             }
-            lds_bar();                                                    // E(nTl - 1)
+            if (static_tiles) lds_bar_t(); else lds_bar();                // E(nTl - 1)
             spar = (spar + nTl) & 1;
             if (t == 0) __syncthreads();                                  // (the chain stored the result)
         }
@@ -621,6 +714,22 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
         fA.w0o[3] = fB.w0o[3] = make_float4(0.f, 0.f, 0.f, 0.f);          // (the fourth group has no later quad)
         static_for<11>([&](auto k_) { request_hid(fA, k_, T - 1, 0); });
         static_for<4>([&](auto k_) { request_out(ob[0], k_, T - 1, fA.g[0], -1, 0); });
+        // the group after the first: the first tile's second group, or (a tile of one group) the second tile's first
+        auto after_first = [&](const int tt, const int U, const int patU, const int g1U, int& tt2, int& U2, int& g2) {
+            const bool two = (patU & (patU - 1)) != 0;
+            const bool more2 = U + 1 < nTl;
+            const int stt = more2 ? tt : (tt > 0 ? tt - 1 : 0), sU = more2 ? U + 1 : 0;
+            tt2 = two ? tt : stt;
+            U2 = two ? U : sU;
+            g2 = two ? g1U : (__builtin_amdgcn_readfirstlane(DGT[8 * sU]) & 0xffff);
+        };
+        {
+            int tt2, U2, g2;
+            after_first(T - 1, 0, fA.pat, fA.g[1], tt2, U2, g2);
+            static_for<4>([&](auto k_) { request_out(ob[1], k_, tt2, g2, U2 - 1, U2); });
+        }
+        NsfChain s;
+        s.o0 = s.o1 = f32x4{0.f, 0.f, 0.f, 0.f};                          // (the first tile of the sweep has no previous tile)
         float4 w00 = bload4(rs, vo_q, (T - 1) * blk_bytes + oCW0);      // layer 0, first tile: the column of rank 0
         float4 r00 = bload4(rs, vo_q, (T - 1) * blk_bytes + oB3I), r01 = bload4(rs, vo_q, (T - 1) * blk_bytes + oB3I + 64);
         const float* Ysrc = Y;                             // the input of the transform: Y, then the previous transform's x array
@@ -628,7 +737,6 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
         for (int t = T - 1; t >= 0; --t) {
             float* X = xsel ? XB : XA;
             xsel ^= 1;
-            NsfChain s;
             {   // rank 0 reads nothing: bias only
                 float xv, l;
                 const float y0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Ysrc) + (p << 4) + Y0T[t]);
@@ -641,7 +749,7 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
             s.accN1 = s.accN2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) s.h2s[j] = 0.0f;
-            lds_bar();                                                    // E(-1): the first tile's staging is complete
+            lds_bar_t();                                                  // E(-1): the first tile's staging is complete
 
             for (int Tt_ = 0; Tt_ < nTl; ++Tt_) {
                 const int Tt = __builtin_amdgcn_readfirstlane(Tt_);
@@ -659,18 +767,28 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { s.a0N[j] = 0.0f; s.h2p[j] = s.h2s[j]; s.h0s[j] = s.h1s[j] = s.h2s[j] = 0.0f; }
                 s.accN1 = s.accN2 = s.acc1 = s.acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                {   // the first group's parameters: what the previous tile's last group formed in the shadow of its spline solve
+                    // (this tile's "previous tile" products) + the staged partial (bias + h2 tiles <= Tt-2)
+                    const float4 q0 = *reinterpret_cast<const float4*>(part + (lane << 2));
+                    const float4 q1 = *reinterpret_cast<const float4*>(part + 256 + (lane << 2));
+                    s.o0[0] += q0.x; s.o0[1] += q0.y; s.o0[2] += q0.z; s.o0[3] += q0.w;
+                    s.o1[0] += q1.x; s.o1[1] += q1.y; s.o1[2] += q1.z; s.o1[3] += q1.w;
+                }
                 const int pat = cur.pat;
-                const int ng = __builtin_popcount(pat);      // (live groups only: the table drops the trailing padding groups)
                 // what follows this tile: the next live tile, or the first tile of the next transform
                 const bool more = Tt + 1 < nTl;
                 const int ntt = more ? t : (t > 0 ? t - 1 : 0), nU = more ? Tt + 1 : 0;
                 take_table(nxt, ntt, nU);
+                int tt2, U2, g2;                             // the group after the next tile's first
+                after_first(ntt, nU, nxt.pat, nxt.g[1], tt2, U2, g2);
                 // the shadows of a group's MFMAs (slot 0..3: behind the pairs of previous-tile output products; 4, 5: behind the
                 // hidden hops): the next group's output fragments -- a later group of this tile, or the next tile's first -- and
                 // this group's share of the next tile's hidden operands
                 auto ahead = [&](auto gi_, auto slot_, auto ng_) {
                     constexpr int G = decltype(gi_)::value, SL = decltype(slot_)::value, NG_ = decltype(ng_)::value;
-                    if constexpr (SL < 4) {
+                    if constexpr (SL < 4 && G == NG_) {
+                        request_out(ob[1], slot_, tt2, g2, U2 - 1, U2);
+                    } else if constexpr (SL < 4) {
                         const bool last = G + 1 >= NG_;
                         const int gn = last ? nxt.g[0] : cur.g[(G + 1) & 3];
                         request_out(ob[(G + 1) & 1], slot_, last ? ntt : t, gn, last ? (more ? Tt : -1) : Tt - 1, last ? nU : Tt);
@@ -696,9 +814,8 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                     *reinterpret_cast<float4*>(H1 + hw) = make_float4(s.h1s[0], s.h1s[1], s.h1s[2], s.h1s[3]);
                     *reinterpret_cast<float4*>(H2 + hw) = make_float4(s.h2s[0], s.h2s[1], s.h2s[2], s.h2s[3]);
                 }
-                if (ng & 1) ob[0] = ob[1];                   // (an odd number of groups leaves the next group's fragments in the second slot)
                 NSF_STAMP(8)
-                lds_bar();                                   // E(Tt): this tile is final
+                lds_bar_t();                                 // E(Tt): this tile is final
                 NSF_STAMP(9)
                 fA = fB;
                 NSF_STAMP(10)

@@ -10,12 +10,10 @@
 #ifndef PMC_RQS_H
 #define PMC_RQS_H
 
+#include <type_traits>
 #include "maf_common.h"
 
 #define RQS_K 8
-#ifndef RQS_SELECT_REGS
-#define RQS_SELECT_REGS 0   // rqs_inverse_split: the bin's derivatives by register selects (1) or by an indexed LDS read (0)
-#endif
 #define RQS_NOUT 23
 #define RQS_BOUND 5.0f
 
@@ -181,38 +179,74 @@ __device__ __forceinline__ void rqs_inverse_coop(const float* par, float* tab, i
 // bounds them by |log slope| / 2 = 3.45, so the softmax needs no maximum), the panel row carries the sixteen unnormalised
 // weights and the raw derivatives, and behind the ONE exchange every lane finds the bin on unnormalised cumulative sums
 // (knot_j < y  <=>  cum_j < (y + B) / 2B * sum) and normalises only the four knots of that bin.  par: 32 floats of LDS.
-__device__ __forceinline__ void rqs_inverse_split(const f32x4& o0, const f32x4& o1, float* par, int q, float y, float& x, float& ladj) {
-    {
-        float4 e;
-        e.x = rqs_exp(rqs_clip2(o0[0])); e.y = rqs_exp(rqs_clip2(o0[1])); e.z = rqs_exp(rqs_clip2(o0[2])); e.w = rqs_exp(rqs_clip2(o0[3]));
-        *reinterpret_cast<float4*>(par + 4 * q) = e;
-        *reinterpret_cast<float4*>(par + 16 + 4 * q) = make_float4(o1[0], o1[1], o1[2], o1[3]);
-    }
+//
+// Round 4: the solve is written in STAGES with fourteen numbered slots between them -- `sh(integral_constant<K>)` is the
+// caller's work for the shadow of stage K (the chain wave issues the NEXT rank's MFMAs there: one per slot, each behind
+// >= 32 cycles of vector work or inside an LDS wait, so the matrix pipe never stalls the solve) -- and the
+// log-derivative, which nothing downstream waits for, is returned UNEVALUATED (RqsPend -> rqs_ladj_1 / _2 / _3, run by the
+// caller in the shadows of the next rank's hops).  Scheduling fences keep the stages in this order; inside a stage the
+// four (or two) independent lines are written side by side so that dependent instructions stand four apart.
+struct RqsPend { float s, e, z, d0, d1, u, rden, jac; bool inside; };
+__device__ __forceinline__ void rqs_ladj_1(RqsPend& r) { r.u = r.z * (1.0f - r.z); r.rden = rqs_rcp(r.s + r.e * r.u); }
+__device__ __forceinline__ void rqs_ladj_2(RqsPend& r) {
+    r.jac = r.s * r.s * (2.0f * r.s * r.u + r.d0 * (1.0f - r.z) * (1.0f - r.z) + r.d1 * r.z * r.z) * (r.rden * r.rden);
+}
+__device__ __forceinline__ float rqs_ladj_3(const RqsPend& r) { return r.inside ? rqs_log(r.jac) : 0.0f; }
+
+struct RqsNoShadow {
+    template <int K> __device__ __forceinline__ void operator()(std::integral_constant<int, K>) const {}
+};
+#define RQS_NSLOTS 14
+#define RQS_SLOT(K) { __builtin_amdgcn_sched_barrier(0); sh(std::integral_constant<int, K>{}); __builtin_amdgcn_sched_barrier(0); }
+
+template <class SH>
+__device__ __forceinline__ void rqs_inverse_split_sh(const f32x4& o0, const f32x4& o1, float* par, int q, float y, float& x, RqsPend& pend,
+                                                     const SH& sh) {
+    // ---- A: soft clip and exponential of the lane's four widths / heights (rqs_exp(rqs_clip2(v)), four lines side by side)
+    const float t0 = o0[0] * (2.0f * RQS_INV_LS), t1 = o0[1] * (2.0f * RQS_INV_LS), t2 = o0[2] * (2.0f * RQS_INV_LS), t3 = o0[3] * (2.0f * RQS_INV_LS);
+    RQS_SLOT(0)
+    const float r0 = rqs_rcp(1.0f + fabsf(t0)), r1 = rqs_rcp(1.0f + fabsf(t1));
+    RQS_SLOT(1)
+    const float r2 = rqs_rcp(1.0f + fabsf(t2)), r3 = rqs_rcp(1.0f + fabsf(t3));
+    RQS_SLOT(2)
+    const float m0 = (o0[0] * r0) * 1.4426950408889634f, m1 = (o0[1] * r1) * 1.4426950408889634f;
+    const float m2 = (o0[2] * r2) * 1.4426950408889634f, m3 = (o0[3] * r3) * 1.4426950408889634f;
+    RQS_SLOT(3)
+    float4 ex;
+    ex.x = __builtin_amdgcn_exp2f(m0); ex.y = __builtin_amdgcn_exp2f(m1);
+    RQS_SLOT(4)
+    ex.z = __builtin_amdgcn_exp2f(m2); ex.w = __builtin_amdgcn_exp2f(m3);
+    // ---- B: the exchange
+    *reinterpret_cast<float4*>(par + 4 * q) = ex;
+    *reinterpret_cast<float4*>(par + 16 + 4 * q) = make_float4(o1[0], o1[1], o1[2], o1[3]);
     WAVE_LDS_FENCE();
-    const float4 w0 = *reinterpret_cast<const float4*>(par), w1 = *reinterpret_cast<const float4*>(par + 4);
     const float4 h0 = *reinterpret_cast<const float4*>(par + 8), h1 = *reinterpret_cast<const float4*>(par + 12);
-    const float ch1 = h0.x, ch2 = ch1 + h0.y, ch3 = ch2 + h0.z, ch4 = ch3 + h0.w, ch5 = ch4 + h1.x, ch6 = ch5 + h1.y, ch7 = ch6 + h1.z, hs = ch7 + h1.w;
-    const float cw1 = w0.x, cw2 = cw1 + w0.y, cw3 = cw2 + w0.z, cw4 = cw3 + w0.w, cw5 = cw4 + w1.x, cw6 = cw5 + w1.y, cw7 = cw6 + w1.z, ws = cw7 + w1.w;
+    const float4 w0 = *reinterpret_cast<const float4*>(par), w1 = *reinterpret_cast<const float4*>(par + 4);
     const bool inside = (y > -RQS_BOUND) && (y <= RQS_BOUND);
-    const float t = (y + RQS_BOUND) * (0.5f / RQS_BOUND) * hs;
-    // the bin and what belongs to it, by compare-and-select over registers (an LDS read by run-time index would put a
-    // second round trip on the dependent path); the end knots' raw log-derivative is 0 (derivative 1)
-#if RQS_SELECT_REGS
-    const float4 d03 = *reinterpret_cast<const float4*>(par + 16), d46 = *reinterpret_cast<const float4*>(par + 20);
-    float a0 = 0.0f, a1 = ch1, b0 = 0.0f, b1 = cw1, q0 = 0.0f, q1 = d03.x;
-#define RQS_STEP(CA, CB, WA, WB, QA, QB) if (CA < t) { a0 = CA; a1 = CB; b0 = WA; b1 = WB; q0 = QA; q1 = QB; }
-    RQS_STEP(ch1, ch2, cw1, cw2, d03.x, d03.y) RQS_STEP(ch2, ch3, cw2, cw3, d03.y, d03.z) RQS_STEP(ch3, ch4, cw3, cw4, d03.z, d03.w)
-    RQS_STEP(ch4, ch5, cw4, cw5, d03.w, d46.x) RQS_STEP(ch5, ch6, cw5, cw6, d46.x, d46.y) RQS_STEP(ch6, ch7, cw6, cw7, d46.y, d46.z)
-    RQS_STEP(ch7, hs, cw7, ws, d46.z, 0.0f)
-#undef RQS_STEP
+    const float ty = (y + RQS_BOUND) * (0.5f / RQS_BOUND);
+    RQS_SLOT(5)
+    RQS_SLOT(6)
+    RQS_SLOT(7)
+    // ---- C: unnormalised cumulative sums, heights and widths side by side
+    const float ch1 = h0.x, cw1 = w0.x;
+    const float ch2 = ch1 + h0.y, cw2 = cw1 + w0.y;
+    const float ch3 = ch2 + h0.z, cw3 = cw2 + w0.z;
+    const float ch4 = ch3 + h0.w, cw4 = cw3 + w0.w;
+    RQS_SLOT(8)
+    const float ch5 = ch4 + h1.x, cw5 = cw4 + w1.x;
+    const float ch6 = ch5 + h1.y, cw6 = cw5 + w1.y;
+    const float ch7 = ch6 + h1.z, cw7 = cw6 + w1.z;
+    const float hs = ch7 + h1.w, ws = cw7 + w1.w;
+    RQS_SLOT(9)
+    const float t = ty * hs;
     const float rh = rqs_rcp(hs) * (2.0f * RQS_BOUND), rw = rqs_rcp(ws) * (2.0f * RQS_BOUND);
-    const float y0 = a0 * rh - RQS_BOUND, y1 = a1 * rh - RQS_BOUND, x0 = b0 * rw - RQS_BOUND, x1 = b1 * rw - RQS_BOUND;
-    const float d0 = rqs_exp(rqs_clip1(q0)), d1 = rqs_exp(rqs_clip1(q1));
-#else
-    // bisection over the nine knots (three compares, 20 selects; the linear scan was 7 compares and 35 selects in a chain)
+    // ---- D: bisection over the nine knots (three compares, 20 selects), then the bin's two raw derivatives by an
+    // indexed LDS read (selecting them from registers next to the knots cost more: a lone wavefront pays ~10 cycles per
+    // dependent select)
     const bool c4 = ch4 < t;
     const float e0 = c4 ? ch4 : 0.0f, e1 = c4 ? ch5 : ch1, e2 = c4 ? ch6 : ch2, e3 = c4 ? ch7 : ch3, e4 = c4 ? hs : ch4;
     const float f0 = c4 ? cw4 : 0.0f, f1 = c4 ? cw5 : cw1, f2 = c4 ? cw6 : cw2, f3 = c4 ? cw7 : cw3, f4 = c4 ? ws : cw4;
+    RQS_SLOT(10)
     const bool c2 = e2 < t;
     const float g0 = c2 ? e2 : e0, g1 = c2 ? e3 : e1, g2 = c2 ? e4 : e2;
     const float i0 = c2 ? f2 : f0, i1 = c2 ? f3 : f1, i2 = c2 ? f4 : f2;
@@ -220,24 +254,32 @@ __device__ __forceinline__ void rqs_inverse_split(const f32x4& o0, const f32x4& 
     const float a0 = c1 ? g1 : g0, a1 = c1 ? g2 : g1, b0 = c1 ? i1 : i0, b1 = c1 ? i2 : i1;
     const int k = (c4 ? 4 : 0) + (c2 ? 2 : 0) + (c1 ? 1 : 0);
     const float q0 = par[2 * RQS_K + (k >= 1 ? k - 1 : 0)], q1 = par[2 * RQS_K + (k + 1 < RQS_K ? k : 0)];
-    const float rh = rqs_rcp(hs) * (2.0f * RQS_BOUND), rw = rqs_rcp(ws) * (2.0f * RQS_BOUND);
+    RQS_SLOT(11)
+    // ---- E: the bin's knots (while the two derivatives are on their way)
     const float y0 = a0 * rh - RQS_BOUND, y1 = a1 * rh - RQS_BOUND, x0 = b0 * rw - RQS_BOUND, x1 = b1 * rw - RQS_BOUND;
-    const float r0 = (k >= 1) ? rqs_clip1(q0) : 0.0f, r1 = (k + 1 < RQS_K) ? rqs_clip1(q1) : 0.0f;
-    const float d0 = rqs_exp(r0), d1 = rqs_exp(r1);
-#endif
     const float dx = x1 - x0, dy = y1 - y0;
     const float s = dy * rqs_rcp(dx);
     const float yr = inside ? y - y0 : 0.0f;
+    RQS_SLOT(12)
+    // ---- F: derivatives at the bin's knots; the end knots' raw log-derivative is 0 (derivative 1)
+    const float v0 = (k >= 1) ? rqs_clip1(q0) : 0.0f, v1 = (k + 1 < RQS_K) ? rqs_clip1(q1) : 0.0f;
+    const float d0 = rqs_exp(v0), d1 = rqs_exp(v1);
+    RQS_SLOT(13)
+    // ---- G: Durkan's inverse
     const float e = d0 + d1 - 2.0f * s;
     const float qa = dy * (s - d0) + yr * e;
     const float qb = dy * d0 - yr * e;
     const float qc = -s * yr;
     const float z = 2.0f * qc * rqs_rcp(-qb - __builtin_amdgcn_sqrtf(qb * qb - 4.0f * qa * qc));
-    const float u = z * (1.0f - z);
-    const float rden = rqs_rcp(s + e * u);
-    const float jac = s * s * (2.0f * s * u + d0 * (1.0f - z) * (1.0f - z) + d1 * z * z) * (rden * rden);
     x = inside ? x0 + z * dx : y;
-    ladj = inside ? rqs_log(jac) : 0.0f;
+    pend.s = s; pend.e = e; pend.z = z; pend.d0 = d0; pend.d1 = d1; pend.inside = inside;
+}
+
+__device__ __forceinline__ void rqs_inverse_split(const f32x4& o0, const f32x4& o1, float* par, int q, float y, float& x, float& ladj) {
+    RqsPend r;
+    rqs_inverse_split_sh(o0, o1, par, q, y, x, r, RqsNoShadow{});
+    rqs_ladj_1(r); rqs_ladj_2(r);
+    ladj = rqs_ladj_3(r);
 }
 
 // Reverse mode of F = gy * y + gl * ladj:  dphi[23] and gx = dF/dx.

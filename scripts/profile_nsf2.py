@@ -22,9 +22,9 @@ torch.cuda.synchronize()
 p = prof.cpu().numpy()
 ranks = f.spec.n_transforms * (D - 1)
 tiles = f.spec.n_transforms * int(f.spec.device_meta()[7])
-names = ["requests (ahead)", "staged partial + previous-tile / earlier-quad output MFMAs", "hidden hops 1, 2", "own-quad output MFMAs",
-         "exchange + spline + x store", "rank-1 updates", "(after the last group)", "(group entry)", "h stores, slot copy", "barrier E",
-         "operand set copy"]
+names = ["-", "-", "hidden hops 1, 2 (+ the previous rank's side effects in their shadows)", "own-quad output MFMAs",
+         "exchange + spline (+ the following rank's MFMAs in its slots)", "rank-1 update of the following quads", "(after the last group: its side effects)",
+         "(group entry)", "h stores", "barrier E", "operand set copy"]
 print(f"D={D} {name} n={n}: {ranks} ranks in {tiles} tiles; chain wave of workgroup 0, cycles")
 for i, nm in enumerate(names):
     per = ranks if i < 6 or i == 7 else tiles
