@@ -259,7 +259,8 @@ def main():
                          "after the other and cost the same whatever their size; a larger first lane puts more of the host "
                          "likelihood behind the second sweep: measured 2605 (0.5) / 2767 (0.65) / 2844 (0.7) / 2843 (0.8) steps/s.  "
                          "Default: 0.65; 0.75 for the flows that take the lane-per-walker sweep (config 3, f16 helpers: 762 (0.5) / "
-                         "811 (0.6) / 864 (0.75) steps/s -- a lane of <= 8192 walkers is one round of that sweep whatever its size)")
+                         "811 (0.6) / 864 (0.75) steps/s -- a lane of <= 8192 walkers is one round of that sweep whatever its size); the spline "
+                         "flows: 8192 walkers (nsf6 1628 (0.65) / 1651 (0.75) / 1661 (0.82), nsf3 2425 / 2483 / 2529)")
     ap.add_argument("--head-rows", type=int, default=0,
                     help="rows of the first lane whose x' crosses PCIe ahead of the others, with a completion word of their own: "
                          "the host's likelihood starts on them while the rest arrives (pmc_step_t.head_rows); 0 (default) = off.  "
@@ -415,6 +416,10 @@ def main():
         import ctypes as _ct
         args.first_lane = 0.75 if (args.inverse in ("auto", "triangular", "lane")
                                    and flow.lib.pmc_debug_inverse_uses_lane(_ct.byref(flow._desc))) else 0.65
+        if flow.spec.univariate == "rqs":
+            # the spline sweep is longer than the whole set's likelihood: nothing of the first lane's likelihood is left to hide,
+            # the second lane's comes behind its sweep -- the first lane takes all the walker sets one round holds (512 x 16)
+            args.first_lane = min(0.82, 8192.0 / n)
     if args.lanes > 1 or pipelined:
         leng = LanedEngine("preconditioned_pcn", n, D, flow, scaler, lanes=args.lanes, group=None,
                            shard_offset=rank * n, seed=20240928, x_order=args.x_order, streams=not pipelined,

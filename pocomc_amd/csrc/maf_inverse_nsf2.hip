@@ -22,7 +22,7 @@
 
 #ifndef NSF2_ABL
 #define NSF2_ABL 0                 // timing experiments only (scripts/abl_nsf.sh): results are wrong when != 0
-#endif                             // 1 no spline solve, 2 no output MFMAs on the chain, 4 burst: no output partials, 8 nor their loads, 16 chain: no output fragment requests, 32 burst: no hidden products
+#endif                             // 1 no spline solve, 2 no output MFMAs on the chain, 4 burst: no output partials, 8 nor their loads, 16 chain: no output fragment requests, 32 burst: no hidden products, 64 no eager partials (results stay right)
 #define NSF2_PK 10                 // K tiles of the hidden bursts held in registers; the static burst tile covers flows of <= NSF2_PK + 1 live tiles
 #define NSF2_PX 4                  // x tiles of the layer-0 product held in registers (D <= 64)
 #define NSF2_OOB 0x40000000        // a lane offset beyond every image: the bounds-checked load returns zeros
@@ -30,8 +30,20 @@
 #define NSF2_PART_FLOATS (4 * 2 * 256)              // output staging [group][half][lane][4]
 #define NSF2_TT_WORDS(m) (((m)->nT + 2) * 8)        // per-tile table: ranks (word 0 also the pattern), x / y byte offsets
 #define NSF2_YT_WORDS(m) ((m)->T * (((m)->nT + 2) * 4 + 1))   // per transform: the y offsets of every tile's groups, of rank 0
-#define NSF2_LDS_FLOATS(m) (3 * (m)->Dp * 16 + 3 * (m)->Hp * 16 + 2 * NSF2_STAGE_FLOATS + 2 * NSF2_PART_FLOATS + 16 * 32 + \
-                            ((NSF2_TT_WORDS(m) + (m)->Dp + NSF2_YT_WORDS(m) + 3) & ~3))
+#define NSF2_LDS_BASE_FLOATS(m) (3 * (m)->Dp * 16 + 3 * (m)->Hp * 16 + 2 * NSF2_STAGE_FLOATS + 2 * NSF2_PART_FLOATS + 16 * 32 + \
+                                 ((NSF2_TT_WORDS(m) + (m)->Dp + NSF2_YT_WORDS(m) + 3) & ~3))
+// EAGER PARTIALS (round 4).  The burst wave's work for tile T1 grows with T1 (40 (T1 - 1) MFMAs at 32 cycles each against a
+// chain that takes ~9 k cycles per tile whatever the tile): from the seventh tile on the chain waited for it (scripts/
+// profile_nsf2_tiles.py: 0.5 / 2.1 / 3.1 k cycles at tiles 5 - 7 of a nine-tile flow) while on tiles 1 - 4 the burst wave waited
+// 2 - 4 k cycles for the chain.  The output partials of the LAST TWO live tiles therefore start early: their ranks' products
+// against h2 tiles 0, 1, 2 (last tile) and 0, 1 (the one before) are formed at steps 2, 3, 4 -- in the burst wave's idle
+// time -- into two more partial buffers in LDS that only the burst wave touches; the two tiles' own steps start from those
+// and run K = 3 .. / 2 .. only (nsf_burst_tile<T1, KS>).  Flows of >= 8 live tiles on the static path whose LDS stays within
+// half a CU's (two workgroups per CU).
+#define NSF2_EAGER_FLOATS (2 * NSF2_PART_FLOATS)
+#define NSF2_EAGER_OK(m) ((m)->nT >= 8 && (m)->nT <= NSF2_PK + 1 && \
+                          (size_t)(NSF2_LDS_BASE_FLOATS(m) + NSF2_EAGER_FLOATS) * sizeof(float) <= 80 * 1024)
+#define NSF2_LDS_FLOATS(m) (NSF2_LDS_BASE_FLOATS(m) + (NSF2_EAGER_OK(m) ? NSF2_EAGER_FLOATS : 0))
 
 __device__ __forceinline__ f32x4 as_acc(const float4& v) { f32x4 r; r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; return r; }
 
@@ -98,6 +110,9 @@ __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (
                                           float* PAR, int D, int q, int p, int lane, float& ladj, const AH& ahead,
                                           long long* pf = nullptr) {
 #define NSF_STAMP(K) if (pf) { const long long now_ = clock64(); pf[K] += now_ - pf[15]; pf[15] = now_; }
+    // a value nothing nearby waits for is computed HERE (instruction selection otherwise sinks a pure computation to its
+    // first use -- the log-derivatives of a whole tile ended up behind its last group, on the dependent path)
+#define NSF_PIN(V) asm volatile("" : "+v"(V));
     constexpr int NG = pat_ngroups(PAT);
     if constexpr (I < NG) {
         constexpr int c0 = pat_start(PAT, I), c1 = pat_end(PAT, I);
@@ -129,7 +144,7 @@ __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (
 #pragma unroll
             for (int c = c0; c <= c1; ++c) s.acc2 = MFMA(comp(f.wt2, c), h1[c], s.acc2);
             CHAIN_FENCE();
-            if constexpr (I > 0) rqs_ladj_1(s.pend);
+            if constexpr (I > 0) { rqs_ladj_1(s.pend); NSF_PIN(s.pend.rden) }
             // (this group's y, and the staged partial the following group's parameters start from)
             const float yv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Y) + (p << 4) + f.yo[I]);
             constexpr bool LAST = I + 1 >= NG;
@@ -153,7 +168,7 @@ __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (
 #pragma unroll
                 for (int c = c0; c <= c1; ++c) s.o0 = MFMA(comp(o.fc0, c), h2[c], s.o0);
                 CHAIN_FENCE();
-                if constexpr (I > 0) rqs_ladj_2(s.pend);
+                if constexpr (I > 0) { rqs_ladj_2(s.pend); NSF_PIN(s.pend.jac) }
                 CHAIN_FENCE();
 #pragma unroll
                 for (int c = c0; c <= c1; ++c) s.o1 = MFMA(comp(o.fc1, c), h2[c], s.o1);
@@ -189,7 +204,7 @@ __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (
                         else n1 = MFMA(comp(on.fc1, c), s.h2s[c], n1);
                     }
                 }
-                if constexpr (K == 5 && I > 0) ladj -= rqs_ladj_3(s.pend);          // (inside the exchange's LDS wait)
+                if constexpr (K == 5 && I > 0) { ladj -= rqs_ladj_3(s.pend); NSF_PIN(ladj) }          // (inside the exchange's LDS wait)
             };
             if (NSF2_ABL & 1) {
                 float* pr = PAR + (p << 5) + (q << 2);
@@ -241,18 +256,22 @@ struct NsfBurstCtx {
     const float *X, *H0, *H1, *H2;
     float *stg, *part;
     int g[4], gn;                  // the ranks of this tile's groups; of the next tile's first group
+    int eag;                       // eager partials on: eg[0] / ea[0]: the ranks / the partial buffer of the last live tile, [1]: of the one before
+    int eg[2][4];
+    float* ea[2];
 };
 
 // Order inside the tile: the four ranks' output partials first (the first rank's fragments came with the previous tile,
 // rank r + 1's are requested in the shadows of rank r's products, the tile's hidden operands in the shadows of the last
 // rank's), then the hidden layers (the next tile's first-rank fragments in their shadows).  Only those cross a tile
 // boundary (in `carry`); everything else is local to the dispatched case.
-template <int T1>
+template <int T1, int KS = 0, bool EAG = false>
 __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCarry& carry) {
     constexpr int NK = T1 > 0 ? T1 - 1 : 0;          // final hidden tiles: 0 .. T1-2
     constexpr int NN = T1;                           // the next tile's: 0 .. T1-1
     constexpr int NF = NK > 0 ? NK : 1;
     static_assert(NN <= NSF2_PK, "carry too small");
+    static_assert(KS <= NK, "eager K tiles beyond the final ones");
     const int lane = c.lane;
     float4 fa0[NF], fa1[NF], fb0[NF], fb1[NF], ba0, ba1, bb0, bb1;
     float4 hp1[NF], hp2[NF], xf[NSF2_PX], hb0, hb1, hb2;
@@ -263,15 +282,55 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
         B0 = bload4(c.rs, vo, so);
         B1 = bload4(c.rs, vo, so + 64);
     };
+    // ---- (0) eager partials of the last two live tiles (EAG; steps 2, 3, 4): this step's jobs are job 0 = the last tile's
+    // ranks against h2 tile T1 - 2 and, from step 3, job 1 = the ranks of the tile before against h2 tile T1 - 3; step 2 is the
+    // first touch of the last tile's partials, step 3 of the other tile's (they start from the ranks' biases).  Their
+    // fragments (and biases) are requested in the shadows of the regular products' MFMAs, `eload(k)`, k = 0 .. 4 EPR - 1,
+    // and multiplied at the end of the tile.
+    constexpr int NJ = !EAG ? 0 : (T1 == 2 ? 1 : ((T1 == 3 || T1 == 4) ? 2 : 0));
+    static_assert(!EAG || NJ > 0, "eager work exists at steps 2, 3, 4 only");
+    constexpr int NJ1 = NJ > 0 ? NJ : 1;
+    constexpr int JK0 = T1 - 2, JK1 = T1 - 3;
+    constexpr bool FIRST0 = T1 == 2, FIRST1 = T1 == 3;
+    constexpr int EPR = 2 * NJ + ((FIRST0 || FIRST1) ? 2 : 0);        // requests per rank
+    constexpr int ELPS = (NJ > 0 && NK > 0) ? (4 * EPR + 4 * NK - 1) / (4 * NK) : 0;      // per shadow of the 4 NK regular K steps
+    float4 ef0[NJ1][4], ef1[NJ1][4], eb0[4], eb1[4];
+    auto eload = [&](const int k) {
+        if constexpr (NJ > 0) {
+            if (k >= 4 * EPR) return;
+            const int r = k / EPR, w = k - r * EPR;
+            const int fb = FIRST0 ? 0 : 1;                           // the tile whose partials are touched first at this step
+            if (w < 2 * NJ) {
+                const int j = w >> 1, g = c.eg[j][r], K = j == 0 ? JK0 : JK1;
+                if ((w & 1) == 0) ef0[j][r] = bload4(c.rs, ovo(g), obase(g) + K * 1024);
+                else ef1[j][r] = bload4(c.rs, ovo(g), obase(g) + (c.nT + K) * 1024);
+            } else {
+                const int g = c.eg[fb][r];
+                const int so = c.tb + c.oB3I + (g < c.D ? g : 0) * 128, vo = g < c.D ? c.vo_q : NSF2_OOB;
+                if (w == 2 * NJ) eb0[r] = bload4(c.rs, vo, so);
+                else eb1[r] = bload4(c.rs, vo, so + 64);
+            }
+        }
+    };
     const int soH1 = c.tb + c.oF1 + T1 * c.nT * 1024, soH2 = c.tb + c.oF2 + T1 * c.nT * 1024;
-    // one rank: bias + the two output tiles against h2 tiles 0 .. NK-1; `side(i)`: the caller's loads for the shadow of K step i
-    auto rank = [&](const float4* F0, const float4* F1, const float4& B0, const float4& B1, float* d, auto&& side) {
-        f32x4 o0 = as_acc(B0), o1 = as_acc(B1);
+    // one rank: bias (or, KS > 0, what the eager steps left) + the two output tiles against h2 tiles KS .. NK-1; `side(i)`:
+    // the caller's loads for the shadow of K step i (steps 0 .. KS-1 have no products: their loads go first)
+    float* const eacc = c.ea[KS == 3 ? 0 : 1];
+    auto rank = [&](const int r, const float4* F0, const float4* F1, const float4& B0, const float4& B1, float* d, auto&& side) {
+        f32x4 o0, o1;
+        if constexpr (KS > 0) {
+            o0 = as_acc(*reinterpret_cast<const float4*>(eacc + (2 * r) * 256 + (lane << 2)));
+            o1 = as_acc(*reinterpret_cast<const float4*>(eacc + (2 * r + 1) * 256 + (lane << 2)));
+        } else {
+            o0 = as_acc(B0); o1 = as_acc(B1);
+        }
+#pragma unroll
+        for (int i = 0; i < KS; ++i) side(i);
         // (the next K step's activations are requested before this step's MFMAs: issued behind them, an LDS read showed
         //  ~50 cycles of its latency at every step -- 37 steps in the last tile of a nine-tile flow)
-        float4 bnx = *reinterpret_cast<const float4*>(c.H2 + (lane << 2));
+        float4 bnx = *reinterpret_cast<const float4*>(c.H2 + (KS << 8) + (lane << 2));
 #pragma unroll
-        for (int i = 0; i < NK; ++i) {
+        for (int i = KS; i < NK; ++i) {
             const float4 b = bnx;
             if (i + 1 < NK) bnx = *reinterpret_cast<const float4*>(c.H2 + ((i + 1) << 8) + (lane << 2));
             if (!(NSF2_ABL & 4)) {
@@ -281,6 +340,8 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
                 o0 = MFMA(F0[i].w, b.w, o0); o1 = MFMA(F1[i].w, b.w, o1);
             }
             side(i);
+#pragma unroll
+            for (int l = 0; l < ELPS; ++l) eload((r * NK + i) * ELPS + l);
             CHAIN_FENCE();
         }
         *reinterpret_cast<float4*>(d + (lane << 2)) = make_float4(o0[0], o0[1], o0[2], o0[3]);
@@ -289,22 +350,23 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
     auto fetch_into = [&](const int g, float4* N0, float4* N1) {
         const int so = obase(g), vo = ovo(g);
         return [=, &c](const int i) {
+            if (i < KS) return;                                                     // (that part of the rank came early)
             if (!(NSF2_ABL & 8)) { N0[i] = bload4(c.rs, vo, so + i * 1024); N1[i] = bload4(c.rs, vo, so + (c.nT + i) * 1024); }
         };
     };
     // ---- (1) output partials
     obias(c.g[1], bb0, bb1);
-    rank(carry.f0, carry.f1, carry.b0, carry.b1, c.part, fetch_into(c.g[1], fb0, fb1));
+    rank(0, carry.f0, carry.f1, carry.b0, carry.b1, c.part, fetch_into(c.g[1], fb0, fb1));
     obias(c.g[2], ba0, ba1);
-    rank(fb0, fb1, bb0, bb1, c.part + 512, fetch_into(c.g[2], fa0, fa1));
+    rank(1, fb0, fb1, bb0, bb1, c.part + 512, fetch_into(c.g[2], fa0, fa1));
     obias(c.g[3], bb0, bb1);
 #pragma unroll
     for (int i = 0; i < NSF2_PX; ++i) xf[i] = bload4(c.rs, i < c.nXT ? c.vo_T : NSF2_OOB, c.tb + c.oF0C + (T1 * c.nXT + i) * 1024);
-    rank(fa0, fa1, ba0, ba1, c.part + 1024, fetch_into(c.g[3], fb0, fb1));
+    rank(2, fa0, fa1, ba0, ba1, c.part + 1024, fetch_into(c.g[3], fb0, fb1));
     hb0 = bload4(c.rs, c.vo_q, c.tb + c.oB0T + 64 * T1);
     hb1 = bload4(c.rs, c.vo_q, c.tb + c.oB1T + 64 * T1);
     hb2 = bload4(c.rs, c.vo_q, c.tb + c.oB2T + 64 * T1);
-    rank(fb0, fb1, bb0, bb1, c.part + 1536, [&](const int i) {
+    rank(3, fb0, fb1, bb0, bb1, c.part + 1536, [&](const int i) {
         hp1[i] = bload4(c.rs, c.vo_T, soH1 + i * 1024);
         hp2[i] = bload4(c.rs, c.vo_T, soH2 + i * 1024);
     });
@@ -344,6 +406,38 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
     *reinterpret_cast<float4*>(c.stg + (lane << 2)) = make_float4(a0[0], a0[1], a0[2], a0[3]);
     *reinterpret_cast<float4*>(c.stg + 256 + (lane << 2)) = make_float4(a1[0], a1[1], a1[2], a1[3]);
     *reinterpret_cast<float4*>(c.stg + 512 + (lane << 2)) = make_float4(a2[0], a2[1], a2[2], a2[3]);
+    // ---- (3) this step's eager jobs: read the partials (all of them up front: one LDS latency), multiply, write back
+    if constexpr (NJ > 0) {
+        const float4 hk0 = *reinterpret_cast<const float4*>(c.H2 + (JK0 << 8) + (lane << 2));
+        float4 hk1 = hk0;
+        if constexpr (NJ > 1) hk1 = *reinterpret_cast<const float4*>(c.H2 + (JK1 << 8) + (lane << 2));
+        f32x4 o0[NJ1][4], o1[NJ1][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const bool first = (j == 0 && FIRST0) || (j == 1 && FIRST1);
+                const float* ap = c.ea[j] + (2 * r) * 256 + (lane << 2);
+                if (first) { o0[j][r] = as_acc(eb0[r]); o1[j][r] = as_acc(eb1[r]); }
+                else { o0[j][r] = as_acc(*reinterpret_cast<const float4*>(ap)); o1[j][r] = as_acc(*reinterpret_cast<const float4*>(ap + 256)); }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float4 b = j == 0 ? hk0 : hk1;
+                const float4 F0 = ef0[j][r], F1 = ef1[j][r];
+                o0[j][r] = MFMA(F0.x, b.x, o0[j][r]); o1[j][r] = MFMA(F1.x, b.x, o1[j][r]);
+                o0[j][r] = MFMA(F0.y, b.y, o0[j][r]); o1[j][r] = MFMA(F1.y, b.y, o1[j][r]);
+                o0[j][r] = MFMA(F0.z, b.z, o0[j][r]); o1[j][r] = MFMA(F1.z, b.z, o1[j][r]);
+                o0[j][r] = MFMA(F0.w, b.w, o0[j][r]); o1[j][r] = MFMA(F1.w, b.w, o1[j][r]);
+                float* ap = c.ea[j] + (2 * r) * 256 + (lane << 2);
+                *reinterpret_cast<float4*>(ap) = make_float4(o0[j][r][0], o0[j][r][1], o0[j][r][2], o0[j][r][3]);
+                *reinterpret_cast<float4*>(ap + 256) = make_float4(o1[j][r][0], o1[j][r][1], o1[j][r][2], o1[j][r][3]);
+            }
+        }
+    }
 }
 
 // Two accumulators over K tiles K0 .. nK-1 with the fragments of four K tiles in flight (the streamed path of the wide
@@ -424,6 +518,7 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
     int* PRM = DGT + NSF2_TT_WORDS(&m);
     int* YT = PRM + Dp;
     int* Y0T = YT + T * (nT + 2) * 4;
+    float* EAG = smem + NSF2_LDS_BASE_FLOATS(&m);      // (only with NSF2_EAGER_OK: the launcher sized the block by the same macro)
     const int* feat_of_rank = m.meta + 8;
     const int* rank_of_feat = m.meta + 8 + T * D;
     const int* quad_meta = m.meta + 8 + 2 * T * D;
@@ -575,6 +670,18 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
         bc.rs = rs; bc.oF1 = oF1; bc.oF2 = oF2; bc.oF0C = oF0C; bc.oB0T = oB0T; bc.oB1T = oB1T; bc.oB2T = oB2T; bc.oF3I = oF3I; bc.oB3I = oB3I;
         bc.nT = nT; bc.nXT = nXT; bc.D = D; bc.lane = lane; bc.vo_lane = vo_lane; bc.vo_T = vo_T; bc.vo_q = vo_q;
         bc.H0 = H0; bc.H1 = H1; bc.H2 = H2;
+        // eager partials of the last two live tiles (NSF2_EAGER_OK)
+        bc.eag = (NSF2_EAGER_OK(&m) && static_tiles && nTl >= 8 && !(NSF2_ABL & 64)) ? 1 : 0;
+        const int eT1 = bc.eag ? nTl - 1 : -1, eT2 = bc.eag ? nTl - 2 : -1;
+        bc.ea[0] = EAG; bc.ea[1] = EAG + NSF2_PART_FLOATS;
+        {
+            const int4 t1 = *reinterpret_cast<const int4*>(DGT + 8 * (bc.eag ? nTl - 1 : 0));
+            const int4 t2 = *reinterpret_cast<const int4*>(DGT + 8 * (bc.eag ? nTl - 2 : 0));
+            bc.eg[0][0] = __builtin_amdgcn_readfirstlane(t1.x & 0xffff); bc.eg[0][1] = __builtin_amdgcn_readfirstlane(t1.y);
+            bc.eg[0][2] = __builtin_amdgcn_readfirstlane(t1.z); bc.eg[0][3] = __builtin_amdgcn_readfirstlane(t1.w);
+            bc.eg[1][0] = __builtin_amdgcn_readfirstlane(t2.x & 0xffff); bc.eg[1][1] = __builtin_amdgcn_readfirstlane(t2.y);
+            bc.eg[1][2] = __builtin_amdgcn_readfirstlane(t2.z); bc.eg[1][3] = __builtin_amdgcn_readfirstlane(t2.w);
+        }
         NsfBurstCarry carry;
         if (!static_tiles) {
             NB_FETCH((T - 1) * blk_bytes, 0, sA.p1, sA.p2, sA.xf, sA.b0, sA.b1, sA.b2)
@@ -656,7 +763,12 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                     bc.part = PART + ((T1 + spar) & 1) * NSF2_PART_FLOATS;
                     switch (T1) {
 #define CASE(K) case K: nsf_burst_tile<K>(bc, carry); break;
-                        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+#define CASE_E(K) case K: if (T1 == eT1) nsf_burst_tile<K, 3>(bc, carry); else if (T1 == eT2) nsf_burst_tile<K, 2>(bc, carry); \
+                          else nsf_burst_tile<K>(bc, carry); break;
+#define CASE_J(K) case K: if (bc.eag) nsf_burst_tile<K, 0, true>(bc, carry); else nsf_burst_tile<K>(bc, carry); break;
+                        CASE(1) CASE_J(2) CASE_J(3) CASE_J(4) CASE(5) CASE_E(6) CASE_E(7) CASE_E(8) CASE_E(9) CASE_E(10)
+#undef CASE_J
+#undef CASE_E
 #undef CASE
                         default: break;
                     }
