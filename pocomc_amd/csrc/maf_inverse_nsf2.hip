@@ -671,7 +671,7 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
         bc.nT = nT; bc.nXT = nXT; bc.D = D; bc.lane = lane; bc.vo_lane = vo_lane; bc.vo_T = vo_T; bc.vo_q = vo_q;
         bc.H0 = H0; bc.H1 = H1; bc.H2 = H2;
         // eager partials of the last two live tiles (NSF2_EAGER_OK)
-        bc.eag = (NSF2_EAGER_OK(&m) && static_tiles && nTl >= 8 && !(NSF2_ABL & 64)) ? 1 : 0;
+        bc.eag = (NSF2_EAGER_OK(&m) && static_tiles && nTl >= 8 && !(NSF2_ABL & 64) && !(m.reserved & 1)) ? 1 : 0;   // (reserved bit 0: launch_nsf2, PMC_NSF2_EAGER=0)
         const int eT1 = bc.eag ? nTl - 1 : -1, eT2 = bc.eag ? nTl - 2 : -1;
         bc.ea[0] = EAG; bc.ea[1] = EAG + NSF2_PART_FLOATS;
         {
@@ -970,6 +970,12 @@ static int launch_nsf2(const ProposeArgs* pa, const pmc_maf_t* m, const float* z
     const size_t lds = (size_t)NSF2_LDS_FLOATS(m) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     const ProposeArgs none{};
+    // PMC_NSF2_EAGER=0: the burst wave's left-looking schedule without the eager partials (the two must agree bit for bit:
+    // every partial receives its K tiles in ascending order either way; tests/test_gpu_flow.py)
+    const char* ev = getenv("PMC_NSF2_EAGER");           // (read per launch: a test flips it inside one process)
+    const int eager = ev ? atoi(ev) : 1;
+    pmc_maf_t mk = *m;
+    mk.reserved = eager ? 0 : 1;
 #define LAUNCHN(FMV)                                                                                              \
     {                                                                                                             \
         if (lds > 48 * 1024) {                                                                                    \
@@ -977,7 +983,7 @@ static int launch_nsf2(const ProposeArgs* pa, const pmc_maf_t* m, const float* z
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
             if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_inverse_nsf2_kernel)");          \
         }                                                                                                         \
-        hipLaunchKernelGGL(maf_inverse_nsf2_kernel<FMV>, dim3((unsigned)((n + 15) / 16)), dim3(128), lds, stream, *m, z, x, \
+        hipLaunchKernelGGL(maf_inverse_nsf2_kernel<FMV>, dim3((unsigned)((n + 15) / 16)), dim3(128), lds, stream, mk, z, x, \
                            ladj, n, pa ? pa->prof : (long long*)nullptr, pa ? *pa : none);                        \
     }
     if (pa && pa->prof) LAUNCHN(-1)

@@ -309,6 +309,24 @@ def test_nsf_float32_evaluations_against_the_float64_yardstick(D, T):
     f.inverse_algo = 0
 
 
+@pytest.mark.parametrize("D,T,n", [(32, 3, 300), (32, 6, 33), (33, 2, 100), (30, 2, 64), (40, 2, 17)])    # 9, 9, 8, 11, 10 hidden tiles
+def test_eager_partials_of_the_spline_sweep_change_no_bit(D, T, n, monkeypatch):
+    """The burst wave of the two-wave spline sweep forms the output partials of the last two hidden tiles early (steps 2-4,
+    csrc/maf_inverse_nsf2.hip: NSF2_EAGER_OK -- flows of >= 8 hidden tiles); PMC_NSF2_EAGER=0 keeps the left-looking schedule.
+    Every partial receives its K tiles in ascending order either way: identical results, plain and fused launches alike."""
+    f, o = make_nsf(D, T)
+    assert f.spec.device_meta()[7] >= 8, "the shape does not reach the eager path"
+    z = (np.random.default_rng(3 * n + D).normal(size=(n, D)) * 1.5).astype(np.float32)
+    f.inverse_algo = 7
+    xe, le = [t.numpy() for t in f.inverse(torch.from_numpy(z))]
+    monkeypatch.setenv("PMC_NSF2_EAGER", "0")
+    xl, ll = [t.numpy() for t in f.inverse(torch.from_numpy(z))]
+    np.testing.assert_array_equal(xe, xl)
+    np.testing.assert_array_equal(le, ll)
+    xo, lo = o.inverse(z)
+    close_rel(xe, xo, NSF_INV, "nsf x, eager partials")
+
+
 def test_spline_sweeps_on_random_flow_shapes():
     """Random spline flows (D <= 64, T, hidden, n): the lone-wave and the two-wave sweep (static burst tiles up to 11 live
     hidden tiles, streamed above) agree to float32 rounding and follow the D-pass inverse on the device."""
