@@ -9,11 +9,14 @@
 //   * CHAIN wave: per degree group the three hidden hops on transposed accumulators (maf_chain_rot.h: one MFMA per
 //     layer and quad), its share of the NEXT tile's hidden pre-activations (right-looking: accN1 / accN2 / a0N), the
 //     part of the rank's 23 parameters that comes from the previous and the own hidden tile (8 + 2 (quads so far)
-//     MFMAs, fragments requested one group ahead), the exchange through a 2 KB LDS panel and the spline solve;
+//     MFMAs, fragments requested one group ahead; round 4: all of it but the group's own quads is formed in the slots
+//     of the PREVIOUS rank's spline solve, see nsf_group), the exchange through a 2 KB LDS panel and the spline solve;
 //   * BURST wave, a whole tile ahead: the hidden layers' left-looking products against tiles <= Tt-2 (as in tri5: f0c
 //     against x, f1 / f2 against h0 / h1, into transposed staging) AND, for each of the tile's ranks, bias + the two
 //     output tiles against h2 tiles <= Tt-2 (into a staged partial the chain's accumulators start from: both waves hold
 //     a 16 x 16 product in the same lane layout, so staging is one 16-byte write and read per lane at the same address).
+//     Round 4: the output partials of the last two live tiles start at steps 2 - 4 (eager partials, NSF2_EAGER_OK): the two
+//     wavefronts are within 10 % of each other at every barrier (scripts/profile_nsf2_tiles.py).
 // One LDS-only barrier per tile: E(Tt) = "tile Tt is final, the staging of tile Tt+1 is complete".
 #include <stdlib.h>
 #include "maf_chain_rot.h"
