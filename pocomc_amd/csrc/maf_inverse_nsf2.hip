@@ -259,6 +259,7 @@ struct NsfBurstCtx {
     const float *X, *H0, *H1, *H2;
     float *stg, *part;
     int g[4], gn;                  // the ranks of this tile's groups; of the next tile's first group
+    long long* ts;                 // (measurement only, NSF2_TILE_STAMPS: where this tile's section stamps go, or null)
     int eag;                       // eager partials on: eg[0] / ea[0]: the ranks / the partial buffer of the last live tile, [1]: of the one before
     int eg[2][4];
     float* ea[2];
@@ -319,6 +320,32 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
     // one rank: bias (or, KS > 0, what the eager steps left) + the two output tiles against h2 tiles KS .. NK-1; `side(i)`:
     // the caller's loads for the shadow of K step i (steps 0 .. KS-1 have no products: their loads go first)
     float* const eacc = c.ea[KS == 3 ? 0 : 1];
+    // The tile's loads that have no K step of their own -- the ranks' biases, the layer-0 fragments, the hidden layers'
+    // biases -- cost ~60 cycles apiece as blocks between the ranks (19 of them: ~1.1 k of a tile's ~9 k cycles) and nothing in
+    // the shadow of an MFMA: with SH = NK - KS >= 1 K steps per rank they ride in the ranks' first steps, each at least one
+    // rank ahead of its use (the second rank's bias: in the first rank's first step); `xload(r, k)`: request k of rank r's list.
+    constexpr int SH = NK - KS;
+    auto xcount = [&](const int r) { return KS > 0 ? (r == 1 ? 2 : (r == 2 ? 5 : 0)) : (r == 0 ? 4 : (r == 1 ? 4 : (r == 2 ? 5 : 0))); };
+    auto xload = [&](const int r, const int k) {
+        if (k >= xcount(r)) return;
+        auto bias_half = [&](const int g, const int half) {
+            const int so = c.tb + c.oB3I + (g < c.D ? g : 0) * 128 + 64 * half, vo = g < c.D ? c.vo_q : NSF2_OOB;
+            return bload4(c.rs, vo, so);
+        };
+        auto xfk = [&](const int i) { return bload4(c.rs, i < c.nXT ? c.vo_T : NSF2_OOB, c.tb + c.oF0C + (T1 * c.nXT + i) * 1024); };
+        auto hbk = [&](const int j) { return bload4(c.rs, c.vo_q, c.tb + (j == 0 ? c.oB0T : (j == 1 ? c.oB1T : c.oB2T)) + 64 * T1); };
+        if (KS == 0) {
+            if (r == 0) { if (k == 0) bb0 = bias_half(c.g[1], 0); else if (k == 1) bb1 = bias_half(c.g[1], 1);
+                          else if (k == 2) ba0 = bias_half(c.g[2], 0); else ba1 = bias_half(c.g[2], 1); }
+            else if (r == 1) { if (k == 0) bb0 = bias_half(c.g[3], 0); else if (k == 1) bb1 = bias_half(c.g[3], 1);
+                               else xf[k - 2] = xfk(k - 2); }
+            else if (r == 2) { if (k < 2) xf[2 + k] = xfk(2 + k); else if (k == 2) hb0 = hbk(0); else if (k == 3) hb1 = hbk(1); else hb2 = hbk(2); }
+        } else {
+            if (r == 1) xf[k] = xfk(k);
+            else if (r == 2) { if (k < 2) xf[2 + k] = xfk(2 + k); else if (k == 2) hb0 = hbk(0); else if (k == 3) hb1 = hbk(1); else hb2 = hbk(2); }
+        }
+    };
+    const float4 bfirst = *reinterpret_cast<const float4*>(c.H2 + (KS << 8) + (lane << 2));
     auto rank = [&](const int r, const float4* F0, const float4* F1, const float4& B0, const float4& B1, float* d, auto&& side) {
         f32x4 o0, o1;
         if constexpr (KS > 0) {
@@ -330,8 +357,9 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
 #pragma unroll
         for (int i = 0; i < KS; ++i) side(i);
         // (the next K step's activations are requested before this step's MFMAs: issued behind them, an LDS read showed
-        //  ~50 cycles of its latency at every step -- 37 steps in the last tile of a nine-tile flow)
-        float4 bnx = *reinterpret_cast<const float4*>(c.H2 + (KS << 8) + (lane << 2));
+        //  ~50 cycles of its latency at every step -- 37 steps in the last tile of a nine-tile flow; the first step's
+        //  tile is the same for the four ranks: read once per tile)
+        float4 bnx = bfirst;
 #pragma unroll
         for (int i = KS; i < NK; ++i) {
             const float4 b = bnx;
@@ -345,6 +373,11 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
             side(i);
 #pragma unroll
             for (int l = 0; l < ELPS; ++l) eload((r * NK + i) * ELPS + l);
+            if constexpr (SH > 0) {
+                const int nx = xcount(r), lpr = (nx + SH - 1) / SH;
+#pragma unroll
+                for (int l = 0; l < 5; ++l) if (l < lpr) xload(r, (i - KS) * lpr + l);
+            }
             CHAIN_FENCE();
         }
         *reinterpret_cast<float4*>(d + (lane << 2)) = make_float4(o0[0], o0[1], o0[2], o0[3]);
@@ -357,22 +390,30 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
             if (!(NSF2_ABL & 8)) { N0[i] = bload4(c.rs, vo, so + i * 1024); N1[i] = bload4(c.rs, vo, so + (c.nT + i) * 1024); }
         };
     };
-    // ---- (1) output partials
-    obias(c.g[1], bb0, bb1);
+#define NSF_BSTAMP(K) if (c.ts && lane == 0) c.ts[K] = clock64();
+    NSF_BSTAMP(0)
+    // ---- (1) output partials (SH == 0: a tile without K steps requests as blocks; an eager tile's ranks start from their
+    // partials: no biases)
+    if constexpr (SH == 0 && KS == 0) obias(c.g[1], bb0, bb1);
     rank(0, carry.f0, carry.f1, carry.b0, carry.b1, c.part, fetch_into(c.g[1], fb0, fb1));
-    obias(c.g[2], ba0, ba1);
+    if constexpr (SH == 0 && KS == 0) obias(c.g[2], ba0, ba1);
     rank(1, fb0, fb1, bb0, bb1, c.part + 512, fetch_into(c.g[2], fa0, fa1));
-    obias(c.g[3], bb0, bb1);
+    if constexpr (SH == 0) {
+        if constexpr (KS == 0) obias(c.g[3], bb0, bb1);
 #pragma unroll
-    for (int i = 0; i < NSF2_PX; ++i) xf[i] = bload4(c.rs, i < c.nXT ? c.vo_T : NSF2_OOB, c.tb + c.oF0C + (T1 * c.nXT + i) * 1024);
+        for (int i = 0; i < NSF2_PX; ++i) xf[i] = bload4(c.rs, i < c.nXT ? c.vo_T : NSF2_OOB, c.tb + c.oF0C + (T1 * c.nXT + i) * 1024);
+    }
     rank(2, fa0, fa1, ba0, ba1, c.part + 1024, fetch_into(c.g[3], fb0, fb1));
-    hb0 = bload4(c.rs, c.vo_q, c.tb + c.oB0T + 64 * T1);
-    hb1 = bload4(c.rs, c.vo_q, c.tb + c.oB1T + 64 * T1);
-    hb2 = bload4(c.rs, c.vo_q, c.tb + c.oB2T + 64 * T1);
+    if constexpr (SH == 0) {
+        hb0 = bload4(c.rs, c.vo_q, c.tb + c.oB0T + 64 * T1);
+        hb1 = bload4(c.rs, c.vo_q, c.tb + c.oB1T + 64 * T1);
+        hb2 = bload4(c.rs, c.vo_q, c.tb + c.oB2T + 64 * T1);
+    }
     rank(3, fb0, fb1, bb0, bb1, c.part + 1536, [&](const int i) {
         hp1[i] = bload4(c.rs, c.vo_T, soH1 + i * 1024);
         hp2[i] = bload4(c.rs, c.vo_T, soH2 + i * 1024);
     });
+    NSF_BSTAMP(1)
     // ---- (2) hidden layers against the final tiles; the next tile's first rank requested in the shadows
     f32x4 a0 = as_acc(hb0), a1 = as_acc(hb1), a2 = as_acc(hb2);
     const int soN = obase(c.gn), voN = ovo(c.gn);
@@ -391,12 +432,19 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
             a1 = MFMA(hp1[i].w, b1.w, a1); a2 = MFMA(hp2[i].w, b2.w, a2);
         }
         if (!(NSF2_ABL & 8)) { carry.f0[i] = bload4(c.rs, voN, soN + i * 1024); carry.f1[i] = bload4(c.rs, voN, soN + (c.nT + i) * 1024); }
+        if (i == 0) obias(c.gn, carry.b0, carry.b1);                               // (the next tile's first rank: its bias ...
+        if (i == NK - 1 && NK < NN && !(NSF2_ABL & 8)) {                            //  ... and its fragments against this tile's h2)
+            carry.f0[NK] = bload4(c.rs, voN, soN + NK * 1024); carry.f1[NK] = bload4(c.rs, voN, soN + (c.nT + NK) * 1024);
+        }
         CHAIN_FENCE();
     }
+    if constexpr (NK == 0) {
 #pragma unroll
-    for (int i = NK; i < NN; ++i)
-        if (!(NSF2_ABL & 8)) { carry.f0[i] = bload4(c.rs, voN, soN + i * 1024); carry.f1[i] = bload4(c.rs, voN, soN + (c.nT + i) * 1024); }
-    obias(c.gn, carry.b0, carry.b1);
+        for (int i = NK; i < NN; ++i)
+            if (!(NSF2_ABL & 8)) { carry.f0[i] = bload4(c.rs, voN, soN + i * 1024); carry.f1[i] = bload4(c.rs, voN, soN + (c.nT + i) * 1024); }
+        obias(c.gn, carry.b0, carry.b1);
+    }
+    NSF_BSTAMP(2)
     // layer 0 against the ranks of tiles <= T1-2 (the chain adds the ranks of tile T1-1 itself)
 #pragma unroll
     for (int i = 0; i < NSF2_PX; ++i) {
@@ -409,6 +457,7 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
     *reinterpret_cast<float4*>(c.stg + (lane << 2)) = make_float4(a0[0], a0[1], a0[2], a0[3]);
     *reinterpret_cast<float4*>(c.stg + 256 + (lane << 2)) = make_float4(a1[0], a1[1], a1[2], a1[3]);
     *reinterpret_cast<float4*>(c.stg + 512 + (lane << 2)) = make_float4(a2[0], a2[1], a2[2], a2[3]);
+    NSF_BSTAMP(3)
     // ---- (3) this step's eager jobs: read the partials (all of them up front: one LDS latency), multiply, write back
     if constexpr (NJ > 0) {
         const float4 hk0 = *reinterpret_cast<const float4*>(c.H2 + (JK0 << 8) + (lane << 2));
@@ -672,7 +721,7 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
         NsfBurstCtx bc;
         bc.rs = rs; bc.oF1 = oF1; bc.oF2 = oF2; bc.oF0C = oF0C; bc.oB0T = oB0T; bc.oB1T = oB1T; bc.oB2T = oB2T; bc.oF3I = oF3I; bc.oB3I = oB3I;
         bc.nT = nT; bc.nXT = nXT; bc.D = D; bc.lane = lane; bc.vo_lane = vo_lane; bc.vo_T = vo_T; bc.vo_q = vo_q;
-        bc.H0 = H0; bc.H1 = H1; bc.H2 = H2;
+        bc.H0 = H0; bc.H1 = H1; bc.H2 = H2; bc.ts = nullptr;
         // eager partials of the last two live tiles (NSF2_EAGER_OK)
         bc.eag = (NSF2_EAGER_OK(&m) && static_tiles && nTl >= 8 && !(NSF2_ABL & 64) && !(m.reserved & 1)) ? 1 : 0;   // (reserved bit 0: launch_nsf2, PMC_NSF2_EAGER=0)
         const int eT1 = bc.eag ? nTl - 1 : -1, eT2 = bc.eag ? nTl - 2 : -1;
@@ -764,6 +813,9 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                     bc.gn = T1 + 1 < nTl ? (__builtin_amdgcn_readfirstlane(DGT[8 * (T1 + 1)]) & 0xffff) : D;
                     bc.stg = STG + ((T1 + spar) & 1) * NSF2_STAGE_FLOATS;
                     bc.part = PART + ((T1 + spar) & 1) * NSF2_PART_FLOATS;
+#ifdef NSF2_TILE_STAMPS
+                    bc.ts = ts ? ts + 4 * T * (nTl + 1) + 4 * bar_no : nullptr;       // (behind the barrier stamps: four section stamps per tile)
+#endif
                     switch (T1) {
 #define CASE(K) case K: nsf_burst_tile<K>(bc, carry); break;
 #define CASE_E(K) case K: if (T1 == eT1) nsf_burst_tile<K, 3>(bc, carry); else if (T1 == eT2) nsf_burst_tile<K, 2>(bc, carry); \

@@ -19,7 +19,7 @@ x = torch.empty_like(z); l = torch.empty(n, device="cuda")
 T = f.spec.n_transforms
 nTl = int(f.spec.device_meta()[7])
 nb = T * (nTl + 1)
-prof = torch.zeros(16 + 4 * nb + 64, dtype=torch.int64, device="cuda")
+prof = torch.zeros(16 + 8 * nb + 64, dtype=torch.int64, device="cuda")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for _ in range(3):
     _lib.check(fn(C.byref(f._desc), _lib.ptr(z), _lib.ptr(x), _lib.ptr(l), n, _lib.ptr(prof), _lib.stream_handle()))
@@ -29,7 +29,9 @@ for _ in range(20):
     _lib.check(fn(C.byref(f._desc), _lib.ptr(z), _lib.ptr(x), _lib.ptr(l), n, _lib.ptr(prof), _lib.stream_handle()))
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / 20 * 1e3
-p = prof.cpu().numpy()[16:16 + 4 * nb].reshape(nb, 4)
+pall = prof.cpu().numpy()
+p = pall[16:16 + 4 * nb].reshape(nb, 4)
+sec = pall[16 + 4 * nb:16 + 8 * nb].reshape(nb, 4)          # burst wave, per barrier: start of outputs | hidden | layer 0 | eager
 t0 = p[0].min()
 span = p[-1].max() - t0
 print(f"D={D} {name} n={n}: {T} transforms x {nTl} live tiles; launch {us:.1f} us; first to last barrier of workgroup 0: {span} cycles")
@@ -43,3 +45,10 @@ for b in range(nb):
     tt, e = divmod(b, nTl + 1)
     print(f"  t{T - 1 - tt} E({e - 1:2d})   {row[0]:7d} {row[1]:6d} | {row[2]:7d} {row[3]:6d}")
 print(f"  sum       {int(tot[0]):7d} {int(tot[1]):6d} | {int(tot[2]):7d} {int(tot[3]):6d}")
+print(" burst wave by section (cycles): before the tile body | output partials | hidden layers | layer 0 + staging | eager jobs + to the barrier")
+for b in range(1, nb):
+    if sec[b][0] == 0:
+        continue
+    tt, e = divmod(b, nTl + 1)
+    s0, s1, s2, s3 = sec[b]
+    print(f"  t{T - 1 - tt} E({e - 1:2d})   {s0 - p[b - 1][3]:6d} {s1 - s0:7d} {s2 - s1:7d} {s3 - s2:7d} {p[b][2] - s3:7d}")
