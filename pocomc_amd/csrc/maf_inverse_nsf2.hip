@@ -252,52 +252,77 @@ __device__ __forceinline__ void nsf_group(NsfChain& s, const NsfHid& f, NsfOut (
 // requested that is not used.  So the next tile's hidden operands are requested in the shadows of this tile's hidden
 // products, and rank r + 1's output fragments in the shadows of rank r's output products.
 struct NsfBurstSet { float4 p1[NSF2_PK], p2[NSF2_PK], xf[NSF2_PX], b0, b1, b2; };       // (the streamed path's operand sets)
-struct NsfBurstCarry { float4 f0[NSF2_PK], f1[NSF2_PK], b0, b1; };                        // the next tile's first rank: fragments, bias rows
+// what crosses a tile boundary on the burst wave: the next tile's fragment sets of its first two K steps and its biases --
+// a set = the four ranks' first output tiles (widths | heights) + the two rank PAIRS' shared derivative tiles
+struct NsfBurstCarry { float4 f[2][6], b[6]; };
 struct NsfBurstCtx {
     __amdgpu_buffer_rsrc_t rs;
     int tb, oF1, oF2, oF0C, oB0T, oB1T, oB2T, oF3I, oB3I, nT, nXT, D, lane, vo_lane, vo_T, vo_q;
     const float *X, *H0, *H1, *H2;
     float *stg, *part;
-    int g[4], gn;                  // the ranks of this tile's groups; of the next tile's first group
+    int g[4], gnx[4], ksn;         // the ranks of this tile's groups; of the next tile's groups, and the first K step of its own products
     long long* ts;                 // (measurement only, NSF2_TILE_STAMPS: where this tile's section stamps go, or null)
     int eag;                       // eager partials on: eg[0] / ea[0]: the ranks / the partial buffer of the last live tile, [1]: of the one before
     int eg[2][4];
     float* ea[2];
 };
 
-// Order inside the tile: the four ranks' output partials first (the first rank's fragments came with the previous tile,
-// rank r + 1's are requested in the shadows of rank r's products, the tile's hidden operands in the shadows of the last
-// rank's), then the hidden layers (the next tile's first-rank fragments in their shadows).  Only those cross a tile
-// boundary (in `carry`); everything else is local to the dispatched case.
+// THE OUTPUT PARTIALS, K-OUTER (round 4).  A rank's 23 parameters are two 16-row output tiles, the second one carrying 7
+// rows (the derivatives): per rank and K tile the burst wave spent 8 MFMAs, 2 fragment loads and one LDS read of h2 on 23
+// useful rows of 32, and it is at the matrix pipe's limit on the late tiles.  The derivative rows of TWO ranks share one
+// tile now -- rows 0-7 from the pair's first rank, rows 8-15 from its second: the same fragment records, addressed per
+// lane (the second rank's rows through an offset in the lane's VGPR; a padding rank's lanes out of range: zeros) --
+// so a tile's four ranks are 6 accumulators instead of 8, and the loop runs K tiles OUTERMOST with all six resident:
+// per K step one read of h2, 6 fragment loads and 24 MFMAs (was 4 x (1 + 2 + 8)), each accumulator's products in the
+// order they had (x, y, z, w of K ascending: the same bits).  The fragments of step j + 2 are requested in the shadows of
+// step j's MFMAs into a ring of three sets; the first two sets and the biases come with the previous tile (carry).  The
+// staged partials keep their layout: a pair's shared tile is stored twice, the second time with the wavefront's halves
+// swapped, so that the chain finds the second rank's derivative rows where it always read them.
 template <int T1, int KS = 0, bool EAG = false>
 __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCarry& carry) {
     constexpr int NK = T1 > 0 ? T1 - 1 : 0;          // final hidden tiles: 0 .. T1-2
-    constexpr int NN = T1;                           // the next tile's: 0 .. T1-1
     constexpr int NF = NK > 0 ? NK : 1;
-    static_assert(NN <= NSF2_PK, "carry too small");
-    static_assert(KS <= NK, "eager K tiles beyond the final ones");
-    const int lane = c.lane;
-    float4 fa0[NF], fa1[NF], fb0[NF], fb1[NF], ba0, ba1, bb0, bb1;
+    constexpr int SH = NK - KS;                      // K steps of this tile's own products
+    static_assert(T1 <= NSF2_PK && KS <= NK, "tile beyond the static path");
+    const int lane = c.lane, q = lane >> 4;
     float4 hp1[NF], hp2[NF], xf[NSF2_PX], hb0, hb1, hb2;
-    auto obase = [&](const int g) { return c.tb + c.oF3I + (g < c.D ? g : 0) * 2 * c.nT * 1024; };
+    const int stride = 2 * c.nT * 1024;              // bytes between two ranks' fragment blocks
+    auto obase = [&](const int tb, const int g) { return tb + c.oF3I + (g < c.D ? g : 0) * stride; };
     auto ovo = [&](const int g) { return g < c.D ? c.vo_lane : NSF2_OOB; };
-    auto obias = [&](const int g, float4& B0, float4& B1) {
-        const int so = c.tb + c.oB3I + (g < c.D ? g : 0) * 128, vo = g < c.D ? c.vo_q : NSF2_OOB;
-        B0 = bload4(c.rs, vo, so);
-        B1 = bload4(c.rs, vo, so + 64);
+    // lane offset of a pair's shared derivative fragment (rows 0-7: rank ga, rows 8-15: rank gb), relative to ga's block
+    auto pair_vo = [&](const int ga, const int gb) {
+        const int i = lane & 15, base = ((q << 4) + (i & 7)) << 4;
+        return i < 8 ? (ga < c.D ? base : NSF2_OOB) : (gb < c.D ? base + (gb - ga) * stride : NSF2_OOB);
     };
+    // ... and of its shared bias rows (lanes q < 2: ga's derivative rows 4q .., lanes q >= 2: gb's rows 4 (q - 2) ..)
+    auto pair_bvo = [&](const int ga, const int gb) {
+        return q < 2 ? (ga < c.D ? (q << 4) : NSF2_OOB) : (gb < c.D ? ((q - 2) << 4) + (gb - ga) * 128 : NSF2_OOB);
+    };
+    // bias k of a tile (0-3: the ranks' first halves, 4 / 5: the pairs' shared second halves)
+    auto bias = [&](const int tb, const int (&g)[4], const int bv0, const int bv1, const int k) {
+        if (k < 4) return bload4(c.rs, g[k] < c.D ? c.vo_q : NSF2_OOB, tb + c.oB3I + (g[k] < c.D ? g[k] : 0) * 128);
+        const int ga = g[k == 4 ? 0 : 2];
+        return bload4(c.rs, k == 4 ? bv0 : bv1, tb + c.oB3I + (ga < c.D ? ga : 0) * 128 + 64);
+    };
+    const int pv0 = pair_vo(c.g[0], c.g[1]), pv1 = pair_vo(c.g[2], c.g[3]);
+    int fb_[6], fvo_[6];                              // this tile's fragment blocks: K tile 0 of fragment k of a set
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int g = c.g[k < 4 ? k : (k == 4 ? 0 : 2)];
+        fb_[k] = obase(c.tb, g) + (k < 4 ? 0 : c.nT) * 1024;
+        fvo_[k] = k < 4 ? ovo(g) : (k == 4 ? pv0 : pv1);
+    }
     // ---- (0) eager partials of the last two live tiles (EAG; steps 2, 3, 4): this step's jobs are job 0 = the last tile's
     // ranks against h2 tile T1 - 2 and, from step 3, job 1 = the ranks of the tile before against h2 tile T1 - 3; step 2 is the
     // first touch of the last tile's partials, step 3 of the other tile's (they start from the ranks' biases).  Their
     // fragments (and biases) are requested in the shadows of the regular products' MFMAs, `eload(k)`, k = 0 .. 4 EPR - 1,
-    // and multiplied at the end of the tile.
+    // and multiplied at the end of the tile.  (The eager partials keep one pair of tiles per rank.)
     constexpr int NJ = !EAG ? 0 : (T1 == 2 ? 1 : ((T1 == 3 || T1 == 4) ? 2 : 0));
     static_assert(!EAG || NJ > 0, "eager work exists at steps 2, 3, 4 only");
     constexpr int NJ1 = NJ > 0 ? NJ : 1;
     constexpr int JK0 = T1 - 2, JK1 = T1 - 3;
     constexpr bool FIRST0 = T1 == 2, FIRST1 = T1 == 3;
     constexpr int EPR = 2 * NJ + ((FIRST0 || FIRST1) ? 2 : 0);        // requests per rank
-    constexpr int ELPS = (NJ > 0 && NK > 0) ? (4 * EPR + 4 * NK - 1) / (4 * NK) : 0;      // per shadow of the 4 NK regular K steps
     float4 ef0[NJ1][4], ef1[NJ1][4], eb0[4], eb1[4];
     auto eload = [&](const int k) {
         if constexpr (NJ > 0) {
@@ -306,8 +331,8 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
             const int fb = FIRST0 ? 0 : 1;                           // the tile whose partials are touched first at this step
             if (w < 2 * NJ) {
                 const int j = w >> 1, g = c.eg[j][r], K = j == 0 ? JK0 : JK1;
-                if ((w & 1) == 0) ef0[j][r] = bload4(c.rs, ovo(g), obase(g) + K * 1024);
-                else ef1[j][r] = bload4(c.rs, ovo(g), obase(g) + (c.nT + K) * 1024);
+                if ((w & 1) == 0) ef0[j][r] = bload4(c.rs, ovo(g), obase(c.tb, g) + K * 1024);
+                else ef1[j][r] = bload4(c.rs, ovo(g), obase(c.tb, g) + (c.nT + K) * 1024);
             } else {
                 const int g = c.eg[fb][r];
                 const int so = c.tb + c.oB3I + (g < c.D ? g : 0) * 128, vo = g < c.D ? c.vo_q : NSF2_OOB;
@@ -317,107 +342,115 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
         }
     };
     const int soH1 = c.tb + c.oF1 + T1 * c.nT * 1024, soH2 = c.tb + c.oF2 + T1 * c.nT * 1024;
-    // one rank: bias (or, KS > 0, what the eager steps left) + the two output tiles against h2 tiles KS .. NK-1; `side(i)`:
-    // the caller's loads for the shadow of K step i (steps 0 .. KS-1 have no products: their loads go first)
-    float* const eacc = c.ea[KS == 3 ? 0 : 1];
-    // The tile's loads that have no K step of their own -- the ranks' biases, the layer-0 fragments, the hidden layers'
-    // biases -- cost ~60 cycles apiece as blocks between the ranks (19 of them: ~1.1 k of a tile's ~9 k cycles) and nothing in
-    // the shadow of an MFMA: with SH = NK - KS >= 1 K steps per rank they ride in the ranks' first steps, each at least one
-    // rank ahead of its use (the second rank's bias: in the first rank's first step); `xload(r, k)`: request k of rank r's list.
-    constexpr int SH = NK - KS;
-    auto xcount = [&](const int r) { return KS > 0 ? (r == 1 ? 2 : (r == 2 ? 5 : 0)) : (r == 0 ? 4 : (r == 1 ? 4 : (r == 2 ? 5 : 0))); };
-    auto xload = [&](const int r, const int k) {
-        if (k >= xcount(r)) return;
-        auto bias_half = [&](const int g, const int half) {
-            const int so = c.tb + c.oB3I + (g < c.D ? g : 0) * 128 + 64 * half, vo = g < c.D ? c.vo_q : NSF2_OOB;
-            return bload4(c.rs, vo, so);
-        };
-        auto xfk = [&](const int i) { return bload4(c.rs, i < c.nXT ? c.vo_T : NSF2_OOB, c.tb + c.oF0C + (T1 * c.nXT + i) * 1024); };
-        auto hbk = [&](const int j) { return bload4(c.rs, c.vo_q, c.tb + (j == 0 ? c.oB0T : (j == 1 ? c.oB1T : c.oB2T)) + 64 * T1); };
-        if (KS == 0) {
-            if (r == 0) { if (k == 0) bb0 = bias_half(c.g[1], 0); else if (k == 1) bb1 = bias_half(c.g[1], 1);
-                          else if (k == 2) ba0 = bias_half(c.g[2], 0); else ba1 = bias_half(c.g[2], 1); }
-            else if (r == 1) { if (k == 0) bb0 = bias_half(c.g[3], 0); else if (k == 1) bb1 = bias_half(c.g[3], 1);
-                               else xf[k - 2] = xfk(k - 2); }
-            else if (r == 2) { if (k < 2) xf[2 + k] = xfk(2 + k); else if (k == 2) hb0 = hbk(0); else if (k == 3) hb1 = hbk(1); else hb2 = hbk(2); }
-        } else {
-            if (r == 1) xf[k] = xfk(k);
-            else if (r == 2) { if (k < 2) xf[2 + k] = xfk(2 + k); else if (k == 2) hb0 = hbk(0); else if (k == 3) hb1 = hbk(1); else hb2 = hbk(2); }
-        }
-    };
-    const float4 bfirst = *reinterpret_cast<const float4*>(c.H2 + (KS << 8) + (lane << 2));
-    auto rank = [&](const int r, const float4* F0, const float4* F1, const float4& B0, const float4& B1, float* d, auto&& side) {
-        f32x4 o0, o1;
-        if constexpr (KS > 0) {
-            o0 = as_acc(*reinterpret_cast<const float4*>(eacc + (2 * r) * 256 + (lane << 2)));
-            o1 = as_acc(*reinterpret_cast<const float4*>(eacc + (2 * r + 1) * 256 + (lane << 2)));
-        } else {
-            o0 = as_acc(B0); o1 = as_acc(B1);
-        }
-#pragma unroll
-        for (int i = 0; i < KS; ++i) side(i);
-        // (the next K step's activations are requested before this step's MFMAs: issued behind them, an LDS read showed
-        //  ~50 cycles of its latency at every step -- 37 steps in the last tile of a nine-tile flow; the first step's
-        //  tile is the same for the four ranks: read once per tile)
-        float4 bnx = bfirst;
-#pragma unroll
-        for (int i = KS; i < NK; ++i) {
-            const float4 b = bnx;
-            if (i + 1 < NK) bnx = *reinterpret_cast<const float4*>(c.H2 + ((i + 1) << 8) + (lane << 2));
-            if (!(NSF2_ABL & 4)) {
-                o0 = MFMA(F0[i].x, b.x, o0); o1 = MFMA(F1[i].x, b.x, o1);
-                o0 = MFMA(F0[i].y, b.y, o0); o1 = MFMA(F1[i].y, b.y, o1);
-                o0 = MFMA(F0[i].z, b.z, o0); o1 = MFMA(F1[i].z, b.z, o1);
-                o0 = MFMA(F0[i].w, b.w, o0); o1 = MFMA(F1[i].w, b.w, o1);
-            }
-            side(i);
-#pragma unroll
-            for (int l = 0; l < ELPS; ++l) eload((r * NK + i) * ELPS + l);
-            if constexpr (SH > 0) {
-                const int nx = xcount(r), lpr = (nx + SH - 1) / SH;
-#pragma unroll
-                for (int l = 0; l < 5; ++l) if (l < lpr) xload(r, (i - KS) * lpr + l);
-            }
-            CHAIN_FENCE();
-        }
-        *reinterpret_cast<float4*>(d + (lane << 2)) = make_float4(o0[0], o0[1], o0[2], o0[3]);
-        *reinterpret_cast<float4*>(d + 256 + (lane << 2)) = make_float4(o1[0], o1[1], o1[2], o1[3]);
-    };
-    auto fetch_into = [&](const int g, float4* N0, float4* N1) {
-        const int so = obase(g), vo = ovo(g);
-        return [=, &c](const int i) {
-            if (i < KS) return;                                                     // (that part of the rank came early)
-            if (!(NSF2_ABL & 8)) { N0[i] = bload4(c.rs, vo, so + i * 1024); N1[i] = bload4(c.rs, vo, so + (c.nT + i) * 1024); }
-        };
+    // the tile's other requests, in the shadows of the K steps (or as a block, SH == 0): the hidden layers' fragments and
+    // biases, the layer-0 fragments, the eager jobs' operands
+    constexpr int NXL = 2 * NK + NSF2_PX + 3 + 4 * EPR;
+    auto xload = [&](const int k) {
+        if (k < NK) hp1[k] = bload4(c.rs, c.vo_T, soH1 + k * 1024);
+        else if (k < 2 * NK) hp2[k - NK] = bload4(c.rs, c.vo_T, soH2 + (k - NK) * 1024);
+        else if (k < 2 * NK + NSF2_PX) { const int i = k - 2 * NK; xf[i] = bload4(c.rs, i < c.nXT ? c.vo_T : NSF2_OOB, c.tb + c.oF0C + (T1 * c.nXT + i) * 1024); }
+        else if (k == 2 * NK + NSF2_PX) hb0 = bload4(c.rs, c.vo_q, c.tb + c.oB0T + 64 * T1);
+        else if (k == 2 * NK + NSF2_PX + 1) hb1 = bload4(c.rs, c.vo_q, c.tb + c.oB1T + 64 * T1);
+        else if (k == 2 * NK + NSF2_PX + 2) hb2 = bload4(c.rs, c.vo_q, c.tb + c.oB2T + 64 * T1);
+        else if (k < NXL) eload(k - (2 * NK + NSF2_PX + 3));
     };
 #define NSF_BSTAMP(K) if (c.ts && lane == 0) c.ts[K] = clock64();
     NSF_BSTAMP(0)
-    // ---- (1) output partials (SH == 0: a tile without K steps requests as blocks; an eager tile's ranks start from their
-    // partials: no biases)
-    if constexpr (SH == 0 && KS == 0) obias(c.g[1], bb0, bb1);
-    rank(0, carry.f0, carry.f1, carry.b0, carry.b1, c.part, fetch_into(c.g[1], fb0, fb1));
-    if constexpr (SH == 0 && KS == 0) obias(c.g[2], ba0, ba1);
-    rank(1, fb0, fb1, bb0, bb1, c.part + 512, fetch_into(c.g[2], fa0, fa1));
-    if constexpr (SH == 0) {
-        if constexpr (KS == 0) obias(c.g[3], bb0, bb1);
+    // ---- (1) output partials: six accumulators, K tiles outermost
+    f32x4 o0[4], o1c[2];
+    if constexpr (KS > 0) {                                            // an eager tile starts from its partials
+        const float* ea = c.ea[KS == 3 ? 0 : 1];
 #pragma unroll
-        for (int i = 0; i < NSF2_PX; ++i) xf[i] = bload4(c.rs, i < c.nXT ? c.vo_T : NSF2_OOB, c.tb + c.oF0C + (T1 * c.nXT + i) * 1024);
+        for (int r = 0; r < 4; ++r) o0[r] = as_acc(*reinterpret_cast<const float4*>(ea + (2 * r) * 256 + (lane << 2)));
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int r = 2 * pr + (q >> 1), l2 = q < 2 ? lane : lane - 32;          // (the pair's second rank: its lanes q = 0, 1)
+            o1c[pr] = as_acc(*reinterpret_cast<const float4*>(ea + (2 * r + 1) * 256 + (l2 << 2)));
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o0[r] = as_acc(carry.b[r]);
+        o1c[0] = as_acc(carry.b[4]); o1c[1] = as_acc(carry.b[5]);
     }
-    rank(2, fa0, fa1, ba0, ba1, c.part + 1024, fetch_into(c.g[3], fb0, fb1));
+    float4 S[3][6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { S[0][k] = carry.f[0][k]; S[1][k] = carry.f[1][k]; }
     if constexpr (SH == 0) {
-        hb0 = bload4(c.rs, c.vo_q, c.tb + c.oB0T + 64 * T1);
-        hb1 = bload4(c.rs, c.vo_q, c.tb + c.oB1T + 64 * T1);
-        hb2 = bload4(c.rs, c.vo_q, c.tb + c.oB2T + 64 * T1);
+#pragma unroll
+        for (int k = 0; k < NXL; ++k) xload(k);
     }
-    rank(3, fb0, fb1, bb0, bb1, c.part + 1536, [&](const int i) {
-        hp1[i] = bload4(c.rs, c.vo_T, soH1 + i * 1024);
-        hp2[i] = bload4(c.rs, c.vo_T, soH2 + i * 1024);
+    float4 bnx = *reinterpret_cast<const float4*>(c.H2 + (KS << 8) + (lane << 2));
+    static_for<SH>([&](auto j_) {
+        constexpr int j = decltype(j_)::value, i = KS + j, cur = j % 3, nxt = (j + 2) % 3;
+        constexpr int SH1 = SH > 0 ? SH : 1;
+        constexpr int XPS = (NXL + SH1 - 1) / SH1;                     // other requests per step
+        const float4 b = bnx;
+        if constexpr (i + 1 < NK) bnx = *reinterpret_cast<const float4*>(c.H2 + ((i + 1) << 8) + (lane << 2));
+        auto ld = [&](const int k) {
+            if constexpr (j + 2 < SH) { if (!(NSF2_ABL & 8)) S[nxt][k] = bload4(c.rs, fvo_[k], fb_[k] + (i + 2) * 1024); }
+        };
+        auto xs = [&](const int part) {                                // this step's share of the other requests, in four parts
+#pragma unroll
+            for (int l = 0; l < XPS; ++l) if ((l & 3) == part) xload(j * XPS + l);
+        };
+        if (!(NSF2_ABL & 4)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o0[r] = MFMA(S[cur][r].x, b.x, o0[r]);
+            o1c[0] = MFMA(S[cur][4].x, b.x, o1c[0]); o1c[1] = MFMA(S[cur][5].x, b.x, o1c[1]);
+        }
+        ld(0); ld(1); xs(0);
+        if (!(NSF2_ABL & 4)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o0[r] = MFMA(S[cur][r].y, b.y, o0[r]);
+            o1c[0] = MFMA(S[cur][4].y, b.y, o1c[0]); o1c[1] = MFMA(S[cur][5].y, b.y, o1c[1]);
+        }
+        ld(2); ld(3); xs(1);
+        if (!(NSF2_ABL & 4)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o0[r] = MFMA(S[cur][r].z, b.z, o0[r]);
+            o1c[0] = MFMA(S[cur][4].z, b.z, o1c[0]); o1c[1] = MFMA(S[cur][5].z, b.z, o1c[1]);
+        }
+        ld(4); ld(5); xs(2);
+        if (!(NSF2_ABL & 4)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o0[r] = MFMA(S[cur][r].w, b.w, o0[r]);
+            o1c[0] = MFMA(S[cur][4].w, b.w, o1c[0]); o1c[1] = MFMA(S[cur][5].w, b.w, o1c[1]);
+        }
+        xs(3);
+        CHAIN_FENCE();
     });
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<float4*>(c.part + (2 * r) * 256 + (lane << 2)) = make_float4(o0[r][0], o0[r][1], o0[r][2], o0[r][3]);
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        const float4 v = make_float4(o1c[pr][0], o1c[pr][1], o1c[pr][2], o1c[pr][3]);
+        *reinterpret_cast<float4*>(c.part + (4 * pr + 1) * 256 + (lane << 2)) = v;                 // the pair's first rank
+        *reinterpret_cast<float4*>(c.part + (4 * pr + 3) * 256 + ((lane ^ 32) << 2)) = v;          // its second: halves swapped
+    }
     NSF_BSTAMP(1)
-    // ---- (2) hidden layers against the final tiles; the next tile's first rank requested in the shadows
+    // ---- (2) hidden layers against the final tiles; the next tile's first two fragment sets and its biases in the shadows
     f32x4 a0 = as_acc(hb0), a1 = as_acc(hb1), a2 = as_acc(hb2);
-    const int soN = obase(c.gn), voN = ovo(c.gn);
+    const int npv0 = pair_vo(c.gnx[0], c.gnx[1]), npv1 = pair_vo(c.gnx[2], c.gnx[3]);
+    const int nbv0 = pair_bvo(c.gnx[0], c.gnx[1]), nbv1 = pair_bvo(c.gnx[2], c.gnx[3]);
+    // the carry: the sets of the next tile's first NCS K steps (it has T1 of them less those its eager steps took) + six biases;
+    // block bases once per tile (a request is then one scalar add)
+    constexpr int NCS = T1 >= 2 ? 2 : T1, NCL = 6 * NCS + 6;
+    int nb_[6], nvo_[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int g = c.gnx[k < 4 ? k : (k == 4 ? 0 : 2)];
+        nb_[k] = obase(c.tb, g) + ((k < 4 ? 0 : c.nT) + c.ksn) * 1024;
+        nvo_[k] = k < 4 ? ovo(g) : (k == 4 ? npv0 : npv1);
+    }
+    auto cload = [&](const int k) {                                    // request k of NCL of the carry
+        if (NSF2_ABL & 8) return;
+        if (k < 6 * NCS) carry.f[k / 6][k % 6] = bload4(c.rs, nvo_[k % 6], nb_[k % 6] + (k / 6) * 1024);
+        else if (k < NCL) carry.b[k - 6 * NCS] = bias(c.tb, c.gnx, nbv0, nbv1, k - 6 * NCS);
+    };
     float4 b1n = *reinterpret_cast<const float4*>(c.H0 + (lane << 2)), b2n = *reinterpret_cast<const float4*>(c.H1 + (lane << 2));
+    constexpr int NK1 = NK > 0 ? NK : 1;
+    constexpr int CPS = (NCL + NK1 - 1) / NK1;
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
         const float4 b1 = b1n, b2 = b2n;
@@ -428,21 +461,20 @@ __device__ __forceinline__ void nsf_burst_tile(const NsfBurstCtx& c, NsfBurstCar
         if (!(NSF2_ABL & 32)) {
             a1 = MFMA(hp1[i].x, b1.x, a1); a2 = MFMA(hp2[i].x, b2.x, a2);
             a1 = MFMA(hp1[i].y, b1.y, a1); a2 = MFMA(hp2[i].y, b2.y, a2);
+        }
+#pragma unroll
+        for (int l = 0; l < CPS; ++l) if ((l & 1) == 0) cload(i * CPS + l);
+        if (!(NSF2_ABL & 32)) {
             a1 = MFMA(hp1[i].z, b1.z, a1); a2 = MFMA(hp2[i].z, b2.z, a2);
             a1 = MFMA(hp1[i].w, b1.w, a1); a2 = MFMA(hp2[i].w, b2.w, a2);
         }
-        if (!(NSF2_ABL & 8)) { carry.f0[i] = bload4(c.rs, voN, soN + i * 1024); carry.f1[i] = bload4(c.rs, voN, soN + (c.nT + i) * 1024); }
-        if (i == 0) obias(c.gn, carry.b0, carry.b1);                               // (the next tile's first rank: its bias ...
-        if (i == NK - 1 && NK < NN && !(NSF2_ABL & 8)) {                            //  ... and its fragments against this tile's h2)
-            carry.f0[NK] = bload4(c.rs, voN, soN + NK * 1024); carry.f1[NK] = bload4(c.rs, voN, soN + (c.nT + NK) * 1024);
-        }
+#pragma unroll
+        for (int l = 0; l < CPS; ++l) if ((l & 1) == 1) cload(i * CPS + l);
         CHAIN_FENCE();
     }
     if constexpr (NK == 0) {
 #pragma unroll
-        for (int i = NK; i < NN; ++i)
-            if (!(NSF2_ABL & 8)) { carry.f0[i] = bload4(c.rs, voN, soN + i * 1024); carry.f1[i] = bload4(c.rs, voN, soN + (c.nT + i) * 1024); }
-        obias(c.gn, carry.b0, carry.b1);
+        for (int k = 0; k < NCL; ++k) cload(k);
     }
     NSF_BSTAMP(2)
     // layer 0 against the ranks of tiles <= T1-2 (the chain adds the ranks of tile T1-1 itself)
@@ -743,15 +775,36 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
         int spar = 0;                                      // staging parity of the transform's first tile (the buffers alternate across transforms)
         // the static path's first tile of transform tt (biases only): staged while the chain still runs the LAST tile of the
         // transform before, so that at a transform boundary the chain solves rank 0 and goes on
+        // the tile after tile U - 1, as the carry sees it: its ranks and the first K step of its own products
+        int4 tnn;                                              // the table row `peek` read ahead (its latency passes behind a tile body)
+        auto peek = [&](const int U) { tnn = *reinterpret_cast<const int4*>(DGT + 8 * (U < nTl ? U : nT)); };     // (behind the last live tile: "no groups")
+        auto set_next = [&](const int U) {                     // (row U was peeked)
+            const int4 tn = tnn;
+            const bool lv = U < nTl;
+            bc.gnx[0] = lv ? (__builtin_amdgcn_readfirstlane(tn.x) & 0xffff) : D; bc.gnx[1] = lv ? __builtin_amdgcn_readfirstlane(tn.y) : D;
+            bc.gnx[2] = lv ? __builtin_amdgcn_readfirstlane(tn.z) : D; bc.gnx[3] = lv ? __builtin_amdgcn_readfirstlane(tn.w) : D;
+            bc.ksn = (bc.eag && U == eT1) ? 3 : ((bc.eag && U == eT2) ? 2 : 0);
+            peek(U + 1);
+        };
         auto first_tile = [&](const int tt, float* Xt, const int par) {
             const int4 tg = *reinterpret_cast<const int4*>(DGT);
-            const int g0n = __builtin_amdgcn_readfirstlane(tg.x & 0xffff);
-            carry.b0 = bload4(rs, vo_q, tt * blk_bytes + oB3I + g0n * 128);
-            carry.b1 = bload4(rs, vo_q, tt * blk_bytes + oB3I + g0n * 128 + 64);
             bc.tb = tt * blk_bytes; bc.X = Xt;
-            bc.g[0] = g0n; bc.g[1] = __builtin_amdgcn_readfirstlane(tg.y);
+            bc.g[0] = __builtin_amdgcn_readfirstlane(tg.x & 0xffff); bc.g[1] = __builtin_amdgcn_readfirstlane(tg.y);
             bc.g[2] = __builtin_amdgcn_readfirstlane(tg.z); bc.g[3] = __builtin_amdgcn_readfirstlane(tg.w);
-            bc.gn = 1 < nTl ? (__builtin_amdgcn_readfirstlane(DGT[8]) & 0xffff) : D;
+            {   // the first tile's biases (nothing else of it exists): the four ranks' first halves, the two pairs' shared second halves
+                const int q_ = lane >> 4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    carry.b[k] = bload4(rs, bc.g[k] < D ? vo_q : NSF2_OOB, bc.tb + oB3I + (bc.g[k] < D ? bc.g[k] : 0) * 128);
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int ga = bc.g[2 * pr], gb = bc.g[2 * pr + 1];
+                    const int vo = q_ < 2 ? (ga < D ? (q_ << 4) : NSF2_OOB) : (gb < D ? ((q_ - 2) << 4) + (gb - ga) * 128 : NSF2_OOB);
+                    carry.b[4 + pr] = bload4(rs, vo, bc.tb + oB3I + (ga < D ? ga : 0) * 128 + 64);
+                }
+            }
+            peek(1);
+            set_next(1);
             bc.stg = STG + (par & 1) * NSF2_STAGE_FLOATS;
             bc.part = PART + (par & 1) * NSF2_PART_FLOATS;
             nsf_burst_tile<0>(bc, carry);
@@ -807,10 +860,8 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
                 lds_bar_t();                                              // E(-1): the chain solved rank 0
                 bc.tb = tb; bc.X = X;
                 for (int T1 = 1; T1 < nTl; ++T1) {
-                    const int4 tg = *reinterpret_cast<const int4*>(DGT + 8 * T1);
-                    bc.g[0] = __builtin_amdgcn_readfirstlane(tg.x & 0xffff); bc.g[1] = __builtin_amdgcn_readfirstlane(tg.y);
-                    bc.g[2] = __builtin_amdgcn_readfirstlane(tg.z); bc.g[3] = __builtin_amdgcn_readfirstlane(tg.w);
-                    bc.gn = T1 + 1 < nTl ? (__builtin_amdgcn_readfirstlane(DGT[8 * (T1 + 1)]) & 0xffff) : D;
+                    bc.g[0] = bc.gnx[0]; bc.g[1] = bc.gnx[1]; bc.g[2] = bc.gnx[2]; bc.g[3] = bc.gnx[3];      // (the previous tile's "next")
+                    set_next(T1 + 1);
                     bc.stg = STG + ((T1 + spar) & 1) * NSF2_STAGE_FLOATS;
                     bc.part = PART + ((T1 + spar) & 1) * NSF2_PART_FLOATS;
 #ifdef NSF2_TILE_STAMPS
