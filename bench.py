@@ -453,11 +453,12 @@ def main():
 
     t_lseg = {"step_call": 0.0, "adapt": 0.0}
 
-    def step_laned():
+    def step_laned(more=True):
         ta = time.perf_counter()
         if pipelined:
-            # sigma / mu adapted on the device, the next pre-steps enqueued before the host sees the sums
-            _, sums = leng.step_pipelined(beta, nu, ad_l.coefficients(), n * world, pc_prior.logpdf, loglike)
+            # sigma / mu adapted on the device, the next pre-steps enqueued before the host sees the sums (more = False: the
+            # call's last step enqueues none, like the last step of a preconditioned_pcn call)
+            _, sums = leng.step_pipelined(beta, nu, ad_l.coefficients(), n * world, pc_prior.logpdf, loglike, more=more)
             tb = time.perf_counter()
             ad_l.update(sums)
         else:
@@ -543,12 +544,19 @@ def main():
             roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = ev_pairs[k]
         else:
             roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = None, None
-        timed_step()
+        if leng is not None and pipelined:
+            # EXACTLY K steps: the K-th enqueues no pre-step of a step K + 1 (the closing barrier would wait ~200 us for
+            # launches that belong to no timed step: 10 us per step at the driver's --steps 20)
+            step_laned(more=k + 1 < args.steps)
+        else:
+            timed_step()
         if step_times is not None:
             step_times.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
+    if leng is not None and pipelined:
+        leng.start_pipeline(float(ad_l.sigma), ad_l.mu, nu)      # (the passes below step on: their first pre-steps)
     head_rows_used = int(leng.lanes[0].head_rows) if (leng is not None and leng.lanes[0]._np_head[2] == 1) else 0
     if step_times is not None and rank == 0:
         st_ = np.diff(np.array([t0] + step_times)) * 1e6
@@ -909,6 +917,7 @@ def main():
                       "lane_rows": [int(e_.n) for e_ in leng.lanes] if leng is not None else [n],
                       "head_rows": head_rows_used,
                       "pipelined_device_adaptation": bool(pipelined and leng is not None),
+                      "timed_region": "exactly K steps between two barriers; the K-th step enqueues no launch of a step K + 1",
                       "inverse_algo": args.inverse, "inverse_precision": args.precision, "host_threads": args.host_threads, "host_prefetch_threads": args.host_prefetch, "host_x_order": args.x_order, "prior_on_device": bool(device_prior),
                       "accept_rate": float((ad_l if leng is not None else ad).mean_alpha),
                       "backend": (dist.get_backend() if world > 1 else None),
