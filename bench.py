@@ -218,6 +218,9 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+LANE16_BOUND = 1e-2          # the bound Flow's own guard uses (pocomc_amd/flow.py::LANE16_BOUND)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,6 +239,8 @@ def main():
                          "uniform factors, not a black box)")
     ap.add_argument("--x-order", choices=["C", "F"], default="F",
                     help="memory order of the (n, D) array handed to the host prior/likelihood")
+    ap.add_argument("--no-steady-state", action="store_true",
+                    help="skip the second closed region of >= 200 steps (side key steady_state)")
     ap.add_argument("--event-every", type=int, default=10,
                     help="record the HIP event pair around the flow-inverse launch on every k-th timed step (an event "
                          "pair per step costs ~5 %% of the step rate: it splits the pre-phase's back-to-back launches)")
@@ -261,12 +266,6 @@ def main():
                          "Default: 0.65; 0.75 for the flows that take the lane-per-walker sweep (config 3, f16 helpers: 762 (0.5) / "
                          "811 (0.6) / 864 (0.75) steps/s -- a lane of <= 8192 walkers is one round of that sweep whatever its size); the spline "
                          "flows: 8192 walkers (nsf6 1628 (0.65) / 1651 (0.75) / 1661 (0.82), nsf3 2425 / 2483 / 2529)")
-    ap.add_argument("--head-rows", type=int, default=0,
-                    help="rows of the first lane whose x' crosses PCIe ahead of the others, with a completion word of their own: "
-                         "the host's likelihood starts on them while the rest arrives (pmc_step_t.head_rows); 0 (default) = off.  "
-                         "Measured at 1536 rows: the word arrives 25 us earlier (wait_device 111 -> 86-93 us), and the likelihood "
-                         "pays it back -- it reads the head while the other rows' 1.3 MB are being written to the same memory "
-                         "(22-32 ns/row instead of 15.5) and is called once more: 3340-3360 steps/s either way")
     ap.add_argument("--flow", default="maf3", help="maf3 | maf6 | maf12 | nsf3 | nsf6 | nsf12 | customN = N-transform MAF (BASELINE configs use maf3; configs[4] is custom8 at --dim 128 --particles 5000)")
     ap.add_argument("--inverse", choices=["auto", "triangular", "naive", "solo", "duo", "lane"], default="auto")
     ap.add_argument("--precision", choices=["f32", "bf16", "f16"], default="f32",
@@ -423,7 +422,7 @@ def main():
     if args.lanes > 1 or pipelined:
         leng = LanedEngine("preconditioned_pcn", n, D, flow, scaler, lanes=args.lanes, group=None,
                            shard_offset=rank * n, seed=20240928, x_order=args.x_order, streams=not pipelined,
-                           first_fraction=args.first_lane, head_rows=max(0, args.head_rows))
+                           first_fraction=args.first_lane)
         if device_prior:
             leng.set_device_prior(pc_prior)
         leng.load_state(u, x, logdetj, logl, logp)
@@ -525,8 +524,11 @@ def main():
     for _ in range(args.warmup):
         step()
     if leng is not None:                                     # (the timed path last, back to back: W warm-up steps of it)
-        for _ in range(args.warmup):
-            step_laned()
+        if args.warmup == 0 and pipelined:
+            leng.finish_pipeline()                           # (drain the primed pre-steps; they are re-issued behind t0)
+        for w in range(args.warmup):
+            # the last warm-up step enqueues NO pre-step of timed step 1: every launch of a timed step is issued behind t0
+            step_laned(more=w + 1 < args.warmup)
     for k in t_seg:
         t_seg[k] = 0.0
     for k in t_lseg:
@@ -537,16 +539,25 @@ def main():
     step_times = [] if os.environ.get("PMC_BENCH_STEP_TIMES") else None      # (debugging aid: distribution of the step times)
     import resource
     ru0 = resource.getrusage(resource.RUSAGE_THREAD) if step_times is not None else None
+    ev_used = []
     barrier()
     t0 = time.perf_counter()
+    if leng is not None and pipelined:
+        # CLOSED region, like one preconditioned_pcn call of K steps (pocomc_amd/mcmc.py::_run): the pre-steps (proposal +
+        # flow inverse + scaler / prior epilogue + hand-over of x') of timed step 1 are enqueued HERE, behind t0, and run
+        # fully exposed; steps 1 .. K-1 enqueue their successor's, the K-th enqueues none.  K steps = K proposal + sweep
+        # launches, K likelihoods, K accepts.
+        roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = None, None
+        leng.resume_pipeline(nu)
     for k in range(args.steps):
-        if k % args.event_every == 0:
+        # (the event pair brackets the sweep the step ENQUEUES -- step k + 1's; the first step's own sweep, enqueued by
+        #  resume_pipeline above, and the K-th step, which enqueues none, carry no pair)
+        if k % args.event_every == 0 and (k + 1 < args.steps or not (leng is not None and pipelined)):
             roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = ev_pairs[k]
+            ev_used.append(ev_pairs[k])
         else:
             roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = None, None
         if leng is not None and pipelined:
-            # EXACTLY K steps: the K-th enqueues no pre-step of a step K + 1 (the closing barrier would wait ~200 us for
-            # launches that belong to no timed step: 10 us per step at the driver's --steps 20)
             step_laned(more=k + 1 < args.steps)
         else:
             timed_step()
@@ -554,10 +565,35 @@ def main():
             step_times.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
+    # ---- the same closed region once more over >= 200 steps (side key "steady_state": the exposed first pre-step is
+    #      1 / K of the region, 5 % of it at the driver's K = 20 and 0.5 % here)
+    roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = None, None
+    n_ss = 0 if args.no_steady_state else max(200, args.steps)
+    dt_ss = None
+    if n_ss:
+        if step_times is not None:
+            step_times_k, step_times = step_times, None
+        barrier()
+        ts0 = time.perf_counter()
+        if leng is not None and pipelined:
+            leng.resume_pipeline(nu)
+        for k in range(n_ss):
+            if leng is not None and pipelined:
+                step_laned(more=k + 1 < n_ss)
+            else:
+                timed_step()
+        barrier()
+        dt_ss = time.perf_counter() - ts0
+        if world > 1:
+            tt = torch.tensor([dt_ss], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ss = float(tt.item())
+        if os.environ.get("PMC_BENCH_STEP_TIMES"):
+            step_times = step_times_k
     gc.enable()
     if leng is not None and pipelined:
-        leng.start_pipeline(float(ad_l.sigma), ad_l.mu, nu)      # (the passes below step on: their first pre-steps)
-    head_rows_used = int(leng.lanes[0].head_rows) if (leng is not None and leng.lanes[0]._np_head[2] == 1) else 0
+        leng.resume_pipeline(nu)                                 # (the passes below step on: their first pre-steps)
     if step_times is not None and rank == 0:
         st_ = np.diff(np.array([t0] + step_times)) * 1e6
         ru1 = resource.getrusage(resource.RUSAGE_THREAD)
@@ -589,6 +625,8 @@ def main():
             # the lane pipeline behind the C ABI keeps its own clocks: waits (completion words of x' and of the sums) and
             # the time it spends enqueuing; what is left of a step call is the interpreter
             laned_host["wait_device"] = (ps["wait_x"] + ps["wait_sums"]) / n_lt * 1e6
+            laned_host["wait_x"] = ps["wait_x"] / n_lt * 1e6
+            laned_host["wait_sums"] = ps["wait_sums"] / n_lt * 1e6
             laned_host["enqueue_accept"] = ps["enqueue_accept"] / n_lt * 1e6
             laned_host["enqueue_next_pre"] = ps["enqueue_next_pre"] / n_lt * 1e6
             laned_host["pipeline"] = "pmc_pipeline_next (C ABI)"
@@ -612,12 +650,9 @@ def main():
             st = stamps.cpu().numpy()
             t0_ = st[:, 6].min()
             us_ = lambda a: (a - t0_) / 100.0
-            names = ["epilogue entry", "elements done", "rows entry", "before x' stores (behind the head wait)", "x' stores issued",
+            names = ["epilogue entry", "elements done", "rows entry", "before x' stores", "x' stores issued",
                      "fence passed", "kernel entry"]
-            hb = int(leng.lanes[0].head_rows) // 16
-            for sel, nm in ((slice(0, hb), "head blocks"), (slice(hb, nb), "other blocks")):
-                if st[sel].shape[0] == 0:
-                    continue
+            for sel, nm in ((slice(0, nb), "blocks"),):
                 for i in (6, 0, 1, 2, 3, 4, 5):
                     v = us_(st[sel, i])
                     print(f"[epilogue stamps] {nm:12s} {names[i]:42s} min {v.min():7.1f} median {np.median(v):7.1f} p90 {np.percentile(v, 90):7.1f} max {v.max():7.1f} us", file=sys.stderr)
@@ -633,7 +668,7 @@ def main():
                   file=sys.stderr)
         if pipelined:
             leng.finish_pipeline()
-    inv_us_live = float(np.mean([lib.pmc_event_elapsed_ms(a, b) for a, b in ev_pairs[::args.event_every]])) * 1e3
+    inv_us_live = float(np.mean([lib.pmc_event_elapsed_ms(a, b) for a, b in ev_used])) * 1e3
     # the same launch without the scaler epilogue (pmc_step_t.no_fuse bit 1: the scaler as a launch of its own), a few
     # untimed steps: what the sweep alone takes -- side key of the roofline object
     inv_us_sweep_only = None
@@ -680,10 +715,19 @@ def main():
         np.setbufsize(bufsize0)
     if pinned_core is not None:
         os.sched_setaffinity(0, affinity0)
+    per_rank = None
     if world > 1:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # every rank's own clocks, so that a multi-GPU line explains itself: wait_sums is the host's wait for the closing
+        # launch of a step -- at world > 1 that launch holds the exchange (comm_adapt_kernel polls the peers' sequence words),
+        # so a rank that waits longer there than the others waited for a LATE PEER, not for its own device
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "timed_region_s": dt_local,
+                **{k: (laned_host or {}).get(k) for k in ("wait_x", "wait_sums", "likelihood", "enqueue_accept", "enqueue_next_pre",
+                                                           "python_overhead", "step_call")}}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     # ---- per-kernel device times from the HIP events recorded inside the timed region
     ev = eng.events
@@ -741,7 +785,7 @@ def main():
                 # `traffic_committed_profile` for reference
                 "traffic": None,
                 "traffic_committed_profile": traffic,
-                "avg_launch_us": inv_us_live, "launches_timed": len(ev_pairs[::args.event_every]),
+                "avg_launch_us": inv_us_live, "launches_timed": len(ev_used),
                 "walkers_per_launch": n_launch,
                 "flops_per_launch": actual_flops,
                 "note": "achieved = executed flops (2 x the unmasked multiply-adds of the flow, each once: the triangular "
@@ -905,8 +949,8 @@ def main():
     out = {"metric": "preconditioned MCMC steps/sec (1e4 particles, 32-D)", "value": value,
            "unit": ("steps/s per 1e4 walkers" if world == 1 else "steps/s × global_walkers/1e4 (weak)"), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": ("f32 flow (MFMA) + f64 step" if args.precision == "f32" else
-                     f"{args.precision} left-looking products + f32 chain of the flow inverse (MFMA, f32 accumulation) + f64 step"),
+           "dtype": ("f32 flow (MFMA) + f64 step" if flow.inverse_precision_active == "f32" else
+                     f"{flow.inverse_precision_active} left-looking products + f32 chain of the flow inverse (MFMA, f32 accumulation) + f64 step"),
            "data": "synthetic",
            "config": {"workload": f"{D}-D {TARGET_NAMES[args.target]}, U({p_lo:g},{p_hi:g})^{D} prior, {n} walkers/GPU x {world} GPU, {args.flow} "
                                   f"(H={spec.hidden}), beta={beta}, tpCN kernel, host numpy likelihood in the loop",
@@ -915,10 +959,14 @@ def main():
                       "flow_fit_rule": ("50 epochs" if D <= 64 else "the Sampler's: patience = D, best validation state restored at the early stop"), "parallelism": f"walker-sharded x{world}",
                       "lanes": len(leng.lanes) if leng is not None else 1,
                       "lane_rows": [int(e_.n) for e_ in leng.lanes] if leng is not None else [n],
-                      "head_rows": head_rows_used,
                       "pipelined_device_adaptation": bool(pipelined and leng is not None),
-                      "timed_region": "exactly K steps between two barriers; the K-th step enqueues no launch of a step K + 1",
-                      "inverse_algo": args.inverse, "inverse_precision": args.precision, "host_threads": args.host_threads, "host_prefetch_threads": args.host_prefetch, "host_x_order": args.x_order, "prior_on_device": bool(device_prior),
+                      "timed_region": ("closed: K steps between two barriers with every launch of the K steps enqueued behind t0 -- the "
+                                       "pre-steps (proposal + flow inverse + scaler/prior epilogue + hand-over of x') of step 1 are "
+                                       "issued right after t0 and run exposed, steps 1..K-1 enqueue their successor's, the K-th "
+                                       "enqueues none: K proposal+sweep launches, K likelihoods, K accepts (one preconditioned_pcn "
+                                       "call of K steps, pocomc_amd/mcmc.py::_run)"),
+                      "inverse_algo": args.inverse, "inverse_precision": flow.inverse_precision_active,
+                      "inverse_precision_requested": args.precision, "inverse_guard": flow.inverse_guard, "host_threads": args.host_threads, "host_prefetch_threads": args.host_prefetch, "host_x_order": args.x_order, "prior_on_device": bool(device_prior),
                       "accept_rate": float((ad_l if leng is not None else ad).mean_alpha),
                       "backend": (dist.get_backend() if world > 1 else None),
                       "collectives": (None if world == 1 else
@@ -946,6 +994,16 @@ def main():
            "host_us_per_step": {**{k: v / n_inst * 1e6 for k, v in eng.host_timers.items()},
                                 **{k: v / n_inst * 1e6 for k, v in t_seg.items()}}}
     out["config"]["driver_pinned_to_core"] = pinned_core
+    if per_rank is not None:
+        out["per_rank_us_per_step"] = per_rank
+    if dt_ss is not None:
+        out["steady_state"] = {"steps": n_ss, "value": (n * world * n_ss / dt_ss) / 1e4, "ms_per_step": dt_ss / n_ss * 1e3,
+                               "note": "the same closed region over more steps (the exposed first pre-step is 1/K of it)"}
+    if lane16_check is not None and not (lane16_check["x_rel_err_max"] <= LANE16_BOUND):
+        # a 16-bit sweep that is not an inverse of the trained flow within the stated bound is not a measurement of this metric
+        out["value_refused"] = {"value_measured": value, "reason": f"16-bit sweep: max per-walker relative error on x "
+                                f"{lane16_check['x_rel_err_max']:.3g} > {LANE16_BOUND:g} against the float32 sweep of the trained flow"}
+        out["value"] = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(D, n, beta, flow.params.cpu().numpy(), spec, x, u, geo, sigma0, seed=0,
                                            target=target, bounds=(p_lo, p_hi))

@@ -314,10 +314,6 @@ int pmc_wait_flag(const int64_t* flag, int64_t value, double timeout_s);
 void* pmc_prefetcher_create(int32_t n_threads, const int32_t* cpus);
 int pmc_prefetcher_submit(void* prefetcher, const void* flag, int64_t value, const void* buf, int64_t bytes,
                           double timeout_s);
-/* the same for `count` pieces of `bytes` bytes, `stride` bytes apart (the first rows of every column of a column-major x':
- * pmc_step_t.head_rows) */
-int pmc_prefetcher_submit_strided(void* prefetcher, const void* flag, int64_t value, const void* buf, int64_t bytes,
-                                  int64_t stride, int64_t count, double timeout_s);
 void pmc_prefetcher_destroy(void* prefetcher);
 
 /* pmc_scaler_inverse and pmc_prior_logpdf in ONE launch (the step's pre-phase is a chain of small
@@ -487,15 +483,6 @@ typedef struct pmc_step {
      * does not count (no device prior, or x' not handed over by the kernels); the host then scans h_fin / logp' as before. */
     int64_t* h_clean;         /* pinned host int64 [1] or NULL */
     uint32_t* clean_count;    /* device uint32 [1], zeroed once by the caller */
-    /* "Head first": the x' of a launch crosses PCIe at ~40 GB/s, ~40 us for 6.5e3 x 32 rows, and the host's likelihood
-     * cannot start before rows are there.  With head_rows > 0 (a multiple of 16, < n) the fused proposal + sweep + scaler
-     * launch sends the rows [0, head_rows) first and raises h_head[0] <- step + 1 when they have arrived (h_head[1] <- rows
-     * counted not clean up to then, as h_clean; -1: not counted); h_done[0] follows when all rows have.  pmc_step_pre
-     * writes h_head[2] <- 1 at enqueue time when the launch sequence it chose raises the word, 0 when it does not (the
-     * host then waits for h_done[0] as without a head). */
-    int64_t head_rows;
-    int64_t* h_head;          /* pinned host int64 [3] or NULL */
-    uint32_t* head_ticket;    /* device uint32 [2], zeroed once by the caller */
     /* 1: in the HOST copy of x' (h_x with host_direct) a row that does not reach the likelihood -- x' or the device-evaluated
      * logp' not finite, the rows h_clean counts -- carries the walker's current x (cur.x) instead of x'.  The host can then
      * hand the whole block to a row-wise likelihood and overwrite those rows' values with -inf (mcmc.py:118-121 does that to
@@ -548,8 +535,15 @@ int pmc_stream_synchronize(void* stream);
  *   exchanges between the ranks' processes (e.g. torch.distributed.all_gather_object);  pmc_comm_connect(comm, world x 64 B).
  *   pmc_comm_adapt_update = pmc_adapt_update with the parts' total summed over the ranks first (every rank calls it in
  *   the same order; timeout_s bounds the wait for a peer: on a timeout sums[0] is NaN and `done` is written all the same).
- *   pmc_pipeline_set_comm(pipeline, comm): the pipelined step of a sharded walker set. */
+ *   pmc_pipeline_set_comm(pipeline, comm): the pipelined step of a sharded walker set.
+ * pmc_comm_create fails (NULL) where the device cannot give it UNCACHED memory -- the protocol is only valid for mailboxes
+ * no device caches.  pmc_comm_create_host: the same communicator with the mailboxes in pinned, coherent HOST memory (a
+ * POSIX shared-memory object per rank, registered with every rank's HIP runtime; the 64-byte handle is its name): every
+ * store and poll crosses PCIe instead of xGMI -- the tier for nodes without hipIpc peer mappings, slower, same bits.  All
+ * ranks of a communicator are of one kind (pmc_comm_kind: 0 device, 1 host). */
 void* pmc_comm_create(int32_t rank, int32_t world, int32_t width);
+void* pmc_comm_create_host(int32_t rank, int32_t world, int32_t width);
+int pmc_comm_kind(void* comm);
 int pmc_comm_handle(void* comm, void* out64);
 int pmc_comm_connect(void* comm, const void* handles);
 void pmc_comm_destroy(void* comm);
@@ -580,9 +574,6 @@ int pmc_pipeline_start(void* pipeline, double nu, int64_t first_step);
 int pmc_pipeline_next(void* pipeline, int32_t lane_done, double beta, double nu, int32_t adapt_mode, double c_sigma,
                       double c_mu, double cap, double n_total, int32_t more);
 /* out f64 [6] <- { seconds spent waiting for x', waiting for the sums, enqueuing accepts, enqueuing pre-steps, steps, 0 } */
-/* behind a lane whose launch sends a head first (pmc_step_t.head_rows): pmc_pipeline_next returned with the head's rows in
- * host memory; this waits for the others */
-int pmc_pipeline_wait_lane(void* pipeline, int32_t lane);
 int pmc_pipeline_stats(void* pipeline, double* out, int32_t reset);
 /* hipEvent helpers for the host language (live kernel timing inside bench.py). */
 void* pmc_event_create(void);

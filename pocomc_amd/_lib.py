@@ -97,7 +97,6 @@ class pmc_step_t(C.Structure):
                 ("adapt_c_sigma", C.c_double), ("adapt_c_mu", C.c_double), ("adapt_cap", C.c_double),
                 ("adapt_n_total", C.c_double), ("adapt_other", C.c_void_p * 7), ("adapt_n_other", C.c_int32),
                 ("adapt_pad2", C.c_int32), ("h_clean", c_p), ("clean_count", c_p),
-                ("head_rows", C.c_int64), ("h_head", c_p), ("head_ticket", c_p),
                 ("fill_rejected", C.c_int32), ("fill_pad", C.c_int32)]
 
 
@@ -130,7 +129,6 @@ SIGNATURES = {
                                            c_p, c_p]),
     "pmc_prefetcher_create": (C.c_void_p, [C.c_int32, c_p]),
     "pmc_prefetcher_submit": (C.c_int, [c_p, c_p, i64, c_p, i64, f64]),
-    "pmc_prefetcher_submit_strided": (C.c_int, [c_p, c_p, i64, c_p, i64, i64, i64, f64]),
     "pmc_prefetcher_destroy": (None, [c_p]),
     "pmc_maf_valid_epoch": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, i64, i64, c_p, c_p, c_p]),
     "pmc_neg_weighted_sum": (C.c_int, [c_p, c_p, c_p, C.c_float, c_p, i64, c_p]),
@@ -157,6 +155,8 @@ SIGNATURES = {
     "pmc_pipeline_create": (C.c_void_p, [C.POINTER(C.c_void_p), i32, C.c_uint64, C.POINTER(C.c_uint64), c_p, f64, c_p]),
     "pmc_pipeline_set_comm": (C.c_int, [c_p, c_p]),
     "pmc_comm_create": (C.c_void_p, [i32, i32, i32]),
+    "pmc_comm_create_host": (C.c_void_p, [i32, i32, i32]),
+    "pmc_comm_kind": (C.c_int, [c_p]),
     "pmc_comm_handle": (C.c_int, [c_p, c_p]),
     "pmc_comm_connect": (C.c_int, [c_p, c_p]),
     "pmc_comm_destroy": (None, [c_p]),
@@ -165,7 +165,6 @@ SIGNATURES = {
     "pmc_pipeline_destroy": (None, [c_p]),
     "pmc_pipeline_start": (C.c_int, [c_p, f64, i64]),
     "pmc_pipeline_next": (C.c_int, [c_p, i32, f64, f64, i32, f64, f64, f64, f64, i32]),
-    "pmc_pipeline_wait_lane": (C.c_int, [c_p, i32]),
     "pmc_pipeline_stats": (C.c_int, [c_p, C.POINTER(C.c_double), i32]),
     "pmc_event_create": (c_p, []),
     "pmc_event_record": (C.c_int, [c_p, c_p]),

@@ -17,8 +17,7 @@
 
 namespace {
 
-// (count pieces of `bytes` bytes, `stride` bytes apart: the head rows of a column-major x'; count = 1: one contiguous buffer)
-struct Job { const volatile int64_t* flag; int64_t value; const char* buf; int64_t bytes; double timeout_s; int64_t stride; int64_t count; };
+struct Job { const volatile int64_t* flag; int64_t value; const char* buf; int64_t bytes; double timeout_s; };
 
 constexpr int RING = 16;
 
@@ -66,15 +65,7 @@ void* worker_main(void* arg) {
             if (w->stop.load(std::memory_order_relaxed)) { ready = false; break; }
             if ((spins & 4095) == 4095 && now_s() - t0 > j.timeout_s) { ready = false; break; }
         }
-        if (ready && j.count > 1) {
-            // the pieces from the last one backwards, dealt to the helpers in turn
-            uint64_t s = 0;
-            for (int64_t p = j.count - 1 - w->idx; p >= 0; p -= w->n) {
-                const char* b = j.buf + p * j.stride;
-                for (int64_t o = j.bytes - 1; o >= 0; o -= 64) s += (unsigned char)b[o];
-            }
-            w->sink += s;
-        } else if (ready) {
+        if (ready) {
             // 4 KB pieces from the end of the buffer, dealt to the helpers in turn; one read per 64-byte line
             const int64_t pieces = (j.bytes + 4095) / 4096;
             uint64_t s = 0;
@@ -108,24 +99,16 @@ extern "C" void* pmc_prefetcher_create(int32_t n_threads, const int32_t* cpus) {
     return p;
 }
 
-extern "C" int pmc_prefetcher_submit_strided(void* handle, const void* flag, int64_t value, const void* buf, int64_t bytes,
-                                             int64_t stride, int64_t count, double timeout_s);
-
 extern "C" int pmc_prefetcher_submit(void* handle, const void* flag, int64_t value, const void* buf, int64_t bytes,
                                      double timeout_s) {
-    return pmc_prefetcher_submit_strided(handle, flag, value, buf, bytes, bytes, 1, timeout_s);
-}
-
-extern "C" int pmc_prefetcher_submit_strided(void* handle, const void* flag, int64_t value, const void* buf, int64_t bytes,
-                                             int64_t stride, int64_t count, double timeout_s) {
     Prefetcher* p = static_cast<Prefetcher*>(handle);
-    if (!p || !flag || !buf || bytes <= 0 || count < 1 || stride < bytes) return 1;
+    if (!p || !flag || !buf || bytes <= 0) return 1;
     for (int i = 0; i < p->n; ++i) {
         Worker& w = p->w[i];
         const uint64_t h = w.head.load(std::memory_order_relaxed);
         if (h - w.tail.load(std::memory_order_acquire) >= RING) continue;      // helper far behind: skip this one
         w.ring[h % RING] = Job{static_cast<const volatile int64_t*>(flag), value, static_cast<const char*>(buf), bytes,
-                               timeout_s > 0 ? timeout_s : 1.0, stride, count};
+                               timeout_s > 0 ? timeout_s : 1.0};
         w.head.store(h + 1, std::memory_order_release);
     }
     return 0;

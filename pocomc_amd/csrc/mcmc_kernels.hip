@@ -8,6 +8,12 @@
 
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <stdio.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <time.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <math.h>
 #include <stdint.h>
 #include "philox.h"
@@ -872,11 +878,14 @@ extern "C" int pmc_adapt_update(const double* const* parts, int32_t n_parts, int
 // ---------------------------------------------------------------------------------------------------------------------
 struct pmc_comm {
     int rank, world, width, stride;        // stride: doubles per slot (width + 1, rounded to 8)
-    double* own;                           // [2][world][stride], uncached device memory
+    double* own;                           // [2][world][stride]: uncached device memory (kind 0) or the device address of host_map[rank] (kind 1)
     double* peer[8];                       // the ranks' mailboxes as mapped into this process (peer[rank] == own)
     long long seq;
-    hipIpcMemHandle_t handle;
+    hipIpcMemHandle_t handle;              // kind 0: the IPC handle; kind 1: the name of the POSIX shared-memory object (a C string)
     bool connected;
+    int kind;                              // 0: device memory shared through hipIpc (xGMI peer stores); 1: pinned host memory (PCIe)
+    size_t bytes;
+    void* host_map[8];                     // kind 1: the ranks' segments as mmap()ed here (registered with the HIP runtime)
 };
 
 struct CommPeers { double* p[8]; };
@@ -928,25 +937,69 @@ __global__ __launch_bounds__(256) void comm_adapt_kernel(AdaptParts parts, int n
     }
 }
 
-extern "C" void* pmc_comm_create(int32_t rank, int32_t world, int32_t width) {
-    if (world < 1 || world > 8 || rank < 0 || rank >= world || width < 1 || width > 260) { pmc_fail("pmc_comm_create: 1..8 ranks, width <= 260"); return nullptr; }
+static pmc_comm* comm_new(int32_t rank, int32_t world, int32_t width, int kind, const char* who) {
+    if (world < 1 || world > 8 || rank < 0 || rank >= world || width < 1 || width > 260) { pmc_fail(who); return nullptr; }
     pmc_comm* c = new pmc_comm();
     c->rank = rank; c->world = world; c->width = width; c->stride = (width + 1 + 7) & ~7;
-    c->seq = 0; c->connected = false;
-    const size_t bytes = (size_t)2 * world * c->stride * sizeof(double);
+    c->seq = 0; c->connected = false; c->kind = kind; c->own = nullptr;
+    c->bytes = (size_t)2 * world * c->stride * sizeof(double);
+    for (int r = 0; r < 8; ++r) { c->peer[r] = nullptr; c->host_map[r] = nullptr; }
+    memset(&c->handle, 0, sizeof(c->handle));
+    return c;
+}
+
+extern "C" void* pmc_comm_create(int32_t rank, int32_t world, int32_t width) {
+    pmc_comm* c = comm_new(rank, world, width, 0, "pmc_comm_create: 1..8 ranks, width <= 260");
+    if (!c) return nullptr;
     void* ptr = nullptr;
-    // uncached: a peer's stores over xGMI must be what this device's loads see, without a cache line of its own in between
-    hipError_t e = hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocUncached);
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&ptr, bytes); }
-    if (e != hipSuccess) { pmc_fail_hip(e, "pmc_comm_create: allocation of the mailbox"); delete c; return nullptr; }
-    if (hipMemset(ptr, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { pmc_fail("pmc_comm_create: hipMemset"); (void)hipFree(ptr); delete c; return nullptr; }
+    // uncached: a peer's stores over xGMI must be what this device's loads see, without a cache line of its own in between.
+    // No cached fallback: the kernel's protocol is only validated for memory the device does not cache -- a caller that
+    // cannot have it takes the host mailboxes (pmc_comm_create_host) or its process group's all-reduce instead.
+    hipError_t e = hipExtMallocWithFlags(&ptr, c->bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); pmc_fail_hip(e, "pmc_comm_create: uncached allocation of the mailbox"); delete c; return nullptr; }
+    if (hipMemset(ptr, 0, c->bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { pmc_fail("pmc_comm_create: hipMemset"); (void)hipFree(ptr); delete c; return nullptr; }
     c->own = (double*)ptr;
-    for (int r = 0; r < 8; ++r) c->peer[r] = nullptr;
     c->peer[rank] = c->own;
     if (world > 1) {
         e = hipIpcGetMemHandle(&c->handle, ptr);
         if (e != hipSuccess) { pmc_fail_hip(e, "pmc_comm_create: hipIpcGetMemHandle"); (void)hipFree(ptr); delete c; return nullptr; }
     } else c->connected = true;
+    return c;
+}
+
+// kind 1: the mailbox in pinned, coherent HOST memory -- a POSIX shared-memory object every rank maps and registers with
+// its HIP runtime (hipHostRegister: fine-grained, never cached by a device).  The same kernel and protocol; every store and
+// every poll crosses PCIe instead of xGMI.  The tier for nodes where hipIpc peer mappings are not to be had, and the way
+// the protocol is exercised over a non-local, uncached path on a single GPU (tests/test_gpu_sharded_sampler.py).
+static void* comm_map_shm(const char* name, size_t bytes, bool create, void** dev_out, const char* who) {
+    const int fd = shm_open(name, create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDWR, 0600);
+    if (fd < 0) { pmc_fail(who); return nullptr; }
+    if (create && ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(name); pmc_fail(who); return nullptr; }
+    void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { if (create) shm_unlink(name); pmc_fail(who); return nullptr; }
+    if (create) memset(p, 0, bytes);
+    hipError_t e = hipHostRegister(p, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(dev_out, p, 0);
+    if (e != hipSuccess) { (void)hipGetLastError(); munmap(p, bytes); if (create) shm_unlink(name); pmc_fail_hip(e, who); return nullptr; }
+    return p;
+}
+
+extern "C" void* pmc_comm_create_host(int32_t rank, int32_t world, int32_t width) {
+    pmc_comm* c = comm_new(rank, world, width, 1, "pmc_comm_create_host: 1..8 ranks, width <= 260");
+    if (!c) return nullptr;
+    static int counter = 0;
+    char* name = reinterpret_cast<char*>(&c->handle);
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    snprintf(name, 64, "/pmc_comm_%d_%d_%lx", (int)getpid(), counter++, (unsigned long)ts.tv_nsec);
+    void* dev = nullptr;
+    void* p = comm_map_shm(name, c->bytes, true, &dev, "pmc_comm_create_host: shared-memory mailbox");
+    if (!p) { delete c; return nullptr; }
+    c->host_map[rank] = p;
+    c->own = (double*)dev;
+    c->peer[rank] = c->own;
+    if (world == 1) c->connected = true;
     return c;
 }
 
@@ -964,6 +1017,17 @@ extern "C" int pmc_comm_connect(void* cc, const void* handles) {
     if (!c || !handles) return pmc_fail("pmc_comm_connect: null argument");
     for (int r = 0; r < c->world; ++r) {
         if (r == c->rank) continue;
+        if (c->kind == 1) {
+            char name[64];
+            memcpy(name, (const char*)handles + 64 * r, 64);
+            name[63] = 0;
+            void* dev = nullptr;
+            void* p = comm_map_shm(name, c->bytes, false, &dev, "pmc_comm_connect: a peer's shared-memory mailbox");
+            if (!p) return 1;
+            c->host_map[r] = p;
+            c->peer[r] = (double*)dev;
+            continue;
+        }
         hipIpcMemHandle_t h;
         memcpy(&h, (const char*)handles + 64 * r, 64);
         void* ptr = nullptr;
@@ -978,11 +1042,21 @@ extern "C" int pmc_comm_connect(void* cc, const void* handles) {
 extern "C" void pmc_comm_destroy(void* cc) {
     pmc_comm* c = (pmc_comm*)cc;
     if (!c) return;
+    if (c->kind == 1) {
+        for (int r = 0; r < c->world; ++r)
+            if (c->host_map[r]) { (void)hipHostUnregister(c->host_map[r]); munmap(c->host_map[r], c->bytes); }
+        if (c->host_map[c->rank]) shm_unlink(reinterpret_cast<const char*>(&c->handle));
+        delete c;
+        return;
+    }
     for (int r = 0; r < c->world; ++r)
         if (r != c->rank && c->peer[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
     if (c->own) (void)hipFree(c->own);
     delete c;
 }
+
+// 0: device mailboxes behind hipIpc handles, 1: host mailboxes in POSIX shared memory
+extern "C" int pmc_comm_kind(void* cc) { return cc ? ((pmc_comm*)cc)->kind : -1; }
 
 // total over the parts of this rank AND over the ranks (rank order), then as pmc_adapt_update: total_out / h_sums / the
 // adaptation / done.  Every rank must make the same sequence of calls.  timeout_s <= 0: wait for ever.

@@ -141,9 +141,6 @@ struct ScalerEpi {
     double* logp_out; int32_t* finite_copy; double* logp_copy;
     unsigned* done_ticket; long long* done_flag; long long done_value;
     unsigned* bad_count; long long* bad_flag;       // optional: rows that are not clean (pmc_step_t.h_clean)
-    // "head first" (pmc_step_t.head_rows): the first head_blocks workgroups send their x' over the link before the others
-    // and raise head_flag[0] <- done_value (head_flag[1] <- rows counted not clean so far) when it has arrived
-    unsigned head_blocks; unsigned* head_ticket; long long* head_flag;
     const double* fill_x;                           // pmc_step_t.fill_rejected: the walkers' current x (device [n][D]) or NULL
     long long* stamps;                              // measurement only (pmc_debug_set_epilogue_stamps): [block][8] of the 100 MHz clock
 };
@@ -211,19 +208,6 @@ __device__ __forceinline__ void scaler_epilogue_rows(const ScalerEpi& e, const d
     }
     if (e.fill_x) __syncthreads();
     if (e.stamps && tid == 0) e.stamps[blockIdx.x * 8 + 2] = wall_clock64();
-    const bool split = e.head_blocks > 0 && e.done_flag && e.head_ticket && e.head_flag;
-    const bool in_head = split && blockIdx.x < e.head_blocks;
-    if (split && !in_head && e.x_colmajor && !cm_done) {
-        // The link takes the launch's x' at ~40 GB/s whoever sends it: the head's workgroups (the lowest block indices:
-        // dispatched first, resident before any block that waits here) go first, so that the host has rows to work on while
-        // the rest is still under way.
-        // (relaxed: nothing is read behind the wait -- it only puts this block's stores behind the head's in time; an acquire
-        //  per poll is a cache invalidate per poll, from ~300 blocks at once)
-        if (tid == 0)
-            while (__hip_atomic_load(e.head_ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)e.done_value)
-                __builtin_amdgcn_s_sleep(8);
-        __syncthreads();
-    }
     if (e.stamps && tid == 0) e.stamps[blockIdx.x * 8 + 3] = wall_clock64();
     if (e.x_colmajor && !cm_done) {
         for (int el = tid; el < rows * D; el += nthr) {
@@ -244,24 +228,9 @@ __device__ __forceinline__ void scaler_epilogue_rows(const ScalerEpi& e, const d
         __syncthreads();
         if (e.stamps && tid == 0) e.stamps[blockIdx.x * 8 + 5] = wall_clock64();
         if (tid == 0) {
-            if (in_head) {
-                // (relaxed: the block's stores were acknowledged at the fence above)
-                const unsigned th = __hip_atomic_fetch_add(e.head_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (th == e.head_blocks - 1) {
-                    // (the count may include rows of blocks behind the head: a non-zero word only sends the host to its scan)
-                    e.head_flag[1] = e.bad_count ? (long long)__hip_atomic_load(e.bad_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : -1LL;
-                    __threadfence_system();
-                    __hip_atomic_store(e.head_flag, e.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                    // the word is on its way before the other blocks put their megabyte into the same queue (released by the
-                    // ticket alone they had it ~25 us ahead of the word)
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    __hip_atomic_store(e.head_ticket + 1, (unsigned)e.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
             const unsigned t = __hip_atomic_fetch_add(e.done_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             if (t == gridDim.x - 1) {
                 *e.done_ticket = 0u;
-                if (split) *e.head_ticket = 0u;           // (every head block drew its ticket; the go word [1] is the step's own)
                 if (e.bad_count && e.bad_flag) {          // (every block's count is in: its ticket came behind its atomicAdd)
                     const unsigned bad = __hip_atomic_exchange(e.bad_count, 0u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
                     *e.bad_flag = (long long)bad;

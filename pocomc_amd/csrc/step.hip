@@ -95,11 +95,6 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
             epi.bad_flag = (done && s->h_clean && s->clean_count) ? (long long*)s->h_clean : nullptr;
             epi.stamps = (n == g_epilogue_stamps_n) ? g_epilogue_stamps : nullptr;
             epi.fill_x = (s->fill_rejected && epi.bad_flag && xT) ? s->cur.x : nullptr;
-            if (done && xT && s->head_rows > 0 && s->head_rows < n && (s->head_rows & 15) == 0 && s->h_head && s->head_ticket) {
-                epi.head_blocks = (unsigned)(s->head_rows >> 4);        // (16 walkers per workgroup in both fused sweeps)
-                epi.head_ticket = s->head_ticket;
-                epi.head_flag = (long long*)s->h_head;
-            }
         }
         if (s->ev_inv0) (void)hipEventRecord((hipEvent_t)s->ev_inv0, st);
         rc = pmc_launch_propose_inverse_tri4(s->kind, s->cur.theta32, mu, s->inv_cov, s->chol, nu, sigma, cn_a, rng,
@@ -123,8 +118,6 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
     const bool counted = done && s->h_clean && s->clean_count && xT && (scaled || pr);
     if (!scaled && counted) { sx.bad_count = s->clean_count; sx.bad_flag = (long long*)s->h_clean; sx.fill_x = s->fill_rejected ? s->cur.x : nullptr; }
     if (s->h_clean && !counted) *s->h_clean = -1;     // (this launch sequence does not count)
-    if (s->h_head)                                   // does the sequence raise the head's word?  (the host reads this before it waits)
-        s->h_head[2] = (scaled && done && xT && s->head_rows > 0 && s->head_rows < n && (s->head_rows & 15) == 0 && s->head_ticket) ? 1 : 0;
     if (scaled) {
         rc = 0;
     } else if (s->preconditioned) {
@@ -354,10 +347,6 @@ static int pipeline_enqueue_pre(pmc_pipeline* p, int64_t step, double nu) {
         p->rng[k].step = (uint64_t)step;
         const int rc = pmc_step_pre(&s, &p->rng[k], nu, 0.0, 0.0, p->stream);
         if (rc) return rc;
-        const bool head = s.head_rows > 0 && s.h_head && s.h_head[2] == 1;
-        if (p->prefetcher && head)                          // (the head of a column-major x': D runs of head_rows doubles)
-            (void)pmc_prefetcher_submit_strided(p->prefetcher, s.h_head, step + 1, s.h_x, s.head_rows * 8, (int64_t)s.n * 8, s.D,
-                                                p->timeout > 0 ? p->timeout : 1.0);
         if (p->prefetcher)                                  // helper threads read x' once as soon as its completion word shows up
             (void)pmc_prefetcher_submit(p->prefetcher, s.h_done, step + 1, s.h_x, (int64_t)s.n * s.D * 8, p->timeout > 0 ? p->timeout : 1.0);
     }
@@ -405,11 +394,9 @@ extern "C" int pmc_pipeline_next(void* pp, int32_t lane_done, double beta, doubl
         t0 = t1;
     }
     if (lane_done < last) {
-        // the next lane's x': its first rows when the launch sends a head first (the caller evaluates those, then
-        // pmc_pipeline_wait_lane for the rest), all of them otherwise
+        // the next lane's x'
         const pmc_step_t* nx = p->lanes[lane_done + 1];
-        const bool head = nx->head_rows > 0 && nx->h_head && nx->h_head[2] == 1;
-        const int rc = pmc_wait_flag(head ? nx->h_head : nx->h_done, p->step + 1, p->timeout);
+        const int rc = pmc_wait_flag(nx->h_done, p->step + 1, p->timeout);
         p->t_wait_x += now_s() - t0;
         return rc;
     }
@@ -424,16 +411,6 @@ extern "C" int pmc_pipeline_next(void* pp, int32_t lane_done, double beta, doubl
     p->t_wait_sums += now_s() - t0;
     p->step += 1;
     p->n_steps += 1;
-    return rc;
-}
-
-// all rows of lane `lane`'s x' of the step in flight (behind a head: pmc_step_t.head_rows)
-extern "C" int pmc_pipeline_wait_lane(void* pp, int32_t lane) {
-    pmc_pipeline* p = (pmc_pipeline*)pp;
-    if (!p || lane < 0 || lane >= p->n_lanes) return pmc_fail("pmc_pipeline_wait_lane: bad argument");
-    const double t0 = now_s();
-    const int rc = pmc_wait_flag(p->lanes[lane]->h_done, p->step + 1, p->timeout);
-    p->t_wait_x += now_s() - t0;
     return rc;
 }
 

@@ -36,22 +36,31 @@ def torch_double_to_float(x: torch.Tensor, warn: bool = True) -> torch.Tensor:
     raise ValueError(f"Unsupported datatype for input data: {x.dtype}")
 
 
+LANE16_BOUND = 1e-2        # largest per-walker relative difference of x the 16-bit sweep may show against the float32 sweep
+LANE16_LADJ_BOUND = 1e-1   # ... and of the log-determinant (it enters the Metropolis ratio of mcmc.py:124-134 as it is)
+
+
 class Flow:
     """Masked autoregressive flow resident on one MI355X."""
 
     def __init__(self, n_dim, flow="nsf3", device=None, seed=None, precision="f32", train_engine=None,
-                 inverse_precision=None):                                                                 # default flow as pocomc/flow.py:46
+                 inverse_precision=None, inverse_guard=True):                                                                 # default flow as pocomc/flow.py:46
         """``precision="bf16"`` (affine flows): ``forward`` / ``log_prob`` run on the bf16 matrix cores with fp32
         accumulation (``csrc/maf_forward_bf16.hip``; BASELINE config 5 names this precision), and ``fit`` takes the bf16
         gradient engine (``csrc/maf_train_bf16.hip``: bf16 weights / activations, fp32 master parameters, accumulation and
         optimizer) when the hidden layers are wide (>= ``train.WIDE_MIN_HIDDEN`` units: the config-5 flow);
         ``train_engine="f32" | "bf16"`` fixes the engine instead of the width rule (kept by ``save_state``).  The
         parameters, the chain of the inverse and the univariate maps stay float32.  ``inverse_precision`` ("f32" | "bf16" |
-        "f16"; default: "bf16" for ``precision="bf16"``, else "f32"): operand type of the LEFT-LOOKING products of the
+        "f16"; default "f32" whatever ``precision`` says -- an explicit opt-in): operand type of the LEFT-LOOKING products of the
         inverse sweep of the wide flows (``csrc/maf_inverse_tri6.hip``: everything left of the diagonal tile, multiplied by
         the helper wavefronts on ``v_mfma_f32_16x16x16_bf16 / _f16`` with float32 accumulation; the dependent chain stays
         float32) -- it halves the activations' LDS footprint, so that BASELINE config 5's 5000 walkers per GPU take one round
         of the sweep instead of two.  Narrow flows (fewer than 16 hidden tiles) keep the float32 sweeps whatever it says.
+        The 16-bit sweep is GUARDED: whenever the parameters change (``set_params``, the end of ``fit``) the 16-bit and the
+        float32 sweep are run on latent points of this flow (``check_inverse_precision``) and the flow goes back to the
+        float32 sweep, with a warning, if a walker's x differs by more than ``LANE16_BOUND`` (relative) or its log-determinant
+        by more than ``LANE16_LADJ_BOUND`` -- ``Flow.inverse`` is the contract of ``flow.py:116-132``: an inverse
+        (``inverse_guard=False`` switches the check off: measurements of the raw 16-bit sweep).
         Default: float32 everywhere, like the reference."""
         self.n_dim = int(n_dim)
         if isinstance(flow, MAFSpec):
@@ -89,7 +98,7 @@ class Flow:
             raise ValueError("train_engine must be None, 'f32' or 'bf16'")
         self.train_engine = train_engine
         if inverse_precision is None:
-            inverse_precision = "bf16" if precision == "bf16" else "f32"
+            inverse_precision = "f32"          # (also what a checkpoint without the key reloads as)
         if inverse_precision not in ("f32", "bf16", "f16"):
             raise ValueError("inverse_precision must be 'f32', 'bf16' or 'f16'")
         if inverse_precision != "f32" and spec.univariate != "affine":
@@ -102,6 +111,8 @@ class Flow:
             self._desc.lane16 = self._lane16.data_ptr()
             self._desc.lane16_fmt = 1 if inverse_precision == "bf16" else 2
         self._bf16 = None              # (gather map, image, elements per transform), built on first use
+        self.inverse_guard = None      # last result of check_inverse_precision
+        self.inverse_guard_enabled = bool(inverse_guard)
         self.repack()
 
     # ---------------------------------------------------------- checkpoints
@@ -112,12 +123,12 @@ class Flow:
                 "spec": (self.spec.n_dim, self.spec.n_transforms, self.spec.hidden, self.spec.univariate, self.spec.bins),
                 "params": self.params.detach().cpu().numpy(), "inverse_algo": self.inverse_algo,
                 "precision": self.precision, "train_engine": self.train_engine,
-                "inverse_precision": self.inverse_precision}
+                "inverse_precision": self.inverse_precision, "inverse_guard": self.inverse_guard_enabled}
 
     def __setstate__(self, st):
         spec = MAFSpec(*st["spec"])
         self.__init__(st["n_dim"], spec, precision=st.get("precision", "f32"), train_engine=st.get("train_engine"),
-                      inverse_precision=st.get("inverse_precision"))
+                      inverse_precision=st.get("inverse_precision"), inverse_guard=st.get("inverse_guard", True))
         self.set_params(st["params"])
         self.inverse_algo = st.get("inverse_algo", 0)
 
@@ -166,6 +177,65 @@ class Flow:
             raise ValueError("parameter vector has the wrong length")
         self.params.copy_(flat.to(self.device))
         self.repack()
+        self.check_inverse_precision()
+
+    # ------------------------------------------------------------ the 16-bit sweep's safety net
+    @property
+    def inverse_precision_active(self):
+        """What the sweep multiplies with right now: ``inverse_precision``, or "f32" after the guard fell back."""
+        return self.inverse_precision if (self._lane16 is not None and self._desc.lane16) else "f32"
+
+    @torch.no_grad()
+    def check_inverse_precision(self, theta=None, rows=2048, bound=None, ladj_bound=None):
+        """Run the 16-bit and the float32 lane sweep on ``theta`` (latent points of THIS flow: ``forward`` of its training
+        rows at the end of ``fit``, standard-normal draws of a fixed generator otherwise -- what ``mcmc.py:88`` hands to
+        ``flow.inverse`` once the flow fits) and compare walker by walker.  If the largest relative difference of x exceeds
+        ``bound`` or the largest difference of the log-determinant ``ladj_bound`` (or the 16-bit sweep leaves rows
+        non-finite that the float32 sweep does not), the flow falls back to the float32 sweep with a warning until its
+        parameters change again.  Returns the comparison (also kept as ``inverse_guard``); None for float32 flows and for
+        flows too narrow for the lane sweep."""
+        if self._lane16 is None or not self.inverse_guard_enabled:
+            return None
+        bound = LANE16_BOUND if bound is None else float(bound)
+        ladj_bound = LANE16_LADJ_BOUND if ladj_bound is None else float(ladj_bound)
+        self._desc.lane16 = self._lane16.data_ptr()              # (re-armed: new parameters get a new verdict)
+        if not self.lib.pmc_debug_inverse_uses_lane(C.byref(self._desc)):
+            self.inverse_guard = None                            # the narrow flows never take the 16-bit sweep
+            return None
+        if theta is None:
+            g = torch.Generator().manual_seed(20240929)
+            theta = torch.randn(int(rows), self.n_dim, generator=g, dtype=torch.float32)
+        theta = theta[:max(int(rows), 1024)].to(self.device, torch.float32).contiguous()
+        keep = self.inverse_algo
+        try:
+            self.inverse_algo = 9                                # PMC_INVERSE_TRIANGULAR_LANE16
+            x16, l16 = self.inverse(theta)
+            self.inverse_algo = 8                                # PMC_INVERSE_TRIANGULAR_LANE: float32 helpers
+            x32, l32 = self.inverse(theta)
+        finally:
+            self.inverse_algo = keep
+        ok32 = torch.isfinite(x32).all(dim=1) & torch.isfinite(l32)
+        ok16 = torch.isfinite(x16).all(dim=1) & torch.isfinite(l16)
+        lost = int((ok32 & ~ok16).sum().item())
+        both = ok32 & ok16
+        if bool(both.any()):
+            ex = ((x16 - x32).abs().max(dim=1).values / x32.abs().max(dim=1).values.clamp_min(1e-30))[both]
+            el = (l16 - l32).abs()[both]
+            x_max, x_med, l_max, l_med = (float(ex.max().item()), float(ex.median().item()),
+                                          float(el.max().item()), float(el.median().item()))
+        else:
+            x_max = x_med = l_max = l_med = float("nan")
+        passed = lost == 0 and x_max <= bound and l_max <= ladj_bound
+        self.inverse_guard = {"precision": self.inverse_precision, "rows": int(theta.shape[0]), "rows_compared": int(both.sum().item()),
+                              "rows_lost_by_16bit": lost, "x_rel_err_max": x_max, "x_rel_err_median": x_med,
+                              "ladj_abs_err_max": l_max, "ladj_abs_err_median": l_med, "bound": bound, "ladj_bound": ladj_bound,
+                              "passed": bool(passed)}
+        if not passed:
+            self._desc.lane16 = None                             # AUTO takes the float32 helpers from here on
+            warnings.warn(f"Flow: the {self.inverse_precision} inverse sweep is not an inverse of this flow within the bounds "
+                          f"(max relative error on x {x_max:.3g} > {bound:g}, or on the log-determinant {l_max:.3g} > {ladj_bound:g}, "
+                          f"or {lost} rows lost); falling back to the float32 sweep.")
+        return self.inverse_guard
 
     def state_dict(self):
         return {"params": self.params.detach().cpu().clone(), "n_dim": self.spec.n_dim,

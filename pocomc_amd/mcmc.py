@@ -177,24 +177,62 @@ def allreduce_sums(sums_dev, group=None):
 _COMMS = {}
 
 
+def _group_key(group):
+    """What identifies a process group across its lifetime: the global ranks of its members (``id(group)`` can be recycled
+    for another subgroup once a group is gone)."""
+    import torch.distributed as dist
+    if group is None:
+        return ("world", dist.get_world_size())
+    try:
+        return tuple(dist.get_process_group_ranks(group))
+    except Exception:
+        return ("id", id(group))
+
+
+def drop_comms():
+    """Destroy every communicator of this process (their mailboxes, mappings and shared-memory objects); the next sharded
+    step builds new ones.  Call before ``dist.destroy_process_group()`` in a long-lived process."""
+    from . import _lib as L
+    lib = L.load()
+    for h, _ in _COMMS.values():
+        if h:
+            lib.pmc_comm_destroy(h)
+    _COMMS.clear()
+
+
 def small_comm(lib, group, width):
-    """The library's own all-reduce for the D + 4 sums of a sharded step (``pmc_comm_*``: a mailbox per rank in its HBM,
-    shared through hipIpc handles; sums in rank order, so every rank holds the same bits): one communicator per process
-    group and process, created on first use -- the 64-byte handles travel through ``torch.distributed.all_gather_object``
-    (any backend), everything after that is device to device.  One node, one process per GPU, <= 8 ranks; returns None
-    where that does not hold or ``PMC_C_ALLREDUCE=0`` (the step then exchanges through ``torch.distributed``)."""
+    """The library's own all-reduce for the D + 4 sums of a sharded step (``pmc_comm_*``: a mailbox per rank, sums in rank
+    order, so every rank holds the same bits): one communicator per process group and process, created on first use -- the
+    64-byte handles travel through ``torch.distributed.all_gather_object`` (any backend), everything after that is device
+    to device.  Two kinds of mailbox, tried in this order (``PMC_COMM_MAILBOX=device|host`` fixes one): uncached HBM shared
+    through hipIpc handles (xGMI peer stores), then pinned host memory in POSIX shared memory (PCIe).  One node, one
+    process per GPU, <= 8 ranks; returns None where that does not hold, where neither kind passes its self-test exchange,
+    or with ``PMC_C_ALLREDUCE=0`` (the step then exchanges through ``torch.distributed``)."""
     import torch.distributed as dist
     if os.environ.get("PMC_C_ALLREDUCE", "1") == "0":
         return None
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if world > 8:
         return None
-    key = (id(group), world, rank)
+    key = (_group_key(group), world, rank)
     c = _COMMS.get(key)
     if c is not None and c[1] >= width:
         return c[0]
     w = max(int(width), 260)                          # (D <= 256: one communicator serves every engine of the group)
-    h = lib.pmc_comm_create(rank, world, w)
+    want = os.environ.get("PMC_COMM_MAILBOX", "")
+    kinds = [k for k in ("device", "host") if want in ("", k)]
+    h = None
+    for kind in kinds:
+        h = _try_comm(lib, group, world, rank, w, kind)
+        if h:
+            break
+    _COMMS[key] = (h, w if h else 1 << 30)
+    return h
+
+
+def _try_comm(lib, group, world, rank, w, kind):
+    import torch.distributed as dist
+    h = (lib.pmc_comm_create if kind == "device" else lib.pmc_comm_create_host)(rank, world, w)
     ok = bool(h)
     buf = (C.c_ubyte * 64)()
     if ok:
@@ -205,7 +243,6 @@ def small_comm(lib, group, width):
     if not all(a[1] for a in allh) or len({a[2] for a in allh}) != 1:
         if h:
             lib.pmc_comm_destroy(h)
-        _COMMS[key] = (None, 1 << 30)
         return None
     blob = b"".join(a[0] for a in allh)
     good = lib.pmc_comm_connect(h, blob) == 0
@@ -214,7 +251,7 @@ def small_comm(lib, group, width):
     if all(flags):
         # one exchange with known values before any step depends on the mailboxes: rank r sends r + 1 in every word (a
         # mapping that opened but whose stores do not arrive shows up here, as a timeout or a wrong sum, on every rank
-        # alike -- the step then exchanges through torch.distributed)
+        # alike -- the step then takes the next kind of mailbox, or torch.distributed)
         dev = torch.device("cuda", torch.cuda.current_device())
         part = torch.full((8,), float(rank + 1), dtype=torch.float64, device=dev)
         tot = torch.zeros(8, dtype=torch.float64, device=dev)
@@ -226,8 +263,7 @@ def small_comm(lib, group, width):
         dist.all_gather_object(flags, good, group=group)
     if not all(flags):
         lib.pmc_comm_destroy(h)
-        h = None
-    _COMMS[key] = (h, w)
+        return None
     return h
 
 
@@ -351,14 +387,6 @@ class StepEngine:
         self.h_clean.fill_(-1)
         self._np_clean = self.h_clean.numpy()
         self._clean_count = torch.zeros(1, dtype=torch.int32, device=dev)
-        # "head first" (pmc_step_t.head_rows): the fused launch sends the first head_rows rows of x' over PCIe before the
-        # others and raises a word of their own, so that the likelihood can start on them; 0: off
-        self.head_rows = 0
-        self.h_head = pin(3, dt=torch.int64)
-        self.h_head.zero_()
-        self._np_head = self.h_head.numpy()
-        self._head_ticket = torch.zeros(2, dtype=torch.int32, device=dev)
-        self._head_views = None
         # rows that do not reach the likelihood (x' or logp' not finite): their HOST rows of x' carry the walker's current x
         # (pmc_step_t.fill_rejected), so that up to fill_rejected_max * n such rows cost a few wasted evaluations instead of
         # the gather x'[mask] of mcmc.py:117 (280 us for 6.5e3 x 50 doubles); their logl' is -inf either way (:118-121)
@@ -548,8 +576,7 @@ class StepEngine:
     def _configure_step(self):
         """The fields of the composite entry points' struct that depend on the engine's switches only: written when
         one of them changed."""
-        cfg = (self.flow.inverse_algo if self.pre else 0, self.rng_prefill, self.host_direct, self.spin_wait, int(self.head_rows),
-               bool(self.fill_rejected))
+        cfg = (self.flow.inverse_algo if self.pre else 0, self.rng_prefill, self.host_direct, self.spin_wait, bool(self.fill_rejected))
         if cfg != self._pre_cfg:
             self._pre_cfg = cfg
             if self.pre:
@@ -565,19 +592,10 @@ class StepEngine:
             self._step.clean_count = self._clean_count.data_ptr() if self._direct_now else None
             self._step.ev_pre_done = None if self._direct_now else self._ev_pre     # (the completion word replaces it)
             self._step.fill_rejected = int(bool(self.fill_rejected) and self._direct_now)
-            h = int(self.head_rows)
-            if h % 16 or not 0 <= h < self.n:
-                raise ValueError("head_rows: a multiple of 16 below the number of rows")
-            self._step.head_rows = h if self._direct_now else 0
-            self._step.h_head = self.h_head.data_ptr() if self._direct_now else None
-            self._step.head_ticket = self._head_ticket.data_ptr() if self._direct_now else None
-            self._np_head[2] = 0
-            self._head_views = (self._np_x[:h], self._np_x[h:], self._np_logl[:h], self._np_logl[h:]) if h else None
 
-    def evaluate(self, log_prior, log_like, have_blobs=False, blobs=None, waited=False, rest=None):
+    def evaluate(self, log_prior, log_like, have_blobs=False, blobs=None, waited=False):
         """Host black boxes on the compacted rows, ``mcmc.py:100-121``.  Returns
-        ``(n_calls, blobs_prime)``.  ``rest``: the caller waited for the head of x' only (``head_rows``); ``rest()`` waits
-        for the other rows."""
+        ``(n_calls, blobs_prime)``."""
         tm = self.host_timers
         t0 = time.perf_counter() if tm is not None else 0.0
         if waited:
@@ -602,26 +620,6 @@ class StepEngine:
             def log_like(a, _f=_ll):
                 ta = time.perf_counter(); r = _f(a); tm["likelihood"] += time.perf_counter() - ta
                 return r
-        if rest is not None:
-            if (self.prior_desc is not None and self._head_views is not None and self._direct_now and self._np_head[1] == 0
-                    and self.host_threads <= 1 and not have_blobs):
-                # the rows of the head are in host memory and clean: their likelihood runs while the others cross the link
-                xh, xt, lh, lt = self._head_views
-                ta = time.perf_counter() if tm is not None else 0.0
-                lh[:] = log_like(xh)[0]
-                tb = time.perf_counter() if tm is not None else 0.0
-                rest()
-                tc = time.perf_counter() if tm is not None else 0.0
-                if self._np_clean[0] == 0:
-                    lt[:] = log_like(xt)[0]
-                    if tm is not None:
-                        tm["head_likelihood"] = tm.get("head_likelihood", 0.0) + tb - ta
-                        tm["head_rest_wait"] = tm.get("head_rest_wait", 0.0) + tc - tb
-                        tm["head_tail_likelihood"] = tm.get("head_tail_likelihood", 0.0) + time.perf_counter() - tc
-                    return self.n, None
-                # (a row behind the head is not clean: the masks below, on all rows -- rare)
-            else:
-                rest()
         if self.prior_desc is not None:
             log_prior = None                          # logp' came back from the device with x'
             if ((waited or self._post_uploads) and self._direct_now and self._np_clean[0] == 0
@@ -788,7 +786,7 @@ class LanedEngine:
     the order in which the D+4 sums are added (last bits of mean(alpha), mean(theta))."""
 
     def __init__(self, kind, n, n_dim, flow, scaler, lanes=2, group=None, shard_offset=0, seed=0, x_order="C",
-                 streams=True, first_fraction=None, head_rows=0):
+                 streams=True, first_fraction=None):
         """``streams=False``: all lanes on the current stream, one after the other (the pipelined mode:
         :meth:`start_pipeline` / :meth:`step_pipelined`)."""
         n = int(n)
@@ -815,10 +813,6 @@ class LanedEngine:
                 e = StepEngine(kind, hi - lo, n_dim, flow, scaler, group=group, shard_offset=int(shard_offset) + lo,
                                seed=seed, x_order=x_order)
             self.lanes.append(e)
-        # "head first": lane 0 is the one the host waits for with nothing else to do -- its launch sends its first rows over
-        # PCIe ahead of the others (pmc_step_t.head_rows; the pipelined mode evaluates them while the rest arrives)
-        h = (int(head_rows) // 16) * 16
-        self.lanes[0].head_rows = h if 0 < h < self.lanes[0].n else 0
         self.lib = self.lanes[0].lib
         self.tpcn, self.pre = self.lanes[0].tpcn, self.lanes[0].pre
         self._tot = torch.zeros(self.D + 4, dtype=torch.float64, device=self.device)
@@ -907,6 +901,18 @@ class LanedEngine:
             e.host_timers = self.host_timers
             e.propose(None, nu)
 
+    def resume_pipeline(self, nu):
+        """Pre-steps of the next step into the queue of a pipeline whose last step enqueued none (``more=False``): what
+        :meth:`start_pipeline` does at the head of a call, without rebuilding the pipeline object -- the adaptation state
+        on the device is the one the last step left."""
+        first = self.lanes[0]
+        if self._pipe:
+            _lib.check(self.lib.pmc_pipeline_start(self._pipe, float(nu), int(first.step_idx)), "pmc_pipeline_start")
+            return
+        for e in self.lanes:
+            e.host_timers = self.host_timers
+            e.propose(None, nu, step=e.step_idx)
+
     def pipeline_stats(self, reset=True):
         """Host seconds the C pipeline spent {waiting for x', waiting for the sums, enqueuing accepts, enqueuing
         pre-steps} and the steps they cover, since the last reset (None without a C pipeline)."""
@@ -931,12 +937,7 @@ class LanedEngine:
             calls = 0
             for k, e in enumerate(self.lanes):
                 e.host_timers = tm
-                rest = None
-                if e._np_head[2] == 1:              # (pmc_pipeline_next returned behind the head of this lane's x' only)
-                    def rest(k=k):
-                        if self.lib.pmc_pipeline_wait_lane(P, k):
-                            _lib.check(1, "pmc_pipeline_wait_lane")
-                calls += e.evaluate(log_prior, log_like, waited=True, rest=rest)[0]
+                calls += e.evaluate(log_prior, log_like, waited=True)[0]
                 if nxt(P, k, beta, nu, mode, c_sigma, c_mu, cap, n_total, int(more)):
                     _lib.check(1, "pmc_pipeline_next")
             for e in self.lanes:
@@ -1095,6 +1096,16 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
 
     log_like = function_dict.get("loglike")
     log_prior = function_dict.get("logprior")
+    # rows actually handed to the likelihood: with ``fill_rejected`` (default for the pipelined step) a row that does not
+    # reach the reference's likelihood call (mcmc.py:117: x'[mask]) is passed with the walker's CURRENT x and its value
+    # dropped -- the likelihood must be row-wise and free of side effects (it is for the reference, which calls it on
+    # arbitrary compacted subsets); results["calls"] counts the reference's rows, results["evaluations"] these
+    _rows_passed = []
+    _user_like = log_like
+
+    def log_like(a, _f=_user_like, _seen=_rows_passed.append):
+        _seen(len(a))
+        return _f(a)
     scaler = function_dict.get("scaler")
     flow = function_dict.get("flow") if pre else None
     geometry = function_dict.get("theta_geometry" if pre else "u_geometry")
@@ -1125,7 +1136,7 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
                  and replay is None and all(option_dict.get(k, True) for k in ("host_direct", "spin_wait")))
     if lanes > 1 or want_pipe:                      # (the pipelined step lives behind pmc_pipeline_*: one lane is a pipeline too)
         eng = LanedEngine(kind, n_walkers, n_dim, flow, scaler, lanes=lanes, group=group,
-                          first_fraction=option_dict.get("first_lane"), head_rows=int(option_dict.get("head_rows") or 0),
+                          first_fraction=option_dict.get("first_lane"),
                           shard_offset=option_dict.get("shard_offset", 0), seed=seed, x_order=x_order,
                           streams=not want_pipe)
         tune = eng.configure
@@ -1233,7 +1244,8 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
     for e_ in (eng.lanes if laned else [eng]):
         e_._recycle = True
     return dict(u=out["u"], x=out["x"], logdetj=out["logdetj"], logl=out["logl"], logp=out["logp"], blobs=blobs,
-                efficiency=ad.sigma, accept=ad.mean_alpha, steps=ad.i, calls=n_calls, proposal_scale=ad.sigma)
+                efficiency=ad.sigma, accept=ad.mean_alpha, steps=ad.i, calls=n_calls, proposal_scale=ad.sigma,
+                evaluations=int(sum(_rows_passed)))
 
 
 def preconditioned_pcn(state_dict, function_dict, option_dict, replay=None, trace=None):

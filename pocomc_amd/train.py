@@ -612,4 +612,17 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
         _pinned_give(t)
     if getattr(flow, "_bf16", None) is not None or getattr(flow, "_lane16", None) is not None:
         flow.repack()                              # the 16-bit images follow the trained float32 parameters
+    if getattr(flow, "_lane16", None) is not None:
+        # the 16-bit sweep's safety net: compared with the float32 sweep on the latent image of the training rows
+        # (what mcmc.py:88 inverts), float32 from here on if it is not an inverse within the bounds
+        guard = flow.check_inverse_precision(theta=flow.forward(x[:4096])[0], rows=4096)
+        if guard is not None:
+            if sharded:
+                # every rank takes the same sweep: one rank's fallback is everybody's
+                flag = torch.tensor([0.0 if guard["passed"] else 1.0], device=dev)
+                dist.all_reduce(flag, group=group)
+                if float(flag.item()) > 0 and guard["passed"]:
+                    flow._desc.lane16 = None
+                    guard["passed"] = False
+            history["inverse_guard"] = guard
     return history

@@ -147,9 +147,9 @@ def test_lane_sweep_with_16bit_helpers_against_the_float32_sweep(D, T, n, prec):
     flat = cases.flow_params(spec, 3)
     f32 = Flow(D, spec)
     f32.set_params(flat)
-    f16 = Flow(D, spec, inverse_precision=prec)
+    f16 = Flow(D, spec, inverse_precision=prec, inverse_guard=False)       # (the raw 16-bit sweep: the guard has its own test below)
     f16.set_params(flat)
-    assert f16.inverse_precision == prec and f16._desc.lane16
+    assert f16.inverse_precision == prec and f16._desc.lane16 and f16.inverse_guard is None
     z = (np.random.default_rng(n).normal(size=(n, D)) * 1.2).astype(np.float32)
     f32.inverse_algo = 8                                     # PMC_INVERSE_TRIANGULAR_LANE: float32 helpers
     xr, lr = (t.numpy() for t in f32.inverse(torch.from_numpy(z)))
@@ -184,3 +184,95 @@ def test_lane_sweep_with_16bit_helpers_against_the_float32_sweep(D, T, n, prec):
     xa, _ = f16.inverse(torch.from_numpy(z[:256]))
     xb, _ = f32.inverse(torch.from_numpy(z[:256]))
     assert (np.abs(xa.numpy() - xb.numpy()).max(axis=1) / np.abs(xb.numpy()).max(axis=1)).max() < tx
+
+
+def test_the_16bit_sweep_is_guarded():
+    """``Flow.inverse`` is an INVERSE (``pocomc/flow.py:116-132``): whenever the parameters of a flow with
+    ``inverse_precision != "f32"`` change, the 16-bit and the float32 sweep are compared on latent points of the flow and the
+    flow goes back to float32, with a warning, if a walker's x differs by more than ``LANE16_BOUND`` (1e-2 relative) or its
+    log-determinant by more than ``LANE16_LADJ_BOUND`` (0.1).  Default construction and old checkpoints are float32."""
+    import pickle
+    import warnings
+    from pocomc_amd import Flow
+    from pocomc_amd.flow import LANE16_BOUND
+    D, T = 128, 8
+    spec = MAFSpec(D, T)
+    flat = cases.flow_params(spec, 3)
+    # precision="bf16" alone no longer switches the inverse to 16 bits (ADVICE r4)
+    assert Flow(D, spec, precision="bf16").inverse_precision == "f32"
+    z = torch.from_numpy((np.random.default_rng(5).normal(size=(512, D)) * 1.2).astype(np.float32))
+    ref = Flow(D, spec)
+    ref.set_params(flat)
+    ref.inverse_algo = 8
+    xr, lr = ref.inverse(z)
+    seen = {}
+    for prec in ("bf16", "f16"):
+        f = Flow(D, spec, inverse_precision=prec)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            f.set_params(flat * np.float32(1.2))              # a flow of 1.2 x the default initialisation: bf16 is 4e-2 off there
+        g = f.inverse_guard
+        assert g is not None and g["rows"] >= 1024 and g["precision"] == prec
+        seen[prec] = (g["x_rel_err_max"], g["ladj_abs_err_max"], g["passed"])
+        fired = any("falling back to the float32 sweep" in str(m.message) for m in w)
+        assert fired == (not g["passed"])
+        assert f.inverse_precision_active == (prec if g["passed"] else "f32")
+        if not g["passed"]:
+            # AUTO is the float32 sweep now, bit for bit
+            r32 = Flow(D, spec)
+            r32.set_params(flat * np.float32(1.2))
+            r32.inverse_algo = 8
+            xa, la = f.inverse(z)
+            xb, lb = r32.inverse(z)
+            np.testing.assert_array_equal(xa.numpy(), xb.numpy())
+            np.testing.assert_array_equal(la.numpy(), lb.numpy())
+            # new parameters get a new verdict: a tame flow passes again
+            f.set_params(flat * np.float32(0.25))
+            assert f.inverse_guard["passed"] and f.inverse_precision_active == prec
+    print("guard at 1.2 x init:", seen)
+    assert not seen["bf16"][2] and seen["bf16"][0] > LANE16_BOUND       # (measured 3.8e-2 in round 4)
+    # checkpoints: the key travels; a state without it reloads as float32
+    f = Flow(D, spec, inverse_precision="f16")
+    f.set_params(flat * np.float32(0.25))
+    g = pickle.loads(pickle.dumps(f))
+    assert g.inverse_precision == "f16" and g.inverse_guard is not None
+    st = f.__getstate__()
+    st.pop("inverse_precision")
+    h = Flow.__new__(Flow)
+    h.__setstate__(st)
+    assert h.inverse_precision == "f32" and h._lane16 is None
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_the_guard_on_a_trained_config3_flow(prec):
+    """BASELINE config 3's flow (maf6 at D = 50) trained as ``bench.py`` trains it (50 epochs on prior draws through the
+    scaler): round 4 measured a maximum relative error of 33.8 on x for the f16 sweep on that flow.  ``Flow.fit`` ends with
+    the guard on the latent image of its training rows: either the sweep is within the bounds or the flow is back on float32."""
+    from pocomc_amd import Flow, Reparameterize
+    D, n = 50, 10000
+    rng = np.random.default_rng(7)
+    x_fit = rng.uniform(-10.0, 10.0, size=(2 * n, D))
+    scaler = Reparameterize(D, bounds=np.array([[-10.0, 10.0]] * D))
+    scaler.fit(x_fit)
+    torch.manual_seed(0)
+    u_fit = torch.from_numpy(scaler.forward(x_fit[:n])).float()
+    f = Flow(D, "maf6", seed=0, inverse_precision=prec)
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        hist = f.fit(u_fit, epochs=50, batch_size=512, validation_split=0.5, patience=D, annealing=False, verbose=0)
+    g = hist["inverse_guard"]
+    print(f"config-3 flow, {prec} sweep after {len(hist['loss'])} epochs: {g}")
+    assert g is f.inverse_guard and g["rows"] >= 1024
+    if g["passed"]:
+        assert g["x_rel_err_max"] <= g["bound"] and g["ladj_abs_err_max"] <= g["ladj_bound"] and g["rows_lost_by_16bit"] == 0
+        assert f.inverse_precision_active == prec
+    else:
+        assert f.inverse_precision_active == "f32" and any("falling back" in str(m.message) for m in w)
+    # whatever the verdict: what the step calls now is an inverse of the flow's forward map within the guard's bound
+    th = f.forward(u_fit[:2048])[0]
+    back = f.inverse(th)[0]
+    ok = torch.isfinite(back).all(dim=1)
+    err = ((back - u_fit[:2048]).abs().max(dim=1).values / u_fit[:2048].abs().max(dim=1).values)[ok]
+    print(f"round trip through forward / inverse ({f.inverse_precision_active}): max {float(err.max()):.3g} median {float(err.median()):.3g}, rows {int(ok.sum())}")
+    assert float(err.median()) < 1e-2

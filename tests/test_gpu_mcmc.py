@@ -846,66 +846,6 @@ def test_rows_that_do_not_reach_the_likelihood_are_filled_not_gathered(kind, flo
     assert sum(seen[1]) == b["calls"] < 8 * N                                      # gathered: exactly the rows of x'[mask]
 
 
-@pytest.mark.parametrize("holes", [False, True])
-@pytest.mark.parametrize("N,lanes,head", [(1000, 1, 256), (2000, 2, 512), (4100, 3, 16)])
-def test_head_first_rows_give_the_same_call(N, lanes, head, holes, monkeypatch):
-    """``pmc_step_t.head_rows``: the fused launch of lane 0 sends its first rows over PCIe ahead of the others and raises
-    a word of their own; the host evaluates them while the rest arrives (``mcmc.py:100-121`` in two calls).  Same walkers,
-    sums and counts as without a head, bit for bit -- with a clean likelihood (the two-call fast path) and with proposals
-    outside the prior's support (the head's count sends the lane to the masks)."""
-    from scipy.stats import uniform
-    import pocomc_amd as pc
-    from pocomc_amd import mcmc as pmcmc
-    from pocomc_amd.geometry import Geometry
-    import torch
-    D = 6
-    prior = pc.Prior([uniform(-5, 10)] * D) if not holes else pc.Prior([uniform(-3, 6)] * D)
-    rng = np.random.default_rng(N + lanes)
-    scaler = pc.Reparameterize(D, bounds=np.array([[-10.0, 10.0]] * D))
-    x = rng.uniform(-2.5, 2.5, size=(N, D))
-    scaler.fit(x)
-    u = scaler.forward(x)
-    seen = []
-
-    def like(xx):
-        seen.append(xx.shape[0])
-        return -0.5 * np.sum(xx ** 2, axis=1), None
-    flow = pc.Flow(D, "maf3", seed=0)
-    geo = Geometry()
-    geo.fit(flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64))
-    geo.normal_cov = np.cov(u.T)
-    res, honoured, shapes = [], [], []
-    real = pmcmc.LanedEngine.start_pipeline
-    for h in (head, 0):
-        engines = []
-
-        def spy(self, *a, _real=real, _e=engines, **k):
-            _real(self, *a, **k)
-            _e.append(self)
-        monkeypatch.setattr(pmcmc.LanedEngine, "start_pipeline", spy)
-        del seen[:]
-        state = dict(u=u.copy(), x=x.copy(), logdetj=scaler.inverse(u)[1], logl=like(x)[0], logp=prior.logpdf(x),
-                     beta=0.5, blobs=None)
-        funcs = dict(loglike=like, logprior=prior.logpdf, scaler=scaler, flow=flow, theta_geometry=geo, u_geometry=geo)
-        opts = dict(n_max=12, n_steps=10 ** 6, progress_bar=None, proposal_scale=(2.38 if holes else 0.5) / D ** 0.5, seed=5,
-                    lanes=lanes, x_order="F", head_rows=h)
-        res.append(pmcmc.preconditioned_pcn(state, funcs, opts))
-        monkeypatch.setattr(pmcmc.LanedEngine, "start_pipeline", real)
-        e0 = engines[0].lanes[0]
-        honoured.append((int(e0.head_rows), int(e0._np_head[2]), int(e0._np_head[0])))
-        shapes.append(sorted(set(seen[1:])))
-    assert honoured[0][:2] == (head, 1) and honoured[0][2] >= 12 and honoured[1][:2] == (0, 0), honoured
-    if not holes:
-        assert head in shapes[0] and head not in shapes[1], shapes      # the likelihood saw the head as a call of its own
-    a, b = res
-    assert a["steps"] == b["steps"] == 12 and a["calls"] == b["calls"]
-    if holes:
-        assert a["calls"] < 12 * N
-    for k in ("u", "x", "logl", "logp", "logdetj"):
-        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
-    assert a["proposal_scale"] == b["proposal_scale"] and a["accept"] == b["accept"] and a["efficiency"] == b["efficiency"]
-
-
 @pytest.mark.parametrize("name", ["tpcn_n256_d10_normal", "tpcn_n128_d6_mixed_bc"])
 def test_likelihoods_with_holes_match_the_oracle(name):
     """Edge cases of mcmc.py:100-134: a likelihood that is -inf on part of the space and NaN on another part

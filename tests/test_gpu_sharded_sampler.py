@@ -194,32 +194,41 @@ def test_two_rank_pipelined_kernel_call_equals_one_rank(tmp_path, lanes):
     np.testing.assert_allclose(np.concatenate([r0["logl"], r1["logl"]])[same], whole["logl"][same], rtol=1e-8)
 
 
-def _comm_worker(rank, world, port, out, c_allreduce):
+def _comm_worker(rank, world, port, out, c_allreduce, mailbox):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      PMC_C_ALLREDUCE=c_allreduce)
+                      PMC_C_ALLREDUCE=c_allreduce, PMC_COMM_MAILBOX=mailbox)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pocomc_amd import mcmc as pmcmc
     lo, hi = rank * 320, (rank + 1) * 320
     r = _kernel_call(lo, hi, 2, dict(group=None, shard_offset=lo))
     used = any(v[0] for v in pmcmc._COMMS.values())
-    np.savez(out % rank, u=r["u"], x=r["x"], logl=r["logl"], sigma=r["proposal_scale"], accept=r["accept"], steps=r["steps"], used=used)
+    kinds = sorted({int(pmcmc._lib.load().pmc_comm_kind(v[0])) for v in pmcmc._COMMS.values() if v[0]})
+    np.savez(out % rank, u=r["u"], x=r["x"], logl=r["logl"], sigma=r["proposal_scale"], accept=r["accept"], steps=r["steps"], used=used,
+             kinds=np.array(kinds, dtype=np.int64))
+    pmcmc.drop_comms()
+    assert not pmcmc._COMMS
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_the_sharded_step_behind_the_c_abi_equals_the_torch_distributed_path(tmp_path):
+@pytest.mark.parametrize("mailbox", ["device", "host"])
+def test_the_sharded_step_behind_the_c_abi_equals_the_torch_distributed_path(tmp_path, mailbox):
     """Two ranks, walkers sharded: the step runs behind ``pmc_pipeline_*`` with the library's own all-reduce between the
-    last accept and the adaptation (``pmc_comm_adapt_update``: hipIpc-shared mailboxes, the ranks' sums added in rank
-    order) -- bit for bit what the round-2 Python pipeline produces with ``torch.distributed.all_reduce`` in that place
-    (``PMC_C_ALLREDUCE=0``): with two ranks a + b is the same double in either order."""
+    last accept and the adaptation (``pmc_comm_adapt_update``: the ranks' sums added in rank order) -- bit for bit what the
+    round-2 Python pipeline produces with ``torch.distributed.all_reduce`` in that place (``PMC_C_ALLREDUCE=0``): with two
+    ranks a + b is the same double in either order.  ``mailbox="device"``: uncached HBM shared through hipIpc handles (two
+    processes on one GPU map LOCAL memory).  ``mailbox="host"``: the mailboxes in pinned host memory (POSIX shared memory
+    registered with both runtimes) -- every system-scope store, sequence word and acquire-poll of the protocol crosses
+    PCIe to memory no device caches: the stand-in for a remote target on a one-GPU box."""
     import torch.multiprocessing as mp
     res = {}
     for flag in ("1", "0"):
         out = str(tmp_path / f"c{flag}_%d.npz")
-        mp.spawn(_comm_worker, args=(2, _free_port(), out, flag), nprocs=2, join=True)
+        mp.spawn(_comm_worker, args=(2, _free_port(), out, flag, mailbox), nprocs=2, join=True)
         res[flag] = [np.load(out % 0), np.load(out % 1)]
     assert bool(res["1"][0]["used"]) and bool(res["1"][1]["used"])          # the communicator was created and connected
+    assert res["1"][0]["kinds"].tolist() == res["1"][1]["kinds"].tolist() == [0 if mailbox == "device" else 1]
     assert not bool(res["0"][0]["used"])
     for rk in (0, 1):
         a, b = res["1"][rk], res["0"][rk]
