@@ -393,6 +393,8 @@ def main():
     pc_prior = Prior([sp_uniform(p_lo, p_hi - p_lo)] * D)                   # pocoMC's own prior object
     device_prior = (not args.host_prior) and eng.set_device_prior(pc_prior)
     eng.load_state(u, x, logdetj, logl, logp)
+    if flow.inverse_precision_active != "f32":
+        flow.check_inverse_precision(theta=eng.theta32[:4096], rows=4096)      # as mcmc._run does at the head of a call
     eng.set_geometry(mu=geo.t_mean, cov=geo.t_cov)
     ad = Adaptation("preconditioned_pcn", D, n * world, n_steps=10 ** 9, n_max=10 ** 9, sigma0=sigma0,
                     mu0=geo.t_mean, logp2_0=-np.inf)

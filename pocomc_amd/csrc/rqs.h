@@ -254,10 +254,15 @@ __device__ __forceinline__ void rqs_inverse_split_sh(const f32x4& o0, const f32x
     const float a0 = c1 ? g1 : g0, a1 = c1 ? g2 : g1, b0 = c1 ? i1 : i0, b1 = c1 ? i2 : i1;
     const int k = (c4 ? 4 : 0) + (c2 ? 2 : 0) + (c1 ? 1 : 0);
     const float q0 = par[2 * RQS_K + (k >= 1 ? k - 1 : 0)], q1 = par[2 * RQS_K + (k + 1 < RQS_K ? k : 0)];
+    // the bin's own unnormalised width and height (two more indexed reads of the panel row): dx and dy as w_k / sum and
+    // h_k / sum carry the rounding of ONE weight -- as differences of knots near +-5 they carried ~eps * 5 each, 1e-5 of a
+    // narrow bin (round 5: the step's worst walker against the float64 evaluation, 1.13e-5 -> see tests/test_gpu_mcmc.py)
+    const float wk = par[k], hk = par[RQS_K + k];
+    (void)a1; (void)b1;
     RQS_SLOT(11)
-    // ---- E: the bin's knots (while the two derivatives are on their way)
-    const float y0 = a0 * rh - RQS_BOUND, y1 = a1 * rh - RQS_BOUND, x0 = b0 * rw - RQS_BOUND, x1 = b1 * rw - RQS_BOUND;
-    const float dx = x1 - x0, dy = y1 - y0;
+    // ---- E: the bin's knots (while the derivatives are on their way)
+    const float y0 = a0 * rh - RQS_BOUND, x0 = b0 * rw - RQS_BOUND;
+    const float dx = wk * rw, dy = hk * rh;
     const float s = dy * rqs_rcp(dx);
     const float yr = inside ? y - y0 : 0.0f;
     RQS_SLOT(12)

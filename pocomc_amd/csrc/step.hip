@@ -74,10 +74,10 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
     double* lp2 = (direct && pr) ? s->h_logp_out : nullptr;
     pmc_done_t dn{s->h_done, (int64_t)rng->step + 1, s->done_ticket};
     const pmc_done_t* done = (direct && s->h_done && s->done_ticket) ? &dn : nullptr;
-    if (s->preconditioned && !(s->no_fuse & 1) && !pmc_tri6_preferred(s->maf) &&
+    if (s->preconditioned && !(s->no_fuse & 1) &&
         (s->inverse_algo == PMC_INVERSE_AUTO || s->inverse_algo == PMC_INVERSE_TRIANGULAR)) {
-        // proposal + flow inverse (+ scaler) in one launch (affine flows, D <= 64, fewer than 16 hidden tiles -- the wider
-        // ones take the lane-per-walker sweep, which has no fused instance); no_fuse & 2 keeps the scaler apart
+        // proposal + flow inverse (+ scaler) in one launch (the two-wave sweeps for D <= 64 and fewer than 16 hidden tiles,
+        // the lane-per-walker sweep for the wider flows up to D = 128); no_fuse & 2 keeps the scaler apart
         ScalerEpi epi{};
         const bool want_epi = !(s->no_fuse & 2) && s->scaler && s->scaler->low && s->scaler->high && s->scaler->kind &&
                               s->scaler->log_width && (!s->scaler->scale || (s->scaler->mu && s->scaler->sigma)) &&

@@ -1160,6 +1160,16 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
     if owner is not None and option_dict.get("device_prior", True) and hasattr(owner, "device_descriptor"):
         eng.set_device_prior(owner)                 # Prior.logpdf of uniform / normal factors on the device
     eng.load_state(u, x, logdetj, logl, logp)
+    if pre and getattr(flow, "inverse_precision_active", "f32") != "f32":
+        # the 16-bit sweep's safety net where the sweep is used: on THESE walkers' theta = flow.forward(u) (mcmc.py:60),
+        # which need not look like the rows the flow was fitted on; float32 from here on if it is not an inverse there
+        th = (eng.lanes[0] if isinstance(eng, LanedEngine) else eng).theta32
+        guard = flow.check_inverse_precision(theta=th[:4096], rows=4096)
+        if sharded and guard is not None:
+            flag = torch.tensor([0.0 if guard["passed"] else 1.0], device=eng.device)
+            dist.all_reduce(flag, group=group)
+            if float(flag.item()) > 0:
+                flow._desc.lane16 = None
     nu = 0.0
     if tpcn:
         nu = float(geometry.t_nu)
