@@ -637,7 +637,10 @@ def main():
                                          - laned_host.get("enqueue_next_pre", 0.0) - laned_host.get("enqueue_adapt", 0.0)
                                          - laned_host.get("wait_sums", 0.0))
         leng.host_timers = None
-        if os.environ.get("PMC_BENCH_EPI_STAMPS") and rank == 0:
+        if os.environ.get("PMC_BENCH_EPI_STAMPS") and rank == 0 and not hasattr(lib, "pmc_debug_set_epilogue_stamps"):
+            print("[epilogue stamps] this library was built without the measurement hooks: make -C pocomc_amd/csrc clean all DEBUG_HOOKS=1",
+                  file=sys.stderr)
+        elif os.environ.get("PMC_BENCH_EPI_STAMPS") and rank == 0:
             # measurement only: where the fused launch of lane 0 spends its epilogue (100 MHz stamps per workgroup)
             import ctypes
             nb = (leng.lanes[0].n + 15) // 16

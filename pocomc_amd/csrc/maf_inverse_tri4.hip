@@ -448,14 +448,7 @@ int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* 
         ProposeArgs pan{kind, cur32, mu, inv_cov, chol, nu, sigma, cn_a, *rng, prop64, quad, quad_prop, adapt};
         return pmc_launch_propose_inverse_nsf2(&pan, epi, epi_done, m, x, ladj, n, stream);
     }
-    if (m->n_out != 2 || !m->tri_ok) return -1;
-    if (m->nOT > 8 || m->D > 64 || pmc_tri6_preferred(m)) {
-        // the wide flows: the lane-per-walker sweep with the proposal as its prologue and -- when its tables fit the idle
-        // activation arrays -- the scaler / prior / hand-over of x' as its epilogue (round 5; D <= 128)
-        ProposeArgs pw{kind, cur32, mu, inv_cov, chol, nu, sigma, cn_a, *rng, prop64, quad, quad_prop, adapt};
-        if (epi && epi_done && epi->s.D == m->D) { pw.epi = *epi; pw.epi.on = 1; }
-        return pmc_launch_tri6(&pw, m, nullptr, x, ladj, n, stream, epi_done);
-    }
+    if (m->n_out != 2 || !m->tri_ok || m->nOT > 8 || m->D > 64) return -1;
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
     const int maxo = m->nOT <= 4 ? 4 : 8;
     const size_t lds = (size_t)(2 * m->Dp * 16 + 2 * m->Hp * 16 + 3 * 256 + maxo * 256 + DG_WORDS(m)) * sizeof(float);
@@ -527,8 +520,10 @@ int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* 
 #define OOB_VOFF 0x40000000        // a lane offset beyond every image: the bounds-checked load returns zeros
 
 template <int MAXO, int FM>
-__device__ __forceinline__ void tri5_body(const pmc_maf_t& m, const float* __restrict__ in, float* __restrict__ out,
-                                          float* __restrict__ ladj_out, int64_t n, const ProposeArgs& pa) {
+__global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pmc_maf_t m, const float* __restrict__ in,
+                                                                              float* __restrict__ out,
+                                                                              float* __restrict__ ladj_out, int64_t n,
+                                                                              ProposeArgs pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1001,30 +996,6 @@ __device__ __forceinline__ void tri5_body(const pmc_maf_t& m, const float* __res
     }
 }
 
-// The sweep as two kernels: one wavefront per SIMD (the compiler takes what it needs: 366 registers at maf3 / D = 32), and
-// the OCCUPANCY instance -- at most 256 registers, two wavefronts per SIMD, i.e. four workgroups (1024 walker sets) resident
-// per CU, so that 1e4 walkers are one round ("Round 5": what the register cut costs).
-template <int MAXO, int FM>
-__global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pmc_maf_t m, const float* __restrict__ in,
-                                                                              float* __restrict__ out,
-                                                                              float* __restrict__ ladj_out, int64_t n,
-                                                                              ProposeArgs pa) {
-    tri5_body<MAXO, FM>(m, in, out, ladj_out, n, pa);
-}
-template <int MAXO, int FM>
-__global__ __launch_bounds__(64 * (TRI5_NC + 1), 2) void maf_inverse_tri5_occ2_kernel(pmc_maf_t m, const float* __restrict__ in,
-                                                                                   float* __restrict__ out,
-                                                                                   float* __restrict__ ladj_out, int64_t n,
-                                                                                   ProposeArgs pa) {
-    tri5_body<MAXO, FM>(m, in, out, ladj_out, n, pa);
-}
-
-// PMC_TRI5_OCC=2: the occupancy instance (A/B runs; MAXO = 4 only -- the 8-output-tile instances spill at 512 registers already)
-static bool tri5_occ2() {
-    static const bool on = getenv("PMC_TRI5_OCC") && atoi(getenv("PMC_TRI5_OCC")) == 2;
-    return on;
-}
-
 // -1: automatic (by size), 0: never, 1: always
 static int tri5_mode() {
     static const int mode = getenv("PMC_INVERSE_DUO") ? atoi(getenv("PMC_INVERSE_DUO")) : -1;
@@ -1058,29 +1029,21 @@ static int launch_tri5(const ProposeArgs* pa, const pmc_maf_t* m, const float* z
     const ProposeArgs none{};
     const int64_t nsets = (n + 15) / 16;
     const unsigned grid = (unsigned)((nsets + TRI5_NC - 1) / TRI5_NC);
-#define LAUNCH5K(KERNEL, MO, FMV)                                                                                 \
+#define LAUNCH5(MO, FMV)                                                                                          \
     {                                                                                                             \
         if (lds > 48 * 1024) {                                                                                    \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<MO, FMV>),                    \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_inverse_tri5_kernel<MO, FMV>),   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
             if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_inverse_tri5_kernel)");          \
         }                                                                                                         \
-        hipLaunchKernelGGL((KERNEL<MO, FMV>), dim3(grid), dim3(64 * (TRI5_NC + 1)), lds,                           \
+        hipLaunchKernelGGL((maf_inverse_tri5_kernel<MO, FMV>), dim3(grid), dim3(64 * (TRI5_NC + 1)), lds,          \
                            stream, *m, z, x, ladj, n, pa ? *pa : none);                                           \
     }
-#define LAUNCH5(MO, FMV) LAUNCH5K(maf_inverse_tri5_kernel, MO, FMV)
-    if (maxo == 4 && tri5_occ2()) {
-        if (!pa || !pa->cur32) LAUNCH5K(maf_inverse_tri5_occ2_kernel, 4, 0)
-        else if (m->D <= 16) LAUNCH5K(maf_inverse_tri5_occ2_kernel, 4, 4)
-        else if (m->D <= 32) LAUNCH5K(maf_inverse_tri5_occ2_kernel, 4, 8)
-        else LAUNCH5K(maf_inverse_tri5_occ2_kernel, 4, 16)
-    }
-    else if (!pa || !pa->cur32) { if (maxo == 4) LAUNCH5(4, 0) else LAUNCH5(8, 0) }       // (pa without a walker state: the profile entry)
+    if (!pa || !pa->cur32) { if (maxo == 4) LAUNCH5(4, 0) else LAUNCH5(8, 0) }       // (pa without a walker state: the profile entry)
     else if (m->D <= 16) { if (maxo == 4) LAUNCH5(4, 4) else LAUNCH5(8, 4) }
     else if (m->D <= 32) { if (maxo == 4) LAUNCH5(4, 8) else LAUNCH5(8, 8) }
     else { if (maxo == 4) LAUNCH5(4, 16) else LAUNCH5(8, 16) }
 #undef LAUNCH5
-#undef LAUNCH5K
     return pmc_check_launch("maf_inverse_tri5_kernel");
 }
 

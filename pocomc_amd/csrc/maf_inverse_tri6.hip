@@ -1015,24 +1015,6 @@ _Pragma("unroll") \
         const int64_t row = set0 * 16 + lane;
         if (row < n) ladj_out[row] = ladj;
     }
-    if constexpr (FM > 0) {
-        if (pa.epi.on) {
-            // The scaler (+ prior) and the hand-over of x' to the host as the sweep's epilogue (scaler_body.h; what
-            // maf_inverse_tri5_kernel does for its one walker set): the subsets one after the other through one scratch
-            // area -- the helper's copy of x and the three activation arrays, idle now -- with every thread of the
-            // workgroup; u' = the last transform's solution, still in LDS by rank.  One completion ticket per workgroup.
-            double* scr = reinterpret_cast<double*>(X16b);
-            const int* rof0 = rank_of_feat;                        // rank of every feature in transform 0
-            for (int sb = 0; sb < NS; ++sb) {
-                const int64_t row0 = (set0 + sb) * 16;
-                if (row0 >= n) break;
-                scaler_epilogue_subset(pa.epi, Xb + sb * szY, rof0, scr, row0, n, D, (int)threadIdx.x, 64 * NW,
-                                       [](int r, int pp) { return lidx(r, pp); });
-                __syncthreads();                                   // (the next subset's tables overwrite this one's)
-            }
-            scaler_epilogue_done(pa.epi, (int)threadIdx.x);
-        }
-    }
 }
 
 static int tri6_hb(const pmc_maf_t* m) { return (m->lane16 && (m->lane16_fmt == 1 || m->lane16_fmt == 2)) ? m->lane16_fmt : 0; }
@@ -1083,43 +1065,20 @@ bool pmc_tri6_preferred(const pmc_maf_t* m) {
     return tri6_five(m, false) && tri6_lds_bytes(m, 1) <= 160 * 1024;
 }
 
-// bytes of LDS the scaler epilogue may use as scratch: the helper's copy of x (16-bit helpers) and the three activation arrays
-static size_t tri6_epi_scratch_bytes(const pmc_maf_t* m, int ns, int hb) {
-    const int h_floats = hb ? ((m->nT + 1) >> 1) * 256 : m->nT * 256;
-    const int x16_floats = hb ? ((m->nXT + 1) >> 1) * 256 : 0;
-    return (size_t)ns * (x16_floats + 3 * h_floats) * sizeof(float);
-}
-
 // same contract as pmc_launch_inverse_tri4 / pmc_launch_propose_inverse_tri4 (pa == nullptr: plain inverse of z);
-// -1: this flow is not covered (spline flows, degree groups wider than a tile, tiles beyond the LDS, a fused instance
-// that is not built).  m->lane16 (pmc_maf_pack_lane16): the helpers multiply with 16-bit operands (Ops above).
-// pa->epi.on: the scaler (+ prior, + the hand-over of x') runs as the kernel's epilogue when its tables fit the idle
-// activation arrays -- *epi_done says whether it did (the caller launches the scaler itself otherwise).
-int pmc_launch_tri6(const ProposeArgs* pa_in, const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
-                    hipStream_t stream, int* epi_done) {
-    if (epi_done) *epi_done = 0;
+// -1: this flow is not covered (spline flows, degree groups wider than a tile, tiles beyond the LDS).
+// m->lane16 (pmc_maf_pack_lane16): the helpers multiply with 16-bit operands (Ops above).
+int pmc_launch_tri6(const ProposeArgs* pa, const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
+                    hipStream_t stream) {
     if (m->n_out != 2 || !m->tri_ok) return -1;
     if (m->pk_per_transform * 4 > 0x7fffffffLL) return -1;
-    if (pa_in && m->D > 128) return -1;
+    if (pa && m->D > 64) return -1;
     if (m->nT > 64) return -1;                           // (a lane per hidden tile holds its rank words)
     const int hb = tri6_hb(m);
-    const int ns = tri6_subsets(m, n, pa_in != nullptr, hb);
+    const int ns = tri6_subsets(m, n, pa != nullptr, hb);
     if (ns == 0) return -1;
     if (hb && m->Dp * 16 > 3 * ((m->nT + 1) >> 1) * 256) return -1;   // (the in-place re-rank parks x in the activation arrays)
-    // fused instances that are built: float32 helpers D <= 128 (one subset per workgroup beyond D = 64 ... two where they
-    // fit); 16-bit helpers 32 < D <= 128 (one or two subsets beyond D = 64)
-    if (pa_in && hb && m->D <= 32) return -1;
-    if (pa_in && m->D > 64 && ns > 2) return -1;
     const size_t lds = tri6_lds_bytes(m, ns, hb);
-    ProposeArgs pa_local;
-    const ProposeArgs* pa = pa_in;
-    if (pa_in) {
-        pa_local = *pa_in;
-        const bool epi_fits = pa_in->epi.on && epi_done && scaler_epilogue_lds_bytes(m->D) <= tri6_epi_scratch_bytes(m, ns, hb);
-        pa_local.epi.on = epi_fits ? 1 : 0;
-        if (epi_fits) *epi_done = 1;
-        pa = &pa_local;
-    }
     const ProposeArgs none{};
     const unsigned grid = (unsigned)((n + 16 * ns - 1) / (16 * ns));
     // wide flows (helpers saturated: their work grows with the hidden tiles, the chain's does not) get a fifth wavefront for
@@ -1139,22 +1098,14 @@ int pmc_launch_tri6(const ProposeArgs* pa_in, const pmc_maf_t* m, const float* z
     { if (ns == 1) LAUNCH6(1, FMV, 4, 0) else if (ns == 2) LAUNCH6(2, FMV, 4, 0) else LAUNCH6(4, FMV, 4, 0) }
 #define LAUNCH6H(HBV)                                                                                              \
     { if (ns == 1) LAUNCH6(1, 0, 4, HBV) else if (ns == 2) LAUNCH6(2, 0, 4, HBV) else LAUNCH6(4, 0, 4, HBV) }
-#define LAUNCH6HF(HBV)        /* fused proposal (+ epilogue) with 16-bit helpers: 32 < D <= 64, D <= 128 */          \
-    {                                                                                                              \
-        if (m->D <= 64) { if (ns == 1) LAUNCH6(1, 16, 4, HBV) else if (ns == 2) LAUNCH6(2, 16, 4, HBV) else LAUNCH6(4, 16, 4, HBV) } \
-        else { if (ns == 1) LAUNCH6(1, 32, 4, HBV) else LAUNCH6(2, 32, 4, HBV) }                                    \
-    }
-    if (hb == 1 && pa) LAUNCH6HF(1)
-    else if (hb == 2 && pa) LAUNCH6HF(2)
-    else if (hb == 1) LAUNCH6H(1)
+    if (hb && pa) return -1;                             // (no fused instance with 16-bit helpers yet)
+    if (hb == 1) LAUNCH6H(1)
     else if (hb == 2) LAUNCH6H(2)
     else if (five) { if (ns == 1) LAUNCH6(1, 0, 5, 0) else LAUNCH6(2, 0, 5, 0) }
     else if (!pa) LAUNCH6F(0)
     else if (m->D <= 16) LAUNCH6F(4)
     else if (m->D <= 32) LAUNCH6F(8)
-    else if (m->D <= 64) LAUNCH6F(16)
-    else { if (ns == 1) LAUNCH6(1, 32, 4, 0) else LAUNCH6(2, 32, 4, 0) }
-#undef LAUNCH6HF
+    else LAUNCH6F(16)
 #undef LAUNCH6H
 #undef LAUNCH6F
 #undef LAUNCH6

@@ -490,310 +490,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void maf_wide_phase_kernel(WideArgs a
 }
 
 
-// ====================================================================================================================
-// FAT PHASES (round 4).  The per-layer launches above are a chain of 8 T + 4 = 68 dependent kernels per <= 512 rows, each
-// 5-9 us of which ~4.7 are the dependent launch itself (an empty kernel in the same chain; a replayed hipGraph changes
-// nothing): 470 of the 551 us of an optimizer step at BASELINE config 5.  A layer's products are too small to pay for a
-// launch, so a batch is cut the other way: a workgroup of sixteen wavefronts owns SIXTEEN ROWS and sweeps ALL layers of
-// ALL transforms for them -- activations in LDS as B operands of v_mfma_f32_16x16x32_bf16, the 16-unit out tiles of a
-// layer dealt to the wavefronts, weights read from the same row-major bf16 image (a lane's 8 k are 16 contiguous bytes),
-// an LDS-only barrier between dependent layers, masked blocks skipped (hidden units are in degree order: W1 / W2 are block
-// lower-triangular, their transposes upper).  Three launches replace the 68:
-//   maf_wide_fwd_sweep_kernel   forward of every transform; keeps what the backward pass reads (x_t, ls, 1 / den^2, the
-//                               hidden activations in both orientations) exactly as the phases above did
-//   maf_wide_bwd_sweep_kernel   the activation gradients of every layer of every transform (both orientations, per
-//                               transform) and dL/dx down to the first transform
-//   maf_wide_wgrad_kernel       EVERY weight / bias gradient of the flow: 32 x 32 tiles over the batch rows, one work item
-//                               each -- the only phase with thousands of independent items, now one launch instead of
-//                               riding in 4 T of them
-// Same values as the per-layer phases up to the order of float32 additions -- and MEASURED SLOWER (scripts/time_fit.py, config
-// 5, us per optimizer step of 512 / 64 rows): 686 / 662 against 559 / 421 for the per-layer launches.  A workgroup that
-// sweeps all layers streams the flow's whole weight image (26 MB forward + transposed) through ONE CU, and a CU takes in
-// ~41 bytes per clock from L2 whatever its wavefronts do (scripts/micro/load_latency.hip): ~130 us per sweep however few
-// rows; a launch per layer spreads the same bytes over all 256 CUs.  Kept behind PMC_WIDE_SWEEPS=1 (gradient parity tests
-// pass on it); the default stays the per-layer phases.
-// ====================================================================================================================
-#define SW_NW 16
-#define SW_PF 4
-
-__device__ __forceinline__ int sw_act_off(int T, int q, int p) {           // 4 units 16 T + 4 q + r of row p: 8 bytes (bf16 elements)
-    return (((T >> 1) * 64 + (2 * (T & 1) + (q >> 1)) * 16 + p) << 3) + 4 * (q & 1);
-}
-__device__ __forceinline__ void sw_store4(u16* act, int T, int q, int p, const f32x4& v) {
-    using namespace fbf;
-    uint2 w;
-    w.x = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
-    w.y = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
-    *reinterpret_cast<uint2*>(act + sw_act_off(T, q, p)) = w;
-}
-__device__ __forceinline__ f32x4 sw_load4(const u16* act, int T, int q, int p) {
-    using namespace fbf;
-    const uint2 w = *reinterpret_cast<const uint2*>(act + sw_act_off(T, q, p));
-    return f32x4{from_bf16((u16)(w.x & 0xffff)), from_bf16((u16)(w.x >> 16)), from_bf16((u16)(w.y & 0xffff)), from_bf16((u16)(w.y >> 16))};
-}
-// acc += sum_{k in [k0, k1)} W[row0 + i][32 k + 8 g ..] . act[k]   (W row-major bf16, act: LDS B operands [k][lane] 16 bytes)
-__device__ __forceinline__ f32x4 sw_mac(f32x4 acc, const u16* __restrict__ W, int ld, int row0, const uint4* act, int k0, int k1, int lane) {
-    using namespace fbf;
-    if (k1 <= k0) return acc;
-    const u16* pa = W + (size_t)(row0 + (lane & 15)) * ld + 8 * (lane >> 4);
-    const uint4* pb = act + lane;
-    uint4 a[SW_PF];
-#pragma unroll
-    for (int j = 0; j < SW_PF; ++j) a[j] = *reinterpret_cast<const uint4*>(pa + ((k0 + j < k1 ? k0 + j : k1 - 1) << 5));
-    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
-    int k = k0;
-    for (; k + SW_PF <= k1; k += SW_PF) {
-#pragma unroll
-        for (int j = 0; j < SW_PF; ++j) {
-            const uint4 aj = a[j];
-            a[j] = *reinterpret_cast<const uint4*>(pa + ((k + j + SW_PF < k1 ? k + j + SW_PF : k1 - 1) << 5));
-            const uint4 bj = pb[(k + j) * 64];
-            if (j & 1) acc1 = mfma_bf(aj, bj, acc1); else acc = mfma_bf(aj, bj, acc);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < SW_PF - 1; ++j)
-        if (k + j < k1) { const uint4 bj = pb[(k + j) * 64]; if (j & 1) acc1 = mfma_bf(a[j], bj, acc1); else acc = mfma_bf(a[j], bj, acc); }
-    return acc + acc1;
-}
-
-__global__ __launch_bounds__(64 * SW_NW) void maf_wide_fwd_sweep_kernel(WideArgs a) {
-    using namespace fbf;
-    extern __shared__ __attribute__((aligned(16))) unsigned char sw_smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q = lane >> 4, p = lane & 15;
-    const WideDims& d = a.d;
-    const int D = d.D, DK = d.DK, HK = d.HK, OK = d.OK, T = d.T, NB = WIDE_NB;
-    const int nX2 = DK >> 5, nK2 = HK >> 5, nHT = HK >> 4, nOT = OK >> 4;
-    WideBufs b;
-    wide_carve(d, (char*)a.wd.scratch, &b);
-    const int n0 = blockIdx.x * 16, n = n0 + p;                     // this lane's row of the chunk
-    // LDS: x of the transform (float32 [feature][16]) twice, its bf16 B operand twice, three activation buffers
-    float* Xf = reinterpret_cast<float*>(sw_smem);
-    float* Xfn = Xf + DK * 16;
-    u16* Xb = reinterpret_cast<u16*>(Xfn + DK * 16);
-    u16* Xbn = Xb + nX2 * 512;
-    u16* A = Xbn + nX2 * 512;
-    u16* B = A + nK2 * 512;
-    u16* C = B + nK2 * 512;
-    auto x_off = [](int f, int pp) { return (((f >> 5) * 64 + ((f & 31) >> 3) * 16 + pp) << 3) + (f & 7); };
-    for (int e = tid; e < DK * 16; e += 64 * SW_NW) {
-        const int f = e >> 4, pp = e & 15;
-        const float v = b.X[(size_t)(n0 + pp) * DK + f];           // (PH_GATHER: zeros beyond the batch rows / the features)
-        Xf[f * 16 + pp] = v;
-        Xb[x_off(f, pp)] = to_bf16(v);
-    }
-    lds_barrier();
-    for (int t = 0; t < T; ++t) {
-        const WideView v = wide_view(a.wd, d, t);
-        u16* H0 = b.H + (size_t)(3 * t) * NB * HK; u16* H1 = H0 + (size_t)NB * HK; u16* H2 = H1 + (size_t)NB * HK;
-        u16* H0T = b.HT + (size_t)(3 * t) * HK * NB; u16* H1T = H0T + (size_t)HK * NB; u16* H2T = H1T + (size_t)HK * NB;
-        // ---- layer 0: h0 = relu(W0 x + b0)
-        for (int ot = wv; ot < nHT; ot += SW_NW) {
-            const float4 bb = *reinterpret_cast<const float4*>(v.b0 + 16 * ot + 4 * q);
-            f32x4 c = sw_mac(f32x4{0.f, 0.f, 0.f, 0.f}, v.W0f, DK, 16 * ot, reinterpret_cast<const uint4*>(Xb), 0, nX2, lane);
-            c[0] = fmaxf(c[0] + bb.x, 0.f); c[1] = fmaxf(c[1] + bb.y, 0.f); c[2] = fmaxf(c[2] + bb.z, 0.f); c[3] = fmaxf(c[3] + bb.w, 0.f);
-            sw_store4(A, ot, q, p, c);
-            put4(H0, HK, H0T, NB, n, 16 * ot + 4 * q, c);
-        }
-        lds_barrier();
-        // ---- layers 1, 2: h' = relu(h + W h + b); units in degree order: out tile ot reads the k-steps <= ot >> 1
-        for (int layer = 1; layer <= 2; ++layer) {
-            const u16* Hin = layer == 1 ? A : B;
-            u16* Hout = layer == 1 ? B : C;
-            const u16* Wf = layer == 1 ? v.W1f : v.W2f;
-            const float* bl = layer == 1 ? v.b1 : v.b2;
-            u16* Hg = layer == 1 ? H1 : H2; u16* HgT = layer == 1 ? H1T : H2T;
-            for (int it = wv; it < nHT; it += SW_NW) {
-                const int ot = nHT - 1 - it;                        // (the long rows first)
-                const float4 bb = *reinterpret_cast<const float4*>(bl + 16 * ot + 4 * q);
-                const f32x4 h = sw_load4(Hin, ot, q, p);
-                f32x4 c = sw_mac(f32x4{0.f, 0.f, 0.f, 0.f}, Wf, HK, 16 * ot, reinterpret_cast<const uint4*>(Hin), 0, d.tri ? (ot >> 1) + 1 : nK2, lane);
-                c[0] = fmaxf((c[0] + bb.x) + h[0], 0.f); c[1] = fmaxf((c[1] + bb.y) + h[1], 0.f);
-                c[2] = fmaxf((c[2] + bb.z) + h[2], 0.f); c[3] = fmaxf((c[3] + bb.w) + h[3], 0.f);
-                sw_store4(Hout, ot, q, p, c);
-                put4(Hg, HK, HgT, NB, n, 16 * ot + 4 * q, c);
-            }
-            lds_barrier();
-        }
-        // ---- output layer + univariate affine map (float32): out tile O = features 8 O .. 8 O + 7, rows (shift, raw)
-        for (int O = wv; O < nOT; O += SW_NW) {
-            const int mr = 16 * O + 4 * q, f0 = mr >> 1;
-            const float4 bb = *reinterpret_cast<const float4*>(v.b3 + mr);
-            const f32x4 c = sw_mac(f32x4{0.f, 0.f, 0.f, 0.f}, v.W3f, HK, 16 * O, reinterpret_cast<const uint4*>(C), 0, nK2, lane);
-            float y[2];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int f = f0 + s2;
-                const size_t e = ((size_t)t * NB + n) * DK + f;
-                float ls = 0.0f, dd = 0.0f;
-                y[s2] = 0.0f;
-                if (f < D) {
-                    const float shift = s2 ? c[2] + bb.z : c[0] + bb.x;
-                    const float raw = s2 ? c[3] + bb.w : c[1] + bb.y;
-                    const float den = 1.0f + fabsf(raw / PMC_LOG_SLOPE);
-                    ls = raw / den;
-                    dd = 1.0f / (den * den);
-                    y[s2] = Xf[f * 16 + p] * expf(ls) + shift;
-                }
-                b.LS[e] = ls;
-                b.DD[e] = dd;
-                b.X[e + (size_t)NB * DK] = y[s2];
-                Xfn[f * 16 + p] = y[s2];
-                Xbn[x_off(f, p)] = to_bf16(y[s2]);
-            }
-            if (t + 1 < T) {
-                const u16 h0 = to_bf16(y[0]), h1 = to_bf16(y[1]);
-                *reinterpret_cast<unsigned*>(b.XB + ((size_t)(t + 1) * NB + n) * DK + f0) = (unsigned)h0 | ((unsigned)h1 << 16);
-                u16* xt = b.XBT + ((size_t)(t + 1) * DK + f0) * NB + n;
-                xt[0] = h0; xt[NB] = h1;
-            }
-        }
-        lds_barrier();
-        { float* s1 = Xf; Xf = Xfn; Xfn = s1; u16* s2 = Xb; Xb = Xbn; Xbn = s2; }
-    }
-}
-
-__global__ __launch_bounds__(64 * SW_NW) void maf_wide_bwd_sweep_kernel(WideArgs a) {
-    using namespace fbf;
-    extern __shared__ __attribute__((aligned(16))) unsigned char sw_smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q = lane >> 4, p = lane & 15;
-    const WideDims& d = a.d;
-    const int D = d.D, DK = d.DK, HK = d.HK, OK = d.OK, T = d.T, NB = WIDE_NB;
-    const int nK2 = HK >> 5, nO2 = OK >> 5, nHT = HK >> 4, nFT = DK >> 4;
-    WideBufs b;
-    wide_carve(d, (char*)a.wd.scratch, &b);
-    const int n0 = blockIdx.x * 16, n = n0 + p;
-    // LDS: dL/dy of the transform (float32 [feature][16]), its output gradients and the three activation gradients as B operands
-    float* G = reinterpret_cast<float*>(sw_smem);
-    u16* DOb = reinterpret_cast<u16*>(G + DK * 16);
-    u16* E2 = DOb + nO2 * 512;
-    u16* E1 = E2 + nK2 * 512;
-    u16* E0 = E1 + nK2 * 512;
-    auto o_off = [](int o, int pp) { return (((o >> 5) * 64 + ((o & 31) >> 3) * 16 + pp) << 3) + (o & 7); };
-    // PH_Z left dL/dz (G) and the last transform's output gradients in global memory
-    for (int e = tid; e < DK * 16; e += 64 * SW_NW) { const int f = e >> 4, pp = e & 15; G[f * 16 + pp] = b.G[(size_t)(n0 + pp) * DK + f]; }
-    {
-        const u16* DOg = b.DO + (size_t)(T - 1) * NB * OK;
-        for (int e = tid; e < nO2 * 64; e += 64 * SW_NW) {
-            const int k = e >> 6, l = e & 63;
-            reinterpret_cast<uint4*>(DOb)[e] = *reinterpret_cast<const uint4*>(DOg + (size_t)(n0 + (l & 15)) * OK + 32 * k + 8 * (l >> 4));
-        }
-    }
-    const float cn = b.C[n];
-    lds_barrier();
-    for (int t = T - 1; t >= 0; --t) {
-        const WideView v = wide_view(a.wd, d, t);
-        const u16* H0 = b.H + (size_t)(3 * t) * NB * HK; const u16* H1 = H0 + (size_t)NB * HK; const u16* H2 = H1 + (size_t)NB * HK;
-        u16* DA2 = b.DA + (size_t)(3 * t) * NB * HK; u16* DA1 = DA2 + (size_t)NB * HK; u16* DA0 = DA1 + (size_t)NB * HK;
-        u16* DA2T = b.DAT + (size_t)(3 * t) * HK * NB; u16* DA1T = DA2T + (size_t)HK * NB; u16* DA0T = DA1T + (size_t)HK * NB;
-        // ---- da2 = relu'(h2) . W3^T do
-        for (int ot = wv; ot < nHT; ot += SW_NW) {
-            const int mr = 16 * ot + 4 * q;
-            const f32x4 h = get4(H2, HK, n, mr);
-            f32x4 c = sw_mac(f32x4{0.f, 0.f, 0.f, 0.f}, v.W3b, OK, 16 * ot, reinterpret_cast<const uint4*>(DOb), 0, nO2, lane);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) c[r] = h[r] > 0.f ? c[r] : 0.f;
-            sw_store4(E2, ot, q, p, c);
-            put4(DA2, HK, DA2T, NB, n, mr, c);
-        }
-        lds_barrier();
-        // ---- da1 = relu'(h1) . (da2 + W2^T da2),  da0 = relu'(h0) . (da1 + W1^T da1): the transposes are block UPPER-triangular
-        for (int layer = 2; layer >= 1; --layer) {
-            const u16* Ein = layer == 2 ? E2 : E1;
-            u16* Eout = layer == 2 ? E1 : E0;
-            const u16* Wb = layer == 2 ? v.W2b : v.W1b;
-            const u16* Hg = layer == 2 ? H1 : H0;
-            u16* Dg = layer == 2 ? DA1 : DA0; u16* DgT = layer == 2 ? DA1T : DA0T;
-            for (int ot = wv; ot < nHT; ot += SW_NW) {               // (ot ascending = the long rows first)
-                const int mr = 16 * ot + 4 * q;
-                const f32x4 h = get4(Hg, HK, n, mr), dp = sw_load4(Ein, ot, q, p);
-                f32x4 c = sw_mac(f32x4{0.f, 0.f, 0.f, 0.f}, Wb, HK, 16 * ot, reinterpret_cast<const uint4*>(Ein), d.tri ? ot >> 1 : 0, nK2, lane);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) c[r] = h[r] > 0.f ? c[r] + dp[r] : 0.f;
-                sw_store4(Eout, ot, q, p, c);
-                put4(Dg, HK, DgT, NB, n, mr, c);
-            }
-            lds_barrier();
-        }
-        // ---- dL/dx_t = dL/dy e^{ls} + W0^T da0 (= dL/dy of transform t - 1) and that transform's output gradients
-        for (int ft = wv; ft < nFT; ft += SW_NW) {
-            const int mr = 16 * ft + 4 * q;
-            const f32x4 c = sw_mac(f32x4{0.f, 0.f, 0.f, 0.f}, v.W0b, HK, 16 * ft, reinterpret_cast<const uint4*>(E0), 0, nK2, lane);
-            const float4 lsv = *reinterpret_cast<const float4*>(b.LS + ((size_t)t * NB + n) * DK + mr);
-            const size_t ep = ((size_t)(t > 0 ? t - 1 : 0) * NB + n) * DK + mr;
-            const float4 px = *reinterpret_cast<const float4*>(b.X + ep), pl = *reinterpret_cast<const float4*>(b.LS + ep),
-                         pd = *reinterpret_cast<const float4*>(b.DD + ep);
-            const float lv[4] = {lsv.x, lsv.y, lsv.z, lsv.w};
-            const float pxv[4] = {px.x, px.y, px.z, px.w}, plv[4] = {pl.x, pl.y, pl.z, pl.w}, pdv[4] = {pd.x, pd.y, pd.z, pd.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = mr + r;
-                float gx = 0.0f;
-                if (f < D) gx = c[r] + G[f * 16 + p] * expf(lv[r]);
-                G[f * 16 + p] = gx;                                   // (each element is read and written by this lane only)
-                if (t > 0) {
-                    const unsigned w2 = emit_do_vals(b, d, t - 1, n, f, gx, cn, pxv[r], plv[r], pdv[r]);
-                    *reinterpret_cast<unsigned*>(DOb + o_off(2 * f, p)) = w2;
-                }
-            }
-        }
-        lds_barrier();
-    }
-}
-
-// every weight / bias gradient of the flow, one work item per 32 x 32 tile (k = the batch rows) or 16 bias rows:
-// per transform  [dW0 | dW1 | dW2 | dW3 | db0 | db1 | db2 | db3]
-__global__ __launch_bounds__(WIDE_THREADS) void maf_wide_wgrad_kernel(WideArgs a) {
-    using namespace fbf;
-    __shared__ __attribute__((aligned(16))) float4 red[4 * 256];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, p = lane & 15;
-    const int mi = wv >> 1, ni = wv & 1;
-    const WideDims& d = a.d;
-    const int DK = d.DK, HK = d.HK, OK = d.OK, NB = WIDE_NB;
-    const int NBc = (a.nb + 31) & ~31;
-    const bool first = a.first != 0;
-    float* __restrict__ grad = a.grad;
-    WideBufs b;
-    wide_carve(d, (char*)a.wd.scratch, &b);
-    const int mH = HK >> 5, mD = DK >> 5, mO = OK >> 5;
-    const int n0w = mH * mD, n1w = mH * mH, n3w = mO * mH, nbH = HK >> 4, nbO = OK >> 4;
-    const int per_t = n0w + 2 * n1w + n3w + 3 * nbH + nbO;
-    const int t = blockIdx.x / per_t;
-    int it = blockIdx.x - t * per_t;
-    const WideView v = wide_view(a.wd, d, t);
-    const u16* H0T = b.HT + (size_t)(3 * t) * HK * NB; const u16* H1T = H0T + (size_t)HK * NB; const u16* H2T = H1T + (size_t)HK * NB;
-    const u16* DA2T = b.DAT + (size_t)(3 * t) * HK * NB; const u16* DA1T = DA2T + (size_t)HK * NB; const u16* DA0T = DA1T + (size_t)HK * NB;
-    const u16* DOT = b.DOT + (size_t)t * OK * NB;
-    const u16* XBT = b.XBT + (size_t)t * DK * NB;
-    const u16 *At, *Bt; const int* imap; int ldi, nKT;
-    if (it < n0w) { At = DA0T; Bt = XBT; imap = v.I0; ldi = DK; nKT = mD; }
-    else if ((it -= n0w) < n1w) { At = DA1T; Bt = H0T; imap = v.I1; ldi = HK; nKT = mH; }
-    else if ((it -= n1w) < n1w) { At = DA2T; Bt = H1T; imap = v.I2; ldi = HK; nKT = mH; }
-    else if ((it -= n1w) < n3w) { At = DOT; Bt = H2T; imap = v.I3; ldi = HK; nKT = mH; }
-    else {
-        it -= n3w;
-        if (it < nbH) bias_rows(DA0T, it << 4, NBc, v.ib0, grad, first, wv, lane);
-        else if ((it -= nbH) < nbH) bias_rows(DA1T, it << 4, NBc, v.ib1, grad, first, wv, lane);
-        else if ((it -= nbH) < nbH) bias_rows(DA2T, it << 4, NBc, v.ib2, grad, first, wv, lane);
-        else bias_rows(DOT, (it - nbH) << 4, NBc, v.ib3, grad, first, wv, lane);
-        return;
-    }
-    const int m0 = (it / nKT) << 5, k0 = (it % nKT) << 5;
-    const DwIdx gx_ = dw_index(imap, ldi, m0 + 16 * mi + 4 * g, k0 + 16 * ni + p);
-    // (a tile whose every entry is masked or padding has nothing to write: uniform over the workgroup after the vote)
-    bool any = false;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) any |= gx_.gi[r] >= 0;
-    if (!__syncthreads_or(any)) return;
-    const f32x4 c = tile_product(At, NB, Bt, NB, m0, k0, NBc, red, wv, lane);
-    scatter_dw(gx_, c, grad, first);
-}
+// (Round 4 built "fat phases" here -- a workgroup of sixteen wavefronts per 16 rows sweeping ALL layers of ALL transforms
+// with the activations in LDS, three launches instead of 68 -- and measured them SLOWER: 686 / 662 us per optimizer step of
+// 512 / 64 rows against 559 / 421 for the per-layer launches.  A workgroup that sweeps all layers streams the flow's whole
+// weight image (26 MB forward + transposed) through ONE CU at ~41 bytes per clock: ~130 us per sweep however few rows; a
+// launch per layer spreads the same bytes over all 256 CUs.  Removed in round 5; DESIGN.md appendix A has the numbers.)
 
 // ------------------------------------------------------------------------------------------------ host side
 extern "C" int64_t pmc_maf_wide_scratch_bytes(const pmc_maf_t* m) {
@@ -831,24 +532,6 @@ static int launch_wide_part(const pmc_maf_t* m, const pmc_maf_wide_t* wd, const 
     const WideDims& d = a.d;
     const int T = d.T, mH = d.HK >> 5, mD = d.DK >> 5, mO = d.OK >> 5;
 #define PHASE(PH, GRID) hipLaunchKernelGGL((maf_wide_phase_kernel<PH>), dim3((unsigned)(GRID)), dim3(WIDE_THREADS), 0, st, a)
-    // PMC_WIDE_SWEEPS=1: the fat phases instead of a launch per dependent layer (measured SLOWER on MI355X: see the note above)
-    static const bool per_layer = !(getenv("PMC_WIDE_SWEEPS") && atoi(getenv("PMC_WIDE_SWEEPS")) != 0);
-    const size_t lds_f = (size_t)2 * d.DK * 16 * 4 + (size_t)2 * (d.DK >> 5) * 1024 + (size_t)3 * (d.HK >> 5) * 1024;
-    const size_t lds_b = (size_t)d.DK * 16 * 4 + (size_t)(d.OK >> 5) * 1024 + (size_t)3 * (d.HK >> 5) * 1024;
-    const bool sweeps = !per_layer && lds_f <= 160 * 1024 && lds_b <= 160 * 1024;
-    if (sweeps) {
-        static size_t set_f = 0, set_b = 0;
-        if (lds_f > 48 * 1024 && lds_f > set_f) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(maf_wide_fwd_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f) != hipSuccess)
-                return pmc_fail("hipFuncSetAttribute(maf_wide_fwd_sweep_kernel)");
-            set_f = lds_f;
-        }
-        if (lds_b > 48 * 1024 && lds_b > set_b) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(maf_wide_bwd_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b) != hipSuccess)
-                return pmc_fail("hipFuncSetAttribute(maf_wide_bwd_sweep_kernel)");
-            set_b = lds_b;
-        }
-    }
     if (do_wsum && w && !wd->wsum) PHASE(PH_WSUM, 1);
     for (int64_t c0 = 0; c0 < n; c0 += WIDE_NB) {
         a.c0 = c0;
@@ -856,15 +539,6 @@ static int launch_wide_part(const pmc_maf_t* m, const pmc_maf_wide_t* wd, const 
         a.first = (c0 == 0);
         const int NBc = (a.nb + 31) & ~31, nNT = NBc >> 5;
         PHASE(PH_GATHER, ((int64_t)NBc * d.DK + WIDE_THREADS - 1) / WIDE_THREADS);
-        if (sweeps) {
-            hipLaunchKernelGGL(maf_wide_fwd_sweep_kernel, dim3((unsigned)(NBc >> 4)), dim3(64 * SW_NW), lds_f, st, a);
-            PHASE(PH_Z, (NBc + 3) / 4);
-            hipLaunchKernelGGL(maf_wide_bwd_sweep_kernel, dim3((unsigned)(NBc >> 4)), dim3(64 * SW_NW), lds_b, st, a);
-            const int per_t = mH * mD + 2 * mH * mH + mO * mH + 3 * (d.HK >> 4) + (d.OK >> 4);
-            hipLaunchKernelGGL(maf_wide_wgrad_kernel, dim3((unsigned)(T * per_t)), dim3(WIDE_THREADS), 0, st, a);
-            PHASE(PH_LOSS, 1);
-            continue;
-        }
         for (int t = 0; t < T; ++t) {
             a.t = t;
             PHASE(PH_F0, mH * nNT);

@@ -229,7 +229,7 @@ struct ProposeArgs {
 // lane-per-walker sweep (maf_inverse_tri6.hip); pa == nullptr: plain inverse of z.  -1: flow not covered
 bool pmc_tri6_preferred(const pmc_maf_t* m);     // AUTO takes the lane-per-walker sweep for this flow (maf_inverse_tri6.hip)
 int pmc_launch_tri6(const ProposeArgs* pa, const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
-                    hipStream_t stream, int* epi_done = nullptr);
+                    hipStream_t stream);
 // two-wave spline sweep (maf_inverse_nsf2.hip) with the fused proposal (+ scaler epilogue: *epi_done); -1: flow not covered
 int pmc_launch_propose_inverse_nsf2(ProposeArgs* pa, const ScalerEpi* epi, int* epi_done, const pmc_maf_t* m, float* x, float* ladj,
                                     int64_t n, hipStream_t stream);

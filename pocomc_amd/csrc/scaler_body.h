@@ -177,11 +177,11 @@ __device__ __forceinline__ void scaler_epilogue_element(const ScalerEpi& e, doub
 }
 
 // the rows' part: log-determinant (numpy's pairwise sum of the Jacobian terms), finite mask, Prior.logpdf; then the
-// column-major store of x (unless the elements stored it already: cm_done).  Every thread of the workgroup calls it
-// behind a barrier that follows the last element; scaler_epilogue_done follows (once per workgroup).
-__device__ __forceinline__ void scaler_epilogue_rows_only(const ScalerEpi& e, const double* Jt, const double* Pt, const double* Xt,
-                                                          int* rowfin, int64_t row0, int64_t n, int D, int tid, int nthr,
-                                                          bool cm_done) {
+// column-major store of x (unless the elements stored it already: cm_done) and the completion word.  Every thread of
+// the workgroup calls it behind a barrier that follows the last element.
+__device__ __forceinline__ void scaler_epilogue_rows(const ScalerEpi& e, const double* Jt, const double* Pt, const double* Xt,
+                                                     int* rowfin, int64_t row0, int64_t n, int D, int tid, int nthr,
+                                                     bool cm_done) {
     const pmc_scaler_t& s = e.s;
     const int rows = (int)min((int64_t)16, n - row0);
     if (tid < rows) {
@@ -217,10 +217,6 @@ __device__ __forceinline__ void scaler_epilogue_rows_only(const ScalerEpi& e, co
         }
     }
     if (e.stamps && tid == 0) e.stamps[blockIdx.x * 8 + 4] = wall_clock64();
-}
-
-// the completion word of the launch: every thread of the workgroup calls it once, behind its last store of x'
-__device__ __forceinline__ void scaler_epilogue_done(const ScalerEpi& e, int tid) {
     if (e.done_flag) {
         // Every thread waits for the acknowledgement of its own stores (agent-scope release: pinned host memory is not
         // cached on the device, so there is nothing to write back), the workgroup draws a ticket (agent-scope acq_rel), the
@@ -246,13 +242,6 @@ __device__ __forceinline__ void scaler_epilogue_done(const ScalerEpi& e, int tid
     }
 }
 
-__device__ __forceinline__ void scaler_epilogue_rows(const ScalerEpi& e, const double* Jt, const double* Pt, const double* Xt,
-                                                     int* rowfin, int64_t row0, int64_t n, int D, int tid, int nthr,
-                                                     bool cm_done) {
-    scaler_epilogue_rows_only(e, Jt, Pt, Xt, rowfin, row0, n, D, tid, nthr, cm_done);
-    scaler_epilogue_done(e, tid);
-}
-
 template <class LIDX>
 __device__ __forceinline__ void scaler_epilogue(const ScalerEpi& e, const float* X, const int* __restrict__ rof,
                                                 double* scr, int64_t row0, int64_t n, int D, int tid, int nthr,
@@ -272,27 +261,6 @@ __device__ __forceinline__ void scaler_epilogue(const ScalerEpi& e, const float*
     __syncthreads();
     if (e.stamps && tid == 0) e.stamps[blockIdx.x * 8 + 1] = wall_clock64();
     scaler_epilogue_rows(e, Jt, Pt, Xt, rowfin, row0, n, D, tid, nthr, false);
-}
-
-// the same for one of SEVERAL 16-walker subsets of a workgroup (maf_inverse_tri6.hip): no completion word -- the caller
-// runs the subsets one after the other through the same scratch (a barrier in between) and calls scaler_epilogue_done once
-template <class LIDX>
-__device__ __forceinline__ void scaler_epilogue_subset(const ScalerEpi& e, const float* X, const int* __restrict__ rof,
-                                                       double* scr, int64_t row0, int64_t n, int D, int tid, int nthr,
-                                                       LIDX lidx_of) {
-    double* Jt = scr;
-    double* Pt = Jt + 16 * D;
-    double* Xt = Pt + 16 * D;
-    int* rowfin = reinterpret_cast<int*>(Xt + D * 17);
-    const int rows = (int)min((int64_t)16, n - row0);
-    if (tid < 16) rowfin[tid] = 1;
-    __syncthreads();
-    for (int el = tid; el < rows * D; el += nthr) {
-        const int r = el / D, j = el - r * D;
-        scaler_epilogue_element(e, Jt, Pt, Xt, rowfin, X[lidx_of(rof[j], r)], r, j, row0, n, D, false);
-    }
-    __syncthreads();
-    scaler_epilogue_rows_only(e, Jt, Pt, Xt, rowfin, row0, n, D, tid, nthr, false);
 }
 
 // the progressive form's tables only (no Xt): [16][D] Jacobian terms, [16][D] prior terms, 16 row flags

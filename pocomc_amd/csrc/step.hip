@@ -13,8 +13,10 @@
 #include "pmc_internal.h"
 #include "scaler_body.h"
 
+#ifdef PMC_DEBUG_HOOKS                               // measurement builds only (make DEBUG_HOOKS=1): not in the product library
 static long long* g_epilogue_stamps = nullptr;       // pmc_debug_set_epilogue_stamps
 static int64_t g_epilogue_stamps_n = 0;
+#endif
 
 extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu, double sigma, double cn_a,
                             void* stream) {
@@ -74,10 +76,15 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
     double* lp2 = (direct && pr) ? s->h_logp_out : nullptr;
     pmc_done_t dn{s->h_done, (int64_t)rng->step + 1, s->done_ticket};
     const pmc_done_t* done = (direct && s->h_done && s->done_ticket) ? &dn : nullptr;
-    if (s->preconditioned && !(s->no_fuse & 1) &&
+    if (s->preconditioned && !(s->no_fuse & 1) && !pmc_tri6_preferred(s->maf) &&
         (s->inverse_algo == PMC_INVERSE_AUTO || s->inverse_algo == PMC_INVERSE_TRIANGULAR)) {
-        // proposal + flow inverse (+ scaler) in one launch (the two-wave sweeps for D <= 64 and fewer than 16 hidden tiles,
-        // the lane-per-walker sweep for the wider flows up to D = 128); no_fuse & 2 keeps the scaler apart
+        // proposal + flow inverse (+ scaler) in one launch (affine flows, D <= 64, fewer than 16 hidden tiles).  The wider
+        // flows take the lane-per-walker sweep with the proposal and the scaler as launches of their own: round 5 built the
+        // fused instances of that sweep (proposal prologue up to D = 128, scaler / prior / x' epilogue, float32 and 16-bit
+        // helpers) and measured them -- the proposal (~90 us per wavefront at D = 128) and the scaler (~40 us) are latency
+        // chains that cost the same inside the sweep's launch as in their own, and the float32 five-wavefront instance has
+        // no registers for them: config 5 255 (fused) against 300 steps/s, 16-bit helpers 420 against 415 (DESIGN.md
+        // appendix A); no_fuse & 2 keeps the scaler apart
         ScalerEpi epi{};
         const bool want_epi = !(s->no_fuse & 2) && s->scaler && s->scaler->low && s->scaler->high && s->scaler->kind &&
                               s->scaler->log_width && (!s->scaler->scale || (s->scaler->mu && s->scaler->sigma)) &&
@@ -93,7 +100,9 @@ extern "C" int pmc_step_pre(const pmc_step_t* s, const pmc_rng_t* rng, double nu
             epi.done_value = done ? (long long)done->value : 0LL;
             epi.bad_count = (done && s->h_clean) ? s->clean_count : nullptr;
             epi.bad_flag = (done && s->h_clean && s->clean_count) ? (long long*)s->h_clean : nullptr;
+#ifdef PMC_DEBUG_HOOKS
             epi.stamps = (n == g_epilogue_stamps_n) ? g_epilogue_stamps : nullptr;
+#endif
             epi.fill_x = (s->fill_rejected && epi.bad_flag && xT) ? s->cur.x : nullptr;
         }
         if (s->ev_inv0) (void)hipEventRecord((hipEvent_t)s->ev_inv0, st);
@@ -218,9 +227,11 @@ extern "C" int pmc_step_post(const pmc_step_t* s, const pmc_rng_t* rng, double b
     return 0;
 }
 
-// measurement only (bench.py, PMC_BENCH_EPI_STAMPS): device int64 [blocks][8] that the epilogue of the fused launches over
-// n_rows rows stamps, or NULL
+#ifdef PMC_DEBUG_HOOKS
+// measurement only (bench.py, PMC_BENCH_EPI_STAMPS, a library built with `make DEBUG_HOOKS=1`): device int64 [blocks][8] that
+// the epilogue of the fused launches over n_rows rows stamps, or NULL
 extern "C" void pmc_debug_set_epilogue_stamps(long long* dev, int64_t n_rows) { g_epilogue_stamps = dev; g_epilogue_stamps_n = n_rows; }
+#endif
 
 extern "C" int pmc_stream_synchronize(void* stream) {
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
@@ -232,8 +243,7 @@ extern "C" int pmc_stream_synchronize(void* stream) {
 // launch of every timed step through pmc_step_t.ev_inv0 / ev_inv1).
 extern "C" void* pmc_event_create(void) {
     hipEvent_t e;
-    const char* fl = getenv("PMC_EVENT_FLAGS");
-    if (hipEventCreateWithFlags(&e, fl ? (unsigned)atoi(fl) : hipEventDefault) != hipSuccess) { pmc_fail("hipEventCreate failed"); return nullptr; }
+    if (hipEventCreateWithFlags(&e, hipEventDefault) != hipSuccess) { pmc_fail("hipEventCreate failed"); return nullptr; }
     return (void*)e;
 }
 extern "C" int pmc_event_record(void* ev, void* stream) {

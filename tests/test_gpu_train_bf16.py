@@ -185,21 +185,3 @@ def test_bf16_two_ranks_equal_one_process(tmp_path):
     np.testing.assert_allclose(got["loss"], hist["loss"], rtol=5e-5)
     np.testing.assert_allclose(got["val"], hist["val_loss"], rtol=5e-5)
     np.testing.assert_allclose(got["params"], f.params.cpu().numpy(), rtol=5e-3, atol=5e-5)
-
-
-def test_fat_phases_pass_the_same_tests():
-    """``PMC_WIDE_SWEEPS=1``: the three fat launches of ``csrc/maf_train_bf16.hip`` (forward sweep, backward-data sweep of a
-    workgroup per 16 rows through all layers of all transforms; every weight gradient in one launch) instead of a launch
-    per dependent layer -- the switch is read once per process, so the gradient / epoch / fit tests of this file run again
-    in a child process with it set.  (Measured slower than the per-layer launches on MI355X, DESIGN.md section 4d: kept as
-    an option, and correct.)"""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get("PMC_WIDE_SWEEPS"):
-        pytest.skip("already the child process")
-    env = dict(os.environ, PMC_WIDE_SWEEPS="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "not fat_phases"],
-                       env=env, capture_output=True, text=True, timeout=1200)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
