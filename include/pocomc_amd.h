@@ -544,6 +544,9 @@ int pmc_stream_synchronize(void* stream);
 void* pmc_comm_create(int32_t rank, int32_t world, int32_t width);
 void* pmc_comm_create_host(int32_t rank, int32_t world, int32_t width);
 int pmc_comm_kind(void* comm);
+/* host mailboxes: drop the shared-memory NAME once every rank has connected (mappings stay valid; nothing is left in /dev/shm
+ * if a process dies later); no-op for device mailboxes */
+int pmc_comm_unlink(void* comm);
 int pmc_comm_handle(void* comm, void* out64);
 int pmc_comm_connect(void* comm, const void* handles);
 void pmc_comm_destroy(void* comm);

@@ -157,6 +157,7 @@ SIGNATURES = {
     "pmc_comm_create": (C.c_void_p, [i32, i32, i32]),
     "pmc_comm_create_host": (C.c_void_p, [i32, i32, i32]),
     "pmc_comm_kind": (C.c_int, [c_p]),
+    "pmc_comm_unlink": (C.c_int, [c_p]),
     "pmc_comm_handle": (C.c_int, [c_p, c_p]),
     "pmc_comm_connect": (C.c_int, [c_p, c_p]),
     "pmc_comm_destroy": (None, [c_p]),

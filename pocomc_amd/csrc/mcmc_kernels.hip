@@ -1045,7 +1045,7 @@ extern "C" void pmc_comm_destroy(void* cc) {
     if (c->kind == 1) {
         for (int r = 0; r < c->world; ++r)
             if (c->host_map[r]) { (void)hipHostUnregister(c->host_map[r]); munmap(c->host_map[r], c->bytes); }
-        if (c->host_map[c->rank]) shm_unlink(reinterpret_cast<const char*>(&c->handle));
+        if (c->host_map[c->rank] && reinterpret_cast<const char*>(&c->handle)[0]) shm_unlink(reinterpret_cast<const char*>(&c->handle));
         delete c;
         return;
     }
@@ -1057,6 +1057,18 @@ extern "C" void pmc_comm_destroy(void* cc) {
 
 // 0: device mailboxes behind hipIpc handles, 1: host mailboxes in POSIX shared memory
 extern "C" int pmc_comm_kind(void* cc) { return cc ? ((pmc_comm*)cc)->kind : -1; }
+
+// host mailboxes: once EVERY rank has connected (the caller knows: it gathered the ranks' pmc_comm_connect results) the name
+// can go -- the mappings stay valid, and a process that dies later leaves nothing behind in /dev/shm.  No-op for kind 0.
+extern "C" int pmc_comm_unlink(void* cc) {
+    pmc_comm* c = (pmc_comm*)cc;
+    if (!c) return pmc_fail("pmc_comm_unlink: null communicator");
+    if (c->kind == 1 && c->host_map[c->rank]) {
+        char* name = reinterpret_cast<char*>(&c->handle);
+        if (name[0]) { shm_unlink(name); name[0] = 0; }
+    }
+    return 0;
+}
 
 // total over the parts of this rank AND over the ranks (rank order), then as pmc_adapt_update: total_out / h_sums / the
 // adaptation / done.  Every rank must make the same sequence of calls.  timeout_s <= 0: wait for ever.

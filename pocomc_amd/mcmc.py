@@ -249,6 +249,7 @@ def _try_comm(lib, group, world, rank, w, kind):
     flags = [None] * world
     dist.all_gather_object(flags, good, group=group)
     if all(flags):
+        lib.pmc_comm_unlink(h)                           # (host mailboxes: every rank has mapped every segment, the names can go)
         # one exchange with known values before any step depends on the mailboxes: rank r sends r + 1 in every word (a
         # mapping that opened but whose stores do not arrive shows up here, as a timeout or a wrong sum, on every rank
         # alike -- the step then takes the next kind of mailbox, or torch.distributed)

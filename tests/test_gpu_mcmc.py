@@ -793,6 +793,58 @@ def test_the_pipeline_behind_the_c_abi_equals_the_python_pipeline_bit_for_bit(ki
     assert a["proposal_scale"] == b["proposal_scale"] and a["accept"] == b["accept"] and a["efficiency"] == b["efficiency"]
 
 
+@pytest.mark.parametrize("c_pipe", ["1", "0"])
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_a_drained_pipeline_resumes_on_the_same_trajectory(lanes, c_pipe, monkeypatch):
+    """``LanedEngine.resume_pipeline`` (``pmc_pipeline_start`` on the existing pipeline object): a step with ``more=False``
+    enqueues no pre-step of its successor; resuming issues exactly the launches the step would have enqueued.  Six steps
+    with the pipeline drained and resumed behind steps 2 and 4 leave the same walkers, bit for bit, as six steps in one go --
+    what ``bench.py`` relies on to put every launch of its timed steps behind ``t0`` (closed region, round 5)."""
+    from scipy.stats import uniform
+    import pocomc_amd as pc
+    from pocomc_amd.mcmc import LanedEngine, Adaptation
+    from pocomc_amd.geometry import Geometry
+    import torch
+    monkeypatch.setenv("PMC_C_PIPELINE", c_pipe)
+    D, N, beta, nu = 6, 1600, 0.5, 5.0
+    prior = pc.Prior([uniform(-5, 10)] * D)
+    rng = np.random.default_rng(31 + lanes)
+    scaler = pc.Reparameterize(D, bounds=prior.bounds)
+    scaler.fit(prior.rvs(2000))
+    x = rng.uniform(-4, 4, size=(N, D))
+    u = scaler.forward(x)
+    like = lambda xx: (-0.5 * np.sum(xx ** 2, axis=1), None)
+    flow = pc.Flow(D, "maf3", seed=0)
+    geo = Geometry()
+    geo.fit(flow.forward(torch.from_numpy(u).float())[0].numpy().astype(np.float64))
+    out = []
+    for drains in ((), (2, 4)):
+        eng = LanedEngine("preconditioned_pcn", N, D, flow, scaler, lanes=lanes, seed=77, x_order="F", streams=False)
+        assert eng.set_device_prior(prior)
+        eng.load_state(u, x, scaler.inverse(u)[1], like(x)[0], prior.logpdf(x))
+        eng.set_geometry(mu=geo.t_mean, cov=geo.t_cov)
+        ad = Adaptation("preconditioned_pcn", D, N, n_steps=10 ** 9, n_max=10 ** 9, sigma0=2.38 / D ** 0.5, mu0=geo.t_mean,
+                        logp2_0=-np.inf)
+        assert eng.can_pipeline()
+        eng.start_pipeline(float(ad.sigma), ad.mu, nu)
+        assert bool(eng._pipe) == (c_pipe == "1")
+        for k in range(1, 7):
+            last = k in drains or k == 6
+            _, sums = eng.step_pipelined(beta, nu, ad.coefficients(), N, prior.logpdf, like, more=not last)
+            ad.update(np.array(sums, copy=True))
+            if k in drains:
+                eng.finish_pipeline()                       # nothing of the next step is in flight ...
+                eng.resume_pipeline(nu)                      # ... until it is asked for
+        eng.finish_pipeline()
+        st = eng.download()
+        out.append((st, float(ad.sigma), ad.mu.copy()))
+    (a, sa, ma), (b, sb, mb) = out
+    assert sa == sb and np.array_equal(ma, mb)
+    for k in ("u", "x", "logl", "logp", "logdetj"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert not np.array_equal(a["x"], x)                     # (walkers did move)
+
+
 @pytest.mark.parametrize("kind,flow_name,D", [("preconditioned_pcn", "maf3", 6), ("preconditioned_pcn", "maf6", 50),
                                               ("preconditioned_rwm", "nsf3", 6), ("pcn", None, 6), ("rwm", None, 6)])
 @pytest.mark.parametrize("lanes", [1, 2])
