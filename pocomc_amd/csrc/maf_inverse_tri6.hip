@@ -44,6 +44,10 @@
 
 typedef unsigned int u32x2_t6 __attribute__((ext_vector_type(2)));
 
+#ifndef TRI6_ABL
+#define TRI6_ABL 0                 // timing experiments only (scripts/abl_tri6.sh): results are wrong when != 0
+#endif
+
 namespace tri6 {
 
 using ::bload4;                    // (maf_common.h)
@@ -152,7 +156,9 @@ template <int HB> struct Ops {
 template <int HB>
 __device__ __forceinline__ void store_quad16(float* H, int T, int c, int p, const f32x4& v) {
     uint2 w;
-    if constexpr (HB == 1) {
+    if constexpr ((TRI6_ABL & 2) != 0) {
+        w.x = __float_as_uint(v[0]); w.y = __float_as_uint(v[2]);
+    } else if constexpr (HB == 1) {
         const b16x2_t6 a = __builtin_convertvector(f32x2_t6{v[0], v[1]}, b16x2_t6), b = __builtin_convertvector(f32x2_t6{v[2], v[3]}, b16x2_t6);
         w.x = *reinterpret_cast<const unsigned*>(&a); w.y = *reinterpret_cast<const unsigned*>(&b);
     } else {
@@ -183,7 +189,7 @@ __device__ __forceinline__ void publish(int* flags, int which, int value) {
 // LDS instruction in front of every DS operation of the chain (measured: chain tile 4.3 k -> 5.3 k cycles)
 template <bool NAP = false>
 __device__ __forceinline__ void wait_for(const int* flags, int which, int value) {
-    while (peek(flags, which) < value) { if constexpr (NAP) __builtin_amdgcn_s_sleep(1); }
+    while (peek(flags, which) < value) { if constexpr (NAP && !(TRI6_ABL & 8)) __builtin_amdgcn_s_sleep(1); }
     asm volatile("" ::: "memory");
 }
 
@@ -204,7 +210,7 @@ struct ChainState {
 template <int HB>
 __device__ __forceinline__ void store_x(float* A, float* X16, int g, int p, float v) {
     A[lidx(g, p)] = v;
-    if constexpr (HB != 0) {
+    if constexpr (HB != 0 && !(TRI6_ABL & 1)) {
         unsigned short h;
         if constexpr (HB == 1) { const __bf16 b = (__bf16)v; h = *reinterpret_cast<const unsigned short*>(&b); }
         else { const _Float16 b = (_Float16)v; h = *reinterpret_cast<const unsigned short*>(&b); }
@@ -765,7 +771,7 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
             // the hidden layer 2's: its row is staged when the chain starts the tile, and it idles from there until the tile's h1
             // is final, while the output wavefront (a tile's output partials, then a new output tile's whole row) is the one the
             // chain waits for (measured: 6.5-8.5 k cycles per iteration against the chain's 5.5 k)
-            constexpr int P0W = NW == 5 ? 4 : (HB ? 2 : 3);
+            constexpr int P0W = NW == 5 ? 4 : ((HB && !(TRI6_ABL & 4)) ? 2 : 3);
             if (wv == P0W) {
                 // layer-0 partial of tile 0: bias only (cut = 0)
                 const float4 b0 = bload4(rs, vo_q, oB0);
