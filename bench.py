@@ -83,10 +83,13 @@ def make_target(name, D):
         return rosenbrock
     if name == "bimodal":
         # BASELINE configs[2] (SURVEY 8(d) cfg 3): equal-weight two-component Gaussian mixture, means +-3, unit covariance
+        # |x -+ 3|^2 = |x|^2 -+ 6 sum(x) + 9 D: two row reductions of x itself instead of two passes over shifted copies
+        # (the same function to 1e-15 relative; round 5 -- the two-pass form cost 590 us per step at 1e4 x 50 on the host and
+        # hid the device behind it)
         def bimodal(x):
-            a = np.einsum("ij,ij->i", x - 3.0, x - 3.0)
-            b = np.einsum("ij,ij->i", x + 3.0, x + 3.0)
-            return np.logaddexp(-0.5 * a, -0.5 * b) - np.log(2.0)
+            s1 = x.sum(axis=1)
+            c = 0.5 * np.einsum("ij,ij->i", x, x) + 4.5 * D
+            return np.logaddexp(3.0 * s1 - c, -3.0 * s1 - c) - np.log(2.0)
         return bimodal
     if name == "funnel":
         # BASELINE configs[4] (SURVEY 8(d) cfg 5): Neal's funnel as a likelihood, x0 ~ N(0, 3^2), x_i ~ N(0, e^{x0})
@@ -415,8 +418,10 @@ def main():
         bufsize0 = np.setbufsize(1024)
     if args.first_lane is None:
         import ctypes as _ct
-        args.first_lane = 0.75 if (args.inverse in ("auto", "triangular", "lane")
-                                   and flow.lib.pmc_debug_inverse_uses_lane(_ct.byref(flow._desc))) else 0.65
+        # (the lane sweep takes the same time for any number of walkers up to a round: the first lane takes a full round of it,
+        #  8192 walkers at two subsets per workgroup -- config 3: 808 (0.65) / 829 (0.75) / 845 (0.82) steps/s, profiles/r05_g_*)
+        args.first_lane = min(0.82, 8192.0 / n) if (args.inverse in ("auto", "triangular", "lane")
+                                                    and flow.lib.pmc_debug_inverse_uses_lane(_ct.byref(flow._desc))) else 0.65
         if flow.spec.univariate == "rqs":
             # the spline sweep is longer than the whole set's likelihood: nothing of the first lane's likelihood is left to hide,
             # the second lane's comes behind its sweep -- the first lane takes all the walker sets one round holds (512 x 16)
