@@ -221,6 +221,15 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def comm_kind_name():
+    """Which kind of mailbox the sharded step's exchange runs on (pocomc_amd.mcmc.small_comm)."""
+    from pocomc_amd import mcmc as pmcmc, _lib
+    lib = _lib.load()
+    kinds = sorted({int(lib.pmc_comm_kind(v[0])) for v in pmcmc._COMMS.values() if v[0]})
+    names = {0: "uncached HBM behind hipIpc handles: peer stores over xGMI", 1: "pinned host memory in POSIX shared memory: PCIe"}
+    return " / ".join(names.get(k, str(k)) for k in kinds) or "none"
+
+
 LANE16_BOUND = 1e-2          # the bound Flow's own guard uses (pocomc_amd/flow.py::LANE16_BOUND)
 
 
@@ -585,11 +594,20 @@ def main():
         ts0 = time.perf_counter()
         if leng is not None and pipelined:
             leng.resume_pipeline(nu)
+        ss_pairs = []
         for k in range(n_ss):
+            if not ev_used and k % args.event_every == 0 and k + 1 < n_ss and len(ss_pairs) < 8:
+                # (a timed region too short to carry an event pair, e.g. --steps 1: the launch is timed here instead)
+                ss_pairs.append((lib.pmc_event_create(), lib.pmc_event_create()))
+                roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = ss_pairs[-1]
+            elif ss_pairs:
+                roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = None, None
             if leng is not None and pipelined:
                 step_laned(more=k + 1 < n_ss)
             else:
                 timed_step()
+        roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = None, None
+        ev_used = ev_used or ss_pairs
         barrier()
         dt_ss = time.perf_counter() - ts0
         if world > 1:
@@ -678,7 +696,7 @@ def main():
                   file=sys.stderr)
         if pipelined:
             leng.finish_pipeline()
-    inv_us_live = float(np.mean([lib.pmc_event_elapsed_ms(a, b) for a, b in ev_used])) * 1e3
+    inv_us_live = (float(np.mean([lib.pmc_event_elapsed_ms(a, b) for a, b in ev_used])) * 1e3 if ev_used else None)
     # the same launch without the scaler epilogue (pmc_step_t.no_fuse bit 1: the scaler as a launch of its own), a few
     # untimed steps: what the sweep alone takes -- side key of the roofline object
     inv_us_sweep_only = None
@@ -748,6 +766,8 @@ def main():
     n_launch = roof_eng.n                                         # walkers of the launch the event pair brackets
     algo_flops = n_launch * spec.flops_inverse_naive()            # (D+1)*F_fwd per walker
     actual_flops = n_launch * 2 * spec.macs_masked()              # what the triangular sweep needs
+    if inv_us_live is None:
+        inv_us_live = us["maf_inverse"]                     # (--steps 1 --no-steady-state: the instrumented pass's figure)
     us["maf_inverse_timed_region"] = inv_us_live            # HIP events inside the timed region
     t_inv = inv_us_live * 1e-6
     lane_auto = args.inverse in ("auto", "triangular") and bool(lib.pmc_debug_inverse_uses_lane(ctypes.byref(flow._desc)))
@@ -980,7 +1000,7 @@ def main():
                       "accept_rate": float((ad_l if leng is not None else ad).mean_alpha),
                       "backend": (dist.get_backend() if world > 1 else None),
                       "collectives": (None if world == 1 else
-                                      ("pmc_comm mailboxes inside the C pipeline (IPC device memory, one 2+2D-double sum per step; "
+                                      ("pmc_comm mailboxes inside the C pipeline (" + comm_kind_name() + ", one D+4-double sum per step; "
                                        "the process group only exchanges the handles at start-up)"
                                        if (laned_host or {}).get("pipeline") else
                                        ("RCCL (torch.distributed nccl backend on ROCm)" if dist.get_backend() == "nccl"
