@@ -260,6 +260,8 @@ def main():
                     help="host likelihood: Rosenbrock (north_star / BASELINE configs[3], default), the 0.95-correlated "
                          "Gaussian of configs[1], the bimodal mixture of configs[2] (--dim 50 --flow maf6) or Neal's funnel of "
                          "configs[4] (--dim 128 --particles 5000 --flow custom8; prior U(-30, 30))")
+    ap.add_argument("--no-pin-calibration", action="store_true",
+                    help="pin the driver thread to the fixed core of its rank instead of the fastest of four probed cores")
     ap.add_argument("--no-pin", action="store_true",
                     help="do not pin the driver thread to the core it starts on (the host likelihood is single-threaded "
                          "numpy; migrations between cores cost ~8 %% and most of the run-to-run noise)")
@@ -496,6 +498,7 @@ def main():
     # pool the CPU baseline uses later, keep the full affinity mask)
     affinity0 = os.sched_getaffinity(0)
     pinned_core = None
+    pin_probe = None
     if not args.no_pin:
         try:
             import ctypes
@@ -505,6 +508,27 @@ def main():
             if cand:
                 pinned_core = cand[(4 + 2 * rank) % len(cand)]          # (rank, not local: ranks that share a GPU in the
                                                                           #  functional test must not share a core)
+                if not args.no_pin_calibration and world == 1 and len(cand) >= 48:   # (ranks keep their fixed cores: no two on one)
+                    # A core of a shared box is not always at its best: scripts/core_probe.py (14 fresh processes x 4 cores
+                    # of this node, profiles/r05_l_core_probe.txt) finds one core sample in ten 10 % slower for tens of
+                    # milliseconds and one in fifty 2x slower (a busy sibling); a process pinned to such a core runs EVERY
+                    # step slower (rounds 4 and 5: one bench process in ten).  So the likelihood is timed for ~3 ms on four
+                    # cores of the node, on the buffer the step hands it, and the driver thread takes the fastest.
+                    xb = (leng.lanes[0] if leng is not None else eng)._np_x
+                    probe = []
+                    for off in (0, 8, 16, 32):
+                        c_ = cand[(4 + 2 * rank + off) % len(cand)]
+                        os.sched_setaffinity(0, {c_})
+                        ts_ = []
+                        for _ in range(3):
+                            target(xb)
+                        t_end = time.perf_counter() + 3e-3
+                        while time.perf_counter() < t_end or len(ts_) < 5:
+                            tq = time.perf_counter(); target(xb); ts_.append(time.perf_counter() - tq)
+                        probe.append((c_, float(np.median(ts_)) * 1e6))
+                    os.sched_setaffinity(0, affinity0)
+                    pinned_core = min(probe, key=lambda t_: t_[1])[0]
+                    pin_probe = [{"core": c_, "likelihood_us": round(u_, 1)} for c_, u_ in probe]
                 # cores for the likelihood's helper threads: the next ones of the same node
                 i0 = cand.index(pinned_core)
                 host_cores = [cand[(i0 + 1 + j) % len(cand)] for j in range(max(0, args.host_threads - 1))]
@@ -1024,6 +1048,7 @@ def main():
            "host_us_per_step": {**{k: v / n_inst * 1e6 for k, v in eng.host_timers.items()},
                                 **{k: v / n_inst * 1e6 for k, v in t_seg.items()}}}
     out["config"]["driver_pinned_to_core"] = pinned_core
+    out["config"]["pin_calibration"] = pin_probe
     if per_rank is not None:
         out["per_rank_us_per_step"] = per_rank
     if dt_ss is not None:
