@@ -143,6 +143,36 @@ def test_a_run_is_reproducible_from_its_random_state(flow_kind):
     assert digests[0] == digests[1]
 
 
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_sampler_runs_on_a_guarded_16bit_flow(prec):
+    """A whole SMC run on a flow wide enough for the lane sweep (16 hidden tiles) with ``inverse_precision`` opted in: every
+    ``Flow.fit`` ends with the guard, every kernel call starts with it on the walkers' own theta, and whichever way the
+    verdicts go (16-bit kept, or float32 with a warning) the run recovers the analytic evidence like the float32 run."""
+    import warnings
+    import pocomc_amd as pc
+    from pocomc_amd.maf_spec import MAFSpec
+    D = 20                                   # (hidden = 256 over 19 degrees: groups of <= 16 units, 16 hidden tiles: the lane sweep)
+    prior = pc.Prior([uniform(-5, 10)] * D)
+
+    def loglike(x):
+        return np.sum(-0.5 * ((x - 0.7) / 0.5) ** 2, axis=1)
+    flow = pc.Flow(D, MAFSpec(D, 3, hidden=256), seed=2, inverse_precision=prec)
+    import ctypes
+    assert flow._lane16 is not None and flow.inverse_precision == prec
+    assert flow.lib.pmc_debug_inverse_uses_lane(ctypes.byref(flow._desc)) == 1
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        s = pc.Sampler(prior=prior, likelihood=loglike, vectorize=True, flow=flow, random_state=5, n_effective=1024,
+                       n_active=512, train_config={"epochs": 40}, mcmc_options=dict(x_order="F"))
+        s.run(progress=False)
+    g = s.flow.inverse_guard
+    fell = [str(m.message) for m in w if "falling back to the float32 sweep" in str(m.message)]
+    print(f"{prec}: last guard {g}; fallbacks during the run: {len(fell)}; active now: {s.flow.inverse_precision_active}")
+    assert g is not None and g["rows"] >= 256 and g["precision"] == prec
+    assert (s.flow.inverse_precision_active == prec) == g["passed"]
+    assert abs(s.evidence()[0] - (D * np.log(0.5 * np.sqrt(2 * np.pi)) - D * np.log(10.0))) < 0.5
+
+
 @pytest.mark.parametrize("flow_name,n", [("maf3", 700), ("maf6", 1500)])
 def test_compute_evidence_replayed_against_the_oracle(flow_name, n):
     """``Sampler._compute_evidence`` (``sampler.py:869-920``: flow.sample -> scaler.inverse -> prior -> likelihood ->
