@@ -229,13 +229,25 @@ __device__ __forceinline__ void tile_groups(const int4& dg, int D, int (&g)[4]) 
 // Speculative hand-over read: the word and the staged data are read in ONE LDS round trip (DS operations of a wave
 // execute in order and the writer stored the data before the word, so data read after a word that already shows
 // `value` are the staged ones); only if the word is behind does the wave poll and read again.
+#if (TRI6_ABL & 32)
+__device__ unsigned long long g_tri6_wait[2 * F_COUNT];      // measurement build: [word] cycles the chain of workgroup 0 waited, [F_COUNT + word] times
+#endif
 template <class LOAD>
 __device__ __forceinline__ void take(const int* flags, int which, int value, LOAD&& load) {
     const int seen = peek(flags, which);
     load();
     asm volatile("" ::: "memory");
     if (seen < value) {
+#if (TRI6_ABL & 32)
+        const long long t0 = clock64();
+#endif
         wait_for(flags, which, value);
+#if (TRI6_ABL & 32)
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+            atomicAdd(&g_tri6_wait[which], (unsigned long long)(clock64() - t0));
+            atomicAdd(&g_tri6_wait[F_COUNT + which], 1ull);
+        }
+#endif
         load();
     }
 }
@@ -560,8 +572,16 @@ __device__ __forceinline__ void chain_group6(ChainState& s, float* H0, float* H1
 
 // NS: 16-walker subsets per workgroup (1, 2 or 4); FM: 0 = plain inverse of `in`, 4 / 8 / 16 / 32 = fused proposal, D <= 4 FM;
 // HB: operand type of the helpers' left-looking products (0 float32, 1 bfloat16, 2 float16; Ops above).
+// Registers (round 5).  Left to itself the compiler gives a four-wavefront instance 300-360 registers: the accumulators of the
+// chain's MFMAs go to AGPRs and every value the vector ALU needs of them comes back through v_accvgpr_read (1068 such moves
+// in the one-subset 16-bit instance, 2852 with two subsets, none in the five-wavefront instances, which have to fit 256) --
+// on a wavefront that is bound by instruction issue.  The plain-inverse instances whose state fits are therefore held to
+// 256 architectural registers (second launch-bound argument: two wavefronts per SIMD): no AGPR, no scratch, and the
+// 16-bit sweep of 5000 x 128 walkers goes from 755 to 649 us (one subset 715 -> 645; D = 50 / maf6 381 -> 329).  With two
+// subsets the helpers' chunks are two pairs instead of four (below: CH) -- they wait thousands of cycles per tile for
+// the chain anyway.  Four subsets and the fused instances need more than 256 and keep the default.
 template <int NS, int FM, int NW = 4, int HB = 0>
-__global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, const float* __restrict__ in,
+__global__ __launch_bounds__(64 * NW, (FM == 0 && (NS == 1 || (NS == 2 && HB != 0))) ? 2 : 1) void maf_inverse_tri6_kernel(pmc_maf_t m, const float* __restrict__ in,
                                                                float* __restrict__ out, float* __restrict__ ladj_out,
                                                                int64_t n, ProposeArgs pa) {
     using namespace tri6;
@@ -759,7 +779,8 @@ __global__ __launch_bounds__(64 * NW) void maf_inverse_tri6_kernel(pmc_maf_t m, 
             };
             // tiles per chunk of the pipelined left-looking products (two chunks' fragments in flight): 16-bit fragments are a
             // quarter of the matrix-pipe time per tile, so the L2 latency needs twice the tiles in flight to stay hidden
-            constexpr int CH = NS <= 2 ? 4 : 2;
+            // (two subsets with 16-bit operands: two pairs per chunk keep the instance within 256 registers, see the kernel's header)
+            constexpr int CH = (NS == 1 || (NS == 2 && HB == 0)) ? 4 : 2;
             // wave 3 keeps the sums of two output tiles (slot = tile & 1) across the hidden tiles: consecutive hidden tiles
             // share their output tiles (8 ranks each), so a hidden tile adds only the h2 tiles that became final since the
             // slot was last staged instead of summing from tile 0 again (same order of additions, same bits); a new output
@@ -1168,6 +1189,15 @@ extern "C" int pmc_maf_pack_lane16(const pmc_maf_t* m, int fmt, uint16_t* image,
     hipLaunchKernelGGL(pack_lane16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *m, fmt, image);
     return pmc_check_launch("pack_lane16_kernel");
 }
+
+#if (TRI6_ABL & 32)
+// measurement build only (scripts/abl_tri6.sh 32): out[2 F_COUNT] <- cycles / times the chain wavefront of workgroup 0 waited per word, then reset
+extern "C" int pmc_debug_tri6_waits(unsigned long long* out) {
+    unsigned long long z[2 * tri6::F_COUNT] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tri6::g_tri6_wait), sizeof(z)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(tri6::g_tri6_wait), z, sizeof(z)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // whether PMC_INVERSE_AUTO (and with it the MCMC step) takes this sweep for the flow (bench.py names the kernel it times)
 extern "C" int pmc_debug_inverse_uses_lane(const pmc_maf_t* m) {

@@ -2,7 +2,7 @@
 # Timing-only ablations of the lane sweep's 16-bit instances (TRI6_ABL bits, csrc/maf_inverse_tri6.hip): one library per
 # value under scripts/abl/, built here (hipcc cross-compiles), timed on the GPU with  PMC_LIBRARY=scripts/abl/lib6_<v>.so
 #   1 no 16-bit copy of x_g   2 no conversion in the chain's activation stores   4 layer-0 partials on the output wavefront
-#   8 helpers poll without naps
+#   8 helpers poll without naps   32 measurement: the chain's waits per hand-over word (scripts/tri6_waits.py)
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p scripts/abl
