@@ -210,10 +210,14 @@ class Flow:
         try:
             self.inverse_algo = 9                                # PMC_INVERSE_TRIANGULAR_LANE16
             x16, l16 = self.inverse(theta)
-            self.inverse_algo = 8                                # PMC_INVERSE_TRIANGULAR_LANE: float32 helpers
+            # the float32 side is what the flow would fall back to: AUTO without the 16-bit image (the float32 lane sweep,
+            # or -- where its activations do not fit the LDS -- the two-wave sweep)
+            self.inverse_algo = 0
+            self._desc.lane16 = None
             x32, l32 = self.inverse(theta)
         finally:
             self.inverse_algo = keep
+            self._desc.lane16 = self._lane16.data_ptr()
         ok32 = torch.isfinite(x32).all(dim=1) & torch.isfinite(l32)
         ok16 = torch.isfinite(x16).all(dim=1) & torch.isfinite(l16)
         lost = int((ok32 & ~ok16).sum().item())
