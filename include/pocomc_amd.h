@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PMC_ABI_VERSION 7
+#define PMC_ABI_VERSION 8
 
 const char* pmc_last_error(void);
 int pmc_abi_version(void);
@@ -97,32 +97,33 @@ int pmc_maf_inverse(const pmc_maf_t* m, const float* z, float* x, float* ladj, i
 int64_t pmc_maf_lane16_elems(const pmc_maf_t* m);
 int pmc_maf_pack_lane16(const pmc_maf_t* m, int fmt, uint16_t* image, void* stream);
 
-/* Training-side device image (host side: MAFSpec.train_index()).  The loss/gradient kernel
- * gives every workgroup a private gradient slab in tile order and a scratch copy of each
- * transform's input; a second kernel sums the slabs into the canonical gradient (no atomics,
- * fixed summation order). */
+/* Training-side device image (host side: MAFSpec.train_index() / train_jobs()).  One minibatch is two launches:
+ * a chain kernel (one workgroup per 16 rows: forward, loss, the backward sweep of the data gradients) that keeps every
+ * activation and every delta of the batch in the scratch arrays below, and a weight-gradient kernel tiled over the
+ * WEIGHT matrices (one workgroup per 16 x 16 tile with an unmasked entry, contracting over all rows of the batch) that
+ * writes the canonical gradient -- no atomics, no per-workgroup copies of the gradient, a fixed summation order. */
 typedef struct pmc_maf_train {
     const float* packedT;     /* transposed weight fragments, filled by pmc_maf_pack with the packT map */
-    const int32_t* gmap;      /* canonical index of every slab element, -1 = masked / padding */
+    const int32_t* gmap;      /* canonical index of every element of a gradient tile / bias row, -1 = masked / padding */
     int64_t pkT_per_transform;
     int64_t gmap_per_transform;
-    float* slabs;             /* [n_slabs][slab_stride] */
-    int64_t slab_stride;      /* floats, >= T * gmap_per_transform, multiple of 4 */
-    int32_t n_slabs;          /* workgroups per launch (row sets beyond that are looped over) */
-    int32_t n_sq_partial;     /* capacity of sq_partial, >= ceil(T * gmap_per_transform / 1024) */
-    float* xt_scratch;        /* [n_slabs][T + 1][Dp * 16] */
-    float* loss_partial;      /* [n_slabs] */
-    float* sq_partial;        /* [n_sq_partial] per-block sums of squared gradient entries */
-    float* act_scratch;       /* [n_slabs][T][3][Hp * 16] hidden activations kept from the forward sweep, or NULL (the
-                               * backward sweep then recomputes them) */
-    const int32_t* sched;     /* device [3][sched_waves][2]: (first, count) of the weight-gradient tiles every wave of a
-                               * workgroup takes in the phases {layer 3, layers 2 and 1, layer 0} (MAFSpec.train_schedule) */
-    int32_t sched_waves;      /* must equal pmc_maf_train_waves(m), the wave count of the training workgroup for this flow */
+    const int32_t* jobs;      /* device int32 [n_jobs][8] (MAFSpec.train_jobs): {kind_a, off_a, kind_b, off_b, gmap offset of
+                               * the weight tile | -1, gmap offset of the 16 bias entries | -1, 0, 0}; kinds 0 xt_scratch,
+                               * 1 act_scratch, 2 delta_scratch, 3 par_scratch; offsets in floats inside a row set's block */
+    int32_t n_jobs;
+    int32_t max_sets;         /* row sets of 16 the scratch arrays hold; a larger batch is taken in chunks of that many */
+    int32_t n_sq_partial;     /* capacity of sq_partial, >= n_jobs */
     int32_t reserved;
+    float* xt_scratch;        /* [max_sets][T + 1][Dp * 16] the input of every transform, then z */
+    float* act_scratch;       /* [max_sets][T][3][Hp * 16] hidden activations h0 h1 h2 */
+    float* delta_scratch;     /* [max_sets][T][3][Hp * 16] their gradients da0 da1 da2 */
+    float* par_scratch;       /* [max_sets][T][par_per_transform] the hyper-network's outputs (affine: nOT tiles of (shift,
+                               * raw); spline: nXT panels of 23 tiles), overwritten by their gradients */
+    int64_t par_per_transform;/* floats: 256 * nOT (affine) or 256 * 23 * nXT (spline) */
+    float* loss_partial;      /* [max_sets] */
+    float* sq_partial;        /* [n_sq_partial] per-workgroup sums of squared gradient entries */
     const float* wsum;        /* NULL: c_n uses the sum of THIS call's weights; else f32 [1] (device) with the sum of
                                * the whole batch's weights, e.g. all-reduced over the ranks of a sharded batch */
-    float* par_scratch;       /* spline flows: [n_slabs][T][nXT][23][256] the hyper-network's output panels kept from the
-                               * forward sweep, or NULL (the backward sweep then multiplies them out again) */
 } pmc_maf_train_t;
 
 /* One minibatch of Flow.fit, pocomc/flow.py:297-323: loss and parameter gradient.
@@ -131,9 +132,7 @@ typedef struct pmc_maf_train {
  * The batch is rows idx[0..n) of x / w (idx i64 device, or NULL for rows 0..n).  x f32 [.][D];
  * grad f32 [n_params] in the canonical layout is OVERWRITTEN at every unmasked entry (masked
  * entries are never touched: allocate it zeroed); loss f32 [1] is ACCUMULATED.
- * tr->sq_partial receives the per-block sums of squares that pmc_maf_train_epoch clips with. */
-/* Wavefronts per training workgroup for this flow: the n_waves pmc_maf_train_t.sched must be built for. */
-int pmc_maf_train_waves(const pmc_maf_t* m);
+ * tr->sq_partial[0 .. n_jobs) receives the sums of squares that pmc_maf_train_epoch clips with. */
 int pmc_maf_loss_grad(const pmc_maf_t* m, const pmc_maf_train_t* tr, const float* x, const float* w,
                       const int64_t* idx, float wmul, float* grad, float* loss, int64_t n, void* stream);
 

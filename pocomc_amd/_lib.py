@@ -28,10 +28,10 @@ class pmc_maf_t(C.Structure):
 class pmc_maf_train_t(C.Structure):
     _fields_ = [("packedT", c_p), ("gmap", c_p), ("pkT_per_transform", C.c_int64),
                 ("gmap_per_transform", C.c_int64),
-                ("slabs", c_p), ("slab_stride", C.c_int64), ("n_slabs", C.c_int32), ("n_sq_partial", C.c_int32),
-                ("xt_scratch", c_p), ("loss_partial", c_p), ("sq_partial", c_p), ("act_scratch", c_p),
-                ("sched", c_p), ("sched_waves", C.c_int32), ("reserved", C.c_int32), ("wsum", c_p),
-                ("par_scratch", c_p)]
+                ("jobs", c_p), ("n_jobs", C.c_int32), ("max_sets", C.c_int32), ("n_sq_partial", C.c_int32),
+                ("reserved", C.c_int32),
+                ("xt_scratch", c_p), ("act_scratch", c_p), ("delta_scratch", c_p), ("par_scratch", c_p),
+                ("par_per_transform", C.c_int64), ("loss_partial", c_p), ("sq_partial", c_p), ("wsum", c_p)]
 
 
 class pmc_maf_wide_t(C.Structure):
@@ -107,7 +107,6 @@ SIGNATURES = {
     "pmc_last_error": (C.c_char_p, []),
     "pmc_adapt_update": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
-    "pmc_maf_train_waves": (C.c_int, [C.POINTER(pmc_maf_t)]),
     "pmc_debug_inverse_uses_duo": (C.c_int, [C.POINTER(pmc_maf_t), C.c_int64]),
     "pmc_debug_inverse_uses_lane": (C.c_int, [C.POINTER(pmc_maf_t)]),
     "pmc_debug_inverse_uses_nsf2": (C.c_int, [C.POINTER(pmc_maf_t)]),
@@ -227,7 +226,7 @@ def load():
         fn = getattr(lib, name)            # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.pmc_abi_version() != 7:
+    if lib.pmc_abi_version() != 8:
         raise PocomcAmdError("libpocomc_amd.so: ABI version mismatch")
     _lib = lib
     return lib

@@ -287,8 +287,8 @@ extern "C" int pmc_maf_forward_bf16(const pmc_maf_t* m, const uint16_t* image, i
     // scratch round trip): 157 / 124 us against 150 / 122 -- nothing: a layer does not start with an exposed round trip, its
     // two tiles per wave stream ~270 KB through a CU that takes in ~41 B/clk (scripts/micro/load_latency.hip): 75 us of the
     // 150 are that feed, the rest barrier skew between sixteen waves.  Removed again.
-    static const int f_rs = getenv("PMC_FWD_BF16_RS") ? atoi(getenv("PMC_FWD_BF16_RS")) : 0;
-    static const int f_nw = getenv("PMC_FWD_BF16_NW") ? atoi(getenv("PMC_FWD_BF16_NW")) : 0;
+    static const int f_rs = pmc_env_int("PMC_FWD_BF16_RS", 0);
+    static const int f_nw = pmc_env_int("PMC_FWD_BF16_NW", 0);
     int rs = f_rs ? f_rs : (n >= 4096 ? 2 : 1);
     int nw = f_nw ? f_nw : (n <= 16 * 1024 ? (m->nT >= 16 ? 16 : 8) : 4);       // (sixteen waves need sixteen tiles a layer)
     if (rs == 2 && fwd_bf16_lds(m, nw == 16 ? 16 : 8, 2) > 160 * 1024) rs = 1;

@@ -182,7 +182,7 @@ static int launch_forward_wg(const pmc_maf_t* m, const float* x, float* z, float
 int pmc_launch_forward_wg(const pmc_maf_t* m, const float* x, float* z, float* ladj, float* log_prob, int64_t n,
                           hipStream_t st, const int64_t* idx) {
     // enough row sets to give every SIMD a few waves anyway -> fewer waves per set (less barrier idling)
-    static const int force = getenv("PMC_FWD_NW") ? atoi(getenv("PMC_FWD_NW")) : 0;      // A/B switch
+    static const int force = pmc_env_int("PMC_FWD_NW", 0);      // A/B switch
     const bool wide = force ? force == 8 : n <= 16 * 1024;
     if (m->n_out == RQS_NOUT)
         return wide ? launch_forward_wg<8, 1, 0>(m, x, z, ladj, log_prob, n, st, idx)

@@ -4,26 +4,32 @@
 //   loss = sum_n c_n * (-log_prob(x_n)),   c_n = 1                         (flow.py:309)
 //                                          c_n = w_n * 1000 / sum(w_batch) (flow.py:311-312)
 //
-// A minibatch is at most 512 rows (sampler.py:289), so the step is latency bound, not throughput
-// bound.  One WORKGROUP of TRAIN_WAVES (16; 8 for narrow spline flows) wavefronts owns 16 rows: the tiles of every layer are dealt to the
-// waves (cost-balanced over the triangular layers), the activations sit in workgroup LDS in
-// the MFMA operand layout of the inference kernels, and a barrier separates dependent layers.
-// Forward stores the input and the three hidden activations of every transform in a global scratch
-// (L2 resident; without the activation scratch the backward sweep recomputes them); the backward
-// sweep takes one transform at a time:
-//     d(shift, raw) -> dW3, db3 -> dh2 = W3^T . -> relu' -> dW2, db2 -> dh1 = da2 + W2^T da2 -> ...
-// Data-gradient products  dh = W^T da  are MFMA bursts over pre-transposed weight fragments
-// (packedT); weight-gradient tiles  dW[out][in] = sum_rows da[out][row] h[in][row]  contract over
-// the 16 rows with four v_mfma_f32_16x16x4_f32.
+// A minibatch is at most 512 rows (sampler.py:289): 32 row sets of 16.  The step is two launches.
 //
-// No atomics: every workgroup owns a gradient SLAB in tile order (one coalesced float4 store per
-// lane per tile; a workgroup that processes several row sets read-modify-writes its own slab), and
-// reduce_slabs_kernel sums the slabs into the canonical gradient through the host-built map
-// (masked weights and padding map to -1 and are never touched).  Sums run in a fixed order, so a
-// training run is bitwise reproducible.
+// (1) maf_chain_kernel -- the part that IS a dependency chain.  One WORKGROUP of TRAIN_WAVES (16; 8 for narrow
+// spline flows) wavefronts owns 16 rows: the tiles of every layer are dealt to the waves, the activations sit in
+// workgroup LDS in the MFMA operand layout of the inference kernels, and a barrier separates dependent layers.
+// Forward keeps, per transform, its input, the three hidden activations and the hyper-network's outputs in a global
+// scratch (L2 / MALL resident); the backward sweep takes one transform at a time:
+//     d(shift, raw) -> dh2 = W3^T . -> relu' -> dh1 = da2 + W2^T da2 -> ...
+// Data-gradient products  dh = W^T da  are MFMA bursts over pre-transposed weight fragments (packedT).  Every delta
+// (d outputs, da2, da1, da0) is stored NEXT TO the activation it pairs with -- the workgroup computes no weight
+// gradient: on the f32 matrix pipe of ONE compute unit (32 cycles per v_mfma_f32_16x16x4_f32 and SIMD) the
+// weight-gradient tiles were a third of the chain's MFMA time, and the 32 workgroups of a 512-row batch leave
+// 224 of the 256 compute units idle.
+//
+// (2) maf_dw_kernel -- the part that is NOT a chain.  dW[out][in] = sum over ALL rows of delta[out][row] *
+// act[in][row] is a K = 512 product tiled over the WEIGHT matrix: one workgroup per 16 x 16 tile with at least one
+// unmasked entry (MAFSpec.train_jobs: a few hundred per flow, on every compute unit), its four wavefronts take a
+// quarter of the row sets each (four v_mfma_f32_16x16x4_f32 per set, operands straight from the scratch in the LDS
+// layout the chain kernel wrote), partial tiles are added in wave order, the bias gradient of the tile's 16 output
+// units rides along with the first tile of a row (the sum of the A operand over the rows), and the tile goes to the
+// canonical gradient through the host-built map (masked weights and padding map to -1 and are never touched).  No
+// atomics, no per-workgroup slabs, no reduction pass: sums run in a fixed order, a training run is bitwise
+// reproducible.  Its block sums of squares feed the clip of the optimizer launch.
 //
 // LDS buffers alias along the backward sweep (4 hidden-width buffers instead of 7):
-//     E: x_t -> da2 -> da0      A: h0      B: h1 -> x_t (reload for dW0)      C: h2 -> da1
+//     E: x_t -> da2 -> da0      A: h0      B: h1      C: h2 -> da1
 //     P: (shift, raw) -> their gradients -> dx      G: dL/dy -> direct dL/dx term -> dL/dy of t-1
 // which keeps the 8-transform, H=512, D=128 flow (BASELINE config 5) inside 160 KB.
 
@@ -35,16 +41,12 @@
 #ifndef TRAIN_PF
 #define TRAIN_PF 4                  // weight fragments in flight per wave
 #endif
-#ifndef TRAIN_WARM_L2
-#define TRAIN_WARM_L2 0      // measured neutral on MI355X (the phases are not L2-miss bound)
-#endif
 #ifndef TRAIN_WAVES
 #define TRAIN_WAVES 16              // waves of a training workgroup ...
 #endif
 // ... except for narrow spline flows (hidden width <= 64): their layers have fewer tiles than that many waves, the
-// spline evaluation runs on four waves either way, and a barrier over 8 waves is cheaper -- measured on MI355X per
-// 256-row batch: nsf6 D=4 142 -> 113 us, D=10 157 -> 135 us, D=20 272 -> 243 us (D=32, H=128: 227 -> 256 us, so not
-// there; the affine flows do not care).  With half the waves a wave has 256 registers: 8 fragments in flight.
+// spline evaluation runs on four waves either way, and a barrier over 8 waves is cheaper.  With half the waves a
+// wave has 256 registers: 8 fragments in flight.
 #define TRAIN_WAVES_NARROW 8
 #define TRAIN_PF_NARROW 8
 static int train_waves_of(const pmc_maf_t& m) {
@@ -53,59 +55,17 @@ static int train_waves_of(const pmc_maf_t& m) {
 
 struct TrainView {
     const float4* f0T; const float4* f1T; const float4* f2T; const float4* f3T;
-    // slab offsets (floats) of this transform's gradient tiles / bias rows
-    int64_t g0, g1, g2, g3, gb0, gb1, gb2, gb3;
 };
 
 __device__ __forceinline__ TrainView train_view(const pmc_maf_t& m, const pmc_maf_train_t& tr, int t) {
     TrainView v;
-    const size_t nT = m.nT, nXT = m.nXT, nOT = m.nOT;
+    const size_t nT = m.nT, nXT = m.nXT;
     const float* p = tr.packedT + (size_t)t * tr.pkT_per_transform;
     v.f0T = reinterpret_cast<const float4*>(p); p += nXT * nT * 256;
     v.f1T = reinterpret_cast<const float4*>(p); p += nT * nT * 256;
     v.f2T = reinterpret_cast<const float4*>(p); p += nT * nT * 256;
     v.f3T = reinterpret_cast<const float4*>(p);
-    int64_t g = (int64_t)t * tr.gmap_per_transform;
-    v.g0 = g; g += nT * nXT * 256;
-    v.g1 = g; g += nT * nT * 256;
-    v.g2 = g; g += nT * nT * 256;
-    v.g3 = g; g += nOT * nT * 256;
-    v.gb0 = g; g += m.Hp;
-    v.gb1 = g; g += m.Hp;
-    v.gb2 = g; g += m.Hp;
-    v.gb3 = g;
     return v;
-}
-
-__device__ __forceinline__ void slab_put4(float* __restrict__ dst, const f32x4& v, bool first) {
-    float4* d = reinterpret_cast<float4*>(dst);
-    float4 o = make_float4(v[0], v[1], v[2], v[3]);
-    if (!first) { const float4 c = *d; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
-    *d = o;
-}
-
-// dW tile: D[i][j] = sum_p a_rows[16*Ta + i][p] * b_rows[16*Tb + j][p]
-__device__ __forceinline__ f32x4 outer_tile(const float* A, int Ta, const float* B, int Tb, int lane) {
-    const int i = lane & 15, kq = lane >> 4;
-    const int offA = (Ta << 8) + ((i & 3) << 6) + (i >> 2);
-    const int offB = (Tb << 8) + ((i & 3) << 6) + (i >> 2);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int pp = (4 * c + kq) << 2;
-        acc = MFMA(A[offA + pp], B[offB + pp], acc);
-    }
-    return acc;
-}
-
-// bias gradient of the 4 rows a lane holds: sum over the 16 rows of the set, written by lane p == 0
-__device__ __forceinline__ void bias_put(float* __restrict__ dst, f32x4 v, int lane, bool first) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float s = v[r];
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-        if ((lane & 15) == 0) dst[r] = first ? s : dst[r] + s;
-    }
 }
 
 // out-layer panel of ranks [16c, 16c+16) of a spline flow: output tiles 23c .. 23c+22 -> P (local tile index).
@@ -132,12 +92,14 @@ __device__ __forceinline__ void rqs_panel_train(const pmc_maf_t& m, const MafVie
 }
 
 // UNI 0: affine univariate (MAF), 2 outputs per feature.  UNI 1: 8-bin spline (NSF), 23 outputs.
+// One workgroup per row set of 16 (rows 16 (set0 + blockIdx.x) ..., scratch block blockIdx.x).
 template <int NW, int PF, bool PROF, int UNI>
-__global__ __launch_bounds__(64 * NW) void maf_lossgrad_kernel(pmc_maf_t m, pmc_maf_train_t tr,
-                                                                     const float* __restrict__ x,
-                                                                     const float* __restrict__ w,
-                                                                     const int64_t* __restrict__ idx, float wmul,
-                                                                     int64_t n, long long* __restrict__ prof) {
+__global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf_train_t tr,
+                                                                  const float* __restrict__ x,
+                                                                  const float* __restrict__ w,
+                                                                  const int64_t* __restrict__ idx, float wmul,
+                                                                  int64_t n, int64_t set0,
+                                                                  long long* __restrict__ prof) {
     long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tk = TICKT();
     const long long t_begin = tk;
@@ -159,12 +121,12 @@ __global__ __launch_bounds__(64 * NW) void maf_lossgrad_kernel(pmc_maf_t m, pmc_
     float* XB = RED + 16 * NW;       // UNI 1: [Dp*16] the transform's input during its backward sweep
     const int* feat_of_rank = m.meta + 8;
     const int* rank_of_feat = m.meta + 8 + T * D;
-    float* slab = tr.slabs + (size_t)blockIdx.x * tr.slab_stride;
-    float* xt = tr.xt_scratch + (size_t)blockIdx.x * (T + 1) * Dp * 16;
-    // hidden activations of every transform, kept from the forward sweep (the backward sweep then loads them
-    // instead of recomputing three layers); NULL: recompute
-    float* act = tr.act_scratch ? tr.act_scratch + (size_t)blockIdx.x * T * 3 * Hp * 16 : nullptr;
-    float* par = (UNI == 1 && tr.par_scratch) ? tr.par_scratch + (size_t)blockIdx.x * T * m.nXT * RQS_NOUT * 256 : nullptr;
+    const int64_t set = blockIdx.x;
+    // what the forward sweep keeps for the backward sweep and both keep for the weight-gradient kernel
+    float* xt = tr.xt_scratch + (size_t)set * (T + 1) * Dp * 16;           // input of every transform (+ z)
+    float* act = tr.act_scratch + (size_t)set * T * 3 * Hp * 16;            // h0, h1, h2 of every transform
+    float* dlt = tr.delta_scratch + (size_t)set * T * 3 * Hp * 16;          // da0, da1, da2 of every transform
+    float* par = tr.par_scratch + (size_t)set * T * tr.par_per_transform;   // outputs, then their gradients
 
     // sum of the batch weights, the same fixed-order sum in every workgroup (flow.py:311)
     float wscale = 1.0f;
@@ -182,30 +144,9 @@ __global__ __launch_bounds__(64 * NW) void maf_lossgrad_kernel(pmc_maf_t m, pmc_
         __syncthreads();
     }
 
-    // Both weight images were rewritten by the previous batch's optimizer step, so this XCD's L2 holds none of
-    // them and every layer would start with a miss to MALL / HBM (~1.5-2 k cycles, ~45 dependent phases).
-    // Workgroups are dealt round-robin to the 8 XCDs: the workgroups of one XCD each touch a share of the two
-    // images once, up front (one dword per 128-byte line, consumed at the very end so nothing waits on them).
-    float warm = 0.0f;
-    if (TRAIN_WARM_L2) {
-        const int per_xcd = max(1, (int)((gridDim.x + 7) >> 3));
-        const int share = min((int)(blockIdx.x >> 3), per_xcd - 1);
-        const int64_t lines_a = ((int64_t)T * m.pk_per_transform * 4) >> 7, lines_b = ((int64_t)T * tr.pkT_per_transform * 4) >> 7;
-        for (int64_t l = (int64_t)share * (64 * NW) + tid; l < lines_a + lines_b; l += (int64_t)per_xcd * (64 * NW))
-            warm += (l < lines_a) ? m.packed[l << 5] : tr.packedT[(l - lines_a) << 5];
-    }
-
-    // contiguous ranges of weight-gradient tiles per phase (layer 3 | layers 2,1 | layer 0), balanced on the host
-    // against the data-gradient tiles the dealing rules give each wave (MAFSpec.train_schedule)
-    const int dw3_start = tr.sched[(0 * NW + wv) * 2], dw3_count = tr.sched[(0 * NW + wv) * 2 + 1];
-    const int dwt_start = tr.sched[(1 * NW + wv) * 2], dwt_count = tr.sched[(1 * NW + wv) * 2 + 1];
-    const int dw0_start = tr.sched[(2 * NW + wv) * 2], dw0_count = tr.sched[(2 * NW + wv) * 2 + 1];
-
     float loss_acc = 0.0f;
-    bool first = true;
-    const int64_t nsets = (n + 15) / 16;
-    for (int64_t set = blockIdx.x; set < nsets; set += gridDim.x, first = false) {
-        const int64_t row0 = set * 16;
+    {
+        const int64_t row0 = (set0 + set) * 16;
         if (tid < 16) {
             float c = 0.0f;
             if (row0 + tid < n) {
@@ -233,8 +174,9 @@ __global__ __launch_bounds__(64 * NW) void maf_lossgrad_kernel(pmc_maf_t m, pmc_
         for (int t = 0; t < T; ++t) {
             const MafView wvw = maf_view(m, t);
             float* xtn = xt + (size_t)(t + 1) * Dp * 16;
+            float* part = par + (size_t)t * tr.par_per_transform;
             hidden_pass_wg<NW, PF, PROF>(m, wvw, Xc, A, B, Cb, wv, lane, pacc, tk);
-            if (act) {                                       // A, B, Cb are contiguous in LDS: one copy
+            {                                                // A, B, Cb are contiguous in LDS: one copy
                 float4* dst = reinterpret_cast<float4*>(act + (size_t)t * 3 * Hp * 16);
                 for (int e = tid; e < 3 * Hp * 4; e += (64 * NW)) dst[e] = reinterpret_cast<const float4*>(A)[e];
             }
@@ -243,6 +185,7 @@ __global__ __launch_bounds__(64 * NW) void maf_lossgrad_kernel(pmc_maf_t m, pmc_
                 for (int O = wv; O < nOeff; O += NW) {
                     f32x4 o = bias4(wvw.b3, 16 * O + 4 * q);
                     o = mac_range<PF>(o, wvw.f3 + (size_t)O * nT * 64, Cb, 0, nT, lane);
+                    store_rows(part, O, q, p, o);            // (shift, raw): the backward sweep reads them back
                     for (int s = 0; s < 2; ++s) {
                         const int rank = 8 * O + 2 * q + s;
                         if (rank < D) {
@@ -259,8 +202,7 @@ __global__ __launch_bounds__(64 * NW) void maf_lossgrad_kernel(pmc_maf_t m, pmc_
                 }
             } else {
                 for (int c = 0; c < nXT; ++c) {
-                    rqs_panel_train<NW, PF>(m, wvw, Cb, P, c, wv, lane,
-                                    par ? par + ((size_t)t * nXT + c) * RQS_NOUT * 256 : nullptr);
+                    rqs_panel_train<NW, PF>(m, wvw, Cb, P, c, wv, lane, part + (size_t)c * RQS_NOUT * 256);
                     lds_barrier();
                     for (int e = tid; e < 256; e += (64 * NW)) {
                         const int rr = e >> 4, pp = e & 15, rank = 16 * c + rr;
@@ -290,7 +232,7 @@ __global__ __launch_bounds__(64 * NW) void maf_lossgrad_kernel(pmc_maf_t m, pmc_
         {
             const float l = quad_sum(ladj);
             if (lane < 16) RED[wv * 16 + lane] = l;
-            __syncthreads();                             // full barrier: the xt scratch written above is read below
+            __syncthreads();                             // full barrier: the scratch written above is read below
             const float* Z = Xc;                         // rank order of the last transform
             if (wv == 0) {
                 float ss = 0.0f;
@@ -315,26 +257,17 @@ __global__ __launch_bounds__(64 * NW) void maf_lossgrad_kernel(pmc_maf_t m, pmc_
 
         // -------------------------------------------------------- backward
         for (int t = T - 1; t >= 0; --t) {
-            const MafView wvw = maf_view(m, t);
             const TrainView tv = train_view(m, tr, t);
             const float4* xsrc = reinterpret_cast<const float4*>(xt + (size_t)t * Dp * 16);
+            float* part = par + (size_t)t * tr.par_per_transform;
+            float* dl = dlt + (size_t)t * 3 * Hp * 16;
+            const float4* asrc = reinterpret_cast<const float4*>(act + (size_t)t * 3 * Hp * 16);
             if (UNI == 0) {
+                // x_t -> E, (h0, h1, h2) -> A, B, C, (shift, raw) -> P: everything the forward sweep kept
                 for (int e = tid; e < Dp * 4; e += (64 * NW)) reinterpret_cast<float4*>(E)[e] = xsrc[e];
-                if (act) {
-                    const float4* src = reinterpret_cast<const float4*>(act + (size_t)t * 3 * Hp * 16);
-                    for (int e = tid; e < 3 * Hp * 4; e += (64 * NW)) reinterpret_cast<float4*>(A)[e] = src[e];
-                    lds_barrier();
-                } else {
-                    lds_barrier();
-                    // recompute this transform's activations
-                    hidden_pass_wg<NW, PF, PROF>(m, wvw, E, A, B, Cb, wv, lane, pacc, tk);
-                }
-                // (shift, raw) of the transform
-                for (int O = wv; O < nOeff; O += NW) {
-                    f32x4 o = bias4(wvw.b3, 16 * O + 4 * q);
-                    o = mac_range<PF>(o, wvw.f3 + (size_t)O * nT * 64, Cb, 0, nT, lane);
-                    store_rows(P, O, q, p, o);
-                }
+                for (int e = tid; e < nOeff * 64; e += (64 * NW))
+                    reinterpret_cast<float4*>(P)[e] = reinterpret_cast<const float4*>(part)[e];
+                for (int e = tid; e < 3 * Hp * 4; e += (64 * NW)) reinterpret_cast<float4*>(A)[e] = asrc[e];
                 PHASE_END(4)
                 // element-wise part: y = x e^{ls} + shift,  L += -c * sum ls   (in place: P -> dP, G -> direct dx)
                 for (int e = tid; e < Dp * 16; e += (64 * NW)) {
@@ -355,40 +288,31 @@ __global__ __launch_bounds__(64 * NW) void maf_lossgrad_kernel(pmc_maf_t m, pmc_
                     Gb[lidx(r, pp)] = gx;
                 }
                 PHASE_END(5)
-                // ---- layer 3: da2 = relu'(h2) . W3^T dP -> E ; dW3, db3, db2
+                // ---- layer 3: da2 = relu'(h2) . W3^T dP -> E ; dP -> scratch (dW3, db3)
+                for (int e = tid; e < nOeff * 64; e += (64 * NW))
+                    reinterpret_cast<float4*>(part)[e] = reinterpret_cast<const float4*>(P)[e];
                 for (int K = wv; K < nT; K += NW) {
                     f32x4 a = {0.f, 0.f, 0.f, 0.f};
                     a = mac_range<PF>(a, tv.f3T + (size_t)K * nOT * 64, P, 0, nOeff, lane);
                     a = relu_gate(a, Cb, K, q, p);
                     store_rows(E, K, q, p, a);
-                    bias_put(slab + tv.gb2 + 16 * K + 4 * q, a, lane, first);
-                }
-                for (int O = wv; O < nOeff; O += NW)
-                    bias_put(slab + tv.gb3 + 16 * O + 4 * q, rows_of(P, O, q, p), lane, first);
-                for (int i = dw3_start, O = 0, K = dw3_start; i < dw3_start + dw3_count; ++i, ++K) {
-                    while (K >= nT) { K -= nT; ++O; }              // (O, K) of tile i without a division
-                    slab_put4(slab + tv.g3 + ((size_t)i * 64 + lane) * 4, outer_tile(P, O, Cb, K, lane), first);
+                    store_rows(dl + 2 * Hp * 16, K, q, p, a);
                 }
                 PHASE_END(6)
             } else {
+                const MafView wvw = maf_view(m, t);
                 // x_t -> XB (kept for the whole spline sweep), E <- 0 (accumulates W3^T dP over the panels)
                 for (int e = tid; e < Dp * 4; e += (64 * NW)) reinterpret_cast<float4*>(XB)[e] = xsrc[e];
                 for (int e = tid; e < Hp * 4; e += (64 * NW))
                     reinterpret_cast<float4*>(E)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (act) {
-                    const float4* src = reinterpret_cast<const float4*>(act + (size_t)t * 3 * Hp * 16);
-                    for (int e = tid; e < 3 * Hp * 4; e += (64 * NW)) reinterpret_cast<float4*>(A)[e] = src[e];
-                    lds_barrier();
-                } else {
-                    lds_barrier();
-                    hidden_pass_wg<NW, PF, PROF>(m, wvw, XB, A, B, Cb, wv, lane, pacc, tk);
-                }
+                for (int e = tid; e < 3 * Hp * 4; e += (64 * NW)) reinterpret_cast<float4*>(A)[e] = asrc[e];
+                lds_barrier();
                 LAPT(4)
                 for (int c = 0; c < nXT; ++c) {
                     const int O0 = RQS_NOUT * c;                         // first output tile of the panel
                     const int nO = min(RQS_NOUT, nOeff - O0);            // its tiles with real rows
-                    rqs_panel_train<NW, PF>(m, wvw, Cb, P, c, wv, lane, nullptr,
-                                    par ? par + ((size_t)t * nXT + c) * RQS_NOUT * 256 : nullptr);
+                    float* pc = part + (size_t)c * RQS_NOUT * 256;
+                    rqs_panel_train<NW, PF>(m, wvw, Cb, P, c, wv, lane, nullptr, pc);
                     PHASE_END(4)
                     // spline backward in place: P -> dP, G -> direct dL/dx term
                     for (int e = tid; e < 256; e += (64 * NW)) {
@@ -405,42 +329,25 @@ __global__ __launch_bounds__(64 * NW) void maf_lossgrad_kernel(pmc_maf_t m, pmc_
                         }
                     }
                     PHASE_END(5)
-                    // W3^T dP of this panel into E (every wave owns whole tiles of E), db3, dW3
+                    // W3^T dP of this panel into E (every wave owns whole tiles of E); dP -> scratch (dW3, db3)
+                    for (int e = tid; e < nO * 64; e += (64 * NW))
+                        reinterpret_cast<float4*>(pc)[e] = reinterpret_cast<const float4*>(P)[e];
                     for (int K = wv; K < nT; K += NW) {
                         f32x4 a = rows_of(E, K, q, p);
                         a = mac_range<PF>(a, tv.f3T + ((size_t)K * nOT + O0) * 64, P, 0, nO, lane);
                         store_rows(E, K, q, p, a);
                     }
-                    for (int i = wv; i < nO; i += NW)
-                        bias_put(slab + tv.gb3 + 16 * (O0 + i) + 4 * q, rows_of(P, i, q, p), lane, first);
-                    {
-                        // dW3 tiles (Ol, K) of the panel.  The waves wv < nT just multiplied a whole tile of E (nO K
-                        // steps each): with fewer hidden tiles than waves they take only qh weight-gradient tiles
-                        // (a tile costs about two K steps), the free waves share the rest.
-                        const int n_light = nO * nT;
-                        int first_i = wv, stride = NW, last_i = n_light;
-                        if (nT < NW) {
-                            const int qh = max(0, ((nT * nO + 2 * n_light) / NW - nO) / 2);
-                            if (wv < nT) { stride = nT; last_i = min(n_light, nT * qh); }
-                            else { first_i = nT * qh + (wv - nT); stride = NW - nT; }
-                        }
-                        for (int i = first_i; i < last_i; i += stride) {
-                            const int Ol = i / nT, K = i - Ol * nT;
-                            slab_put4(slab + tv.g3 + (((size_t)(O0 + Ol) * nT + K) * 64 + lane) * 4,
-                                      outer_tile(P, Ol, Cb, K, lane), first);
-                        }
-                    }
                     PHASE_END(6)
                 }
-                // da2 = relu'(h2) . (W3^T dP), db2
+                // da2 = relu'(h2) . (W3^T dP)
                 for (int K = wv; K < nT; K += NW) {
                     f32x4 a = relu_gate(rows_of(E, K, q, p), Cb, K, q, p);
                     store_rows(E, K, q, p, a);
-                    bias_put(slab + tv.gb2 + 16 * K + 4 * q, a, lane, first);
+                    store_rows(dl + 2 * Hp * 16, K, q, p, a);
                 }
                 PHASE_END(6)
             }
-            // ---- layer 2: da1 = relu'(h1) . (da2 + W2^T da2) -> C ; dW2 (da2 x h1), db1
+            // ---- layer 2: da1 = relu'(h1) . (da2 + W2^T da2) -> C
             for (int it = 0;; ++it) {                              // the tiles this wave owns, most expensive first
                 const int Ti = snake_item<NW>(wv, it);
                 if (Ti >= nT) break;
@@ -448,19 +355,10 @@ __global__ __launch_bounds__(64 * NW) void maf_lossgrad_kernel(pmc_maf_t m, pmc_
                 a = mac_range<PF>(a, tv.f2T + (size_t)Ti * nT * 64, E, (m.tri_ok ? Ti : 0), nT, lane);
                 a = relu_gate(a, B, Ti, q, p);
                 store_rows(Cb, Ti, q, p, a);
-                bias_put(slab + tv.gb1 + 16 * Ti + 4 * q, a, lane, first);
-            }
-            {   // weight-gradient tiles (To, Ti <= To) in row-major order: this wave's contiguous range
-                int To = 0, Ti = dwt_start;
-                for (int i = 0; i < dwt_count; ++i, ++Ti) {
-                    if (m.tri_ok) { while (Ti > To) { Ti -= To + 1; ++To; } }
-                    else { while (Ti >= nT) { Ti -= nT; ++To; } }
-                    slab_put4(slab + tv.g2 + (((size_t)To * nT + Ti) * 64 + lane) * 4, outer_tile(E, To, B, Ti, lane),
-                              first);
-                }
+                store_rows(dl + Hp * 16, Ti, q, p, a);
             }
             PHASE_END(7)
-            // ---- layer 1: da0 = relu'(h0) . (da1 + W1^T da1) -> E ; dW1 (da1 x h0), db0 ; x_t -> B
+            // ---- layer 1: da0 = relu'(h0) . (da1 + W1^T da1) -> E
             for (int it = 0;; ++it) {
                 const int Ti = snake_item<NW>(wv, it);
                 if (Ti >= nT) break;
@@ -468,36 +366,17 @@ __global__ __launch_bounds__(64 * NW) void maf_lossgrad_kernel(pmc_maf_t m, pmc_
                 a = mac_range<PF>(a, tv.f1T + (size_t)Ti * nT * 64, Cb, (m.tri_ok ? Ti : 0), nT, lane);
                 a = relu_gate(a, A, Ti, q, p);
                 store_rows(E, Ti, q, p, a);
-                bias_put(slab + tv.gb0 + 16 * Ti + 4 * q, a, lane, first);
-            }
-            for (int e = tid; e < Dp * 4; e += (64 * NW)) reinterpret_cast<float4*>(B)[e] = xsrc[e];
-            {   // weight-gradient tiles (To, Ti <= To) in row-major order: this wave's contiguous range
-                int To = 0, Ti = dwt_start;
-                for (int i = 0; i < dwt_count; ++i, ++Ti) {
-                    if (m.tri_ok) { while (Ti > To) { Ti -= To + 1; ++To; } }
-                    else { while (Ti >= nT) { Ti -= nT; ++To; } }
-                    slab_put4(slab + tv.g1 + (((size_t)To * nT + Ti) * 64 + lane) * 4, outer_tile(Cb, To, A, Ti, lane),
-                              first);
-                }
+                store_rows(dl, Ti, q, p, a);
             }
             PHASE_END(8)
-            // ---- layer 0: dW0 (da0 x x), dx = direct + W0^T da0 -> P
+            // ---- layer 0: dx = direct + W0^T da0 -> P
             if (t > 0) {
                 for (int Xi = wv; Xi < nXT; Xi += NW) {
                     f32x4 a = rows_of(Gb, Xi, q, p);
                     a = mac_range<PF>(a, tv.f0T + (size_t)Xi * nT * 64, E, 0, nT, lane);
                     store_rows(P, Xi, q, p, a);
                 }
-            }
-            {
-                // without the dx tiles (t == 0) the ranges are still a valid partition, just less balanced
-                for (int i = dw0_start, To = 0, Xi = dw0_start; i < dw0_start + dw0_count; ++i, ++Xi) {
-                    while (Xi >= nXT) { Xi -= nXT; ++To; }
-                    slab_put4(slab + tv.g0 + ((size_t)i * 64 + lane) * 4, outer_tile(E, To, B, Xi, lane), first);
-                }
-            }
-            PHASE_END(9)
-            if (t > 0) {
+                PHASE_END(9)
                 // re-rank for transform t-1 (its output order)
                 for (int e = tid; e < Dp * 16; e += (64 * NW)) {
                     const int r = e >> 4, pp = e & 15;
@@ -507,8 +386,7 @@ __global__ __launch_bounds__(64 * NW) void maf_lossgrad_kernel(pmc_maf_t m, pmc_
             }
         }
     }
-    if (TRAIN_WARM_L2) asm volatile("" :: "v"(warm));
-    if (tid == 0) tr.loss_partial[blockIdx.x] = loss_acc;
+    if (tid == 0) tr.loss_partial[set] = loss_acc;
     if (PROF && lane == 0) {
         pacc[0] = TICKT() - t_begin;
         long long* o = prof + ((size_t)blockIdx.x * NW + wv) * 16;
@@ -516,44 +394,105 @@ __global__ __launch_bounds__(64 * NW) void maf_lossgrad_kernel(pmc_maf_t m, pmc_
     }
 }
 
-// grad[gmap[i]] = sum over slabs of slab[i]; per-block sum of squares; loss += sum of the per-workgroup losses
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(pmc_maf_train_t tr, int n_slabs, int64_t g_total,
-                                                           float* __restrict__ grad, float* __restrict__ loss) {
-    __shared__ float red[4];
-    const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float sq = 0.0f;
-    if (i4 * 4 < g_total) {
-        const int4 g = reinterpret_cast<const int4*>(tr.gmap)[i4];
-        if ((g.x & g.y & g.z & g.w) >= 0) {               // any element mapped
-            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-            const float4* src = reinterpret_cast<const float4*>(tr.slabs) + i4;
-            const size_t stride4 = (size_t)tr.slab_stride / 4;
-            int b = 0;
-            for (; b + 1 < n_slabs; b += 2) {
-                const float4 u = src[(size_t)b * stride4], v = src[(size_t)(b + 1) * stride4];
-                s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
-                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+// Weight- and bias-gradient tiles over the whole batch (header comment, part 2).  One workgroup per job
+// (MAFSpec.train_jobs), int32 [8]: {kind_a, off_a, kind_b, off_b, gmap offset of the tile | -1, gmap offset of the 16
+// bias entries | -1, 0, 0}; kind 0: xt_scratch, 1: act_scratch, 2: delta_scratch, 3: par_scratch, offsets in floats
+// inside a row set's block.  A = delta tile (out), B = activation tile (in):
+//     dW[out 16 To + i][in 16 Ti + j] = sum_sets sum_p A[i][p] B[j][p],    db[16 To + i] = sum_sets sum_p A[i][p].
+// accumulate: the batch comes in chunks of at most max_sets row sets, later chunks add to the gradient in place.
+#define DW_WAVES 4
+#define DW_AHEAD 8
+__global__ __launch_bounds__(64 * DW_WAVES) void maf_dw_kernel(pmc_maf_t m, pmc_maf_train_t tr, int nsets, int accumulate,
+                                                               float* __restrict__ grad, float* __restrict__ loss) {
+    __shared__ float red[DW_WAVES - 1][64 * 4];
+    __shared__ float redb[DW_WAVES - 1][16];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int* job = tr.jobs + (size_t)blockIdx.x * 8;
+    const int ka = job[0], oa = job[1], kb = job[2], ob = job[3], gw = job[4], gbias = job[5];
+    const int64_t s_xt = (int64_t)(m.T + 1) * m.Dp * 16, s_act = (int64_t)m.T * 3 * m.Hp * 16,
+                  s_par = (int64_t)m.T * tr.par_per_transform;
+    const float* base_a = ka == 0 ? tr.xt_scratch : ka == 1 ? tr.act_scratch : ka == 2 ? tr.delta_scratch : tr.par_scratch;
+    const float* base_b = kb == 0 ? tr.xt_scratch : kb == 1 ? tr.act_scratch : kb == 2 ? tr.delta_scratch : tr.par_scratch;
+    const int64_t sa = ka == 0 ? s_xt : ka == 3 ? s_par : s_act, sb = kb == 0 ? s_xt : kb == 3 ? s_par : s_act;
+    // operand element [i = lane & 15][p = 4 c + (lane >> 4)] of a tile stored by store_rows / lidx
+    const int i = lane & 15, kq = lane >> 4;
+    const int lo = ((i & 3) << 6) + (i >> 2) + (kq << 2);
+    const float* pa = base_a + oa + lo;
+    const float* pb = base_b + (gw >= 0 ? ob : 0) + lo;
+    const int per = (nsets + DW_WAVES - 1) / DW_WAVES;
+    const int s0 = wv * per, s1 = min(nsets, s0 + per);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float bs = 0.0f;
+    for (int sg = s0; sg < s1; sg += DW_AHEAD) {
+        float a[DW_AHEAD][4], b[DW_AHEAD][4];
+#pragma unroll
+        for (int u = 0; u < DW_AHEAD; ++u) {
+            const int s = min(sg + u, s1 - 1);                // (clamped: the loads stay branch free)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                a[u][c] = pa[(int64_t)s * sa + 16 * c];
+                b[u][c] = gw >= 0 ? pb[(int64_t)s * sb + 16 * c] : 0.0f;
             }
-            if (b < n_slabs) {
-                const float4 u = src[(size_t)b * stride4];
-                s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+        }
+#pragma unroll
+        for (int u = 0; u < DW_AHEAD; ++u) {
+            if (sg + u < s1) {
+                if (u & 1) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc1 = MFMA(a[u][c], b[u][c], acc1);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc0 = MFMA(a[u][c], b[u][c], acc0);
+                }
+                bs += (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
             }
-            s0.x += s1.x; s0.y += s1.y; s0.z += s1.z; s0.w += s1.w;
-            if (g.x >= 0) { grad[g.x] = s0.x; sq += s0.x * s0.x; }
-            if (g.y >= 0) { grad[g.y] = s0.y; sq += s0.y * s0.y; }
-            if (g.z >= 0) { grad[g.z] = s0.z; sq += s0.z * s0.z; }
-            if (g.w >= 0) { grad[g.w] = s0.w; sq += s0.w * s0.w; }
         }
     }
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    f32x4 acc = acc0 + acc1;
+    bs += __shfl_xor(bs, 16);
+    bs += __shfl_xor(bs, 32);                                   // lanes 0..15: this wave's share of db[16 To + lane]
+    if (wv > 0) {
+        reinterpret_cast<float4*>(red[wv - 1])[lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (lane < 16) redb[wv - 1][lane] = bs;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        tr.sq_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-        if (blockIdx.x == 0 && loss) {
-            float s = 0.0f;
-            for (int b = 0; b < n_slabs; ++b) s += tr.loss_partial[b];
-            *loss += s;
+    if (wv == 0) {
+#pragma unroll
+        for (int k = 0; k < DW_WAVES - 1; ++k) {                // wave order: a fixed order of additions
+            const float4 v = reinterpret_cast<const float4*>(red[k])[lane];
+            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+            if (lane < 16) bs += redb[k][lane];
+        }
+        float sq = 0.0f;
+        if (gw >= 0) {
+            const int4 g = reinterpret_cast<const int4*>(tr.gmap + gw)[lane];
+            const int gi[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (gi[r] >= 0) {
+                    const float v = accumulate ? grad[gi[r]] + acc[r] : acc[r];
+                    grad[gi[r]] = v;
+                    sq += v * v;
+                }
+            }
+        }
+        if (gbias >= 0 && lane < 16) {
+            const int g = tr.gmap[gbias + lane];
+            if (g >= 0) {
+                const float v = accumulate ? grad[g] + bs : bs;
+                grad[g] = v;
+                sq += v * v;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        if (lane == 0) {
+            tr.sq_partial[blockIdx.x] = sq;
+            if (blockIdx.x == 0 && loss) {
+                float s = 0.0f;
+                for (int b = 0; b < nsets; ++b) s += tr.loss_partial[b];
+                *loss += s;
+            }
         }
     }
 }
@@ -679,9 +618,10 @@ static size_t train_lds_bytes(const pmc_maf_t& m) {
 }
 
 static int train_check(const pmc_maf_t* m, const pmc_maf_train_t* tr, const char* who) {
-    if (!m || !tr || !tr->packedT || !tr->gmap || !tr->slabs || !tr->xt_scratch || !tr->loss_partial ||
-        !tr->sq_partial || !tr->sched || tr->sched_waves != train_waves_of(*m) || tr->n_slabs < 1 || tr->slab_stride < (int64_t)m->T * tr->gmap_per_transform ||
-        (tr->slab_stride & 3))
+    if (!m || !tr || !tr->packedT || !tr->gmap || !tr->jobs || tr->n_jobs < 1 || tr->max_sets < 1 || !tr->xt_scratch ||
+        !tr->act_scratch || !tr->delta_scratch || !tr->par_scratch || !tr->loss_partial || !tr->sq_partial ||
+        tr->n_sq_partial < tr->n_jobs ||
+        tr->par_per_transform < (int64_t)(m->n_out == RQS_NOUT ? m->nXT * RQS_NOUT : m->nOT) * 256)
         return pmc_fail((std::string(who) + ": incomplete training image").c_str());
     return 0;
 }
@@ -694,33 +634,45 @@ static int launch_lossgrad(const pmc_maf_t* m, const pmc_maf_train_t* tr, const 
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
         hipError_t e = hipSuccess;
-        const void* ks[6] = {reinterpret_cast<const void*>(maf_lossgrad_kernel<TRAIN_WAVES, TRAIN_PF, false, 0>),
-                             reinterpret_cast<const void*>(maf_lossgrad_kernel<TRAIN_WAVES, TRAIN_PF, true, 0>),
-                             reinterpret_cast<const void*>(maf_lossgrad_kernel<TRAIN_WAVES, TRAIN_PF, false, 1>),
-                             reinterpret_cast<const void*>(maf_lossgrad_kernel<TRAIN_WAVES, TRAIN_PF, true, 1>),
-                             reinterpret_cast<const void*>(maf_lossgrad_kernel<TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, false, 1>),
-                             reinterpret_cast<const void*>(maf_lossgrad_kernel<TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, true, 1>)};
-        for (int i = 0; i < 6 && e == hipSuccess; ++i)
+        const void* ks[] = {reinterpret_cast<const void*>(maf_chain_kernel<TRAIN_WAVES, TRAIN_PF, false, 0>),
+                            reinterpret_cast<const void*>(maf_chain_kernel<TRAIN_WAVES, TRAIN_PF, false, 1>),
+                            reinterpret_cast<const void*>(maf_chain_kernel<TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, false, 1>),
+#ifdef PMC_DEBUG_HOOKS
+                            reinterpret_cast<const void*>(maf_chain_kernel<TRAIN_WAVES, TRAIN_PF, true, 0>),
+                            reinterpret_cast<const void*>(maf_chain_kernel<TRAIN_WAVES, TRAIN_PF, true, 1>),
+                            reinterpret_cast<const void*>(maf_chain_kernel<TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, true, 1>),
+#endif
+        };
+        for (size_t i = 0; i < sizeof(ks) / sizeof(ks[0]) && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_lossgrad_kernel)");
+        if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_chain_kernel)");
         lds_set = lds;
     }
-    const int64_t nsets = (n + 15) / 16;
-    const int n_wg = (int)(nsets < tr->n_slabs ? nsets : tr->n_slabs);
     const bool rqs = (m->n_out == RQS_NOUT);
     const bool narrow = train_waves_of(*m) == TRAIN_WAVES_NARROW;
+    const int64_t nsets = (n + 15) / 16;
+    // a batch of more row sets than the scratch arrays hold comes in chunks: chain + weight gradients per chunk, the
+    // later chunks adding to the gradient in place (the same order of additions whatever the rows are)
+    for (int64_t set0 = 0; set0 < nsets; set0 += tr->max_sets) {
+        const int n_wg = (int)(nsets - set0 < tr->max_sets ? nsets - set0 : tr->max_sets);
 #define LG(NWV, PFV, PR, UN)                                                                                       \
-    hipLaunchKernelGGL((maf_lossgrad_kernel<NWV, PFV, PR, UN>), dim3((unsigned)n_wg), dim3(64 * NWV), lds, st, *m, *tr, x, \
-                       w, idx, wmul, n, prof)
-    if (narrow) { if (prof) LG(TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, true, 1); else LG(TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, false, 1); }
-    else if (rqs) { if (prof) LG(TRAIN_WAVES, TRAIN_PF, true, 1); else LG(TRAIN_WAVES, TRAIN_PF, false, 1); }
-    else { if (prof) LG(TRAIN_WAVES, TRAIN_PF, true, 0); else LG(TRAIN_WAVES, TRAIN_PF, false, 0); }
+    hipLaunchKernelGGL((maf_chain_kernel<NWV, PFV, PR, UN>), dim3((unsigned)n_wg), dim3(64 * NWV), lds, st, *m, *tr, x, \
+                       w, idx, wmul, n, set0, prof)
+#ifdef PMC_DEBUG_HOOKS
+        if (prof) {
+            if (narrow) LG(TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, true, 1);
+            else if (rqs) LG(TRAIN_WAVES, TRAIN_PF, true, 1);
+            else LG(TRAIN_WAVES, TRAIN_PF, true, 0);
+        } else
+#endif
+        if (narrow) LG(TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, false, 1);
+        else if (rqs) LG(TRAIN_WAVES, TRAIN_PF, false, 1);
+        else LG(TRAIN_WAVES, TRAIN_PF, false, 0);
 #undef LG
-    const int64_t g_total = (int64_t)m->T * tr->gmap_per_transform;
-    const int64_t blocks = (g_total / 4 + 255) / 256;
-    if (blocks > tr->n_sq_partial) return pmc_fail("pmc_maf_loss_grad: sq_partial too small");
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, *tr, n_wg, g_total, grad, loss);
-    return pmc_check_launch("maf_lossgrad_kernel");
+        hipLaunchKernelGGL(maf_dw_kernel, dim3((unsigned)tr->n_jobs), dim3(64 * DW_WAVES), 0, st, *m, *tr, n_wg,
+                           set0 > 0 ? 1 : 0, grad, loss);
+    }
+    return pmc_check_launch("maf_chain_kernel");
 }
 
 extern "C" int pmc_maf_loss_grad(const pmc_maf_t* m, const pmc_maf_train_t* tr, const float* x, const float* w,
@@ -731,14 +683,15 @@ extern "C" int pmc_maf_loss_grad(const pmc_maf_t* m, const pmc_maf_train_t* tr, 
     return launch_lossgrad(m, tr, x, w, idx, wmul, grad, loss, n, (hipStream_t)stream);
 }
 
-// in-kernel cycle profile (scripts/profile_train.py; not part of the ABI): prof i64 [n_wg][TRAIN_WAVES][16]
+#ifdef PMC_DEBUG_HOOKS
+// in-kernel cycle profile of the chain kernel (scripts/profile_train.py; DEBUG_HOOKS builds only): prof i64 [sets][waves][16]
 extern "C" int pmc_debug_lossgrad_profile(const pmc_maf_t* m, const pmc_maf_train_t* tr, const float* x, float* grad,
                                           float* loss, int64_t n, long long* prof, void* stream) {
     if (train_check(m, tr, "pmc_debug_lossgrad_profile")) return 1;
     return launch_lossgrad(m, tr, x, nullptr, nullptr, 1000.0f, grad, loss, n, (hipStream_t)stream, prof);
 }
-// waves per training workgroup for this flow = the n_waves of pmc_maf_train_t.sched (MAFSpec.train_schedule)
-extern "C" int pmc_maf_train_waves(const pmc_maf_t* m) { return m ? train_waves_of(*m) : TRAIN_WAVES; }
+extern "C" int pmc_debug_train_waves(const pmc_maf_t* m) { return m ? train_waves_of(*m) : TRAIN_WAVES; }
+#endif
 
 // One pass over a validation set in batches (flow.py:327-348), everything enqueued by one call.
 extern "C" int pmc_maf_valid_epoch(const pmc_maf_t* m, const float* x, const float* w, const int64_t* perm, int64_t n,
@@ -816,8 +769,7 @@ extern "C" int pmc_maf_train_epoch(const pmc_maf_t* m, const pmc_maf_train_t* tr
         !opt->packT_idx || !opt->packedT || opt->n_params <= 0 || !x || !loss || n < 0 || batch_size < 1)
         return pmc_fail("pmc_maf_train_epoch: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t g_total = (int64_t)m->T * tr->gmap_per_transform;
-    const int n_part = (int)((g_total / 4 + 255) / 256);
+    const int n_part = tr->n_jobs;                      // maf_dw_kernel's block sums of squares
     for (int64_t b0 = 0; b0 < n; b0 += batch_size) {
         const int64_t nb = (n - b0 < batch_size) ? n - b0 : batch_size;
         // a batch is rows perm[b0 .. b0+nb) of x, or rows b0 .. b0+nb when perm == NULL

@@ -5,6 +5,14 @@
 #include <hip/hip_runtime.h>
 #include "../../include/pocomc_amd.h"
 
+// A/B switches of measurement builds (make DEBUG_HOOKS=1): the product library never reads the environment.
+#ifdef PMC_DEBUG_HOOKS
+#include <stdlib.h>
+static inline int pmc_env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+#define pmc_env_int(name, dflt) (dflt)
+#endif
+
 int pmc_fail(const char* msg);
 int pmc_fail_hip(hipError_t e, const char* what);
 int pmc_check_launch(const char* what);

@@ -558,45 +558,52 @@ class MAFSpec:
             o += v
         return dict(szT=szT, offT=offT, pkT_per_transform=pkT, szG=szG, offG=offG, gmap_per_transform=o)
 
-    def train_schedule(self, n_waves: int = 8, light_cost: float = 2.0) -> np.ndarray:
-        """``int32 [3][n_waves][2]``: (first, count) of the weight-gradient tiles each wave of a training
-        workgroup takes in the phases {layer 3, layers 2 / 1, layer 0}.
+    def par_per_transform(self) -> int:
+        """Floats of the hyper-network's outputs kept per row set and transform (``pmc_maf_train_t.par_scratch``):
+        ``nOT`` tiles for the affine flows, ``nXT`` panels of 23 tiles for the spline flows."""
+        return 256 * (self.nXT * 23 if self.univariate == "rqs" else self.nOT)
 
-        Every phase also has data-gradient tiles that are dealt by fixed rules (``K = wave, wave + n_waves, ...``
-        for layer 3 and layer 0, the cost snake ``wave, 2n-1-wave, 2n+wave, ...`` for the triangular layers);
-        a data-gradient tile costs its number of K tiles + 1, a weight-gradient tile ``light_cost`` (its
-        operands are 8 scalar LDS reads and it ends in a global store).  The weight-gradient tiles are handed
-        out as contiguous ranges so that the waves finish a phase at about the same time."""
-        nT, nXT, nOT = self.nT, self.nXT, self.nOT
-        n_oeff = min(nOT, -(-self.n_out * self.n_dim // 16))
+    def train_jobs(self) -> np.ndarray:
+        """``int32 [n_jobs][8]``: the weight-gradient tiles of one minibatch, one workgroup of ``maf_dw_kernel`` each.
 
-        def snake(w):
-            i = 0
-            while True:
-                r = (i + 1) * n_waves - 1 - w if i & 1 else i * n_waves + w
-                if r >= nT:
-                    return
-                yield r
-                i += 1
-
-        heavy3 = [sum(n_oeff + 1 for _ in range(w, nT, n_waves)) for w in range(n_waves)]
-        heavyt = [sum(((nT - Ti) if self.tri_ok else nT) + 1 for Ti in snake(w)) for w in range(n_waves)]
-        heavy0 = [sum(nT + 1 for _ in range(w, nXT, n_waves)) for w in range(n_waves)]
-        n3 = n_oeff * nT
-        nt = nT * (nT + 1) // 2 if self.tri_ok else nT * nT
-        n0 = nT * nXT
-        out = np.zeros((3, n_waves, 2), dtype=np.int32)
-        for ph, (heavy, n_light) in enumerate(((heavy3, n3), (heavyt, nt), (heavy0, n0))):
-            target = (sum(heavy) + light_cost * n_light) / n_waves
-            want = np.maximum(0.0, (target - np.asarray(heavy, dtype=np.float64)) / light_cost)
-            if want.sum() <= 0:
-                want[:] = 1.0
-            cum = np.round(np.cumsum(want) * (n_light / want.sum())).astype(np.int64)
-            cnt = np.diff(np.concatenate([[0], cum]))
-            out[ph, :, 0] = np.concatenate([[0], cum[:-1]])
-            out[ph, :, 1] = cnt
-            assert cnt.sum() == n_light and (cnt >= 0).all()
-        return out
+        ``{kind_a, off_a, kind_b, off_b, g_w, g_b, 0, 0}``: the tile ``dW[out tile][in tile] = sum over the batch's rows
+        of delta[out] x activation[in]`` takes its A operand (delta, 16 x rows) from scratch array ``kind_a`` at float
+        offset ``off_a`` inside a row set's block and its B operand (activation) likewise; ``g_w`` is the offset of
+        the tile's 256 entries in ``gmap`` (or -1: bias only), ``g_b`` the offset of the 16 bias entries of the out
+        tile (carried by ONE job per out tile, -1 elsewhere).  Kinds: 0 ``xt_scratch`` (transform inputs), 1
+        ``act_scratch`` (h0, h1, h2), 2 ``delta_scratch`` (da0, da1, da2), 3 ``par_scratch`` (output gradients).
+        Only tiles with at least one unmasked entry get a job."""
+        L = self.train_layout()
+        _, gm = self.train_index()
+        nT, nXT, nOT, Hp, Dp = self.nT, self.nXT, self.nOT, self.Hp, self.Dp
+        G = L["gmap_per_transform"]
+        ppt = self.par_per_transform()
+        jobs = []
+        for t in range(self.n_transforms):
+            gt = t * G
+            layers = (
+                # (gmap weights, [out tiles][in tiles], gmap bias, A kind / base, B kind / base)
+                ("g0", nT, nXT, "gb0", 2, (t * 3 + 0) * Hp * 16, 0, t * Dp * 16),
+                ("g1", nT, nT, "gb1", 2, (t * 3 + 1) * Hp * 16, 1, (t * 3 + 0) * Hp * 16),
+                ("g2", nT, nT, "gb2", 2, (t * 3 + 2) * Hp * 16, 1, (t * 3 + 1) * Hp * 16),
+                ("g3", nOT, nT, "gb3", 3, t * ppt, 1, (t * 3 + 2) * Hp * 16),
+            )
+            for gname, n_out_t, n_in_t, bname, ka, base_a, kb, base_b in layers:
+                gw0, gb0 = gt + L["offG"][gname], gt + L["offG"][bname]
+                n_bias = L["szG"][bname]
+                for To in range(n_out_t):
+                    bias_live = 16 * To < n_bias and (gm[gb0 + 16 * To: gb0 + min(16 * To + 16, n_bias)] >= 0).any()
+                    first = True
+                    for Ti in range(n_in_t):
+                        off = gw0 + (To * n_in_t + Ti) * 256
+                        if not (gm[off: off + 256] >= 0).any():
+                            continue
+                        jobs.append((ka, base_a + To * 256, kb, base_b + Ti * 256, off,
+                                     gb0 + 16 * To if (first and bias_live) else -1, 0, 0))
+                        first = False
+                    if first and bias_live:                  # an out tile whose weights are all masked still has biases
+                        jobs.append((ka, base_a + To * 256, -1, 0, -1, gb0 + 16 * To, 0, 0))
+        return np.asarray(jobs, dtype=np.int32).reshape(-1, 8)
 
     def train_index(self):
         """``(packT_idx, gmap)``: gather map for ``packedT`` (like ``pack_index``) and the

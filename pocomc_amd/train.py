@@ -19,7 +19,8 @@ import torch
 from . import _lib
 
 
-MAX_SLABS = 64      # workgroups per loss/gradient launch (16 rows each; larger batches are looped over)
+MAX_SETS = 256              # row sets of 16 per loss/gradient launch (one workgroup each; larger batches come in chunks)
+SCRATCH_BUDGET = 1 << 29    # bytes of activation / delta scratch a flow may hold (wide flows keep fewer sets, >= 32)
 
 
 class TrainState:
@@ -44,42 +45,46 @@ class TrainState:
             return
         L = spec.train_layout()
         pT_idx, gmap = spec.train_index()
+        jobs = spec.train_jobs()
         self.packT_idx = torch.from_numpy(pT_idx).to(dev)
         self.gmap = torch.from_numpy(gmap).to(dev)
+        self.jobs = torch.from_numpy(jobs.reshape(-1).copy()).to(dev)
+        self.n_jobs = int(jobs.shape[0])
         self.packedT = torch.zeros(pT_idx.size, dtype=torch.float32, device=dev)
-        self.n_waves = int(flow.lib.pmc_maf_train_waves(C.byref(flow._desc)))   # waves per training workgroup
-        self.sched = torch.from_numpy(spec.train_schedule(self.n_waves).reshape(-1).copy()).to(dev)
-        self.g_total = spec.n_transforms * L["gmap_per_transform"]
-        self.n_sq = (self.g_total // 4 + 255) // 256
-        self.sq_partial = torch.zeros(max(self.n_sq, 256), dtype=torch.float32, device=dev)   # >= PMC_ADAMW_SCRATCH
+        self.sq_partial = torch.zeros(max(self.n_jobs, 256), dtype=torch.float32, device=dev)   # >= PMC_ADAMW_SCRATCH
+        self.par_pt = spec.par_per_transform()
         self.desc = _lib.pmc_maf_train_t(packedT=self.packedT.data_ptr(), gmap=self.gmap.data_ptr(),
                                          pkT_per_transform=L["pkT_per_transform"],
                                          gmap_per_transform=L["gmap_per_transform"],
-                                         slab_stride=self.g_total, n_sq_partial=self.sq_partial.numel(),
-                                         sq_partial=self.sq_partial.data_ptr(), sched=self.sched.data_ptr(),
-                                         sched_waves=self.n_waves)
+                                         jobs=self.jobs.data_ptr(), n_jobs=self.n_jobs,
+                                         n_sq_partial=self.sq_partial.numel(), par_per_transform=self.par_pt,
+                                         sq_partial=self.sq_partial.data_ptr())
         self.xt_floats = (spec.n_transforms + 1) * spec.Dp * 16
         self.act_floats = spec.n_transforms * 3 * spec.Hp * 16
-        self.par_floats = spec.n_transforms * spec.nXT * 23 * 256 if spec.univariate == "rqs" else 0
+        self.par_floats = spec.n_transforms * self.par_pt
+        per_set = 4 * (self.xt_floats + 2 * self.act_floats + self.par_floats)
+        self.set_cap = int(max(32, min(MAX_SETS, SCRATCH_BUDGET // per_set)))
 
-    def ensure_slabs(self, n_rows):
-        """One gradient slab + one scratch block per concurrently running workgroup."""
-        need = max(1, min(MAX_SLABS, (int(n_rows) + 15) // 16))
+    def ensure_sets(self, n_rows):
+        """Scratch for the row sets of one launch: transform inputs, activations, deltas, output gradients."""
+        need = max(1, min(self.set_cap, (int(n_rows) + 15) // 16))
         if need <= self.n_slabs:
             return
         dev = self.grad.device
-        self.slabs = torch.empty(need * self.g_total, dtype=torch.float32, device=dev)
         self.xt_scratch = torch.empty(need * self.xt_floats, dtype=torch.float32, device=dev)
         self.act_scratch = torch.empty(need * self.act_floats, dtype=torch.float32, device=dev)
-        self.par_scratch = torch.empty(max(1, need * self.par_floats), dtype=torch.float32, device=dev)
+        self.delta_scratch = torch.empty(need * self.act_floats, dtype=torch.float32, device=dev)
+        self.par_scratch = torch.empty(need * self.par_floats, dtype=torch.float32, device=dev)
         self.loss_partial = torch.zeros(need, dtype=torch.float32, device=dev)
         self.n_slabs = need
-        self.desc.slabs = self.slabs.data_ptr()
         self.desc.xt_scratch = self.xt_scratch.data_ptr()
         self.desc.act_scratch = self.act_scratch.data_ptr()
-        self.desc.par_scratch = self.par_scratch.data_ptr() if self.par_floats else None
+        self.desc.delta_scratch = self.delta_scratch.data_ptr()
+        self.desc.par_scratch = self.par_scratch.data_ptr()
         self.desc.loss_partial = self.loss_partial.data_ptr()
-        self.desc.n_slabs = need
+        self.desc.max_sets = need
+
+    ensure_slabs = ensure_sets          # (the name older scripts call)
 
     def scatter_maps(self, flow):
         """CSR inverse of the two pack maps (``pmc_adamw_t.scatter_*``): where every parameter sits in the forward /
@@ -175,7 +180,7 @@ def loss_and_grad(flow, xb, wb=None, idx=None, refresh=True):
                                                        1000.0, _lib.ptr(ts.grad), _lib.ptr(ts.scal), n,
                                                        _lib.stream_handle()), "pmc_maf_loss_grad_bf16")
         return ts.scal[0]
-    ts.ensure_slabs(n)
+    ts.ensure_sets(n)
     with torch.cuda.device(flow.device):
         _lib.check(flow.lib.pmc_maf_loss_grad(C.byref(flow._desc), C.byref(ts.desc), _lib.ptr(xb),
                                               _lib.ptr(wb) if wb is not None else None,
@@ -261,7 +266,7 @@ class AdamW:
             self.t = int(c.step)
             f.repack()                      # the float32 / fragment images follow once per epoch (validation, inference)
             return
-        ts.ensure_slabs(batch_size)
+        ts.ensure_sets(batch_size)
         sc_ptr, sc_dst = ts.scatter_maps(f)
         c = _lib.pmc_adamw_t(params=f.params.data_ptr(), grad=ts.grad.data_ptr(), exp_avg=self.m.data_ptr(),
                              exp_avg_sq=self.v.data_ptr(), n_params=f.params.numel(),
@@ -335,7 +340,7 @@ def sharded_epoch(flow, opt, x, w, perm, batch_size, max_norm, loss_acc, group, 
     n = x.shape[0]
     wide = _wide_state(flow)
     if wide is None:
-        ts.ensure_slabs(lb)
+        ts.ensure_sets(lb)
     st = _lib.stream_handle()
     for b0 in range(0, n, lb):
         nb = min(lb, n - b0)

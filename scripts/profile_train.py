@@ -13,14 +13,14 @@ D = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 f = Flow(D, sys.argv[3] if len(sys.argv) > 3 else "maf3", seed=0)
 ts = _train_state(f)
 ts.repack(f)
-ts.ensure_slabs(n)
+ts.ensure_sets(n)
 lib = _lib.load()
 fn = lib.pmc_debug_lossgrad_profile
 fn.restype = C.c_int
 fn.argtypes = [C.POINTER(_lib.pmc_maf_t), C.POINTER(_lib.pmc_maf_train_t)] + [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p]
 x = torch.randn(n, D, device="cuda")
 nb = min(ts.n_slabs, (n + 15) // 16)
-NW = lib.pmc_maf_train_waves(C.byref(f._desc))
+NW = lib.pmc_debug_train_waves(C.byref(f._desc))      # (make DEBUG_HOOKS=1 build, PMC_LIBRARY=...)
 prof = torch.zeros(nb, NW, 16, dtype=torch.int64, device="cuda")
 for _ in range(3):
     _lib.check(fn(C.byref(f._desc), C.byref(ts.desc), _lib.ptr(x), _lib.ptr(ts.grad), _lib.ptr(ts.scal), n, _lib.ptr(prof),

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), s
         assert s in _lib.SIGNATURES, f"{s} declared in the header but not bound"
-    assert lib.pmc_abi_version() == 7
+    assert lib.pmc_abi_version() == 8
 
 
 def test_struct_sizes():
@@ -103,21 +103,28 @@ def test_flop_accounting_matches_survey():
 
 @pytest.mark.parametrize("D,T,H,uni", [(2, 3, None, "affine"), (10, 3, None, "affine"), (32, 3, None, "rqs"),
                                        (50, 6, 256, "affine"), (128, 8, 512, "affine"), (17, 2, None, "rqs")])
-@pytest.mark.parametrize("n_waves", [8, 16])
-def test_train_schedule_partitions_the_gradient_tiles(D, T, H, uni, n_waves):
-    """MAFSpec.train_schedule: per phase the waves' ranges are contiguous, disjoint and cover every
-    weight-gradient tile exactly once (host logic of the training kernel's work split)."""
+def test_train_jobs_cover_every_gradient_entry_exactly_once(D, T, H, uni):
+    """MAFSpec.train_jobs (the work list of maf_dw_kernel): every unmasked parameter -- weight or bias -- is written by
+    exactly one job, masked entries by none, and a job's operand tiles lie inside a row set's scratch block."""
     from pocomc_amd.maf_spec import MAFSpec
     s = MAFSpec(D, T, H, univariate=uni)
-    sched = s.train_schedule(n_waves)
-    assert sched.shape == (3, n_waves, 2) and sched.dtype == np.int32
-    n_oeff = min(s.nOT, -(-s.n_out * D // 16))
-    totals = [n_oeff * s.nT, s.nT * (s.nT + 1) // 2 if s.tri_ok else s.nT * s.nT, s.nT * s.nXT]
-    for ph in range(3):
-        start, cnt = sched[ph, :, 0], sched[ph, :, 1]
-        assert (cnt >= 0).all() and start[0] == 0
-        assert np.array_equal(start[1:], np.cumsum(cnt)[:-1])
-        assert cnt.sum() == totals[ph]
+    jobs = s.train_jobs()
+    _, gm = s.train_index()
+    assert jobs.dtype == np.int32 and jobs.shape[1] == 8 and len(jobs) > 0
+    hits = np.zeros(s.n_params, dtype=np.int64)
+    sizes = {0: (T + 1) * s.Dp * 16, 1: T * 3 * s.Hp * 16, 2: T * 3 * s.Hp * 16, 3: T * s.par_per_transform()}
+    for ka, oa, kb, ob, gw, gb, _, _ in jobs:
+        assert 0 <= oa and oa + 256 <= sizes[ka] and oa % 256 == 0
+        if gw >= 0:
+            assert 0 <= ob and ob + 256 <= sizes[kb] and ob % 256 == 0
+            g = gm[gw: gw + 256]
+            assert (g >= 0).any()
+            np.add.at(hits, g[g >= 0], 1)
+        if gb >= 0:
+            g = gm[gb: gb + 16]
+            np.add.at(hits, g[g >= 0], 1)
+    mask = s.mask_flat() != 0
+    assert np.array_equal(hits[mask], np.ones(mask.sum(), dtype=np.int64)) and not hits[~mask].any()
 
 
 @pytest.mark.parametrize("D,T", [(2, 3), (4, 3), (10, 3), (32, 3)])
