@@ -432,7 +432,7 @@ def main():
         # (the lane sweep takes the same time for any number of walkers up to a round: the first lane takes a full round of it,
         #  8192 walkers at two subsets per workgroup -- config 3: 808 (0.65) / 829 (0.75) / 845 (0.82) steps/s, profiles/r05_g_*)
         args.first_lane = min(0.82, 8192.0 / n) if (args.inverse in ("auto", "triangular", "lane")
-                                                    and flow.lib.pmc_debug_inverse_uses_lane(_ct.byref(flow._desc))) else 0.65
+                                                    and flow.lib.pmc_maf_inverse_auto_is_lane(_ct.byref(flow._desc))) else 0.65
         if flow.spec.univariate == "rqs":
             # the spline sweep is longer than the whole set's likelihood: nothing of the first lane's likelihood is left to hide,
             # the second lane's comes behind its sweep -- the first lane takes all the walker sets one round holds (512 x 16)
@@ -794,11 +794,11 @@ def main():
         inv_us_live = us["maf_inverse"]                     # (--steps 1 --no-steady-state: the instrumented pass's figure)
     us["maf_inverse_timed_region"] = inv_us_live            # HIP events inside the timed region
     t_inv = inv_us_live * 1e-6
-    lane_auto = args.inverse in ("auto", "triangular") and bool(lib.pmc_debug_inverse_uses_lane(ctypes.byref(flow._desc)))
-    nsf2 = spec.univariate == "rqs" and bool(lib.pmc_debug_inverse_uses_nsf2(ctypes.byref(flow._desc)))
+    lane_auto = args.inverse in ("auto", "triangular") and bool(lib.pmc_maf_inverse_auto_is_lane(ctypes.byref(flow._desc)))
+    nsf2 = spec.univariate == "rqs" and bool(lib.pmc_maf_inverse_auto_is_nsf2(ctypes.byref(flow._desc)))
     fused = (eng.pre and spec.tri_ok and not lane_auto and args.inverse in ("auto", "triangular")
              and ((spec.univariate == "affine" and spec.nOT <= 8) or nsf2))
-    duo = bool(lib.pmc_debug_inverse_uses_duo(ctypes.byref(flow._desc), n_launch))
+    duo = bool(lib.pmc_maf_inverse_auto_is_duo(ctypes.byref(flow._desc), n_launch))
     roof_kernel = ("maf_dense_kernel<1>" if (args.inverse == "naive" or not spec.tri_ok) else
                    "maf_inverse_nsf2_kernel" if (nsf2 and args.inverse in ("auto", "triangular", "duo")) else
                    "maf_inverse_tri_nsf_kernel" if spec.univariate == "rqs" else

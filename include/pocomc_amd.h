@@ -33,6 +33,10 @@ extern "C" {
 
 const char* pmc_last_error(void);
 int pmc_abi_version(void);
+/* 16 hex digits: sha256 over csrc/Makefile, csrc/*.hip, csrc/*.h and this header (sorted by name, concatenated) at build
+ * time, "+debug" appended by DEBUG_HOOKS builds.  The Python loader recomputes it from the tree and refuses a library
+ * that was not built from the sources it sits next to. */
+const char* pmc_build_id(void);
 
 /* ------------------------------------------------------------------ flow */
 
@@ -51,8 +55,12 @@ typedef struct pmc_maf {
                                * the inverse of the wide flows then multiplies everything left of the diagonal tile with 16-bit
                                * operands and float32 accumulation -- an opt-in precision, see PMC_INVERSE_TRIANGULAR_LANE16 */
     int32_t lane16_fmt;       /* 1 bfloat16, 2 float16 (0: no image) */
-    int32_t reserved;
+    int32_t reserved;         /* 0, or PMC_MAF_VARIANT_* bits: schedule variants of the inverse sweeps that must agree with
+                               * the default bit for bit (the cross-checks of tests/test_gpu_flow.py) */
 } pmc_maf_t;
+
+#define PMC_MAF_VARIANT_LEFT_LOOKING 1  /* two-wave spline sweep: the burst wave forms no output partials ahead of time */
+#define PMC_MAF_VARIANT_LANE_FOUR 2     /* lane-per-walker sweep of a flow of >= 16 hidden tiles: no fifth wavefront */
 
 #define PMC_INVERSE_AUTO 0
 #define PMC_INVERSE_TRIANGULAR 1   /* one sweep over the degree groups */
@@ -90,6 +98,12 @@ int pmc_maf_forward_bf16(const pmc_maf_t* m, const uint16_t* image, int64_t imag
  * inverse map.  z,x f32 [n][D]; ladj f32 [n] or NULL. */
 int pmc_maf_inverse(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
                     int algo, void* stream);
+/* Which sweep PMC_INVERSE_AUTO (and with it the MCMC step) launches for this flow: 1 / 0.  _is_duo: the two-wave sweep of
+ * the affine flows with D <= 64 for a call of n rows; _is_lane: the lane-per-walker sweep; _is_nsf2: the two-wave spline
+ * sweep.  (bench.py names the kernel its roofline line is about with them.) */
+int pmc_maf_inverse_auto_is_duo(const pmc_maf_t* m, int64_t n);
+int pmc_maf_inverse_auto_is_lane(const pmc_maf_t* m);
+int pmc_maf_inverse_auto_is_nsf2(const pmc_maf_t* m);
 
 /* 16-bit helper image of the lane-per-walker inverse sweep (Flow.inverse of the wide flows, flow.py:116-132, in the opt-in
  * precision of BASELINE config 5): image u16 [pmc_maf_lane16_elems(m)], derived on the device from m->packed (call again

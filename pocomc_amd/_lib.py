@@ -107,10 +107,11 @@ SIGNATURES = {
     "pmc_last_error": (C.c_char_p, []),
     "pmc_adapt_update": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
-    "pmc_debug_inverse_uses_duo": (C.c_int, [C.POINTER(pmc_maf_t), C.c_int64]),
-    "pmc_debug_inverse_uses_lane": (C.c_int, [C.POINTER(pmc_maf_t)]),
-    "pmc_debug_inverse_uses_nsf2": (C.c_int, [C.POINTER(pmc_maf_t)]),
+    "pmc_maf_inverse_auto_is_duo": (C.c_int, [C.POINTER(pmc_maf_t), C.c_int64]),
+    "pmc_maf_inverse_auto_is_lane": (C.c_int, [C.POINTER(pmc_maf_t)]),
+    "pmc_maf_inverse_auto_is_nsf2": (C.c_int, [C.POINTER(pmc_maf_t)]),
     "pmc_abi_version": (C.c_int, []),
+    "pmc_build_id": (C.c_char_p, []),
     "pmc_maf_pack": (C.c_int, [c_p, c_p, c_p, i64, c_p]),
     "pmc_maf_forward": (C.c_int, [P(pmc_maf_t), c_p, c_p, c_p, c_p, i64, c_p]),
     "pmc_maf_pack_bf16": (C.c_int, [c_p, c_p, c_p, i64, c_p]),
@@ -228,8 +229,31 @@ def load():
         fn.argtypes = args
     if lib.pmc_abi_version() != 8:
         raise PocomcAmdError("libpocomc_amd.so: ABI version mismatch")
+    built, tree = lib.pmc_build_id().decode(), source_build_id()
+    if tree is not None and built.split("+")[0] != tree:
+        raise PocomcAmdError(f"{LIB_PATH} was built from other sources than the ones next to it (library id {built}, "
+                             f"tree id {tree}): rebuild it with `make -C pocomc_amd/csrc` (or __graft_entry__.build())")
     _lib = lib
     return lib
+
+
+def source_build_id():
+    """The id ``csrc/Makefile`` stamps into the library (``pmc_build_id``): sha256 over Makefile, ``*.hip``, ``*.h`` of
+    ``csrc/`` and the public header, sorted by name within each group -- or None where the sources do not travel with the
+    package (an installed copy of the library alone)."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "pocomc_amd.h")
+    if not (os.path.isfile(os.path.join(csrc, "Makefile")) and os.path.isfile(hdr)):
+        return None
+    files = ([os.path.join(csrc, "Makefile")] + sorted(glob.glob(os.path.join(csrc, "*.hip")))
+             + sorted(glob.glob(os.path.join(csrc, "*.h"))) + [hdr])
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 _gpu_seen = False

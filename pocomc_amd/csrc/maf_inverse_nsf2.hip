@@ -1069,19 +1069,17 @@ __global__ __launch_bounds__(128) void maf_inverse_nsf2_kernel(pmc_maf_t m, cons
 // over the whole image.  -1: not covered (the caller launches the lone-wave sweep / the separate kernels).
 // pa == nullptr: plain inverse of z; else the fused proposal (+ scaler epilogue when pa->epi.on).
 static int launch_nsf2(const ProposeArgs* pa, const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t stream) {
-    static const int mode = getenv("PMC_INVERSE_NSF_DUO") ? atoi(getenv("PMC_INVERSE_NSF_DUO")) : -1;
+    static const int mode = pmc_env_int("PMC_INVERSE_NSF_DUO", -1);
     if (mode == 0) return -1;
     if (m->n_out != 23 || !m->tri_ok || m->D > 64 || m->D < 2) return -1;
     if (m->pk_per_transform * 4 * m->T >= (int64_t)NSF2_OOB) return -1;
     const size_t lds = (size_t)NSF2_LDS_FLOATS(m) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     const ProposeArgs none{};
-    // PMC_NSF2_EAGER=0: the burst wave's left-looking schedule without the eager partials (the two must agree bit for bit:
-    // every partial receives its K tiles in ascending order either way; tests/test_gpu_flow.py)
-    const char* ev = getenv("PMC_NSF2_EAGER");           // (read per launch: a test flips it inside one process)
-    const int eager = ev ? atoi(ev) : 1;
+    // PMC_MAF_VARIANT_LEFT_LOOKING: the burst wave's left-looking schedule without the eager partials (the two must agree
+    // bit for bit: every partial receives its K tiles in ascending order either way; tests/test_gpu_flow.py)
     pmc_maf_t mk = *m;
-    mk.reserved = eager ? 0 : 1;
+    mk.reserved = (m->reserved & PMC_MAF_VARIANT_LEFT_LOOKING) ? 1 : 0;
 #define LAUNCHN(FMV)                                                                                              \
     {                                                                                                             \
         if (lds > 48 * 1024) {                                                                                    \
@@ -1102,8 +1100,8 @@ static int launch_nsf2(const ProposeArgs* pa, const pmc_maf_t* m, const float* z
 }
 
 // whether PMC_INVERSE_AUTO launches this kernel for the flow (bench.py names the kernel it times with it)
-extern "C" int pmc_debug_inverse_uses_nsf2(const pmc_maf_t* m) {
-    static const int mode = getenv("PMC_INVERSE_NSF_DUO") ? atoi(getenv("PMC_INVERSE_NSF_DUO")) : -1;
+extern "C" int pmc_maf_inverse_auto_is_nsf2(const pmc_maf_t* m) {
+    static const int mode = pmc_env_int("PMC_INVERSE_NSF_DUO", -1);
     if (!m || mode == 0 || m->n_out != 23 || !m->tri_ok || m->D > 64 || m->D < 2) return 0;
     if (m->pk_per_transform * 4 * m->T >= (int64_t)NSF2_OOB) return 0;
     return (size_t)NSF2_LDS_FLOATS(m) * sizeof(float) <= 160 * 1024 ? 1 : 0;
@@ -1125,9 +1123,11 @@ int pmc_launch_propose_inverse_nsf2(ProposeArgs* pa, const ScalerEpi* epi, int* 
     return rc;
 }
 
+#ifdef PMC_DEBUG_HOOKS
 // measurement only (scripts/profile_nsf2.py): cycles of the chain wave of workgroup 0 by section of a group, summed over the sweep
 extern "C" int pmc_debug_nsf2_profile(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, long long* prof, void* stream) {
     ProposeArgs pa{};
     pa.prof = prof;
     return launch_nsf2(&pa, m, z, x, ladj, n, (hipStream_t)stream) < 0 ? pmc_fail("pmc_debug_nsf2_profile: flow not covered") : 0;
 }
+#endif

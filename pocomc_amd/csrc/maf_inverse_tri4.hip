@@ -399,7 +399,7 @@ static int launch_tri5(const ProposeArgs* pa, const pmc_maf_t* m, const float* z
 // against 66-83 us for up to 8192 rows), the lane-per-walker sweep for the wider ones (pmc_tri6_preferred: D = 50 / maf6
 // 314 against 650 us, D = 128 / 8 transforms 0.69 ms per round) and for everything with more than 8 output tiles.
 static bool lane_sweep_enabled() {
-    static const bool on = getenv("PMC_INVERSE_LANE") && atoi(getenv("PMC_INVERSE_LANE")) != 0;
+    static const bool on = pmc_env_int("PMC_INVERSE_LANE", 0) != 0;
     return on;
 }
 
@@ -998,7 +998,7 @@ __global__ __launch_bounds__(64 * (TRI5_NC + 1)) void maf_inverse_tri5_kernel(pm
 
 // -1: automatic (by size), 0: never, 1: always
 static int tri5_mode() {
-    static const int mode = getenv("PMC_INVERSE_DUO") ? atoi(getenv("PMC_INVERSE_DUO")) : -1;
+    static const int mode = pmc_env_int("PMC_INVERSE_DUO", -1);
     return mode;
 }
 
@@ -1013,7 +1013,7 @@ static bool tri5_wanted(const pmc_maf_t* m, int64_t n) {
 }
 
 // which of the two D <= 64 sweeps PMC_INVERSE_AUTO launches for n rows (bench.py names the kernel it times with it)
-extern "C" int pmc_debug_inverse_uses_duo(const pmc_maf_t* m, int64_t n) {
+extern "C" int pmc_maf_inverse_auto_is_duo(const pmc_maf_t* m, int64_t n) {
     if (!m || m->n_out != 2 || !m->tri_ok || m->nOT > 8 || m->D > 64) return 0;
     return tri5_wanted(m, n) ? 1 : 0;
 }
@@ -1047,6 +1047,7 @@ static int launch_tri5(const ProposeArgs* pa, const pmc_maf_t* m, const float* z
     return pmc_check_launch("maf_inverse_tri5_kernel");
 }
 
+#ifdef PMC_DEBUG_HOOKS
 // measurement only (scripts/profile_tri5.py): cycle stamps of the chain wave of workgroup 0 -- prof[transform * nT + tile][8]
 extern "C" int pmc_debug_tri5_profile(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, long long* prof,
                                       void* stream) {
@@ -1054,3 +1055,4 @@ extern "C" int pmc_debug_tri5_profile(const pmc_maf_t* m, const float* z, float*
     pa.prof = prof;
     return launch_tri5(&pa, m, z, x, ladj, n, (hipStream_t)stream) < 0 ? pmc_fail("pmc_debug_tri5_profile: flow not covered") : 0;
 }
+#endif

@@ -1056,17 +1056,17 @@ static size_t tri6_lds_bytes(const pmc_maf_t* m, int ns, int hb = 0) {
 // walker subsets per workgroup: as few as keep the launch in one round (a chain wavefront takes the same time for 16
 // and for 64 walkers; the helpers' share grows with the subsets), as many as the LDS admits otherwise
 static int tri6_five_min() {
-    static const int v = getenv("PMC_TRI6_FIVE_MIN") ? atoi(getenv("PMC_TRI6_FIVE_MIN")) : 16;   // (A/B runs)
+    static const int v = pmc_env_int("PMC_TRI6_FIVE_MIN", 16);   // (A/B runs)
     return v;
 }
 // the five-wavefront variant: plain float32 inverse of a flow with >= 16 hidden tiles, one or two subsets (the kernel must
 // stay within 256 registers: two wavefronts share a SIMD, and only one such workgroup fits a CU).  With 16-bit helper
 // operands the helpers are an order of magnitude below the chain: four wavefronts, a SIMD each.
 static bool tri6_five(const pmc_maf_t* m, bool fused, int hb = 0) {
-    return !fused && !hb && m->nT >= tri6_five_min() && !getenv("PMC_TRI6_FOUR");
+    return !fused && !hb && m->nT >= tri6_five_min() && !(m->reserved & PMC_MAF_VARIANT_LANE_FOUR);
 }
 static int tri6_subsets(const pmc_maf_t* m, int64_t n, bool fused, int hb = 0) {
-    static const int forced = getenv("PMC_TRI6_SUBSETS") ? atoi(getenv("PMC_TRI6_SUBSETS")) : 0;
+    static const int forced = pmc_env_int("PMC_TRI6_SUBSETS", 0);
     const bool five = tri6_five(m, fused, hb);
     int best = 0;
     for (int ns = 1; ns <= (five ? 2 : 4); ns *= 2) {
@@ -1200,11 +1200,12 @@ extern "C" int pmc_debug_tri6_waits(unsigned long long* out) {
 #endif
 
 // whether PMC_INVERSE_AUTO (and with it the MCMC step) takes this sweep for the flow (bench.py names the kernel it times)
-extern "C" int pmc_debug_inverse_uses_lane(const pmc_maf_t* m) {
+extern "C" int pmc_maf_inverse_auto_is_lane(const pmc_maf_t* m) {
     if (!m || m->n_out != 2 || !m->tri_ok) return 0;
     return (m->nOT > 8 || pmc_tri6_preferred(m)) ? 1 : 0;
 }
 
+#ifdef PMC_DEBUG_HOOKS
 // measurement only (scripts/profile_tri6.py): cycle stamps of workgroup 0 -- prof[transform * nT + tile][wave 0..3][4]
 extern "C" int pmc_debug_tri6_profile(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, long long* prof,
                                       void* stream) {
@@ -1230,3 +1231,4 @@ extern "C" int pmc_debug_tri6_profile(const pmc_maf_t* m, const float* z, float*
 #undef LP
     return pmc_check_launch("maf_inverse_tri6_kernel<profile>");
 }
+#endif

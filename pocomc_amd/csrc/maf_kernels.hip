@@ -195,6 +195,7 @@ extern "C" int pmc_maf_forward(const pmc_maf_t* m, const float* x, float* z, flo
     return pmc_launch_forward_wg(m, x, z, ladj, log_prob, n, (hipStream_t)stream);
 }
 
+#ifdef PMC_DEBUG_HOOKS
 // the lone-wave forward (one wavefront per 16 rows), kept as a cross-check of the workgroup kernel
 extern "C" int pmc_debug_forward_lone_wave(const pmc_maf_t* m, const float* x, float* z, float* ladj, float* log_prob,
                                            int64_t n, void* stream) {
@@ -206,6 +207,7 @@ extern "C" int pmc_debug_forward_lone_wave(const pmc_maf_t* m, const float* x, f
                        *m, x, z, ladj, log_prob, n);
     return pmc_check_launch("maf_dense_kernel<forward>");
 }
+#endif
 
 extern "C" int pmc_maf_inverse(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n,
                                int algo, void* stream) {

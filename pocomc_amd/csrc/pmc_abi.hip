@@ -24,3 +24,10 @@ int pmc_check_launch(const char* what) {
 
 extern "C" const char* pmc_last_error(void) { return g_err; }
 extern "C" int pmc_abi_version(void) { return PMC_ABI_VERSION; }
+
+// the hash of the sources this library was built from (csrc/Makefile: BUILD_ID); pocomc_amd/_lib.py compares it with the
+// hash of the sources next to it and refuses a stale library
+#ifndef PMC_BUILD_ID
+#define PMC_BUILD_ID "unknown"
+#endif
+extern "C" const char* pmc_build_id(void) { return PMC_BUILD_ID; }

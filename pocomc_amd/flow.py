@@ -199,7 +199,7 @@ class Flow:
         bound = LANE16_BOUND if bound is None else float(bound)
         ladj_bound = LANE16_LADJ_BOUND if ladj_bound is None else float(ladj_bound)
         self._desc.lane16 = self._lane16.data_ptr()              # (re-armed: new parameters get a new verdict)
-        if not self.lib.pmc_debug_inverse_uses_lane(C.byref(self._desc)):
+        if not self.lib.pmc_maf_inverse_auto_is_lane(C.byref(self._desc)):
             self.inverse_guard = None                            # the narrow flows never take the 16-bit sweep
             return None
         if theta is None:

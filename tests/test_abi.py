@@ -27,6 +27,34 @@ def test_library_exports_every_declared_symbol():
     assert lib.pmc_abi_version() == 8
 
 
+def test_product_library_has_no_measurement_hooks():
+    """The default build exports no ``pmc_debug_*`` entry point and never reads the environment on a launch path: the
+    in-kernel profiles and A/B switches exist only in ``make DEBUG_HOOKS=1`` (``libpocomc_amd_debug.so``)."""
+    import subprocess
+    from pocomc_amd import _lib
+    _lib.load()
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    assert len([s for s in exported if s.startswith("pmc_")]) >= 80
+    assert not [s for s in exported if s.startswith("pmc_debug")]
+    csrc = os.path.join(ROOT, "pocomc_amd", "csrc")
+    uses = [f for f in sorted(os.listdir(csrc)) if f.endswith(".hip") and "getenv" in open(os.path.join(csrc, f)).read()]
+    assert uses == [], uses
+
+
+def test_a_stale_library_is_refused(monkeypatch):
+    """``pmc_build_id()`` is the hash of the sources the library was built from; ``_lib.load()`` recomputes it from the
+    tree and raises for a library built from other sources (here: the tree's id is made to differ)."""
+    from pocomc_amd import _lib
+    lib = _lib.load()
+    assert lib.pmc_build_id().decode().split("+")[0] == _lib.source_build_id()
+    assert re.fullmatch(r"[0-9a-f]{16}", _lib.source_build_id())
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "source_build_id", lambda: "0123456789abcdef")
+    with pytest.raises(_lib.PocomcAmdError, match="built from other sources"):
+        _lib.load()
+
+
 def test_struct_sizes():
     from pocomc_amd import _lib
     assert ctypes.sizeof(_lib.pmc_maf_t) == 80

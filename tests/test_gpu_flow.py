@@ -112,13 +112,13 @@ def test_the_two_wave_sweep_does_not_depend_on_the_launch_and_agrees_with_the_lo
     import ctypes as C
     from pocomc_amd import _lib
     if f.spec.nT < 16:
-        assert _lib.load().pmc_debug_inverse_uses_duo(C.byref(f._desc), n) == 1
+        assert _lib.load().pmc_maf_inverse_auto_is_duo(C.byref(f._desc), n) == 1
 
 
 @pytest.mark.parametrize("n", [1, 33, 700])
-def test_wide_sweep_with_four_and_five_wavefronts_agrees_bit_for_bit(n, monkeypatch):
+def test_wide_sweep_with_four_and_five_wavefronts_agrees_bit_for_bit(n):
     """The lane-per-walker sweep of a wide flow (>= 20 hidden tiles: (D, T, H) = (128, 2, 512)) gives the layer-0
-    partials to a fifth wavefront and assigns the roles by SIMD; PMC_TRI6_FOUR keeps them on the output wavefront.  Same
+    partials to a fifth wavefront and assigns the roles by SIMD; PMC_MAF_VARIANT_LANE_FOUR keeps them on the output wavefront.  Same
     additions in the same order: identical results, and both within 1e-5 of the oracle."""
     from pocomc_amd.maf_spec import MAFSpec
     import pocomc_amd as pc
@@ -127,7 +127,7 @@ def test_wide_sweep_with_four_and_five_wavefronts_agrees_bit_for_bit(n, monkeypa
     z = torch.randn(n, 128, generator=torch.Generator().manual_seed(n))
     f.inverse_algo = 0
     x5, l5 = [t.cpu().numpy() for t in f.inverse(z.cuda())]
-    monkeypatch.setenv("PMC_TRI6_FOUR", "1")
+    f._desc.reserved = 2                                   # PMC_MAF_VARIANT_LANE_FOUR
     x4, l4 = [t.cpu().numpy() for t in f.inverse(z.cuda())]
     np.testing.assert_array_equal(x5, x4)
     np.testing.assert_array_equal(l5, l4)
@@ -310,16 +310,16 @@ def test_nsf_float32_evaluations_against_the_float64_yardstick(D, T):
 
 
 @pytest.mark.parametrize("D,T,n", [(32, 3, 300), (32, 6, 33), (33, 2, 100), (30, 2, 64), (40, 2, 17)])    # 9, 9, 8, 11, 10 hidden tiles
-def test_eager_partials_of_the_spline_sweep_change_no_bit(D, T, n, monkeypatch):
+def test_eager_partials_of_the_spline_sweep_change_no_bit(D, T, n):
     """The burst wave of the two-wave spline sweep forms the output partials of the last two hidden tiles early (steps 2-4,
-    csrc/maf_inverse_nsf2.hip: NSF2_EAGER_OK -- flows of >= 8 hidden tiles); PMC_NSF2_EAGER=0 keeps the left-looking schedule.
+    csrc/maf_inverse_nsf2.hip: NSF2_EAGER_OK -- flows of >= 8 hidden tiles); PMC_MAF_VARIANT_LEFT_LOOKING keeps the left-looking schedule.
     Every partial receives its K tiles in ascending order either way: identical results, plain and fused launches alike."""
     f, o = make_nsf(D, T)
     assert f.spec.device_meta()[7] >= 8, "the shape does not reach the eager path"
     z = (np.random.default_rng(3 * n + D).normal(size=(n, D)) * 1.5).astype(np.float32)
     f.inverse_algo = 7
     xe, le = [t.numpy() for t in f.inverse(torch.from_numpy(z))]
-    monkeypatch.setenv("PMC_NSF2_EAGER", "0")
+    f._desc.reserved = 1                                   # PMC_MAF_VARIANT_LEFT_LOOKING
     xl, ll = [t.numpy() for t in f.inverse(torch.from_numpy(z))]
     np.testing.assert_array_equal(xe, xl)
     np.testing.assert_array_equal(le, ll)

@@ -159,7 +159,7 @@ def test_sampler_runs_on_a_guarded_16bit_flow(prec):
     flow = pc.Flow(D, MAFSpec(D, 3, hidden=256), seed=2, inverse_precision=prec)
     import ctypes
     assert flow._lane16 is not None and flow.inverse_precision == prec
-    assert flow.lib.pmc_debug_inverse_uses_lane(ctypes.byref(flow._desc)) == 1
+    assert flow.lib.pmc_maf_inverse_auto_is_lane(ctypes.byref(flow._desc)) == 1
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         s = pc.Sampler(prior=prior, likelihood=loglike, vectorize=True, flow=flow, random_state=5, n_effective=1024,
