@@ -127,7 +127,10 @@ typedef struct pmc_maf_train {
     int32_t n_jobs;
     int32_t max_sets;         /* row sets of 16 the scratch arrays hold; a larger batch is taken in chunks of that many */
     int32_t n_sq_partial;     /* capacity of sq_partial, >= n_jobs */
-    int32_t reserved;
+    int32_t table_waves;      /* the wave count `tables` was built for: must equal pmc_maf_train_waves(m) */
+    const int32_t* tables;    /* device int32 (MAFSpec.train_tables): [16][8] cost ranks of the hidden tiles every wave of the
+                               * chain workgroup owns (-1 ends a row), [T][D] rank in transform t + 1 of the feature at rank r of
+                               * transform t, [T][D] likewise for t - 1 */
     float* xt_scratch;        /* [max_sets][T + 1][Dp * 16] the input of every transform, then z */
     float* act_scratch;       /* [max_sets][T][3][Hp * 16] hidden activations h0 h1 h2 */
     float* delta_scratch;     /* [max_sets][T][3][Hp * 16] their gradients da0 da1 da2 */
@@ -147,6 +150,8 @@ typedef struct pmc_maf_train {
  * grad f32 [n_params] in the canonical layout is OVERWRITTEN at every unmasked entry (masked
  * entries are never touched: allocate it zeroed); loss f32 [1] is ACCUMULATED.
  * tr->sq_partial[0 .. n_jobs) receives the sums of squares that pmc_maf_train_epoch clips with. */
+/* Wavefronts per chain workgroup for this flow (16; 8 for spline flows of hidden width <= 64). */
+int pmc_maf_train_waves(const pmc_maf_t* m);
 int pmc_maf_loss_grad(const pmc_maf_t* m, const pmc_maf_train_t* tr, const float* x, const float* w,
                       const int64_t* idx, float wmul, float* grad, float* loss, int64_t n, void* stream);
 

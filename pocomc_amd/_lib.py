@@ -29,7 +29,7 @@ class pmc_maf_train_t(C.Structure):
     _fields_ = [("packedT", c_p), ("gmap", c_p), ("pkT_per_transform", C.c_int64),
                 ("gmap_per_transform", C.c_int64),
                 ("jobs", c_p), ("n_jobs", C.c_int32), ("max_sets", C.c_int32), ("n_sq_partial", C.c_int32),
-                ("reserved", C.c_int32),
+                ("table_waves", C.c_int32), ("tables", c_p),
                 ("xt_scratch", c_p), ("act_scratch", c_p), ("delta_scratch", c_p), ("par_scratch", c_p),
                 ("par_per_transform", C.c_int64), ("loss_partial", c_p), ("sq_partial", c_p), ("wsum", c_p)]
 
@@ -110,6 +110,7 @@ SIGNATURES = {
     "pmc_maf_inverse_auto_is_duo": (C.c_int, [C.POINTER(pmc_maf_t), C.c_int64]),
     "pmc_maf_inverse_auto_is_lane": (C.c_int, [C.POINTER(pmc_maf_t)]),
     "pmc_maf_inverse_auto_is_nsf2": (C.c_int, [C.POINTER(pmc_maf_t)]),
+    "pmc_maf_train_waves": (C.c_int, [C.POINTER(pmc_maf_t)]),
     "pmc_abi_version": (C.c_int, []),
     "pmc_build_id": (C.c_char_p, []),
     "pmc_maf_pack": (C.c_int, [c_p, c_p, c_p, i64, c_p]),

@@ -68,6 +68,49 @@ __device__ __forceinline__ TrainView train_view(const pmc_maf_t& m, const pmc_ma
     return v;
 }
 
+#define TRAIN_OWN_MAX 8            // hidden tiles a wave can own through the table (more: the snake deal)
+
+// hidden layers of one transform for the workgroup's 16 rows: X -> H0, H1, H2.  Like hidden_pass_wg (maf_wg.h), with the
+// tiles of the two triangular layers dealt by the host-built ownership table: tile cost ranks per wave, balanced over the
+// four SIMDs the waves share (the f32 matrix pipe of a SIMD is what bounds a layer).
+template <int NW, int PF, bool PROF>
+__device__ __forceinline__ void hidden_pass_train(const pmc_maf_t& m, const MafView& w, const float* X, float* H0,
+                                                  float* H1, float* H2, int wv, int lane, const int* own,
+                                                  long long* pacc, long long& tk) {
+    const int q = lane >> 4, p = lane & 15;
+    const int nT = m.nT, nXT = m.nXT;
+    for (int T = wv; T < nT; T += NW) {
+        f32x4 a = bias4(w.b0, 16 * T + 4 * q);
+        a = mac_range<PF>(a, w.f0 + (size_t)T * nXT * 64, X, 0, nXT, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.0f);
+        store_rows(H0, T, q, p, a);
+    }
+    LAPT(15)
+    lds_barrier();
+    LAPT(14)
+    for (int layer = 1; layer <= 2; ++layer) {
+        const float* Hin = layer == 1 ? H0 : H1;
+        float* Hout = layer == 1 ? H1 : H2;
+        const float4* f = layer == 1 ? w.f1 : w.f2;
+        const float* b = layer == 1 ? w.b1 : w.b2;
+        for (int it = 0; it < TRAIN_OWN_MAX; ++it) {
+            const int r = own[it];
+            if (r < 0) break;
+            const int T = nT - 1 - r;
+            f32x4 a = bias4(b, 16 * T + 4 * q);
+            a = mac_range<PF>(a, f + (size_t)T * nT * 64, Hin, 0, m.tri_ok ? T + 1 : nT, lane);
+            const f32x4 h = rows_of(Hin, T, q, p);
+#pragma unroll
+            for (int r2 = 0; r2 < 4; ++r2) a[r2] = fmaxf(a[r2] + h[r2], 0.0f);
+            store_rows(Hout, T, q, p, a);
+        }
+        LAPT(13)
+        lds_barrier();
+        LAPT(14)
+    }
+}
+
 // out-layer panel of ranks [16c, 16c+16) of a spline flow: output tiles 23c .. 23c+22 -> P (local tile index).
 // keep != NULL: the panel (23 tiles of 256 floats, one float4 per lane and tile) is also written there for the
 // backward sweep; from != NULL: it is read back from there instead of being multiplied out.
@@ -98,7 +141,7 @@ __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf
                                                                   const float* __restrict__ x,
                                                                   const float* __restrict__ w,
                                                                   const int64_t* __restrict__ idx, float wmul,
-                                                                  int64_t n, int64_t set0,
+                                                                  int64_t n, int64_t set0, int ksplit,
                                                                   long long* __restrict__ prof) {
     long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tk = TICKT();
@@ -119,8 +162,13 @@ __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf
     float* CC = Gb + Dp * 16;                 // [16] per-row loss coefficient
     float* RED = CC + 16;                     // [16 * NW]
     float* XB = RED + 16 * NW;       // UNI 1: [Dp*16] the transform's input during its backward sweep
+    float* PART = XB + (UNI ? Dp * 16 : 0);   // ksplit: [NW][256] partial tiles of the phases with fewer tiles than waves
     const int* feat_of_rank = m.meta + 8;
-    const int* rank_of_feat = m.meta + 8 + T * D;
+    // host-built tables (MAFSpec.train_tables): which hidden tiles a wave owns (by cost rank, balanced over the SIMDs),
+    // and where a rank of transform t sits in transform t + 1 / t - 1
+    const int* own = tr.tables + wv * TRAIN_OWN_MAX;
+    const int* nxt_rank = tr.tables + TRAIN_WAVES * TRAIN_OWN_MAX;
+    const int* prv_rank = nxt_rank + T * D;
     const int64_t set = blockIdx.x;
     // what the forward sweep keeps for the backward sweep and both keep for the weight-gradient kernel
     float* xt = tr.xt_scratch + (size_t)set * (T + 1) * Dp * 16;           // input of every transform (+ z)
@@ -175,16 +223,40 @@ __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf
             const MafView wvw = maf_view(m, t);
             float* xtn = xt + (size_t)(t + 1) * Dp * 16;
             float* part = par + (size_t)t * tr.par_per_transform;
-            hidden_pass_wg<NW, PF, PROF>(m, wvw, Xc, A, B, Cb, wv, lane, pacc, tk);
+            hidden_pass_train<NW, PF, PROF>(m, wvw, Xc, A, B, Cb, wv, lane, own, pacc, tk);
             {                                                // A, B, Cb are contiguous in LDS: one copy
                 float4* dst = reinterpret_cast<float4*>(act + (size_t)t * 3 * Hp * 16);
                 for (int e = tid; e < 3 * Hp * 4; e += (64 * NW)) dst[e] = reinterpret_cast<const float4*>(A)[e];
             }
             LAPT(2)
             if (UNI == 0) {
+                // fewer output tiles than half the waves: a tile's contraction is split over NW / tiles waves (every
+                // fragment of the layer in flight at once, the SIMDs evenly loaded), partial tiles meet in LDS
+                const int nch = ksplit ? NW / nOeff : 1;
+                if (nch > 1) {
+                    const int O = wv % nOeff, ch = wv / nOeff;
+                    if (ch > 0 && ch < nch) {
+                        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                        o = mac_range<PF>(o, wvw.f3 + (size_t)O * nT * 64, Cb, ch * nT / nch, (ch + 1) * nT / nch, lane);
+                        reinterpret_cast<float4*>(PART)[(wv - nOeff) * 64 + lane] = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                }
                 for (int O = wv; O < nOeff; O += NW) {
+                    // where this lane's two ranks go in the next transform (requested ahead of the products)
+                    int r2[2];
+                    for (int s = 0; s < 2; ++s) {
+                        const int rank = 8 * O + 2 * q + s;
+                        r2[s] = (rank < D && t + 1 < T) ? nxt_rank[t * D + rank] : rank;
+                    }
                     f32x4 o = bias4(wvw.b3, 16 * O + 4 * q);
-                    o = mac_range<PF>(o, wvw.f3 + (size_t)O * nT * 64, Cb, 0, nT, lane);
+                    o = mac_range<PF>(o, wvw.f3 + (size_t)O * nT * 64, Cb, 0, nch > 1 ? nT / nch : nT, lane);
+                    if (nch > 1) {
+                        lds_barrier();
+                        for (int ch = 1; ch < nch; ++ch) {          // chunk order: a fixed order of additions
+                            const float4 v = reinterpret_cast<const float4*>(PART)[(ch * nOeff + O - nOeff) * 64 + lane];
+                            o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+                        }
+                    }
                     store_rows(part, O, q, p, o);            // (shift, raw): the backward sweep reads them back
                     for (int s = 0; s < 2; ++s) {
                         const int rank = 8 * O + 2 * q + s;
@@ -192,14 +264,13 @@ __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf
                             const float shift = s ? o[2] : o[0];
                             const float ls = soft_ls(s ? o[3] : o[1]);
                             const float y = Xc[lidx(rank, p)] * expf(ls) + shift;
-                            // the next transform reads its input by its own rank order
-                            const int r2 = (t + 1 < T) ? rank_of_feat[(t + 1) * D + feat_of_rank[t * D + rank]] : rank;
-                            Xn[lidx(r2, p)] = y;
-                            xtn[lidx(r2, p)] = y;
+                            Xn[lidx(r2[s], p)] = y;          // the next transform reads its input by its own rank order
+                            xtn[lidx(r2[s], p)] = y;
                             ladj += ls;
                         }
                     }
                 }
+                if (nch > 1 && wv >= nOeff) lds_barrier();       // (the waves without a tile meet the owners' barrier)
             } else {
                 for (int c = 0; c < nXT; ++c) {
                     rqs_panel_train<NW, PF>(m, wvw, Cb, P, c, wv, lane, part + (size_t)c * RQS_NOUT * 256);
@@ -212,7 +283,7 @@ __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf
                             for (int j = 0; j < RQS_NOUT; ++j) phi[j] = P[lidx(RQS_NOUT * rr + j, pp)];
                             float y, l;
                             rqs_forward(phi, Xc[lidx(rank, pp)], y, l);
-                            const int r2 = (t + 1 < T) ? rank_of_feat[(t + 1) * D + feat_of_rank[t * D + rank]] : rank;
+                            const int r2 = (t + 1 < T) ? nxt_rank[t * D + rank] : rank;
                             Xn[lidx(r2, pp)] = y;
                             xtn[lidx(r2, pp)] = y;
                             ladj += l;
@@ -267,7 +338,8 @@ __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf
                 for (int e = tid; e < Dp * 4; e += (64 * NW)) reinterpret_cast<float4*>(E)[e] = xsrc[e];
                 for (int e = tid; e < nOeff * 64; e += (64 * NW))
                     reinterpret_cast<float4*>(P)[e] = reinterpret_cast<const float4*>(part)[e];
-                for (int e = tid; e < 3 * Hp * 4; e += (64 * NW)) reinterpret_cast<float4*>(A)[e] = asrc[e];
+                if (t < T - 1)                               // (the last transform's activations never left LDS)
+                    for (int e = tid; e < 3 * Hp * 4; e += (64 * NW)) reinterpret_cast<float4*>(A)[e] = asrc[e];
                 PHASE_END(4)
                 // element-wise part: y = x e^{ls} + shift,  L += -c * sum ls   (in place: P -> dP, G -> direct dx)
                 for (int e = tid; e < Dp * 16; e += (64 * NW)) {
@@ -305,7 +377,8 @@ __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf
                 for (int e = tid; e < Dp * 4; e += (64 * NW)) reinterpret_cast<float4*>(XB)[e] = xsrc[e];
                 for (int e = tid; e < Hp * 4; e += (64 * NW))
                     reinterpret_cast<float4*>(E)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int e = tid; e < 3 * Hp * 4; e += (64 * NW)) reinterpret_cast<float4*>(A)[e] = asrc[e];
+                if (t < T - 1)
+                    for (int e = tid; e < 3 * Hp * 4; e += (64 * NW)) reinterpret_cast<float4*>(A)[e] = asrc[e];
                 lds_barrier();
                 LAPT(4)
                 for (int c = 0; c < nXT; ++c) {
@@ -348,9 +421,9 @@ __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf
                 PHASE_END(6)
             }
             // ---- layer 2: da1 = relu'(h1) . (da2 + W2^T da2) -> C
-            for (int it = 0;; ++it) {                              // the tiles this wave owns, most expensive first
-                const int Ti = snake_item<NW>(wv, it);
-                if (Ti >= nT) break;
+            for (int it = 0; it < TRAIN_OWN_MAX; ++it) {           // the tiles this wave owns, most expensive first
+                const int Ti = own[it];
+                if (Ti < 0) break;
                 f32x4 a = rows_of(E, Ti, q, p);
                 a = mac_range<PF>(a, tv.f2T + (size_t)Ti * nT * 64, E, (m.tri_ok ? Ti : 0), nT, lane);
                 a = relu_gate(a, B, Ti, q, p);
@@ -359,9 +432,9 @@ __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf
             }
             PHASE_END(7)
             // ---- layer 1: da0 = relu'(h0) . (da1 + W1^T da1) -> E
-            for (int it = 0;; ++it) {
-                const int Ti = snake_item<NW>(wv, it);
-                if (Ti >= nT) break;
+            for (int it = 0; it < TRAIN_OWN_MAX; ++it) {
+                const int Ti = own[it];
+                if (Ti < 0) break;
                 f32x4 a = rows_of(Cb, Ti, q, p);
                 a = mac_range<PF>(a, tv.f1T + (size_t)Ti * nT * 64, Cb, (m.tri_ok ? Ti : 0), nT, lane);
                 a = relu_gate(a, A, Ti, q, p);
@@ -371,16 +444,33 @@ __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf
             PHASE_END(8)
             // ---- layer 0: dx = direct + W0^T da0 -> P
             if (t > 0) {
+                const int nch = (ksplit && 2 * nXT <= NW) ? min(nT, NW / nXT) : 1;
+                if (nch > 1) {
+                    const int Xi = wv % nXT, ch = wv / nXT;
+                    if (ch > 0 && ch < nch) {
+                        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                        a = mac_range<PF>(a, tv.f0T + (size_t)Xi * nT * 64, E, ch * nT / nch, (ch + 1) * nT / nch, lane);
+                        reinterpret_cast<float4*>(PART)[(wv - nXT) * 64 + lane] = make_float4(a[0], a[1], a[2], a[3]);
+                    }
+                }
                 for (int Xi = wv; Xi < nXT; Xi += NW) {
                     f32x4 a = rows_of(Gb, Xi, q, p);
-                    a = mac_range<PF>(a, tv.f0T + (size_t)Xi * nT * 64, E, 0, nT, lane);
+                    a = mac_range<PF>(a, tv.f0T + (size_t)Xi * nT * 64, E, 0, nch > 1 ? nT / nch : nT, lane);
+                    if (nch > 1) {
+                        lds_barrier();
+                        for (int ch = 1; ch < nch; ++ch) {
+                            const float4 v = reinterpret_cast<const float4*>(PART)[(ch * nXT + Xi - nXT) * 64 + lane];
+                            a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+                        }
+                    }
                     store_rows(P, Xi, q, p, a);
                 }
+                if (nch > 1 && wv >= nXT) lds_barrier();
                 PHASE_END(9)
                 // re-rank for transform t-1 (its output order)
                 for (int e = tid; e < Dp * 16; e += (64 * NW)) {
                     const int r = e >> 4, pp = e & 15;
-                    if (r < D) Gb[lidx(rank_of_feat[(t - 1) * D + feat_of_rank[t * D + r]], pp)] = P[lidx(r, pp)];
+                    if (r < D) Gb[lidx(prv_rank[t * D + r], pp)] = P[lidx(r, pp)];
                 }
                 PHASE_END(9)
             }
@@ -611,16 +701,17 @@ __global__ __launch_bounds__(256) void pack2_kernel(const float* __restrict__ fl
 }
 
 // ---------------------------------------------------------------------------
-static size_t train_lds_bytes(const pmc_maf_t& m) {
+static size_t train_lds_bytes(const pmc_maf_t& m, bool ksplit) {
+    const size_t part = ksplit ? (size_t)TRAIN_WAVES * 256 : 0;
     if (m.n_out == RQS_NOUT)
-        return (size_t)(4 * m.Hp * 16 + RQS_NOUT * 256 + 2 * m.Dp * 16 + 16 + 16 * TRAIN_WAVES) * sizeof(float);
-    return (size_t)(4 * m.Hp * 16 + 2 * m.Dp * 16 + m.Dp * 16 + 16 + 16 * TRAIN_WAVES) * sizeof(float);   // (sized for 16 waves)
+        return (size_t)(4 * m.Hp * 16 + RQS_NOUT * 256 + 2 * m.Dp * 16 + 16 + 16 * TRAIN_WAVES + part) * sizeof(float);
+    return (size_t)(4 * m.Hp * 16 + 2 * m.Dp * 16 + m.Dp * 16 + 16 + 16 * TRAIN_WAVES + part) * sizeof(float);   // (sized for 16 waves)
 }
 
 static int train_check(const pmc_maf_t* m, const pmc_maf_train_t* tr, const char* who) {
     if (!m || !tr || !tr->packedT || !tr->gmap || !tr->jobs || tr->n_jobs < 1 || tr->max_sets < 1 || !tr->xt_scratch ||
         !tr->act_scratch || !tr->delta_scratch || !tr->par_scratch || !tr->loss_partial || !tr->sq_partial ||
-        tr->n_sq_partial < tr->n_jobs ||
+        tr->n_sq_partial < tr->n_jobs || !tr->tables || tr->table_waves != train_waves_of(*m) ||
         tr->par_per_transform < (int64_t)(m->n_out == RQS_NOUT ? m->nXT * RQS_NOUT : m->nOT) * 256)
         return pmc_fail((std::string(who) + ": incomplete training image").c_str());
     return 0;
@@ -629,7 +720,9 @@ static int train_check(const pmc_maf_t* m, const pmc_maf_train_t* tr, const char
 static int launch_lossgrad(const pmc_maf_t* m, const pmc_maf_train_t* tr, const float* x, const float* w,
                            const int64_t* idx, float wmul, float* grad, float* loss, int64_t n, hipStream_t st,
                            long long* prof = nullptr) {
-    const size_t lds = train_lds_bytes(*m);
+    // partial-tile staging for the phases with fewer tiles than waves, where the workgroup's LDS has room for it
+    const bool ksplit = train_lds_bytes(*m, true) <= 64 * 1024;
+    const size_t lds = train_lds_bytes(*m, ksplit);
     if (lds > 160 * 1024) return pmc_fail("pmc_maf_loss_grad: flow too wide for the 160 KB LDS of one workgroup");
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
@@ -657,7 +750,7 @@ static int launch_lossgrad(const pmc_maf_t* m, const pmc_maf_train_t* tr, const 
         const int n_wg = (int)(nsets - set0 < tr->max_sets ? nsets - set0 : tr->max_sets);
 #define LG(NWV, PFV, PR, UN)                                                                                       \
     hipLaunchKernelGGL((maf_chain_kernel<NWV, PFV, PR, UN>), dim3((unsigned)n_wg), dim3(64 * NWV), lds, st, *m, *tr, x, \
-                       w, idx, wmul, n, set0, prof)
+                       w, idx, wmul, n, set0, ksplit ? 1 : 0, prof)
 #ifdef PMC_DEBUG_HOOKS
         if (prof) {
             if (narrow) LG(TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, true, 1);
@@ -690,8 +783,9 @@ extern "C" int pmc_debug_lossgrad_profile(const pmc_maf_t* m, const pmc_maf_trai
     if (train_check(m, tr, "pmc_debug_lossgrad_profile")) return 1;
     return launch_lossgrad(m, tr, x, nullptr, nullptr, 1000.0f, grad, loss, n, (hipStream_t)stream, prof);
 }
-extern "C" int pmc_debug_train_waves(const pmc_maf_t* m) { return m ? train_waves_of(*m) : TRAIN_WAVES; }
 #endif
+// wavefronts per training workgroup for this flow: what MAFSpec.train_tables builds the ownership table for
+extern "C" int pmc_maf_train_waves(const pmc_maf_t* m) { return m ? train_waves_of(*m) : TRAIN_WAVES; }
 
 // One pass over a validation set in batches (flow.py:327-348), everything enqueued by one call.
 extern "C" int pmc_maf_valid_epoch(const pmc_maf_t* m, const float* x, const float* w, const int64_t* perm, int64_t n,

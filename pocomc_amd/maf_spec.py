@@ -563,6 +563,43 @@ class MAFSpec:
         ``nOT`` tiles for the affine flows, ``nXT`` panels of 23 tiles for the spline flows."""
         return 256 * (self.nXT * 23 if self.univariate == "rqs" else self.nOT)
 
+    def train_tables(self, n_waves: int = 16) -> np.ndarray:
+        """``int32`` tables of the chain kernel (``pmc_maf_train_t.tables``):
+
+        ``[16][8]`` ownership of the hidden tiles of the triangular layers: row ``w`` lists the COST RANKS (0 = the
+        tile with the longest contraction: ``nT - r`` K tiles when the degree groups fit a tile) wave ``w`` of the
+        ``n_waves`` takes, most expensive first, -1 ends the row.  The four SIMDs of a compute unit each run
+        ``n_waves / 4`` of the waves (wave ``w`` on SIMD ``w % 4``) and a layer is bound by its busiest f32 matrix pipe,
+        so tiles go to the least-loaded SIMD first and to its least-loaded wave (longest processing time first).
+        ``[T][D]`` the rank in transform ``t + 1`` of the feature at rank ``r`` of transform ``t`` (last row unused);
+        ``[T][D]`` likewise for ``t - 1`` (first row unused)."""
+        nT, D, T = self.nT, self.n_dim, self.n_transforms
+        own = np.full((16, 8), -1, dtype=np.int64)
+        if nT <= 8 * n_waves:
+            simd_load = np.zeros(4)
+            wave_load = np.zeros(n_waves)
+            wave_cnt = np.zeros(n_waves, dtype=np.int64)
+            for r in range(nT):
+                cost = (nT - r) if self.tri_ok else nT
+                live = [sd for sd in range(min(4, n_waves)) if any(wave_cnt[w] < 8 for w in range(sd, n_waves, 4))]
+                sd = min(live, key=lambda k: (simd_load[k], k))
+                w = min((w for w in range(sd, n_waves, 4) if wave_cnt[w] < 8), key=lambda k: (wave_load[k], k))
+                own[w, wave_cnt[w]] = r
+                wave_cnt[w] += 1
+                wave_load[w] += cost
+                simd_load[sd] += cost
+        else:
+            raise NotImplementedError("more than 8 hidden tiles per wave of the training workgroup")
+        f_o_r = [np.argsort(o) for o in self.orders]
+        nxt = np.zeros((T, D), dtype=np.int64)
+        prv = np.zeros((T, D), dtype=np.int64)
+        for t in range(T):
+            if t + 1 < T:
+                nxt[t] = np.asarray(self.orders[t + 1])[f_o_r[t]]
+            if t > 0:
+                prv[t] = np.asarray(self.orders[t - 1])[f_o_r[t]]
+        return np.concatenate([own.reshape(-1), nxt.reshape(-1), prv.reshape(-1)]).astype(np.int32)
+
     def train_jobs(self) -> np.ndarray:
         """``int32 [n_jobs][8]``: the weight-gradient tiles of one minibatch, one workgroup of ``maf_dw_kernel`` each.
 

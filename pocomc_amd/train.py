@@ -49,6 +49,8 @@ class TrainState:
         self.packT_idx = torch.from_numpy(pT_idx).to(dev)
         self.gmap = torch.from_numpy(gmap).to(dev)
         self.jobs = torch.from_numpy(jobs.reshape(-1).copy()).to(dev)
+        self.n_waves = int(flow.lib.pmc_maf_train_waves(C.byref(flow._desc)))   # waves per chain workgroup
+        self.tables = torch.from_numpy(spec.train_tables(self.n_waves)).to(dev)
         self.n_jobs = int(jobs.shape[0])
         self.packedT = torch.zeros(pT_idx.size, dtype=torch.float32, device=dev)
         self.sq_partial = torch.zeros(max(self.n_jobs, 256), dtype=torch.float32, device=dev)   # >= PMC_ADAMW_SCRATCH
@@ -57,6 +59,7 @@ class TrainState:
                                          pkT_per_transform=L["pkT_per_transform"],
                                          gmap_per_transform=L["gmap_per_transform"],
                                          jobs=self.jobs.data_ptr(), n_jobs=self.n_jobs,
+                                         tables=self.tables.data_ptr(), table_waves=self.n_waves,
                                          n_sq_partial=self.sq_partial.numel(), par_per_transform=self.par_pt,
                                          sq_partial=self.sq_partial.data_ptr())
         self.xt_floats = (spec.n_transforms + 1) * spec.Dp * 16

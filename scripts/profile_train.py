@@ -20,7 +20,7 @@ fn.restype = C.c_int
 fn.argtypes = [C.POINTER(_lib.pmc_maf_t), C.POINTER(_lib.pmc_maf_train_t)] + [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p]
 x = torch.randn(n, D, device="cuda")
 nb = min(ts.n_slabs, (n + 15) // 16)
-NW = lib.pmc_debug_train_waves(C.byref(f._desc))      # (make DEBUG_HOOKS=1 build, PMC_LIBRARY=...)
+NW = lib.pmc_maf_train_waves(C.byref(f._desc))
 prof = torch.zeros(nb, NW, 16, dtype=torch.int64, device="cuda")
 for _ in range(3):
     _lib.check(fn(C.byref(f._desc), C.byref(ts.desc), _lib.ptr(x), _lib.ptr(ts.grad), _lib.ptr(ts.scal), n, _lib.ptr(prof),
