@@ -169,14 +169,15 @@ def cpu_baseline(D, n, beta, flat, spec, x0, u0_unused, geo, sigma0, seed, max_s
             dt = time.perf_counter() - t0
         return res["steps"], dt
 
-    # (a) 1 thread = the reference's default (pytorch_threads=1, sampler.py:168), (b) all host cores; both
-    # printed.  20 steps each; the all-cores leg (BLAS threads only pay for the float32 products of the flow, and 256 of
-    # them cost more than they give) is time-boxed to ~20 s through a 2-step probe, never below 5 steps.
-    for th in sorted({1, max_threads}):
-        steps = 20
-        if th > 1:
-            k, dt = run(th, 2)
-            steps = int(min(20, max(5, (max_seconds * 0.66) / (dt / k))))
+    # 1 thread = the reference's default (pytorch_threads=1, sampler.py:168), and the host's cores.  BLAS
+    # threads only pay for the float32 products of the flow (1e3 x 128 operands): a few help, hundreds cost more than they
+    # give (round 5: 128 threads ran 3.7x SLOWER than one) -- so the legs are 1, 8 and 32 threads, the best one is the
+    # baseline `value`, all are printed.  Every leg is time-boxed through a 2-step probe: <= 20 steps, never below 5.
+    legs = sorted({1, min(8, max_threads), min(32, max_threads)})
+    budget = {th: max_seconds * (0.4 if th == 1 else 0.6 / max(1, len(legs) - 1)) for th in legs}
+    for th in legs:
+        k, dt = run(th, 2)
+        steps = int(min(20, max(5, budget[th] / (dt / k))))
         k, dt = run(th, steps)
         by_threads[th] = k / dt * (n_s / 1e4)               # steps/s of a 1e4-walker population
         steps_by_threads[th], secs_by_threads[th] = k, dt
@@ -193,12 +194,13 @@ def cpu_baseline(D, n, beta, flat, spec, x0, u0_unused, geo, sigma0, seed, max_s
         pass
     return {"value": value, "unit": "steps/s (1e4 walkers, 32-D)", "cores": int(threads), "kind": "port",
             "sample": f"{steps_by_threads[threads]} steps of {n_s} walkers (oracle: numpy f64 step + f32 D-pass MAF inverse, "
-                      f"{threads} BLAS/torch thread(s)); the other thread count is reported next to it "
-                      f"(host cpu_count={os.cpu_count()}); scaled linearly to 1e4 walkers",
+                      f"{threads} BLAS/torch thread(s) = the fastest of the legs {legs}, all in steps_per_s_by_threads; "
+                      f"host cpu_count={os.cpu_count()}); scaled linearly to 1e4 walkers",
             "cpu_model": model, "host_cpu_count": os.cpu_count(),
             "threads_1": {"steps_per_s": by_threads[1], "steps": steps_by_threads[1], "seconds": secs_by_threads[1]},
-            "threads_all": {"threads": int(max_threads), "steps_per_s": by_threads[max_threads],
-                            "steps": steps_by_threads[max_threads], "seconds": secs_by_threads[max_threads]},
+            "legs": {str(k): {"steps_per_s": by_threads[k], "steps": steps_by_threads[k], "seconds": secs_by_threads[k]}
+                     for k in legs},
+            "blas_max_threads": int(max_threads),
             "steps_per_s_by_threads": {str(k): v for k, v in sorted(by_threads.items())}}
 
 
@@ -606,6 +608,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     dt_local = dt
+    # the host clocks of the K timed steps, taken HERE: the steady-state loop below adds to the same accumulators (round 5
+    # divided their sum over K + 200 steps by K: step_call read 11x a step)
+    seg_region = dict(t_lseg if leng is not None else t_seg)
     # ---- the same closed region once more over >= 200 steps (side key "steady_state": the exposed first pre-step is
     #      1 / K of the region, 5 % of it at the driver's K = 20 and 0.5 % here)
     roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = None, None
@@ -656,7 +661,7 @@ def main():
         print(f"[step times us] median {np.median(st_):.1f} p90 {np.percentile(st_, 90):.1f} p99 {np.percentile(st_, 99):.1f} max {st_.max():.1f} "
               f"first5 {np.round(st_[:5], 1).tolist()} slow(>1.5x median) {int((st_ > 1.5 * np.median(st_)).sum())}", file=sys.stderr)
     roof_eng._step.ev_inv0, roof_eng._step.ev_inv1 = None, None
-    seg_timed = {k: v / args.steps * 1e6 for k, v in (t_lseg if leng is not None else t_seg).items()}
+    seg_timed = {k: v / args.steps * 1e6 for k, v in seg_region.items()}
     laned_host = None
     if leng is not None:                                    # same pipeline again with host timers
         leng.host_timers = {"wait_device": 0.0, "prior": 0.0, "likelihood": 0.0}
@@ -775,7 +780,7 @@ def main():
         # every rank's own clocks, so that a multi-GPU line explains itself: wait_sums is the host's wait for the closing
         # launch of a step -- at world > 1 that launch holds the exchange (comm_adapt_kernel polls the peers' sequence words),
         # so a rank that waits longer there than the others waited for a LATE PEER, not for its own device
-        mine = {"rank": rank, "device": torch.cuda.current_device(), "timed_region_s": dt_local,
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "pinned_core": pinned_core, "timed_region_s": dt_local,
                 **{k: (laned_host or {}).get(k) for k in ("wait_x", "wait_sums", "likelihood", "enqueue_accept", "enqueue_next_pre",
                                                            "python_overhead", "step_call")}}
         per_rank = [None] * world
@@ -1006,7 +1011,7 @@ def main():
            "dtype": ("f32 flow (MFMA) + f64 step" if flow.inverse_precision_active == "f32" else
                      f"{flow.inverse_precision_active} left-looking products + f32 chain of the flow inverse (MFMA, f32 accumulation) + f64 step"),
            "data": "synthetic",
-           "config": {"workload": f"{D}-D {TARGET_NAMES[args.target]}, U({p_lo:g},{p_hi:g})^{D} prior, {n} walkers/GPU x {world} GPU, {args.flow} "
+           "config": {"workload": f"{D}-D {TARGET_NAMES[args.target]}, U({p_lo:g},{p_hi:g})^{D} prior, {n} walkers/GPU x {world} GPU = {n * world} walkers, {args.flow} "
                                   f"(H={spec.hidden}), beta={beta}, tpCN kernel, host numpy likelihood in the loop",
                       "walkers_per_gpu": n, "global_walkers": n * world, "n_dim": D, "flow": args.flow,
                       "flow_trained_50_epochs": flow_trained, "flow_fit_epochs": (flow_fit or {}).get("epochs"),

@@ -33,7 +33,7 @@ extern "C" {
 
 const char* pmc_last_error(void);
 int pmc_abi_version(void);
-/* 16 hex digits: sha256 over csrc/Makefile, csrc/*.hip, csrc/*.h and this header (sorted by name, concatenated) at build
+/* 16 hex digits: sha256 over the Makefile, the .hip and .h files of csrc/ and this header (sorted by name, concatenated) at build
  * time, "+debug" appended by DEBUG_HOOKS builds.  The Python loader recomputes it from the tree and refuses a library
  * that was not built from the sources it sits next to. */
 const char* pmc_build_id(void);
@@ -240,7 +240,7 @@ int pmc_mean_distance_f32(const float* x, int64_t n, int32_t D, int64_t row, flo
 
 /* The validation pass of one epoch, flow.py:327-348, in one call: for every batch (rows perm[b0 .. b0+nb) or
  * consecutive rows) loss += sum_n c_n * (-log_prob(x_n)) with c_n as in pmc_maf_loss_grad.
- * logp_scratch f32 [batch_size]. */
+ * logp_scratch f32 [n] (one forward launch evaluates every row; the batches only shape the weight normalisation). */
 int pmc_maf_valid_epoch(const pmc_maf_t* m, const float* x, const float* w, const int64_t* perm, int64_t n,
                         int64_t batch_size, float* logp_scratch, float* loss, void* stream);
 

@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf
 
 // Weight- and bias-gradient tiles over the whole batch (header comment, part 2).  One workgroup per job
 // (MAFSpec.train_jobs), int32 [8]: {kind_a, off_a, kind_b, off_b, gmap offset of the tile | -1, gmap offset of the 16
-// bias entries | -1, 0, 0}; kind 0: xt_scratch, 1: act_scratch, 2: delta_scratch, 3: par_scratch, offsets in floats
+// bias entries | -1, 0, 0} (kind_a = -1: no-op); kind 0: xt_scratch, 1: act_scratch, 2: delta_scratch, 3: par_scratch, offsets in floats
 // inside a row set's block.  A = delta tile (out), B = activation tile (in):
 //     dW[out 16 To + i][in 16 Ti + j] = sum_sets sum_p A[i][p] B[j][p],    db[16 To + i] = sum_sets sum_p A[i][p].
 // accumulate: the batch comes in chunks of at most max_sets row sets, later chunks add to the gradient in place.
@@ -500,6 +500,10 @@ __global__ __launch_bounds__(64 * DW_WAVES) void maf_dw_kernel(pmc_maf_t m, pmc_
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int* job = tr.jobs + (size_t)blockIdx.x * 8;
     const int ka = job[0], oa = job[1], kb = job[2], ob = job[3], gw = job[4], gbias = job[5];
+    if (ka < 0) {                                               // padding of the XCD placement (MAFSpec.train_jobs)
+        if (threadIdx.x == 0) tr.sq_partial[blockIdx.x] = 0.0f;
+        return;
+    }
     const int64_t s_xt = (int64_t)(m.T + 1) * m.Dp * 16, s_act = (int64_t)m.T * 3 * m.Hp * 16,
                   s_par = (int64_t)m.T * tr.par_per_transform;
     const float* base_a = ka == 0 ? tr.xt_scratch : ka == 1 ? tr.act_scratch : ka == 2 ? tr.delta_scratch : tr.par_scratch;
@@ -602,31 +606,6 @@ __global__ __launch_bounds__(256) void neg_weighted_sum_kernel(const float* __re
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) *out += (red[0] + red[1]) + (red[2] + red[3]);      // ONE block: a fixed order of additions
-}
-
-// validation loss of one batch (flow.py:336-341): loss += sum_i -(logp_i * c_i), c_i = 1 or
-// w[idx_i] * wmul / sum_j w[idx_j]; ONE block, fixed order (deterministic)
-__global__ __launch_bounds__(256) void batch_nll_kernel(const float* __restrict__ logp, const float* __restrict__ w,
-                                                        const int64_t* __restrict__ idx, float wmul,
-                                                        float* __restrict__ loss, int64_t n) {
-    __shared__ float red[4];
-    const int tid = threadIdx.x;
-    float scale = 1.0f;
-    if (w) {
-        float s = 0.0f;
-        for (int64_t i = tid; i < n; i += 256) s += w[idx ? idx[i] : i];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if ((tid & 63) == 0) red[tid >> 6] = s;
-        __syncthreads();
-        scale = wmul / ((red[0] + red[1]) + (red[2] + red[3]));
-        __syncthreads();
-    }
-    float s = 0.0f;
-    for (int64_t i = tid; i < n; i += 256) s += -(logp[i] * (w ? w[idx ? idx[i] : i] * scale : 1.0f));
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((tid & 63) == 0) red[tid >> 6] = s;
-    __syncthreads();
-    if (tid == 0) *loss += (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ v, float* __restrict__ out, int64_t n) {
@@ -787,19 +766,48 @@ extern "C" int pmc_debug_lossgrad_profile(const pmc_maf_t* m, const pmc_maf_trai
 // wavefronts per training workgroup for this flow: what MAFSpec.train_tables builds the ownership table for
 extern "C" int pmc_maf_train_waves(const pmc_maf_t* m) { return m ? train_waves_of(*m) : TRAIN_WAVES; }
 
-// One pass over a validation set in batches (flow.py:327-348), everything enqueued by one call.
+// validation loss of a whole pass (flow.py:327-348) from the rows' log-densities: per batch b of `bs` rows
+// loss += sum_i -(logp_i * c_i), c_i = 1 or w[idx_i] * wmul / sum_j w[idx_j] over the batch.  ONE block walks the batches
+// in order: a fixed order of additions.
+__global__ __launch_bounds__(256) void epoch_nll_kernel(const float* __restrict__ logp, const float* __restrict__ w,
+                                                        const int64_t* __restrict__ idx, float wmul,
+                                                        float* __restrict__ loss, int64_t n, int64_t bs) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    float total = *loss;
+    for (int64_t b0 = 0; b0 < n; b0 += bs) {
+        const int64_t nb = n - b0 < bs ? n - b0 : bs;
+        float scale = 1.0f;
+        if (w) {
+            float s = 0.0f;
+            for (int64_t i = tid; i < nb; i += 256) s += w[idx ? idx[b0 + i] : b0 + i];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            __syncthreads();
+            if ((tid & 63) == 0) red[tid >> 6] = s;
+            __syncthreads();
+            scale = wmul / ((red[0] + red[1]) + (red[2] + red[3]));
+        }
+        float s = 0.0f;
+        for (int64_t i = tid; i < nb; i += 256) s += -(logp[b0 + i] * (w ? w[idx ? idx[b0 + i] : b0 + i] * scale : 1.0f));
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = s;
+        __syncthreads();
+        total += (red[0] + red[1]) + (red[2] + red[3]);
+    }
+    if (tid == 0) *loss = total;
+}
+
+// One pass over a validation set in batches (flow.py:327-348), everything enqueued by one call: ONE forward launch over all
+// n rows (a row's log-density does not depend on its batch), one launch for the batches' weighted sums.
 extern "C" int pmc_maf_valid_epoch(const pmc_maf_t* m, const float* x, const float* w, const int64_t* perm, int64_t n,
                                    int64_t batch_size, float* logp_scratch, float* loss, void* stream) {
     if (!m || !x || !logp_scratch || !loss || n < 0 || batch_size < 1) return pmc_fail("pmc_maf_valid_epoch: bad argument");
+    if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    for (int64_t b0 = 0; b0 < n; b0 += batch_size) {
-        const int64_t nb = (n - b0 < batch_size) ? n - b0 : batch_size;
-        const float* xb = perm ? x : x + b0 * m->D;
-        const float* wb = (w && !perm) ? w + b0 : w;
-        const int64_t* ib = perm ? perm + b0 : nullptr;
-        if (int rc = pmc_launch_forward_wg(m, xb, nullptr, nullptr, logp_scratch, nb, st, ib)) return rc;
-        hipLaunchKernelGGL(batch_nll_kernel, dim3(1), dim3(256), 0, st, (const float*)logp_scratch, wb, ib, 1000.0f, loss, nb);
-    }
+    if (int rc = pmc_launch_forward_wg(m, x, nullptr, nullptr, logp_scratch, n, st, perm)) return rc;
+    hipLaunchKernelGGL(epoch_nll_kernel, dim3(1), dim3(256), 0, st, (const float*)logp_scratch, w, perm, 1000.0f, loss, n,
+                       batch_size);
     return pmc_check_launch("pmc_maf_valid_epoch");
 }
 

@@ -609,13 +609,19 @@ class MAFSpec:
         the tile's 256 entries in ``gmap`` (or -1: bias only), ``g_b`` the offset of the 16 bias entries of the out
         tile (carried by ONE job per out tile, -1 elsewhere).  Kinds: 0 ``xt_scratch`` (transform inputs), 1
         ``act_scratch`` (h0, h1, h2), 2 ``delta_scratch`` (da0, da1, da2), 3 ``par_scratch`` (output gradients).
-        Only tiles with at least one unmasked entry get a job."""
+        Only tiles with at least one unmasked entry get a job.
+
+        Order: workgroup ``b`` of a launch runs on XCD ``b % 8`` (observed on MI355X, used for speed only), and the eight
+        L2s are not shared.  Jobs that read the same operand tiles -- the tiles of one layer of one transform -- are
+        therefore placed in the same residue class mod 8 (pieces of a layer's job list, longest first onto the least
+        loaded class), so that an operand crosses the fabric into ONE L2 instead of eight; classes are padded to equal
+        length with no-op jobs (``kind_a = -1``)."""
         L = self.train_layout()
         _, gm = self.train_index()
         nT, nXT, nOT, Hp, Dp = self.nT, self.nXT, self.nOT, self.Hp, self.Dp
         G = L["gmap_per_transform"]
         ppt = self.par_per_transform()
-        jobs = []
+        jobs, groups, g_start = [], [], 0
         for t in range(self.n_transforms):
             gt = t * G
             layers = (
@@ -640,7 +646,21 @@ class MAFSpec:
                         first = False
                     if first and bias_live:                  # an out tile whose weights are all masked still has biases
                         jobs.append((ka, base_a + To * 256, -1, 0, -1, gb0 + 16 * To, 0, 0))
-        return np.asarray(jobs, dtype=np.int32).reshape(-1, 8)
+                groups.append(jobs[g_start:])
+                g_start = len(jobs)
+        # ---- placement by XCD (docstring): pieces of <= piece jobs, longest processing time first
+        piece = max(4, -(-len(jobs) // 32))
+        pieces = [g[i:i + piece] for g in groups for i in range(0, len(g), piece)]
+        buckets = [[] for _ in range(8)]
+        for pc in sorted(pieces, key=len, reverse=True):
+            min(buckets, key=len).extend(pc)
+        buckets.sort(key=len, reverse=True)                  # (block 0, which also adds up the loss, gets a real job)
+        depth = len(buckets[0])
+        noop = (-1, 0, -1, 0, -1, -1, 0, 0)
+        out = [buckets[b][k] if k < len(buckets[b]) else noop for k in range(depth) for b in range(8)]
+        while out and out[-1] == noop:
+            out.pop()
+        return np.asarray(out, dtype=np.int32).reshape(-1, 8)
 
     def train_index(self):
         """``(packT_idx, gmap)``: gather map for ``packedT`` (like ``pack_index``) and the

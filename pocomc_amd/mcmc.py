@@ -167,10 +167,23 @@ def _host_pool(n_threads, cores=None):
 
 
 def allreduce_sums(sums_dev, group=None):
-    """Sum the per-shard reductions over all ranks (no-op without a process group)."""
+    """Sum the per-shard reductions over all ranks (no-op without a process group) IN RANK ORDER: beyond two ranks the
+    shards are all-gathered and added ((r0 + r1) + r2) + ..., so the bits of sigma, mu and of the stop rule do not depend
+    on the backend's reduction algorithm (gloo's ring, RCCL's tree) and equal the library's own exchange
+    (``pmc_comm_adapt_update`` adds the ranks' mailbox slots in the same order).  D + 4 doubles per rank: the gather costs
+    what the all-reduce costs."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(sums_dev, op=dist.ReduceOp.SUM, group=group)
+        world = dist.get_world_size(group)
+        if world == 2:
+            dist.all_reduce(sums_dev, op=dist.ReduceOp.SUM, group=group)      # (a + b: the same double in either order)
+        else:
+            parts = [torch.empty_like(sums_dev) for _ in range(world)]
+            dist.all_gather(parts, sums_dev, group=group)
+            acc = parts[0].clone()
+            for p_ in parts[1:]:
+                acc += p_
+            sums_dev.copy_(acc)
     return sums_dev
 
 

@@ -490,8 +490,8 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
     d_perm = [[torch.empty(max(n_train, 1), dtype=torch.int64, device=dev) for _ in range(slots)],
               [torch.empty(max(n_valid, 1), dtype=torch.int64, device=dev) for _ in range(slots)]]
     ts = _train_state(flow)
-    if validation and not sharded and (getattr(ts, "logp_scratch", None) is None or ts.logp_scratch.numel() < batch_size):
-        ts.logp_scratch = torch.empty(int(batch_size), dtype=torch.float32, device=dev)
+    if validation and not sharded and (getattr(ts, "logp_scratch", None) is None or ts.logp_scratch.numel() < n_valid):
+        ts.logp_scratch = torch.empty(int(n_valid), dtype=torch.float32, device=dev)
 
     def upload_perm(which, sl, n):
         # DataLoader(shuffle=...), flow.py:251-265: a fresh permutation per pass (pinned staging, no host sync)

@@ -141,7 +141,12 @@ def test_train_jobs_cover_every_gradient_entry_exactly_once(D, T, H, uni):
     assert jobs.dtype == np.int32 and jobs.shape[1] == 8 and len(jobs) > 0
     hits = np.zeros(s.n_params, dtype=np.int64)
     sizes = {0: (T + 1) * s.Dp * 16, 1: T * 3 * s.Hp * 16, 2: T * 3 * s.Hp * 16, 3: T * s.par_per_transform()}
+    assert jobs[0][0] >= 0                                   # (block 0 also adds up the loss)
+    assert (jobs[:, 0] < 0).sum() <= 8 + len(jobs) // 4     # padding of the XCD placement stays small
     for ka, oa, kb, ob, gw, gb, _, _ in jobs:
+        if ka < 0:
+            assert gw < 0 and gb < 0
+            continue
         assert 0 <= oa and oa + 256 <= sizes[ka] and oa % 256 == 0
         if gw >= 0:
             assert 0 <= ob and ob + 256 <= sizes[kb] and ob % 256 == 0

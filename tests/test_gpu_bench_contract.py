@@ -64,3 +64,29 @@ def test_two_ranks_on_a_shared_gpu_report_a_two_rank_line():
     assert h["pipeline"] == "pmc_pipeline_next (C ABI)" and "pmc_comm" in c["collectives"]
     print("two-rank python_overhead us/step:", h["python_overhead"])
     assert h["python_overhead"] <= 12.0, h               # (measured 9.3 on a shared GPU, 20 timed steps; 2 us of margin)
+
+
+def test_eight_ranks_on_a_shared_gpu_report_an_eight_rank_line():
+    """``python bench.py --gpus 8`` on a one-GPU box (BASELINE configs[3]: 80 000 walkers sharded 8 x): eight ranks share
+    device 0 over gloo -- a rehearsal of the 8-way plumbing (handle exchange, mailbox indexing, per-rank core choice, the
+    data-parallel fit at 64 local rows per batch), not a measurement: rc 0, one line, ``n_gpus == 8``, eight ranks reported
+    by the backend, a workload that names 80 000 walkers, eight per-rank clock records on eight distinct cores."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2", "--no-flow-bench",
+           "--no-steady-state"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 6 and d["scaling"] == "weak"
+    c = d["config"]
+    assert c["global_walkers"] == 80000 and c["walkers_per_gpu"] == 10000 and "80000 walkers" in c["workload"]
+    assert c["ranks_reported_by_backend"] == 8 and "pmc_comm" in c["collectives"]
+    assert d["value"] > 0 and abs(d["ms_per_step"] - 80000 / 1e4 / d["value"] * 1e3) < 1e-6 * d["ms_per_step"] + 1e-9
+    pr = d["per_rank_us_per_step"]
+    assert len(pr) == 8 and sorted(r["rank"] for r in pr) == list(range(8))
+    cores = [r["pinned_core"] for r in pr]
+    assert None not in cores and len(set(cores)) == 8, cores
+    assert all(r["wait_x"] is not None and r["likelihood"] > 0 for r in pr)
+    assert d["cpu_baseline"] is None and d["roofline"]["frac"] > 0

@@ -293,7 +293,9 @@ def test_kernel_call_matches_reference_golden(name, no_fuse, golden_dir, monkeyp
         # walkers may be off at 1e-5 relative (spline flows: at their stated bound, NSF_X).  In a longer call every
         # walker's step k+1 proposal is scaled by sigma_{k+1} = f(mean alpha_k) (mcmc.py:152-156): the float32 flow's
         # noise in alpha (and any flip, 1/N) reaches ALL walkers through sigma and mu, so the set follows the reference
-        # at ~1e-3, not 1e-5; the step-by-step statement for those steps is the teacher-forced test.
+        # at ~1e-3, not 1e-5; the walker-by-walker 1e-5 statement for whole calls of several steps is
+        # test_whole_call_with_the_references_sigma_and_mu_follows_it_walker_by_walker below (sigma_k and mu_k from the
+        # oracle, everything else on the device), the step-by-step one the teacher-forced test.
         off, worst = _off_trajectory(res, g, tag, TOL)
         print(f"{tag}: {int(off.sum())} of {off.size} walkers off the reference trajectory at {TOL:g} relative "
               f"(worst of the others {worst:.2e}); sigma ratio {res['proposal_scale'] / float(g[f'{tag}/proposal_scale']) - 1.0:.2e}")
@@ -307,6 +309,68 @@ def test_kernel_call_matches_reference_golden(name, no_fuse, golden_dir, monkeyp
                 assert (rel < 1e-3).mean() > 0.97, f"{tag}/{k}: {(rel < 1e-3).mean()}"
         np.testing.assert_allclose(res["accept"], g[f"{tag}/accept"], atol=0.02)
         np.testing.assert_allclose(res["proposal_scale"], g[f"{tag}/proposal_scale"], rtol=5e-3)
+
+
+@pytest.mark.parametrize("name", list(cases.MCMC_CASES))
+def test_whole_call_with_the_references_sigma_and_mu_follows_it_walker_by_walker(name, golden_dir, monkeypatch):
+    """The multi-step parity statement (mcmc.py:74-180).  A whole kernel call of ``n_max`` steps runs on the device; the
+    walkers evolve there and nowhere else.  The ONLY quantities taken from the oracle's trace are the two global ones of
+    every step -- sigma_k and mu_k, functions of means over all walkers (mcmc.py:152-156), through which one accept flip
+    or the float32 flow's noise in alpha would otherwise reach every walker's next proposal -- and the stop decision that
+    depends on them.  Then every walker must sit within 1e-5 (spline flows: their stated bound) of the reference's FINAL
+    golden state, except walkers whose accept decision flipped, and a decision may only flip where the uniform draw lies
+    between the device's alpha and the oracle's: at most 2 new flips per step."""
+    from pocomc_amd import mcmc as pmcmc
+    g = np.load(f"{golden_dir}/mcmc_reference.npz")
+    c = cases.MCMC_CASES[name]
+    TOL = tols(c)[0]
+    kind = c["kind"]
+    # the oracle's run: trace (sigma_k, mu_k, alpha_k, decisions) and the variates the reference drew
+    state, funcs, opts, _ = oracle_case(name)
+    rng, otrace = omcmc.LegacyStream(), []
+    np.random.seed(c["seed"])
+    ores = getattr(omcmc, kind)(state, funcs, opts, rng=rng, trace=otrace)
+    n_steps = len(otrace)
+    tag = f"mcmc/{name}/nmax{c['n_max']}"
+    assert n_steps == int(g[f"{tag}/steps"]) == ores["steps"]
+
+    class Forced(pmcmc.Adaptation):
+        """The product's adaptation with its two global results replaced by the oracle's after every step."""
+
+        def update(self, sums):
+            super().update(sums)
+            tr = otrace[self.i - 1]
+            self.sigma = tr["sigma"]
+            if self.kind == "preconditioned_pcn":
+                self.mu = tr["mu"].copy()
+            return self.i >= n_steps
+
+    monkeypatch.setattr(pmcmc, "Adaptation", Forced)
+    pstate, pfuncs, popts, _ = product_case(name)
+    ptrace = []
+    res = getattr(pmcmc, kind)(pstate, pfuncs, popts, replay=omcmc.Replay(rng.record), trace=ptrace)
+    assert res["steps"] == n_steps == len(ptrace)
+    # ---- step by step: decisions are u < alpha; a walker leaves the reference's trajectory only through a flip inside
+    # the alpha gap; walkers that left are not looked at again
+    N = c["N"]
+    on = np.ones(N, dtype=bool)
+    flips_per_step = []
+    for k in range(n_steps):
+        u_rand, a_dev, a_ref = rng.record[k]["u"], ptrace[k]["alpha"], otrace[k]["alpha"]
+        assert np.array_equal(ptrace[k]["accept"], u_rand < a_dev), f"step {k}: decision != (u < alpha)"
+        flips = on & (ptrace[k]["accept"] != otrace[k]["accept"])
+        lo, hi = np.minimum(a_dev, a_ref), np.maximum(a_dev, a_ref)
+        assert ((u_rand[flips] >= lo[flips]) & (u_rand[flips] <= hi[flips])).all(), f"step {k}: a flip outside the alpha gap"
+        np.testing.assert_allclose(a_dev[on], a_ref[on], rtol=2e-3, atol=2e-5)
+        flips_per_step.append(int(flips.sum()))
+        on &= ~flips
+    assert max(flips_per_step) <= 2, flips_per_step
+    # ---- the final state of every walker that never flipped, against the REFERENCE's own output
+    off, worst = _off_trajectory(res, g, tag, TOL)
+    print(f"{tag}: sigma / mu forced, {n_steps} steps: {int((off & on).sum())} of {int(on.sum())} unflipped walkers off the "
+          f"reference's final state at {TOL:g} (worst {worst:.2e}); flips per step {flips_per_step}")
+    assert not (off & on).any(), f"{tag}: {int((off & on).sum())} walkers left the reference's trajectory without a flip"
+    assert abs(res["calls"] - int(g[f"{tag}/calls"])) <= 2 * n_steps
 
 
 @pytest.mark.parametrize("name", list(cases.BIG_GOLDEN_CASES))

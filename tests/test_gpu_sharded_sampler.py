@@ -133,12 +133,12 @@ def test_sharded_sampler_needs_a_seed():
         pc.sampler._Ranks = orig
 
 
-def _kernel_case():
+def _kernel_case(Dk=6):
     from scipy.stats import uniform
     import torch
     import pocomc_amd as pc
     from pocomc_amd.geometry import Geometry
-    Dk, N = 6, 640
+    N = 640
     prior = pc.Prior([uniform(-5, 10)] * Dk)
     rng = np.random.default_rng(12)
     scaler = pc.Reparameterize(Dk, bounds=prior.bounds)
@@ -152,14 +152,14 @@ def _kernel_case():
     return prior, scaler, x, u, like, flow, geo
 
 
-def _kernel_call(lo, hi, lanes, group_opts):
+def _kernel_call(lo, hi, lanes, group_opts, Dk=6):
     from pocomc_amd import mcmc as pmcmc
-    prior, scaler, x, u, like, flow, geo = _kernel_case()
+    prior, scaler, x, u, like, flow, geo = _kernel_case(Dk)
     sl = slice(lo, hi)
     state = dict(u=u[sl].copy(), x=x[sl].copy(), logdetj=scaler.inverse(u[sl])[1], logl=like(x[sl])[0],
                  logp=prior.logpdf(x[sl]), beta=0.5, blobs=None)
     funcs = dict(loglike=like, logprior=prior.logpdf, scaler=scaler, flow=flow, theta_geometry=geo)
-    opts = dict(n_max=6, n_steps=10 ** 6, progress_bar=None, proposal_scale=2.38 / 6 ** 0.5, seed=21, x_order="F",
+    opts = dict(n_max=6, n_steps=10 ** 6, progress_bar=None, proposal_scale=2.38 / Dk ** 0.5, seed=21, x_order="F",
                 lanes=lanes, **group_opts)
     return pmcmc.preconditioned_pcn(state, funcs, opts)
 
@@ -168,40 +168,41 @@ def _kernel_worker(rank, world, port, out, lanes):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lo, hi = rank * 320, (rank + 1) * 320
+    lo, hi = rank * 640 // world, (rank + 1) * 640 // world
     r = _kernel_call(lo, hi, lanes, dict(group=None, shard_offset=lo))
     np.savez(out % rank, u=r["u"], logl=r["logl"], sigma=r["proposal_scale"], accept=r["accept"], steps=r["steps"])
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("lanes", [1, 2])
-def test_two_rank_pipelined_kernel_call_equals_one_rank(tmp_path, lanes):
-    """Walkers sharded over two ranks, adaptation on the device (lane sums -> all-reduce -> sigma / mu update,
-    the next pre-step enqueued behind it): the same trajectory as the whole set on one rank, up to the order
-    in which the sums are added."""
+@pytest.mark.parametrize("world,lanes", [(2, 1), (2, 2), (4, 2), (8, 2)])
+def test_sharded_pipelined_kernel_call_equals_one_rank(tmp_path, world, lanes):
+    """Walkers sharded over 2, 4 and 8 ranks (one GPU shared by the processes: the rank plumbing, not the links), adaptation
+    on the device (lane sums -> exchange -> sigma / mu update, the next pre-step enqueued behind it): the same trajectory
+    as the whole set on one rank, up to the order in which the sums are added."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "k%d.npz")
-    mp.spawn(_kernel_worker, args=(2, _free_port(), out, lanes), nprocs=2, join=True)
-    r0, r1 = np.load(out % 0), np.load(out % 1)
+    mp.spawn(_kernel_worker, args=(world, _free_port(), out, lanes), nprocs=world, join=True)
+    rs = [np.load(out % r) for r in range(world)]
     whole = _kernel_call(0, 640, 1, {})
-    assert float(r0["sigma"]) == float(r1["sigma"]) and int(r0["steps"]) == int(r1["steps"]) == whole["steps"] == 6
-    np.testing.assert_allclose(float(r0["sigma"]), whole["proposal_scale"], rtol=1e-12)
-    np.testing.assert_allclose(float(r0["accept"]), whole["accept"], rtol=1e-12)
-    u2 = np.concatenate([r0["u"], r1["u"]])
+    for r in rs:
+        assert float(r["sigma"]) == float(rs[0]["sigma"]) and int(r["steps"]) == whole["steps"] == 6
+    np.testing.assert_allclose(float(rs[0]["sigma"]), whole["proposal_scale"], rtol=1e-12)
+    np.testing.assert_allclose(float(rs[0]["accept"]), whole["accept"], rtol=1e-12)
+    u2 = np.concatenate([r["u"] for r in rs])
     same = np.isclose(u2, whole["u"], rtol=1e-9, atol=1e-12).all(axis=1)
     assert same.mean() >= 0.995, same.mean()
-    np.testing.assert_allclose(np.concatenate([r0["logl"], r1["logl"]])[same], whole["logl"][same], rtol=1e-8)
+    np.testing.assert_allclose(np.concatenate([r["logl"] for r in rs])[same], whole["logl"][same], rtol=1e-8)
 
 
-def _comm_worker(rank, world, port, out, c_allreduce, mailbox):
+def _comm_worker(rank, world, port, out, c_allreduce, mailbox, Dk=6):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       PMC_C_ALLREDUCE=c_allreduce, PMC_COMM_MAILBOX=mailbox)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pocomc_amd import mcmc as pmcmc
-    lo, hi = rank * 320, (rank + 1) * 320
-    r = _kernel_call(lo, hi, 2, dict(group=None, shard_offset=lo))
+    lo, hi = rank * 640 // world, (rank + 1) * 640 // world
+    r = _kernel_call(lo, hi, 2, dict(group=None, shard_offset=lo), Dk)
     used = any(v[0] for v in pmcmc._COMMS.values())
     kinds = sorted({int(pmcmc._lib.load().pmc_comm_kind(v[0])) for v in pmcmc._COMMS.values() if v[0]})
     np.savez(out % rank, u=r["u"], x=r["x"], logl=r["logl"], sigma=r["proposal_scale"], accept=r["accept"], steps=r["steps"], used=used,
@@ -212,28 +213,32 @@ def _comm_worker(rank, world, port, out, c_allreduce, mailbox):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mailbox", ["device", "host"])
-def test_the_sharded_step_behind_the_c_abi_equals_the_torch_distributed_path(tmp_path, mailbox):
-    """Two ranks, walkers sharded: the step runs behind ``pmc_pipeline_*`` with the library's own all-reduce between the
-    last accept and the adaptation (``pmc_comm_adapt_update``: the ranks' sums added in rank order) -- bit for bit what the
-    round-2 Python pipeline produces with ``torch.distributed.all_reduce`` in that place (``PMC_C_ALLREDUCE=0``): with two
-    ranks a + b is the same double in either order.  ``mailbox="device"``: uncached HBM shared through hipIpc handles (two
-    processes on one GPU map LOCAL memory).  ``mailbox="host"``: the mailboxes in pinned host memory (POSIX shared memory
-    registered with both runtimes) -- every system-scope store, sequence word and acquire-poll of the protocol crosses
-    PCIe to memory no device caches: the stand-in for a remote target on a one-GPU box."""
+@pytest.mark.parametrize("world,mailbox,Dk", [(2, "device", 6), (2, "host", 6), (4, "device", 6), (4, "host", 6),
+                                              (8, "device", 6), (8, "host", 6), (8, "device", 32), (8, "host", 128)])
+def test_the_sharded_step_behind_the_c_abi_equals_the_torch_distributed_path(tmp_path, world, mailbox, Dk):
+    """2, 4 and 8 ranks, walkers sharded (D = 6, 32, 128: the two-wave sweep, the headline's, and the lane sweep of config 5's
+    width): the step runs behind ``pmc_pipeline_*`` with the library's own exchange between the last accept and the
+    adaptation (``pmc_comm_adapt_update``: mailboxes ``[2 parities][world][D + 5]``, the ranks' sums added in rank order)
+    -- bit for bit what the Python pipeline produces with ``torch.distributed`` in that place (``PMC_C_ALLREDUCE=0``;
+    ``allreduce_sums`` adds in rank order too).  ``mailbox="device"``: uncached HBM shared through hipIpc handles (the
+    processes share one GPU here and map LOCAL memory; on a node every handle is a peer's).  ``mailbox="host"``: the
+    mailboxes in pinned host memory (POSIX shared memory registered with every rank's runtime) -- every system-scope
+    store, sequence word and acquire-poll of the protocol crosses PCIe to memory no device caches: the stand-in for a
+    remote target on a one-GPU box.  No link between two GPUs is crossed by this test: what it rehearses is the 4- and
+    8-way handle exchange, the mailbox indexing and the rank-ordered sums."""
     import torch.multiprocessing as mp
     res = {}
     for flag in ("1", "0"):
         out = str(tmp_path / f"c{flag}_%d.npz")
-        mp.spawn(_comm_worker, args=(2, _free_port(), out, flag, mailbox), nprocs=2, join=True)
-        res[flag] = [np.load(out % 0), np.load(out % 1)]
-    assert bool(res["1"][0]["used"]) and bool(res["1"][1]["used"])          # the communicator was created and connected
-    assert res["1"][0]["kinds"].tolist() == res["1"][1]["kinds"].tolist() == [0 if mailbox == "device" else 1]
-    assert not bool(res["0"][0]["used"])
-    for rk in (0, 1):
+        mp.spawn(_comm_worker, args=(world, _free_port(), out, flag, mailbox, Dk), nprocs=world, join=True)
+        res[flag] = [np.load(out % r) for r in range(world)]
+    assert all(bool(r["used"]) for r in res["1"])                              # the communicator was created and connected
+    assert all(r["kinds"].tolist() == [0 if mailbox == "device" else 1] for r in res["1"])
+    assert not any(bool(r["used"]) for r in res["0"])
+    for rk in range(world):
         a, b = res["1"][rk], res["0"][rk]
         assert int(a["steps"]) == int(b["steps"]) == 6
         assert float(a["sigma"]) == float(b["sigma"]) and float(a["accept"]) == float(b["accept"])
         for k in ("u", "x", "logl"):
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
-    assert float(res["1"][0]["sigma"]) == float(res["1"][1]["sigma"])
+        assert float(a["sigma"]) == float(res["1"][0]["sigma"])

@@ -282,7 +282,7 @@ def test_validation_epoch_call_equals_batch_by_batch(name, weighted):
         idx = perm[b0:b0 + bs]
         ref += float(batch_loss(f, x[idx].contiguous(), None if w is None else w[idx].contiguous()))
     acc = torch.zeros(1, dtype=torch.float32, device="cuda")
-    scratch = torch.empty(bs, dtype=torch.float32, device="cuda")
+    scratch = torch.empty(n, dtype=torch.float32, device="cuda")
     _lib.check(f.lib.pmc_maf_valid_epoch(C.byref(f._desc), _lib.ptr(x), _lib.ptr(w) if w is not None else None,
                                          _lib.ptr(perm), n, bs, _lib.ptr(scratch), _lib.ptr(acc), _lib.stream_handle()))
     np.testing.assert_allclose(float(acc), ref, rtol=2e-6)
