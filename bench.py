@@ -232,7 +232,6 @@ def comm_kind_name():
     return " / ".join(names.get(k, str(k)) for k in kinds) or "none"
 
 
-LANE16_BOUND = 1e-2          # the bound Flow's own guard uses (pocomc_amd/flow.py::LANE16_BOUND)
 
 
 def main():
@@ -296,6 +295,7 @@ def main():
     import torch
     import torch.distributed as dist
     from pocomc_amd import Flow, Reparameterize
+    from pocomc_amd.flow import LANE16_BOUND          # the bound Flow's own guard uses
     from pocomc_amd.geometry import Geometry
     from pocomc_amd.mcmc import StepEngine, LanedEngine, Adaptation
 
@@ -409,9 +409,23 @@ def main():
     pc_prior = Prior([sp_uniform(p_lo, p_hi - p_lo)] * D)                   # pocoMC's own prior object
     device_prior = (not args.host_prior) and eng.set_device_prior(pc_prior)
     eng.load_state(u, x, logdetj, logl, logp)
-    if flow.inverse_precision_active != "f32":
-        flow.check_inverse_precision(theta=eng.theta32[:4096], rows=4096)      # as mcmc._run does at the head of a call
     eng.set_geometry(mu=geo.t_mean, cov=geo.t_cov)
+    if getattr(flow, "_lane16", None) is not None and flow.inverse_guard_enabled:
+        # as mcmc._run does at the head of a call: the guard on proposals drawn at the starting sigma / mu, every rank in
+        # the reduction whatever its own state
+        from pocomc_amd.mcmc import _proposal_draws
+        armed = flow.inverse_precision_active != "f32"
+        guard = flow.check_inverse_precision(theta=_proposal_draws("preconditioned_pcn", eng.theta32, geo, min(sigma0, 0.99), 4096),
+                                             rows=4096) if armed else None
+        fall = (not armed) or (guard is not None and not guard["passed"])
+        if world > 1:
+            fl_ = torch.tensor([1.0 if fall else 0.0], device="cuda")
+            dist.all_reduce(fl_)
+            fall = float(fl_.item()) > 0
+        if fall and flow._desc.lane16:
+            flow._desc.lane16 = None
+            if flow.inverse_guard is not None:
+                flow.inverse_guard["passed"] = False
     ad = Adaptation("preconditioned_pcn", D, n * world, n_steps=10 ** 9, n_max=10 ** 9, sigma0=sigma0,
                     mu0=geo.t_mean, logp2_0=-np.inf)
     # the timed region steps the same walkers as a pipeline of row ranges (what mcmc._run does from 4096 walkers

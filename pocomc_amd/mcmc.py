@@ -1066,6 +1066,32 @@ class LanedEngine:
         return {k: cat([p[k] for p in parts]) for k in parts[0]}
 
 
+def _proposal_draws(kind, theta32, geometry, sigma, rows, seed=20240929):
+    """``rows`` proposals theta' (float32, on the walkers' device) for a strided sample of the walkers ``theta32``, drawn
+    from the step's proposal law: tpCN ``mu + sqrt(1 - sigma^2) (theta - mu) + sigma sqrt(s) L z`` with the Student-t scale
+    ``s = 1 / Gamma((D + nu) / 2, 2 / (nu + delta))`` (``mcmc.py:77-85``), RWM ``theta + sigma L z`` (``:251-253``).  Host
+    float64 arithmetic from a private numpy generator (no global stream is touched): the input of the 16-bit sweep's guard,
+    which must see the heavy-tailed points the sweep will be given, not the walkers' current positions."""
+    n, D = theta32.shape
+    take = int(min(rows, n))
+    idx = torch.linspace(0, n - 1, take, device=theta32.device).long()
+    th = theta32[idx].double().cpu().numpy()
+    g = np.random.default_rng(seed)
+    z = g.standard_normal((take, D))
+    if kind == "preconditioned_pcn":
+        mu, cov, nu = np.asarray(geometry.t_mean, float), np.asarray(geometry.t_cov, float), float(geometry.t_nu)
+        L = np.linalg.cholesky(cov)
+        d = th - mu
+        delta = np.einsum("ij,ij->i", d @ np.linalg.inv(cov), d)
+        s = 1.0 / (g.standard_gamma((D + nu) / 2.0, size=take) * 2.0 / (nu + delta))
+        sig = min(float(sigma), 0.99)
+        thp = mu + np.sqrt(1.0 - sig ** 2) * d + sig * np.sqrt(s)[:, None] * (z @ L.T)
+    else:
+        L = np.linalg.cholesky(np.asarray(geometry.normal_cov, float))
+        thp = th + float(sigma) * (z @ L.T)
+    return torch.from_numpy(thp.astype(np.float32)).to(theta32.device)
+
+
 def _global_count(n, group):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -1174,16 +1200,6 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
     if owner is not None and option_dict.get("device_prior", True) and hasattr(owner, "device_descriptor"):
         eng.set_device_prior(owner)                 # Prior.logpdf of uniform / normal factors on the device
     eng.load_state(u, x, logdetj, logl, logp)
-    if pre and getattr(flow, "inverse_precision_active", "f32") != "f32":
-        # the 16-bit sweep's safety net where the sweep is used: on THESE walkers' theta = flow.forward(u) (mcmc.py:60),
-        # which need not look like the rows the flow was fitted on; float32 from here on if it is not an inverse there
-        th = (eng.lanes[0] if isinstance(eng, LanedEngine) else eng).theta32
-        guard = flow.check_inverse_precision(theta=th[:4096], rows=4096)
-        if sharded and guard is not None:
-            flag = torch.tensor([0.0 if guard["passed"] else 1.0], device=eng.device)
-            dist.all_reduce(flag, group=group)
-            if float(flag.item()) > 0:
-                flow._desc.lane16 = None
     nu = 0.0
     if tpcn:
         nu = float(geometry.t_nu)
@@ -1204,6 +1220,27 @@ def _run(kind, state_dict, function_dict, option_dict, replay=None, trace=None):
     init = init.cpu().numpy()
     ad = Adaptation(kind, n_dim, n_total, n_steps, n_max, option_dict.get("proposal_scale"),
                     geometry.t_mean if tpcn else None, (init[1] if tpcn else init[2]) / n_total)
+
+    if pre and getattr(flow, "_lane16", None) is not None and flow.inverse_guard_enabled:
+        # the 16-bit sweep's safety net where the sweep is used: on the points THIS call hands to flow.inverse (mcmc.py:88)
+        # -- proposals drawn from the step's own law at the starting sigma / mu, a strided sample over ALL lanes' walkers;
+        # float32 from here on if the sweep is not an inverse there.  Sharded: every rank enters the reduction whatever its
+        # own state (a rank that already fell back votes for the fallback), one rank's fallback is everybody's.
+        armed = flow.inverse_precision_active != "f32"
+        guard = None
+        if armed:
+            th_all = torch.cat([e_.theta32 for e_ in (eng.lanes if laned else [eng])])
+            thp = _proposal_draws(kind, th_all, geometry, float(ad.sigma), 4096)
+            guard = flow.check_inverse_precision(theta=thp, rows=4096)
+        fall = (not armed) or (guard is not None and not guard["passed"])
+        if sharded:
+            flag = torch.tensor([1.0 if fall else 0.0], device=eng.device)
+            dist.all_reduce(flag, group=group)
+            fall = float(flag.item()) > 0
+        if fall and flow._desc.lane16:
+            flow._desc.lane16 = None
+            if flow.inverse_guard is not None:
+                flow.inverse_guard["passed"] = False
 
     n_calls = 0
     pipelined = want_pipe and eng.can_pipeline() and (laned or not sharded)

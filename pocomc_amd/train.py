@@ -67,6 +67,7 @@ class TrainState:
         self.par_floats = spec.n_transforms * self.par_pt
         per_set = 4 * (self.xt_floats + 2 * self.act_floats + self.par_floats)
         self.set_cap = int(max(32, min(MAX_SETS, SCRATCH_BUDGET // per_set)))
+        self.scatter_maps(flow)             # (host-built once per Flow, like the maps above: not a per-fit cost)
 
     def ensure_sets(self, n_rows):
         """Scratch for the row sets of one launch: transform inputs, activations, deltas, output gradients."""

@@ -533,3 +533,33 @@ def test_host_prefetcher_runs_a_job_and_shuts_down():
     lib.pmc_prefetcher_destroy(h)
     assert np.array_equal(buf, ref)
     assert lib.pmc_prefetcher_submit(None, flag.ctypes.data, 1, buf.ctypes.data, 8, 0.1) != 0
+
+
+def test_proposal_draws_of_the_16bit_guard_follow_the_proposal_law():
+    """``mcmc._proposal_draws`` (the points the 16-bit sweep's guard is run on at the head of a kernel call): tpCN draws
+    have the proposal's mean ``mu + sqrt(1 - sigma^2) (theta - mu)`` and Student-t tails (``mcmc.py:77-85``), RWM draws the
+    covariance ``sigma^2 Sigma`` around the walker (``:251-253``); a strided sample over all walkers, no global RNG touched."""
+    import torch
+    from types import SimpleNamespace
+    from pocomc_amd.mcmc import _proposal_draws
+    rng = np.random.default_rng(0)
+    D, n = 5, 20000
+    A = rng.normal(size=(D, D))
+    cov = A @ A.T + D * np.eye(D)
+    mu = rng.normal(size=D)
+    theta = torch.from_numpy((mu + rng.normal(size=(n, D)) @ np.linalg.cholesky(cov).T).astype(np.float32))
+    geo = SimpleNamespace(t_mean=mu, t_cov=cov, t_nu=5.0, normal_cov=cov)
+    state = np.random.get_state()[1].copy()
+    t_state = torch.get_rng_state()
+    sigma = 0.6
+    thp = _proposal_draws("preconditioned_pcn", theta, geo, sigma, 8192).numpy().astype(np.float64)
+    assert thp.shape == (8192, D) and np.isfinite(thp).all()
+    idx = np.linspace(0, n - 1, 8192).astype(np.int64)
+    resid = thp - (mu + np.sqrt(1 - sigma ** 2) * (theta.numpy()[idx] - mu))
+    assert np.abs(resid.mean(axis=0)).max() < 0.25
+    white = resid @ np.linalg.inv(np.linalg.cholesky(cov)).T / sigma
+    kurt = (white ** 4).mean() / (white ** 2).mean() ** 2
+    assert kurt > 3.5, kurt                                   # heavier than Gaussian: the Student-t scale mixture
+    rw = _proposal_draws("preconditioned_rwm", theta, geo, sigma, 8192).numpy().astype(np.float64) - theta.numpy()[idx]
+    np.testing.assert_allclose(np.cov(rw.T), sigma ** 2 * cov, rtol=0.15, atol=0.15)
+    assert np.array_equal(np.random.get_state()[1], state) and torch.equal(torch.get_rng_state(), t_state)

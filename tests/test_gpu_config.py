@@ -190,7 +190,8 @@ def test_the_16bit_sweep_is_guarded():
     """``Flow.inverse`` is an INVERSE (``pocomc/flow.py:116-132``): whenever the parameters of a flow with
     ``inverse_precision != "f32"`` change, the 16-bit and the float32 sweep are compared on latent points of the flow and the
     flow goes back to float32, with a warning, if a walker's x differs by more than ``LANE16_BOUND`` (1e-2 relative) or its
-    log-determinant by more than ``LANE16_LADJ_BOUND`` (0.1).  Default construction and old checkpoints are float32."""
+    log-determinant by more than ``LANE16_LADJ_BOUND`` (0.1; 99th percentile ``LANE16_LADJ_Q99_BOUND``, 5e-2).  Default
+    construction and old checkpoints are float32."""
     import pickle
     import warnings
     from pocomc_amd import Flow
@@ -226,6 +227,9 @@ def test_the_16bit_sweep_is_guarded():
             xb, lb = r32.inverse(z)
             np.testing.assert_array_equal(xa.numpy(), xb.numpy())
             np.testing.assert_array_equal(la.numpy(), lb.numpy())
+            # the verdict travels with a checkpoint: a flow that fell back reloads on float32 (no re-check on other points)
+            r = pickle.loads(pickle.dumps(f))
+            assert r.inverse_precision == prec and r.inverse_precision_active == "f32" and r.inverse_guard["passed"] is False
             # new parameters get a new verdict: a tame flow passes again
             f.set_params(flat * np.float32(0.25))
             assert f.inverse_guard["passed"] and f.inverse_precision_active == prec
