@@ -8,22 +8,23 @@
 // SIMD cover each other's weight-fetch latency.  NW = 8 for small batches (validation batches of
 // Flow.fit, evidence draws), NW = 4 when there are enough row sets to fill the chip anyway.
 //
-// Spline flows: the output layer has 23 rows per feature.  It is produced 16 ranks (= exactly 23
-// output tiles) at a time into an LDS panel, then one thread per (rank, row) evaluates its spline.
+// Spline flows: the output layer has 3 K - 1 rows per feature (K bins: 23 for the reference's 8).  It is
+// produced 16 ranks (= exactly 3 K - 1 output tiles) at a time into an LDS panel, then one thread per
+// (rank, row) evaluates its spline.  UNI: 0 = affine, else the number of bins (4, 8, 16).
 #include <stdlib.h>
 #include "maf_wg.h"
 #include "rqs.h"
 
-#define PANEL_TILES RQS_NOUT             // 16 ranks x 23 outputs = 23 tiles of 16 rows
+#define PANEL_TILES(UNI) RQS_NOUT_OF(UNI)   // 16 ranks x (3 K - 1) outputs = 3 K - 1 tiles of 16 rows
 
-// out-layer panel of ranks [16c, 16c+16): tiles 23c .. 23c+22 -> P (LDS, local tile index)
-template <int NW>
+// out-layer panel of ranks [16c, 16c+16): tiles NOUT c .. NOUT c + NOUT - 1 -> P (LDS, local tile index)
+template <int NW, int NOUT>
 __device__ __forceinline__ void rqs_panel(const pmc_maf_t& m, const MafView& w, const float* H2, float* P, int c,
                                           int wv, int lane) {
     const int q = lane >> 4, p = lane & 15;
-    for (int i = wv; i < PANEL_TILES; i += NW) {
-        const int O = PANEL_TILES * c + i;
-        if (16 * O >= RQS_NOUT * m.D) continue;              // padding rows: never read
+    for (int i = wv; i < NOUT; i += NW) {
+        const int O = NOUT * c + i;
+        if (16 * O >= NOUT * m.D) continue;                  // padding rows: never read
         f32x4 o = bias4(w.b3, 16 * O + 4 * q);
         o = mac_range<4>(o, w.f3 + (size_t)O * m.nT * 64, H2, 0, m.nT, lane);
         store_rows(P, i, q, p, o);
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(64 * NW) void maf_forward_wg_kernel(pmc_maf_t m, co
                                                                  float* __restrict__ logprob_out, int64_t n,
                                                                  const int64_t* __restrict__ idx) {
     constexpr bool PROF = false;
+    constexpr int NOUT = UNI ? RQS_NOUT_OF(UNI) : 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -51,8 +53,8 @@ __global__ __launch_bounds__(64 * NW) void maf_forward_wg_kernel(pmc_maf_t m, co
     float* B = A + Hp * 16;
     float* C = B + Hp * 16;
     float* RED = C + Hp * 16;                 // [16 * NW]
-    float* P = RED + 16 * NW;                 // UNI 1: [PANEL_TILES * 256]
-    float* Y = P + (UNI ? PANEL_TILES * 256 : 0);   // MODE 1: the transform's input, by rank
+    float* P = RED + 16 * NW;                 // spline: [NOUT * 256]
+    float* Y = P + (UNI ? NOUT * 256 : 0);    // MODE 1: the transform's input, by rank
     const int* feat_of_rank = m.meta + 8;
     const int* rank_of_feat = m.meta + 8 + T * D;
     long long* pacc = nullptr; long long tk = 0;
@@ -105,17 +107,17 @@ __global__ __launch_bounds__(64 * NW) void maf_forward_wg_kernel(pmc_maf_t m, co
                 }
             } else {
                 for (int c = 0; c < nXT; ++c) {
-                    rqs_panel<NW>(m, w, C, P, c, wv, lane);
+                    rqs_panel<NW, NOUT>(m, w, C, P, c, wv, lane);
                     lds_barrier();
                     for (int e = tid; e < 256; e += 64 * NW) {
                         const int rr = e >> 4, pp = e & 15, rank = 16 * c + rr;
                         if (rank < D) {
-                            float phi[RQS_NOUT];
+                            float phi[NOUT];
 #pragma unroll
-                            for (int j = 0; j < RQS_NOUT; ++j) phi[j] = P[lidx(RQS_NOUT * rr + j, pp)];
+                            for (int j = 0; j < NOUT; ++j) phi[j] = P[lidx(NOUT * rr + j, pp)];
                             float y, l;
-                            if (MODE) rqs_inverse(phi, Y[lidx(rank, pp)], y, l);
-                            else rqs_forward(phi, Xc[lidx(rank, pp)], y, l);
+                            if (MODE) rqs_inverse_t<(UNI ? UNI : 8)>(phi, Y[lidx(rank, pp)], y, l);
+                            else rqs_forward_t<(UNI ? UNI : 8)>(phi, Xc[lidx(rank, pp)], y, l);
                             const int feat = feat_of_rank[t * D + rank];
                             if (MODE && !fin) {
                                 Xn[lidx(rank, pp)] = y;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(64 * NW) void maf_forward_wg_kernel(pmc_maf_t m, co
 template <int NW, int UNI, int MODE>
 static int launch_forward_wg(const pmc_maf_t* m, const float* x, float* z, float* ladj, float* log_prob, int64_t n,
                              hipStream_t st, const int64_t* idx = nullptr) {
-    const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 16 * NW + (UNI ? PANEL_TILES * 256 : 0) +
+    const size_t lds = (size_t)(2 * m->Dp * 16 + 3 * m->Hp * 16 + 16 * NW + (UNI ? PANEL_TILES(UNI) * 256 : 0) +
                                 (MODE ? m->Dp * 16 : 0)) * sizeof(float);
     if (lds > 160 * 1024) return pmc_fail("pmc_maf_forward: flow too wide for 160 KB of LDS");
     static size_t lds_set = 0;
@@ -184,9 +186,12 @@ int pmc_launch_forward_wg(const pmc_maf_t* m, const float* x, float* z, float* l
     // enough row sets to give every SIMD a few waves anyway -> fewer waves per set (less barrier idling)
     static const int force = pmc_env_int("PMC_FWD_NW", 0);      // A/B switch
     const bool wide = force ? force == 8 : n <= 16 * 1024;
-    if (m->n_out == RQS_NOUT)
-        return wide ? launch_forward_wg<8, 1, 0>(m, x, z, ladj, log_prob, n, st, idx)
-                    : launch_forward_wg<4, 1, 0>(m, x, z, ladj, log_prob, n, st, idx);
+#define FWD_SPLINE(K)                                                                                   \
+    if (m->n_out == RQS_NOUT_OF(K))                                                                      \
+        return wide ? launch_forward_wg<8, K, 0>(m, x, z, ladj, log_prob, n, st, idx)                    \
+                    : launch_forward_wg<4, K, 0>(m, x, z, ladj, log_prob, n, st, idx);
+    FWD_SPLINE(8) FWD_SPLINE(4) FWD_SPLINE(16)
+#undef FWD_SPLINE
     return wide ? launch_forward_wg<8, 0, 0>(m, x, z, ladj, log_prob, n, st, idx)
                 : launch_forward_wg<4, 0, 0>(m, x, z, ladj, log_prob, n, st, idx);
 }
@@ -194,6 +199,8 @@ int pmc_launch_forward_wg(const pmc_maf_t* m, const float* x, float* z, float* l
 // D-pass inverse through the same workgroup kernel (the only inverse of the spline flows until the
 // triangular sweep learns the spline; a cross-check for the affine flows)
 int pmc_launch_inverse_dpass_wg(const pmc_maf_t* m, const float* z, float* x, float* ladj, int64_t n, hipStream_t st) {
-    if (m->n_out == RQS_NOUT) return launch_forward_wg<8, 1, 1>(m, z, x, ladj, nullptr, n, st);
+    if (m->n_out == RQS_NOUT_OF(8)) return launch_forward_wg<8, 8, 1>(m, z, x, ladj, nullptr, n, st);
+    if (m->n_out == RQS_NOUT_OF(4)) return launch_forward_wg<8, 4, 1>(m, z, x, ladj, nullptr, n, st);
+    if (m->n_out == RQS_NOUT_OF(16)) return launch_forward_wg<8, 16, 1>(m, z, x, ladj, nullptr, n, st);
     return launch_forward_wg<8, 0, 1>(m, z, x, ladj, nullptr, n, st);
 }

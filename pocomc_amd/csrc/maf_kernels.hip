@@ -182,7 +182,7 @@ extern "C" int pmc_maf_pack(const float* flat, const int32_t* pack_idx, float* p
 static int check_maf(const pmc_maf_t* m) {
     if (!m || !m->packed || !m->meta) return pmc_fail("pmc_maf: null descriptor field");
     if (m->D < 2 || m->T < 1 || (m->Hp & 15) || (m->Dp & 15) || m->nT * 16 != m->Hp ||
-        m->nXT * 16 != m->Dp || (m->n_out != 2 && m->n_out != 23) || m->nOT * 16 != m->n_out * m->Dp)
+        m->nXT * 16 != m->Dp || (m->n_out != 2 && m->n_out != 11 && m->n_out != 23 && m->n_out != 47) || m->nOT * 16 != m->n_out * m->Dp)
         return pmc_fail("pmc_maf: inconsistent descriptor");
     return 0;
 }
@@ -217,9 +217,11 @@ extern "C" int pmc_maf_inverse(const pmc_maf_t* m, const float* z, float* x, flo
     if (m->n_out != 2) {
         // spline flows: triangular sweep, or the D-pass algorithm of the reference (zuko) as cross-check
         // and for layouts whose degree groups exceed a tile
-        if (algo == PMC_INVERSE_AUTO) algo = m->tri_ok ? PMC_INVERSE_TRIANGULAR : PMC_INVERSE_NAIVE;
+        // (the sweeps are built for the reference's 8 bins; other bin counts take zuko's own D-pass algorithm)
+        if (algo == PMC_INVERSE_AUTO) algo = (m->tri_ok && m->n_out == 23) ? PMC_INVERSE_TRIANGULAR : PMC_INVERSE_NAIVE;
         if (algo == PMC_INVERSE_TRIANGULAR || algo == PMC_INVERSE_TRIANGULAR_SOLO || algo == PMC_INVERSE_TRIANGULAR_DUO) {
             if (!m->tri_ok) return pmc_fail("pmc_maf_inverse: triangular sweep needs degree groups <= one tile");
+            if (m->n_out != 23) return pmc_fail("pmc_maf_inverse: the spline sweeps are built for 8 bins (PMC_INVERSE_NAIVE covers the others)");
             // two wavefronts per 16 rows (D <= 64), else / on request the lone-wave sweep
             if (algo != PMC_INVERSE_TRIANGULAR_SOLO) {
                 const int rc = pmc_launch_inverse_nsf2(m, z, x, ladj, n, (hipStream_t)stream);

@@ -50,7 +50,7 @@
 #define TRAIN_WAVES_NARROW 8
 #define TRAIN_PF_NARROW 8
 static int train_waves_of(const pmc_maf_t& m) {
-    return (m.n_out == RQS_NOUT && m.nT <= 6) ? TRAIN_WAVES_NARROW : TRAIN_WAVES;     // hidden width <= 64
+    return (m.n_out != 2 && m.nT <= 6) ? TRAIN_WAVES_NARROW : TRAIN_WAVES;     // spline flows of hidden width <= 64
 }
 
 struct TrainView {
@@ -111,16 +111,16 @@ __device__ __forceinline__ void hidden_pass_train(const pmc_maf_t& m, const MafV
     }
 }
 
-// out-layer panel of ranks [16c, 16c+16) of a spline flow: output tiles 23c .. 23c+22 -> P (local tile index).
-// keep != NULL: the panel (23 tiles of 256 floats, one float4 per lane and tile) is also written there for the
+// out-layer panel of ranks [16c, 16c+16) of a spline flow: output tiles NOUT c .. NOUT c + NOUT - 1 -> P (local tile index).
+// keep != NULL: the panel (NOUT tiles of 256 floats, one float4 per lane and tile) is also written there for the
 // backward sweep; from != NULL: it is read back from there instead of being multiplied out.
-template <int NW, int PF>
+template <int NW, int PF, int NOUT>
 __device__ __forceinline__ void rqs_panel_train(const pmc_maf_t& m, const MafView& w, const float* H2, float* P, int c,
                                                 int wv, int lane, float* keep = nullptr, const float* from = nullptr) {
     const int q = lane >> 4, p = lane & 15;
-    for (int i = wv; i < RQS_NOUT; i += NW) {
-        const int O = RQS_NOUT * c + i;
-        if (16 * O >= RQS_NOUT * m.D) continue;              // padding rows: never read
+    for (int i = wv; i < NOUT; i += NW) {
+        const int O = NOUT * c + i;
+        if (16 * O >= NOUT * m.D) continue;              // padding rows: never read
         f32x4 o;
         if (from) {
             const float4 v = reinterpret_cast<const float4*>(from)[i * 64 + lane];
@@ -134,7 +134,7 @@ __device__ __forceinline__ void rqs_panel_train(const pmc_maf_t& m, const MafVie
     }
 }
 
-// UNI 0: affine univariate (MAF), 2 outputs per feature.  UNI 1: 8-bin spline (NSF), 23 outputs.
+// UNI 0: affine univariate (MAF), 2 outputs per feature.  UNI = K > 0: K-bin spline (NSF; K = 4, 8, 16), 3 K - 1 outputs.
 // One workgroup per row set of 16 (rows 16 (set0 + blockIdx.x) ..., scratch block blockIdx.x).
 template <int NW, int PF, bool PROF, int UNI>
 __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf_train_t tr,
@@ -143,6 +143,8 @@ __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf
                                                                   const int64_t* __restrict__ idx, float wmul,
                                                                   int64_t n, int64_t set0, int ksplit,
                                                                   long long* __restrict__ prof) {
+    constexpr int NOUT = UNI ? RQS_NOUT_OF(UNI) : 2;
+    constexpr int KB = UNI ? UNI : 8;                           // bins of the spline instances
     long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tk = TICKT();
     const long long t_begin = tk;
@@ -151,8 +153,8 @@ __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: tile ownership branches stay scalar
     const int q = lane >> 4, p = lane & 15;
     const int D = m.D, Dp = m.Dp, Hp = m.Hp, T = m.T, nT = m.nT, nXT = m.nXT, nOT = m.nOT;
-    const int Psz = UNI ? RQS_NOUT * 256 : 2 * Dp * 16;       // spline flows: one 16-rank panel at a time
-    const int nOeff = UNI ? (RQS_NOUT * D + 15) / 16 : min(nOT, (D + 7) / 8);   // output tiles with real rows
+    const int Psz = UNI ? NOUT * 256 : 2 * Dp * 16;       // spline flows: one 16-rank panel at a time
+    const int nOeff = UNI ? (NOUT * D + 15) / 16 : min(nOT, (D + 7) / 8);   // output tiles with real rows
     float* A = smem;
     float* B = A + Hp * 16;
     float* Cb = B + Hp * 16;
@@ -273,16 +275,16 @@ __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf
                 if (nch > 1 && wv >= nOeff) lds_barrier();       // (the waves without a tile meet the owners' barrier)
             } else {
                 for (int c = 0; c < nXT; ++c) {
-                    rqs_panel_train<NW, PF>(m, wvw, Cb, P, c, wv, lane, part + (size_t)c * RQS_NOUT * 256);
+                    rqs_panel_train<NW, PF, NOUT>(m, wvw, Cb, P, c, wv, lane, part + (size_t)c * NOUT * 256);
                     lds_barrier();
                     for (int e = tid; e < 256; e += (64 * NW)) {
                         const int rr = e >> 4, pp = e & 15, rank = 16 * c + rr;
                         if (rank < D) {
-                            float phi[RQS_NOUT];
+                            float phi[NOUT];
 #pragma unroll
-                            for (int j = 0; j < RQS_NOUT; ++j) phi[j] = P[lidx(RQS_NOUT * rr + j, pp)];
+                            for (int j = 0; j < NOUT; ++j) phi[j] = P[lidx(NOUT * rr + j, pp)];
                             float y, l;
-                            rqs_forward(phi, Xc[lidx(rank, pp)], y, l);
+                            rqs_forward_t<KB>(phi, Xc[lidx(rank, pp)], y, l);
                             const int r2 = (t + 1 < T) ? nxt_rank[t * D + rank] : rank;
                             Xn[lidx(r2, pp)] = y;
                             xtn[lidx(r2, pp)] = y;
@@ -382,22 +384,22 @@ __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf
                 lds_barrier();
                 LAPT(4)
                 for (int c = 0; c < nXT; ++c) {
-                    const int O0 = RQS_NOUT * c;                         // first output tile of the panel
-                    const int nO = min(RQS_NOUT, nOeff - O0);            // its tiles with real rows
-                    float* pc = part + (size_t)c * RQS_NOUT * 256;
-                    rqs_panel_train<NW, PF>(m, wvw, Cb, P, c, wv, lane, nullptr, pc);
+                    const int O0 = NOUT * c;                         // first output tile of the panel
+                    const int nO = min(NOUT, nOeff - O0);            // its tiles with real rows
+                    float* pc = part + (size_t)c * NOUT * 256;
+                    rqs_panel_train<NW, PF, NOUT>(m, wvw, Cb, P, c, wv, lane, nullptr, pc);
                     PHASE_END(4)
                     // spline backward in place: P -> dP, G -> direct dL/dx term
                     for (int e = tid; e < 256; e += (64 * NW)) {
                         const int rr = e >> 4, pp = e & 15, rank = 16 * c + rr;
                         if (rank < D) {
-                            float phi[RQS_NOUT], dphi[RQS_NOUT];
+                            float phi[NOUT], dphi[NOUT];
 #pragma unroll
-                            for (int j = 0; j < RQS_NOUT; ++j) phi[j] = P[lidx(RQS_NOUT * rr + j, pp)];
+                            for (int j = 0; j < NOUT; ++j) phi[j] = P[lidx(NOUT * rr + j, pp)];
                             float gx;
-                            rqs_backward(phi, XB[lidx(rank, pp)], Gb[lidx(rank, pp)], -CC[pp], dphi, gx);
+                            rqs_backward_t<KB>(phi, XB[lidx(rank, pp)], Gb[lidx(rank, pp)], -CC[pp], dphi, gx);
 #pragma unroll
-                            for (int j = 0; j < RQS_NOUT; ++j) P[lidx(RQS_NOUT * rr + j, pp)] = dphi[j];
+                            for (int j = 0; j < NOUT; ++j) P[lidx(NOUT * rr + j, pp)] = dphi[j];
                             Gb[lidx(rank, pp)] = gx;
                         }
                     }
@@ -682,8 +684,8 @@ __global__ __launch_bounds__(256) void pack2_kernel(const float* __restrict__ fl
 // ---------------------------------------------------------------------------
 static size_t train_lds_bytes(const pmc_maf_t& m, bool ksplit) {
     const size_t part = ksplit ? (size_t)TRAIN_WAVES * 256 : 0;
-    if (m.n_out == RQS_NOUT)
-        return (size_t)(4 * m.Hp * 16 + RQS_NOUT * 256 + 2 * m.Dp * 16 + 16 + 16 * TRAIN_WAVES + part) * sizeof(float);
+    if (m.n_out != 2)
+        return (size_t)(4 * m.Hp * 16 + m.n_out * 256 + 2 * m.Dp * 16 + 16 + 16 * TRAIN_WAVES + part) * sizeof(float);
     return (size_t)(4 * m.Hp * 16 + 2 * m.Dp * 16 + m.Dp * 16 + 16 + 16 * TRAIN_WAVES + part) * sizeof(float);   // (sized for 16 waves)
 }
 
@@ -691,7 +693,7 @@ static int train_check(const pmc_maf_t* m, const pmc_maf_train_t* tr, const char
     if (!m || !tr || !tr->packedT || !tr->gmap || !tr->jobs || tr->n_jobs < 1 || tr->max_sets < 1 || !tr->xt_scratch ||
         !tr->act_scratch || !tr->delta_scratch || !tr->par_scratch || !tr->loss_partial || !tr->sq_partial ||
         tr->n_sq_partial < tr->n_jobs || !tr->tables || tr->table_waves != train_waves_of(*m) ||
-        tr->par_per_transform < (int64_t)(m->n_out == RQS_NOUT ? m->nXT * RQS_NOUT : m->nOT) * 256)
+        tr->par_per_transform < (int64_t)(m->n_out != 2 ? m->nXT * m->n_out : m->nOT) * 256)
         return pmc_fail((std::string(who) + ": incomplete training image").c_str());
     return 0;
 }
@@ -703,24 +705,6 @@ static int launch_lossgrad(const pmc_maf_t* m, const pmc_maf_train_t* tr, const 
     const bool ksplit = train_lds_bytes(*m, true) <= 64 * 1024;
     const size_t lds = train_lds_bytes(*m, ksplit);
     if (lds > 160 * 1024) return pmc_fail("pmc_maf_loss_grad: flow too wide for the 160 KB LDS of one workgroup");
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) {
-        hipError_t e = hipSuccess;
-        const void* ks[] = {reinterpret_cast<const void*>(maf_chain_kernel<TRAIN_WAVES, TRAIN_PF, false, 0>),
-                            reinterpret_cast<const void*>(maf_chain_kernel<TRAIN_WAVES, TRAIN_PF, false, 1>),
-                            reinterpret_cast<const void*>(maf_chain_kernel<TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, false, 1>),
-#ifdef PMC_DEBUG_HOOKS
-                            reinterpret_cast<const void*>(maf_chain_kernel<TRAIN_WAVES, TRAIN_PF, true, 0>),
-                            reinterpret_cast<const void*>(maf_chain_kernel<TRAIN_WAVES, TRAIN_PF, true, 1>),
-                            reinterpret_cast<const void*>(maf_chain_kernel<TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, true, 1>),
-#endif
-        };
-        for (size_t i = 0; i < sizeof(ks) / sizeof(ks[0]) && e == hipSuccess; ++i)
-            e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_chain_kernel)");
-        lds_set = lds;
-    }
-    const bool rqs = (m->n_out == RQS_NOUT);
     const bool narrow = train_waves_of(*m) == TRAIN_WAVES_NARROW;
     const int64_t nsets = (n + 15) / 16;
     // a batch of more row sets than the scratch arrays hold comes in chunks: chain + weight gradients per chunk, the
@@ -728,18 +712,28 @@ static int launch_lossgrad(const pmc_maf_t* m, const pmc_maf_train_t* tr, const 
     for (int64_t set0 = 0; set0 < nsets; set0 += tr->max_sets) {
         const int n_wg = (int)(nsets - set0 < tr->max_sets ? nsets - set0 : tr->max_sets);
 #define LG(NWV, PFV, PR, UN)                                                                                       \
-    hipLaunchKernelGGL((maf_chain_kernel<NWV, PFV, PR, UN>), dim3((unsigned)n_wg), dim3(64 * NWV), lds, st, *m, *tr, x, \
-                       w, idx, wmul, n, set0, ksplit ? 1 : 0, prof)
+    {                                                                                                              \
+        static size_t lds_set = 0;                                                                                 \
+        if (lds > 48 * 1024 && lds > lds_set) {                                                                    \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(maf_chain_kernel<NWV, PFV, PR, UN>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+            if (e != hipSuccess) return pmc_fail_hip(e, "hipFuncSetAttribute(maf_chain_kernel)");                  \
+            lds_set = lds;                                                                                         \
+        }                                                                                                          \
+        hipLaunchKernelGGL((maf_chain_kernel<NWV, PFV, PR, UN>), dim3((unsigned)n_wg), dim3(64 * NWV), lds, st, *m, *tr, \
+                           x, w, idx, wmul, n, set0, ksplit ? 1 : 0, prof);                                        \
+    }
+#define LGK(PR, K)                                                                                                 \
+    if (m->n_out == RQS_NOUT_OF(K)) {                                                                              \
+        if (narrow) LG(TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, PR, K) else LG(TRAIN_WAVES, TRAIN_PF, PR, K)           \
+    } else
 #ifdef PMC_DEBUG_HOOKS
         if (prof) {
-            if (narrow) LG(TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, true, 1);
-            else if (rqs) LG(TRAIN_WAVES, TRAIN_PF, true, 1);
-            else LG(TRAIN_WAVES, TRAIN_PF, true, 0);
+            LGK(true, 8) LGK(true, 4) LGK(true, 16) LG(TRAIN_WAVES, TRAIN_PF, true, 0)
         } else
 #endif
-        if (narrow) LG(TRAIN_WAVES_NARROW, TRAIN_PF_NARROW, false, 1);
-        else if (rqs) LG(TRAIN_WAVES, TRAIN_PF, false, 1);
-        else LG(TRAIN_WAVES, TRAIN_PF, false, 0);
+        { LGK(false, 8) LGK(false, 4) LGK(false, 16) LG(TRAIN_WAVES, TRAIN_PF, false, 0) }
+#undef LGK
 #undef LG
         hipLaunchKernelGGL(maf_dw_kernel, dim3((unsigned)tr->n_jobs), dim3(64 * DW_WAVES), 0, st, *m, *tr, n_wg,
                            set0 > 0 ? 1 : 0, grad, loss);

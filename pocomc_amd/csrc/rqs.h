@@ -16,6 +16,10 @@
 #define RQS_K 8
 #define RQS_NOUT 23
 #define RQS_BOUND 5.0f
+// Other bin counts (the reference accepts any zuko flow object, flow.py:87-88): the element code below is templated on the
+// number of bins K (3 K - 1 hyper-network outputs per feature); the forward / log_prob kernel, the D-pass inverse and the
+// training kernels are instantiated for K = 4, 8, 16, the triangular sweeps for the default K = 8 only.
+#define RQS_NOUT_OF(K) (3 * (K) - 1)
 
 struct RqsBin {                 // the selected bin and what the backward pass needs of the tables
     float x0, x1, y0, y1, d0, d1;
@@ -23,10 +27,12 @@ struct RqsBin {                 // the selected bin and what the backward pass n
     bool inside;
 };
 
-struct RqsTables {
-    float pw[RQS_K], ph[RQS_K];     // softmax probabilities (bin widths / heights over 2*bound)
-    float xk[RQS_K + 1], yk[RQS_K + 1];
+template <int K>
+struct RqsTablesT {
+    float pw[K], ph[K];             // softmax probabilities (bin widths / heights over 2*bound)
+    float xk[K + 1], yk[K + 1];
 };
+typedef RqsTablesT<8> RqsTables;
 
 // Hardware transcendentals (v_rcp_f32 / v_exp_f32 / v_log_f32, ~1 ulp): a lone wave per SIMD pays four
 // cycles per VALU instruction, and the IEEE-exact division / expf sequences of ~60 divisions and 18
@@ -38,44 +44,47 @@ __device__ __forceinline__ float rqs_log(float v) { return __builtin_amdgcn_logf
 __device__ __forceinline__ float rqs_clip2(float v) { return v * rqs_rcp(1.0f + fabsf(v * (2.0f * RQS_INV_LS))); }
 __device__ __forceinline__ float rqs_clip1(float v) { return v * rqs_rcp(1.0f + fabsf(v * RQS_INV_LS)); }
 
-__device__ __forceinline__ void rqs_softmax_knots(const float* v, float* p, float* knots) {
-    float c[RQS_K];
+template <int K>
+__device__ __forceinline__ void rqs_softmax_knots_t(const float* v, float* p, float* knots) {
+    float c[K];
     float mx = -3.0e38f;
 #pragma unroll
-    for (int j = 0; j < RQS_K; ++j) { c[j] = rqs_clip2(v[j]); mx = fmaxf(mx, c[j]); }
+    for (int j = 0; j < K; ++j) { c[j] = rqs_clip2(v[j]); mx = fmaxf(mx, c[j]); }
     float sum = 0.0f;
 #pragma unroll
-    for (int j = 0; j < RQS_K; ++j) { c[j] = rqs_exp(c[j] - mx); sum += c[j]; }
+    for (int j = 0; j < K; ++j) { c[j] = rqs_exp(c[j] - mx); sum += c[j]; }
     const float rsum = rqs_rcp(sum);
     float cum = 0.0f;
     knots[0] = -RQS_BOUND;
 #pragma unroll
-    for (int j = 0; j < RQS_K; ++j) {
+    for (int j = 0; j < K; ++j) {
         p[j] = c[j] * rsum;
         cum += p[j];
         knots[j + 1] = RQS_BOUND * (2.0f * cum - 1.0f);
     }
 }
 
-__device__ __forceinline__ void rqs_tables(const float* phi, RqsTables& t) {
-    rqs_softmax_knots(phi, t.pw, t.xk);
-    rqs_softmax_knots(phi + RQS_K, t.ph, t.yk);
+template <int K>
+__device__ __forceinline__ void rqs_tables_t(const float* phi, RqsTablesT<K>& t) {
+    rqs_softmax_knots_t<K>(phi, t.pw, t.xk);
+    rqs_softmax_knots_t<K>(phi + K, t.ph, t.yk);
 }
 
 // bin of `v` in `knots` (the x knots for the forward map, the y knots for the inverse)
-__device__ __forceinline__ void rqs_select(const RqsTables& t, const float* phi, const float* knots, float v,
-                                           RqsBin& b) {
-    b.inside = (v > knots[0]) && (v <= knots[RQS_K]);
+template <int K>
+__device__ __forceinline__ void rqs_select_t(const RqsTablesT<K>& t, const float* phi, const float* knots, float v,
+                                             RqsBin& b) {
+    b.inside = (v > knots[0]) && (v <= knots[K]);
     b.k = 0;
     b.x0 = t.xk[0]; b.x1 = t.xk[1]; b.y0 = t.yk[0]; b.y1 = t.yk[1];
-    float r0 = 0.0f, r1 = rqs_clip1(phi[2 * RQS_K]);          // raw (clipped) log-derivatives at the bin's knots
+    float r0 = 0.0f, r1 = rqs_clip1(phi[2 * K]);          // raw (clipped) log-derivatives at the bin's knots
 #pragma unroll
-    for (int j = 1; j < RQS_K; ++j) {
+    for (int j = 1; j < K; ++j) {
         if (knots[j] < v) {
             b.k = j;
             b.x0 = t.xk[j]; b.x1 = t.xk[j + 1]; b.y0 = t.yk[j]; b.y1 = t.yk[j + 1];
-            r0 = rqs_clip1(phi[2 * RQS_K + j - 1]);
-            r1 = (j + 1 < RQS_K) ? rqs_clip1(phi[2 * RQS_K + j]) : 0.0f;
+            r0 = rqs_clip1(phi[2 * K + j - 1]);
+            r1 = (j + 1 < K) ? rqs_clip1(phi[2 * K + j]) : 0.0f;
         }
     }
     b.d0 = rqs_exp(r0);
@@ -83,11 +92,12 @@ __device__ __forceinline__ void rqs_select(const RqsTables& t, const float* phi,
 }
 
 // y = f(x), ladj = log f'(x)
-__device__ __forceinline__ void rqs_forward(const float* phi, float x, float& y, float& ladj) {
-    RqsTables t;
-    rqs_tables(phi, t);
+template <int K>
+__device__ __forceinline__ void rqs_forward_t(const float* phi, float x, float& y, float& ladj) {
+    RqsTablesT<K> t;
+    rqs_tables_t<K>(phi, t);
     RqsBin b;
-    rqs_select(t, phi, t.xk, x, b);
+    rqs_select_t<K>(t, phi, t.xk, x, b);
     const float dx = b.x1 - b.x0, dy = b.y1 - b.y0;
     const float rdx = rqs_rcp(dx);
     const float s = dy * rdx;
@@ -101,11 +111,12 @@ __device__ __forceinline__ void rqs_forward(const float* phi, float x, float& y,
 }
 
 // x = f^-1(y), ladj = log f'(x)  (the forward log-derivative at the solution)
-__device__ __forceinline__ void rqs_inverse(const float* phi, float y, float& x, float& ladj) {
-    RqsTables t;
-    rqs_tables(phi, t);
+template <int K>
+__device__ __forceinline__ void rqs_inverse_t(const float* phi, float y, float& x, float& ladj) {
+    RqsTablesT<K> t;
+    rqs_tables_t<K>(phi, t);
     RqsBin b;
-    rqs_select(t, phi, t.yk, y, b);
+    rqs_select_t<K>(t, phi, t.yk, y, b);
     const float dx = b.x1 - b.x0, dy = b.y1 - b.y0;
     const float s = dy * rqs_rcp(dx);
     const float yr = b.inside ? y - b.y0 : 0.0f;
@@ -120,6 +131,11 @@ __device__ __forceinline__ void rqs_inverse(const float* phi, float y, float& x,
     x = b.inside ? b.x0 + z * dx : y;
     ladj = b.inside ? rqs_log(jac) : 0.0f;
 }
+
+// the reference's default, 8 bins (pocomc/flow.py:71): what the sweep kernels are built for
+__device__ __forceinline__ void rqs_softmax_knots(const float* v, float* p, float* knots) { rqs_softmax_knots_t<RQS_K>(v, p, knots); }
+__device__ __forceinline__ void rqs_forward(const float* phi, float x, float& y, float& ladj) { rqs_forward_t<RQS_K>(phi, x, y, ladj); }
+__device__ __forceinline__ void rqs_inverse(const float* phi, float y, float& x, float& ladj) { rqs_inverse_t<RQS_K>(phi, y, x, ladj); }
 
 // Inverse for the sweep kernel, where the four lanes q = 0..3 of a row would otherwise all repeat the same
 // work: lanes with even q build the x-knot table, odd q the y-knot table (the same code on different
@@ -287,14 +303,15 @@ __device__ __forceinline__ void rqs_inverse_split(const f32x4& o0, const f32x4& 
     ladj = rqs_ladj_3(r);
 }
 
-// Reverse mode of F = gy * y + gl * ladj:  dphi[23] and gx = dF/dx.
-__device__ __forceinline__ void rqs_backward(const float* phi, float x, float gy, float gl, float* dphi, float& gx) {
-    RqsTables t;
-    rqs_tables(phi, t);
+// Reverse mode of F = gy * y + gl * ladj:  dphi[3 K - 1] and gx = dF/dx.
+template <int K>
+__device__ __forceinline__ void rqs_backward_t(const float* phi, float x, float gy, float gl, float* dphi, float& gx) {
+    RqsTablesT<K> t;
+    rqs_tables_t<K>(phi, t);
     RqsBin b;
-    rqs_select(t, phi, t.xk, x, b);
+    rqs_select_t<K>(t, phi, t.xk, x, b);
 #pragma unroll
-    for (int j = 0; j < RQS_NOUT; ++j) dphi[j] = 0.0f;
+    for (int j = 0; j < (3 * K - 1); ++j) dphi[j] = 0.0f;
     gx = gy;
     if (!b.inside) return;
     const float dx = b.x1 - b.x0, dy = b.y1 - b.y0;
@@ -324,10 +341,10 @@ __device__ __forceinline__ void rqs_backward(const float* phi, float x, float gy
     const float g_y0 = gy - g_dy, g_y1 = g_dy;
     // knots -> softmax probabilities: knot_j = B (2 sum_{i<j} p_i - 1)
     //   dF/dp_i = 2B (g_k0 [i < k] + g_k1 [i < k+1])
-    float gpw[RQS_K], gph[RQS_K];
+    float gpw[K], gph[K];
     float dotw = 0.0f, doth = 0.0f;
 #pragma unroll
-    for (int i = 0; i < RQS_K; ++i) {
+    for (int i = 0; i < K; ++i) {
         const float lo = (i < b.k) ? 1.0f : 0.0f, hi = (i <= b.k) ? 1.0f : 0.0f;
         gpw[i] = 2.0f * RQS_BOUND * (g_x0 * lo + g_x1 * hi);
         gph[i] = 2.0f * RQS_BOUND * (g_y0 * lo + g_y1 * hi);
@@ -335,22 +352,26 @@ __device__ __forceinline__ void rqs_backward(const float* phi, float x, float gy
         doth += t.ph[i] * gph[i];
     }
 #pragma unroll
-    for (int i = 0; i < RQS_K; ++i) {
+    for (int i = 0; i < K; ++i) {
         // softmax backward, then the soft clip v / (1 + |2v/ls|) whose derivative is 1 / (1 + |2v/ls|)^2
         const float cw = rqs_rcp(1.0f + fabsf(phi[i] * (2.0f * RQS_INV_LS)));
-        const float ch = rqs_rcp(1.0f + fabsf(phi[RQS_K + i] * (2.0f * RQS_INV_LS)));
+        const float ch = rqs_rcp(1.0f + fabsf(phi[K + i] * (2.0f * RQS_INV_LS)));
         dphi[i] = t.pw[i] * (gpw[i] - dotw) * (cw * cw);
-        dphi[RQS_K + i] = t.ph[i] * (gph[i] - doth) * (ch * ch);
+        dphi[K + i] = t.ph[i] * (gph[i] - doth) * (ch * ch);
     }
-    // derivatives: d = exp(clip1(v)); knot k uses phi[16 + k - 1] (k >= 1), knot k+1 uses phi[16 + k] (k + 1 <= 7)
+    // derivatives: d = exp(clip1(v)); knot k uses phi[2 K + k - 1] (k >= 1), knot k+1 uses phi[2 K + k] (k + 1 <= K - 1)
 #pragma unroll
-    for (int j = 0; j < RQS_K - 1; ++j) {
-        const float c = rqs_rcp(1.0f + fabsf(phi[2 * RQS_K + j] * RQS_INV_LS));
+    for (int j = 0; j < K - 1; ++j) {
+        const float c = rqs_rcp(1.0f + fabsf(phi[2 * K + j] * RQS_INV_LS));
         float g = 0.0f;
         if (j == b.k - 1) g = g_d0 * b.d0;
         if (j == b.k) g = g_d1 * b.d1;
-        dphi[2 * RQS_K + j] = g * (c * c);
+        dphi[2 * K + j] = g * (c * c);
     }
+}
+
+__device__ __forceinline__ void rqs_backward(const float* phi, float x, float gy, float gl, float* dphi, float& gx) {
+    rqs_backward_t<RQS_K>(phi, x, gy, gl, dphi, gx);
 }
 
 #endif

@@ -82,8 +82,12 @@ class MAFSpec:
             raise NotImplementedError("hidden width must be >= n_dim - 1")
         if self.univariate not in ("affine", "rqs"):
             raise ValueError("univariate must be 'affine' or 'rqs'")
-        if self.univariate == "rqs" and self.bins != 8:
-            raise NotImplementedError("the spline kernels are built for 8 bins (pocomc/flow.py:71,77,83)")
+        self.bins = int(self.bins)
+        if self.univariate == "rqs" and self.bins not in (4, 8, 16):
+            # (the reference builds 8 bins, pocomc/flow.py:71,77,83, and accepts any zuko flow object, :87-88; the element
+            #  code is instantiated for these three counts -- csrc/rqs.h -- and only the default 8 has the triangular
+            #  inverse sweeps: the others invert with zuko's own D-pass algorithm)
+            raise NotImplementedError("spline flows are built for bins in (4, 8, 16)")
         # hyper-network outputs per feature: (shift, raw log-scale) or (K widths, K heights, K-1 derivatives)
         self.n_out = 2 if self.univariate == "affine" else 3 * int(self.bins) - 1
         NO = self.n_out
@@ -219,7 +223,7 @@ class MAFSpec:
         parts = [("f0", self.sz_f0), ("f1", self.sz_f12), ("f2", self.sz_f12),
                  ("f3", self.sz_f3), ("w0n", self.sz_w0n), ("b0", self.sz_b),
                  ("b1", self.sz_b), ("b2", self.sz_b), ("b3", self.sz_b3)]
-        if self.univariate == "rqs":
+        if self.univariate == "rqs" and self.bins == 8:
             # inverse sweep: the 23 output rows of every rank padded to two 16-row tiles of their own
             self.sz_f3i = D * 2 * nT * 256       # [rank][half][ktile][lane][4]
             self.sz_b3i = D * 32                 # [rank][32]
@@ -227,7 +231,7 @@ class MAFSpec:
             # the two-wave spline sweep (csrc/maf_inverse_nsf2.hip) shares the affine two-wave sweep's hidden part: the
             # layer-0 window columns (cw0), the masked layer-0 fragments (f0c), the transposed biases -- see below
             parts += [("cw0", nT * 256), ("f0c", self.sz_f0), ("b0t", Hp), ("b1t", Hp), ("b2t", Hp)]
-        else:
+        elif self.univariate == "affine":
             # chain image of the lane-per-walker inverse sweep (csrc/maf_inverse_tri6.hip): A operands of
             # v_mfma_f32_4x4x1_16b_f32 -- lane l holds W[out quad row l & 3][k slot l >> 2], one VGPR = a 4 x 16 block --
             # for the diagonal tile of the hidden layers (cw1, cw2: [tile][lane][out quad]), the layer-0 columns of the
@@ -330,7 +334,7 @@ class MAFSpec:
             put("f0", f0); put("f1", f12["W1"]); put("f2", f12["W2"]); put("f3", f3)
             put("w0n", w0n); put("b0", bidx("b0")); put("b1", bidx("b1")); put("b2", bidx("b2"))
             put("b3", b3)
-            if True:                                         # (cw1 / cw2 / cw3: the affine image only)
+            if self.univariate == "affine" or self.bins == 8:   # the sweeps' images (cw1 / cw2 / cw3: the affine one only)
                 affine = self.univariate == "affine"
                 ci, ck = lane & 3, lane >> 2                # 4x4x1 A operand: row within the out quad, k slot
                 tg = self.tile_groups()                      # per tile: degrees of its groups (in order)
@@ -368,7 +372,7 @@ class MAFSpec:
                 tr = (np.arange(Hp) & ~15) + 4 * (np.arange(Hp) & 3) + ((np.arange(Hp) >> 2) & 3)
                 for name in ("b0", "b1", "b2"):
                     put(name + "t", bidx(name)[tr])
-            if self.univariate == "rqs":
+            if self.univariate == "rqs" and self.bins == 8:
                 NO = self.n_out
                 f3i = np.full((D, 2, nT, 64, 4), -1, dtype=np.int64)
                 b3i = np.full((D, 32), -1, dtype=np.int64)
@@ -560,8 +564,8 @@ class MAFSpec:
 
     def par_per_transform(self) -> int:
         """Floats of the hyper-network's outputs kept per row set and transform (``pmc_maf_train_t.par_scratch``):
-        ``nOT`` tiles for the affine flows, ``nXT`` panels of 23 tiles for the spline flows."""
-        return 256 * (self.nXT * 23 if self.univariate == "rqs" else self.nOT)
+        ``nOT`` tiles for the affine flows, ``nXT`` panels of ``n_out`` (= 3 bins - 1) tiles for the spline flows."""
+        return 256 * (self.nXT * self.n_out if self.univariate == "rqs" else self.nOT)
 
     def train_tables(self, n_waves: int = 16) -> np.ndarray:
         """``int32`` tables of the chain kernel (``pmc_maf_train_t.tables``):

@@ -42,6 +42,23 @@ if kt:
     print(f"{'kernel':64s} {'grid':>9s} {'calls':>7s} {'avg_us':>10s}")
     for (n, g), v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
         print(f"{n:64s} {g:>9s} {len(v):7d} {sum(v) / len(v):10.2f}")
+if kt:
+    # the trainer's launches in launch order: the fit is the first GPU work of the bench process (50 epochs, ~50 ms), so
+    # its first launches run while the device's clocks ramp up from idle -- the mean of a kernel over the whole fit is not
+    # its steady duration; median and the means by fifth of the launch order say which is which
+    rows = sorted(csv.DictReader(open(kt)), key=lambda r: int(r["Start_Timestamp"]))
+    tr = defaultdict(list)
+    for r in rows:
+        n = short(r["Kernel_Name"])
+        if any(w in n for w in ("maf_chain", "maf_dw", "adamw_kernel")):
+            tr[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    if tr:
+        print("\n## trainer kernels in launch order (us): median, 10th / 90th percentile, mean of each fifth of the launches")
+        for n, v in tr.items():
+            v_ = sorted(v)
+            q = lambda f: v_[min(len(v_) - 1, int(f * len(v_)))]
+            fifths = [sum(v[i * len(v) // 5:(i + 1) * len(v) // 5]) / max(1, (i + 1) * len(v) // 5 - i * len(v) // 5) for i in range(5)]
+            print(f"{n:48s} n={len(v):5d} median {q(0.5):8.2f}  p10 {q(0.1):8.2f}  p90 {q(0.9):8.2f}  fifths " + " ".join(f"{f:8.2f}" for f in fifths))
 pmc = defaultdict(lambda: defaultdict(list))
 grids = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
@@ -52,7 +69,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         key = (short(r["Kernel_Name"]), r.get("Grid_Size", "?"))
         pmc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("\n## PMC counters, mean per launch (kernel, grid)")
-want = ("tri4", "tri5", "tri6", "tri_nsf", "scaler_inverse", "accept_kernel", "lossgrad", "forward_wg", "wide_phase", "forward_bf16")
+want = ("tri4", "tri5", "tri6", "tri_nsf", "scaler_inverse", "accept_kernel", "maf_chain", "maf_dw", "adamw", "forward_wg", "wide_phase", "forward_bf16")
 traffic = None
 for key in sorted(pmc, key=lambda k: -len(pmc[k].get("SQ_WAVE_CYCLES", []))):
     if not any(w in key[0] for w in want):

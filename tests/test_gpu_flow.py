@@ -219,9 +219,9 @@ NSF_SHAPES = [(2, 3), (4, 3), (10, 3), (17, 2), (32, 3), (40, 2), (50, 6)]     #
 NSF_FWD, NSF_INV, NSF_LADJ = 2e-5, 5e-5, 1e-4        # per walker, pure relative (the header says why not 1e-5)
 
 
-def make_nsf(D, T, seed=3, gain=1.0):
+def make_nsf(D, T, seed=3, gain=1.0, H=None, bins=8):
     from pocomc_amd import Flow
-    spec = MAFSpec(D, T, univariate="rqs")
+    spec = MAFSpec(D, T, H, univariate="rqs", bins=bins)
     flat = cases.flow_params(spec, seed, gain=gain)
     f = Flow(D, spec)
     f.set_params(flat)
@@ -241,6 +241,66 @@ def test_nsf_forward_logprob_matches_oracle(D, T, n):
     close_rel(ladj.numpy(), lo, NSF_LADJ, "nsf ladj", cancel=terms)
     base = 0.5 * (zo.astype(np.float64) ** 2).sum(axis=1) + 0.5 * D * np.log(2 * np.pi)
     close_rel(f.log_prob(torch.from_numpy(x)).numpy(), o.log_prob(x), NSF_LADJ, "nsf log_prob", cancel=terms + base)
+
+
+@pytest.mark.parametrize("bins", [4, 16])
+@pytest.mark.parametrize("D,T,H,n", [(4, 3, None, 37), (10, 3, 100, 200), (17, 2, None, 16)])
+def test_spline_flows_with_other_bin_counts_match_the_oracle(bins, D, T, H, n):
+    """What ``pocomc/flow.py:87-88`` accepts beyond its named flows, as far as a ``MAFSpec`` expresses it: spline flows of 4 and
+    16 bins (11 / 47 hyper-network outputs per feature).  Forward / log_prob, ``sample``'s direction (the inverse: zuko's
+    own D-pass algorithm on the device -- the triangular sweeps are built for the default 8 bins and say so) and the round
+    trip, against the oracle's arithmetic for that bin count."""
+    from pocomc_amd import _lib
+    f, o = make_nsf(D, T, H=H, bins=bins)
+    assert f.spec.n_out == 3 * bins - 1
+    x = (np.random.default_rng(n + bins).normal(size=(n, D)) * 2.5).astype(np.float32)
+    z, ladj = f.forward(torch.from_numpy(x))
+    zo, lo = o.forward(x)
+    terms = o.ladj_abs_terms(x)
+    close_rel(z.numpy(), zo, NSF_FWD, f"nsf z, {bins} bins")
+    close_rel(ladj.numpy(), lo, NSF_LADJ, f"nsf ladj, {bins} bins", cancel=terms)
+    base = 0.5 * (zo.astype(np.float64) ** 2).sum(axis=1) + 0.5 * D * np.log(2 * np.pi)
+    close_rel(f.log_prob(torch.from_numpy(x)).numpy(), o.log_prob(x), NSF_LADJ, f"nsf log_prob, {bins} bins", cancel=terms + base)
+    zz = (np.random.default_rng(7 + n).normal(size=(n, D)) * 1.5).astype(np.float32)
+    xo, lio = o.inverse(zz)
+    xi, li = f.inverse(torch.from_numpy(zz))                    # AUTO
+    close_rel(xi.numpy(), xo, NSF_INV, f"nsf x, {bins} bins")
+    close_rel(li.numpy(), lio, NSF_LADJ, f"nsf ladj inverse, {bins} bins", cancel=o.ladj_abs_terms(xo))
+    back, lb = f.forward(xi)
+    close_rel(back.numpy(), zz, 10 * NSF_INV, f"nsf round trip, {bins} bins")
+    f.inverse_algo = 1
+    with pytest.raises(_lib.PocomcAmdError, match="8 bins"):
+        f.inverse(torch.from_numpy(zz))
+    f.inverse_algo = 0
+    with pytest.raises(NotImplementedError):
+        MAFSpec(D, T, univariate="rqs", bins=5)
+
+
+@pytest.mark.parametrize("D,T,H,uni", [(10, 3, 100, "affine"), (7, 3, 48, "affine"), (10, 3, 100, "rqs"), (12, 2, 11, "affine"),
+                                       (33, 2, 200, "affine"), (9, 3, 72, "rqs")])
+def test_hidden_widths_that_are_not_powers_of_two(D, T, H, uni):
+    """``hidden_features`` of any width >= D - 1 (``flow.py:46-68`` takes a power of two; a zuko flow object need not):
+    forward, every inverse sweep AUTO can pick, and the round trip against the oracle."""
+    from pocomc_amd import Flow
+    spec = MAFSpec(D, T, H, univariate=uni)
+    flat = cases.flow_params(spec, 5)
+    f = Flow(D, spec)
+    f.set_params(flat)
+    o = OracleMAF(spec, flat)
+    tol_x, tol_l = (NSF_INV, NSF_LADJ) if uni == "rqs" else (TOL, TOL)
+    x = (np.random.default_rng(H).normal(size=(150, D)) * 1.5).astype(np.float32)
+    z, ladj = f.forward(torch.from_numpy(x))
+    zo, lo = o.forward(x)
+    close_rel(z.numpy(), zo, tol_x, f"z, H={H}")
+    close_rel(ladj.numpy(), lo, tol_l, f"ladj, H={H}", cancel=o.ladj_abs_terms(x))
+    xo, lio = o.inverse(x)
+    for algo in ([0, 1, 2] if spec.tri_ok else [0, 2]):
+        f.inverse_algo = algo
+        xi, li = f.inverse(torch.from_numpy(x))
+        close_rel(xi.numpy(), xo, tol_x, f"x, H={H}, algorithm {algo}")
+        close_rel(li.numpy(), lio, tol_l, f"ladj inverse, H={H}, algorithm {algo}", cancel=o.ladj_abs_terms(xo))
+    with pytest.raises(NotImplementedError):
+        MAFSpec(D, T, D - 2)
 
 
 @pytest.mark.parametrize("D,T", NSF_SHAPES)

@@ -11,21 +11,21 @@ from pocomc_amd.maf_spec import MAFSpec
 pytestmark = pytest.mark.gpu
 
 
-def make(D, T, seed=1):
+def make(D, T, seed=1, H=None):
     from pocomc_amd import Flow
-    spec = MAFSpec(D, T)
+    spec = MAFSpec(D, T, H)
     flat = cases.flow_params(spec, seed)
     f = Flow(D, spec)
     f.set_params(flat)
     return f, spec, flat
 
 
-@pytest.mark.parametrize("D,T", [(2, 3), (4, 3), (10, 3), (32, 3), (7, 6)])
+@pytest.mark.parametrize("D,T,H", [(2, 3, None), (4, 3, None), (10, 3, None), (32, 3, None), (7, 6, None), (10, 3, 100), (12, 2, 11)])
 @pytest.mark.parametrize("n", [5, 16, 100])
 @pytest.mark.parametrize("weighted", [False, True])
-def test_loss_and_gradient_match_autograd(D, T, n, weighted):
+def test_loss_and_gradient_match_autograd(D, T, H, n, weighted):
     from pocomc_amd.train import loss_and_grad, _train_state
-    f, spec, flat = make(D, T)
+    f, spec, flat = make(D, T, H=H)
     rng = np.random.default_rng(n + D)
     x = (rng.normal(size=(n, D)) * 1.3).astype(np.float32)
     w = rng.uniform(0.1, 1.0, size=n).astype(np.float32) if weighted else None
@@ -210,15 +210,17 @@ def test_epoch_call_equals_batch_by_batch(weighted):
 
 
 # ----------------------------------------------------------------- neural spline flows
-@pytest.mark.parametrize("D,T,H", [(2, 3, None), (4, 3, None), (10, 3, None), (17, 2, None), (32, 3, None), (50, 6, None)])
+@pytest.mark.parametrize("D,T,H,bins", [(2, 3, None, 8), (4, 3, None, 8), (10, 3, None, 8), (17, 2, None, 8), (32, 3, None, 8),
+                                        (50, 6, None, 8), (4, 3, None, 4), (10, 3, 100, 4), (20, 2, None, 4), (4, 3, None, 16),
+                                        (10, 2, 100, 16), (20, 2, None, 16), (10, 3, 100, 8)])
 @pytest.mark.parametrize("n,weighted", [(5, False), (40, True)])
-def test_nsf_loss_and_gradient_match_autograd(D, T, H, n, weighted):
+def test_nsf_loss_and_gradient_match_autograd(D, T, H, bins, n, weighted):
     """Spline flows: hyper-network gradients through the rational-quadratic spline (knots via
     softmax + cumsum, bin selection, end-knot derivatives) against torch autograd on the oracle
     twin; data spread beyond the spline box so that the identity tails are exercised too."""
     from pocomc_amd import Flow
     from pocomc_amd.train import loss_and_grad, _train_state
-    spec = MAFSpec(D, T, H, univariate="rqs")
+    spec = MAFSpec(D, T, H, univariate="rqs", bins=bins)          # (bins 4 / 16, odd hidden widths: flow.py:87-88)
     flat = cases.flow_params(spec, 4, gain=1.0)
     f = Flow(D, spec)
     f.set_params(flat)
