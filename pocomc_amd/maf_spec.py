@@ -668,7 +668,12 @@ class MAFSpec:
 
     def train_index(self):
         """``(packT_idx, gmap)``: gather map for ``packedT`` (like ``pack_index``) and the
-        gradient scatter map, both int32, all transforms concatenated."""
+        gradient scatter map, both int32, all transforms concatenated.  (Built once per spec: ``train_jobs`` reads it too.)"""
+        if getattr(self, "_train_index", None) is None:
+            self._train_index = self._build_train_index()
+        return self._train_index
+
+    def _build_train_index(self):
         D, H, Hp = self.n_dim, self.hidden, self.Hp
         nT, nXT, nOT = self.nT, self.nXT, self.nOT
         L = self.train_layout()
@@ -703,20 +708,19 @@ class MAFSpec:
             f1T = np.full((nT, nT, 64, 4), -1, dtype=np.int64)
             f2T = np.full((nT, nT, 64, 4), -1, dtype=np.int64)
             f3T = np.full((nT, nOT, 64, 4), -1, dtype=np.int64)
+            # (the inner tile index is broadcast: one numpy call per (tile, component) instead of one per tile pair)
+            in_all = su[16 * np.arange(nT)[:, None] + li[None, :]]                 # [Ti][lane]: hidden unit of the in slot
+            x_all = feat(16 * np.arange(nXT)[:, None] + li[None, :])               # [Xi][lane]: feature of the in rank
             for To in range(nT):
                 for c in range(4):
-                    out_u = su[16 * To + 4 * c + lk]
-                    for Xi in range(nXT):
-                        f0T[Xi, To, :, c] = cidx("W0", out_u, feat(16 * Xi + li), D, M0)
-                    for Ti in range(nT):
-                        in_u = su[16 * Ti + li]
-                        f1T[Ti, To, :, c] = cidx("W1", out_u, in_u, H, M1)
-                        f2T[Ti, To, :, c] = cidx("W2", out_u, in_u, H, M2)
+                    out_u = su[16 * To + 4 * c + lk][None, :]
+                    f0T[:, To, :, c] = cidx("W0", np.broadcast_to(out_u, x_all.shape), x_all, D, M0)
+                    f1T[:, To, :, c] = cidx("W1", np.broadcast_to(out_u, in_all.shape), in_all, H, M1)
+                    f2T[:, To, :, c] = cidx("W2", np.broadcast_to(out_u, in_all.shape), in_all, H, M2)
             for O in range(nOT):
                 for c in range(4):
-                    crow = orow(16 * O + 4 * c + lk)
-                    for Ki in range(nT):
-                        f3T[Ki, O, :, c] = cidx("W3", crow, su[16 * Ki + li], H, M3)
+                    crow = orow(16 * O + 4 * c + lk)[None, :]
+                    f3T[:, O, :, c] = cidx("W3", np.broadcast_to(crow, in_all.shape), in_all, H, M3)
             # ---- gradient scatter: lane (q = lane>>4, j = lane&15), reg r
             g0 = np.full((nT, nXT, 64, 4), -1, dtype=np.int64)
             g1 = np.full((nT, nT, 64, 4), -1, dtype=np.int64)
@@ -724,18 +728,14 @@ class MAFSpec:
             g3 = np.full((nOT, nT, 64, 4), -1, dtype=np.int64)
             for To in range(nT):
                 for r in range(4):
-                    out_u = su[16 * To + 4 * lk + r]
-                    for Xi in range(nXT):
-                        g0[To, Xi, :, r] = cidx("W0", out_u, feat(16 * Xi + li), D, M0)
-                    for Ti in range(nT):
-                        in_u = su[16 * Ti + li]
-                        g1[To, Ti, :, r] = cidx("W1", out_u, in_u, H, M1)
-                        g2[To, Ti, :, r] = cidx("W2", out_u, in_u, H, M2)
+                    out_u = su[16 * To + 4 * lk + r][None, :]
+                    g0[To, :, :, r] = cidx("W0", np.broadcast_to(out_u, x_all.shape), x_all, D, M0)
+                    g1[To, :, :, r] = cidx("W1", np.broadcast_to(out_u, in_all.shape), in_all, H, M1)
+                    g2[To, :, :, r] = cidx("W2", np.broadcast_to(out_u, in_all.shape), in_all, H, M2)
             for O in range(nOT):
                 for r in range(4):
-                    crow = orow(16 * O + 4 * lk + r)
-                    for Ki in range(nT):
-                        g3[O, Ki, :, r] = cidx("W3", crow, su[16 * Ki + li], H, M3)
+                    crow = orow(16 * O + 4 * lk + r)[None, :]
+                    g3[O, :, :, r] = cidx("W3", np.broadcast_to(crow, in_all.shape), in_all, H, M3)
 
             def bidx(name):
                 off, _ = self.offsets[name]

@@ -155,7 +155,12 @@ class Sampler:
                           ``dict(lanes=2)``.
 
         Supported ``train_config`` keys: those of ``sampler.py:287-299`` (``validation_split, epochs, batch_size,
-        patience, learning_rate, annealing, gaussian_scale, laplace_scale, noise, shuffle, clip_grad_norm, verbose``).
+        patience, learning_rate, annealing, gaussian_scale, laplace_scale, noise, shuffle, clip_grad_norm, verbose``),
+        plus ``fit_parallel`` for a sharded Sampler: ``"data"`` (every rank fits on a share of the rows, gradients all-reduced
+        before the clip: RCCL), ``"replicated"`` (every rank runs the whole fit on the replicated pool: the same bits on
+        every rank, no communication) or ``"auto"`` (default: data parallel from 256 local rows per batch on -- a training
+        step is a latency chain that takes the same time for 64 rows as for 512, DESIGN.md section 6, so below that the
+        all-reduce is pure overhead).
         """
         if n_ess is not None:
             import warnings
@@ -212,7 +217,8 @@ class Sampler:
             self.flow.repack()
         self.train_config = dict(validation_split=0.5, epochs=5000, batch_size=np.minimum(self.n_effective // 2, 512),
                                  patience=D, learning_rate=1e-3, annealing=False, gaussian_scale=None,
-                                 laplace_scale=None, noise=None, shuffle=True, clip_grad_norm=1.0, verbose=0)   # :287-299
+                                 laplace_scale=None, noise=None, shuffle=True, clip_grad_norm=1.0, verbose=0,   # :287-299
+                                 fit_parallel="auto")
         self.train_config.update(train_config or {})
         self.train_frequency = (np.maximum(self.n_effective // (self.n_active * 2), 1) if train_frequency is None
                                 else int(train_frequency))                                                       # :305
@@ -377,7 +383,12 @@ class Sampler:
             self.flow_untrained = False
             c = self.train_config
             u32, w32 = u.to(torch.float32), w.to(torch.float32)
-            if self.world > 1:
+            bs = int(np.minimum(len(u32) // 2, c["batch_size"]))
+            how = c.get("fit_parallel", "auto")
+            if how not in ("auto", "data", "replicated"):
+                raise ValueError("train_config['fit_parallel'] must be 'auto', 'data' or 'replicated'")
+            data_parallel = self.world > 1 and (how == "data" or (how == "auto" and bs // self.world >= 256))
+            if data_parallel:
                 # data parallel: every rank fits on a strided share of the rows (equal shares; the remainder rows are
                 # dropped), gradients and losses are all-reduced inside fit
                 m = len(u32) // self.world
@@ -385,11 +396,11 @@ class Sampler:
             else:
                 ut, wt = u32, w32
             self.flow.fit(ut, weights=wt, validation_split=c["validation_split"], epochs=c["epochs"],
-                          batch_size=int(np.minimum(len(u32) // 2, c["batch_size"])), gaussian_scale=c["gaussian_scale"],
+                          batch_size=bs, gaussian_scale=c["gaussian_scale"],
                           laplace_scale=c["laplace_scale"], patience=c["patience"], learning_rate=c["learning_rate"],
                           annealing=c["annealing"], noise=c["noise"], shuffle=c["shuffle"],
                           clip_grad_norm=c["clip_grad_norm"], verbose=c["verbose"], group=self.group,
-                          sharded=self.world > 1)
+                          sharded=data_parallel)
             theta = self.flow.forward(u32)[0]              # float32 on the device (tools.py:336-340)
             self.theta_geometry.fit(theta, weights=w)
         else:

@@ -29,7 +29,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, fit_parallel="auto"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -43,7 +43,7 @@ def _worker(rank, world, port, out):
 
     prior = pc.Prior([norm(0.0, 5.0)] * D)
     s = pc.Sampler(prior=prior, likelihood=counted, vectorize=True, flow="maf3", n_active=256, n_effective=512,
-                   random_state=4)
+                   random_state=4, train_config=dict(fit_parallel=fit_parallel))
     assert s.world == world and s.rank == rank
     s.run(n_total=1024, n_evidence=1024, progress=False)
     logz, err = s.evidence()
@@ -54,10 +54,14 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_sampler(tmp_path):
+@pytest.mark.parametrize("fit_parallel", ["auto", "data"])
+def test_two_rank_sampler(tmp_path, fit_parallel):
+    """``fit_parallel="data"``: the flow fits are data parallel (gradients all-reduced before the clip); ``"auto"`` at this
+    size (128 local rows per batch) lets every rank run the whole fit on the replicated pool -- either way both ranks hold
+    the same flow bit for bit."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "rank%d.npz")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, fit_parallel), nprocs=2, join=True)
     r0, r1 = np.load(out % 0), np.load(out % 1)
     # replicated bookkeeping: identical temperature ladder, pool, evidence and flow on both ranks
     assert np.array_equal(r0["beta"], r1["beta"])
