@@ -1,5 +1,8 @@
 """Cycles of the chain wave of workgroup 0 of the two-wave spline sweep, by section of a degree group, summed over the
 sweep (pmc_debug_nsf2_profile; measurement only).   python scripts/profile_nsf2.py [D] [flow] [n]"""
+import os as _os
+# the in-kernel profile entry points exist only in the measurement build: make -C pocomc_amd/csrc DEBUG_HOOKS=1
+_os.environ.setdefault("PMC_LIBRARY", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "pocomc_amd", "libpocomc_amd_debug.so"))
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

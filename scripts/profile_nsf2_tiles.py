@@ -1,6 +1,9 @@
 """When the two wavefronts of workgroup 0 of the two-wave spline sweep reach and leave every barrier (a library built with
 -DNSF2_TILE_STAMPS: scripts/abl_nsf.sh stamps; measurement only).
     PMC_LIBRARY=scripts/abl/lib_nsf_stamps.so python scripts/profile_nsf2_tiles.py [D] [flow] [n]"""
+import os as _os
+# the in-kernel profile entry points exist only in the measurement build: make -C pocomc_amd/csrc DEBUG_HOOKS=1
+_os.environ.setdefault("PMC_LIBRARY", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "pocomc_amd", "libpocomc_amd_debug.so"))
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

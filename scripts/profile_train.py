@@ -1,4 +1,7 @@
 """In-kernel phase profile of the loss/gradient kernel (debug entry point, not part of the ABI)."""
+import os as _os
+# the in-kernel profile entry points exist only in the measurement build: make -C pocomc_amd/csrc DEBUG_HOOKS=1
+_os.environ.setdefault("PMC_LIBRARY", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "pocomc_amd", "libpocomc_amd_debug.so"))
 import ctypes as C
 import os
 import sys

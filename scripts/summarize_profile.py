@@ -54,6 +54,10 @@ if kt:
             tr[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     if tr:
         print("\n## trainer kernels in launch order (us): median, 10th / 90th percentile, mean of each fifth of the launches")
+        print("# (bench.py fits TWO flows with the float32 trainer: the step benchmark's own -- maf3 at D = 32 by default, 50 epochs,")
+        print("#  the first ~90 % of the launches -- and, unless --no-flow-bench, the config-5 flow of its flow_config5 sub-metric")
+        print("#  (D = 128, 8 transforms, H = 512: the same kernel template and grid, ~6 x the time): the kernel-trace MEAN above mixes")
+        print("#  the two; the median is the step benchmark's flow)")
         for n, v in tr.items():
             v_ = sorted(v)
             q = lambda f: v_[min(len(v_) - 1, int(f * len(v_)))]

@@ -144,11 +144,17 @@ def test_wide_flows_fit_in_lds(D, T, H, n):
     np.testing.assert_allclose(g, g_ref, rtol=1e-3, atol=5e-5 * scale)
 
 
-def test_large_batch_loops_over_row_sets():
-    """More rows than gradient slabs (64 workgroups x 16 rows): a workgroup accumulates several row
-    sets into its own slab; indexed and contiguous batches agree bit for bit."""
+@pytest.mark.parametrize("cap", [None, 40])
+def test_large_batch_loops_over_row_sets(cap):
+    """A batch of many row sets; ``cap = 40``: more row sets (131) than the scratch arrays hold, so the batch comes in four
+    chunks -- chain kernel + weight-gradient kernel per chunk, the later chunks adding to the gradient in place.  Indexed and
+    contiguous batches agree bit for bit either way."""
     from pocomc_amd.train import loss_and_grad, _train_state
     f, spec, flat = make(10, 3)
+    if cap is not None:
+        ts = _train_state(f)
+        ts.set_cap = cap
+        assert ts.n_slabs == 0
     n = 64 * 16 * 2 + 37
     rng = np.random.default_rng(5)
     x = (rng.normal(size=(n, 10)) * 1.2).astype(np.float32)
@@ -170,6 +176,7 @@ def test_large_batch_loops_over_row_sets():
     loss2 = float(loss_and_grad(f, xd[perm.cuda()].contiguous(), wd[perm.cuda()].contiguous(), idx=inv.cuda()))
     assert loss2 == loss
     assert np.array_equal(f._train.grad.cpu().numpy(), g)
+    assert f._train.desc.max_sets == (cap or (n + 15) // 16)
 
 
 @pytest.mark.parametrize("weighted", [False, True])
