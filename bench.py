@@ -976,7 +976,7 @@ def main():
                                           "peak_tflops": PEAK_F32_MFMA_TFLOPS, "frac": tf_inv / PEAK_F32_MFMA_TFLOPS}
                     flow_cfg5["inverse_f32"] = inv
                 # Flow.fit's optimizer step at the reference's batch size (sampler.py:289: 512 rows): loss + gradient,
-                # clip, AdamW, image refresh -- the float32 slab kernels against the bf16 per-layer products
+                # clip, AdamW, image refresh -- the float32 chain + weight-gradient kernels against the bf16 per-layer products
                 from pocomc_amd.train import AdamW
                 opt5 = AdamW(f5, 1e-3)
                 acc5 = torch.zeros(1, dtype=torch.float32, device="cuda")

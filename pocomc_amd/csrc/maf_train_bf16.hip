@@ -1,9 +1,10 @@
 // Flow.fit's loss + parameter gradient (pocomc/flow.py:297-323) for the WIDE affine flows on the bf16 matrix cores
 // (BASELINE config 5: D = 128, 8 transforms, H = 512 -- "MFMA-bound flow training").
 //
-// Why not the structure of maf_train.hip (a workgroup per 16 rows, gradient slabs): a batch is <= 512 rows
-// (sampler.py:289), i.e. 32 workgroups on 256 CUs, each of which streams the whole 23 MB of fp32 weights and writes a
-// 23 MB gradient slab: 1.66 ms per batch at config 5 (scripts/time_fit.py).  Here a layer is what it is, a dense product
+// Why not the structure of maf_train.hip (a workgroup per 16 rows for the whole chain): a batch is <= 512 rows
+// (sampler.py:289), i.e. 32 workgroups on 256 CUs, each of which streams the whole 23 MB of fp32 weights through one
+// compute unit: 1.04 ms per batch at config 5 (scripts/time_fit.py; 1.65 ms before maf_train.hip's weight gradients moved to
+// their own kernel in round 6).  Here a layer is what it is, a dense product
 //     Y[out][row] = W[out][in] . H[in][row]          (forward and data gradients:  A = weights, B = activations)
 //     dW[out][in] = dA[out][row] . H[in][row]        (weight gradients:  both operands are activations, k = row)
 // on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  Both MFMA operands want their k index contiguous (8 bf16 = one

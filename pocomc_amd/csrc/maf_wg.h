@@ -6,7 +6,7 @@
 
 #include "maf_common.h"
 
-// Workgroup barrier that orders LDS traffic only: global stores (gradient slabs) and prefetched
+// Workgroup barrier that orders LDS traffic only: global stores (activation / delta scratch) and prefetched
 // weight loads stay in flight across it (a __syncthreads() would drain vmcnt to zero).
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -38,7 +38,7 @@ class TrainState:
         self.wsum = torch.zeros(1, dtype=torch.float32, device=dev)
         self.scal = torch.zeros(4, dtype=torch.float32, device=dev)      # [loss, spare...]
         self.light = bool(light)
-        self.n_slabs = 0
+        self.n_sets = 0
         if light:
             self.sq_partial = torch.zeros(256, dtype=torch.float32, device=dev)       # PMC_ADAMW_SCRATCH
             self.desc = None
@@ -72,7 +72,7 @@ class TrainState:
     def ensure_sets(self, n_rows):
         """Scratch for the row sets of one launch: transform inputs, activations, deltas, output gradients."""
         need = max(1, min(self.set_cap, (int(n_rows) + 15) // 16))
-        if need <= self.n_slabs:
+        if need <= self.n_sets:
             return
         dev = self.grad.device
         self.xt_scratch = torch.empty(need * self.xt_floats, dtype=torch.float32, device=dev)
@@ -80,15 +80,13 @@ class TrainState:
         self.delta_scratch = torch.empty(need * self.act_floats, dtype=torch.float32, device=dev)
         self.par_scratch = torch.empty(need * self.par_floats, dtype=torch.float32, device=dev)
         self.loss_partial = torch.zeros(need, dtype=torch.float32, device=dev)
-        self.n_slabs = need
+        self.n_sets = need
         self.desc.xt_scratch = self.xt_scratch.data_ptr()
         self.desc.act_scratch = self.act_scratch.data_ptr()
         self.desc.delta_scratch = self.delta_scratch.data_ptr()
         self.desc.par_scratch = self.par_scratch.data_ptr()
         self.desc.loss_partial = self.loss_partial.data_ptr()
         self.desc.max_sets = need
-
-    ensure_slabs = ensure_sets          # (the name older scripts call)
 
     def scatter_maps(self, flow):
         """CSR inverse of the two pack maps (``pmc_adamw_t.scatter_*``): where every parameter sits in the forward /

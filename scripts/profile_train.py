@@ -22,7 +22,7 @@ fn = lib.pmc_debug_lossgrad_profile
 fn.restype = C.c_int
 fn.argtypes = [C.POINTER(_lib.pmc_maf_t), C.POINTER(_lib.pmc_maf_train_t)] + [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p]
 x = torch.randn(n, D, device="cuda")
-nb = min(ts.n_slabs, (n + 15) // 16)
+nb = min(ts.n_sets, (n + 15) // 16)
 NW = lib.pmc_maf_train_waves(C.byref(f._desc))
 prof = torch.zeros(nb, NW, 16, dtype=torch.int64, device="cuda")
 for _ in range(3):

@@ -154,7 +154,7 @@ def test_large_batch_loops_over_row_sets(cap):
     if cap is not None:
         ts = _train_state(f)
         ts.set_cap = cap
-        assert ts.n_slabs == 0
+        assert ts.n_sets == 0
     n = 64 * 16 * 2 + 37
     rng = np.random.default_rng(5)
     x = (rng.normal(size=(n, 10)) * 1.2).astype(np.float32)
