@@ -230,6 +230,12 @@ def load():
         fn.argtypes = args
     if lib.pmc_abi_version() != 8:
         raise PocomcAmdError("libpocomc_amd.so: ABI version mismatch")
+    # timing-only ablation builds (scripts/abl_*.sh: TRI5_ABL / TRI6_ABL / NSF2_ABL != 0) compute WRONG results by design and
+    # carry a marker symbol: never loaded by accident
+    for marker in ("pmc_ablation_tri5", "pmc_ablation_tri6", "pmc_ablation_nsf2"):
+        if hasattr(lib, marker) and not os.environ.get("PMC_ALLOW_ABLATION"):
+            raise PocomcAmdError(f"{LIB_PATH} is a timing-only ablation build ({marker}): its results are wrong by design; "
+                                 "set PMC_ALLOW_ABLATION=1 to time it")
     built, tree = lib.pmc_build_id().decode(), source_build_id()
     if tree is not None and built.split("+")[0] != tree:
         raise PocomcAmdError(f"{LIB_PATH} was built from other sources than the ones next to it (library id {built}, "

@@ -25,6 +25,9 @@
 
 #ifndef NSF2_ABL
 #define NSF2_ABL 0                 // timing experiments only (scripts/abl_nsf.sh): results are wrong when != 0
+#endif
+#if NSF2_ABL != 0
+extern "C" int pmc_ablation_nsf2(void) { return NSF2_ABL; }      // (see pmc_ablation_tri6)
 #endif                             // 1 no spline solve, 2 no output MFMAs on the chain, 4 burst: no output partials, 8 nor their loads, 16 chain: no output fragment requests, 32 burst: no hidden products, 64 no eager partials (results stay right)
 #define NSF2_PK 10                 // K tiles of the hidden bursts held in registers; the static burst tile covers flows of <= NSF2_PK + 1 live tiles
 #define NSF2_PX 4                  // x tiles of the layer-0 product held in registers (D <= 64)

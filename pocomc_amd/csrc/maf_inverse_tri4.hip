@@ -514,6 +514,9 @@ int pmc_launch_propose_inverse_tri4(int kind, const float* cur32, const double* 
 #ifndef TRI5_ABL
 #define TRI5_ABL 0                 // timing experiments only (scripts/abl_tri5.sh): results are wrong when != 0
 #endif
+#if TRI5_ABL != 0
+extern "C" int pmc_ablation_tri5(void) { return TRI5_ABL; }      // (see pmc_ablation_tri6)
+#endif
 #define PXB 4                      // x tiles of the layer-0 product held in registers (D <= 64)
 #define TRI5_STAGE_FLOATS(MO) ((3 + (MO)) * 256)                 // one staging buffer: S0 | S1 | S2 (transposed, [lane][4]) | SO[MO] (natural)
 #define TRI5_SET_FLOATS(Dp, Hp, MO) (2 * (Dp) * 16 + 2 * (Hp) * 16 + 2 * 256 + 2 * TRI5_STAGE_FLOATS(MO))

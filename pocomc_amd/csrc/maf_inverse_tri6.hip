@@ -47,6 +47,10 @@ typedef unsigned int u32x2_t6 __attribute__((ext_vector_type(2)));
 #ifndef TRI6_ABL
 #define TRI6_ABL 0                 // timing experiments only (scripts/abl_tri6.sh): results are wrong when != 0
 #endif
+#if TRI6_ABL != 0
+// marks a library built with an ablation: pocomc_amd/_lib.py refuses it unless PMC_ALLOW_ABLATION is set
+extern "C" int pmc_ablation_tri6(void) { return TRI6_ABL; }
+#endif
 
 namespace tri6 {
 

@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p scripts/abl
-objs=$(ls pocomc_amd/csrc/*.o | grep -v maf_inverse_nsf2.o)
+objs=$(ls pocomc_amd/csrc/obj/*.o | grep -v maf_inverse_nsf2.o)
 for bits in "$@"; do
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-value $( [ "$bits" = stamps ] && echo -DNSF2_TILE_STAMPS=1 || echo -DNSF2_ABL=$bits ) \
       -c pocomc_amd/csrc/maf_inverse_nsf2.hip -o scripts/abl/nsf_$bits.o 2> scripts/abl/build_nsf_$bits.log && \

@@ -22,5 +22,6 @@ for lib in libs:
     env = dict(os.environ)
     if lib:
         env["PMC_LIBRARY"] = lib
+        env["PMC_ALLOW_ABLATION"] = "1"                      # (timing-only builds: pocomc_amd._lib refuses them otherwise)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     print(f"{os.path.basename(lib) if lib else 'product':24s} {out.stdout.strip() or out.stderr.strip()[-200:]} us")

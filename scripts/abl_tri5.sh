@@ -7,7 +7,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p scripts/abl
-objs=$(ls pocomc_amd/csrc/*.o | grep -v maf_inverse_tri4.o)
+objs=$(ls pocomc_amd/csrc/obj/*.o | grep -v maf_inverse_tri4.o)
 for bits in "$@"; do
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-value -DTRI5_ABL=$bits \
       -c pocomc_amd/csrc/maf_inverse_tri4.hip -o scripts/abl/tri4_$bits.o 2> scripts/abl/build_$bits.log && \
