@@ -216,6 +216,13 @@ typedef struct pmc_adamw {
 int pmc_maf_train_epoch(const pmc_maf_t* m, const pmc_maf_train_t* tr, pmc_adamw_t* opt, const float* x,
                         const float* w, const int64_t* perm, int64_t n, int64_t batch_size, float* loss,
                         void* stream);
+/* The same with a gate: the epoch's first optimizer step waits for gate_event (a hipEvent_t, or NULL) -- its loss / gradient
+ * launches, which only read the parameters, do not.  Lets the validation pass of the previous epoch (flow.py:327-348), which
+ * reads the kernel images that step rewrites, run on another stream next to this epoch's first batch: a batch's chain kernel
+ * occupies 32 of the 256 compute units. */
+int pmc_maf_train_epoch_gated(const pmc_maf_t* m, const pmc_maf_train_t* tr, pmc_adamw_t* opt, const float* x,
+                              const float* w, const int64_t* perm, int64_t n, int64_t batch_size, float* loss,
+                              void* gate_event, void* stream);
 
 /* Options of Flow.fit.
  * Weight regularisation, flow.py:314-315 with regularization_loss :387-421 as its docstring defines it (the function

@@ -123,6 +123,8 @@ SIGNATURES = {
     "pmc_maf_loss_grad": (C.c_int, [P(pmc_maf_t), P(pmc_maf_train_t), c_p, c_p, c_p, C.c_float, c_p, c_p, i64, c_p]),
     "pmc_maf_train_epoch": (C.c_int, [P(pmc_maf_t), P(pmc_maf_train_t), P(pmc_adamw_t), c_p, c_p, c_p, i64, i64, c_p,
                                       c_p]),
+    "pmc_maf_train_epoch_gated": (C.c_int, [P(pmc_maf_t), P(pmc_maf_train_t), P(pmc_adamw_t), c_p, c_p, c_p, i64, i64, c_p,
+                                            c_p, c_p]),
     "pmc_maf_wide_scratch_bytes": (C.c_int64, [P(pmc_maf_t)]),
     "pmc_maf_wide_refresh": (C.c_int, [P(pmc_maf_t), P(pmc_maf_wide_t), c_p, c_p]),
     "pmc_maf_loss_grad_bf16": (C.c_int, [P(pmc_maf_t), P(pmc_maf_wide_t), c_p, c_p, c_p, C.c_float, c_p, c_p, i64, c_p]),

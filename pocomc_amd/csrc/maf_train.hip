@@ -857,9 +857,22 @@ extern "C" int pmc_adamw_step(float* params, const float* grad, float* exp_avg, 
     return pmc_check_launch("adamw_kernel");
 }
 
+extern "C" int pmc_maf_train_epoch_gated(const pmc_maf_t* m, const pmc_maf_train_t* tr, pmc_adamw_t* opt, const float* x,
+                                         const float* w, const int64_t* perm, int64_t n, int64_t batch_size, float* loss,
+                                         void* gate_event, void* stream);
+
 extern "C" int pmc_maf_train_epoch(const pmc_maf_t* m, const pmc_maf_train_t* tr, pmc_adamw_t* opt, const float* x,
                                    const float* w, const int64_t* perm, int64_t n, int64_t batch_size, float* loss,
                                    void* stream) {
+    return pmc_maf_train_epoch_gated(m, tr, opt, x, w, perm, n, batch_size, loss, nullptr, stream);
+}
+
+// gate_event: the first OPTIMIZER STEP of the epoch waits for it (the loss / gradient launches in front of it only read
+// the parameters): the validation pass of the previous epoch, running on another stream on the compute units the chain
+// kernel leaves idle, reads the kernel images this step rewrites.
+extern "C" int pmc_maf_train_epoch_gated(const pmc_maf_t* m, const pmc_maf_train_t* tr, pmc_adamw_t* opt, const float* x,
+                                         const float* w, const int64_t* perm, int64_t n, int64_t batch_size, float* loss,
+                                         void* gate_event, void* stream) {
     if (train_check(m, tr, "pmc_maf_train_epoch")) return 1;
     if (!opt || !opt->params || !opt->grad || !opt->exp_avg || !opt->exp_avg_sq || !opt->pack_idx || !opt->packed ||
         !opt->packT_idx || !opt->packedT || opt->n_params <= 0 || !x || !loss || n < 0 || batch_size < 1)
@@ -872,6 +885,10 @@ extern "C" int pmc_maf_train_epoch(const pmc_maf_t* m, const pmc_maf_train_t* tr
         const float* xb = perm ? x : x + b0 * m->D;
         const float* wb = (w && !perm) ? w + b0 : w;
         if (launch_lossgrad(m, tr, xb, wb, perm ? perm + b0 : nullptr, 1000.0f, opt->grad, loss, nb, st)) return 1;
+        if (gate_event && b0 == 0) {
+            const hipError_t e = hipStreamWaitEvent(st, (hipEvent_t)gate_event, 0);
+            if (e != hipSuccess) return pmc_fail_hip(e, "hipStreamWaitEvent(pmc_maf_train_epoch_gated)");
+        }
         opt->step += 1;
         const bool scatter = opt->scatter_ptr && opt->scatter_dst && opt->n_packed < 0x7fffffffLL;
         launch_adamw(opt->params, opt->grad, opt->exp_avg, opt->exp_avg_sq, opt->n_params, opt->lr, opt->beta1,

@@ -68,6 +68,12 @@ class TrainState:
         per_set = 4 * (self.xt_floats + 2 * self.act_floats + self.par_floats)
         self.set_cap = int(max(32, min(MAX_SETS, SCRATCH_BUDGET // per_set)))
         self.scatter_maps(flow)             # (host-built once per Flow, like the maps above: not a per-fit cost)
+        # the stream the validation passes of a fit run on (fit_flow): created and used once here -- a new HIP stream's first
+        # launch sets up its hardware queue, tens of milliseconds that do not belong to an epoch
+        self.side_stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(self.side_stream):
+            self.scal.zero_()
+        self.side_stream.synchronize()
 
     def ensure_sets(self, n_rows):
         """Scratch for the row sets of one launch: transform inputs, activations, deltas, output gradients."""
@@ -246,10 +252,11 @@ class AdamW:
         else:
             ts.repack(f)
 
-    def epoch(self, x, w, perm, batch_size, max_norm, loss_acc):
+    def epoch(self, x, w, perm, batch_size, max_norm, loss_acc, gate=None):
         """``flow.py:297-323`` for one epoch in a single library call: every batch's loss/gradient,
         clip, AdamW step and image refresh is enqueued back to back; ``loss_acc`` (f32 [1], device)
-        accumulates the batch losses."""
+        accumulates the batch losses.  ``gate`` (a recorded ``torch.cuda.Event``): the epoch's first optimizer step waits
+        for it (``pmc_maf_train_epoch_gated``: the previous epoch's validation pass on another stream)."""
         f = self.flow
         ts = _train_state(f)
         ws = _wide_state(f)
@@ -279,11 +286,12 @@ class AdamW:
                              max_norm=float(max_norm) if max_norm is not None else 0.0, step=self.t,
                              scatter_ptr=sc_ptr.data_ptr(), scatter_dst=sc_dst.data_ptr())
         with torch.cuda.device(f.device):
-            _lib.check(f.lib.pmc_maf_train_epoch(C.byref(f._desc), C.byref(ts.desc), C.byref(c), _lib.ptr(x),
-                                                 _lib.ptr(w) if w is not None else None,
-                                                 _lib.ptr(perm) if perm is not None else None,
-                                                 x.shape[0], int(batch_size), _lib.ptr(loss_acc),
-                                                 _lib.stream_handle()), "pmc_maf_train_epoch")
+            _lib.check(f.lib.pmc_maf_train_epoch_gated(C.byref(f._desc), C.byref(ts.desc), C.byref(c), _lib.ptr(x),
+                                                       _lib.ptr(w) if w is not None else None,
+                                                       _lib.ptr(perm) if perm is not None else None,
+                                                       x.shape[0], int(batch_size), _lib.ptr(loss_acc),
+                                                       C.c_void_p(gate.cuda_event) if gate is not None else None,
+                                                       _lib.stream_handle()), "pmc_maf_train_epoch")
         self.t = int(c.step)
 
 
@@ -491,6 +499,23 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
     ts = _train_state(flow)
     if validation and not sharded and (getattr(ts, "logp_scratch", None) is None or ts.logp_scratch.numel() < n_valid):
         ts.logp_scratch = torch.empty(int(n_valid), dtype=torch.float32, device=dev)
+    # The validation pass of epoch e only READS the parameters, and so do the loss / gradient launches of epoch e + 1's
+    # first batch; a batch's chain kernel occupies 32 of 256 compute units.  So the pass runs on a second stream, next to
+    # that batch, and only the first optimizer step of epoch e + 1 waits for it (pmc_maf_train_epoch_gated).  Float32
+    # engine, one process, no penalty term (those paths enqueue batch by batch from Python).
+    # It pays where the pass (two cross-stream hand-overs of ~16 us, the forward launch, the reduction, the copies: ~65 us
+    # at the Sampler's sizes) is SHORTER than the first batch's chain + weight-gradient launches it hides behind, and costs
+    # the host ~15 us per epoch: deep or spline flows (chain >= ~80 us) with a validation set of at most two batches' worth
+    # of rows -- the Sampler's regime (README example, nsf6: 152 -> 123 us per epoch).  Measured otherwise: maf3 at D = 10
+    # 76 -> 91 us (the epoch is bound by its ~120 us of enqueue, not by the device), the bench's fit (maf3 at D = 32, ten
+    # batches, 5000 validation rows whose 313 workgroups crowd the chain's 32) 0.95 -> 1.05 ms.
+    side = None
+    long_chain = flow.spec.n_transforms * (2 if flow.spec.univariate == "rqs" else 1) >= 6
+    if (validation and not sharded and penalty is None and _wide_state(flow) is None and long_chain
+            and n_valid <= 2 * int(batch_size)):
+        side = ts.side_stream
+    train_done = [torch.cuda.Event() for _ in range(slots)] if side is not None else None
+    gate = [None]                                                     # the event the next epoch's first update waits for
 
     def upload_perm(which, sl, n):
         # DataLoader(shuffle=...), flow.py:251-265: a fresh permutation per pass (pinned staging, no host sync)
@@ -547,6 +572,25 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
                           penalty=add_penalty if penalty is not None else None)
         elif penalty is not None:
             penalised_epoch(xs, w_train, perm, acc)
+        elif side is not None:
+            opt.epoch(xs, w_train, perm, batch_size, clip_grad_norm, acc, gate=gate[0])
+            after[sl].copy_(flow.params)                              # (the parameters after this epoch's last update)
+            main = torch.cuda.current_stream(dev)
+            train_done[sl].record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(train_done[sl])
+                x_valid_e = with_noise(1, sl, epoch, x_valid)
+                vperm = upload_perm(1, sl, n_valid) if shuffle else None
+                with torch.cuda.device(dev):
+                    _lib.check(flow.lib.pmc_maf_valid_epoch(C.byref(flow._desc), _lib.ptr(x_valid_e),
+                                                            _lib.ptr(w_valid) if w_valid is not None else None,
+                                                            _lib.ptr(vperm) if vperm is not None else None,
+                                                            n_valid, int(batch_size), _lib.ptr(ts.logp_scratch),
+                                                            _lib.ptr(acc2[1:2]), _lib.stream_handle()), "pmc_maf_valid_epoch")
+                acc_h[sl].copy_(acc2, non_blocking=True)
+                done[sl].record(side)
+            gate[0] = done[sl]
+            return
         else:
             opt.epoch(xs, w_train, perm, batch_size, clip_grad_norm, acc)
         vacc = acc2[1:2]
@@ -601,6 +645,8 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
             best_loss, best_epoch = history[monitor][-1], epoch
             best_model.copy_(after[sl])
         if epoch - best_epoch >= int(1.5 * patience):                 # flow.py:369-374
+            if side is not None:
+                torch.cuda.current_stream(dev).wait_stream(side)      # (a speculative validation pass still reads the images)
             flow.params.copy_(best_model)
             flow.repack()
             if verbose > 0:
@@ -614,6 +660,9 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
         print("\nTime total:     %5.2f sec" % total)
         print("Time per epoch: %5.2f sec" % (total / epochs))
     # a speculative epoch may still be copying its permutations / losses: wait before the staging goes back
+    if side is not None:
+        torch.cuda.current_stream(dev).wait_stream(side)
+        side.synchronize()
     torch.cuda.current_stream().synchronize()
     for t in acc_h + h_perm[0] + h_perm[1]:
         _pinned_give(t)
