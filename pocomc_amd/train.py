@@ -252,7 +252,7 @@ class AdamW:
         else:
             ts.repack(f)
 
-    def epoch(self, x, w, perm, batch_size, max_norm, loss_acc, gate=None):
+    def epoch(self, x, w, perm, batch_size, max_norm, loss_acc, gate=None, stream=None):
         """``flow.py:297-323`` for one epoch in a single library call: every batch's loss/gradient,
         clip, AdamW step and image refresh is enqueued back to back; ``loss_acc`` (f32 [1], device)
         accumulates the batch losses.  ``gate`` (a recorded ``torch.cuda.Event``): the epoch's first optimizer step waits
@@ -276,22 +276,34 @@ class AdamW:
             f.repack()                      # the float32 / fragment images follow once per epoch (validation, inference)
             return
         ts.ensure_sets(batch_size)
-        sc_ptr, sc_dst = ts.scatter_maps(f)
-        c = _lib.pmc_adamw_t(params=f.params.data_ptr(), grad=ts.grad.data_ptr(), exp_avg=self.m.data_ptr(),
-                             exp_avg_sq=self.v.data_ptr(), n_params=f.params.numel(),
-                             pack_idx=f._pack_idx.data_ptr(), packed=f._packed.data_ptr(), n_packed=f._packed.numel(),
-                             packT_idx=ts.packT_idx.data_ptr(), packedT=ts.packedT.data_ptr(),
-                             n_packedT=ts.packedT.numel(), lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                             eps=self.eps, weight_decay=self.wd,
-                             max_norm=float(max_norm) if max_norm is not None else 0.0, step=self.t,
-                             scatter_ptr=sc_ptr.data_ptr(), scatter_dst=sc_dst.data_ptr())
-        with torch.cuda.device(f.device):
-            _lib.check(f.lib.pmc_maf_train_epoch_gated(C.byref(f._desc), C.byref(ts.desc), C.byref(c), _lib.ptr(x),
-                                                       _lib.ptr(w) if w is not None else None,
-                                                       _lib.ptr(perm) if perm is not None else None,
-                                                       x.shape[0], int(batch_size), _lib.ptr(loss_acc),
-                                                       C.c_void_p(gate.cuda_event) if gate is not None else None,
-                                                       _lib.stream_handle()), "pmc_maf_train_epoch")
+        # (the descriptor is built once per optimizer: an epoch of the Sampler's fits is ~100 us and this method runs once
+        #  per epoch on the driver thread -- only what changes between epochs is written)
+        c = getattr(self, "_desc", None)
+        if c is None:
+            sc_ptr, sc_dst = ts.scatter_maps(f)
+            c = self._desc = _lib.pmc_adamw_t(
+                params=f.params.data_ptr(), grad=ts.grad.data_ptr(), exp_avg=self.m.data_ptr(),
+                exp_avg_sq=self.v.data_ptr(), n_params=f.params.numel(),
+                pack_idx=f._pack_idx.data_ptr(), packed=f._packed.data_ptr(), n_packed=f._packed.numel(),
+                packT_idx=ts.packT_idx.data_ptr(), packedT=ts.packedT.data_ptr(), n_packedT=ts.packedT.numel(),
+                beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd,
+                scatter_ptr=sc_ptr.data_ptr(), scatter_dst=sc_dst.data_ptr())
+            self._desc_refs = (C.byref(f._desc), C.byref(ts.desc), C.byref(c))
+        c.lr, c.step, c.max_norm = self.lr, self.t, float(max_norm) if max_norm is not None else 0.0
+        d_maf, d_tr, d_opt = self._desc_refs
+
+        def call():
+            return f.lib.pmc_maf_train_epoch_gated(d_maf, d_tr, d_opt, x.data_ptr(), w.data_ptr() if w is not None else None,
+                                                   perm.data_ptr() if perm is not None else None, x.shape[0], int(batch_size),
+                                                   loss_acc.data_ptr(), gate.cuda_event if gate is not None else None,
+                                                   stream if stream is not None else torch.cuda.current_stream(f.device).cuda_stream)
+        if torch.cuda.current_device() == f.device.index:           # (the usual case: no device switch to pay for)
+            rc = call()
+        else:
+            with torch.cuda.device(f.device):
+                rc = call()
+        if rc:
+            _lib.check(rc, "pmc_maf_train_epoch")
         self.t = int(c.step)
 
 
@@ -515,6 +527,7 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
             and n_valid <= 2 * int(batch_size)):
         side = ts.side_stream
     train_done = [torch.cuda.Event() for _ in range(slots)] if side is not None else None
+    main_h = torch.cuda.current_stream(dev).cuda_stream               # (looked up once: the fit stays on this stream)
     gate = [None]                                                     # the event the next epoch's first update waits for
 
     def upload_perm(which, sl, n):
@@ -573,7 +586,7 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
         elif penalty is not None:
             penalised_epoch(xs, w_train, perm, acc)
         elif side is not None:
-            opt.epoch(xs, w_train, perm, batch_size, clip_grad_norm, acc, gate=gate[0])
+            opt.epoch(xs, w_train, perm, batch_size, clip_grad_norm, acc, gate=gate[0], stream=main_h)
             after[sl].copy_(flow.params)                              # (the parameters after this epoch's last update)
             main = torch.cuda.current_stream(dev)
             train_done[sl].record(main)
@@ -586,13 +599,13 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
                                                             _lib.ptr(w_valid) if w_valid is not None else None,
                                                             _lib.ptr(vperm) if vperm is not None else None,
                                                             n_valid, int(batch_size), _lib.ptr(ts.logp_scratch),
-                                                            _lib.ptr(acc2[1:2]), _lib.stream_handle()), "pmc_maf_valid_epoch")
+                                                            _lib.ptr(acc2[1:2]), C.c_void_p(side.cuda_stream)), "pmc_maf_valid_epoch")
                 acc_h[sl].copy_(acc2, non_blocking=True)
                 done[sl].record(side)
             gate[0] = done[sl]
             return
         else:
-            opt.epoch(xs, w_train, perm, batch_size, clip_grad_norm, acc)
+            opt.epoch(xs, w_train, perm, batch_size, clip_grad_norm, acc, stream=main_h)
         vacc = acc2[1:2]
         x_valid_e = with_noise(1, sl, epoch, x_valid) if validation else None
         if validation and not sharded:
