@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PMC_ABI_VERSION 8
+#define PMC_ABI_VERSION 9
 
 const char* pmc_last_error(void);
 int pmc_abi_version(void);
@@ -206,6 +206,9 @@ typedef struct pmc_adamw {
      * With both non-NULL the AdamW kernel refreshes the two images itself (no separate gather launch per step). */
     const int32_t* scatter_ptr;   /* device int32 [n_params + 1] */
     const int32_t* scatter_dst;   /* device int32 [scatter_ptr[n_params]] */
+    float* snapshot;              /* NULL, or device f32 [n_params]: pmc_maf_train_epoch writes the parameters behind the epoch's
+                                   * LAST optimizer step there as well (the state Flow.fit restores at an early stop,
+                                   * flow.py:364-374, without a separate copy launch per epoch) */
 } pmc_adamw_t;
 
 /* One epoch of the training loop, pocomc/flow.py:297-323: for every batch of `batch_size` rows

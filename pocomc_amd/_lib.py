@@ -46,7 +46,7 @@ class pmc_adamw_t(C.Structure):
                 ("packT_idx", c_p), ("packedT", c_p), ("n_packedT", C.c_int64),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("weight_decay", C.c_double), ("max_norm", C.c_double), ("step", C.c_int64),
-                ("scatter_ptr", c_p), ("scatter_dst", c_p)]
+                ("scatter_ptr", c_p), ("scatter_dst", c_p), ("snapshot", c_p)]
 
 
 class pmc_scaler_t(C.Structure):
@@ -230,7 +230,7 @@ def load():
         fn = getattr(lib, name)            # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.pmc_abi_version() != 8:
+    if lib.pmc_abi_version() != 9:
         raise PocomcAmdError("libpocomc_amd.so: ABI version mismatch")
     # timing-only ablation builds (scripts/abl_*.sh: TRI5_ABL / TRI6_ABL / NSF2_ABL != 0) compute WRONG results by design and
     # carry a marker symbol: never loaded by accident

@@ -639,7 +639,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float lr, float b1, float b2, float eps, float wd, float max_norm,
                                                     float bc1, float bc2, const float* __restrict__ sq_part, int n_part,
                                                     const int* __restrict__ sc_ptr, const int* __restrict__ sc_dst,
-                                                    float* __restrict__ img_a, int n_a, float* __restrict__ img_b) {
+                                                    float* __restrict__ img_a, int n_a, float* __restrict__ img_b,
+                                                    float* __restrict__ snap) {
     // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
     __shared__ float red[4];
     float coef = 1.0f;
@@ -660,6 +661,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         const float v1 = b2 * vo[e] + (1.0f - b2) * gr * gr;
         pv -= step * m1 / (sqrtf(v1) * rs2 + eps);
         p[e] = pv; mo[e] = m1; vo[e] = v1;
+        if (snap) snap[e] = pv;                           // (pmc_adamw_t.snapshot: the parameters behind an epoch's last step)
         if (sc_ptr) {
             // refresh of the kernel images (pmc_adamw_t.scatter_*): every place this parameter is packed to
             for (int k = sc_ptr[e], k1 = sc_ptr[e + 1]; k < k1; ++k) {
@@ -824,12 +826,12 @@ extern "C" int pmc_sum_f32(const float* v, float* out, int64_t n, void* stream) 
 static void launch_adamw(float* params, const float* grad, float* m1, float* m2, int64_t n, double lr, double beta1,
                          double beta2, double eps, double wd, double max_norm, int64_t step, const float* sq_part,
                          int n_part, hipStream_t st, const int* sc_ptr = nullptr, const int* sc_dst = nullptr,
-                         float* img_a = nullptr, int n_a = 0, float* img_b = nullptr) {
+                         float* img_a = nullptr, int n_a = 0, float* img_b = nullptr, float* snap = nullptr) {
     int64_t grid = (n + 255) / 256; if (grid > 512) grid = 512;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, st, params, grad, m1, m2, n, (float)lr,
                        (float)beta1, (float)beta2, (float)eps, (float)wd, (float)max_norm, (float)bc1, (float)bc2,
-                       sq_part, n_part, sc_ptr, sc_dst, img_a, n_a, img_b);
+                       sq_part, n_part, sc_ptr, sc_dst, img_a, n_a, img_b, snap);
 }
 
 // (for maf_train_bf16.hip) sum-of-squares partials + clipped AdamW step without image refresh
@@ -894,7 +896,7 @@ extern "C" int pmc_maf_train_epoch_gated(const pmc_maf_t* m, const pmc_maf_train
         launch_adamw(opt->params, opt->grad, opt->exp_avg, opt->exp_avg_sq, opt->n_params, opt->lr, opt->beta1,
                      opt->beta2, opt->eps, opt->weight_decay, opt->max_norm, opt->step, tr->sq_partial, n_part, st,
                      scatter ? opt->scatter_ptr : nullptr, opt->scatter_dst, opt->packed, (int)opt->n_packed,
-                     opt->packedT);
+                     opt->packedT, (b0 + batch_size >= n) ? opt->snapshot : nullptr);
         if (!scatter) {
             const int64_t tot = opt->n_packed + opt->n_packedT;
             int64_t grid = (tot + 255) / 256; if (grid > 2048) grid = 2048;

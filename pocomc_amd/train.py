@@ -252,7 +252,7 @@ class AdamW:
         else:
             ts.repack(f)
 
-    def epoch(self, x, w, perm, batch_size, max_norm, loss_acc, gate=None, stream=None):
+    def epoch(self, x, w, perm, batch_size, max_norm, loss_acc, gate=None, stream=None, snapshot=None):
         """``flow.py:297-323`` for one epoch in a single library call: every batch's loss/gradient,
         clip, AdamW step and image refresh is enqueued back to back; ``loss_acc`` (f32 [1], device)
         accumulates the batch losses.  ``gate`` (a recorded ``torch.cuda.Event``): the epoch's first optimizer step waits
@@ -290,6 +290,7 @@ class AdamW:
                 scatter_ptr=sc_ptr.data_ptr(), scatter_dst=sc_dst.data_ptr())
             self._desc_refs = (C.byref(f._desc), C.byref(ts.desc), C.byref(c))
         c.lr, c.step, c.max_norm = self.lr, self.t, float(max_norm) if max_norm is not None else 0.0
+        c.snapshot = snapshot.data_ptr() if snapshot is not None else None     # (the parameters behind the epoch's last step)
         d_maf, d_tr, d_opt = self._desc_refs
 
         def call():
@@ -504,11 +505,26 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
     done = [torch.cuda.Event() for _ in range(slots)]
     after = [torch.empty_like(flow.params) for _ in range(slots)]                    # parameters after the epoch
     # (pinned staging from the process-wide free list: page-locking a buffer costs about a millisecond)
-    h_perm = [[_pinned_take((max(n_train, 1),), torch.int64) for _ in range(slots)],
-              [_pinned_take((max(n_valid, 1),), torch.int64) for _ in range(slots)]]
-    d_perm = [[torch.empty(max(n_train, 1), dtype=torch.int64, device=dev) for _ in range(slots)],
-              [torch.empty(max(n_valid, 1), dtype=torch.int64, device=dev) for _ in range(slots)]]
     ts = _train_state(flow)
+    # Plain fits (one process, float32 engine, no penalty term, shuffled): ONE host-to-device copy per epoch carries both
+    # permutations AND the zeros of the two loss accumulators (two int64 words in front of the permutations in one staging
+    # buffer), and the parameters behind the epoch's last step are written by that step itself (pmc_adamw_t.snapshot) --
+    # three ~5 us launches fewer per epoch, of the ~75-120 us an epoch of the Sampler's fits takes.
+    fused = bool(shuffle) and not sharded and penalty is None and _wide_state(flow) is None
+    if fused:
+        n_stage = 2 + n_train + n_valid
+        h_stage = [_pinned_take((n_stage,), torch.int64) for _ in range(slots)]
+        for h_ in h_stage:
+            h_[:2] = 0
+        d_stage = [torch.zeros(n_stage, dtype=torch.int64, device=dev) for _ in range(slots)]
+        acc_d = [d[:1].view(torch.float32) for d in d_stage]           # [train loss, val loss] in the first word
+        view = lambda b, which: b[2:2 + n_train] if which == 0 else b[2 + n_train:n_stage]
+        h_perm, d_perm = [[], []], [[], []]
+    else:
+        h_perm = [[_pinned_take((max(n_train, 1),), torch.int64) for _ in range(slots)],
+                  [_pinned_take((max(n_valid, 1),), torch.int64) for _ in range(slots)]]
+        d_perm = [[torch.empty(max(n_train, 1), dtype=torch.int64, device=dev) for _ in range(slots)],
+                  [torch.empty(max(n_valid, 1), dtype=torch.int64, device=dev) for _ in range(slots)]]
     if validation and not sharded and (getattr(ts, "logp_scratch", None) is None or ts.logp_scratch.numel() < n_valid):
         ts.logp_scratch = torch.empty(int(n_valid), dtype=torch.float32, device=dev)
     # The validation pass of epoch e only READS the parameters, and so do the loss / gradient launches of epoch e + 1's
@@ -529,6 +545,13 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
     train_done = [torch.cuda.Event() for _ in range(slots)] if side is not None else None
     main_h = torch.cuda.current_stream(dev).cuda_stream               # (looked up once: the fit stays on this stream)
     gate = [None]                                                     # the event the next epoch's first update waits for
+
+    def upload_both(sl):
+        torch.randperm(n_train, out=view(h_stage[sl], 0))            # (the same draws in the same order as upload_perm)
+        if n_valid:
+            torch.randperm(n_valid, out=view(h_stage[sl], 1))
+        d_stage[sl].copy_(h_stage[sl], non_blocking=True)
+        return view(d_stage[sl], 0), (view(d_stage[sl], 1) if n_valid else None)
 
     def upload_perm(which, sl, n):
         # DataLoader(shuffle=...), flow.py:251-265: a fresh permutation per pass (pinned staging, no host sync)
@@ -576,9 +599,13 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
     def enqueue(epoch):
         sl = epoch % slots
         acc2 = acc_d[sl]
-        acc2.zero_()
+        vperm_f = None
+        if fused:
+            perm, vperm_f = upload_both(sl)                          # (also zeroes acc2)
+        else:
+            acc2.zero_()
+            perm = upload_perm(0, sl, n_train) if shuffle else None
         acc = acc2[0:1]
-        perm = upload_perm(0, sl, n_train) if shuffle else None
         xs = with_noise(0, sl, epoch, x_train)
         if sharded:
             sharded_epoch(flow, opt, xs, w_train, perm, batch_size, clip_grad_norm, acc, group,
@@ -586,14 +613,16 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
         elif penalty is not None:
             penalised_epoch(xs, w_train, perm, acc)
         elif side is not None:
-            opt.epoch(xs, w_train, perm, batch_size, clip_grad_norm, acc, gate=gate[0], stream=main_h)
-            after[sl].copy_(flow.params)                              # (the parameters after this epoch's last update)
+            opt.epoch(xs, w_train, perm, batch_size, clip_grad_norm, acc, gate=gate[0], stream=main_h,
+                      snapshot=after[sl] if fused else None)
+            if not fused:
+                after[sl].copy_(flow.params)                          # (the parameters after this epoch's last update)
             main = torch.cuda.current_stream(dev)
             train_done[sl].record(main)
             with torch.cuda.stream(side):
                 side.wait_event(train_done[sl])
                 x_valid_e = with_noise(1, sl, epoch, x_valid)
-                vperm = upload_perm(1, sl, n_valid) if shuffle else None
+                vperm = vperm_f if fused else (upload_perm(1, sl, n_valid) if shuffle else None)
                 with torch.cuda.device(dev):
                     _lib.check(flow.lib.pmc_maf_valid_epoch(C.byref(flow._desc), _lib.ptr(x_valid_e),
                                                             _lib.ptr(w_valid) if w_valid is not None else None,
@@ -605,12 +634,12 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
             gate[0] = done[sl]
             return
         else:
-            opt.epoch(xs, w_train, perm, batch_size, clip_grad_norm, acc, stream=main_h)
+            opt.epoch(xs, w_train, perm, batch_size, clip_grad_norm, acc, stream=main_h, snapshot=after[sl] if fused else None)
         vacc = acc2[1:2]
         x_valid_e = with_noise(1, sl, epoch, x_valid) if validation else None
         if validation and not sharded:
             # the whole validation pass in one library call (batches of the reference's DataLoader, flow.py:327-348)
-            vperm = upload_perm(1, sl, n_valid) if shuffle else None
+            vperm = vperm_f if fused else (upload_perm(1, sl, n_valid) if shuffle else None)
             with torch.cuda.device(dev):
                 _lib.check(flow.lib.pmc_maf_valid_epoch(C.byref(flow._desc), _lib.ptr(x_valid_e),
                                                         _lib.ptr(w_valid) if w_valid is not None else None,
@@ -631,7 +660,8 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
             # flow.py:342-343: every validation batch's loss carries the penalty
             vb = int(batch_size) if not sharded else max(1, int(batch_size) // world)
             add_penalty(None, vacc, mult=-(-n_valid // vb))
-        after[sl].copy_(flow.params)
+        if not fused:
+            after[sl].copy_(flow.params)
         acc_h[sl].copy_(acc2, non_blocking=True)
         done[sl].record()
 
@@ -677,7 +707,7 @@ def fit_flow(flow, x, weights=None, validation_split=0.0, epochs=1000, batch_siz
         torch.cuda.current_stream(dev).wait_stream(side)
         side.synchronize()
     torch.cuda.current_stream().synchronize()
-    for t in acc_h + h_perm[0] + h_perm[1]:
+    for t in acc_h + h_perm[0] + h_perm[1] + (h_stage if fused else []):
         _pinned_give(t)
     if getattr(flow, "_bf16", None) is not None or getattr(flow, "_lane16", None) is not None:
         flow.repack()                              # the 16-bit images follow the trained float32 parameters

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), s
         assert s in _lib.SIGNATURES, f"{s} declared in the header but not bound"
-    assert lib.pmc_abi_version() == 8
+    assert lib.pmc_abi_version() == 9
 
 
 def test_product_library_has_no_measurement_hooks():
