@@ -277,6 +277,7 @@ __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf
                 for (int c = 0; c < nXT; ++c) {
                     rqs_panel_train<NW, PF, NOUT>(m, wvw, Cb, P, c, wv, lane, part + (size_t)c * NOUT * 256);
                     lds_barrier();
+                    LAPT(11)
                     for (int e = tid; e < 256; e += (64 * NW)) {
                         const int rr = e >> 4, pp = e & 15, rank = 16 * c + rr;
                         if (rank < D) {
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(64 * NW) void maf_chain_kernel(pmc_maf_t m, pmc_maf
                             ladj += l;
                         }
                     }
+                    LAPT(12)
                     lds_barrier();
                 }
             }

@@ -31,8 +31,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 p = prof.cpu().numpy().astype(np.float64)
 names = ["total", "load/loss", "fwd hidden", "fwd out", "bwd recompute", "elementwise", "L3 (da2,dW3)", "L2 (da1,dW2)",
-         "L1 (da0,dW1)", "L0 (dx,dW0,rerank)", "barrier wait", "hid L1/2 frag loads", "hid L1/2 MFMA", "hid L1/2 epilogue",
-         "hid L1/2 barrier", "hid other"]
+         "L1 (da0,dW1)", "L0 (dx,dW0,rerank)", "barrier wait", "fwd spline panel product", "fwd spline evaluation", "hid L1 + L2",
+         "hid barriers", "hid L0"]
 print("workgroups", nb, "cycles; per wave mean over workgroups")
 for i, nm in enumerate(names[:16]):
     print(f"{nm:20s} " + "  ".join(f"w{w}: {p[:, w, i].mean():9.0f}" for w in range(NW)))
